@@ -1,0 +1,226 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark: queries/sec, FLAT-IP 10M x 768 float32, batch 256, k=10.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+      --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one batch of `--batch` queries answered against the WHOLE collection.  With N>1 the
+collection is row-sharded (global row g lives on rank g % N, VectorStore/cluster sharding §8e), every
+rank scans its shard for the whole batch, per-shard (distance,row) candidates are exchanged with one
+RCCL all-gather and merged on the device: total work is fixed -> "scaling": "strong".
+Inputs (rows and queries) are resident in HBM before the timed region; the timed region is bracketed
+by barrier + torch.cuda.synchronize() and the MAX over ranks is reported.
+
+Extra objects on the JSON line: "roofline" (dominant kernel k_scan_f16 — algorithmic bytes / HIP-event
+duration measured on the launch stream during the timed region) and "cpu_baseline" (the oracle's
+restatement of the reference's rayon scan, timed on this host's cores over a bounded row sample).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+GEN_BLOCK = 100_000     # rows per generation block (flat_search_bench.py:71-77 batches of 100k)
+
+
+def parse_args():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=20)
+    p.add_argument("--warmup", type=int, default=3)
+    p.add_argument("--rows", type=int, default=10_000_000, help="TOTAL rows of the collection")
+    p.add_argument("--dim", type=int, default=768)
+    p.add_argument("--batch", type=int, default=256)
+    p.add_argument("--k", type=int, default=10)
+    p.add_argument("--metric", default="ip")
+    p.add_argument("--seed", type=int, default=42)
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-sample-rows", type=int, default=1_000_000)
+    p.add_argument("--cpu-queries", type=int, default=8)
+    p.add_argument("--no-verify", action="store_true")
+    p.add_argument("--verify-queries", type=int, default=16)
+    return p.parse_args()
+
+
+def gen_block(block: int, rows_in_block: int, dim: int, seed: int, device) -> torch.Tensor:
+    """Global rows [block*GEN_BLOCK, +rows_in_block): uniform[0,1) f32, identical for every world size."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed * 1_000_003 + block)
+    return torch.rand((rows_in_block, dim), generator=g, device=device, dtype=torch.float32)
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    os.environ["LYNSE_HIP_DEVICE"] = str(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+
+        dist = dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)  # "nccl" is RCCL on ROCm
+
+    import lynsedb_amd as L
+    from lynsedb_amd.sharded import ShardedFlat
+
+    N, D, B, K = args.rows, args.dim, args.batch, args.k
+    metric = L.metric_from_str(args.metric)
+
+    # ---- build the shard: rows g with g % world == rank, generated block-wise on the device
+    sh = ShardedFlat(D, rank=rank, world=world, device=local_rank, group=dist)
+    n_local = (N - rank + world - 1) // world if N > rank else 0
+    sh.index.reserve(max(n_local, 1))
+    qrng = np.random.default_rng(args.seed + 7)
+    q_rows = np.sort(qrng.integers(0, N, size=B))
+    q_src = torch.empty((B, D), device=dev, dtype=torch.float32)
+    t0 = time.time()
+    for b in range((N + GEN_BLOCK - 1) // GEN_BLOCK):
+        r0 = b * GEN_BLOCK
+        nb = min(GEN_BLOCK, N - r0)
+        blk = gen_block(b, nb, D, args.seed, dev)
+        sel = np.nonzero((q_rows >= r0) & (q_rows < r0 + nb))[0]
+        if sel.size:
+            q_src[torch.as_tensor(sel, device=dev)] = blk[torch.as_tensor(q_rows[sel] - r0, device=dev)]
+        first = (rank - r0) % world  # first local row of this block owned by this rank
+        mine = blk[first::world].contiguous()
+        if mine.shape[0]:
+            sh.index.write_device(mine)
+        del blk, mine
+    sh.index.finalize()
+    torch.cuda.synchronize()
+    build_s = time.time() - t0
+    assert len(sh.index) == n_local, (len(sh.index), n_local)
+    g = torch.Generator(device=dev)
+    g.manual_seed(args.seed + 11)
+    queries = (q_src + 0.03 * torch.randn((B, D), generator=g, device=dev, dtype=torch.float32)).contiguous()
+
+    out = sh.alloc_outputs(B, K)
+
+    def step():
+        sh.search_device(queries, K, metric, out)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sh.index.profile_enable(True)
+    sh.index.profile_get(reset=True)
+    barrier()
+    t_start = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t_start
+    prof = sh.index.profile_get(reset=True)
+    sh.index.profile_enable(False)
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- verification (outside the timed region): recall@k and score agreement vs torch fp32
+    verify = None
+    if not args.no_verify:
+        verify = sh.verify_against_torch(queries, K, metric, out, nverify=min(args.verify_queries, B))
+
+    result = None
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1000.0
+        qps = B * args.steps / elapsed
+        scan_s = prof["scan_us"] * 1e-6
+        achieved = (prof["scan_bytes"] / scan_s / 1e9) if scan_s > 0 else 0.0
+        launches = max(int(prof["scan_launches"]), 1)
+        roofline = {
+            "bound": "hbm", "kernel": "k_scan_f16" if metric < 3 else "k_scan_binary",
+            "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+            "launches": launches, "avg_launch_us": round(prof["scan_us"] / launches, 2),
+            "algorithmic_bytes_per_launch": int(prof["scan_bytes"] // launches),
+            "note": "rank-0 shard; bytes = rows scanned x dim x 4 B, time = HIP events around each scan launch",
+        }
+        result = {
+            "metric": "queries/sec, FLAT-%s %dx%d float32, batch=%d, k=%d" % (args.metric.upper(), N, D, B, K),
+            "value": round(qps, 1), "unit": "queries/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32" if metric < 3 else "u64", "data": "synthetic",
+            "config": {"workload": "FLAT-%s %dx%d f32 uniform[0,1), %d queries = perturbed rows, k=%d"
+                                   % (args.metric.upper(), N, D, B, K),
+                       "rows_per_gpu": n_local, "sharding": "row %% %d" % world,
+                       "exchange": "rccl all_gather of %d B/rank" % (B * K * 12) if world > 1 else "none",
+                       "build_s": round(build_s, 1)},
+            "roofline": roofline,
+            "pipeline_us_per_step": round(prof["total_us"] / max(prof["searches"], 1), 1),
+            "rescored_per_query": round(prof["pool_entries"] / max(prof["searches"] * B, 1), 1),
+            "fallback_queries": int(prof["fallback_queries"]),
+        }
+        if verify is not None:
+            result["verify"] = verify
+        if not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(args, N, D, K, metric)
+        print(json.dumps(result), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(args, N, D, K, metric):
+    """The oracle's restatement of the reference's chunked rayon scan (flat_mmap.rs:4845-4982), timed on
+    this host's cores over a bounded row sample; one full pass per query, as the reference's
+    batch_search loops queries sequentially (engine.rs:5484-5496)."""
+    import oracle as O
+
+    orc = O.get()
+    cores = os.cpu_count() or 1
+    sample = min(N, args.cpu_sample_rows)
+    rng = np.random.default_rng(args.seed)
+    data = rng.random((sample, D), dtype=np.float32)
+    qs = data[rng.integers(0, sample, size=args.cpu_queries)] + 0.03 * rng.standard_normal((args.cpu_queries, D)).astype(np.float32)
+    if metric >= 3:
+        words = orc.pack_binary(data)
+        qw = orc.pack_binary(qs)
+        orc.packed_binary_search(qw[0], words, K, metric, n_threads=cores, mt=True)
+        t0 = time.perf_counter()
+        for i in range(args.cpu_queries):
+            orc.packed_binary_search(qw[i], words, K, metric, n_threads=cores, mt=True)
+    else:
+        orc.flat_search(qs[0], data, K, metric, n_threads=cores, mt=True)  # warm-up
+        t0 = time.perf_counter()
+        for i in range(args.cpu_queries):
+            orc.flat_search(qs[i], data, K, metric, n_threads=cores, mt=True)
+    per_query_sample = (time.perf_counter() - t0) / args.cpu_queries
+    per_query_full = per_query_sample * (N / sample)
+    return {"value": round(1.0 / per_query_full, 3), "unit": "queries/s", "cores": cores, "kind": "port",
+            "sample": "%d queries x %d-row sample (of %d), %d threads, time scaled by rows ratio; "
+                      "%.1f ms/query on the sample = %.1f GB/s" % (
+                          args.cpu_queries, sample, N, cores, per_query_sample * 1e3,
+                          sample * D * 4 / per_query_sample / 1e9)}
+
+
+if __name__ == "__main__":
+    main()

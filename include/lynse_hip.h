@@ -1,0 +1,207 @@
+/*
+ * lynse_hip.h — C ABI of liblynse_hip.so: the MI355X (gfx950) implementation of LynseDB's
+ * FLAT / IVF-Flat search hot path (src/distance + the FLAT/IVF search in src/index, src/storage).
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no C++/torch types.  Each entry point
+ * names the reference interface it replaces (file:line relative to BirchKwok/lynsedb).  The
+ * reference-side binding a maintainer would add (Rust `extern "C"` + the PyO3 glue that already
+ * exists) is shown in INTEGRATION.md.
+ *
+ * Conventions (mirroring the reference boundary):
+ *  - inputs are borrowed for the duration of the call; outputs are CALLER-allocated, fixed size
+ *    (nq*k), short results are padded and the true length is written to out_counts[q];
+ *  - empty store or k == 0 -> counts 0, not an error (flat_mmap.rs:832-835); k > N clamps (:836);
+ *  - rows returned are ROW INDICES (u32 per segment in the reference, u64 here after the row map),
+ *    best-first; ties are ordered by row ascending — the order VectorStore::merge_results imposes
+ *    (vector_store.rs:953-970);
+ *  - distances: IP raw dot (descending), L2 squared, cosine distance, Hamming/Jaccard/Dice as f32;
+ *  - every function returns a status code (LynseError variants, src/error.rs:5-52); the message is
+ *    available per thread from lynse_hip_last_error(); nothing throws or aborts across the ABI;
+ *  - a handle may be searched from several threads (calls serialise on an internal mutex);
+ *    append/finalize are exclusive, like `&mut self` in FlatMmap::write.
+ *  - there is NO CPU fallback: without a usable HIP device every compute entry returns
+ *    LYNSE_ERR_DEVICE.
+ */
+#ifndef LYNSE_HIP_H
+#define LYNSE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LYNSE_HIP_ABI_VERSION 1
+
+/* Status codes — src/error.rs:5-52 (DimensionMismatch / InvalidArgument / IndexNotBuilt / Io ...). */
+enum {
+    LYNSE_OK = 0,
+    LYNSE_ERR_INVALID_ARGUMENT = 1,
+    LYNSE_ERR_DIMENSION_MISMATCH = 2,
+    LYNSE_ERR_UNKNOWN_METRIC = 3,
+    LYNSE_ERR_NOT_FINALIZED = 4,
+    LYNSE_ERR_OUT_OF_MEMORY = 5,
+    LYNSE_ERR_DEVICE = 6,
+    LYNSE_ERR_INTERNAL = 7,
+    LYNSE_ERR_INDEX_NOT_BUILT = 8,
+    LYNSE_ERR_UNSUPPORTED = 9
+};
+
+/* Metric ids — DistanceMetric (src/distance/mod.rs:19-36), in-scope subset. */
+enum {
+    LYNSE_METRIC_IP = 0,
+    LYNSE_METRIC_L2 = 1,
+    LYNSE_METRIC_COSINE = 2,
+    LYNSE_METRIC_HAMMING = 3,
+    LYNSE_METRIC_JACCARD = 4,
+    LYNSE_METRIC_DICE = 5,
+    LYNSE_METRIC_TANIMOTO = 6
+};
+
+/* IP accumulation form of the exact rescoring pass. */
+enum { LYNSE_IPFORM_AUTO = 0, LYNSE_IPFORM_SINGLE = 1, LYNSE_IPFORM_BATCH8 = 2 };
+
+typedef struct lynse_hip_flat lynse_hip_flat; /* one HBM-resident FLAT shard: replaces FlatMmap */
+typedef struct lynse_hip_ivf lynse_hip_ivf;   /* IVF-Flat over cluster slabs: replaces IVFIndex / IvfFlatMmap */
+
+/* Per-search profile (the reference's QueryProfile, src/engine.rs:6906-6919, plus kernel timings
+ * measured with HIP events on the launch stream).  Times in microseconds. */
+typedef struct lynse_hip_profile {
+    uint64_t searches;        /* profiled search calls accumulated */
+    uint64_t scan_launches;   /* launches of the dominant scan kernel */
+    double scan_us;           /* summed duration of those launches */
+    uint64_t scan_rows;       /* rows scanned by those launches */
+    uint64_t scan_bytes;      /* algorithmic bytes of those launches (rows * row bytes) */
+    double total_us;          /* whole pipeline, first launch -> last launch */
+    uint64_t fallback_queries;/* queries re-run on the exhaustive safe plan */
+    uint64_t pool_entries;    /* candidates rescored exactly (sum over queries) */
+} lynse_hip_profile;
+
+/* ---- library ---- */
+int lynse_hip_abi_version(void);
+/* Copies the calling thread's last error message (NUL-terminated) and returns its length. */
+size_t lynse_hip_last_error(char *buf, size_t cap);
+int lynse_hip_device_count(int *out_count);
+/* DistanceMetric::from_str (distance/mod.rs:39-63) / from_index_mode (:67-107). */
+int lynse_hip_metric_from_str(const char *name, int *out_metric);
+int lynse_hip_metric_from_index_mode(const char *mode, int *out_metric);
+int lynse_hip_metric_is_ascending(int metric); /* distance/mod.rs:111-116 */
+int lynse_hip_metric_is_binary(int metric);    /* distance/mod.rs:161-166 */
+
+/* ---- FLAT shard: FlatMmap (src/storage/flat_mmap.rs:89-109, :187-221) ---- */
+
+/* FlatMmap::open(path, dim, F32) -> an empty row-major f32 store on `device`. */
+int lynse_hip_flat_create(uint32_t dim, int device, lynse_hip_flat **out);
+int lynse_hip_flat_destroy(lynse_hip_flat *h);
+int lynse_hip_flat_reserve(lynse_hip_flat *h, uint64_t rows);
+/* FlatMmap::write / append (flat_mmap.rs:223-330): rows are n*dim little-endian f32, row-major —
+ * exactly a reference segment file's bytes. */
+int lynse_hip_flat_append_f32(lynse_hip_flat *h, const float *rows, uint64_t n);
+int lynse_hip_flat_append_f32_device(lynse_hip_flat *h, const float *d_rows, uint64_t n);
+/* Pre-packed one-bit rows, ceil(dim/64) u64 words per row, bit i of word i/64 LSB-first — the
+ * BinaryData layout (flat_mmap.rs:145-160, simd.rs:750-757).  A store holds f32 rows or packed
+ * rows, not both appended. */
+int lynse_hip_flat_append_packed_u64(lynse_hip_flat *h, const uint64_t *words, uint64_t n);
+int lynse_hip_flat_append_packed_u64_device(lynse_hip_flat *h, const uint64_t *d_words, uint64_t n);
+/* Row statistics for newly appended rows (norms, scale).  Idempotent. */
+int lynse_hip_flat_finalize(lynse_hip_flat *h);
+/* Returned row = local_row * stride + offset (multi-GPU shards; default 1, 0). */
+int lynse_hip_flat_set_row_map(lynse_hip_flat *h, uint64_t stride, uint64_t offset);
+int lynse_hip_flat_set_ip_form(lynse_hip_flat *h, int ip_form);
+uint64_t lynse_hip_flat_len(const lynse_hip_flat *h); /* FlatMmap::len */
+uint32_t lynse_hip_flat_dim(const lynse_hip_flat *h); /* FlatMmap::dim */
+int lynse_hip_flat_device(const lynse_hip_flat *h);
+/* Copy rows [first, first+n) back to host f32 (FlatMmap::as_slice). */
+int lynse_hip_flat_read_rows(const lynse_hip_flat *h, uint64_t first, uint64_t n, float *out);
+/* Same, into a device buffer of this handle's GPU (n*dim f32, dense). */
+int lynse_hip_flat_copy_rows_device(const lynse_hip_flat *h, uint64_t first, uint64_t n, float *d_out);
+/* ensure_binary (flat_mmap.rs:388-401) contents: packed words of rows [first, first+n). */
+int lynse_hip_flat_read_packed(lynse_hip_flat *h, uint64_t first, uint64_t n, uint64_t *out_words);
+
+/* FlatMmap::search (flat_mmap.rs:824-923) for a batch of queries (Collection::batch_search,
+ * engine.rs:5352-5498).  queries: nq*dim f32.  Binary metrics threshold the f32 query at 0.5
+ * (pack_binary_query, flat_mmap.rs:1292-1296).  out_rows/out_dists: nq*k; out_counts: nq. */
+int lynse_hip_flat_search_f32(lynse_hip_flat *h, const float *queries, uint64_t nq, uint32_t k,
+                              int metric, uint64_t *out_rows, float *out_dists,
+                              uint32_t *out_counts);
+/* Same with every buffer already resident in this handle's device memory; enqueued on `stream`
+ * (a hipStream_t, NULL = the handle's stream) and synchronised before returning. */
+int lynse_hip_flat_search_f32_device(lynse_hip_flat *h, const float *d_queries, uint64_t nq,
+                                     uint32_t k, int metric, uint64_t *d_out_rows,
+                                     float *d_out_dists, uint32_t *d_out_counts, void *stream);
+/* packed_binary_search (flat_mmap.rs:1345-1409) with pre-packed queries (nq * words u64). */
+int lynse_hip_flat_search_packed_u64(lynse_hip_flat *h, const uint64_t *query_words, uint64_t nq,
+                                     uint32_t k, int metric, uint64_t *out_rows, float *out_dists,
+                                     uint32_t *out_counts);
+int lynse_hip_flat_search_packed_u64_device(lynse_hip_flat *h, const uint64_t *d_query_words,
+                                            uint64_t nq, uint32_t k, int metric,
+                                            uint64_t *d_out_rows, float *d_out_dists,
+                                            uint32_t *d_out_counts, void *stream);
+
+/* Profiling: when enabled, searches bracket the scan kernel with HIP events on its stream. */
+int lynse_hip_flat_profile_enable(lynse_hip_flat *h, int on);
+int lynse_hip_flat_profile_get(lynse_hip_flat *h, lynse_hip_profile *out, int reset);
+/* Tuning knobs (defaults are fine): stage-0 rows, stage growth factor, candidate capacity. */
+int lynse_hip_flat_set_plan(lynse_hip_flat *h, uint32_t stage0_rows, uint32_t growth, uint32_t cap);
+
+/* ---- stand-alone functions (src/python/mod.rs:2161-2223) ---- */
+/* py_compute_distance -> distance::compute_distance_f32 (distance/mod.rs:193-213). */
+int lynse_hip_compute_distance(const float *a, const float *b, uint32_t dim, int metric, int device,
+                               float *out);
+/* py_top_k_search -> distance::top_k_search (distance/mod.rs:373-422): u32 indices. */
+int lynse_hip_top_k_search(const float *query, const float *candidates, uint64_t n, uint32_t dim,
+                           uint32_t k, int metric, int device, uint32_t *out_idx, float *out_dist,
+                           uint32_t *out_count);
+/* pack_binary_f32 (simd.rs:760-763) for n rows on the device. */
+int lynse_hip_pack_binary_f32(const float *rows, uint64_t n, uint32_t dim, int device,
+                              uint64_t *out_words);
+/* VectorStore::merge_results (vector_store.rs:953-970) / cluster::merge_search_blocks
+ * (cluster.rs:327-393): host k-way merge of per-shard candidates, canonical (dist, id) order.
+ * ids/dists: n_lists blocks of `stride` entries, counts[i] valid in block i. */
+int lynse_hip_merge_topk(const uint64_t *ids, const float *dists, const uint32_t *counts,
+                         uint32_t n_lists, uint32_t stride, uint32_t k, int metric,
+                         uint64_t *out_ids, float *out_dists, uint32_t *out_count);
+
+/* Device-side variant used after the RCCL all-gather of per-rank result blocks.  `blocks` holds
+ * n_lists blocks of `block_bytes`; inside a block: rows u64[nq*k] at rows_off, dists f32[nq*k] at
+ * dists_off, counts u32[nq] at counts_off (the message shape of rpc.rs:1156-1177, fixed size).
+ * Output: merged rows u64[nq*k], dists f32[nq*k], counts u32[nq] in device memory.  Enqueued on
+ * `stream` (hipStream_t; NULL = default stream) without synchronising. */
+int lynse_hip_merge_topk_device(const void *d_blocks, uint64_t block_bytes, uint64_t rows_off,
+                                uint64_t dists_off, uint64_t counts_off, uint32_t n_lists,
+                                uint64_t nq, uint32_t k, int metric, uint64_t *d_out_rows,
+                                float *d_out_dists, uint32_t *d_out_counts, void *stream);
+
+/* ---- IVF-Flat: IVFIndex (src/index/ivf.rs) / IvfFlatMmap (src/storage/ivf_flat_mmap.rs) ---- */
+
+/* Build from host rows with device k-means (kmeans.rs:74-139 semantics: FastRng(42) init,
+ * Lloyd <= max_iter, empty-cluster reseed, final re-assign).  routing follows ivf.rs:81-87
+ * (`l2_partitions` = 1 forces L2 Voronoi cells like IvfFlatMmap::build, ivf_flat_mmap.rs:98). */
+int lynse_hip_ivf_build(const float *rows, uint64_t n, uint32_t dim, uint32_t nlist,
+                        uint32_t max_iter, int metric, int l2_partitions, int device,
+                        lynse_hip_ivf **out);
+/* Load given centroids (nlist*dim) + assignments (n): parity tests feed the oracle's. */
+int lynse_hip_ivf_load(const float *rows, uint64_t n, uint32_t dim, const float *centroids,
+                       uint32_t nlist, const uint32_t *assignments, int metric, int device,
+                       lynse_hip_ivf **out);
+int lynse_hip_ivf_destroy(lynse_hip_ivf *h);
+uint64_t lynse_hip_ivf_len(const lynse_hip_ivf *h);
+uint32_t lynse_hip_ivf_nlist(const lynse_hip_ivf *h);
+/* Trained state back to the host: centroids nlist*dim, assignments n, slab offsets nlist+1,
+ * original row id per slab position (ivf_flat_mmap.rs:22-39).  NULL pointers are skipped. */
+int lynse_hip_ivf_export(const lynse_hip_ivf *h, float *centroids, uint32_t *assignments,
+                         uint64_t *offsets, uint32_t *original_ids);
+int lynse_hip_ivf_set_row_map(lynse_hip_ivf *h, uint64_t stride, uint64_t offset);
+/* IVFIndex::search (ivf.rs:181-348): rank all centroids with the routing metric, scan the nprobe
+ * nearest lists, exact top-k of the probed rows.  nprobe == 0 -> 1 (ivf.rs:192-196). */
+int lynse_hip_ivf_search_f32(lynse_hip_ivf *h, const float *queries, uint64_t nq, uint32_t k,
+                             uint32_t nprobe, uint64_t *out_rows, float *out_dists,
+                             uint32_t *out_counts);
+int lynse_hip_ivf_profile_enable(lynse_hip_ivf *h, int on);
+int lynse_hip_ivf_profile_get(lynse_hip_ivf *h, lynse_hip_profile *out, int reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LYNSE_HIP_H */

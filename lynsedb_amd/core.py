@@ -1,0 +1,491 @@
+"""Host-side mirror of the `lynse._core` surface for the FLAT / IVF-Flat hot path.
+
+Same class / function names, argument meaning and error behaviour as the reference's PyO3 module
+(src/python/mod.rs) for the entry points on this path, so the reference's own benchmarks and tests
+(`benchmarks/flat_search_bench.py`, `tests/standard_tests/test_backend.py`) read unchanged against it:
+
+    FlatIndex            src/python/mod.rs:1942-2047   (FlatMmap)
+    IvfFlatIndex         src/python/mod.rs:2056-2156   (IvfFlatMmap)
+    py_compute_distance  src/python/mod.rs:2161-2185
+    py_top_k_search      src/python/mod.rs:2189-2223
+    DatabaseManager / Collection / SearchResult  (the subset `flat_search_bench.py:43-96` drives,
+                         src/python/mod.rs:984-1005, :1135-1150, :1171-1193, :1343, :1383-1408,
+                         :1876-1921, :2235-2418)
+
+All arithmetic happens in liblynse_hip.so on the GPU; nothing here computes distances on the host.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Iterable, Optional, Sequence
+
+import numpy as np
+
+from . import _lib
+from ._lib import check, lib
+
+_METRIC_IS_BINARY = {_lib.METRIC_HAMMING, _lib.METRIC_JACCARD, _lib.METRIC_DICE, _lib.METRIC_TANIMOTO}
+
+
+def default_device() -> int:
+    """Device ordinal: LYNSE_HIP_DEVICE, else LOCAL_RANK (one process per GPU), else 0."""
+    for var in ("LYNSE_HIP_DEVICE", "LOCAL_RANK"):
+        v = os.environ.get(var)
+        if v is not None and v != "":
+            return int(v)
+    return 0
+
+
+def metric_from_str(metric: str) -> int:
+    """DistanceMetric::from_str (src/distance/mod.rs:39-63); unknown -> ValueError("Unknown metric: ...")."""
+    out = C.c_int(-1)
+    check(lib.lynse_hip_metric_from_str(str(metric).encode(), C.byref(out)))
+    return out.value
+
+
+def metric_from_index_mode(mode: str) -> int:
+    out = C.c_int(-1)
+    check(lib.lynse_hip_metric_from_index_mode(str(mode).encode(), C.byref(out)))
+    return out.value
+
+
+def _f32(a, ndim: int, what: str) -> np.ndarray:
+    a = np.asarray(a)
+    if a.dtype != np.float32:
+        a = a.astype(np.float32)
+    if a.ndim != ndim:
+        raise ValueError(f"{what} must be a {ndim}-D array")
+    if not a.flags["C_CONTIGUOUS"]:
+        if ndim == 2:
+            raise ValueError("numpy array must be contiguous (C-order)")  # src/python/mod.rs:1393-1395
+        a = np.ascontiguousarray(a)
+    return a
+
+
+def _ptr(a: np.ndarray):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class FlatIndex:
+    """`lynse._core.FlatIndex` (src/python/mod.rs:1942-2047) on one MI355X.
+
+    The reference opens an mmapped file at `path`; here rows live in HBM (`path` may be None).  If
+    `path` names an existing raw little-endian f32 row file (the reference's segment format,
+    flat_mmap.rs:89-109) it is loaded.
+    """
+
+    def __init__(self, path: Optional[str], dim: int, device: Optional[int] = None):
+        self._h = C.c_void_p()
+        self._dim = int(dim)
+        dev = default_device() if device is None else int(device)
+        check(lib.lynse_hip_flat_create(self._dim, dev, C.byref(self._h)))
+        self.path = path
+        if path and os.path.exists(path) and os.path.getsize(path) > 0:
+            data = np.fromfile(path, dtype="<f4")
+            if data.size % self._dim:
+                raise IOError("vector file size is not a multiple of the row size")
+            self.write(data.reshape(-1, self._dim))
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            lib.lynse_hip_flat_destroy(h)
+
+    def __len__(self) -> int:
+        return int(lib.lynse_hip_flat_len(self._h))
+
+    @property
+    def dim(self) -> int:
+        return self._dim
+
+    @property
+    def handle(self):
+        return self._h
+
+    def reserve(self, rows: int) -> None:
+        check(lib.lynse_hip_flat_reserve(self._h, int(rows)))
+
+    def write(self, data) -> None:
+        """Append rows from a contiguous (n, dim) float32 array (FlatMmap::write)."""
+        a = _f32(data, 2, "data")
+        if a.shape[1] != self._dim:
+            raise ValueError(f"data dimension mismatch: expected {self._dim}, got {a.shape[1]}")
+        check(lib.lynse_hip_flat_append_f32(self._h, _ptr(a), a.shape[0]))
+
+    def write_device(self, tensor) -> None:
+        """Append rows already resident in HBM (a contiguous float32 torch tensor on this device)."""
+        if tensor.dim() != 2 or tensor.shape[1] != self._dim or not tensor.is_contiguous():
+            raise ValueError("tensor must be a contiguous (n, dim) float32 device tensor")
+        check(lib.lynse_hip_flat_append_f32_device(self._h, C.c_void_p(tensor.data_ptr()), tensor.shape[0]))
+
+    def write_packed(self, words) -> None:
+        """Append pre-packed one-bit rows: (n, ceil(dim/64)) uint64, LSB-first (BinaryData layout)."""
+        w = np.ascontiguousarray(words, dtype=np.uint64)
+        if w.ndim != 2 or w.shape[1] != (self._dim + 63) // 64:
+            raise ValueError("packed rows must have ceil(dim/64) u64 words")
+        check(lib.lynse_hip_flat_append_packed_u64(self._h, _ptr(w), w.shape[0]))
+
+    def write_packed_device(self, tensor) -> None:
+        check(lib.lynse_hip_flat_append_packed_u64_device(self._h, C.c_void_p(tensor.data_ptr()), tensor.shape[0]))
+
+    def finalize(self) -> None:
+        check(lib.lynse_hip_flat_finalize(self._h))
+
+    def set_row_map(self, stride: int, offset: int) -> None:
+        check(lib.lynse_hip_flat_set_row_map(self._h, int(stride), int(offset)))
+
+    def set_ip_form(self, form: int) -> None:
+        check(lib.lynse_hip_flat_set_ip_form(self._h, int(form)))
+
+    def set_plan(self, stage0_rows: int = 4096, growth: int = 8, cap: int = 8192) -> None:
+        check(lib.lynse_hip_flat_set_plan(self._h, stage0_rows, growth, cap))
+
+    def read_rows(self, first: int, n: int) -> np.ndarray:
+        out = np.empty((n, self._dim), np.float32)
+        check(lib.lynse_hip_flat_read_rows(self._h, first, n, _ptr(out)))
+        return out
+
+    def read_packed(self, first: int, n: int) -> np.ndarray:
+        out = np.empty((n, (self._dim + 63) // 64), np.uint64)
+        check(lib.lynse_hip_flat_read_packed(self._h, first, n, _ptr(out)))
+        return out
+
+    # -- search -------------------------------------------------------------------------------
+    def search_batch_arrays(self, queries, k: int, metric):
+        """Batched search returning padded arrays (rows u64[nq,k], dists f32[nq,k], counts u32[nq])."""
+        m = metric if isinstance(metric, int) else metric_from_str(metric)
+        q = _f32(queries, 2, "queries")
+        if q.shape[1] != self._dim:
+            raise ValueError(f"query dimension mismatch: expected {self._dim}, got {q.shape[1]}")
+        nq, k = q.shape[0], int(k)
+        rows = np.empty((nq, max(k, 1)), np.uint64)
+        dists = np.empty((nq, max(k, 1)), np.float32)
+        counts = np.zeros(nq, np.uint32)
+        check(lib.lynse_hip_flat_search_f32(self._h, _ptr(q), nq, k, m, _ptr(rows), _ptr(dists), _ptr(counts)))
+        return rows[:, :k], dists[:, :k], counts
+
+    def search_packed_arrays(self, query_words, k: int, metric):
+        m = metric if isinstance(metric, int) else metric_from_str(metric)
+        qw = np.ascontiguousarray(query_words, dtype=np.uint64)
+        if qw.ndim == 1:
+            qw = qw.reshape(1, -1)
+        nq, k = qw.shape[0], int(k)
+        rows = np.empty((nq, max(k, 1)), np.uint64)
+        dists = np.empty((nq, max(k, 1)), np.float32)
+        counts = np.zeros(nq, np.uint32)
+        check(lib.lynse_hip_flat_search_packed_u64(self._h, _ptr(qw), nq, k, m, _ptr(rows), _ptr(dists), _ptr(counts)))
+        return rows[:, :k], dists[:, :k], counts
+
+    def search(self, query, k: int = 10, metric: str = "ip"):
+        """Brute-force top-k -> (indices u32[k'], distances f32[k']) (src/python/mod.rs:1990-2006)."""
+        m = metric_from_str(metric)
+        q = _f32(query, 1, "query")
+        rows, dists, counts = self.search_batch_arrays(q.reshape(1, -1), k, m)
+        c = int(counts[0])
+        return rows[0, :c].astype(np.uint32), dists[0, :c].copy()
+
+    def batch_search(self, queries, k: int = 10, metric: str = "ip"):
+        """list of (indices, distances) per query (src/python/mod.rs:2018-2046).  The reference loops
+        queries sequentially, re-reading the collection each time; here the batch shares one pass."""
+        m = metric_from_str(metric)
+        rows, dists, counts = self.search_batch_arrays(queries, k, m)
+        return [(rows[i, :int(c)].astype(np.uint32), dists[i, :int(c)].copy()) for i, c in enumerate(counts)]
+
+    def search_device(self, d_queries, k: int, metric, d_rows, d_dists, d_counts, stream=None):
+        """All buffers are torch tensors resident on this device (bench path: no PCIe in the timed region)."""
+        m = metric if isinstance(metric, int) else metric_from_str(metric)
+        nq = d_queries.shape[0]
+        check(lib.lynse_hip_flat_search_f32_device(
+            self._h, C.c_void_p(d_queries.data_ptr()), nq, int(k), m, C.c_void_p(d_rows.data_ptr()),
+            C.c_void_p(d_dists.data_ptr()), C.c_void_p(d_counts.data_ptr()),
+            C.c_void_p(stream) if stream else None))
+
+    def search_packed_device(self, d_qwords, k: int, metric, d_rows, d_dists, d_counts, stream=None):
+        m = metric if isinstance(metric, int) else metric_from_str(metric)
+        nq = d_qwords.shape[0]
+        check(lib.lynse_hip_flat_search_packed_u64_device(
+            self._h, C.c_void_p(d_qwords.data_ptr()), nq, int(k), m, C.c_void_p(d_rows.data_ptr()),
+            C.c_void_p(d_dists.data_ptr()), C.c_void_p(d_counts.data_ptr()),
+            C.c_void_p(stream) if stream else None))
+
+    # -- profiling ----------------------------------------------------------------------------
+    def profile_enable(self, on: bool = True) -> None:
+        check(lib.lynse_hip_flat_profile_enable(self._h, 1 if on else 0))
+
+    def profile_get(self, reset: bool = True) -> dict:
+        p = _lib.Profile()
+        check(lib.lynse_hip_flat_profile_get(self._h, C.byref(p), 1 if reset else 0))
+        return {f: getattr(p, f) for f, _ in _lib.Profile._fields_}
+
+
+class IvfFlatIndex:
+    """`lynse._core.IvfFlatIndex` (src/python/mod.rs:2056-2156): k-means partitions, rows stored as
+    contiguous per-partition slabs in HBM, search scans the nprobe nearest slabs."""
+
+    def __init__(self, handle, dim: int):
+        self._h = handle
+        self._dim = dim
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            lib.lynse_hip_ivf_destroy(h)
+
+    @staticmethod
+    def build(path, data, dim: int, n_partitions: int = 256, n_iters: int = 20, metric: str = "ip",
+              device: Optional[int] = None, l2_partitions: bool = True) -> "IvfFlatIndex":
+        m = metric_from_str(metric)
+        a = _f32(data, 2, "data")
+        if a.shape[1] != dim:
+            raise ValueError(f"data dimension mismatch: expected {dim}, got {a.shape[1]}")
+        if n_partitions <= 0:
+            raise IOError("IVF partition count must be greater than zero")
+        if a.shape[0] < n_partitions:
+            raise IOError("IVF requires at least as many vectors as partitions")
+        h = C.c_void_p()
+        dev = default_device() if device is None else int(device)
+        check(lib.lynse_hip_ivf_build(_ptr(a), a.shape[0], dim, n_partitions, n_iters, m,
+                                      1 if l2_partitions else 0, dev, C.byref(h)))
+        return IvfFlatIndex(h, dim)
+
+    @staticmethod
+    def load(data, centroids, assignments, metric: str = "ip", device: Optional[int] = None) -> "IvfFlatIndex":
+        m = metric_from_str(metric)
+        a = _f32(data, 2, "data")
+        c = _f32(centroids, 2, "centroids")
+        asg = np.ascontiguousarray(assignments, dtype=np.uint32)
+        h = C.c_void_p()
+        dev = default_device() if device is None else int(device)
+        check(lib.lynse_hip_ivf_load(_ptr(a), a.shape[0], a.shape[1], _ptr(c), c.shape[0], _ptr(asg), m, dev, C.byref(h)))
+        return IvfFlatIndex(h, a.shape[1])
+
+    def __len__(self) -> int:
+        return int(lib.lynse_hip_ivf_len(self._h))
+
+    @property
+    def dim(self) -> int:
+        return self._dim
+
+    @property
+    def n_partitions(self) -> int:
+        return int(lib.lynse_hip_ivf_nlist(self._h))
+
+    def export(self):
+        n, nl = len(self), self.n_partitions
+        cen = np.empty((nl, self._dim), np.float32)
+        asg = np.empty(n, np.uint32)
+        off = np.empty(nl + 1, np.uint64)
+        orig = np.empty(n, np.uint32)
+        check(lib.lynse_hip_ivf_export(self._h, _ptr(cen), _ptr(asg), _ptr(off), _ptr(orig)))
+        return cen, asg, off, orig
+
+    def search_batch_arrays(self, queries, k: int, nprobe: int):
+        q = _f32(queries, 2, "queries")
+        if q.shape[1] != self._dim:
+            raise ValueError(f"query dimension mismatch: expected {self._dim}, got {q.shape[1]}")
+        nq, k = q.shape[0], int(k)
+        rows = np.empty((nq, max(k, 1)), np.uint64)
+        dists = np.empty((nq, max(k, 1)), np.float32)
+        counts = np.zeros(nq, np.uint32)
+        check(lib.lynse_hip_ivf_search_f32(self._h, _ptr(q), nq, k, int(nprobe), _ptr(rows), _ptr(dists), _ptr(counts)))
+        return rows[:, :k], dists[:, :k], counts
+
+    def search(self, query, k: int = 10, nprobe: int = 10, metric: str = "ip"):
+        metric_from_str(metric)  # validates like the reference (ValueError on unknown names)
+        q = _f32(query, 1, "query")
+        if q.size != self._dim:
+            raise ValueError(f"query dimension mismatch: expected {self._dim}, got {q.size}")
+        rows, dists, counts = self.search_batch_arrays(q.reshape(1, -1), k, nprobe)
+        c = int(counts[0])
+        return rows[0, :c].astype(np.uint32), dists[0, :c].copy()
+
+
+def py_compute_distance(a, b, metric: str) -> float:
+    """src/python/mod.rs:2161-2185."""
+    m = metric_from_str(metric)
+    a = _f32(a, 1, "a")
+    b = _f32(b, 1, "b")
+    if a.size != b.size:
+        raise ValueError("Vector dimensions must match")
+    out = C.c_float(0.0)
+    check(lib.lynse_hip_compute_distance(_ptr(a), _ptr(b), a.size, m, default_device(), C.byref(out)))
+    return float(out.value)
+
+
+def py_top_k_search(query, candidates, metric: str, k: int):
+    """src/python/mod.rs:2189-2223 -> (indices u32[], distances f32[])."""
+    m = metric_from_str(metric)
+    q = _f32(query, 1, "query")
+    c = _f32(candidates, 2, "candidates")
+    if q.size != c.shape[1]:
+        raise ValueError("Query dimension must match candidate dimension")
+    k = int(k)
+    idx = np.empty(max(k, 1), np.uint32)
+    dist = np.empty(max(k, 1), np.float32)
+    cnt = C.c_uint32(0)
+    check(lib.lynse_hip_top_k_search(_ptr(q), _ptr(c), c.shape[0], c.shape[1], k, m, default_device(),
+                                     _ptr(idx), _ptr(dist), C.byref(cnt)))
+    return idx[:cnt.value].copy(), dist[:cnt.value].copy()
+
+
+def merge_topk(ids, dists, counts, k: int, metric) -> tuple:
+    """VectorStore::merge_results (vector_store.rs:953-970) over per-shard blocks [n_lists, stride]."""
+    m = metric if isinstance(metric, int) else metric_from_str(metric)
+    ids = np.ascontiguousarray(ids, dtype=np.uint64)
+    dists = np.ascontiguousarray(dists, dtype=np.float32)
+    counts = np.ascontiguousarray(counts, dtype=np.uint32)
+    n_lists, stride = ids.shape
+    out_i = np.empty(max(k, 1), np.uint64)
+    out_d = np.empty(max(k, 1), np.float32)
+    cnt = C.c_uint32(0)
+    check(lib.lynse_hip_merge_topk(_ptr(ids), _ptr(dists), _ptr(counts), n_lists, stride, int(k), m,
+                                   _ptr(out_i), _ptr(out_d), C.byref(cnt)))
+    return out_i[:cnt.value].copy(), out_d[:cnt.value].copy()
+
+
+# ---------------------------------------------------------------------------------------------
+# Minimal engine glue: only what `benchmarks/flat_search_bench.py:43-96` and the reference's
+# search tests drive.  Storage/WAL/fields/filters are out of scope.
+# ---------------------------------------------------------------------------------------------
+class SearchResult:
+    """src/python/mod.rs:1876-1921 / engine.rs:6895-6902."""
+
+    def __init__(self, ids: np.ndarray, distances: np.ndarray, index_mode: str, dimension: int, k: int):
+        self._ids = np.asarray(ids, dtype=np.int64)
+        self._d = np.asarray(distances, dtype=np.float32)
+        self._mode, self._dim, self._k = index_mode, dimension, k
+
+    def ids(self) -> np.ndarray:
+        return self._ids
+
+    def distances(self) -> np.ndarray:
+        return self._d
+
+    def fields(self) -> list:
+        return []
+
+    def index_mode(self) -> str:
+        return self._mode
+
+    def to_tuple(self):
+        return self._ids, self._d, []
+
+    def __len__(self) -> int:
+        return int(self._ids.size)
+
+    def __repr__(self) -> str:
+        return f"SearchResult(n={len(self)}, k={self._k}, dim={self._dim}, index={self._mode})"
+
+
+class Collection:
+    """The search-path subset of `lynse._core.Collection` (engine.rs Collection)."""
+
+    def __init__(self, name: str, dim: int, device: Optional[int] = None):
+        self._name, self._dim = name, int(dim)
+        self._device = device
+        self._flat = FlatIndex(None, dim, device)
+        self._ids: list = []           # row -> user id (engine.rs:3071-3073)
+        self._id_arrays: list = []
+        self._index_mode = "FLAT-IP"   # resolve_metric default IP (engine.rs:5529-5534)
+        self._metric = _lib.METRIC_IP
+        self._ivf: Optional[IvfFlatIndex] = None
+        self._ivf_nprobe = 32           # IndexBuildOptions default (src/index/mod.rs:498-655)
+        self._pending: list = []
+
+    def name(self) -> str:
+        return self._name
+
+    def add_items(self, vectors, ids: Sequence[int], fields=None) -> None:
+        a = _f32(vectors, 2, "vectors")
+        if a.shape[1] != self._dim:
+            raise RuntimeError(f"Dimension mismatch: expected {self._dim}, got {a.shape[1]}")
+        if len(ids) != a.shape[0]:
+            raise RuntimeError("ids length must match the number of vectors")
+        if fields is not None:
+            raise NotImplementedError("field metadata is outside the FLAT/IVF hot path (SURVEY.md §2 #20)")
+        self._flat.write(a)
+        self._id_arrays.append(np.asarray(ids, dtype=np.int64))
+
+    def commit(self) -> None:
+        self._flat.finalize()
+
+    def shape(self):
+        return (len(self._flat), self._dim)
+
+    def _id_map(self) -> np.ndarray:
+        if len(self._id_arrays) != 1:
+            self._id_arrays = [np.concatenate(self._id_arrays) if self._id_arrays else np.zeros(0, np.int64)]
+        return self._id_arrays[0]
+
+    def build_index(self, index_type: str, params: Optional[dict] = None) -> None:
+        """Collection::build_index_with_build_options (engine.rs:4515-4655): FLAT-* keeps no index object
+        (engine.rs:4559-4567); IVF-* trains a k-means IVF (engine.rs:4616-4627)."""
+        mode = str(index_type).upper()
+        try:
+            metric = metric_from_index_mode(mode)
+        except ValueError as e:
+            raise RuntimeError(str(e))
+        params = dict(params or {})
+        if mode.startswith("FLAT"):
+            self._ivf = None
+        elif mode.startswith("IVF"):
+            if any(t in mode for t in ("SQ8", "PQ")):
+                raise NotImplementedError("quantized IVF variants are outside this path")
+            nlist = int(params.get("n_clusters", 256))
+            self._ivf_nprobe = int(params.get("nprobe", 32))
+            data = self._flat.read_rows(0, len(self._flat))
+            self._ivf = IvfFlatIndex.build(None, data, self._dim, min(nlist, max(len(self._flat), 1)), 20,
+                                           "ip" if metric == _lib.METRIC_IP else
+                                           {1: "l2", 2: "cosine"}.get(metric, "l2"),
+                                           device=self._device, l2_partitions=False)
+        else:
+            raise NotImplementedError(f"index type {index_type} is outside the FLAT/IVF hot path")
+        self._index_mode, self._metric = mode, metric
+
+    def _wrap(self, rows, dists, count, k) -> SearchResult:
+        ids = self._id_map()[rows[:count].astype(np.int64)]
+        return SearchResult(ids, dists[:count].copy(), self._index_mode, self._dim, k)
+
+    def search(self, vector, k: Optional[int] = None, where_expr: Optional[str] = None,
+               nprobe: Optional[int] = None, approx: Optional[bool] = None, eps: Optional[float] = None) -> SearchResult:
+        res = self.batch_search(np.asarray(vector, dtype=np.float32).reshape(1, -1), k, where_expr, nprobe)
+        return res[0]
+
+    def batch_search(self, vectors, k: Optional[int] = None, where_expr: Optional[str] = None,
+                     nprobe: Optional[int] = None) -> list:
+        if where_expr:
+            raise NotImplementedError("filtered search is a 'next' row (SURVEY.md §8f #1)")
+        k = 10 if k is None else int(k)
+        q = _f32(vectors, 2, "vectors")
+        if q.shape[1] != self._dim:  # engine.rs:4707-4712 -> wrapped as RuntimeError (src/python/mod.rs:1190)
+            raise RuntimeError(f"Dimension mismatch: expected {self._dim}, got {q.shape[1]}")
+        if self._ivf is not None:
+            np_ = self._ivf_nprobe if not nprobe else int(nprobe)
+            rows, dists, counts = self._ivf.search_batch_arrays(q, k, np_)
+        else:
+            rows, dists, counts = self._flat.search_batch_arrays(q, k, self._metric)
+        return [self._wrap(rows[i], dists[i], int(counts[i]), k) for i in range(q.shape[0])]
+
+
+class DatabaseManager:
+    """src/python/mod.rs:2235-2418 — in-memory registry (persistence is out of scope)."""
+
+    def __init__(self, root: str):
+        self.root = root
+        self._dbs: dict = {}
+
+    def create_database(self, name: str) -> None:
+        self._dbs.setdefault(name, {})
+
+    def require_collection(self, db: str, coll: str, dim: int) -> None:
+        self._dbs.setdefault(db, {})
+        if coll not in self._dbs[db]:
+            self._dbs[db][coll] = Collection(coll, dim)
+
+    def get_collection(self, db: str, coll: str, dim: int) -> Collection:
+        self.require_collection(db, coll, dim)
+        c = self._dbs[db][coll]
+        if c._dim != dim:
+            raise RuntimeError(f"Dimension mismatch: expected {c._dim}, got {dim}")
+        return c

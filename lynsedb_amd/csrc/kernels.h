@@ -1,0 +1,775 @@
+// kernels.h — hand-written HIP kernels for CDNA4 (gfx950, wave64) of the FLAT scan pipeline.
+//
+// Pipeline for a batch of queries against one HBM-resident shard:
+//   k_prep_queries   per-query scale / norms / certified error margin, f16 query image
+//   k_scan_f16       THE HOT KERNEL: rows streamed once from HBM (f32, coalesced 256-B row pieces),
+//                    converted to f16 in flight, staged through LDS, Q·Vᵀ on MFMA 32x32x16 f16,
+//                    threshold-filter epilogue appending (score,row) keys per query
+//   k_scan_binary    packed-binary rows: xor/and/or + popcount, same filter epilogue (exact ints)
+//   k_select         per-query LDS bitonic sort of the candidate keys, new threshold, prune
+//   k_final          exact rescoring of the survivors in the REFERENCE's accumulation order
+//                    (bit-exact with src/distance/simd.rs AVX2 kernels), final sort, output
+//   k_row_stats / k_pack_bits   one-time per appended row range
+#pragma once
+
+#include "common.h"
+
+namespace lynse {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define LY_INF __builtin_huge_valf()
+
+// ------------------------------------------------------------------------------------------------
+// Exact scoring in the reference's accumulation order.  Eight lanes emulate the eight AVX lanes:
+// lane g accumulates elements 8*i+g with fused multiply-add, the horizontal sum follows
+// lo128+hi128 -> +movehdup -> +movehl, and the D%8 tail is separate multiply + add (Rust never
+// contracts).  Result is identical on all 8 lanes and bit-identical to the oracle / AVX2 reference.
+//   IP single : simd.rs:1343-1396   IP batch8 : simd.rs:1452-1525
+//   L2        : simd.rs:1529-1581   cosine    : simd.rs:1585-1636
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float hsum8(float a) {
+    float t = __fadd_rn(a, __shfl_xor(a, 4, 8));  // lo128 + hi128
+    t = __fadd_rn(t, __shfl_xor(t, 1, 8));        // + movehdup
+    t = __fadd_rn(t, __shfl_xor(t, 2, 8));        // + movehl
+    return t;
+}
+
+__device__ __forceinline__ float exact_score(int metric, int ip_form, const float* __restrict__ q,
+                                             const float* __restrict__ v, uint32_t D, int g) {
+    const uint32_t chunks = D / 8, rem = D % 8, base = chunks * 8;
+    if (metric == M_IP && ip_form == LYNSE_IPFORM_BATCH8) {
+        float acc = 0.0f;
+        for (uint32_t i = 0; i < chunks; ++i) acc = __fmaf_rn(q[i * 8 + g], v[i * 8 + g], acc);
+        float sum = hsum8(acc);
+        for (uint32_t i = 0; i < rem; ++i) sum = __fadd_rn(sum, __fmul_rn(q[base + i], v[base + i]));
+        return sum;
+    }
+    if (metric == M_IP || metric == M_L2) {
+        const bool l2 = metric == M_L2;
+        const uint32_t dbl = chunks / 2, single = chunks % 2;
+        float acc0 = 0.0f, acc1 = 0.0f;
+        for (uint32_t i = 0; i < dbl; ++i) {
+            float a0 = q[i * 16 + g], b0 = v[i * 16 + g];
+            float a1 = q[i * 16 + 8 + g], b1 = v[i * 16 + 8 + g];
+            if (l2) {
+                float d0 = __fsub_rn(a0, b0), d1 = __fsub_rn(a1, b1);
+                acc0 = __fmaf_rn(d0, d0, acc0);
+                acc1 = __fmaf_rn(d1, d1, acc1);
+            } else {
+                acc0 = __fmaf_rn(a0, b0, acc0);
+                acc1 = __fmaf_rn(a1, b1, acc1);
+            }
+        }
+        if (single) {
+            float a0 = q[dbl * 16 + g], b0 = v[dbl * 16 + g];
+            if (l2) {
+                float d0 = __fsub_rn(a0, b0);
+                acc0 = __fmaf_rn(d0, d0, acc0);
+            } else {
+                acc0 = __fmaf_rn(a0, b0, acc0);
+            }
+        }
+        float sum = hsum8(__fadd_rn(acc0, acc1));
+        for (uint32_t i = 0; i < rem; ++i) {
+            if (l2) {
+                float d = __fsub_rn(q[base + i], v[base + i]);
+                sum = __fadd_rn(sum, __fmul_rn(d, d));
+            } else {
+                sum = __fadd_rn(sum, __fmul_rn(q[base + i], v[base + i]));
+            }
+        }
+        return sum;
+    }
+    // cosine distance
+    float d = 0.0f, x = 0.0f, y = 0.0f;
+    for (uint32_t i = 0; i < chunks; ++i) {
+        float a = q[i * 8 + g], b = v[i * 8 + g];
+        d = __fmaf_rn(a, b, d);
+        x = __fmaf_rn(a, a, x);
+        y = __fmaf_rn(b, b, y);
+    }
+    float dot = hsum8(d), na = hsum8(x), nb = hsum8(y);
+    for (uint32_t i = 0; i < rem; ++i) {
+        float a = q[base + i], b = v[base + i];
+        dot = __fadd_rn(dot, __fmul_rn(a, b));
+        na = __fadd_rn(na, __fmul_rn(a, a));
+        nb = __fadd_rn(nb, __fmul_rn(b, b));
+    }
+    float denom = __fsqrt_rn(__fmul_rn(na, nb));
+    if (denom < 1e-30f) return 1.0f;
+    return __fsub_rn(1.0f, __fdiv_rn(dot, denom));
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_row_stats: per-row squared norm + reciprocal norm for rows [row0,row1), and collection-wide
+// statistics (max |v|, max / min-nonzero squared norm, count of degenerate tiny-norm rows) that
+// parameterise the certified f16 error margin.  One wave per row.
+// stats[0]=bits(max|v|) stats[1]=bits(max n2) stats[2]=bits(min nonzero n2) stats[3]=#rows with 0<n2<1e-30
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_row_stats(const float* __restrict__ V, uint32_t ld, uint32_t D,
+                                                   uint32_t row0, uint32_t row1, float* __restrict__ vn2,
+                                                   float* __restrict__ vrinv, uint32_t* __restrict__ stats) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
+    float amax = 0.0f;
+    for (uint32_t row = row0 + wave; row < row1; row += nwaves) {
+        const float* v = V + (size_t)row * ld;
+        float s = 0.0f;
+        for (uint32_t i = lane; i < D; i += 64) {
+            float x = v[i];
+            s = __fmaf_rn(x, x, s);
+            amax = fmaxf(amax, fabsf(x));
+        }
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        if (lane == 0) {
+            vn2[row] = s;
+            vrinv[row] = s > 0.0f ? 1.0f / sqrtf(s) : 0.0f;
+            atomicMax(&stats[1], __float_as_uint(s));
+            if (s > 0.0f) atomicMin(&stats[2], __float_as_uint(s));
+            if (s > 0.0f && s < 1e-30f) atomicAdd(&stats[3], 1u);
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+    if (lane == 0) atomicMax(&stats[0], __float_as_uint(amax));
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_pack_bits: bit i of word i/64 = (value > 0.5), LSB first — pack_binary_row_f32
+// (flat_mmap.rs:1284-1290, simd.rs:750-757).  One wave per row; wave64 __ballot IS one u64 word.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_pack_bits(const float* __restrict__ V, uint32_t ld, uint32_t D,
+                                                   uint32_t nrows, uint64_t* __restrict__ out, uint32_t W) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
+    for (uint32_t row = wave; row < nrows; row += nwaves) {
+        const float* v = V + (size_t)row * ld;
+        for (uint32_t w = 0; w < W; ++w) {
+            uint32_t i = w * 64 + lane;
+            bool bit = (i < D) && (v[i] > 0.5f);
+            uint64_t m = __ballot(bit);
+            if (lane == 0) out[(size_t)row * W + w] = m;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_prep_queries: one block per query.
+//  - scale sq = 2^(13-ilogb(max|q|)) so the f16 image uses the full normal range;
+//  - f16 query image Q16[slab][q][72] (k >= D zero) — exactly the LDS image of a Q slab;
+//  - qinv = 1/(sq*sv) (power of two), |q|^2, 1/|q|;
+//  - marg2 = 2E where E bounds |coarse f16/MFMA score - reference-order f32 score|;
+//  - thr = worst, count = 0.
+// ------------------------------------------------------------------------------------------------
+struct PrepArgs {
+    const float* Q;      // nq x D f32
+    uint32_t D, nq, qpad, nslab;
+    int metric;
+    float sv;            // row scale (power of two)
+    float vmax, vmin;    // max / min-nonzero row norm
+    int cos_degenerate;  // rows with 0 < |v|^2 < 1e-30 exist
+    _Float16* Q16;
+    float *qinv, *qn2, *qrinv, *marg2, *thr;
+    uint32_t* count;
+    uint32_t* overflow;
+};
+
+__global__ void __launch_bounds__(256) k_prep_queries(PrepArgs a) {
+    __shared__ float red[3][4];
+    __shared__ float s_sq;
+    const uint32_t q = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* qv = a.Q + (size_t)q * a.D;
+    float amax = 0.0f, s2 = 0.0f, s1 = 0.0f;
+    for (uint32_t i = tid; i < a.D; i += 256) {
+        float x = qv[i];
+        amax = fmaxf(amax, fabsf(x));
+        s2 = __fmaf_rn(x, x, s2);
+        s1 += fabsf(x);
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+        s2 += __shfl_xor(s2, o, 64);
+        s1 += __shfl_xor(s1, o, 64);
+    }
+    if (lane == 0) { red[0][wave] = amax; red[1][wave] = s2; red[2][wave] = s1; }
+    __syncthreads();
+    if (tid == 0) {
+        amax = fmaxf(fmaxf(red[0][0], red[0][1]), fmaxf(red[0][2], red[0][3]));
+        s2 = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+        s1 = (red[2][0] + red[2][1]) + (red[2][2] + red[2][3]);
+        int e = (amax > 0.0f && amax < LY_INF) ? ilogbf(amax) : 13;
+        if (e < -100) e = -100;
+        if (e > 100) e = 100;
+        const float sq = ldexpf(1.0f, 13 - e);
+        s_sq = sq;
+        const float qn = sqrtf(s2);
+        const float Df = (float)a.D;
+        const float u = 4.8828125e-4f;                 // 2^-11, f16 unit roundoff
+        const float c1 = 2.0f * u + u * u;
+        const float gam = 10.0f * Df * 5.9604645e-8f;  // MFMA f32 accumulate + reference f32 order
+        const float eta_v = ldexpf(1.0f, -25) / a.sv;  // f16 subnormal floor, original units
+        const float eta_q = ldexpf(1.0f, -25) / sq;
+        const float e_ip = (c1 + gam) * qn * a.vmax + eta_v * (1.0f + u) * s1 +
+                           eta_q * (1.0f + u) * sqrtf(Df) * a.vmax + Df * eta_q * eta_v;
+        float E;
+        if (a.metric == M_IP) {
+            E = 1.02f * e_ip;
+        } else if (a.metric == M_L2) {
+            E = 1.02f * (2.0f * e_ip + 4.0f * (Df + 8.0f) * 5.9604645e-8f * (s2 + a.vmax * a.vmax));
+        } else {
+            if (s2 < 1e-30f || a.cos_degenerate) {
+                E = 4.0f;  // covers the whole [0,2] range: forces the exhaustive exact path
+            } else {
+                const float vmin = a.vmin > 0.0f ? a.vmin : 1.0f;
+                E = 1.02f * (c1 + gam + sqrtf(Df) * (1.0f + u) * (eta_v / vmin + eta_q / qn) +
+                             Df * eta_q * eta_v / (qn * vmin) + 4.0f * (Df + 8.0f) * 5.9604645e-8f);
+            }
+        }
+        if (!(E == E) || E > 3.0e38f) E = 3.0e38f;
+        a.qinv[q] = 1.0f / (sq * a.sv);
+        a.qn2[q] = s2;
+        a.qrinv[q] = s2 > 0.0f ? 1.0f / qn : 0.0f;
+        a.marg2[q] = 2.0f * E;
+        a.thr[q] = metric_ascending(a.metric) ? LY_INF : -LY_INF;
+        a.count[q] = 0u;
+        a.overflow[q] = 0u;
+    }
+    __syncthreads();
+    const float sq = s_sq;
+    const uint32_t total = a.nslab * SCAN_BK;
+    for (uint32_t i = tid; i < total; i += 256) {
+        const uint32_t s = i / SCAN_BK, k = i % SCAN_BK;
+        const float x = i < a.D ? qv[i] * sq : 0.0f;
+        a.Q16[((size_t)s * a.qpad + q) * SCAN_LDK + k] = (_Float16)x;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_scan_f16 — the hot kernel.
+//
+// Tile: BR=128 rows x BQ queries (256: 8 waves as 4(q) x 2(r), each 64x64; 32: 4 waves as 1 x 4,
+// each 32x32).  Persistent blocks walk row tiles; for each K slab of 64:
+//   HBM  -> VGPR : 16 consecutive lanes read one row's 256 contiguous bytes (float4 each)
+//   VGPR -> LDS  : scale (power of two), cvt f32->f16 (RNE), ds_write_b64, row stride 144 B
+//   L2   -> LDS  : the pre-built f16 query slab image, linear 16-B copies
+//   LDS  -> MFMA : ds_read_b128 fragments (stride 144 B is conflict-free), v_mfma_f32_32x32x16_f16,
+//                  A = rows (M), B = queries (N) so that each lane owns ONE query column per block
+// LDS is double buffered with register prefetch of the next slab (also across tile boundaries), one
+// barrier per slab.  Epilogue: score transform (IP / L2 via norms / cosine via reciprocal norms),
+// compare with the per-query threshold, append passing (score,row) keys with a global atomic slot
+// (stage 0: slot = row, no atomics).  Every row byte is read from HBM exactly once per batch.
+// Algorithmic bytes per launch = rows * D * 4.
+// ------------------------------------------------------------------------------------------------
+struct ScanArgs {
+    const float* V;
+    uint32_t ld, D;
+    uint32_t row0, row1;  // stage rows [row0,row1)
+    const _Float16* Q16;  // [nslab][qpad][72]
+    uint32_t qpad, nq, nslab, ntiles;
+    const float *qinv, *qn2, *qrinv, *thr;
+    const float *vn2, *vrinv;
+    float sv;
+    uint64_t* cand;
+    uint32_t* count;
+    uint32_t cap;
+    int emit_all;
+};
+
+template <int WQ, int WR, int TQ, int TR, int METRIC>
+__global__ void __launch_bounds__(WQ * WR * 64, (WQ * WR * 64 == 512) ? 2 : 2) k_scan_f16(ScanArgs a) {
+    constexpr int NT = WQ * WR * 64;
+    constexpr int BQ = WQ * TQ * 32;
+    constexpr int BR = WR * TR * 32;
+    static_assert(BR == SCAN_BR, "tile rows");
+    constexpr int ROWS_PER_PASS = NT / 16;
+    constexpr int PV = BR / ROWS_PER_PASS;           // float4 loads per thread per slab
+    constexpr int QCHUNKS = BQ * (SCAN_LDK * 2 / 16);  // 16-B chunks of one Q slab image
+    constexpr int PQ = (QCHUNKS + NT - 1) / NT;
+    constexpr int VBUF = BR * SCAN_LDK;  // halves per V buffer
+    constexpr int QBUF = BQ * SCAN_LDK;
+    constexpr bool ASC = METRIC != M_IP;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    _Float16* Vl = reinterpret_cast<_Float16*>(smem);             // [2][VBUF]
+    _Float16* Ql = reinterpret_cast<_Float16*>(smem) + 2 * VBUF;  // [2][QBUF]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wq = wave % WQ, wr = wave / WQ;
+    const int vrow = tid >> 4, vk = (tid & 15) * 4;
+
+    uint32_t tile = blockIdx.x;
+    if (tile >= a.ntiles) return;
+
+    f32x4 vreg[PV];
+    u32x4 qreg[PQ];
+
+    auto load_regs = [&](uint32_t t, uint32_t s) {
+        const uint32_t rbase = a.row0 + t * BR;
+        const uint32_t k = s * SCAN_BK + vk;
+#pragma unroll
+        for (int p = 0; p < PV; ++p) {
+            const uint32_t row = rbase + p * ROWS_PER_PASS + vrow;
+            if (row < a.row1 && k < a.ld)
+                vreg[p] = *reinterpret_cast<const f32x4*>(a.V + (size_t)row * a.ld + k);
+            else
+                vreg[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        const u32x4* qsrc = reinterpret_cast<const u32x4*>(a.Q16 + (size_t)s * a.qpad * SCAN_LDK);
+#pragma unroll
+        for (int j = 0; j < PQ; ++j) {
+            const int c = tid + j * NT;
+            qreg[j] = qsrc[c < QCHUNKS ? c : QCHUNKS - 1];  // unconditional: keeps qreg in VGPRs
+        }
+    };
+    auto store_lds = [&](int buf) {
+        _Float16* vb = Vl + buf * VBUF;
+#pragma unroll
+        for (int p = 0; p < PV; ++p) {
+            half4 h;
+            h[0] = (_Float16)(vreg[p][0] * a.sv);
+            h[1] = (_Float16)(vreg[p][1] * a.sv);
+            h[2] = (_Float16)(vreg[p][2] * a.sv);
+            h[3] = (_Float16)(vreg[p][3] * a.sv);
+            *reinterpret_cast<half4*>(vb + (p * ROWS_PER_PASS + vrow) * SCAN_LDK + vk) = h;
+        }
+        u32x4* qb = reinterpret_cast<u32x4*>(Ql + buf * QBUF);
+#pragma unroll
+        for (int j = 0; j < PQ; ++j) {
+            const int c = tid + j * NT;
+            if (c < QCHUNKS) qb[c] = qreg[j];
+        }
+    };
+
+    f32x16 acc[TR][TQ];
+#pragma unroll
+    for (int i = 0; i < TR; ++i)
+#pragma unroll
+        for (int j = 0; j < TQ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    load_regs(tile, 0);
+    store_lds(0);
+    __syncthreads();
+    int buf = 0;
+
+    const int frag_k = (lane >> 5) * 8;
+    const int a_row = wr * (TR * 32) + (lane & 31);
+    const int b_row = wq * (TQ * 32) + (lane & 31);
+
+    while (true) {
+        for (uint32_t s = 0; s < a.nslab; ++s) {
+            uint32_t nt = tile, ns = s + 1;
+            if (ns == a.nslab) { ns = 0; nt = tile + gridDim.x; }
+            const bool has_next = nt < a.ntiles;
+            if (has_next) load_regs(nt, ns);
+
+            const _Float16* vb = Vl + buf * VBUF;
+            const _Float16* qb = Ql + buf * QBUF;
+#pragma unroll
+            for (int kk = 0; kk < SCAN_BK / 16; ++kk) {
+                half8 af[TR], bf[TQ];
+#pragma unroll
+                for (int i = 0; i < TR; ++i)
+                    af[i] = *reinterpret_cast<const half8*>(vb + (a_row + i * 32) * SCAN_LDK + kk * 16 + frag_k);
+#pragma unroll
+                for (int j = 0; j < TQ; ++j)
+                    bf[j] = *reinterpret_cast<const half8*>(qb + (b_row + j * 32) * SCAN_LDK + kk * 16 + frag_k);
+#pragma unroll
+                for (int i = 0; i < TR; ++i)
+#pragma unroll
+                    for (int j = 0; j < TQ; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+            }
+            if (has_next) store_lds(buf ^ 1);
+            __syncthreads();
+            buf ^= 1;
+        }
+
+        // ---- epilogue for this tile: C[row m][query n], lane owns column n = lane&31 of each block
+        const uint32_t rbase = a.row0 + tile * BR;
+#pragma unroll
+        for (int j = 0; j < TQ; ++j) {
+            const uint32_t n = wq * (TQ * 32) + j * 32 + (lane & 31);
+            const bool qok = n < a.nq;
+            const float qinv = qok ? a.qinv[n] : 0.0f;
+            const float thr = qok ? a.thr[n] : 0.0f;
+            float qextra = 0.0f;
+            if (METRIC == M_L2) qextra = qok ? a.qn2[n] : 0.0f;
+            if (METRIC == M_COS) qextra = qok ? a.qrinv[n] : 0.0f;
+#pragma unroll
+            for (int i = 0; i < TR; ++i) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const uint32_t m = rbase + wr * (TR * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    const bool rok = m < a.row1;
+                    float sc = acc[i][j][r] * qinv;
+                    if (METRIC == M_L2) sc = (rok ? a.vn2[m] : 0.0f) - 2.0f * sc + qextra;
+                    if (METRIC == M_COS) sc = 1.0f - sc * (rok ? a.vrinv[m] : 0.0f) * qextra;
+                    acc[i][j][r] = 0.0f;
+                    const bool pass = ASC ? (sc <= thr) : (sc >= thr);
+                    if (qok && rok && (a.emit_all || pass)) {
+                        const uint32_t slot = a.emit_all ? (m - a.row0) : atomicAdd(&a.count[n], 1u);
+                        if (slot < a.cap) a.cand[(size_t)n * a.cap + slot] = make_key(sc, m, ASC);
+                    }
+                }
+            }
+        }
+        tile += gridDim.x;
+        if (tile >= a.ntiles) break;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_scan_binary: packed one-bit rows (ceil(D/64) u64 words per row).  Eight lanes own one row
+// (16 B per lane per chunk -> a row's words are read as contiguous 128-B pieces), row words stay
+// in registers across the query loop, packed queries + thresholds sit in LDS.  Distances follow
+// packed_hamming / packed_jaccard / packed_dice (flat_mmap.rs:1298-1334) — integer popcounts,
+// converted to f32 exactly as the reference does.  HBM-bound: algorithmic bytes = rows * W * 8.
+// ------------------------------------------------------------------------------------------------
+struct BinArgs {
+    const uint64_t* P;  // rows x W
+    uint32_t W;
+    uint32_t row0, row1;
+    const uint64_t* QW;  // nq x W
+    uint32_t nq;
+    const float* thr;
+    uint64_t* cand;
+    uint32_t* count;
+    uint32_t cap;
+    int emit_all;
+    int strict_unused;
+};
+
+constexpr int BIN_MAX_CHUNKS = 4;  // 4 chunks x 8 lanes x 2 words = 64 words = 4096 bits
+
+template <int KIND>  // 0 hamming, 1 jaccard/tanimoto, 2 dice
+__global__ void __launch_bounds__(256) k_scan_binary(BinArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint64_t* qw = reinterpret_cast<uint64_t*>(smem);              // nq * W
+    float* thr_l = reinterpret_cast<float*>(qw + (size_t)a.nq * a.W);  // nq
+    const int tid = threadIdx.x, g = tid & 7;
+    for (uint32_t i = tid; i < a.nq * a.W; i += 256) qw[i] = a.QW[i];
+    for (uint32_t i = tid; i < a.nq; i += 256) thr_l[i] = a.thr[i];
+    __syncthreads();
+    const uint32_t nchunks = (a.W + 15) / 16;
+    for (uint32_t rb = a.row0 + blockIdx.x * 32; rb < a.row1; rb += gridDim.x * 32) {
+        const uint32_t row = rb + (tid >> 3);
+        const bool valid = row < a.row1;
+        uint64_t rw[2 * BIN_MAX_CHUNKS];
+#pragma unroll
+        for (int c = 0; c < BIN_MAX_CHUNKS; ++c) {
+            const uint32_t w0 = 2 * (g + 8 * c);
+            rw[2 * c] = (valid && (uint32_t)c < nchunks && w0 < a.W) ? a.P[(size_t)row * a.W + w0] : 0ull;
+            rw[2 * c + 1] = (valid && (uint32_t)c < nchunks && w0 + 1 < a.W) ? a.P[(size_t)row * a.W + w0 + 1] : 0ull;
+        }
+        uint32_t popr = 0;
+        if (KIND == 2) {
+#pragma unroll
+            for (int c = 0; c < 2 * BIN_MAX_CHUNKS; ++c) popr += __popcll(rw[c]);
+        }
+        for (uint32_t q = 0; q < a.nq; ++q) {
+            uint32_t c0 = 0, c1 = 0;
+#pragma unroll
+            for (int c = 0; c < BIN_MAX_CHUNKS; ++c) {
+                const uint32_t w0 = 2 * (g + 8 * c);
+                if ((uint32_t)c < nchunks) {
+                    const uint64_t x0 = w0 < a.W ? qw[(size_t)q * a.W + w0] : 0ull;
+                    const uint64_t x1 = w0 + 1 < a.W ? qw[(size_t)q * a.W + w0 + 1] : 0ull;
+                    if (KIND == 0) {
+                        c0 += __popcll(x0 ^ rw[2 * c]) + __popcll(x1 ^ rw[2 * c + 1]);
+                    } else if (KIND == 1) {
+                        c0 += __popcll(x0 & rw[2 * c]) + __popcll(x1 & rw[2 * c + 1]);
+                        c1 += __popcll(x0 | rw[2 * c]) + __popcll(x1 | rw[2 * c + 1]);
+                    } else {
+                        c0 += __popcll(x0 & rw[2 * c]) + __popcll(x1 & rw[2 * c + 1]);
+                        c1 += __popcll(x0) + __popcll(x1);
+                    }
+                }
+            }
+            if (KIND == 2) c1 += popr;
+            c0 += __shfl_xor(c0, 1, 8);
+            c0 += __shfl_xor(c0, 2, 8);
+            c0 += __shfl_xor(c0, 4, 8);
+            if (KIND != 0) {
+                c1 += __shfl_xor(c1, 1, 8);
+                c1 += __shfl_xor(c1, 2, 8);
+                c1 += __shfl_xor(c1, 4, 8);
+            }
+            if (g == 0 && valid) {
+                float dist;
+                if (KIND == 0) dist = (float)c0;
+                else if (KIND == 1) dist = c1 == 0 ? 0.0f : __fsub_rn(1.0f, __fdiv_rn((float)c0, (float)c1));
+                else dist = c1 == 0 ? 0.0f : __fsub_rn(1.0f, __fdiv_rn((float)(2u * c0), (float)c1));
+                if (a.emit_all || dist <= thr_l[q]) {
+                    const uint32_t slot = a.emit_all ? (row - a.row0) : atomicAdd(&a.count[q], 1u);
+                    if (slot < a.cap) a.cand[(size_t)q * a.cap + slot] = make_key(dist, row, true);
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Block-wide bitonic sort of npow2 u64 keys in LDS (ascending).
+// ------------------------------------------------------------------------------------------------
+template <int NT>
+__device__ __forceinline__ void bitonic_sort_lds(uint64_t* keys, uint32_t npow2, int tid) {
+    for (uint32_t size = 2; size <= npow2; size <<= 1) {
+        for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+            __syncthreads();
+            for (uint32_t i = tid; i < (npow2 >> 1); i += NT) {
+                const uint32_t lo = 2 * i - (i & (stride - 1));
+                const uint32_t hi = lo + stride;
+                const bool up = (lo & size) == 0;
+                const uint64_t x = keys[lo], y = keys[hi];
+                if ((x > y) == up) { keys[lo] = y; keys[hi] = x; }
+            }
+        }
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ uint32_t next_pow2(uint32_t n) {
+    uint32_t p = 1;
+    while (p < n) p <<= 1;
+    return p;
+}
+
+// Rescore keys[0..n) exactly (8 lanes per candidate); overwrite their score words.
+template <int NT>
+__device__ __forceinline__ void rescore_keys(uint64_t* keys, uint32_t n, int metric, int ip_form,
+                                             const float* qv, const float* V, uint32_t ld, uint32_t D,
+                                             bool asc, int tid) {
+    const int g = tid & 7;
+    const uint32_t grp = tid >> 3;
+    const uint32_t rounds = (n + NT / 8 - 1) / (NT / 8);
+    for (uint32_t r = 0; r < rounds; ++r) {
+        const uint32_t i = r * (NT / 8) + grp;
+        const bool ok = i < n;
+        const uint32_t row = ok ? key_row(keys[i]) : 0u;
+        float s = 0.0f;
+        // all 8 lanes of a group take the same branch, shuffles stay inside the group
+        if (ok) s = exact_score(metric, ip_form, qv, V + (size_t)row * ld, D, g);
+        if (ok && g == 0) keys[i] = make_key(s, row, asc);
+    }
+    __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_select: one block per query after each scan stage.  Sorts the candidate keys, sets the new
+// per-query threshold and prunes.
+//   float metrics: thr = tau -/+ 2E (tau = k-th best coarse score so far).  Any row whose exact
+//     score could still reach the final top-k has coarse score within 2E of tau, so it survives.
+//     If more than keep_max survive (huge margins / massive ties) the survivors are rescored
+//     exactly on the spot and cut to the exact top-k (always valid: a row outside the exact top-k of
+//     the rows seen so far can never enter the final top-k).
+//   exact (binary) metrics: keep the top-k, later rows must be STRICTLY better (they have larger
+//     row ids, so a tie loses) — the reference's strict admission rule (flat_mmap.rs:2170-2176).
+// ------------------------------------------------------------------------------------------------
+struct SelectArgs {
+    uint64_t* cand;
+    uint32_t* count;
+    uint32_t* overflow;
+    float* thr;
+    const float* marg2;
+    uint32_t k, cap, keep_max;
+    int metric, ip_form, exact;
+    int emit_all_n;  // >=0: stage 0 wrote exactly this many keys per query
+    const float* Qf;
+    const float* V;
+    uint32_t ld, D;
+};
+
+template <int NT>
+__global__ void __launch_bounds__(NT) k_select(SelectArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint64_t* keys = reinterpret_cast<uint64_t*>(smem);
+    __shared__ uint32_t s_keep;
+    const uint32_t q = blockIdx.x;
+    const int tid = threadIdx.x;
+    const bool asc = metric_ascending(a.metric);
+    uint32_t n = a.emit_all_n >= 0 ? (uint32_t)a.emit_all_n : a.count[q];
+    if (n > a.cap) {
+        if (tid == 0) a.overflow[q] = 1u;
+        n = a.cap;
+    }
+    uint32_t np2 = next_pow2(n < 2 ? 2 : n);
+    const uint64_t* src = a.cand + (size_t)q * a.cap;
+    for (uint32_t i = tid; i < np2; i += NT) keys[i] = i < n ? src[i] : KEY_SENTINEL;
+    if (tid == 0) s_keep = 0;
+    bitonic_sort_lds<NT>(keys, np2, tid);
+
+    float thr_new = asc ? LY_INF : -LY_INF;
+    uint32_t keep = n;
+    if (n >= a.k && a.k > 0) {
+        const float tau = key_score(keys[a.k - 1], asc);
+        if (a.exact) {
+            thr_new = asc ? nextafterf(tau, -LY_INF) : nextafterf(tau, LY_INF);
+            keep = a.k;
+        } else {
+            const float m2 = a.marg2[q];
+            thr_new = asc ? tau + m2 : tau - m2;
+            uint32_t local = 0;
+            for (uint32_t i = tid; i < n; i += NT) {
+                const float s = key_score(keys[i], asc);
+                local += (asc ? (s <= thr_new) : (s >= thr_new)) ? 1u : 0u;
+            }
+            if (local) atomicAdd(&s_keep, local);
+            __syncthreads();
+            keep = s_keep;
+            if (keep < a.k) keep = a.k;  // NaN-free safety: never drop the current top-k
+            if (keep > a.keep_max) {
+                rescore_keys<NT>(keys, keep, a.metric, a.ip_form, a.Qf + (size_t)q * a.D, a.V, a.ld, a.D, asc, tid);
+                for (uint32_t i = keep + tid; i < np2; i += NT) keys[i] = KEY_SENTINEL;
+                bitonic_sort_lds<NT>(keys, np2, tid);
+                keep = a.k;
+                const float xk = key_score(keys[a.k - 1], asc);
+                thr_new = asc ? xk + m2 : xk - m2;
+            }
+        }
+    }
+    uint64_t* dst = a.cand + (size_t)q * a.cap;
+    for (uint32_t i = tid; i < keep; i += NT) dst[i] = keys[i];
+    if (tid == 0) {
+        a.count[q] = keep;
+        a.thr[q] = thr_new;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_final: one block per query.  Rescores the surviving pool exactly in the reference's
+// accumulation order (float metrics), sorts by (score,row) and writes the top-k:
+// rows (u64, after the shard row map), distances (f32) and the count.  Output order is the
+// canonical (distance, row ascending) order of vector_store.rs:953-970.
+// ------------------------------------------------------------------------------------------------
+struct FinalArgs {
+    const uint64_t* cand;
+    const uint32_t* count;
+    uint32_t k, cap;
+    int metric, ip_form, exact;
+    const float* Qf;
+    const float* V;
+    uint32_t ld, D;
+    uint64_t row_stride, row_offset;
+    uint64_t* out_rows;
+    float* out_dists;
+    uint32_t* out_counts;
+    unsigned long long* pool_total;
+};
+
+template <int NT>
+__global__ void __launch_bounds__(NT) k_final(FinalArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint64_t* keys = reinterpret_cast<uint64_t*>(smem);
+    const uint32_t q = blockIdx.x;
+    const int tid = threadIdx.x;
+    const bool asc = metric_ascending(a.metric);
+    uint32_t n = a.count[q];
+    if (n > a.cap) n = a.cap;
+    const uint32_t np2 = next_pow2(n < 2 ? 2 : n);
+    const uint64_t* src = a.cand + (size_t)q * a.cap;
+    for (uint32_t i = tid; i < np2; i += NT) keys[i] = i < n ? src[i] : KEY_SENTINEL;
+    __syncthreads();
+    if (!a.exact)
+        rescore_keys<NT>(keys, n, a.metric, a.ip_form, a.Qf + (size_t)q * a.D, a.V, a.ld, a.D, asc, tid);
+    bitonic_sort_lds<NT>(keys, np2, tid);
+    const uint32_t cnt = n < a.k ? n : a.k;
+    for (uint32_t i = tid; i < a.k; i += NT) {
+        if (i < cnt) {
+            a.out_rows[(size_t)q * a.k + i] = (uint64_t)key_row(keys[i]) * a.row_stride + a.row_offset;
+            a.out_dists[(size_t)q * a.k + i] = key_score(keys[i], asc);
+        } else {
+            a.out_rows[(size_t)q * a.k + i] = ~0ull;
+            a.out_dists[(size_t)q * a.k + i] = asc ? LY_INF : -LY_INF;
+        }
+    }
+    if (tid == 0) {
+        a.out_counts[q] = cnt;
+        if (a.pool_total) atomicAdd(a.pool_total, (unsigned long long)n);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_merge: k-way merge of per-shard result blocks after the RCCL all-gather — one block per query.
+// (score image, global row) pairs are sorted with an LDS bitonic network under the canonical
+// (distance in metric order, row ascending) order: VectorStore::merge_results (vector_store.rs:953-970),
+// cluster::merge_search_blocks (cluster.rs:327-393).
+// ------------------------------------------------------------------------------------------------
+struct MergeArgs {
+    const char* blocks;
+    uint64_t block_bytes, rows_off, dists_off, counts_off;
+    uint32_t n_lists, k;
+    int metric;
+    uint64_t* out_rows;
+    float* out_dists;
+    uint32_t* out_counts;
+};
+
+template <int NT>
+__global__ void __launch_bounds__(NT) k_merge(MergeArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const uint32_t total = a.n_lists * a.k;
+    const uint32_t np2 = next_pow2(total < 2 ? 2 : total);
+    uint64_t* ids = reinterpret_cast<uint64_t*>(smem);
+    uint32_t* ords = reinterpret_cast<uint32_t*>(ids + np2);
+    __shared__ uint32_t s_n;
+    const uint32_t q = blockIdx.x;
+    const int tid = threadIdx.x;
+    const bool asc = metric_ascending(a.metric);
+    if (tid == 0) s_n = 0;
+    __syncthreads();
+    for (uint32_t i = tid; i < np2; i += NT) {
+        uint64_t id = ~0ull;
+        uint32_t o = 0xffffffffu;
+        if (i < total) {
+            const uint32_t l = i / a.k, j = i % a.k;
+            const char* blk = a.blocks + (size_t)l * a.block_bytes;
+            const uint32_t cnt = reinterpret_cast<const uint32_t*>(blk + a.counts_off)[q];
+            if (j < cnt) {
+                id = reinterpret_cast<const uint64_t*>(blk + a.rows_off)[(size_t)q * a.k + j];
+                const float d = reinterpret_cast<const float*>(blk + a.dists_off)[(size_t)q * a.k + j];
+                o = (uint32_t)(make_key(d, 0u, asc) >> 32);
+                atomicAdd(&s_n, 1u);
+            }
+        }
+        ids[i] = id;
+        ords[i] = o;
+    }
+    for (uint32_t size = 2; size <= np2; size <<= 1) {
+        for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+            __syncthreads();
+            for (uint32_t i = tid; i < (np2 >> 1); i += NT) {
+                const uint32_t lo = 2 * i - (i & (stride - 1));
+                const uint32_t hi = lo + stride;
+                const bool up = (lo & size) == 0;
+                const uint32_t ox = ords[lo], oy = ords[hi];
+                const uint64_t ix = ids[lo], iy = ids[hi];
+                const bool gt = ox > oy || (ox == oy && ix > iy);
+                if (gt == up) { ords[lo] = oy; ords[hi] = ox; ids[lo] = iy; ids[hi] = ix; }
+            }
+        }
+    }
+    __syncthreads();
+    const uint32_t n = s_n;
+    const uint32_t cnt = n < a.k ? n : a.k;
+    for (uint32_t i = tid; i < a.k; i += NT) {
+        if (i < cnt) {
+            a.out_rows[(size_t)q * a.k + i] = ids[i];
+            a.out_dists[(size_t)q * a.k + i] = key_score((uint64_t)ords[i] << 32, asc);
+        } else {
+            a.out_rows[(size_t)q * a.k + i] = ~0ull;
+            a.out_dists[(size_t)q * a.k + i] = asc ? LY_INF : -LY_INF;
+        }
+    }
+    if (tid == 0) a.out_counts[q] = cnt;
+}
+
+}  // namespace lynse

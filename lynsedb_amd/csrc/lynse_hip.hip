@@ -1,0 +1,946 @@
+// lynse_hip.hip — host side of liblynse_hip.so: handles, HBM layout, stage planning, launches and
+// the C ABI declared in include/lynse_hip.h.  gfx950 only; there is no CPU fallback anywhere in
+// this file — every compute entry needs a HIP device.
+//
+// Reference call path replaced:
+//   Collection::search / batch_search (engine.rs:4697-4833, :5352-5498)
+//     -> VectorStore::search (vector_store.rs:972-1004) -> FlatMmap::search (flat_mmap.rs:824-923)
+//     -> exact_flat_search / packed_binary_search (:1173-1230, :1345-1409) -> simd kernels.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+#include "ivf.h"
+
+using namespace lynse;
+
+// ------------------------------------------------------------------------------------ errors ----
+static thread_local std::string g_last_error;
+
+static int set_error(int code, const std::string& msg) {
+    g_last_error = msg;
+    return code;
+}
+
+#define LY_HIP(expr)                                                                          \
+    do {                                                                                      \
+        hipError_t _e = (expr);                                                               \
+        if (_e != hipSuccess) {                                                               \
+            int _code = (_e == hipErrorOutOfMemory) ? LYNSE_ERR_OUT_OF_MEMORY : LYNSE_ERR_DEVICE; \
+            return set_error(_code, std::string(#expr) + ": " + hipGetErrorString(_e));       \
+        }                                                                                     \
+    } while (0)
+
+#define LY_TRY(expr)                  \
+    do {                              \
+        int _rc = (expr);             \
+        if (_rc != LYNSE_OK) return _rc; \
+    } while (0)
+
+extern "C" int lynse_hip_abi_version(void) { return LYNSE_HIP_ABI_VERSION; }
+
+extern "C" size_t lynse_hip_last_error(char* buf, size_t cap) {
+    if (buf && cap) {
+        size_t n = std::min(cap - 1, g_last_error.size());
+        memcpy(buf, g_last_error.data(), n);
+        buf[n] = 0;
+    }
+    return g_last_error.size();
+}
+
+extern "C" int lynse_hip_device_count(int* out) {
+    if (!out) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "out_count is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        *out = 0;
+        return set_error(LYNSE_ERR_DEVICE, std::string("hipGetDeviceCount: ") + hipGetErrorString(e));
+    }
+    *out = n;
+    return LYNSE_OK;
+}
+
+// ----------------------------------------------------------------------------------- metrics ----
+static std::string lower(const char* s) {
+    std::string r(s ? s : "");
+    for (auto& c : r) c = (char)tolower((unsigned char)c);
+    return r;
+}
+
+extern "C" int lynse_hip_metric_from_str(const char* name, int* out) {  // distance/mod.rs:39-63
+    if (!name || !out) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "NULL argument");
+    const std::string s = lower(name);
+    static const struct { const char* n; int m; } tab[] = {
+        {"ip", M_IP}, {"inner_product", M_IP}, {"inner", M_IP}, {"dot", M_IP},
+        {"l2", M_L2}, {"l2sq", M_L2}, {"l2_squared", M_L2}, {"euclidean", M_L2},
+        {"cosine", M_COS}, {"cos", M_COS}, {"cosine_distance", M_COS},
+        {"hamming", M_HAMMING}, {"jaccard", M_JACCARD},
+        {"dice", M_DICE}, {"sorensen", M_DICE}, {"sorensen_dice", M_DICE}, {"sorensen-dice", M_DICE},
+        {"tanimoto", M_TANIMOTO},
+    };
+    for (auto& t : tab)
+        if (s == t.n) { *out = t.m; return LYNSE_OK; }
+    return set_error(LYNSE_ERR_UNKNOWN_METRIC, std::string("Unknown metric: ") + name);
+}
+
+extern "C" int lynse_hip_metric_from_index_mode(const char* mode, int* out) {  // distance/mod.rs:67-107
+    if (!mode || !out) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "NULL argument");
+    std::string up(mode);
+    for (auto& c : up) c = (char)toupper((unsigned char)c);
+    std::vector<std::string> tok;
+    size_t p = 0;
+    while (p <= up.size()) {
+        size_t e = up.find('-', p);
+        if (e == std::string::npos) e = up.size();
+        tok.push_back(up.substr(p, e - p));
+        p = e + 1;
+    }
+    auto has = [&](const char* v) { return std::find(tok.begin(), tok.end(), v) != tok.end(); };
+    // metric families outside this path take precedence in the reference's chain
+    for (const char* o : {"JENSENSHANNON", "JS", "CHEBYSHEV", "CHEBYCHEV", "LINF", "CANBERRA", "BRAYCURTIS"})
+        if (has(o)) return set_error(LYNSE_ERR_UNKNOWN_METRIC, std::string("metric out of scope: ") + mode);
+    int m = -1;
+    if (has("TANIMOTO")) m = M_TANIMOTO;
+    else if (has("JACCARD")) m = M_JACCARD;
+    else if (has("HAMMING")) m = M_HAMMING;
+    else if (has("DICE") || has("SORENSEN")) m = M_DICE;
+    else {
+        for (const char* o : {"HAVERSINE", "GEO", "CORRELATION", "PEARSON", "HELLINGER", "WASSERSTEIN",
+                              "WASSERSTEIN1D", "EMD", "L1", "MANHATTAN", "CITYBLOCK"})
+            if (has(o)) return set_error(LYNSE_ERR_UNKNOWN_METRIC, std::string("metric out of scope: ") + mode);
+        if (has("L2") || has("L2SQ")) m = M_L2;
+        else if (has("COS") || has("COSINE")) m = M_COS;
+        else if (has("IP")) m = M_IP;
+    }
+    if (m < 0) return set_error(LYNSE_ERR_UNKNOWN_METRIC, std::string("Unknown index mode: ") + mode);
+    *out = m;
+    return LYNSE_OK;
+}
+
+extern "C" int lynse_hip_metric_is_ascending(int metric) { return metric_ascending(metric) ? 1 : 0; }
+extern "C" int lynse_hip_metric_is_binary(int metric) { return (metric >= M_HAMMING && metric <= M_TANIMOTO) ? 1 : 0; }
+
+static bool metric_valid(int m) { return m >= M_IP && m <= M_TANIMOTO; }
+
+// ------------------------------------------------------------------------------------ handle ----
+struct Workspace {
+    uint32_t qcap = 0, cap = 0, D = 0, W = 0, kcap = 0;
+    uint64_t* cand = nullptr;
+    uint32_t *count = nullptr, *overflow = nullptr;
+    float *thr = nullptr, *qinv = nullptr, *qn2 = nullptr, *qrinv = nullptr, *marg2 = nullptr;
+    _Float16* Q16 = nullptr;
+    size_t q16_halves = 0;
+    float* Qf = nullptr;
+    uint64_t* QW = nullptr;
+    uint64_t* out_rows = nullptr;
+    float* out_dists = nullptr;
+    uint32_t* out_counts = nullptr;
+    unsigned long long* pool_total = nullptr;
+    void release() {
+        for (void* p : {(void*)cand, (void*)count, (void*)overflow, (void*)thr, (void*)qinv, (void*)qn2,
+                        (void*)qrinv, (void*)marg2, (void*)Q16, (void*)Qf, (void*)QW, (void*)out_rows,
+                        (void*)out_dists, (void*)out_counts, (void*)pool_total})
+            if (p) (void)hipFree(p);
+        *this = Workspace();
+    }
+};
+
+struct lynse_hip_flat {
+    uint32_t dim = 0, ld = 0, words = 0;
+    int device = 0;
+    int num_cu = 256;
+    hipStream_t stream = nullptr;
+    std::mutex mu;
+
+    uint64_t n = 0, capacity = 0;
+    float* rows = nullptr;       // capacity x ld f32, row-major (pad columns zero)
+    uint64_t n_packed = 0, packed_capacity = 0;
+    uint64_t* packed = nullptr;  // n x words u64
+    bool packed_only = false;
+
+    uint64_t n_stats = 0;        // rows covered by vn2/vrinv/stats
+    uint64_t stats_capacity = 0;
+    float *vn2 = nullptr, *vrinv = nullptr;
+    uint32_t* d_stats = nullptr;  // 4 words, see k_row_stats
+    float amax = 0.f, vmax = 0.f, vmin = 0.f, sv = 1.f;
+    int cos_degenerate = 0;
+
+    uint64_t row_stride = 1, row_offset = 0;
+    int ip_form = LYNSE_IPFORM_AUTO;
+    uint32_t stage0_rows = 4096, growth = 8, cap = 8192;
+
+    Workspace ws;
+
+    bool profiling = false;
+    lynse_hip_profile prof{};
+    std::vector<hipEvent_t> ev_pool;
+};
+
+static int use_device(const lynse_hip_flat* h) {
+    LY_HIP(hipSetDevice(h->device));
+    return LYNSE_OK;
+}
+
+static uint32_t round_up(uint32_t x, uint32_t m) { return (x + m - 1) / m * m; }
+
+extern "C" int lynse_hip_flat_create(uint32_t dim, int device, lynse_hip_flat** out) {
+    if (!out) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "out is NULL");
+    *out = nullptr;
+    if (dim == 0) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "dimension must be greater than zero");
+    int ndev = 0;
+    LY_TRY(lynse_hip_device_count(&ndev));
+    if (ndev <= 0) return set_error(LYNSE_ERR_DEVICE, "no HIP device available (this library has no CPU fallback)");
+    if (device < 0 || device >= ndev) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "device ordinal out of range");
+    LY_HIP(hipSetDevice(device));
+    auto* h = new lynse_hip_flat();
+    h->dim = dim;
+    h->ld = round_up(dim, 4);
+    h->words = (dim + 63) / 64;
+    h->device = device;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
+        h->num_cu = prop.multiProcessorCount;
+    hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        delete h;
+        return set_error(LYNSE_ERR_DEVICE, std::string("hipStreamCreate: ") + hipGetErrorString(e));
+    }
+    e = hipMalloc(&h->d_stats, 4 * sizeof(uint32_t));
+    if (e != hipSuccess) {
+        (void)hipStreamDestroy(h->stream);
+        delete h;
+        return set_error(LYNSE_ERR_OUT_OF_MEMORY, "hipMalloc(stats)");
+    }
+    const uint32_t init[4] = {0u, 0u, 0x7f800000u, 0u};
+    (void)hipMemcpy(h->d_stats, init, sizeof init, hipMemcpyHostToDevice);
+    *out = h;
+    return LYNSE_OK;
+}
+
+extern "C" int lynse_hip_flat_destroy(lynse_hip_flat* h) {
+    if (!h) return LYNSE_OK;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    h->ws.release();
+    for (auto e : h->ev_pool) (void)hipEventDestroy(e);
+    for (void* p : {(void*)h->rows, (void*)h->packed, (void*)h->vn2, (void*)h->vrinv, (void*)h->d_stats})
+        if (p) (void)hipFree(p);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+    return LYNSE_OK;
+}
+
+static int grow_rows(lynse_hip_flat* h, uint64_t need) {
+    if (need <= h->capacity) return LYNSE_OK;
+    uint64_t cap = std::max<uint64_t>(need, h->capacity + h->capacity / 2);
+    cap = std::max<uint64_t>(cap, 1024);
+    float* nr = nullptr;
+    LY_HIP(hipMalloc(&nr, (size_t)cap * h->ld * sizeof(float)));
+    if (h->rows && h->n)
+        LY_HIP(hipMemcpyAsync(nr, h->rows, (size_t)h->n * h->ld * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+    LY_HIP(hipStreamSynchronize(h->stream));
+    if (h->rows) (void)hipFree(h->rows);
+    h->rows = nr;
+    h->capacity = cap;
+    return LYNSE_OK;
+}
+
+static int grow_packed(lynse_hip_flat* h, uint64_t need) {
+    if (need <= h->packed_capacity) return LYNSE_OK;
+    uint64_t cap = std::max<uint64_t>(need, h->packed_capacity + h->packed_capacity / 2);
+    cap = std::max<uint64_t>(cap, 1024);
+    uint64_t* np = nullptr;
+    LY_HIP(hipMalloc(&np, (size_t)cap * h->words * sizeof(uint64_t)));
+    if (h->packed && h->n_packed)
+        LY_HIP(hipMemcpyAsync(np, h->packed, (size_t)h->n_packed * h->words * 8, hipMemcpyDeviceToDevice, h->stream));
+    LY_HIP(hipStreamSynchronize(h->stream));
+    if (h->packed) (void)hipFree(h->packed);
+    h->packed = np;
+    h->packed_capacity = cap;
+    return LYNSE_OK;
+}
+
+extern "C" int lynse_hip_flat_reserve(lynse_hip_flat* h, uint64_t rows) {
+    if (!h) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "handle is NULL");
+    std::lock_guard<std::mutex> lk(h->mu);
+    LY_TRY(use_device(h));
+    if (rows > 0xfffffff0ull) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "row count exceeds the u32 id capacity of one shard");
+    if (h->packed_only) return grow_packed(h, rows);
+    if (rows > h->capacity) {
+        // exact reservation (no 1.5x slack): callers reserve to size a shard to its HBM budget
+        float* nr = nullptr;
+        LY_HIP(hipMalloc(&nr, (size_t)rows * h->ld * sizeof(float)));
+        if (h->rows && h->n)
+            LY_HIP(hipMemcpyAsync(nr, h->rows, (size_t)h->n * h->ld * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+        LY_HIP(hipStreamSynchronize(h->stream));
+        if (h->rows) (void)hipFree(h->rows);
+        h->rows = nr;
+        h->capacity = rows;
+    }
+    return LYNSE_OK;
+}
+
+static int append_f32_impl(lynse_hip_flat* h, const float* src, uint64_t n, hipMemcpyKind kind) {
+    if (!h) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "handle is NULL");
+    if (n == 0) return LYNSE_OK;
+    if (!src) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "rows is NULL");
+    std::lock_guard<std::mutex> lk(h->mu);
+    LY_TRY(use_device(h));
+    if (h->packed_only) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "store holds packed rows; cannot append f32 rows");
+    if (h->n + n > 0xfffffff0ull) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "row count exceeds the u32 id capacity of one shard");
+    LY_TRY(grow_rows(h, h->n + n));
+    float* dst = h->rows + (size_t)h->n * h->ld;
+    if (h->ld == h->dim) {
+        LY_HIP(hipMemcpyAsync(dst, src, (size_t)n * h->dim * sizeof(float), kind, h->stream));
+    } else {
+        LY_HIP(hipMemsetAsync(dst, 0, (size_t)n * h->ld * sizeof(float), h->stream));
+        LY_HIP(hipMemcpy2DAsync(dst, (size_t)h->ld * 4, src, (size_t)h->dim * 4, (size_t)h->dim * 4, (size_t)n, kind, h->stream));
+    }
+    LY_HIP(hipStreamSynchronize(h->stream));
+    h->n += n;
+    return LYNSE_OK;
+}
+
+extern "C" int lynse_hip_flat_append_f32(lynse_hip_flat* h, const float* rows, uint64_t n) {
+    return append_f32_impl(h, rows, n, hipMemcpyHostToDevice);
+}
+extern "C" int lynse_hip_flat_append_f32_device(lynse_hip_flat* h, const float* d_rows, uint64_t n) {
+    return append_f32_impl(h, d_rows, n, hipMemcpyDeviceToDevice);
+}
+
+static int append_packed_impl(lynse_hip_flat* h, const uint64_t* src, uint64_t n, hipMemcpyKind kind) {
+    if (!h) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "handle is NULL");
+    if (n == 0) return LYNSE_OK;
+    if (!src) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "words is NULL");
+    std::lock_guard<std::mutex> lk(h->mu);
+    LY_TRY(use_device(h));
+    if (h->n > 0 && !h->packed_only) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "store holds f32 rows; cannot append packed rows");
+    if (h->n + n > 0xfffffff0ull) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "row count exceeds the u32 id capacity of one shard");
+    h->packed_only = true;
+    LY_TRY(grow_packed(h, h->n + n));
+    LY_HIP(hipMemcpyAsync(h->packed + (size_t)h->n * h->words, src, (size_t)n * h->words * 8, kind, h->stream));
+    LY_HIP(hipStreamSynchronize(h->stream));
+    h->n += n;
+    h->n_packed = h->n;
+    return LYNSE_OK;
+}
+
+extern "C" int lynse_hip_flat_append_packed_u64(lynse_hip_flat* h, const uint64_t* words, uint64_t n) {
+    return append_packed_impl(h, words, n, hipMemcpyHostToDevice);
+}
+extern "C" int lynse_hip_flat_append_packed_u64_device(lynse_hip_flat* h, const uint64_t* d_words, uint64_t n) {
+    return append_packed_impl(h, d_words, n, hipMemcpyDeviceToDevice);
+}
+
+// Row statistics for rows [n_stats, n): norms + collection stats (locked by caller).
+static int finalize_locked(lynse_hip_flat* h) {
+    if (h->packed_only || h->n_stats == h->n) return LYNSE_OK;
+    if (h->n > h->stats_capacity) {
+        uint64_t cap = std::max<uint64_t>(h->n, h->capacity);
+        float *a = nullptr, *b = nullptr;
+        LY_HIP(hipMalloc(&a, (size_t)cap * sizeof(float)));
+        LY_HIP(hipMalloc(&b, (size_t)cap * sizeof(float)));
+        if (h->n_stats) {
+            LY_HIP(hipMemcpyAsync(a, h->vn2, (size_t)h->n_stats * 4, hipMemcpyDeviceToDevice, h->stream));
+            LY_HIP(hipMemcpyAsync(b, h->vrinv, (size_t)h->n_stats * 4, hipMemcpyDeviceToDevice, h->stream));
+            LY_HIP(hipStreamSynchronize(h->stream));
+        }
+        if (h->vn2) (void)hipFree(h->vn2);
+        if (h->vrinv) (void)hipFree(h->vrinv);
+        h->vn2 = a;
+        h->vrinv = b;
+        h->stats_capacity = cap;
+    }
+    const uint64_t nnew = h->n - h->n_stats;
+    const uint32_t blocks = (uint32_t)std::min<uint64_t>((nnew + 3) / 4, (uint64_t)h->num_cu * 16);
+    hipLaunchKernelGGL(k_row_stats, dim3(blocks), dim3(256), 0, h->stream, h->rows, h->ld, h->dim,
+                       (uint32_t)h->n_stats, (uint32_t)h->n, h->vn2, h->vrinv, h->d_stats);
+    LY_HIP(hipGetLastError());
+    uint32_t st[4];
+    LY_HIP(hipMemcpyAsync(st, h->d_stats, sizeof st, hipMemcpyDeviceToHost, h->stream));
+    LY_HIP(hipStreamSynchronize(h->stream));
+    float f[3];
+    memcpy(f, st, sizeof f);
+    h->amax = f[0];
+    h->vmax = std::sqrt(f[1]);
+    h->vmin = (st[2] == 0x7f800000u) ? 0.0f : std::sqrt(f[2]);
+    h->cos_degenerate = st[3] ? 1 : 0;
+    int e = (h->amax > 0.0f && std::isfinite(h->amax)) ? std::ilogb(h->amax) : 13;
+    e = std::max(-100, std::min(100, e));
+    h->sv = std::ldexp(1.0f, 13 - e);
+    h->n_stats = h->n;
+    return LYNSE_OK;
+}
+
+extern "C" int lynse_hip_flat_finalize(lynse_hip_flat* h) {
+    if (!h) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "handle is NULL");
+    std::lock_guard<std::mutex> lk(h->mu);
+    LY_TRY(use_device(h));
+    return finalize_locked(h);
+}
+
+// ensure_binary (flat_mmap.rs:388-401): lazily pack f32 rows [n_packed, n).
+static int ensure_packed_locked(lynse_hip_flat* h) {
+    if (h->packed_only || h->n_packed == h->n) return LYNSE_OK;
+    LY_TRY(grow_packed(h, std::max<uint64_t>(h->n, h->capacity)));
+    const uint64_t nnew = h->n - h->n_packed;
+    const uint32_t blocks = (uint32_t)std::min<uint64_t>((nnew + 3) / 4, (uint64_t)h->num_cu * 16);
+    hipLaunchKernelGGL(k_pack_bits, dim3(blocks), dim3(256), 0, h->stream,
+                       h->rows + (size_t)h->n_packed * h->ld, h->ld, h->dim, (uint32_t)nnew,
+                       h->packed + (size_t)h->n_packed * h->words, h->words);
+    LY_HIP(hipGetLastError());
+    LY_HIP(hipStreamSynchronize(h->stream));
+    h->n_packed = h->n;
+    return LYNSE_OK;
+}
+
+extern "C" int lynse_hip_flat_set_row_map(lynse_hip_flat* h, uint64_t stride, uint64_t offset) {
+    if (!h || stride == 0) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "bad row map");
+    std::lock_guard<std::mutex> lk(h->mu);
+    h->row_stride = stride;
+    h->row_offset = offset;
+    return LYNSE_OK;
+}
+
+extern "C" int lynse_hip_flat_set_ip_form(lynse_hip_flat* h, int f) {
+    if (!h || f < LYNSE_IPFORM_AUTO || f > LYNSE_IPFORM_BATCH8) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "bad ip form");
+    std::lock_guard<std::mutex> lk(h->mu);
+    h->ip_form = f;
+    return LYNSE_OK;
+}
+
+extern "C" int lynse_hip_flat_set_plan(lynse_hip_flat* h, uint32_t stage0_rows, uint32_t growth, uint32_t cap) {
+    if (!h) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "handle is NULL");
+    if (cap < 256 || cap > 16384 || (cap & (cap - 1))) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "cap must be a power of two in [256,16384]");
+    if (stage0_rows == 0 || stage0_rows > cap || growth < 2) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "bad stage plan");
+    std::lock_guard<std::mutex> lk(h->mu);
+    (void)hipSetDevice(h->device);
+    if (cap != h->cap) h->ws.release();
+    h->stage0_rows = stage0_rows;
+    h->growth = growth;
+    h->cap = cap;
+    return LYNSE_OK;
+}
+
+extern "C" uint64_t lynse_hip_flat_len(const lynse_hip_flat* h) { return h ? h->n : 0; }
+extern "C" uint32_t lynse_hip_flat_dim(const lynse_hip_flat* h) { return h ? h->dim : 0; }
+extern "C" int lynse_hip_flat_device(const lynse_hip_flat* h) { return h ? h->device : -1; }
+
+extern "C" int lynse_hip_flat_read_rows(const lynse_hip_flat* hc, uint64_t first, uint64_t n, float* out) {
+    auto* h = const_cast<lynse_hip_flat*>(hc);
+    if (!h || (!out && n)) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "NULL argument");
+    std::lock_guard<std::mutex> lk(h->mu);
+    LY_TRY(use_device(h));
+    if (h->packed_only) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "store holds packed rows only");
+    if (first + n > h->n) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "row range out of bounds");
+    if (n == 0) return LYNSE_OK;
+    LY_HIP(hipMemcpy2DAsync(out, (size_t)h->dim * 4, h->rows + (size_t)first * h->ld, (size_t)h->ld * 4,
+                            (size_t)h->dim * 4, (size_t)n, hipMemcpyDeviceToHost, h->stream));
+    LY_HIP(hipStreamSynchronize(h->stream));
+    return LYNSE_OK;
+}
+
+extern "C" int lynse_hip_flat_copy_rows_device(const lynse_hip_flat* hc, uint64_t first, uint64_t n, float* d_out) {
+    auto* h = const_cast<lynse_hip_flat*>(hc);
+    if (!h || (!d_out && n)) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "NULL argument");
+    std::lock_guard<std::mutex> lk(h->mu);
+    LY_TRY(use_device(h));
+    if (h->packed_only) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "store holds packed rows only");
+    if (first + n > h->n) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "row range out of bounds");
+    if (n == 0) return LYNSE_OK;
+    LY_HIP(hipMemcpy2DAsync(d_out, (size_t)h->dim * 4, h->rows + (size_t)first * h->ld, (size_t)h->ld * 4,
+                            (size_t)h->dim * 4, (size_t)n, hipMemcpyDeviceToDevice, h->stream));
+    LY_HIP(hipStreamSynchronize(h->stream));
+    return LYNSE_OK;
+}
+
+extern "C" int lynse_hip_flat_read_packed(lynse_hip_flat* h, uint64_t first, uint64_t n, uint64_t* out) {
+    if (!h || (!out && n)) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "NULL argument");
+    std::lock_guard<std::mutex> lk(h->mu);
+    LY_TRY(use_device(h));
+    if (first + n > h->n) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "row range out of bounds");
+    LY_TRY(ensure_packed_locked(h));
+    if (n == 0) return LYNSE_OK;
+    LY_HIP(hipMemcpyAsync(out, h->packed + (size_t)first * h->words, (size_t)n * h->words * 8, hipMemcpyDeviceToHost, h->stream));
+    LY_HIP(hipStreamSynchronize(h->stream));
+    return LYNSE_OK;
+}
+
+// ---------------------------------------------------------------------------------- profiling ----
+extern "C" int lynse_hip_flat_profile_enable(lynse_hip_flat* h, int on) {
+    if (!h) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "handle is NULL");
+    std::lock_guard<std::mutex> lk(h->mu);
+    h->profiling = on != 0;
+    return LYNSE_OK;
+}
+
+extern "C" int lynse_hip_flat_profile_get(lynse_hip_flat* h, lynse_hip_profile* out, int reset) {
+    if (!h || !out) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "NULL argument");
+    std::lock_guard<std::mutex> lk(h->mu);
+    LY_TRY(use_device(h));
+    if (h->ws.pool_total) {
+        unsigned long long pool = 0;
+        LY_HIP(hipStreamSynchronize(h->stream));
+        LY_HIP(hipMemcpy(&pool, h->ws.pool_total, 8, hipMemcpyDeviceToHost));
+        h->prof.pool_entries = pool;
+        if (reset) LY_HIP(hipMemset(h->ws.pool_total, 0, 8));
+    }
+    *out = h->prof;
+    if (reset) h->prof = lynse_hip_profile{};
+    return LYNSE_OK;
+}
+
+// ------------------------------------------------------------------------------------- search ----
+constexpr uint32_t QCHUNK = 256;
+constexpr int SEL_NT = 512;
+
+static size_t scan_lds_bytes(int bq) { return (size_t)2 * (SCAN_BR + bq) * SCAN_LDK * sizeof(_Float16); }
+
+template <typename K>
+static int set_max_lds(K kernel, size_t bytes) {
+    LY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return LYNSE_OK;
+}
+
+static int ensure_workspace(lynse_hip_flat* h, uint32_t k) {
+    Workspace& w = h->ws;
+    const uint32_t nslab = (h->dim + SCAN_BK - 1) / SCAN_BK;
+    if (w.cand && w.cap == h->cap && w.D == h->dim && w.kcap >= k) return LYNSE_OK;
+    w.release();
+    w.qcap = QCHUNK;
+    w.cap = h->cap;
+    w.D = h->dim;
+    w.W = h->words;
+    w.kcap = std::max<uint32_t>(k, 128);
+    LY_HIP(hipMalloc(&w.cand, (size_t)QCHUNK * w.cap * 8));
+    LY_HIP(hipMalloc(&w.count, QCHUNK * 4));
+    LY_HIP(hipMalloc(&w.overflow, QCHUNK * 4));
+    LY_HIP(hipMalloc(&w.thr, QCHUNK * 4));
+    LY_HIP(hipMalloc(&w.qinv, QCHUNK * 4));
+    LY_HIP(hipMalloc(&w.qn2, QCHUNK * 4));
+    LY_HIP(hipMalloc(&w.qrinv, QCHUNK * 4));
+    LY_HIP(hipMalloc(&w.marg2, QCHUNK * 4));
+    w.q16_halves = (size_t)nslab * QCHUNK * SCAN_LDK;
+    LY_HIP(hipMalloc(&w.Q16, w.q16_halves * sizeof(_Float16)));
+    LY_HIP(hipMemset(w.Q16, 0, w.q16_halves * sizeof(_Float16)));
+    LY_HIP(hipMalloc(&w.Qf, (size_t)QCHUNK * h->dim * 4));
+    LY_HIP(hipMalloc(&w.QW, (size_t)QCHUNK * h->words * 8));
+    LY_HIP(hipMalloc(&w.out_rows, (size_t)QCHUNK * w.kcap * 8));
+    LY_HIP(hipMalloc(&w.out_dists, (size_t)QCHUNK * w.kcap * 4));
+    LY_HIP(hipMalloc(&w.out_counts, QCHUNK * 4));
+    LY_HIP(hipMalloc(&w.pool_total, 8));
+    LY_HIP(hipMemset(w.pool_total, 0, 8));
+    return LYNSE_OK;
+}
+
+struct Stage { uint32_t r0, r1; };
+
+static std::vector<Stage> make_plan(const lynse_hip_flat* h, uint32_t k, bool safe) {
+    std::vector<Stage> plan;
+    const uint64_t n = h->n;
+    if (n == 0) return plan;
+    if (safe) {
+        const uint32_t step = h->cap / 2;
+        for (uint64_t r = 0; r < n; r += step) plan.push_back({(uint32_t)r, (uint32_t)std::min<uint64_t>(n, r + step)});
+        return plan;
+    }
+    uint64_t s0 = std::max<uint64_t>(h->stage0_rows, std::min<uint64_t>(h->cap, 4ull * k));
+    s0 = std::min<uint64_t>(std::min<uint64_t>(s0, h->cap), n);
+    uint64_t g = std::max<uint64_t>(2, std::min<uint64_t>(h->growth, h->cap / (4ull * std::max<uint32_t>(k, 1))));
+    uint64_t b = s0;
+    plan.push_back({0u, (uint32_t)b});
+    while (b < n) {
+        uint64_t nb = std::min<uint64_t>(n, b * g);
+        plan.push_back({(uint32_t)b, (uint32_t)nb});
+        b = nb;
+    }
+    return plan;
+}
+
+template <int WQ, int WR, int TQ, int TR>
+static int launch_scan(lynse_hip_flat* h, const ScanArgs& a, int metric, uint32_t grid, hipStream_t st) {
+    constexpr int NT = WQ * WR * 64;
+    constexpr int BQ = WQ * TQ * 32;
+    const size_t lds = scan_lds_bytes(BQ);
+    static bool attr_done[3] = {false, false, false};
+    auto go = [&](auto kern, int slot) -> int {
+        if (!attr_done[slot]) {
+            LY_TRY(set_max_lds(kern, lds));
+            attr_done[slot] = true;
+        }
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), lds, st, a);
+        LY_HIP(hipGetLastError());
+        return LYNSE_OK;
+    };
+    (void)h;
+    switch (metric) {
+    case M_IP: return go(k_scan_f16<WQ, WR, TQ, TR, M_IP>, 0);
+    case M_L2: return go(k_scan_f16<WQ, WR, TQ, TR, M_L2>, 1);
+    default: return go(k_scan_f16<WQ, WR, TQ, TR, M_COS>, 2);
+    }
+}
+
+static int launch_scan_binary(const BinArgs& a, int metric, uint32_t grid, size_t lds, hipStream_t st) {
+    static bool attr_done[3] = {false, false, false};
+    auto go = [&](auto kern, int slot) -> int {
+        if (!attr_done[slot]) {
+            LY_TRY(set_max_lds(kern, 160 * 1024 - 64));
+            attr_done[slot] = true;
+        }
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a);
+        LY_HIP(hipGetLastError());
+        return LYNSE_OK;
+    };
+    switch (metric) {
+    case M_HAMMING: return go(k_scan_binary<0>, 0);
+    case M_DICE: return go(k_scan_binary<2>, 2);
+    default: return go(k_scan_binary<1>, 1);
+    }
+}
+
+static int get_event(lynse_hip_flat* h, size_t idx, hipEvent_t* out) {
+    while (h->ev_pool.size() <= idx) {
+        hipEvent_t e;
+        LY_HIP(hipEventCreate(&e));
+        h->ev_pool.push_back(e);
+    }
+    *out = h->ev_pool[idx];
+    return LYNSE_OK;
+}
+
+// One chunk (<= QCHUNK queries) whose inputs are already in the workspace (Qf for float metrics,
+// QW for binary).  Results land in ws.out_*.  `safe` selects the exhaustive plan.
+static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, int metric, bool safe, hipStream_t st,
+                     size_t* ev_used, std::vector<std::pair<size_t, uint64_t>>* scan_events) {
+    Workspace& w = h->ws;
+    const bool binary = metric >= M_HAMMING;
+    const bool asc = metric_ascending(metric);
+    const uint32_t nslab = (h->dim + SCAN_BK - 1) / SCAN_BK;
+    const bool small = nq <= SCAN_BQ_SMALL;
+    const uint32_t qpad = small ? SCAN_BQ_SMALL : SCAN_BQ_LARGE;
+    int ip_form = h->ip_form;
+    if (ip_form == LYNSE_IPFORM_AUTO) ip_form = h->n < 4096 ? LYNSE_IPFORM_SINGLE : LYNSE_IPFORM_BATCH8;
+
+    static bool sel_attr = false;
+    if (!sel_attr) {
+        LY_TRY(set_max_lds(k_select<SEL_NT>, 16384 * 8));
+        LY_TRY(set_max_lds(k_final<SEL_NT>, 16384 * 8));
+        sel_attr = true;
+    }
+
+    if (binary) {
+        std::vector<float> thr0(nq, INFINITY);
+        LY_HIP(hipMemcpyAsync(w.thr, thr0.data(), nq * 4, hipMemcpyHostToDevice, st));
+        LY_HIP(hipMemsetAsync(w.count, 0, nq * 4, st));
+        LY_HIP(hipMemsetAsync(w.overflow, 0, nq * 4, st));
+        LY_HIP(hipStreamSynchronize(st));  // thr0 is a stack/heap temporary
+    } else {
+        // queries with index >= nq inside the padded tile must be finite: zero the image
+        LY_HIP(hipMemsetAsync(w.Q16, 0, (size_t)nslab * qpad * SCAN_LDK * sizeof(_Float16), st));
+        PrepArgs p{};
+        p.Q = w.Qf; p.D = h->dim; p.nq = nq; p.qpad = qpad; p.nslab = nslab; p.metric = metric;
+        p.sv = h->sv; p.vmax = h->vmax; p.vmin = h->vmin; p.cos_degenerate = h->cos_degenerate;
+        p.Q16 = w.Q16; p.qinv = w.qinv; p.qn2 = w.qn2; p.qrinv = w.qrinv; p.marg2 = w.marg2; p.thr = w.thr;
+        p.count = w.count; p.overflow = w.overflow;
+        hipLaunchKernelGGL(k_prep_queries, dim3(nq), dim3(256), 0, st, p);
+        LY_HIP(hipGetLastError());
+    }
+
+    const std::vector<Stage> plan = make_plan(h, k, safe);
+    for (size_t si = 0; si < plan.size(); ++si) {
+        const Stage s = plan[si];
+        const bool emit_all = si == 0;
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (h->profiling) {
+            LY_TRY(get_event(h, (*ev_used)++, &e0));
+            LY_TRY(get_event(h, (*ev_used)++, &e1));
+            LY_HIP(hipEventRecord(e0, st));
+        }
+        if (binary) {
+            BinArgs b{};
+            b.P = h->packed; b.W = h->words; b.row0 = s.r0; b.row1 = s.r1; b.QW = w.QW; b.nq = nq;
+            b.thr = w.thr; b.cand = w.cand; b.count = w.count; b.cap = w.cap; b.emit_all = emit_all ? 1 : 0;
+            const uint32_t groups = (s.r1 - s.r0 + 31) / 32;
+            const uint32_t grid = std::max<uint32_t>(1, std::min<uint32_t>(groups, (uint32_t)h->num_cu * 8));
+            const size_t lds = (size_t)nq * h->words * 8 + (size_t)nq * 4;
+            LY_TRY(launch_scan_binary(b, metric, grid, lds, st));
+        } else {
+            ScanArgs a{};
+            a.V = h->rows; a.ld = h->ld; a.D = h->dim; a.row0 = s.r0; a.row1 = s.r1; a.Q16 = w.Q16;
+            a.qpad = qpad; a.nq = nq; a.nslab = nslab; a.ntiles = (s.r1 - s.r0 + SCAN_BR - 1) / SCAN_BR;
+            a.qinv = w.qinv; a.qn2 = w.qn2; a.qrinv = w.qrinv; a.thr = w.thr; a.vn2 = h->vn2; a.vrinv = h->vrinv;
+            a.sv = h->sv; a.cand = w.cand; a.count = w.count; a.cap = w.cap; a.emit_all = emit_all ? 1 : 0;
+            if (small) {
+                const uint32_t grid = std::min<uint32_t>(a.ntiles, (uint32_t)h->num_cu * 3);
+                LY_TRY((launch_scan<1, 4, 1, 1>(h, a, metric, grid, st)));
+            } else {
+                const uint32_t grid = std::min<uint32_t>(a.ntiles, (uint32_t)h->num_cu);
+                LY_TRY((launch_scan<4, 2, 2, 2>(h, a, metric, grid, st)));
+            }
+        }
+        if (h->profiling) {
+            LY_HIP(hipEventRecord(e1, st));
+            scan_events->push_back({*ev_used - 2, (uint64_t)(s.r1 - s.r0)});
+        }
+        SelectArgs sa{};
+        sa.cand = w.cand; sa.count = w.count; sa.overflow = w.overflow; sa.thr = w.thr; sa.marg2 = w.marg2;
+        sa.k = k; sa.cap = w.cap; sa.keep_max = w.cap / 2; sa.metric = metric; sa.ip_form = ip_form;
+        sa.exact = binary ? 1 : 0; sa.emit_all_n = emit_all ? (int)(s.r1 - s.r0) : -1;
+        sa.Qf = w.Qf; sa.V = h->rows; sa.ld = h->ld; sa.D = h->dim;
+        hipLaunchKernelGGL(k_select<SEL_NT>, dim3(nq), dim3(SEL_NT), (size_t)w.cap * 8, st, sa);
+        LY_HIP(hipGetLastError());
+    }
+    FinalArgs fa{};
+    fa.cand = w.cand; fa.count = w.count; fa.k = k; fa.cap = w.cap; fa.metric = metric; fa.ip_form = ip_form;
+    fa.exact = binary ? 1 : 0; fa.Qf = w.Qf; fa.V = h->rows; fa.ld = h->ld; fa.D = h->dim;
+    fa.row_stride = h->row_stride; fa.row_offset = h->row_offset;
+    fa.out_rows = w.out_rows; fa.out_dists = w.out_dists; fa.out_counts = w.out_counts;
+    fa.pool_total = h->profiling ? w.pool_total : nullptr;
+    hipLaunchKernelGGL(k_final<SEL_NT>, dim3(nq), dim3(SEL_NT), (size_t)w.cap * 8, st, fa);
+    LY_HIP(hipGetLastError());
+    (void)asc;
+    return LYNSE_OK;
+}
+
+// Shared driver: q_src is nq x dim f32 (float metrics / f32 binary queries) or nq x words u64
+// (pre-packed).  Sources and destinations are host or device pointers according to `on_device`.
+static int search_impl(lynse_hip_flat* h, const void* q_src, bool packed_queries, uint64_t nq, uint32_t k,
+                       int metric, uint64_t* out_rows, float* out_dists, uint32_t* out_counts,
+                       bool on_device, hipStream_t user_stream) {
+    if (!h) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "handle is NULL");
+    if (!metric_valid(metric)) return set_error(LYNSE_ERR_UNKNOWN_METRIC, "Unknown metric id");
+    if (nq == 0) return LYNSE_OK;
+    if (!q_src || !out_counts || (k && (!out_rows || !out_dists))) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "NULL argument");
+    std::lock_guard<std::mutex> lk(h->mu);
+    LY_TRY(use_device(h));
+    const bool binary = metric >= M_HAMMING;
+    hipStream_t st = user_stream ? user_stream : h->stream;
+    const hipMemcpyKind in_kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    const hipMemcpyKind out_kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+
+    if (packed_queries && !binary) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "packed queries need a binary metric");
+    if (!binary && h->packed_only) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "store holds packed rows; float metrics unavailable");
+
+    // empty store or k == 0 -> empty results, not an error (flat_mmap.rs:832-835)
+    if (h->n == 0 || k == 0) {
+        if (on_device) LY_HIP(hipMemsetAsync(out_counts, 0, nq * 4, st));
+        else memset(out_counts, 0, nq * 4);
+        if (on_device) LY_HIP(hipStreamSynchronize(st));
+        return LYNSE_OK;
+    }
+    const uint32_t kk = (uint32_t)std::min<uint64_t>(k, h->n);  // k.min(n), flat_mmap.rs:836
+    if (h->n > h->cap && kk > h->cap / 4)
+        return set_error(LYNSE_ERR_UNSUPPORTED, "k > cap/4 with more rows than the candidate capacity is not supported yet");
+    if (binary && h->words > 16u * BIN_MAX_CHUNKS)
+        return set_error(LYNSE_ERR_UNSUPPORTED, "packed-binary rows wider than 4096 bits are not supported yet");
+    if (binary && (size_t)QCHUNK * h->words * 8 + QCHUNK * 4 > 150 * 1024)
+        return set_error(LYNSE_ERR_UNSUPPORTED, "packed query tile exceeds LDS");
+
+    if (binary) LY_TRY(ensure_packed_locked(h));
+    else LY_TRY(finalize_locked(h));
+    LY_TRY(ensure_workspace(h, kk));
+    Workspace& w = h->ws;
+
+    hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+    size_t ev_used = 0;
+    std::vector<std::pair<size_t, uint64_t>> scan_events;
+    if (h->profiling) {
+        LY_TRY(get_event(h, ev_used++, &ev_begin));
+        LY_TRY(get_event(h, ev_used++, &ev_end));
+        LY_HIP(hipEventRecord(ev_begin, st));
+    }
+    uint64_t fallback_queries = 0;
+
+    for (uint64_t q0 = 0; q0 < nq; q0 += QCHUNK) {
+        const uint32_t nqc = (uint32_t)std::min<uint64_t>(QCHUNK, nq - q0);
+        // stage the chunk's queries in the workspace
+        if (binary) {
+            if (packed_queries) {
+                LY_HIP(hipMemcpyAsync(w.QW, (const uint64_t*)q_src + q0 * h->words, (size_t)nqc * h->words * 8, in_kind, st));
+            } else {  // pack_binary_query (flat_mmap.rs:1292-1296)
+                LY_HIP(hipMemcpyAsync(w.Qf, (const float*)q_src + q0 * h->dim, (size_t)nqc * h->dim * 4, in_kind, st));
+                hipLaunchKernelGGL(k_pack_bits, dim3((nqc + 3) / 4), dim3(256), 0, st, w.Qf, h->dim, h->dim, nqc, w.QW, h->words);
+                LY_HIP(hipGetLastError());
+            }
+        } else {
+            LY_HIP(hipMemcpyAsync(w.Qf, (const float*)q_src + q0 * h->dim, (size_t)nqc * h->dim * 4, in_kind, st));
+        }
+        bool safe = false;
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            LY_TRY(run_chunk(h, nqc, kk, metric, safe, st, &ev_used, &scan_events));
+            std::vector<uint32_t> ovf(nqc);
+            LY_HIP(hipMemcpyAsync(ovf.data(), w.overflow, nqc * 4, hipMemcpyDeviceToHost, st));
+            LY_HIP(hipStreamSynchronize(st));
+            uint32_t nov = 0;
+            for (uint32_t v : ovf) nov += v ? 1 : 0;
+            if (nov == 0) break;
+            if (safe) return set_error(LYNSE_ERR_INTERNAL, "candidate overflow on the exhaustive plan");
+            fallback_queries += nov;
+            safe = true;  // rerun the chunk on the exhaustive plan
+        }
+        // outputs: workspace rows are [nqc][kk]; caller layout is [nq][k]
+        if (kk == k) {
+            LY_HIP(hipMemcpyAsync(out_rows + q0 * k, w.out_rows, (size_t)nqc * k * 8, out_kind, st));
+            LY_HIP(hipMemcpyAsync(out_dists + q0 * k, w.out_dists, (size_t)nqc * k * 4, out_kind, st));
+        } else {
+            LY_HIP(hipMemcpy2DAsync(out_rows + q0 * k, (size_t)k * 8, w.out_rows, (size_t)kk * 8, (size_t)kk * 8, nqc, out_kind, st));
+            LY_HIP(hipMemcpy2DAsync(out_dists + q0 * k, (size_t)k * 4, w.out_dists, (size_t)kk * 4, (size_t)kk * 4, nqc, out_kind, st));
+        }
+        LY_HIP(hipMemcpyAsync(out_counts + q0, w.out_counts, nqc * 4, out_kind, st));
+        LY_HIP(hipStreamSynchronize(st));
+    }
+
+    if (h->profiling) {
+        LY_HIP(hipEventRecord(ev_end, st));
+        LY_HIP(hipEventSynchronize(ev_end));
+        float ms = 0.f;
+        LY_HIP(hipEventElapsedTime(&ms, ev_begin, ev_end));
+        h->prof.total_us += (double)ms * 1000.0;
+        const uint64_t row_bytes = binary ? (uint64_t)h->words * 8 : (uint64_t)h->dim * 4;
+        for (auto& se : scan_events) {
+            float sms = 0.f;
+            LY_HIP(hipEventElapsedTime(&sms, h->ev_pool[se.first], h->ev_pool[se.first + 1]));
+            h->prof.scan_us += (double)sms * 1000.0;
+            h->prof.scan_launches += 1;
+            h->prof.scan_rows += se.second;
+            h->prof.scan_bytes += se.second * row_bytes;
+        }
+        h->prof.searches += 1;
+        h->prof.fallback_queries += fallback_queries;
+    }
+    return LYNSE_OK;
+}
+
+extern "C" int lynse_hip_flat_search_f32(lynse_hip_flat* h, const float* queries, uint64_t nq, uint32_t k, int metric,
+                                         uint64_t* out_rows, float* out_dists, uint32_t* out_counts) {
+    return search_impl(h, queries, false, nq, k, metric, out_rows, out_dists, out_counts, false, nullptr);
+}
+
+extern "C" int lynse_hip_flat_search_f32_device(lynse_hip_flat* h, const float* d_queries, uint64_t nq, uint32_t k,
+                                                int metric, uint64_t* d_out_rows, float* d_out_dists,
+                                                uint32_t* d_out_counts, void* stream) {
+    return search_impl(h, d_queries, false, nq, k, metric, d_out_rows, d_out_dists, d_out_counts, true, (hipStream_t)stream);
+}
+
+extern "C" int lynse_hip_flat_search_packed_u64(lynse_hip_flat* h, const uint64_t* qw, uint64_t nq, uint32_t k, int metric,
+                                                uint64_t* out_rows, float* out_dists, uint32_t* out_counts) {
+    return search_impl(h, qw, true, nq, k, metric, out_rows, out_dists, out_counts, false, nullptr);
+}
+
+extern "C" int lynse_hip_flat_search_packed_u64_device(lynse_hip_flat* h, const uint64_t* d_qw, uint64_t nq, uint32_t k,
+                                                       int metric, uint64_t* d_out_rows, float* d_out_dists,
+                                                       uint32_t* d_out_counts, void* stream) {
+    return search_impl(h, d_qw, true, nq, k, metric, d_out_rows, d_out_dists, d_out_counts, true, (hipStream_t)stream);
+}
+
+// --------------------------------------------------------------------------- stand-alone calls ----
+extern "C" int lynse_hip_top_k_search(const float* query, const float* candidates, uint64_t n, uint32_t dim, uint32_t k,
+                                      int metric, int device, uint32_t* out_idx, float* out_dist, uint32_t* out_count) {
+    // distance::top_k_search (distance/mod.rs:373-422): single-row kernels for every candidate.
+    if (!out_count) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "out_count is NULL");
+    *out_count = 0;
+    if (!metric_valid(metric)) return set_error(LYNSE_ERR_UNKNOWN_METRIC, "Unknown metric id");
+    if (dim == 0) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "dimension must be greater than zero");
+    if (n == 0 || k == 0) return LYNSE_OK;
+    if (!query || !candidates || !out_idx || !out_dist) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "NULL argument");
+    lynse_hip_flat* h = nullptr;
+    LY_TRY(lynse_hip_flat_create(dim, device, &h));
+    int rc = lynse_hip_flat_append_f32(h, candidates, n);
+    if (rc == LYNSE_OK) rc = lynse_hip_flat_set_ip_form(h, LYNSE_IPFORM_SINGLE);
+    const uint32_t kk = (uint32_t)std::min<uint64_t>(k, n);
+    std::vector<uint64_t> rows(kk);
+    uint32_t cnt = 0;
+    if (rc == LYNSE_OK) rc = lynse_hip_flat_search_f32(h, query, 1, kk, metric, rows.data(), out_dist, &cnt);
+    lynse_hip_flat_destroy(h);
+    if (rc != LYNSE_OK) return rc;
+    for (uint32_t i = 0; i < cnt; ++i) out_idx[i] = (uint32_t)rows[i];
+    *out_count = cnt;
+    return LYNSE_OK;
+}
+
+extern "C" int lynse_hip_compute_distance(const float* a, const float* b, uint32_t dim, int metric, int device, float* out) {
+    // distance::compute_distance_f32(a, b) (distance/mod.rs:193-213): a plays the query.
+    if (!a || !b || !out) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "NULL argument");
+    uint32_t idx = 0, cnt = 0;
+    float d = 0.f;
+    LY_TRY(lynse_hip_top_k_search(a, b, 1, dim, 1, metric, device, &idx, &d, &cnt));
+    if (cnt != 1) return set_error(LYNSE_ERR_INTERNAL, "distance kernel returned no result");
+    *out = d;
+    return LYNSE_OK;
+}
+
+extern "C" int lynse_hip_pack_binary_f32(const float* rows, uint64_t n, uint32_t dim, int device, uint64_t* out_words) {
+    if (n == 0) return LYNSE_OK;
+    if (!rows || !out_words) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "NULL argument");
+    lynse_hip_flat* h = nullptr;
+    LY_TRY(lynse_hip_flat_create(dim, device, &h));
+    int rc = lynse_hip_flat_append_f32(h, rows, n);
+    if (rc == LYNSE_OK) rc = lynse_hip_flat_read_packed(h, 0, n, out_words);
+    lynse_hip_flat_destroy(h);
+    return rc;
+}
+
+extern "C" int lynse_hip_merge_topk(const uint64_t* ids, const float* dists, const uint32_t* counts, uint32_t n_lists,
+                                    uint32_t stride, uint32_t k, int metric, uint64_t* out_ids, float* out_dists,
+                                    uint32_t* out_count) {
+    // VectorStore::merge_results (vector_store.rs:953-970): (distance in metric order, id ascending).
+    if (!out_count) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "out_count is NULL");
+    *out_count = 0;
+    if (!metric_valid(metric)) return set_error(LYNSE_ERR_UNKNOWN_METRIC, "Unknown metric id");
+    if (n_lists == 0 || k == 0) return LYNSE_OK;
+    if (!ids || !dists || !counts || !out_ids || !out_dists) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "NULL argument");
+    const bool asc = metric_ascending(metric);
+    struct E { float d; uint64_t id; };
+    std::vector<E> all;
+    for (uint32_t l = 0; l < n_lists; ++l) {
+        if (counts[l] > stride) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "count exceeds stride");
+        for (uint32_t i = 0; i < counts[l]; ++i) all.push_back({dists[(size_t)l * stride + i], ids[(size_t)l * stride + i]});
+    }
+    auto before = [asc](const E& x, const E& y) {
+        if (x.d < y.d) return asc;
+        if (x.d > y.d) return !asc;
+        return x.id < y.id;  // NaN compares Equal like partial_cmp().unwrap_or(Equal)
+    };
+    const size_t kk = std::min<size_t>(k, all.size());
+    std::partial_sort(all.begin(), all.begin() + kk, all.end(), before);
+    for (size_t i = 0; i < kk; ++i) { out_ids[i] = all[i].id; out_dists[i] = all[i].d; }
+    *out_count = (uint32_t)kk;
+    return LYNSE_OK;
+}
+
+extern "C" int lynse_hip_merge_topk_device(const void* d_blocks, uint64_t block_bytes, uint64_t rows_off,
+                                           uint64_t dists_off, uint64_t counts_off, uint32_t n_lists, uint64_t nq,
+                                           uint32_t k, int metric, uint64_t* d_out_rows, float* d_out_dists,
+                                           uint32_t* d_out_counts, void* stream) {
+    if (!metric_valid(metric)) return set_error(LYNSE_ERR_UNKNOWN_METRIC, "Unknown metric id");
+    if (nq == 0) return LYNSE_OK;
+    if (!d_blocks || !d_out_counts || (k && (!d_out_rows || !d_out_dists))) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (n_lists == 0) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "n_lists is zero");
+    if (k == 0) {
+        LY_HIP(hipMemsetAsync(d_out_counts, 0, nq * 4, (hipStream_t)stream));
+        return LYNSE_OK;
+    }
+    const uint64_t total = (uint64_t)n_lists * k;
+    if (total > 8192) return set_error(LYNSE_ERR_UNSUPPORTED, "n_lists * k exceeds the merge kernel capacity (8192)");
+    uint32_t np2 = 2;
+    while (np2 < total) np2 <<= 1;
+    static bool attr = false;
+    if (!attr) {
+        LY_TRY(set_max_lds(k_merge<256>, 8192 * 12));
+        attr = true;
+    }
+    MergeArgs a{};
+    a.blocks = (const char*)d_blocks; a.block_bytes = block_bytes; a.rows_off = rows_off; a.dists_off = dists_off;
+    a.counts_off = counts_off; a.n_lists = n_lists; a.k = k; a.metric = metric;
+    a.out_rows = d_out_rows; a.out_dists = d_out_dists; a.out_counts = d_out_counts;
+    hipLaunchKernelGGL(k_merge<256>, dim3((uint32_t)nq), dim3(256), (size_t)np2 * 12, (hipStream_t)stream, a);
+    LY_HIP(hipGetLastError());
+    return LYNSE_OK;
+}
+
+#include "ivf_host.inc"

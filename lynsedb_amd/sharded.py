@@ -1,0 +1,214 @@
+"""Row-sharded FLAT search across the GPUs of one node — one process per GPU.
+
+Replaces the reference's only parallelism/communication strategy, the TCP scatter-gather of
+`src/cluster.rs` (fan-out to every shard :173-217, `merge_search_blocks` :327-393) and the Python
+`ClusterCoordinator._merge_pairs` (python/lynse/cluster.py:535-556), with:
+
+    per-rank scan of the local shard (liblynse_hip.so)  ->  ONE RCCL all-gather over xGMI of the
+    fixed-size per-rank result block [rows u64 | dists f32 | counts u32] (B*k*12 + B*4 bytes)
+    ->  k-way merge on the device in the canonical (distance, row ascending) order.
+
+Global row g lives on rank g % world (local row l <-> global l*world + rank), which keeps local row
+order monotone in the global id — the tie-break order is therefore identical to a single shard.
+`torch.distributed` is used for the process group only (backend "nccl" = RCCL on ROCm, "gloo" in the
+CPU tests); no tensor math of the search path runs in torch.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import numpy as np
+
+from . import _lib
+from ._lib import check, lib
+from .core import FlatIndex
+
+
+def shard_of_row(global_row: int, world: int) -> int:
+    return global_row % world
+
+
+def block_layout(nq: int, k: int):
+    """Byte layout of one rank's result block (the RCCL message; cf. the 12 B/candidate TCP block of
+    src/rpc.rs:1156-1177)."""
+    rows_off = 0
+    dists_off = rows_off + nq * k * 8
+    counts_off = dists_off + nq * k * 4
+    total = counts_off + nq * 4
+    total = (total + 15) // 16 * 16
+    return rows_off, dists_off, counts_off, total
+
+
+class ShardOutputs:
+    def __init__(self, nq: int, k: int, world: int, device):
+        import torch
+
+        self.nq, self.k, self.world = nq, k, world
+        self.rows_off, self.dists_off, self.counts_off, self.block_bytes = block_layout(nq, k)
+        self.local = torch.zeros(self.block_bytes, dtype=torch.uint8, device=device)
+        self.gathered = torch.zeros(self.block_bytes * world, dtype=torch.uint8, device=device) if world > 1 else self.local
+        self.rows = torch.zeros((nq, k), dtype=torch.int64, device=device)     # u64 bits
+        self.dists = torch.zeros((nq, k), dtype=torch.float32, device=device)
+        self.counts = torch.zeros(nq, dtype=torch.int32, device=device)        # u32 bits
+
+    def local_ptrs(self):
+        base = self.local.data_ptr()
+        return base + self.rows_off, base + self.dists_off, base + self.counts_off
+
+
+class ShardedFlat:
+    def __init__(self, dim: int, rank: int = 0, world: int = 1, device: Optional[int] = None, group=None):
+        self.dim, self.rank, self.world = dim, rank, world
+        self.dist = group  # the torch.distributed module (or None when world == 1)
+        self.index = FlatIndex(None, dim, device)
+        self.index.set_row_map(world, rank)
+
+    # -- data ------------------------------------------------------------------------------------
+    def add_global_rows(self, data: np.ndarray, first_global_row: int = 0) -> None:
+        """Append this rank's share of `data` (global rows first_global_row ...)."""
+        first = (self.rank - first_global_row) % self.world
+        mine = np.ascontiguousarray(data[first::self.world])
+        if mine.shape[0]:
+            self.index.write(mine)
+
+    def alloc_outputs(self, nq: int, k: int) -> ShardOutputs:
+        import torch
+
+        return ShardOutputs(nq, k, self.world, torch.device("cuda", self.index_device()))
+
+    def index_device(self) -> int:
+        return int(lib.lynse_hip_flat_device(self.index.handle))
+
+    # -- search ----------------------------------------------------------------------------------
+    def search_device(self, d_queries, k: int, metric: int, out: ShardOutputs) -> None:
+        """Whole-collection search; results (identical on every rank) land in out.rows/dists/counts."""
+        nq = d_queries.shape[0]
+        if self.world == 1:  # single shard: results are already globally merged and ordered
+            check(lib.lynse_hip_flat_search_f32_device(
+                self.index.handle, C.c_void_p(d_queries.data_ptr()), nq, k, metric, C.c_void_p(out.rows.data_ptr()),
+                C.c_void_p(out.dists.data_ptr()), C.c_void_p(out.counts.data_ptr()), None))
+            return
+        pr, pd, pc = out.local_ptrs()
+        check(lib.lynse_hip_flat_search_f32_device(self.index.handle, C.c_void_p(d_queries.data_ptr()), nq, k,
+                                                   metric, C.c_void_p(pr), C.c_void_p(pd), C.c_void_p(pc), None))
+        self.dist.all_gather_into_tensor(out.gathered, out.local)
+        import torch
+
+        stream = torch.cuda.current_stream().cuda_stream
+        check(lib.lynse_hip_merge_topk_device(C.c_void_p(out.gathered.data_ptr()), out.block_bytes, out.rows_off,
+                                              out.dists_off, out.counts_off, self.world, nq, k, metric,
+                                              C.c_void_p(out.rows.data_ptr()), C.c_void_p(out.dists.data_ptr()),
+                                              C.c_void_p(out.counts.data_ptr()), C.c_void_p(stream)))
+
+    def search(self, queries: np.ndarray, k: int, metric: int):
+        """Host-array convenience wrapper around search_device."""
+        import torch
+
+        dev = torch.device("cuda", self.index_device())
+        q = torch.as_tensor(np.ascontiguousarray(queries, dtype=np.float32), device=dev)
+        out = self.alloc_outputs(q.shape[0], k)
+        self.search_device(q, k, metric, out)
+        torch.cuda.synchronize()
+        return (out.rows.cpu().numpy().view(np.uint64), out.dists.cpu().numpy(),
+                out.counts.cpu().numpy().view(np.uint32))
+
+    # -- host-array variant of the exchange step (also the path the gloo CPU tests exercise) -------
+    @staticmethod
+    def pack_block(rows: np.ndarray, dists: np.ndarray, counts: np.ndarray) -> np.ndarray:
+        nq, k = rows.shape
+        ro, do, co, total = block_layout(nq, k)
+        buf = np.zeros(total, np.uint8)
+        buf[ro:ro + nq * k * 8] = np.ascontiguousarray(rows, np.uint64).view(np.uint8).ravel()
+        buf[do:do + nq * k * 4] = np.ascontiguousarray(dists, np.float32).view(np.uint8).ravel()
+        buf[co:co + nq * 4] = np.ascontiguousarray(counts, np.uint32).view(np.uint8).ravel()
+        return buf
+
+    @staticmethod
+    def unpack_blocks(gathered: np.ndarray, world: int, nq: int, k: int):
+        ro, do, co, total = block_layout(nq, k)
+        g = gathered.reshape(world, total)
+        rows = np.stack([g[r, ro:ro + nq * k * 8].view(np.uint64).reshape(nq, k) for r in range(world)])
+        dists = np.stack([g[r, do:do + nq * k * 4].view(np.float32).reshape(nq, k) for r in range(world)])
+        counts = np.stack([g[r, co:co + nq * 4].view(np.uint32) for r in range(world)])
+        return rows, dists, counts
+
+    @staticmethod
+    def allgather_merge_host(dist, world: int, rows: np.ndarray, dists: np.ndarray, counts: np.ndarray, k: int, metric: int):
+        """all-gather the per-rank result blocks over `dist` (any backend) and merge on the host with
+        lynse_hip_merge_topk — the same message layout and order as the device path."""
+        import torch
+
+        from .core import merge_topk
+
+        nq = rows.shape[0]
+        local = torch.from_numpy(ShardedFlat.pack_block(rows, dists, counts))
+        if world > 1:
+            parts = [torch.empty_like(local) for _ in range(world)]
+            dist.all_gather(parts, local)
+            gathered = torch.cat(parts).numpy()
+        else:
+            gathered = local.numpy()
+        g_rows, g_dists, g_counts = ShardedFlat.unpack_blocks(gathered, world, nq, k)
+        out_r = np.full((nq, k), np.iinfo(np.uint64).max, np.uint64)
+        out_d = np.zeros((nq, k), np.float32)
+        out_c = np.zeros(nq, np.uint32)
+        for q in range(nq):
+            i, d = merge_topk(g_rows[:, q, :], g_dists[:, q, :], g_counts[:, q], k, metric)
+            out_r[q, :len(i)], out_d[q, :len(i)], out_c[q] = i, d, len(i)
+        return out_r, out_d, out_c
+
+    # -- verification against an independent torch fp32 computation (bench.py, outside timing) -----
+    def verify_against_torch(self, d_queries, k: int, metric: int, out: ShardOutputs, nverify: int = 16) -> dict:
+        import torch
+
+        if metric >= _lib.METRIC_HAMMING:
+            return {"skipped": "binary metric"}
+        n_local = len(self.index)
+        dev = d_queries.device
+        q = d_queries[:nverify]
+        asc = metric != _lib.METRIC_IP
+        best_s = torch.full((nverify, k), float("inf") if asc else float("-inf"), device=dev)
+        best_i = torch.full((nverify, k), -1, dtype=torch.int64, device=dev)
+        chunk = 500_000
+        buf = torch.empty((chunk, self.dim), dtype=torch.float32, device=dev)
+        qn = (q * q).sum(1, keepdim=True)
+        for r0 in range(0, n_local, chunk):
+            nr = min(chunk, n_local - r0)
+            # rows come back from the library's own HBM copy (device-to-device)
+            check(lib.lynse_hip_flat_copy_rows_device(self.index.handle, r0, nr, C.c_void_p(buf.data_ptr())))
+            v = buf[:nr]
+            s = q @ v.T
+            if metric == _lib.METRIC_L2:
+                s = qn + (v * v).sum(1)[None, :] - 2.0 * s
+            elif metric == _lib.METRIC_COSINE:
+                s = 1.0 - s / (qn.sqrt() * (v * v).sum(1).sqrt()[None, :]).clamp_min(1e-30)
+            gid = (torch.arange(r0, r0 + nr, device=dev, dtype=torch.int64) * self.world + self.rank)[None, :].expand(nverify, -1)
+            cs = torch.cat([best_s, s], 1)
+            ci = torch.cat([best_i, gid], 1)
+            ts, ti = torch.topk(cs, k, dim=1, largest=not asc)
+            best_s, best_i = ts, torch.gather(ci, 1, ti)
+        if self.world > 1:
+            gs = [torch.empty_like(best_s) for _ in range(self.world)]
+            gi = [torch.empty_like(best_i) for _ in range(self.world)]
+            self.dist.all_gather(gs, best_s)
+            self.dist.all_gather(gi, best_i)
+            cs, ci = torch.cat(gs, 1), torch.cat(gi, 1)
+            ts, ti = torch.topk(cs, k, dim=1, largest=not asc)
+            best_s, best_i = ts, torch.gather(ci, 1, ti)
+        got_i = out.rows[:nverify]
+        got_d = out.dists[:nverify]
+        strict = 0
+        tolerant = 0
+        kth = best_s[:, -1:]
+        scale = best_s.abs().max().clamp_min(1e-30)
+        tol = 1e-5 * scale
+        for r in range(nverify):
+            ref = set(best_i[r].tolist())
+            strict += sum(1 for x in got_i[r].tolist() if x in ref)
+        ok = (got_d >= kth - tol) if not asc else (got_d <= kth + tol)
+        tolerant = int(ok.sum().item())
+        rel = ((got_d - best_s).abs() / best_s.abs().clamp_min(1e-6)).max().item()
+        return {"queries": nverify, "recall_at_k": round(strict / (nverify * k), 6),
+                "recall_at_k_tolerant": round(tolerant / (nverify * k), 6),
+                "max_rel_score_diff_vs_torch_fp32": float("%.3g" % rel), "reference": "torch fp32 matmul top-k (GPU)"}

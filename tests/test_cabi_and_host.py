@@ -1,0 +1,146 @@
+"""CPU tests: the C-ABI library loads and exports every symbol include/lynse_hip.h declares, host-side
+logic (metric parsing, error mapping, host merge) works without a GPU, and compute entry points fail
+loudly (no silent CPU fallback).  No compute calls are made."""
+import ctypes as C
+import json
+import re
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def declared_symbols():
+    text = (ROOT / "include" / "lynse_hip.h").read_text()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(lynse_hip_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_exported_and_bound():
+    import lynsedb_amd._lib as lb
+
+    syms = declared_symbols()
+    assert len(syms) >= 40
+    raw = C.CDLL(str(lb.LIB_PATH))
+    for s in syms:
+        assert hasattr(raw, s), f"{s} declared in include/lynse_hip.h but not exported"
+        assert s in lb.SIGNATURES, f"{s} has no ctypes signature in lynsedb_amd/_lib.py"
+    assert set(lb.SIGNATURES) == set(syms)
+    assert lb.lib.lynse_hip_abi_version() == 1
+
+
+def test_library_does_not_link_the_oracle():
+    import subprocess
+
+    import lynsedb_amd._lib as lb
+
+    out = subprocess.run(["nm", "-D", str(lb.LIB_PATH)], capture_output=True, text=True).stdout
+    assert "lo_" not in "".join(l.split()[-1][:3] for l in out.splitlines() if l.split())
+    for src in (ROOT / "lynsedb_amd").rglob("*"):
+        if src.suffix in (".py", ".hip", ".h", ".inc", ".cpp") and src.is_file():
+            txt = src.read_text(errors="ignore")
+            assert "import oracle" not in txt and "from oracle" not in txt and "lynse_oracle" not in txt, src
+
+
+def test_metric_parsing_matches_reference_and_oracle(oracle, golden_dir):
+    import lynsedb_amd as L
+
+    for name in ["ip", "IP", "inner_product", "inner", "dot", "DOT", "l2", "l2sq", "l2_squared", "euclidean",
+                 "cosine", "cos", "cosine_distance", "hamming", "jaccard", "dice", "sorensen", "sorensen_dice",
+                 "sorensen-dice", "tanimoto"]:
+        assert L.metric_from_str(name) == oracle.metric_from_str(name)
+    with pytest.raises(ValueError, match="Unknown metric: bogus"):  # src/python/mod.rs:2000-2002
+        L.metric_from_str("bogus")
+    g = json.loads((golden_dir / "python_reference_vectors.json").read_text())
+    for row in g["is_ascending_index"]:  # python/lynse/cluster.py:182 via the golden vectors
+        if row["mode"] is None:
+            continue
+        m = L.metric_from_index_mode(row["mode"])
+        assert m == oracle.metric_from_index_mode(row["mode"])
+        assert bool(L._lib.lib.lynse_hip_metric_is_ascending(m)) == row["ascending"]
+    names = {"IP": 0, "L2": 1, "Cosine": 2, "Hamming": 3, "Jaccard": 4, "Dice": 5, "Tanimoto": 6}
+    for row in g["parse_index_mode"]:  # result_view._parse_index_mode
+        assert L.metric_from_index_mode(row["mode"]) == names[row["parsed"][1]]
+    with pytest.raises(ValueError):
+        L.metric_from_index_mode("FLAT-BOGUS")
+    assert L._lib.lib.lynse_hip_metric_is_binary(5) == 1 and L._lib.lib.lynse_hip_metric_is_binary(2) == 0
+
+
+def test_host_merge_matches_golden_and_oracle(oracle, golden_dir):
+    import lynsedb_amd as L
+
+    g = json.loads((golden_dir / "python_reference_vectors.json").read_text())
+    for case in g["merge_pairs"]:  # cluster._merge_pairs golden outputs
+        blocks = case["blocks"]
+        stride = max([len(b[0]) for b in blocks] + [1])
+        ids = np.zeros((len(blocks), stride), np.uint64)
+        ds = np.zeros((len(blocks), stride), np.float32)
+        cnt = np.zeros(len(blocks), np.uint32)
+        for i, (bi, bs) in enumerate(blocks):
+            ids[i, :len(bi)], ds[i, :len(bs)], cnt[i] = bi, bs, len(bi)
+        got_i, got_d = L.merge_topk(ids, ds, cnt, case["k"], "l2" if case["ascending"] else "ip")
+        assert [int(x) for x in got_i] == case["ids"]
+        assert np.allclose(got_d, np.asarray(case["scores"], np.float32))
+    rng = np.random.default_rng(1)
+    for metric in (0, 1):  # heavy ties: canonical (distance, id) order == oracle merge_results
+        ids = rng.permutation(400).astype(np.uint64).reshape(8, 50)
+        ds = rng.integers(0, 6, size=(8, 50)).astype(np.float32)
+        cnt = rng.integers(0, 51, size=8).astype(np.uint32)
+        flat_i = np.concatenate([ids[i, :cnt[i]] for i in range(8)])
+        flat_d = np.concatenate([ds[i, :cnt[i]] for i in range(8)])
+        e_i, e_d = oracle.merge_results(flat_i, flat_d, 37, metric)
+        g_i, g_d = L.merge_topk(ids, ds, cnt, 37, metric)
+        assert np.array_equal(e_i, g_i) and np.array_equal(e_d, g_d)
+
+
+def test_no_cpu_fallback_without_device():
+    import lynsedb_amd as L
+
+    if L._lib.device_count() > 0:
+        pytest.skip("a HIP device is present")
+    with pytest.raises(L._lib.LynseHipError):
+        L.FlatIndex(None, 8)
+    with pytest.raises(L._lib.LynseHipError):
+        L.py_top_k_search(np.zeros(4, np.float32), np.zeros((3, 4), np.float32), "ip", 2)
+    with pytest.raises(ValueError, match="Unknown metric"):  # argument errors are still reported first
+        L.py_compute_distance(np.zeros(2, np.float32), np.zeros(2, np.float32), "nope")
+
+
+def test_block_layout_roundtrip():
+    from lynsedb_amd.sharded import ShardedFlat, block_layout
+
+    rng = np.random.default_rng(0)
+    nq, k, world = 5, 7, 3
+    ro, do, co, total = block_layout(nq, k)
+    assert ro == 0 and do == nq * k * 8 and co == do + nq * k * 4 and total % 16 == 0
+    blocks, src = [], []
+    for r in range(world):
+        rows = rng.integers(0, 1 << 40, size=(nq, k)).astype(np.uint64)
+        d = rng.random((nq, k), dtype=np.float32)
+        c = rng.integers(0, k + 1, size=nq).astype(np.uint32)
+        src.append((rows, d, c))
+        blocks.append(ShardedFlat.pack_block(rows, d, c))
+    R, D, Cn = ShardedFlat.unpack_blocks(np.concatenate(blocks), world, nq, k)
+    for r in range(world):
+        assert np.array_equal(R[r], src[r][0]) and np.array_equal(D[r], src[r][1]) and np.array_equal(Cn[r], src[r][2])
+
+
+def test_sift_vecs_reader_matches_golden(golden_dir, tmp_path):
+    """benchmarks/sift_io.py read_fvecs/read_ivecs outputs captured from the reference."""
+    from lynsedb_amd.datasets import read_fvecs, read_ivecs
+
+    g = json.loads((golden_dir / "python_reference_vectors.json").read_text())
+    p = tmp_path / "t.fvecs"
+    p.write_bytes(bytes.fromhex(g["fvecs"]["hex"]))
+    a = read_fvecs(p)
+    assert list(a.shape) == g["fvecs"]["shape"] and a.dtype == np.float32
+    assert np.array_equal(a.ravel(), np.asarray(g["fvecs"]["values"], np.float32))
+    p = tmp_path / "t.ivecs"
+    p.write_bytes(bytes.fromhex(g["ivecs"]["hex"]))
+    b = read_ivecs(p)
+    assert list(b.shape) == g["ivecs"]["shape"] and np.array_equal(b.ravel(), np.asarray(g["ivecs"]["values"], np.int32))
+    with pytest.raises(ValueError):
+        (tmp_path / "e.fvecs").write_bytes(b"")
+        read_fvecs(tmp_path / "e.fvecs")

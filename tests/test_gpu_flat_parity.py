@@ -1,0 +1,325 @@
+"""GPU parity tests: the HIP path (through the C ABI of liblynse_hip.so) vs the CPU oracle.
+
+Bar (task ③): ids/ranks bit-exact under the canonical (distance, row) order; float distances are
+ALSO compared bit-exactly because the final rescoring pass reproduces the reference's accumulation
+order (tolerance stated per test: 0 ulp unless noted; north_star allows 1e-5 relative).
+Run on the GPU box with `pytest -m gpu`.
+"""
+import numpy as np
+import pytest
+
+import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+IP, L2, COS, HAM, JAC, DICE, TANI = O.IP, O.L2, O.COS, O.HAMMING, O.JACCARD, O.DICE, O.TANIMOTO
+NAME = {IP: "ip", L2: "l2", COS: "cosine", HAM: "hamming", JAC: "jaccard", DICE: "dice", TANI: "tanimoto"}
+f32 = np.float32
+
+
+@pytest.fixture(scope="module")
+def L():
+    import lynsedb_amd as L_
+
+    assert L_._lib.device_count() >= 1, "no HIP device: GPU tests need the MI355X box"
+    return L_
+
+
+def make_index(L, data):
+    idx = L.FlatIndex(None, data.shape[1])
+    if data.shape[0]:
+        idx.write(data)
+    return idx
+
+
+def check_batch(L, oracle, idx, data, queries, k, metric, ip_form=O.IPFORM_AUTO, exact_dist=True):
+    rows, dists, counts = idx.search_batch_arrays(queries, k, NAME[metric])
+    for qi in range(queries.shape[0]):
+        e_ids, e_d = oracle.canonical_topk(queries[qi], data, k, metric, ip_form)
+        c = int(counts[qi])
+        assert c == len(e_ids), (qi, c, len(e_ids))
+        got_ids = rows[qi, :c].astype(np.uint32)
+        got_d = dists[qi, :c]
+        if exact_dist:
+            assert np.array_equal(got_d.view(np.uint32), e_d.view(np.uint32)), \
+                (NAME[metric], qi, got_d[:5], e_d[:5], got_ids[:5], e_ids[:5])
+        else:
+            assert np.allclose(got_d, e_d, rtol=1e-5, atol=1e-6)
+        assert np.array_equal(got_ids, e_ids), (NAME[metric], qi, got_ids[:10], e_ids[:10], got_d[:10], e_d[:10])
+
+
+# ------------------------------------------------------------------ reference KATs through the GPU
+
+def test_kat_flat_mmap_write_search(L):  # flat_mmap.rs:6022-6054
+    data = np.array([[1, 0, 0, 0], [0, 1, 0, 0], [0.5, 0.5, 0, 0], [0, 0, 1, 0], [0, 0, 0, 1]], f32)
+    idx = make_index(L, data)
+    assert len(idx) == 5 and idx.dim == 4
+    ids, d = idx.search(np.array([1, 0, 0, 0], f32), 2, "ip")
+    assert len(ids) == 2 and ids[0] == 0 and abs(d[0] - 1.0) < 1e-6
+    ids, _ = idx.search(np.zeros(4, f32), 1, "l2")
+    assert ids[0] == 2
+    assert ids.dtype == np.uint32 and d.dtype == np.float32
+
+
+def test_kat_top_k_functions(L):  # distance/mod.rs:502-527, :571-621; test_backend.py:25-92
+    ids, d = L.py_top_k_search(np.array([1, 0, 0, 0], f32), np.array([[1, 0, 0, 0], [.5, .5, 0, 0], [0, 1, 0, 0]], f32), "IP", 2)
+    assert list(ids) == [0, 1] and abs(d[0] - 1.0) < 1e-6
+    ids, _ = L.py_top_k_search(np.zeros(3, f32), np.array([[1, 0, 0], [.1, 0, 0], [2, 0, 0]], f32), "L2", 2)
+    assert ids[0] == 1
+    ids, d = L.py_top_k_search(np.array([0, 0], f32), np.array([[2, 0], [1, 0]], f32), "l2", 10)  # clamp
+    assert list(ids) == [1, 0] and d[0] <= d[1]
+    ids, d = L.py_top_k_search(np.array([1, 2], f32), np.zeros((0, 2), f32), "l2", 5)  # empty
+    assert len(ids) == 0 and len(d) == 0
+    ids, d = L.py_top_k_search(np.array([1, 2], f32), np.array([[1, 2], [3, 4]], f32), "l2", 0)  # k == 0
+    assert len(ids) == 0
+    q = np.array([1, 0, 1, 0], f32)
+    c = np.array([[1, 0, 1, 0], [1, 1, 1, 0], [0, 1, 0, 1]], f32)
+    ids, d = L.py_top_k_search(q, c, "hamming", 3)
+    assert list(ids) == [0, 1, 2] and list(d) == [0.0, 1.0, 4.0]
+    ids, d = L.py_top_k_search(q, c, "jaccard", 3)
+    assert list(ids) == [0, 1, 2] and abs(d[1] - 1 / 3) < 1e-6 and abs(d[2] - 1) < 1e-6
+    for a, b, m, exp, tol in [([1, 0, 0], [0, 1, 0], "IP", 0.0, 1e-5), ([0, 0], [3, 4], "L2", 25.0, 1e-4),
+                              ([1, 0], [0, 1], "cosine", 1.0, 1e-5), ([1, 1, 0], [1, 0, 1], "dice", 0.5, 1e-5),
+                              ([1, 1, 0], [1, 0, 1], "tanimoto", 2 / 3, 1e-5), ([3, 4], [3, 4], "IP", 25.0, 1e-4)]:
+        assert abs(L.py_compute_distance(np.array(a, f32), np.array(b, f32), m) - exp) < tol
+    with pytest.raises(ValueError, match="Unknown metric"):
+        L.py_compute_distance(np.zeros(2, f32), np.zeros(2, f32), "bogus")
+    with pytest.raises(ValueError):
+        L.py_compute_distance(np.zeros(2, f32), np.zeros(3, f32), "ip")
+
+
+def test_kat_packed_binary_dim130(L, oracle):  # flat_mmap.rs:6386-6421 (3 words, tail bits)
+    dim = 130
+    rows = np.zeros((3, dim), f32)
+    for i in (0, 1, 64, 129):
+        rows[0, i] = rows[1, i] = 1.0
+    rows[1, 5] = 1.0
+    for i in (2, 3, 65):
+        rows[2, i] = 1.0
+    idx = make_index(L, rows)
+    assert np.array_equal(idx.read_packed(0, 3), oracle.pack_binary(rows))  # ballot pack == pack_binary_f32
+    for m in ("hamming", "jaccard", "tanimoto", "dice"):
+        ids, d = idx.search(rows[0], 3, m)
+        r_ids, r_d = oracle.top_k_search(rows[0], rows, 3, oracle.metric_from_str(m))
+        assert np.array_equal(ids, r_ids) and np.all(np.abs(d - r_d) < 1e-6)
+
+
+def test_kat_eye_and_backend_fixtures(L, oracle):  # test_backend.py:107-190
+    eye = np.eye(16, dtype=f32)
+    idx = make_index(L, eye)
+    for i in range(16):
+        ids, d = idx.search(eye[i], 1, "ip")
+        assert ids[0] == i and abs(d[0] - 1) < 1e-5
+    ids, d = idx.search(eye[3], 1, "l2")
+    assert ids[0] == 3 and abs(d[0]) < 1e-5
+    np.random.seed(7)
+    vecs = np.random.rand(200, 16).astype(f32)
+    np.random.seed(1)
+    q = np.random.rand(16).astype(f32)
+    idx = make_index(L, vecs)
+    assert idx.search(q, 1, "ip")[0][0] == int(np.argmax(vecs @ q))
+    assert idx.search(q, 1, "l2")[0][0] == int(np.argmin(((vecs - q) ** 2).sum(1)))
+    ids, d = idx.search(q, 300, "ip")
+    assert len(ids) == 200
+    check_batch(L, oracle, idx, vecs, q.reshape(1, -1), 20, IP)
+    check_batch(L, oracle, idx, vecs, q.reshape(1, -1), 20, L2)
+    check_batch(L, oracle, idx, vecs, q.reshape(1, -1), 20, COS)
+
+
+# ------------------------------------------------------------------ randomized differential parity
+
+@pytest.mark.parametrize("metric", [IP, L2, COS])
+@pytest.mark.parametrize("n,dim,nq,k", [
+    (1, 4, 1, 1), (5, 3, 2, 10), (100, 16, 7, 10), (1000, 130, 3, 5), (4095, 32, 4, 10), (4097, 32, 33, 10),
+    (20000, 128, 40, 10), (50000, 96, 256, 10), (30000, 64, 300, 7), (9000, 24, 5, 100), (70000, 768, 12, 10),
+])
+def test_float_parity_uniform(L, oracle, metric, n, dim, nq, k):
+    rng = np.random.default_rng(n * 31 + dim)
+    data = rng.random((n, dim), dtype=f32)
+    queries = rng.random((nq, dim), dtype=f32)
+    if n > 10:
+        queries[0] = data[n // 2]  # exact self match
+    idx = make_index(L, data)
+    sel = list(range(min(nq, 6))) + ([nq - 1] if nq > 6 else [])
+    rows, dists, counts = idx.search_batch_arrays(queries, k, NAME[metric])
+    for qi in sel:
+        e_ids, e_d = oracle.canonical_topk(queries[qi], data, k, metric)
+        c = int(counts[qi])
+        assert c == len(e_ids)
+        assert np.array_equal(dists[qi, :c].view(np.uint32), e_d.view(np.uint32)), (qi, dists[qi, :c], e_d)
+        assert np.array_equal(rows[qi, :c].astype(np.uint32), e_ids), (qi, rows[qi, :c], e_ids)
+
+
+@pytest.mark.parametrize("metric", [IP, L2, COS])
+def test_float_parity_gaussian_mixed_scale(L, oracle, metric):
+    """Signed data with very different row norms: stresses the f16 scale + certified margin."""
+    rng = np.random.default_rng(99)
+    n, dim = 40000, 100
+    data = rng.standard_normal((n, dim)).astype(f32) * (10.0 ** rng.uniform(-2, 2, size=(n, 1))).astype(f32)
+    queries = rng.standard_normal((9, dim)).astype(f32) * f32(3.0)
+    idx = make_index(L, data)
+    check_batch(L, oracle, idx, data, queries, 10, metric)
+
+
+@pytest.mark.parametrize("metric", [IP, L2, COS])
+def test_float_parity_massive_ties(L, oracle, metric):
+    """Duplicated rows -> exact score ties far beyond k: order must still be (distance, row asc)."""
+    rng = np.random.default_rng(5)
+    base = rng.random((7, 48), dtype=f32)
+    data = np.repeat(base, 3000, axis=0)  # 21000 rows, 7 distinct
+    data = data[rng.permutation(data.shape[0])]
+    queries = np.vstack([base[2], rng.random(48, dtype=f32)])
+    idx = make_index(L, data)
+    check_batch(L, oracle, idx, data, queries, 25, metric)
+
+
+def test_float_parity_adversarial_monotone(L, oracle):
+    """Scores increase with the row index: every later row beats the running threshold, so the
+    candidate buffers overflow and the exhaustive safe plan must take over."""
+    n, dim = 60000, 8
+    data = np.zeros((n, dim), f32)
+    data[:, 0] = np.arange(n, dtype=f32) / f32(n)
+    data[:, 1] = f32(0.5)
+    q = np.zeros((2, dim), f32)
+    q[:, 0] = 1.0
+    q[1, 1] = 0.25
+    idx = make_index(L, data)
+    idx.profile_enable(True)
+    check_batch(L, oracle, idx, data, q, 10, IP)
+    assert idx.profile_get()["fallback_queries"] > 0
+
+
+def test_zero_vectors_and_zero_query(L, oracle):
+    rng = np.random.default_rng(3)
+    data = rng.random((5000, 20), dtype=f32)
+    data[::7] = 0.0
+    queries = np.vstack([np.zeros(20, f32), rng.random(20, dtype=f32)])
+    idx = make_index(L, data)
+    for m in (IP, L2, COS):
+        check_batch(L, oracle, idx, data, queries, 12, m)
+
+
+def test_append_after_search_and_small_plan(L, oracle):
+    rng = np.random.default_rng(8)
+    data = rng.random((30000, 40), dtype=f32)
+    idx = L.FlatIndex(None, 40)
+    idx.set_plan(stage0_rows=256, growth=2, cap=1024)  # many stages
+    idx.write(data[:12000])
+    q = rng.random((3, 40), dtype=f32)
+    check_batch(L, oracle, idx, data[:12000], q, 10, L2)
+    idx.write(data[12000:] * f32(50.0))  # new rows change the collection scale
+    full = np.vstack([data[:12000], data[12000:] * f32(50.0)])
+    for m in (IP, L2, COS):
+        check_batch(L, oracle, idx, full, q, 10, m)
+
+
+def test_ip_forms(L, oracle):
+    rng = np.random.default_rng(21)
+    data = rng.random((3000, 37), dtype=f32)
+    q = rng.random((2, 37), dtype=f32)
+    idx = make_index(L, data)
+    idx.set_ip_form(O.IPFORM_BATCH8)
+    check_batch(L, oracle, idx, data, q, 10, IP, ip_form=O.IPFORM_BATCH8)
+    idx.set_ip_form(O.IPFORM_SINGLE)
+    check_batch(L, oracle, idx, data, q, 10, IP, ip_form=O.IPFORM_SINGLE)
+    # reference policy for n < 4096 is the single-row kernel (flat_mmap.rs:4852): identical to lo_flat_search
+    idx.set_ip_form(O.IPFORM_AUTO)
+    ids, d = idx.search(q[0], 10, "ip")
+    r_ids, r_d = oracle.flat_search(q[0], data, 10, IP)
+    assert np.array_equal(ids, r_ids) and np.array_equal(d.view(np.uint32), r_d.view(np.uint32))
+
+
+# ------------------------------------------------------------------ packed binary (integer path)
+
+@pytest.mark.parametrize("metric", [HAM, JAC, DICE, TANI])
+@pytest.mark.parametrize("n,bits,nq,k,p", [(50, 64, 3, 10, 0.5), (4000, 130, 5, 50, 0.5), (100000, 1024, 4, 50, 0.5),
+                                           (60000, 1024, 2, 50, 0.05), (30000, 2048, 33, 10, 0.3), (20000, 100, 260, 5, 0.5)])
+def test_binary_parity_packed(L, oracle, metric, n, bits, nq, k, p):
+    rng = np.random.default_rng(n + bits)
+    W = (bits + 63) // 64
+    dense = rng.random((n, bits)) < p
+    rows = np.zeros((n, W), np.uint64)
+    for w in range(W):
+        chunk = dense[:, w * 64:(w + 1) * 64]
+        rows[:, w] = (chunk.astype(np.uint64) << np.arange(chunk.shape[1], dtype=np.uint64)).sum(axis=1, dtype=np.uint64)
+    queries = rows[rng.integers(0, n, size=nq)].copy()
+    queries[-1] ^= np.uint64(0x5)
+    idx = L.FlatIndex(None, bits)
+    idx.write_packed(rows)
+    r, d, c = idx.search_packed_arrays(queries, k, NAME[metric])
+    for qi in list(range(min(nq, 4))) + [nq - 1]:
+        e_ids, e_d = oracle.canonical_topk_packed(queries[qi], rows, k, metric)
+        cc = int(c[qi])
+        assert cc == len(e_ids)
+        assert np.array_equal(d[qi, :cc].view(np.uint32), e_d.view(np.uint32)), (qi, d[qi, :cc], e_d)
+        assert np.array_equal(r[qi, :cc].astype(np.uint32), e_ids), (qi, r[qi, :cc], e_ids)
+
+
+def test_binary_from_f32_rows_all_identical(L, oracle):
+    """f32 {0,1} rows packed lazily on the device (ensure_binary); all rows identical -> every
+    distance ties, ids must be 0..k-1."""
+    n, dim = 30000, 96
+    row = (np.arange(dim) % 3 == 0).astype(f32)
+    data = np.tile(row, (n, 1))
+    idx = make_index(L, data)
+    for m in ("hamming", "jaccard", "dice"):
+        ids, d = idx.search(row, 20, m)
+        assert list(ids) == list(range(20)) and np.all(d == 0.0)
+    q = row.copy()
+    q[:5] = 1.0 - q[:5]
+    ids, d = idx.search(q, 20, "hamming")
+    assert list(ids) == list(range(20)) and np.all(d == 5.0)
+    e_ids, e_d = oracle.canonical_topk(q, data, 20, HAM)
+    assert np.array_equal(ids, e_ids) and np.array_equal(d, e_d)
+
+
+# ------------------------------------------------------------------ boundary behaviour
+
+def test_boundary_errors_and_edges(L):
+    idx = L.FlatIndex(None, 8)
+    ids, d = idx.search(np.zeros(8, f32), 5, "ip")  # empty store -> empty result, not an error
+    assert len(ids) == 0 and len(d) == 0
+    data = np.random.default_rng(0).random((10, 8), dtype=f32)
+    idx.write(data)
+    ids, d = idx.search(data[3], 0, "ip")  # k == 0
+    assert len(ids) == 0
+    ids, d = idx.search(data[3], 50, "l2")  # k > N clamps
+    assert len(ids) == 10 and ids[0] == 3
+    with pytest.raises(ValueError, match="Unknown metric"):
+        idx.search(data[0], 5, "nope")
+    with pytest.raises(ValueError, match="dimension mismatch"):
+        idx.search(np.zeros(7, f32), 5, "ip")
+    with pytest.raises(ValueError):
+        idx.write(np.zeros((2, 9), f32))
+    res = idx.batch_search(data[:4], 3, "cosine")
+    assert len(res) == 4 and all(len(r[0]) == 3 for r in res) and [int(r[0][0]) for r in res] == [0, 1, 2, 3]
+
+
+def test_collection_surface_like_flat_search_bench(L, oracle, tmp_path):
+    """The `_core` call sequence of benchmarks/flat_search_bench.py:43-96 at a reduced row count."""
+    rows, dim, k = 20000, 128, 10
+    rng = np.random.default_rng(42)
+    query = rng.random(dim, dtype=f32)
+    mgr = L.DatabaseManager(str(tmp_path))
+    mgr.create_database("bench_db")
+    mgr.require_collection("bench_db", "bench_vectors", dim)
+    coll = mgr.get_collection("bench_db", "bench_vectors", dim)
+    allv = []
+    for start in range(0, rows, 5000):
+        v = rng.random((5000, dim), dtype=f32)
+        if start == 0:
+            v[0] = query
+        coll.add_items(v, list(range(start, start + 5000)), None)
+        allv.append(v)
+    coll.commit()
+    coll.build_index("FLAT-IP", None)
+    assert coll.shape() == (rows, dim)
+    res = coll.search(query, k, None, 10)
+    assert len(res) == k and res.ids()[0] == 0 and res.ids().dtype == np.int64 and res.index_mode() == "FLAT-IP"
+    data = np.vstack(allv)
+    e_ids, e_d = oracle.canonical_topk(query, data, k, IP)
+    assert np.array_equal(res.ids(), e_ids.astype(np.int64)) and np.array_equal(res.distances(), e_d)
+    coll.build_index("FLAT-HAMMING-BINARY", None)
+    res = coll.search((query > 0.5).astype(f32), 5)
+    e_ids, e_d = oracle.canonical_topk((query > 0.5).astype(f32), data, 5, HAM)
+    assert np.array_equal(res.ids(), e_ids.astype(np.int64)) and np.array_equal(res.distances(), e_d)
