@@ -100,7 +100,7 @@ __device__ __forceinline__ float exact_score(int metric, int ip_form, const floa
         na = __fadd_rn(na, __fmul_rn(a, a));
         nb = __fadd_rn(nb, __fmul_rn(b, b));
     }
-    float denom = __fsqrt_rn(__fmul_rn(na, nb));
+    float denom = __builtin_sqrtf(__fmul_rn(na, nb));  // IEEE sqrt (-fhip-fp32-correctly-rounded-divide-sqrt); __fsqrt_rn is the native approximation
     if (denom < 1e-30f) return 1.0f;
     return __fsub_rn(1.0f, __fdiv_rn(dot, denom));
 }
