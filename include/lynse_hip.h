@@ -126,7 +126,9 @@ int lynse_hip_flat_search_f32(lynse_hip_flat *h, const float *queries, uint64_t 
                               int metric, uint64_t *out_rows, float *out_dists,
                               uint32_t *out_counts);
 /* Same with every buffer already resident in this handle's device memory; enqueued on `stream`
- * (a hipStream_t, NULL = the handle's stream) and synchronised before returning. */
+ * (a hipStream_t, NULL = the handle's own non-blocking stream) and synchronised before returning.
+ * Device inputs of every *_device entry must be COMPLETE when the call is made (synchronise the
+ * stream that produced them): the handle's stream does not order against other streams. */
 int lynse_hip_flat_search_f32_device(lynse_hip_flat *h, const float *d_queries, uint64_t nq,
                                      uint32_t k, int metric, uint64_t *d_out_rows,
                                      float *d_out_dists, uint32_t *d_out_counts, void *stream);

@@ -67,6 +67,14 @@ def _ptr(a: np.ndarray):
     return a.ctypes.data_as(C.c_void_p)
 
 
+def _sync_producer(tensor) -> None:
+    """The library works on its own HIP stream: device inputs must be complete before the call.
+    Synchronise the torch stream that (may have) produced `tensor`."""
+    import torch
+
+    torch.cuda.current_stream(tensor.device).synchronize()
+
+
 class FlatIndex:
     """`lynse._core.FlatIndex` (src/python/mod.rs:1942-2047) on one MI355X.
 
@@ -117,6 +125,7 @@ class FlatIndex:
         """Append rows already resident in HBM (a contiguous float32 torch tensor on this device)."""
         if tensor.dim() != 2 or tensor.shape[1] != self._dim or not tensor.is_contiguous():
             raise ValueError("tensor must be a contiguous (n, dim) float32 device tensor")
+        _sync_producer(tensor)
         check(lib.lynse_hip_flat_append_f32_device(self._h, C.c_void_p(tensor.data_ptr()), tensor.shape[0]))
 
     def write_packed(self, words) -> None:
@@ -127,6 +136,7 @@ class FlatIndex:
         check(lib.lynse_hip_flat_append_packed_u64(self._h, _ptr(w), w.shape[0]))
 
     def write_packed_device(self, tensor) -> None:
+        _sync_producer(tensor)
         check(lib.lynse_hip_flat_append_packed_u64_device(self._h, C.c_void_p(tensor.data_ptr()), tensor.shape[0]))
 
     def finalize(self) -> None:
@@ -196,6 +206,7 @@ class FlatIndex:
         """All buffers are torch tensors resident on this device (bench path: no PCIe in the timed region)."""
         m = metric if isinstance(metric, int) else metric_from_str(metric)
         nq = d_queries.shape[0]
+        _sync_producer(d_queries)
         check(lib.lynse_hip_flat_search_f32_device(
             self._h, C.c_void_p(d_queries.data_ptr()), nq, int(k), m, C.c_void_p(d_rows.data_ptr()),
             C.c_void_p(d_dists.data_ptr()), C.c_void_p(d_counts.data_ptr()),
@@ -204,6 +215,7 @@ class FlatIndex:
     def search_packed_device(self, d_qwords, k: int, metric, d_rows, d_dists, d_counts, stream=None):
         m = metric if isinstance(metric, int) else metric_from_str(metric)
         nq = d_qwords.shape[0]
+        _sync_producer(d_qwords)
         check(lib.lynse_hip_flat_search_packed_u64_device(
             self._h, C.c_void_p(d_qwords.data_ptr()), nq, int(k), m, C.c_void_p(d_rows.data_ptr()),
             C.c_void_p(d_dists.data_ptr()), C.c_void_p(d_counts.data_ptr()),

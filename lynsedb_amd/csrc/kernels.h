@@ -140,6 +140,23 @@ __global__ void __launch_bounds__(256) k_row_stats(const float* __restrict__ V, 
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_copy_rows: dst[r][0..width) = src[r][0..width) with independent pitches (elements); columns
+// [width, dst_pitch) of dst are zero-filled when zero_pad is set.  Used for the padded row layout
+// (ld = round_up(dim,4)) — hipMemcpy2D proved unreliable on this stack for multi-GB buffers.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_copy_rows(float* __restrict__ dst, uint32_t dst_pitch,
+                                                   const float* __restrict__ src, uint32_t src_pitch,
+                                                   uint32_t width, uint64_t nrows, int zero_pad) {
+    const uint32_t cols = zero_pad ? dst_pitch : width;
+    const uint64_t total = nrows * cols;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t r = i / cols;
+        const uint32_t c = (uint32_t)(i % cols);
+        dst[r * dst_pitch + c] = c < width ? src[r * src_pitch + c] : 0.0f;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // k_pack_bits: bit i of word i/64 = (value > 0.5), LSB first — pack_binary_row_f32
 // (flat_mmap.rs:1284-1290, simd.rs:750-757).  One wave per row; wave64 __ballot IS one u64 word.
 // ------------------------------------------------------------------------------------------------
@@ -654,6 +671,7 @@ struct FinalArgs {
     const uint64_t* cand;
     const uint32_t* count;
     uint32_t k, cap;
+    uint32_t out_k;  // row stride of the output arrays (caller's k >= effective k)
     int metric, ip_form, exact;
     const float* Qf;
     const float* V;
@@ -682,13 +700,13 @@ __global__ void __launch_bounds__(NT) k_final(FinalArgs a) {
         rescore_keys<NT>(keys, n, a.metric, a.ip_form, a.Qf + (size_t)q * a.D, a.V, a.ld, a.D, asc, tid);
     bitonic_sort_lds<NT>(keys, np2, tid);
     const uint32_t cnt = n < a.k ? n : a.k;
-    for (uint32_t i = tid; i < a.k; i += NT) {
+    for (uint32_t i = tid; i < a.out_k; i += NT) {
         if (i < cnt) {
-            a.out_rows[(size_t)q * a.k + i] = (uint64_t)key_row(keys[i]) * a.row_stride + a.row_offset;
-            a.out_dists[(size_t)q * a.k + i] = key_score(keys[i], asc);
+            a.out_rows[(size_t)q * a.out_k + i] = (uint64_t)key_row(keys[i]) * a.row_stride + a.row_offset;
+            a.out_dists[(size_t)q * a.out_k + i] = key_score(keys[i], asc);
         } else {
-            a.out_rows[(size_t)q * a.k + i] = ~0ull;
-            a.out_dists[(size_t)q * a.k + i] = asc ? LY_INF : -LY_INF;
+            a.out_rows[(size_t)q * a.out_k + i] = ~0ull;
+            a.out_dists[(size_t)q * a.out_k + i] = asc ? LY_INF : -LY_INF;
         }
     }
     if (tid == 0) {

@@ -285,6 +285,17 @@ extern "C" int lynse_hip_flat_reserve(lynse_hip_flat* h, uint64_t rows) {
     return LYNSE_OK;
 }
 
+static int copy_rows_kernel(lynse_hip_flat* h, float* dst, uint32_t dp, const float* src, uint32_t sp, uint32_t width,
+                            uint64_t n, int zero_pad) {
+    const uint64_t total = n * (zero_pad ? dp : width);
+    const uint32_t blocks = (uint32_t)std::min<uint64_t>((total + 255) / 256, (uint64_t)h->num_cu * 32);
+    hipLaunchKernelGGL(k_copy_rows, dim3(std::max<uint32_t>(blocks, 1)), dim3(256), 0, h->stream, dst, dp, src, sp, width, n, zero_pad);
+    LY_HIP(hipGetLastError());
+    return LYNSE_OK;
+}
+
+constexpr uint64_t STAGE_BYTES = 64ull << 20;  // dense staging buffer for padded-layout host transfers
+
 static int append_f32_impl(lynse_hip_flat* h, const float* src, uint64_t n, hipMemcpyKind kind) {
     if (!h) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "handle is NULL");
     if (n == 0) return LYNSE_OK;
@@ -297,9 +308,21 @@ static int append_f32_impl(lynse_hip_flat* h, const float* src, uint64_t n, hipM
     float* dst = h->rows + (size_t)h->n * h->ld;
     if (h->ld == h->dim) {
         LY_HIP(hipMemcpyAsync(dst, src, (size_t)n * h->dim * sizeof(float), kind, h->stream));
+    } else if (kind == hipMemcpyDeviceToDevice) {
+        LY_TRY(copy_rows_kernel(h, dst, h->ld, src, h->dim, h->dim, n, 1));
     } else {
-        LY_HIP(hipMemsetAsync(dst, 0, (size_t)n * h->ld * sizeof(float), h->stream));
-        LY_HIP(hipMemcpy2DAsync(dst, (size_t)h->ld * 4, src, (size_t)h->dim * 4, (size_t)h->dim * 4, (size_t)n, kind, h->stream));
+        const uint64_t chunk = std::max<uint64_t>(1, STAGE_BYTES / ((uint64_t)h->dim * 4));
+        float* stage = nullptr;
+        LY_HIP(hipMalloc(&stage, (size_t)std::min<uint64_t>(chunk, n) * h->dim * 4));
+        for (uint64_t r = 0; r < n; r += chunk) {
+            const uint64_t nr = std::min<uint64_t>(chunk, n - r);
+            hipError_t e = hipMemcpyAsync(stage, src + r * h->dim, (size_t)nr * h->dim * 4, kind, h->stream);
+            int rc = e == hipSuccess ? copy_rows_kernel(h, dst + r * h->ld, h->ld, stage, h->dim, h->dim, nr, 1)
+                                     : set_error(LYNSE_ERR_DEVICE, hipGetErrorString(e));
+            if (rc == LYNSE_OK && hipStreamSynchronize(h->stream) != hipSuccess) rc = set_error(LYNSE_ERR_DEVICE, "stream sync failed");
+            if (rc != LYNSE_OK) { (void)hipFree(stage); return rc; }
+        }
+        (void)hipFree(stage);
     }
     LY_HIP(hipStreamSynchronize(h->stream));
     h->n += n;
@@ -439,9 +462,23 @@ extern "C" int lynse_hip_flat_read_rows(const lynse_hip_flat* hc, uint64_t first
     if (h->packed_only) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "store holds packed rows only");
     if (first + n > h->n) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "row range out of bounds");
     if (n == 0) return LYNSE_OK;
-    LY_HIP(hipMemcpy2DAsync(out, (size_t)h->dim * 4, h->rows + (size_t)first * h->ld, (size_t)h->ld * 4,
-                            (size_t)h->dim * 4, (size_t)n, hipMemcpyDeviceToHost, h->stream));
-    LY_HIP(hipStreamSynchronize(h->stream));
+    if (h->ld == h->dim) {
+        LY_HIP(hipMemcpyAsync(out, h->rows + (size_t)first * h->ld, (size_t)n * h->dim * 4, hipMemcpyDeviceToHost, h->stream));
+        LY_HIP(hipStreamSynchronize(h->stream));
+        return LYNSE_OK;
+    }
+    const uint64_t chunk = std::max<uint64_t>(1, STAGE_BYTES / ((uint64_t)h->dim * 4));
+    float* stage = nullptr;
+    LY_HIP(hipMalloc(&stage, (size_t)std::min<uint64_t>(chunk, n) * h->dim * 4));
+    for (uint64_t r = 0; r < n; r += chunk) {
+        const uint64_t nr = std::min<uint64_t>(chunk, n - r);
+        int rc = copy_rows_kernel(h, stage, h->dim, h->rows + (size_t)(first + r) * h->ld, h->ld, h->dim, nr, 0);
+        if (rc == LYNSE_OK && hipMemcpyAsync(out + r * h->dim, stage, (size_t)nr * h->dim * 4, hipMemcpyDeviceToHost, h->stream) != hipSuccess)
+            rc = set_error(LYNSE_ERR_DEVICE, "device-to-host copy failed");
+        if (rc == LYNSE_OK && hipStreamSynchronize(h->stream) != hipSuccess) rc = set_error(LYNSE_ERR_DEVICE, "stream sync failed");
+        if (rc != LYNSE_OK) { (void)hipFree(stage); return rc; }
+    }
+    (void)hipFree(stage);
     return LYNSE_OK;
 }
 
@@ -453,8 +490,10 @@ extern "C" int lynse_hip_flat_copy_rows_device(const lynse_hip_flat* hc, uint64_
     if (h->packed_only) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "store holds packed rows only");
     if (first + n > h->n) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "row range out of bounds");
     if (n == 0) return LYNSE_OK;
-    LY_HIP(hipMemcpy2DAsync(d_out, (size_t)h->dim * 4, h->rows + (size_t)first * h->ld, (size_t)h->ld * 4,
-                            (size_t)h->dim * 4, (size_t)n, hipMemcpyDeviceToDevice, h->stream));
+    if (h->ld == h->dim)
+        LY_HIP(hipMemcpyAsync(d_out, h->rows + (size_t)first * h->ld, (size_t)n * h->dim * 4, hipMemcpyDeviceToDevice, h->stream));
+    else
+        LY_TRY(copy_rows_kernel(h, d_out, h->dim, h->rows + (size_t)first * h->ld, h->ld, h->dim, n, 0));
     LY_HIP(hipStreamSynchronize(h->stream));
     return LYNSE_OK;
 }
@@ -507,7 +546,7 @@ static int set_max_lds(K kernel, size_t bytes) {
     return LYNSE_OK;
 }
 
-static int ensure_workspace(lynse_hip_flat* h, uint32_t k) {
+static int ensure_workspace(lynse_hip_flat* h, uint32_t k /* caller's k = output stride */) {
     Workspace& w = h->ws;
     const uint32_t nslab = (h->dim + SCAN_BK - 1) / SCAN_BK;
     if (w.cand && w.cap == h->cap && w.D == h->dim && w.kcap >= k) return LYNSE_OK;
@@ -615,7 +654,7 @@ static int get_event(lynse_hip_flat* h, size_t idx, hipEvent_t* out) {
 
 // One chunk (<= QCHUNK queries) whose inputs are already in the workspace (Qf for float metrics,
 // QW for binary).  Results land in ws.out_*.  `safe` selects the exhaustive plan.
-static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, int metric, bool safe, hipStream_t st,
+static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k, int metric, bool safe, hipStream_t st,
                      size_t* ev_used, std::vector<std::pair<size_t, uint64_t>>* scan_events) {
     Workspace& w = h->ws;
     const bool binary = metric >= M_HAMMING;
@@ -696,7 +735,7 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, int metric, boo
         LY_HIP(hipGetLastError());
     }
     FinalArgs fa{};
-    fa.cand = w.cand; fa.count = w.count; fa.k = k; fa.cap = w.cap; fa.metric = metric; fa.ip_form = ip_form;
+    fa.cand = w.cand; fa.count = w.count; fa.k = k; fa.out_k = out_k; fa.cap = w.cap; fa.metric = metric; fa.ip_form = ip_form;
     fa.exact = binary ? 1 : 0; fa.Qf = w.Qf; fa.V = h->rows; fa.ld = h->ld; fa.D = h->dim;
     fa.row_stride = h->row_stride; fa.row_offset = h->row_offset;
     fa.out_rows = w.out_rows; fa.out_dists = w.out_dists; fa.out_counts = w.out_counts;
@@ -743,7 +782,7 @@ static int search_impl(lynse_hip_flat* h, const void* q_src, bool packed_queries
 
     if (binary) LY_TRY(ensure_packed_locked(h));
     else LY_TRY(finalize_locked(h));
-    LY_TRY(ensure_workspace(h, kk));
+    LY_TRY(ensure_workspace(h, k));
     Workspace& w = h->ws;
 
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
@@ -772,7 +811,7 @@ static int search_impl(lynse_hip_flat* h, const void* q_src, bool packed_queries
         }
         bool safe = false;
         for (int attempt = 0; attempt < 2; ++attempt) {
-            LY_TRY(run_chunk(h, nqc, kk, metric, safe, st, &ev_used, &scan_events));
+            LY_TRY(run_chunk(h, nqc, kk, k, metric, safe, st, &ev_used, &scan_events));
             std::vector<uint32_t> ovf(nqc);
             LY_HIP(hipMemcpyAsync(ovf.data(), w.overflow, nqc * 4, hipMemcpyDeviceToHost, st));
             LY_HIP(hipStreamSynchronize(st));
@@ -784,13 +823,8 @@ static int search_impl(lynse_hip_flat* h, const void* q_src, bool packed_queries
             safe = true;  // rerun the chunk on the exhaustive plan
         }
         // outputs: workspace rows are [nqc][kk]; caller layout is [nq][k]
-        if (kk == k) {
-            LY_HIP(hipMemcpyAsync(out_rows + q0 * k, w.out_rows, (size_t)nqc * k * 8, out_kind, st));
-            LY_HIP(hipMemcpyAsync(out_dists + q0 * k, w.out_dists, (size_t)nqc * k * 4, out_kind, st));
-        } else {
-            LY_HIP(hipMemcpy2DAsync(out_rows + q0 * k, (size_t)k * 8, w.out_rows, (size_t)kk * 8, (size_t)kk * 8, nqc, out_kind, st));
-            LY_HIP(hipMemcpy2DAsync(out_dists + q0 * k, (size_t)k * 4, w.out_dists, (size_t)kk * 4, (size_t)kk * 4, nqc, out_kind, st));
-        }
+        LY_HIP(hipMemcpyAsync(out_rows + q0 * k, w.out_rows, (size_t)nqc * k * 8, out_kind, st));
+        LY_HIP(hipMemcpyAsync(out_dists + q0 * k, w.out_dists, (size_t)nqc * k * 4, out_kind, st));
         LY_HIP(hipMemcpyAsync(out_counts + q0, w.out_counts, nqc * 4, out_kind, st));
         LY_HIP(hipStreamSynchronize(st));
     }

@@ -83,7 +83,10 @@ class ShardedFlat:
     # -- search ----------------------------------------------------------------------------------
     def search_device(self, d_queries, k: int, metric: int, out: ShardOutputs) -> None:
         """Whole-collection search; results (identical on every rank) land in out.rows/dists/counts."""
+        import torch
+
         nq = d_queries.shape[0]
+        torch.cuda.current_stream().synchronize()  # inputs must be complete: the library uses its own stream
         if self.world == 1:  # single shard: results are already globally merged and ordered
             check(lib.lynse_hip_flat_search_f32_device(
                 self.index.handle, C.c_void_p(d_queries.data_ptr()), nq, k, metric, C.c_void_p(out.rows.data_ptr()),
@@ -93,8 +96,6 @@ class ShardedFlat:
         check(lib.lynse_hip_flat_search_f32_device(self.index.handle, C.c_void_p(d_queries.data_ptr()), nq, k,
                                                    metric, C.c_void_p(pr), C.c_void_p(pd), C.c_void_p(pc), None))
         self.dist.all_gather_into_tensor(out.gathered, out.local)
-        import torch
-
         stream = torch.cuda.current_stream().cuda_stream
         check(lib.lynse_hip_merge_topk_device(C.c_void_p(out.gathered.data_ptr()), out.block_bytes, out.rows_off,
                                               out.dists_off, out.counts_off, self.world, nq, k, metric,
