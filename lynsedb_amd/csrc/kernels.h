@@ -117,7 +117,8 @@ __global__ void __launch_bounds__(256) k_row_stats(const float* __restrict__ V, 
     const int lane = threadIdx.x & 63;
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
-    float amax = 0.0f;
+    float amax = 0.0f, n2max = 0.0f, n2min = LY_INF;
+    uint32_t ndegen = 0;
     for (uint32_t row = row0 + wave; row < row1; row += nwaves) {
         const float* v = V + (size_t)row * ld;
         float s = 0.0f;
@@ -130,13 +131,18 @@ __global__ void __launch_bounds__(256) k_row_stats(const float* __restrict__ V, 
         if (lane == 0) {
             vn2[row] = s;
             vrinv[row] = s > 0.0f ? 1.0f / sqrtf(s) : 0.0f;
-            atomicMax(&stats[1], __float_as_uint(s));
-            if (s > 0.0f) atomicMin(&stats[2], __float_as_uint(s));
-            if (s > 0.0f && s < 1e-30f) atomicAdd(&stats[3], 1u);
         }
+        n2max = fmaxf(n2max, s);
+        if (s > 0.0f) n2min = fminf(n2min, s);
+        if (s > 0.0f && s < 1e-30f) ndegen += 1;
     }
     for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
-    if (lane == 0) atomicMax(&stats[0], __float_as_uint(amax));
+    if (lane == 0) {  // one set of atomics per wave (per-row atomics on one address serialise)
+        atomicMax(&stats[0], __float_as_uint(amax));
+        atomicMax(&stats[1], __float_as_uint(n2max));
+        if (n2min < LY_INF) atomicMin(&stats[2], __float_as_uint(n2min));
+        if (ndegen) atomicAdd(&stats[3], ndegen);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -187,6 +193,7 @@ __global__ void __launch_bounds__(256) k_pack_bits(const float* __restrict__ V, 
 struct PrepArgs {
     const float* Q;      // nq x D f32
     uint32_t D, nq, qpad, nslab;
+    int layout;          // 0: [slab64][q][72] (k_scan_f16)   1: [slab32][q][4 slots ^ ((q>>2)&3)][8] (k_scan_glds)
     int metric;
     float sv;            // row scale (power of two)
     float vmax, vmin;    // max / min-nonzero row norm
@@ -260,11 +267,22 @@ __global__ void __launch_bounds__(256) k_prep_queries(PrepArgs a) {
     }
     __syncthreads();
     const float sq = s_sq;
-    const uint32_t total = a.nslab * SCAN_BK;
-    for (uint32_t i = tid; i < total; i += 256) {
-        const uint32_t s = i / SCAN_BK, k = i % SCAN_BK;
-        const float x = i < a.D ? qv[i] * sq : 0.0f;
-        a.Q16[((size_t)s * a.qpad + q) * SCAN_LDK + k] = (_Float16)x;
+    if (a.layout == 0) {
+        const uint32_t total = a.nslab * SCAN_BK;
+        for (uint32_t i = tid; i < total; i += 256) {
+            const uint32_t s = i / SCAN_BK, k = i % SCAN_BK;
+            const float x = i < a.D ? qv[i] * sq : 0.0f;
+            a.Q16[((size_t)s * a.qpad + q) * SCAN_LDK + k] = (_Float16)x;
+        }
+    } else {
+        const uint32_t total = a.nslab * 32;
+        for (uint32_t i = tid; i < total; i += 256) {
+            const uint32_t s = i / 32, k = i % 32;
+            const uint32_t l = k >> 3, e = k & 7;          // logical 16-B slot, element
+            const uint32_t p = l ^ ((q >> 2) & 3);          // physical slot (bank-conflict swizzle)
+            const float x = i < a.D ? qv[i] * sq : 0.0f;
+            a.Q16[(((size_t)s * a.qpad + q) * 4 + p) * 8 + e] = (_Float16)x;
+        }
     }
 }
 
@@ -297,16 +315,18 @@ struct ScanArgs {
     uint32_t* count;
     uint32_t cap;
     int emit_all;
+    int debug_flags;  // timing experiments only: 1 = linear (blocked-layout-like) row addressing, 2 = no emission
 };
 
-template <int WQ, int WR, int TQ, int TR, int METRIC>
-__global__ void __launch_bounds__(WQ * WR * 64, (WQ * WR * 64 == 512) ? 2 : 2) k_scan_f16(ScanArgs a) {
+template <int WQ, int WR, int TQ, int TR, int METRIC, int PD>
+__global__ void __launch_bounds__(WQ * WR * 64, 2) k_scan_f16(ScanArgs a) {
     constexpr int NT = WQ * WR * 64;
     constexpr int BQ = WQ * TQ * 32;
     constexpr int BR = WR * TR * 32;
     static_assert(BR == SCAN_BR, "tile rows");
+    static_assert(PD == 1 || PD == 2, "prefetch depth");
     constexpr int ROWS_PER_PASS = NT / 16;
-    constexpr int PV = BR / ROWS_PER_PASS;           // float4 loads per thread per slab
+    constexpr int PV = BR / ROWS_PER_PASS;             // float4 loads per thread per slab
     constexpr int QCHUNKS = BQ * (SCAN_LDK * 2 / 16);  // 16-B chunks of one Q slab image
     constexpr int PQ = (QCHUNKS + NT - 1) / NT;
     constexpr int VBUF = BR * SCAN_LDK;  // halves per V buffer
@@ -321,23 +341,29 @@ __global__ void __launch_bounds__(WQ * WR * 64, (WQ * WR * 64 == 512) ? 2 : 2) k
     const int wq = wave % WQ, wr = wave / WQ;
     const int vrow = tid >> 4, vk = (tid & 15) * 4;
 
-    uint32_t tile = blockIdx.x;
-    if (tile >= a.ntiles) return;
+    if (blockIdx.x >= a.ntiles) return;
 
-    f32x4 vreg[PV];
+    // Register staging: vA / vB hold the f32 row pieces of the next one (PD=1) or two (PD=2) K slabs
+    // while they are in flight from HBM; qreg holds the next f16 query slab (L2-resident).
+    f32x4 vA[PV], vB[PV];
     u32x4 qreg[PQ];
 
-    auto load_regs = [&](uint32_t t, uint32_t s) {
+    // Branch-free loads (a divergent branch around a load makes hipcc drain vmcnt(0) and kills the
+    // prefetch pipeline): rows past the stage end are clamped to the last row (their scores are
+    // masked in the epilogue), columns past ld are clamped here and zeroed in store_v.
+    const uint32_t last_row = a.row1 - 1;
+    auto load_v = [&](f32x4(&v)[PV], uint32_t t, uint32_t s) {
         const uint32_t rbase = a.row0 + t * BR;
-        const uint32_t k = s * SCAN_BK + vk;
+        uint32_t k = s * SCAN_BK + vk;
+        k = k < a.ld ? k : a.ld - 4;
 #pragma unroll
         for (int p = 0; p < PV; ++p) {
-            const uint32_t row = rbase + p * ROWS_PER_PASS + vrow;
-            if (row < a.row1 && k < a.ld)
-                vreg[p] = *reinterpret_cast<const f32x4*>(a.V + (size_t)row * a.ld + k);
-            else
-                vreg[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+            uint32_t row = rbase + p * ROWS_PER_PASS + vrow;
+            row = row < last_row ? row : last_row;
+            v[p] = *reinterpret_cast<const f32x4*>(a.V + (size_t)row * a.ld + k);
         }
+    };
+    auto load_q = [&](uint32_t s) {
         const u32x4* qsrc = reinterpret_cast<const u32x4*>(a.Q16 + (size_t)s * a.qpad * SCAN_LDK);
 #pragma unroll
         for (int j = 0; j < PQ; ++j) {
@@ -345,17 +371,21 @@ __global__ void __launch_bounds__(WQ * WR * 64, (WQ * WR * 64 == 512) ? 2 : 2) k
             qreg[j] = qsrc[c < QCHUNKS ? c : QCHUNKS - 1];  // unconditional: keeps qreg in VGPRs
         }
     };
-    auto store_lds = [&](int buf) {
+    auto store_v = [&](const f32x4(&v)[PV], int buf, uint32_t s) {
         _Float16* vb = Vl + buf * VBUF;
+        const float scale = (s * SCAN_BK + vk < a.ld) ? a.sv : 0.0f;  // zero the K padding of the last slab
+        const bool kin = s * SCAN_BK + vk < a.ld;
 #pragma unroll
         for (int p = 0; p < PV; ++p) {
             half4 h;
-            h[0] = (_Float16)(vreg[p][0] * a.sv);
-            h[1] = (_Float16)(vreg[p][1] * a.sv);
-            h[2] = (_Float16)(vreg[p][2] * a.sv);
-            h[3] = (_Float16)(vreg[p][3] * a.sv);
+            h[0] = kin ? (_Float16)(v[p][0] * scale) : (_Float16)0.0f;
+            h[1] = kin ? (_Float16)(v[p][1] * scale) : (_Float16)0.0f;
+            h[2] = kin ? (_Float16)(v[p][2] * scale) : (_Float16)0.0f;
+            h[3] = kin ? (_Float16)(v[p][3] * scale) : (_Float16)0.0f;
             *reinterpret_cast<half4*>(vb + (p * ROWS_PER_PASS + vrow) * SCAN_LDK + vk) = h;
         }
+    };
+    auto store_q = [&](int buf) {
         u32x4* qb = reinterpret_cast<u32x4*>(Ql + buf * QBUF);
 #pragma unroll
         for (int j = 0; j < PQ; ++j) {
@@ -372,45 +402,32 @@ __global__ void __launch_bounds__(WQ * WR * 64, (WQ * WR * 64 == 512) ? 2 : 2) k
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-    load_regs(tile, 0);
-    store_lds(0);
-    __syncthreads();
-    int buf = 0;
-
     const int frag_k = (lane >> 5) * 8;
     const int a_row = wr * (TR * 32) + (lane & 31);
     const int b_row = wq * (TQ * 32) + (lane & 31);
 
-    while (true) {
-        for (uint32_t s = 0; s < a.nslab; ++s) {
-            uint32_t nt = tile, ns = s + 1;
-            if (ns == a.nslab) { ns = 0; nt = tile + gridDim.x; }
-            const bool has_next = nt < a.ntiles;
-            if (has_next) load_regs(nt, ns);
-
-            const _Float16* vb = Vl + buf * VBUF;
-            const _Float16* qb = Ql + buf * QBUF;
+    auto compute = [&](int buf) {
+        const _Float16* vb = Vl + buf * VBUF;
+        const _Float16* qb = Ql + buf * QBUF;
 #pragma unroll
-            for (int kk = 0; kk < SCAN_BK / 16; ++kk) {
-                half8 af[TR], bf[TQ];
+        for (int kk = 0; kk < SCAN_BK / 16; ++kk) {
+            half8 af[TR], bf[TQ];
 #pragma unroll
-                for (int i = 0; i < TR; ++i)
-                    af[i] = *reinterpret_cast<const half8*>(vb + (a_row + i * 32) * SCAN_LDK + kk * 16 + frag_k);
+            for (int i = 0; i < TR; ++i)
+                af[i] = *reinterpret_cast<const half8*>(vb + (a_row + i * 32) * SCAN_LDK + kk * 16 + frag_k);
+#pragma unroll
+            for (int j = 0; j < TQ; ++j)
+                bf[j] = *reinterpret_cast<const half8*>(qb + (b_row + j * 32) * SCAN_LDK + kk * 16 + frag_k);
+#pragma unroll
+            for (int i = 0; i < TR; ++i)
 #pragma unroll
                 for (int j = 0; j < TQ; ++j)
-                    bf[j] = *reinterpret_cast<const half8*>(qb + (b_row + j * 32) * SCAN_LDK + kk * 16 + frag_k);
-#pragma unroll
-                for (int i = 0; i < TR; ++i)
-#pragma unroll
-                    for (int j = 0; j < TQ; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
-            }
-            if (has_next) store_lds(buf ^ 1);
-            __syncthreads();
-            buf ^= 1;
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
         }
+    };
 
-        // ---- epilogue for this tile: C[row m][query n], lane owns column n = lane&31 of each block
+    // epilogue for one finished tile: C[row m][query n]; a lane owns column n = lane&31 of each block
+    auto epilogue = [&](uint32_t tile) {
         const uint32_t rbase = a.row0 + tile * BR;
 #pragma unroll
         for (int j = 0; j < TQ; ++j) {
@@ -439,9 +456,250 @@ __global__ void __launch_bounds__(WQ * WR * 64, (WQ * WR * 64 == 512) ? 2 : 2) k
                 }
             }
         }
-        tile += gridDim.x;
-        if (tile >= a.ntiles) break;
+    };
+
+    // Flat sequence of (tile, slab) steps of this persistent block; the pipeline runs across tile
+    // boundaries.  cur = step being computed, n1 / n2 = the next two steps.
+    uint32_t cur_t = blockIdx.x, cur_s = 0;
+    uint32_t n1_t = cur_t, n1_s = 1;
+    if (n1_s == a.nslab) { n1_s = 0; n1_t += gridDim.x; }
+    uint32_t n2_t = n1_t, n2_s = n1_s + 1;
+    if (n2_s == a.nslab) { n2_s = 0; n2_t += gridDim.x; }
+
+    load_v(vA, cur_t, cur_s);
+    load_q(cur_s);
+    store_v(vA, 0, cur_s);
+    store_q(0);
+    if (PD == 2 && n1_t < a.ntiles) load_v(vB, n1_t, n1_s);
+    __syncthreads();
+    int buf = 0;
+
+    // X: registers whose slab goes to LDS at the end of this iteration; Y: registers free to receive
+    // the slab two steps ahead (PD=2).  With PD=1, X is loaded and stored within the iteration.
+    auto iteration = [&](f32x4(&X)[PV], f32x4(&Y)[PV]) {
+        const bool v1 = n1_t < a.ntiles, v2 = n2_t < a.ntiles;
+        if (v1) load_q(n1_s);
+        if (PD == 2) {
+            if (v2) load_v(Y, n2_t, n2_s);
+        } else {
+            if (v1) load_v(X, n1_t, n1_s);
+        }
+        compute(buf);
+        if (v1) {
+            store_v(X, buf ^ 1, n1_s);
+            store_q(buf ^ 1);
+        }
+        __syncthreads();
+        buf ^= 1;
+        if (cur_s == a.nslab - 1) epilogue(cur_t);
+        cur_t = n1_t; cur_s = n1_s;
+        n1_t = n2_t; n1_s = n2_s;
+        n2_s += 1;
+        if (n2_s == a.nslab) { n2_s = 0; n2_t += gridDim.x; }
+    };
+    while (true) {
+        if (PD == 2) iteration(vB, vA); else iteration(vA, vA);
+        if (cur_t >= a.ntiles) break;
+        iteration(vA, vB);
+        if (cur_t >= a.ntiles) break;
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_scan_glds — the hot kernel, LDS-DMA edition (default).
+//
+// Same tile / MFMA / epilogue structure as k_scan_f16, but every operand byte travels HBM/L2 -> LDS
+// with `global_load_lds_dwordx4` (no VGPR staging), through a 4-stage LDS ring of K=32 slabs, so up
+// to three slabs (48 KB of rows + 48 KB of query image per CU) are in flight while one is computed:
+//   per slab and wave: VPW + QPW LDS-DMA instructions (1 KiB each) -> s_waitcnt vmcnt((NS-2)*OPS)
+//   -> ONE raw s_barrier -> issue slab g+3 into the stage that was computed last -> MFMA on slab g.
+// Rows sit in LDS as f32 (the DMA cannot convert): the A fragment is two ds_read_b128 + cvt to f16 in
+// registers.  Bank conflicts are removed by an XOR swizzle of the 16-B slot index applied on the
+// per-lane SOURCE address (the DMA destination is lane-linear): rows use slot ^ ((row>>1)&7), the
+// query image is stored pre-swizzled in global memory (slot ^ ((q>>2)&3)) by k_prep_queries.
+// Out-of-range rows / K columns are clamped to valid addresses: clamped rows are masked in the
+// epilogue, clamped columns meet zeros in the query image.
+// ------------------------------------------------------------------------------------------------
+constexpr int GL_BK = 32;   // K elements per slab
+constexpr int GL_NS = 4;    // ring stages
+
+template <int AUX>
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_dst, 16, 0, AUX);
+}
+
+// NS ring stages; NT_HINT = 2 marks the row stream non-temporal (each row byte is read once per
+// batch by exactly one CU), the query image keeps the default policy (re-read by every CU from L2).
+template <int WQ, int WR, int TQ, int TR, int METRIC, bool SCALE, int NS, int NT_HINT>
+__global__ void __launch_bounds__(WQ * WR * 64, 2) k_scan_glds(ScanArgs a) {
+    constexpr int NW = WQ * WR;
+    constexpr int BQ = WQ * TQ * 32;
+    constexpr int BR = WR * TR * 32;
+    static_assert(NS >= 3, "ring depth");
+    constexpr int V_BYTES = BR * GL_BK * 4;   // 16 KiB of f32 rows per stage
+    constexpr int Q_BYTES = BQ * GL_BK * 2;   // f16 query slab
+    constexpr int STAGE = V_BYTES + Q_BYTES;
+    constexpr int V_INSTR = V_BYTES / 1024;
+    constexpr int Q_INSTR = Q_BYTES / 1024;
+    static_assert(V_INSTR % NW == 0, "row DMA split");
+    constexpr int VPW = V_INSTR / NW;
+    constexpr int QPW = (Q_INSTR + NW - 1) / NW;
+    constexpr int OPS = VPW + QPW;             // LDS-DMA instructions per wave per slab
+    constexpr bool ASC = METRIC != M_IP;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wq = wave % WQ, wr = wave / WQ;
+
+    if (blockIdx.x >= a.ntiles) return;
+    const uint32_t my_tiles = (a.ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x;
+    const uint32_t G = my_tiles * a.nslab;
+    const uint32_t last_row = a.row1 - 1;
+
+    // ---- per-lane DMA source geometry (constant for the whole kernel)
+    uint32_t v_row[VPW], v_col[VPW];
+#pragma unroll
+    for (int j = 0; j < VPW; ++j) {
+        const uint32_t r = (wave * VPW + j) * 8 + (lane >> 3);  // row inside the tile
+        const uint32_t p = lane & 7;                            // physical 16-B slot
+        v_row[j] = r;
+        v_col[j] = (p ^ ((r >> 1) & 7)) * 4;                    // logical slot -> f32 column
+    }
+    uint32_t q_off[QPW];
+#pragma unroll
+    for (int j = 0; j < QPW; ++j) q_off[j] = (((wave * QPW + j) % Q_INSTR) * 1024 + lane * 16);
+
+    auto issue = [&](uint32_t g) {
+        // clamp past-the-end steps to the last real one: keeps the per-wave DMA count uniform
+        const uint32_t gg = g < G ? g : G - 1;
+        const uint32_t ti = gg / a.nslab, s = gg - ti * a.nslab;
+        const uint32_t rbase = a.row0 + (blockIdx.x + ti * gridDim.x) * BR;
+        char* stage = smem + (g % NS) * STAGE;
+#pragma unroll
+        for (int j = 0; j < VPW; ++j) {
+            uint32_t row = rbase + v_row[j];
+            row = row < last_row ? row : last_row;
+            uint32_t col = s * GL_BK + v_col[j];
+            col = col < a.ld ? col : a.ld - 4;
+            const float* src = a.V + (size_t)row * a.ld + col;
+            if (a.debug_flags & 1)  // EXPERIMENT: what a tile-blocked HBM layout would read (wrong results)
+                src = a.V + ((size_t)(blockIdx.x + ti * gridDim.x) * a.nslab + s) * (BR * GL_BK) + (wave * VPW + j) * 256 + lane * 4;
+            glds16<NT_HINT>(src, stage + (wave * VPW + j) * 1024);
+        }
+        const char* qsrc = reinterpret_cast<const char*>(a.Q16) + (size_t)s * a.qpad * (GL_BK * 2);
+#pragma unroll
+        for (int j = 0; j < QPW; ++j)
+            glds16<0>(qsrc + q_off[j], stage + V_BYTES + ((wave * QPW + j) % Q_INSTR) * 1024);
+    };
+
+    f32x16 acc[TR][TQ];
+#pragma unroll
+    for (int i = 0; i < TR; ++i)
+#pragma unroll
+        for (int j = 0; j < TQ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    // fragment geometry
+    const int l32 = lane & 31, hi = lane >> 5;
+    const int a_swz = (l32 >> 1) & 7;   // (row>>1)&7 — tile-row offsets are multiples of 32
+    const int b_swz = (l32 >> 2) & 3;   // (q>>2)&3
+    const int a_base = (wr * (TR * 32) + l32) * (GL_BK * 4);
+    const int b_base = V_BYTES + (wq * (TQ * 32) + l32) * (GL_BK * 2);
+
+    // per-query constants of this lane's columns (loaded once: no ordinary loads inside the ring loop)
+    float c_qinv[TQ], c_thr[TQ], c_extra[TQ];
+    bool c_ok[TQ];
+#pragma unroll
+    for (int j = 0; j < TQ; ++j) {
+        const uint32_t n = wq * (TQ * 32) + j * 32 + l32;
+        c_ok[j] = n < a.nq;
+        c_qinv[j] = c_ok[j] ? a.qinv[n] : 0.0f;
+        c_thr[j] = c_ok[j] ? a.thr[n] : 0.0f;
+        if (a.debug_flags & 2) c_thr[j] = ASC ? -LY_INF : LY_INF;
+        c_extra[j] = 0.0f;
+        if (METRIC == M_L2) c_extra[j] = c_ok[j] ? a.qn2[n] : 0.0f;
+        if (METRIC == M_COS) c_extra[j] = c_ok[j] ? a.qrinv[n] : 0.0f;
+    }
+    // Make the compiler wait for these ordinary loads HERE: a first use inside the ring loop would
+    // cost an s_waitcnt vmcnt(0) per tile, draining the in-flight LDS-DMA slabs.
+#pragma unroll
+    for (int j = 0; j < TQ; ++j) asm volatile("" : "+v"(c_qinv[j]), "+v"(c_thr[j]), "+v"(c_extra[j]));
+
+#pragma unroll
+    for (int g0 = 0; g0 < NS - 1; ++g0) issue(g0);
+
+    uint32_t s_in_tile = 0, tile = blockIdx.x;
+    for (uint32_t g = 0; g < G; ++g) {
+        // slab g has landed once at most (NS-2) younger slabs of this wave are outstanding
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * OPS) : "memory");
+        __builtin_amdgcn_s_barrier();   // everyone's pieces landed; everyone finished slab g-1
+        issue(g + NS - 1);              // refill the stage that was computed last
+
+        const char* st = smem + (g % NS) * STAGE;
+#pragma unroll
+        for (int kk = 0; kk < GL_BK / 16; ++kk) {
+            half8 af[TR], bf[TQ];
+            const int la = (kk * 4 + hi * 2) ^ a_swz;  // physical slot of the first 16 B
+#pragma unroll
+            for (int i = 0; i < TR; ++i) {
+                const char* rp = st + a_base + i * 32 * (GL_BK * 4);
+                const f32x4 x0 = *reinterpret_cast<const f32x4*>(rp + la * 16);
+                const f32x4 x1 = *reinterpret_cast<const f32x4*>(rp + (la ^ 1) * 16);
+                half8 h;
+                if (SCALE) {
+                    h[0] = (_Float16)(x0[0] * a.sv); h[1] = (_Float16)(x0[1] * a.sv);
+                    h[2] = (_Float16)(x0[2] * a.sv); h[3] = (_Float16)(x0[3] * a.sv);
+                    h[4] = (_Float16)(x1[0] * a.sv); h[5] = (_Float16)(x1[1] * a.sv);
+                    h[6] = (_Float16)(x1[2] * a.sv); h[7] = (_Float16)(x1[3] * a.sv);
+                } else {
+                    h[0] = (_Float16)x0[0]; h[1] = (_Float16)x0[1]; h[2] = (_Float16)x0[2]; h[3] = (_Float16)x0[3];
+                    h[4] = (_Float16)x1[0]; h[5] = (_Float16)x1[1]; h[6] = (_Float16)x1[2]; h[7] = (_Float16)x1[3];
+                }
+                af[i] = h;
+            }
+            const int lb = (kk * 2 + hi) ^ b_swz;
+#pragma unroll
+            for (int j = 0; j < TQ; ++j)
+                bf[j] = *reinterpret_cast<const half8*>(st + b_base + j * 32 * (GL_BK * 2) + lb * 16);
+#pragma unroll
+            for (int i = 0; i < TR; ++i)
+#pragma unroll
+                for (int j = 0; j < TQ; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+
+        if (++s_in_tile == a.nslab) {
+            // ---- epilogue of a finished tile
+            const uint32_t rbase = a.row0 + tile * BR;
+#pragma unroll
+            for (int j = 0; j < TQ; ++j) {
+                const uint32_t n = wq * (TQ * 32) + j * 32 + l32;
+#pragma unroll
+                for (int i = 0; i < TR; ++i) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const uint32_t m = rbase + wr * (TR * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                        const bool rok = m < a.row1;
+                        float sc = acc[i][j][r] * c_qinv[j];
+                        if (METRIC == M_L2) sc = (rok ? a.vn2[m] : 0.0f) - 2.0f * sc + c_extra[j];
+                        if (METRIC == M_COS) sc = 1.0f - sc * (rok ? a.vrinv[m] : 0.0f) * c_extra[j];
+                        acc[i][j][r] = 0.0f;
+                        const bool pass = ASC ? (sc <= c_thr[j]) : (sc >= c_thr[j]);
+                        if (c_ok[j] && rok && (a.emit_all || pass)) {
+                            const uint32_t slot = a.emit_all ? (m - a.row0) : atomicAdd(&a.count[n], 1u);
+                            if (slot < a.cap) a.cand[(size_t)n * a.cap + slot] = make_key(sc, m, ASC);
+                        }
+                    }
+                }
+            }
+            s_in_tile = 0;
+            tile += gridDim.x;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the clamped tail DMAs before the LDS is released
 }
 
 // ------------------------------------------------------------------------------------------------

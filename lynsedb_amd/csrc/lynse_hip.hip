@@ -395,7 +395,9 @@ static int finalize_locked(lynse_hip_flat* h) {
     h->cos_degenerate = st[3] ? 1 : 0;
     int e = (h->amax > 0.0f && std::isfinite(h->amax)) ? std::ilogb(h->amax) : 13;
     e = std::max(-100, std::min(100, e));
-    h->sv = std::ldexp(1.0f, 13 - e);
+    // no scaling when max|v| in [2^-6, 2^15): the f16 subnormal floor (2^-25 absolute) is then far
+    // below u*|v| for every element that matters, and the hot loop saves the multiply
+    h->sv = (e >= -6 && e <= 14) ? 1.0f : std::ldexp(1.0f, 13 - e);
     h->n_stats = h->n;
     return LYNSE_OK;
 }
@@ -601,7 +603,7 @@ static std::vector<Stage> make_plan(const lynse_hip_flat* h, uint32_t k, bool sa
     return plan;
 }
 
-template <int WQ, int WR, int TQ, int TR>
+template <int WQ, int WR, int TQ, int TR, int PD>
 static int launch_scan(lynse_hip_flat* h, const ScanArgs& a, int metric, uint32_t grid, hipStream_t st) {
     constexpr int NT = WQ * WR * 64;
     constexpr int BQ = WQ * TQ * 32;
@@ -618,10 +620,47 @@ static int launch_scan(lynse_hip_flat* h, const ScanArgs& a, int metric, uint32_
     };
     (void)h;
     switch (metric) {
-    case M_IP: return go(k_scan_f16<WQ, WR, TQ, TR, M_IP>, 0);
-    case M_L2: return go(k_scan_f16<WQ, WR, TQ, TR, M_L2>, 1);
-    default: return go(k_scan_f16<WQ, WR, TQ, TR, M_COS>, 2);
+    case M_IP: return go(k_scan_f16<WQ, WR, TQ, TR, M_IP, PD>, 0);
+    case M_L2: return go(k_scan_f16<WQ, WR, TQ, TR, M_L2, PD>, 1);
+    default: return go(k_scan_f16<WQ, WR, TQ, TR, M_COS, PD>, 2);
     }
+}
+
+template <int WQ, int WR, int TQ, int TR, int NS>
+static int launch_scan_glds(const ScanArgs& a, int metric, bool scale, uint32_t grid, hipStream_t st) {
+    constexpr int NT = WQ * WR * 64;
+    constexpr int BQ = WQ * TQ * 32;
+    constexpr int BR = WR * TR * 32;
+    const size_t lds = (size_t)NS * (BR * GL_BK * 4 + BQ * GL_BK * 2);
+    static bool attr_done[12] = {false};
+    static const int nt_hint = []() { const char* e = getenv("LYNSE_HIP_SCAN_NT"); return e ? atoi(e) : 1; }();
+    auto go = [&](auto kern, int slot) -> int {
+        if (!attr_done[slot]) {
+            LY_TRY(set_max_lds(kern, lds));
+            attr_done[slot] = true;
+        }
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), lds, st, a);
+        LY_HIP(hipGetLastError());
+        return LYNSE_OK;
+    };
+#define LY_GO(M, S, H, slot) return go(k_scan_glds<WQ, WR, TQ, TR, M, S, NS, H>, slot)
+    if (nt_hint) {
+        if (scale) {
+            switch (metric) { case M_IP: LY_GO(M_IP, true, 2, 0); case M_L2: LY_GO(M_L2, true, 2, 1); default: LY_GO(M_COS, true, 2, 2); }
+        }
+        switch (metric) { case M_IP: LY_GO(M_IP, false, 2, 3); case M_L2: LY_GO(M_L2, false, 2, 4); default: LY_GO(M_COS, false, 2, 5); }
+    }
+    if (scale) {
+        switch (metric) { case M_IP: LY_GO(M_IP, true, 0, 6); case M_L2: LY_GO(M_L2, true, 0, 7); default: LY_GO(M_COS, true, 0, 8); }
+    }
+    switch (metric) { case M_IP: LY_GO(M_IP, false, 0, 9); case M_L2: LY_GO(M_L2, false, 0, 10); default: LY_GO(M_COS, false, 0, 11); }
+#undef LY_GO
+}
+
+// 0 = LDS-DMA ring kernel (default), 1 / 2 = register-staged kernel with prefetch depth 1 / 2
+static int scan_variant() {
+    static const int v = []() { const char* e = getenv("LYNSE_HIP_SCAN_VARIANT"); return e ? atoi(e) : 0; }();
+    return v;
 }
 
 static int launch_scan_binary(const BinArgs& a, int metric, uint32_t grid, size_t lds, hipStream_t st) {
@@ -659,7 +698,8 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
     Workspace& w = h->ws;
     const bool binary = metric >= M_HAMMING;
     const bool asc = metric_ascending(metric);
-    const uint32_t nslab = (h->dim + SCAN_BK - 1) / SCAN_BK;
+    const bool glds = scan_variant() == 0;
+    const uint32_t nslab = glds ? (h->dim + GL_BK - 1) / GL_BK : (h->dim + SCAN_BK - 1) / SCAN_BK;
     const bool small = nq <= SCAN_BQ_SMALL;
     const uint32_t qpad = small ? SCAN_BQ_SMALL : SCAN_BQ_LARGE;
     int ip_form = h->ip_form;
@@ -680,9 +720,9 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
         LY_HIP(hipStreamSynchronize(st));  // thr0 is a stack/heap temporary
     } else {
         // queries with index >= nq inside the padded tile must be finite: zero the image
-        LY_HIP(hipMemsetAsync(w.Q16, 0, (size_t)nslab * qpad * SCAN_LDK * sizeof(_Float16), st));
+        LY_HIP(hipMemsetAsync(w.Q16, 0, (size_t)nslab * qpad * (glds ? GL_BK : SCAN_LDK) * sizeof(_Float16), st));
         PrepArgs p{};
-        p.Q = w.Qf; p.D = h->dim; p.nq = nq; p.qpad = qpad; p.nslab = nslab; p.metric = metric;
+        p.Q = w.Qf; p.D = h->dim; p.nq = nq; p.qpad = qpad; p.nslab = nslab; p.metric = metric; p.layout = glds ? 1 : 0;
         p.sv = h->sv; p.vmax = h->vmax; p.vmin = h->vmin; p.cos_degenerate = h->cos_degenerate;
         p.Q16 = w.Q16; p.qinv = w.qinv; p.qn2 = w.qn2; p.qrinv = w.qrinv; p.marg2 = w.marg2; p.thr = w.thr;
         p.count = w.count; p.overflow = w.overflow;
@@ -711,15 +751,35 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
         } else {
             ScanArgs a{};
             a.V = h->rows; a.ld = h->ld; a.D = h->dim; a.row0 = s.r0; a.row1 = s.r1; a.Q16 = w.Q16;
-            a.qpad = qpad; a.nq = nq; a.nslab = nslab; a.ntiles = (s.r1 - s.r0 + SCAN_BR - 1) / SCAN_BR;
+            static const int big_rows = []() { const char* e = getenv("LYNSE_HIP_SCAN_BR"); return e ? atoi(e) : 256; }();
+            const uint32_t tile_rows = (glds && !small && big_rows == 256) ? 256u : (uint32_t)SCAN_BR;
+            a.qpad = qpad; a.nq = nq; a.nslab = nslab; a.ntiles = (s.r1 - s.r0 + tile_rows - 1) / tile_rows;
             a.qinv = w.qinv; a.qn2 = w.qn2; a.qrinv = w.qrinv; a.thr = w.thr; a.vn2 = h->vn2; a.vrinv = h->vrinv;
             a.sv = h->sv; a.cand = w.cand; a.count = w.count; a.cap = w.cap; a.emit_all = emit_all ? 1 : 0;
-            if (small) {
+            static const int dbg = []() { const char* e = getenv("LYNSE_HIP_DEBUG_FLAGS"); return e ? atoi(e) : 0; }();
+            a.debug_flags = dbg;
+            if (dbg & 2) a.emit_all = 0;
+            const int variant = scan_variant();
+            if (glds) {
+                const bool scale = h->sv != 1.0f;
+                if (small) {
+                    const uint32_t grid = std::min<uint32_t>(a.ntiles, (uint32_t)h->num_cu * 2);
+                    LY_TRY((launch_scan_glds<1, 4, 1, 1, 4>(a, metric, scale, grid, st)));
+                } else if (tile_rows == 256) {
+                    const uint32_t grid = std::min<uint32_t>(a.ntiles, (uint32_t)h->num_cu);
+                    LY_TRY((launch_scan_glds<4, 2, 2, 4, 3>(a, metric, scale, grid, st)));
+                } else {
+                    const uint32_t grid = std::min<uint32_t>(a.ntiles, (uint32_t)h->num_cu);
+                    LY_TRY((launch_scan_glds<4, 2, 2, 2, 4>(a, metric, scale, grid, st)));
+                }
+            } else if (small) {
                 const uint32_t grid = std::min<uint32_t>(a.ntiles, (uint32_t)h->num_cu * 3);
-                LY_TRY((launch_scan<1, 4, 1, 1>(h, a, metric, grid, st)));
+                if (variant == 1) LY_TRY((launch_scan<1, 4, 1, 1, 1>(h, a, metric, grid, st)));
+                else LY_TRY((launch_scan<1, 4, 1, 1, 2>(h, a, metric, grid, st)));
             } else {
                 const uint32_t grid = std::min<uint32_t>(a.ntiles, (uint32_t)h->num_cu);
-                LY_TRY((launch_scan<4, 2, 2, 2>(h, a, metric, grid, st)));
+                if (variant == 1) LY_TRY((launch_scan<4, 2, 2, 2, 1>(h, a, metric, grid, st)));
+                else LY_TRY((launch_scan<4, 2, 2, 2, 2>(h, a, metric, grid, st)));
             }
         }
         if (h->profiling) {
