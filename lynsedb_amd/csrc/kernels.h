@@ -531,8 +531,8 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
 
 // NS ring stages; NT_HINT = 2 marks the row stream non-temporal (each row byte is read once per
 // batch by exactly one CU), the query image keeps the default policy (re-read by every CU from L2).
-template <int WQ, int WR, int TQ, int TR, int METRIC, bool SCALE, int NS, int NT_HINT>
-__global__ void __launch_bounds__(WQ * WR * 64, 2) k_scan_glds(ScanArgs a) {
+template <int WQ, int WR, int TQ, int TR, int METRIC, bool SCALE, int NS, int NT_HINT, bool TWO_BAR = false>
+__global__ void __launch_bounds__(WQ * WR * 64, (WQ * WR >= 8) ? (WQ * WR / 4) : 2) k_scan_glds(ScanArgs a) {
     constexpr int NW = WQ * WR;
     constexpr int BQ = WQ * TQ * 32;
     constexpr int BR = WR * TR * 32;
@@ -628,47 +628,72 @@ __global__ void __launch_bounds__(WQ * WR * 64, 2) k_scan_glds(ScanArgs a) {
 #pragma unroll
     for (int j = 0; j < TQ; ++j) asm volatile("" : "+v"(c_qinv[j]), "+v"(c_thr[j]), "+v"(c_extra[j]));
 
+    // Ring protocol (two raw barriers per slab, NS-1 slabs always in flight):
+    //   compute(g) -> barrier A (everyone finished reading stage g%NS) -> refill it with slab g+NS
+    //   -> wait until at most (NS-1)*OPS of this wave's DMAs are outstanding (slab g+1 landed)
+    //   -> barrier B (everyone's pieces of slab g+1 landed).
+    // The refill is issued as soon as the stage is free — it does not wait for slab g+1 to arrive.
+    // One-barrier variant (default, measured faster): wait slab g -> barrier -> refill the stage
+    // computed last with slab g+NS-1 -> compute(g).
 #pragma unroll
-    for (int g0 = 0; g0 < NS - 1; ++g0) issue(g0);
+    for (int g0 = 0; g0 < (TWO_BAR ? NS : NS - 1); ++g0) issue(g0);
+    if (TWO_BAR) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 1) * OPS) : "memory");
+        __builtin_amdgcn_s_barrier();
+    }
 
     uint32_t s_in_tile = 0, tile = blockIdx.x;
     for (uint32_t g = 0; g < G; ++g) {
-        // slab g has landed once at most (NS-2) younger slabs of this wave are outstanding
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * OPS) : "memory");
-        __builtin_amdgcn_s_barrier();   // everyone's pieces landed; everyone finished slab g-1
-        issue(g + NS - 1);              // refill the stage that was computed last
-
+        if (!TWO_BAR) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * OPS) : "memory");
+            __builtin_amdgcn_s_barrier();
+            issue(g + NS - 1);
+        }
         const char* st = smem + (g % NS) * STAGE;
+        if (!(a.debug_flags & 4)) {  // EXPERIMENT flag 4: DMA stream only, no LDS reads / MFMA
+            // Issue every LDS read of the slab first (one LDS latency per slab instead of one per
+            // fragment group), then convert + MFMA in consumption order.
+            f32x4 araw[GL_BK / 16][TR][2];
+            half8 bf[GL_BK / 16][TQ];
 #pragma unroll
-        for (int kk = 0; kk < GL_BK / 16; ++kk) {
-            half8 af[TR], bf[TQ];
-            const int la = (kk * 4 + hi * 2) ^ a_swz;  // physical slot of the first 16 B
+            for (int kk = 0; kk < GL_BK / 16; ++kk) {
+                const int la = (kk * 4 + hi * 2) ^ a_swz;  // physical slot of the first 16 B
 #pragma unroll
-            for (int i = 0; i < TR; ++i) {
-                const char* rp = st + a_base + i * 32 * (GL_BK * 4);
-                const f32x4 x0 = *reinterpret_cast<const f32x4*>(rp + la * 16);
-                const f32x4 x1 = *reinterpret_cast<const f32x4*>(rp + (la ^ 1) * 16);
-                half8 h;
-                if (SCALE) {
-                    h[0] = (_Float16)(x0[0] * a.sv); h[1] = (_Float16)(x0[1] * a.sv);
-                    h[2] = (_Float16)(x0[2] * a.sv); h[3] = (_Float16)(x0[3] * a.sv);
-                    h[4] = (_Float16)(x1[0] * a.sv); h[5] = (_Float16)(x1[1] * a.sv);
-                    h[6] = (_Float16)(x1[2] * a.sv); h[7] = (_Float16)(x1[3] * a.sv);
-                } else {
-                    h[0] = (_Float16)x0[0]; h[1] = (_Float16)x0[1]; h[2] = (_Float16)x0[2]; h[3] = (_Float16)x0[3];
-                    h[4] = (_Float16)x1[0]; h[5] = (_Float16)x1[1]; h[6] = (_Float16)x1[2]; h[7] = (_Float16)x1[3];
+                for (int i = 0; i < TR; ++i) {
+                    const char* rp = st + a_base + i * 32 * (GL_BK * 4);
+                    araw[kk][i][0] = *reinterpret_cast<const f32x4*>(rp + la * 16);
+                    araw[kk][i][1] = *reinterpret_cast<const f32x4*>(rp + (la ^ 1) * 16);
                 }
-                af[i] = h;
-            }
-            const int lb = (kk * 2 + hi) ^ b_swz;
-#pragma unroll
-            for (int j = 0; j < TQ; ++j)
-                bf[j] = *reinterpret_cast<const half8*>(st + b_base + j * 32 * (GL_BK * 2) + lb * 16);
-#pragma unroll
-            for (int i = 0; i < TR; ++i)
+                const int lb = (kk * 2 + hi) ^ b_swz;
 #pragma unroll
                 for (int j = 0; j < TQ; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+                    bf[kk][j] = *reinterpret_cast<const half8*>(st + b_base + j * 32 * (GL_BK * 2) + lb * 16);
+            }
+#pragma unroll
+            for (int kk = 0; kk < GL_BK / 16; ++kk) {
+#pragma unroll
+                for (int i = 0; i < TR; ++i) {
+                    const f32x4 x0 = araw[kk][i][0], x1 = araw[kk][i][1];
+                    half8 h;
+                    if (SCALE) {
+                        h[0] = (_Float16)(x0[0] * a.sv); h[1] = (_Float16)(x0[1] * a.sv);
+                        h[2] = (_Float16)(x0[2] * a.sv); h[3] = (_Float16)(x0[3] * a.sv);
+                        h[4] = (_Float16)(x1[0] * a.sv); h[5] = (_Float16)(x1[1] * a.sv);
+                        h[6] = (_Float16)(x1[2] * a.sv); h[7] = (_Float16)(x1[3] * a.sv);
+                    } else {
+                        h[0] = (_Float16)x0[0]; h[1] = (_Float16)x0[1]; h[2] = (_Float16)x0[2]; h[3] = (_Float16)x0[3];
+                        h[4] = (_Float16)x1[0]; h[5] = (_Float16)x1[1]; h[6] = (_Float16)x1[2]; h[7] = (_Float16)x1[3];
+                    }
+#pragma unroll
+                    for (int j = 0; j < TQ; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h, bf[kk][j], acc[i][j], 0, 0, 0);
+                }
+            }
+        }
+
+        if (TWO_BAR) {
+            __builtin_amdgcn_s_barrier();   // A: stage g%NS is free
+            issue(g + NS);
         }
 
         if (++s_in_tile == a.nslab) {
@@ -697,6 +722,11 @@ __global__ void __launch_bounds__(WQ * WR * 64, 2) k_scan_glds(ScanArgs a) {
             }
             s_in_tile = 0;
             tile += gridDim.x;
+        }
+        // extra VM ops of the epilogue only make this wait conservative (in-order retirement)
+        if (TWO_BAR) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 1) * OPS) : "memory");
+            __builtin_amdgcn_s_barrier();   // B: slab g+1 is complete in LDS
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the clamped tail DMAs before the LDS is released
