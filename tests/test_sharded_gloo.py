@@ -1,0 +1,76 @@
+"""world_size-2 `gloo` test of the multi-GPU exchange step on CPU (no GPU needed).
+
+Covers the N>1 path of lynsedb_amd/sharded.py: the row partition rule (global row g on rank g % G),
+the fixed-size per-rank result block, the all-gather and the canonical (distance, row) k-way merge
+(lynse_hip_merge_topk, host side of the C ABI).  The per-shard scan itself needs a GPU, so each rank
+produces its shard's top-k with the CPU oracle (allowed in tests) and the merged result must equal
+the oracle's answer on the unsharded collection — bit-exact ids and distances, ties included.
+"""
+import os
+import socket
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, metric, ret):
+    sys.path.insert(0, str(ROOT))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+
+    import oracle as O
+    from lynsedb_amd.sharded import ShardedFlat, shard_of_row
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        orc = O.get()
+        rng = np.random.default_rng(1234)  # same global data on every rank
+        n, dim, nq, k = 3001, 24, 5, 12
+        data = rng.integers(0, 4, size=(n, dim)).astype(np.float32)  # small ints -> many exact ties
+        queries = rng.integers(0, 4, size=(nq, dim)).astype(np.float32)
+        mine = np.arange(rank, n, world)
+        assert all(shard_of_row(int(g), world) == rank for g in mine[:10])
+        local = data[mine]
+        rows = np.full((nq, k), np.iinfo(np.uint64).max, np.uint64)
+        dists = np.zeros((nq, k), np.float32)
+        counts = np.zeros(nq, np.uint32)
+        for q in range(nq):
+            i, d = orc.canonical_topk(queries[q], local, k, metric, O.IPFORM_SINGLE)
+            rows[q, :len(i)] = i.astype(np.uint64) * world + rank  # local row -> global row (row map)
+            dists[q, :len(i)] = d
+            counts[q] = len(i)
+        m_rows, m_dists, m_counts = ShardedFlat.allgather_merge_host(dist, world, rows, dists, counts, k, metric)
+        ok = True
+        for q in range(nq):
+            e_i, e_d = orc.canonical_topk(queries[q], data, k, metric, O.IPFORM_SINGLE)
+            ok &= int(m_counts[q]) == len(e_i)
+            ok &= np.array_equal(m_rows[q, :len(e_i)], e_i.astype(np.uint64))
+            ok &= np.array_equal(m_dists[q, :len(e_i)], e_d)
+        ret[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("metric", [0, 1, 3])  # IP (descending), L2, Hamming (heavy ties)
+def test_allgather_merge_world2(metric):
+    import torch.multiprocessing as mp
+
+    world = 2
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, port, metric, ret), nprocs=world, join=True)
+    assert dict(ret) == {0: True, 1: True}
