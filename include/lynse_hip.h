@@ -195,6 +195,10 @@ uint32_t lynse_hip_ivf_nlist(const lynse_hip_ivf *h);
 int lynse_hip_ivf_export(const lynse_hip_ivf *h, float *centroids, uint32_t *assignments,
                          uint64_t *offsets, uint32_t *original_ids);
 int lynse_hip_ivf_set_row_map(lynse_hip_ivf *h, uint64_t stride, uint64_t offset);
+/* Probe selection semantics: 0 = IVFIndex (rank every centroid, ivf.rs:227-249, empty-probe fallback
+ * :258-265); 1 = IvfFlatMmap (IP 16-dim shortlist heuristic, ivf_flat_mmap.rs:381-421).  build() sets
+ * it from `l2_partitions`, load() defaults to 0. */
+int lynse_hip_ivf_set_routing(lynse_hip_ivf *h, int ivfflat_routing);
 /* IVFIndex::search (ivf.rs:181-348): rank all centroids with the routing metric, scan the nprobe
  * nearest lists, exact top-k of the probed rows.  nprobe == 0 -> 1 (ivf.rs:192-196). */
 int lynse_hip_ivf_search_f32(lynse_hip_ivf *h, const float *queries, uint64_t nq, uint32_t k,

@@ -262,7 +262,9 @@ class IvfFlatIndex:
         return IvfFlatIndex(h, dim)
 
     @staticmethod
-    def load(data, centroids, assignments, metric: str = "ip", device: Optional[int] = None) -> "IvfFlatIndex":
+    def load(data, centroids, assignments, metric: str = "ip", device: Optional[int] = None,
+             ivfflat_routing: bool = False) -> "IvfFlatIndex":
+        """Assemble from given centroids + assignments (parity tests feed the oracle's k-means output)."""
         m = metric_from_str(metric)
         a = _f32(data, 2, "data")
         c = _f32(centroids, 2, "centroids")
@@ -270,7 +272,10 @@ class IvfFlatIndex:
         h = C.c_void_p()
         dev = default_device() if device is None else int(device)
         check(lib.lynse_hip_ivf_load(_ptr(a), a.shape[0], a.shape[1], _ptr(c), c.shape[0], _ptr(asg), m, dev, C.byref(h)))
-        return IvfFlatIndex(h, a.shape[1])
+        idx = IvfFlatIndex(h, a.shape[1])
+        if ivfflat_routing:
+            check(lib.lynse_hip_ivf_set_routing(h, 1))
+        return idx
 
     def __len__(self) -> int:
         return int(lib.lynse_hip_ivf_len(self._h))

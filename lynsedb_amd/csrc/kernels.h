@@ -316,6 +316,16 @@ struct ScanArgs {
     uint32_t cap;
     int emit_all;
     int debug_flags;  // timing experiments only: 1 = linear (blocked-layout-like) row addressing, 2 = no emission
+    // work-list mode (IVF slabs): tile t covers rows [tiles[t].row0, +nrows) for the query group whose
+    // f16 image starts at Q16 + qimg_off halves; local query n of the group is query pair_q[pair0+n]
+    const struct IvfTile* tiles;
+    const uint32_t* pair_q;
+};
+
+struct IvfTile {
+    uint32_t row0, nrows;
+    uint32_t qimg_off;  // in halves
+    uint32_t pair0, nq;
 };
 
 template <int WQ, int WR, int TQ, int TR, int METRIC, int PD>
@@ -531,7 +541,7 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
 
 // NS ring stages; NT_HINT = 2 marks the row stream non-temporal (each row byte is read once per
 // batch by exactly one CU), the query image keeps the default policy (re-read by every CU from L2).
-template <int WQ, int WR, int TQ, int TR, int METRIC, bool SCALE, int NS, int NT_HINT, bool TWO_BAR = false>
+template <int WQ, int WR, int TQ, int TR, int METRIC, bool SCALE, int NS, int NT_HINT, bool TWO_BAR = false, bool TILED = false>
 __global__ void __launch_bounds__(WQ * WR * 64, (WQ * WR >= 8) ? (WQ * WR / 4) : 2) k_scan_glds(ScanArgs a) {
     constexpr int NW = WQ * WR;
     constexpr int BQ = WQ * TQ * 32;
@@ -575,12 +585,22 @@ __global__ void __launch_bounds__(WQ * WR * 64, (WQ * WR >= 8) ? (WQ * WR / 4) :
         // clamp past-the-end steps to the last real one: keeps the per-wave DMA count uniform
         const uint32_t gg = g < G ? g : G - 1;
         const uint32_t ti = gg / a.nslab, s = gg - ti * a.nslab;
-        const uint32_t rbase = a.row0 + (blockIdx.x + ti * gridDim.x) * BR;
+        uint32_t rbase = a.row0 + (blockIdx.x + ti * gridDim.x) * BR;
+        uint32_t tile_last = last_row;
+        const char* qbase = reinterpret_cast<const char*>(a.Q16);
+        uint32_t qslab_bytes = a.qpad * (GL_BK * 2);
+        if (TILED) {
+            const IvfTile td = a.tiles[blockIdx.x + ti * gridDim.x];  // uniform -> scalar loads
+            rbase = td.row0;
+            tile_last = td.row0 + td.nrows - 1;
+            qbase += (size_t)td.qimg_off * 2;
+            qslab_bytes = BQ * (GL_BK * 2);
+        }
         char* stage = smem + (g % NS) * STAGE;
 #pragma unroll
         for (int j = 0; j < VPW; ++j) {
             uint32_t row = rbase + v_row[j];
-            row = row < last_row ? row : last_row;
+            row = row < tile_last ? row : tile_last;
             uint32_t col = s * GL_BK + v_col[j];
             col = col < a.ld ? col : a.ld - 4;
             const float* src = a.V + (size_t)row * a.ld + col;
@@ -588,7 +608,7 @@ __global__ void __launch_bounds__(WQ * WR * 64, (WQ * WR >= 8) ? (WQ * WR / 4) :
                 src = a.V + ((size_t)(blockIdx.x + ti * gridDim.x) * a.nslab + s) * (BR * GL_BK) + (wave * VPW + j) * 256 + lane * 4;
             glds16<NT_HINT>(src, stage + (wave * VPW + j) * 1024);
         }
-        const char* qsrc = reinterpret_cast<const char*>(a.Q16) + (size_t)s * a.qpad * (GL_BK * 2);
+        const char* qsrc = qbase + (size_t)s * qslab_bytes;
 #pragma unroll
         for (int j = 0; j < QPW; ++j)
             glds16<0>(qsrc + q_off[j], stage + V_BYTES + ((wave * QPW + j) % Q_INSTR) * 1024);
@@ -615,7 +635,7 @@ __global__ void __launch_bounds__(WQ * WR * 64, (WQ * WR >= 8) ? (WQ * WR / 4) :
 #pragma unroll
     for (int j = 0; j < TQ; ++j) {
         const uint32_t n = wq * (TQ * 32) + j * 32 + l32;
-        c_ok[j] = n < a.nq;
+        c_ok[j] = !TILED && n < a.nq;
         c_qinv[j] = c_ok[j] ? a.qinv[n] : 0.0f;
         c_thr[j] = c_ok[j] ? a.thr[n] : 0.0f;
         if (a.debug_flags & 2) c_thr[j] = ASC ? -LY_INF : LY_INF;
@@ -698,23 +718,38 @@ __global__ void __launch_bounds__(WQ * WR * 64, (WQ * WR >= 8) ? (WQ * WR / 4) :
 
         if (++s_in_tile == a.nslab) {
             // ---- epilogue of a finished tile
-            const uint32_t rbase = a.row0 + tile * BR;
+            uint32_t rbase = a.row0 + tile * BR;
+            uint32_t row_end = a.row1;
+            IvfTile td{};
+            if (TILED) {
+                td = a.tiles[tile];
+                rbase = td.row0;
+                row_end = td.row0 + td.nrows;
+            }
 #pragma unroll
             for (int j = 0; j < TQ; ++j) {
-                const uint32_t n = wq * (TQ * 32) + j * 32 + l32;
+                uint32_t n = wq * (TQ * 32) + j * 32 + l32;
+                if (TILED) {  // group-local query -> global query id and its per-query constants
+                    c_ok[j] = n < td.nq;
+                    n = c_ok[j] ? a.pair_q[td.pair0 + n] : 0u;
+                    c_qinv[j] = c_ok[j] ? a.qinv[n] : 0.0f;
+                    c_thr[j] = c_ok[j] ? a.thr[n] : 0.0f;
+                    if (METRIC == M_L2) c_extra[j] = c_ok[j] ? a.qn2[n] : 0.0f;
+                    if (METRIC == M_COS) c_extra[j] = c_ok[j] ? a.qrinv[n] : 0.0f;
+                }
 #pragma unroll
                 for (int i = 0; i < TR; ++i) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const uint32_t m = rbase + wr * (TR * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                        const bool rok = m < a.row1;
+                        const bool rok = m < row_end;
                         float sc = acc[i][j][r] * c_qinv[j];
                         if (METRIC == M_L2) sc = (rok ? a.vn2[m] : 0.0f) - 2.0f * sc + c_extra[j];
                         if (METRIC == M_COS) sc = 1.0f - sc * (rok ? a.vrinv[m] : 0.0f) * c_extra[j];
                         acc[i][j][r] = 0.0f;
                         const bool pass = ASC ? (sc <= c_thr[j]) : (sc >= c_thr[j]);
                         if (c_ok[j] && rok && (a.emit_all || pass)) {
-                            const uint32_t slot = a.emit_all ? (m - a.row0) : atomicAdd(&a.count[n], 1u);
+                            const uint32_t slot = (a.emit_all && !TILED) ? (m - a.row0) : atomicAdd(&a.count[n], 1u);
                             if (slot < a.cap) a.cand[(size_t)n * a.cap + slot] = make_key(sc, m, ASC);
                         }
                     }
@@ -888,6 +923,7 @@ struct SelectArgs {
     uint32_t k, cap, keep_max;
     int metric, ip_form, exact;
     int emit_all_n;  // >=0: stage 0 wrote exactly this many keys per query
+    int keep_ties;   // IVF: key rows are slab positions, not ids -> an exact cut must keep every tie of the k-th score
     const float* Qf;
     const float* V;
     uint32_t ld, D;
@@ -935,8 +971,18 @@ __global__ void __launch_bounds__(NT) k_select(SelectArgs a) {
                 rescore_keys<NT>(keys, keep, a.metric, a.ip_form, a.Qf + (size_t)q * a.D, a.V, a.ld, a.D, asc, tid);
                 for (uint32_t i = keep + tid; i < np2; i += NT) keys[i] = KEY_SENTINEL;
                 bitonic_sort_lds<NT>(keys, np2, tid);
-                keep = a.k;
                 const float xk = key_score(keys[a.k - 1], asc);
+                uint32_t kept = a.k;
+                if (a.keep_ties) {
+                    if (tid == 0) s_keep = 0;
+                    __syncthreads();
+                    uint32_t ties = 0;
+                    for (uint32_t i = a.k + tid; i < keep; i += NT) ties += key_score(keys[i], asc) == xk ? 1u : 0u;
+                    if (ties) atomicAdd(&s_keep, ties);
+                    __syncthreads();
+                    kept += s_keep;
+                }
+                keep = kept;
                 thr_new = asc ? xk + m2 : xk - m2;
             }
         }
@@ -965,6 +1011,7 @@ struct FinalArgs {
     const float* V;
     uint32_t ld, D;
     uint64_t row_stride, row_offset;
+    const uint32_t* orig_ids;  // IVF: slab position -> original row (tie-break and output use the original row)
     uint64_t* out_rows;
     float* out_dists;
     uint32_t* out_counts;
@@ -986,6 +1033,10 @@ __global__ void __launch_bounds__(NT) k_final(FinalArgs a) {
     __syncthreads();
     if (!a.exact)
         rescore_keys<NT>(keys, n, a.metric, a.ip_form, a.Qf + (size_t)q * a.D, a.V, a.ld, a.D, asc, tid);
+    if (a.orig_ids) {  // canonical order is (distance, ORIGINAL row): swap the row word before the final sort
+        for (uint32_t i = tid; i < n; i += NT) keys[i] = (keys[i] & 0xffffffff00000000ull) | a.orig_ids[key_row(keys[i])];
+        __syncthreads();
+    }
     bitonic_sort_lds<NT>(keys, np2, tid);
     const uint32_t cnt = n < a.k ? n : a.k;
     for (uint32_t i = tid; i < a.out_k; i += NT) {

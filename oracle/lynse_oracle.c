@@ -1071,11 +1071,11 @@ size_t lo_ivf_search(const float *query, const float *data, const uint64_t *pack
         size_t c = cand[j];
         sc[j].d = pq ? pf(pq, packed + c * words, words)
                      : lo_compute_distance(query, data + c * dim, dim, metric);
-        sc[j].id = j; /* local candidate position */
+        sc[j].id = c; /* canonical tie-break: original row id (the reference's sort_unstable leaves ties unpinned) */
     }
     g_cmp_asc = asc;
     qsort(sc, total, sizeof(cpair_t), cmp_canonical);
-    for (size_t j = 0; j < pool; ++j) { out_ids[j] = cand[sc[j].id]; out_dist[j] = sc[j].d; }
+    for (size_t j = 0; j < pool; ++j) { out_ids[j] = sc[j].id; out_dist[j] = sc[j].d; }
     free(pq); free(sc); free(cand);
     return pool;
 }

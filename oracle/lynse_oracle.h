@@ -127,10 +127,9 @@ void lo_fastrng_stream(uint64_t seed, size_t count, double *out);
 
 /* IVFIndex::search (ivf.rs:181-348), QuantizerType::None / packed-binary:
  * lists are given as CSR (list_offsets[nlist+1], list_rows ascending per list,
- * kmeans.rs:317-345).  `packed` may be NULL for float metrics.  Candidate
- * order = centroid rank order then ascending row; final order is canonical
- * (distance, candidate position) which equals the reference for distinct
- * distances.  Returns count. */
+ * kmeans.rs:317-345).  `packed` may be NULL for float metrics.  Final order is
+ * canonical (distance, row id), which equals the reference for distinct
+ * distances (its sort_unstable leaves ties unpinned).  Returns count. */
 size_t lo_ivf_search(const float *query, const float *data, const uint64_t *packed, size_t words,
                      size_t dim, size_t n, const float *centroids, size_t nlist,
                      const uint64_t *list_offsets, const uint32_t *list_rows, size_t nprobe,

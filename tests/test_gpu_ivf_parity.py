@@ -1,0 +1,146 @@
+"""GPU parity tests for IVF-Flat: HIP path (C ABI) vs the CPU oracle's restatement of IVFIndex
+(src/index/ivf.rs) and IvfFlatMmap (src/storage/ivf_flat_mmap.rs).
+
+Parity definition: the same centroids + assignments in -> the same probes, candidates
+and results out, bit-exact ids and distances.  The device k-means is additionally compared with the
+oracle's k-means where the reference itself is deterministic (n < 8192, sequential sums)."""
+import numpy as np
+import pytest
+
+import oracle as O
+
+pytestmark = pytest.mark.gpu
+IP, L2, COS = O.IP, O.L2, O.COS
+NAME = {IP: "ip", L2: "l2", COS: "cosine"}
+f32 = np.float32
+
+
+@pytest.fixture(scope="module")
+def L():
+    import lynsedb_amd as L_
+
+    assert L_._lib.device_count() >= 1
+    return L_
+
+
+def oracle_ivf(oracle, data, nlist, metric, iters=20, train_metric=None):
+    cen, asg = oracle.kmeans_train(data, nlist, iters, metric if train_metric is None else train_metric)
+    off, rows = oracle.lists_from_assignments(asg, cen.shape[0])
+    return cen, asg, off, rows
+
+
+def check_ivfindex(L, oracle, data, queries, nlist, nprobe, k, metric):
+    cen, asg, off, rows = oracle_ivf(oracle, data, nlist, metric)
+    idx = L.IvfFlatIndex.load(data, cen, asg, NAME[metric])
+    assert len(idx) == data.shape[0] and idx.n_partitions == cen.shape[0]
+    g_rows, g_d, g_c = idx.search_batch_arrays(queries, k, nprobe)
+    for qi in range(queries.shape[0]):
+        e_ids, e_d, _ = oracle.ivf_search(queries[qi], data, cen, off, rows, nprobe, k, metric)
+        c = int(g_c[qi])
+        assert c == len(e_ids), (qi, c, len(e_ids))
+        assert np.array_equal(g_d[qi, :c].view(np.uint32), e_d.view(np.uint32)), (qi, g_d[qi, :c], e_d)
+        assert np.array_equal(g_rows[qi, :c], e_ids), (qi, g_rows[qi, :c], e_ids)
+
+
+@pytest.mark.parametrize("metric", [IP, L2, COS])
+@pytest.mark.parametrize("n,dim,nlist,nprobe,nq,k", [
+    (800, 32, 32, 2, 4, 10), (800, 32, 32, 32, 3, 10), (3000, 20, 16, 4, 40, 5), (6000, 100, 64, 10, 9, 10),
+    (5000, 48, 300, 7, 70, 10), (400, 8, 8, 1, 2, 25),
+])
+def test_ivfindex_parity(L, oracle, metric, n, dim, nlist, nprobe, nq, k):
+    rng = np.random.default_rng(n + dim + nlist)
+    centers = rng.standard_normal((max(nlist // 2, 2), dim)).astype(f32)
+    data = (centers[rng.integers(0, centers.shape[0], n)] + 0.3 * rng.standard_normal((n, dim))).astype(f32)
+    queries = (data[rng.integers(0, n, nq)] + 0.05 * rng.standard_normal((nq, dim))).astype(f32)
+    check_ivfindex(L, oracle, data, queries, nlist, nprobe, k, metric)
+
+
+def test_ivf_reference_kats(L, oracle):
+    # ivf.rs:578-638 — n=800, D=32 generator, nlist=32: nprobe=32 => exact; recall monotone in nprobe
+    n, dim = 800, 32
+    i = np.arange(n)[:, None]
+    j = np.arange(dim)[None, :]
+    data = (((i * 131 + j * 17 + 1) % 997).astype(f32) / f32(997.0) + f32(0.01)).astype(f32)
+    cen, asg, off, rows = oracle_ivf(oracle, data, 32, IP)
+    idx = L.IvfFlatIndex.load(data, cen, asg, "ip")
+    q = data[0]
+    flat_ids, _ = oracle.canonical_topk(q, data, 10, IP, O.IPFORM_SINGLE)
+    hi, _ = idx.search(q, 10, 32, "ip")
+    lo, _ = idx.search(q, 10, 2, "ip")
+    assert set(hi.tolist()) == set(flat_ids.tolist())
+    assert len(set(lo.tolist()) & set(flat_ids.tolist())) <= 10
+    # ivf.rs:546-575 (unfiltered part): two well separated clusters, nprobe=1 from the near one
+    d2 = np.array([[0, 0], [0.1, 0], [10, 10], [10.1, 10]], f32)
+    cen, asg, off, rows = oracle_ivf(oracle, d2, 2, L2)
+    idx = L.IvfFlatIndex.load(d2, cen, asg, "l2")
+    ids, _ = idx.search(np.zeros(2, f32), 2, 1, "l2")
+    assert sorted(ids.tolist()) == [0, 1]
+    ids0, d0 = idx.search(np.zeros(2, f32), 2, 0, "l2")  # nprobe 0 == 1 (ivf.rs:192-196)
+    assert np.array_equal(ids0, ids)
+
+
+@pytest.mark.parametrize("n,dim,nlist,nprobe", [(12, 4, 3, 1), (1000, 8, 10, 10), (4000, 64, 64, 5), (6000, 96, 128, 12), (4, 2, 2, 2)])
+def test_ivfflat_parity_and_heuristic_routing(L, oracle, n, dim, nlist, nprobe):
+    """IvfFlatMmap semantics: L2-trained partitions, IP search, 16-dim shortlist routing when
+    D >= 64 and nlist >= 64 (ivf_flat_mmap.rs:381-421)."""
+    rng = np.random.default_rng(n * 7 + dim)
+    data = rng.standard_normal((n, dim)).astype(f32)
+    cen, asg = oracle.kmeans_train(data, nlist, 10, L2)
+    offsets, orig = oracle.ivf_flat_layout(asg, cen.shape[0])
+    slab = data[orig]
+    rd = oracle.ivf_routing_dims(cen)
+    idx = L.IvfFlatIndex.load(data, cen, asg, "ip", ivfflat_routing=True)
+    c2, a2, o2, orig2 = idx.export()
+    assert np.array_equal(o2, offsets) and np.array_equal(orig2, orig) and np.array_equal(a2, asg)
+    for qi in range(6):
+        q = (data[rng.integers(0, n)] + 0.1 * rng.standard_normal(dim)).astype(f32)
+        e_ids, e_d = oracle.ivf_flat_search(q, slab, cen, offsets, orig, nprobe, 5, IP, rd)
+        g_ids, g_d = idx.search(q, 5, nprobe, "ip")
+        assert np.array_equal(g_d.view(np.uint32), e_d.view(np.uint32)), (qi, g_d, e_d)
+        assert np.array_equal(g_ids, e_ids), (qi, g_ids, e_ids)
+
+
+@pytest.mark.parametrize("metric,l2p", [(IP, False), (L2, False), (COS, False), (IP, True)])
+def test_device_kmeans_matches_oracle(L, oracle, metric, l2p):
+    """lynse_hip_ivf_build vs kmeans::train_for_metric (kmeans.rs:74-139) restated by the oracle:
+    identical FastRng(42) init, assignments and (sequential-order) centroid sums -> bit-identical."""
+    rng = np.random.default_rng(17)
+    n, dim, nlist = 3000, 24, 40
+    data = rng.random((n, dim), dtype=f32) + (rng.integers(0, 5, size=(n, 1)) * 0.7).astype(f32)
+    idx = L.IvfFlatIndex.build(None, data, dim, nlist, 20, NAME[metric], l2_partitions=l2p)
+    cen, asg, off, orig = idx.export()
+    e_cen, e_asg = oracle.kmeans_train(data, nlist, 20, L2 if l2p else metric)
+    assert cen.shape == e_cen.shape
+    assert np.array_equal(asg, e_asg)
+    assert np.array_equal(cen.view(np.uint32), e_cen.view(np.uint32))
+    q = data[5]
+    e_off, e_rows = oracle.lists_from_assignments(e_asg, e_cen.shape[0])
+    if not l2p:
+        e_ids, e_d, _ = oracle.ivf_search(q, data, e_cen, e_off, e_rows, 6, 10, metric)
+        g_ids, g_d = idx.search(q, 10, 6, NAME[metric])
+        assert np.array_equal(g_ids.astype(np.uint64), e_ids) and np.array_equal(g_d, e_d)
+
+
+def test_ivf_build_recall_and_errors(L, oracle):
+    rng = np.random.default_rng(3)
+    n, dim = 20000, 64
+    centers = rng.standard_normal((50, dim)).astype(f32)
+    data = (centers[np.arange(n) % 50] + 0.2 * rng.standard_normal((n, dim))).astype(f32)
+    idx = L.IvfFlatIndex.build(None, data, dim, 64, 10, "l2")
+    qs = (data[:20] + 0.01).astype(f32)
+    rows, d, c = idx.search_batch_arrays(qs, 10, 8)
+    hit = 0
+    for i in range(20):
+        e_ids, _ = oracle.canonical_topk(qs[i], data, 10, L2)
+        hit += len(set(rows[i, :c[i]].tolist()) & set(e_ids.tolist()))
+    assert hit / 200 >= 0.85  # reference gate floor for IVF (benchmarks/gate_index_modes.py:271)
+    rows_all, d_all, c_all = idx.search_batch_arrays(qs[:3], 10, 64)  # all partitions -> exact
+    for i in range(3):
+        e_ids, e_d = oracle.canonical_topk(qs[i], data, 10, L2)
+        assert np.array_equal(rows_all[i].astype(np.uint32), e_ids) and np.array_equal(d_all[i], e_d)
+    with pytest.raises(IOError):
+        L.IvfFlatIndex.build(None, data[:5], dim, 8)  # fewer vectors than partitions
+    with pytest.raises(ValueError):
+        idx.search(np.zeros(dim + 1, f32), 5, 4, "l2")
+    with pytest.raises(ValueError, match="Unknown metric"):
+        idx.search(np.zeros(dim, f32), 5, 4, "nope")
