@@ -541,13 +541,14 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
 
 // NS ring stages; NT_HINT = 2 marks the row stream non-temporal (each row byte is read once per
 // batch by exactly one CU), the query image keeps the default policy (re-read by every CU from L2).
-template <int WQ, int WR, int TQ, int TR, int METRIC, bool SCALE, int NS, int NT_HINT, bool TWO_BAR = false, bool TILED = false>
+// TILED = work-list mode for IVF slabs (tile descriptors + per-group query images).
+template <int WQ, int WR, int TQ, int TR, int METRIC, bool SCALE, int NS, int NT_HINT, bool TILED = false>
 __global__ void __launch_bounds__(WQ * WR * 64, (WQ * WR >= 8) ? (WQ * WR / 4) : 2) k_scan_glds(ScanArgs a) {
     constexpr int NW = WQ * WR;
     constexpr int BQ = WQ * TQ * 32;
     constexpr int BR = WR * TR * 32;
     static_assert(NS >= 3, "ring depth");
-    constexpr int V_BYTES = BR * GL_BK * 4;   // 16 KiB of f32 rows per stage
+    constexpr int V_BYTES = BR * GL_BK * 4;   // f32 rows per stage
     constexpr int Q_BYTES = BQ * GL_BK * 2;   // f16 query slab
     constexpr int STAGE = V_BYTES + Q_BYTES;
     constexpr int V_INSTR = V_BYTES / 1024;
@@ -555,7 +556,7 @@ __global__ void __launch_bounds__(WQ * WR * 64, (WQ * WR >= 8) ? (WQ * WR / 4) :
     static_assert(V_INSTR % NW == 0, "row DMA split");
     constexpr int VPW = V_INSTR / NW;
     constexpr int QPW = (Q_INSTR + NW - 1) / NW;
-    constexpr int OPS = VPW + QPW;             // LDS-DMA instructions per wave per slab
+    constexpr int OPS = VPW + QPW;  // LDS-DMA instructions per wave per slab
     constexpr bool ASC = METRIC != M_IP;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -565,53 +566,74 @@ __global__ void __launch_bounds__(WQ * WR * 64, (WQ * WR >= 8) ? (WQ * WR / 4) :
 
     if (blockIdx.x >= a.ntiles) return;
     const uint32_t my_tiles = (a.ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x;
-    const uint32_t G = my_tiles * a.nslab;
-    const uint32_t last_row = a.row1 - 1;
+    const uint32_t G = my_tiles * a.nslab;  // slab steps of this persistent block
+    const bool ragged_k = (a.ld % GL_BK) != 0;  // last slab reaches past ld: clamp columns (they meet zeros in the query image)
 
-    // ---- per-lane DMA source geometry (constant for the whole kernel)
-    uint32_t v_row[VPW], v_col[VPW];
+    // ---- DMA issue stream: position (tile, slab), ring stage, per-lane source pointers of the tile.
+    // Addresses advance incrementally (one 64-bit add per DMA); everything else is recomputed only at
+    // tile changes — the per-slab SALU/VALU overhead of the first version cost more than the MFMAs.
+    uint32_t v_rowoff[VPW], v_col[VPW];
 #pragma unroll
     for (int j = 0; j < VPW; ++j) {
         const uint32_t r = (wave * VPW + j) * 8 + (lane >> 3);  // row inside the tile
-        const uint32_t p = lane & 7;                            // physical 16-B slot
-        v_row[j] = r;
-        v_col[j] = (p ^ ((r >> 1) & 7)) * 4;                    // logical slot -> f32 column
+        v_rowoff[j] = r;
+        v_col[j] = ((lane & 7) ^ ((r >> 1) & 7)) * 4;            // physical 16-B slot -> logical f32 column
     }
-    uint32_t q_off[QPW];
+    const float* v_src[VPW];  // row pointers (incl. swizzled column) of the tile being issued
+    const char* q_src[QPW];
+    uint32_t q_dst[QPW];
 #pragma unroll
-    for (int j = 0; j < QPW; ++j) q_off[j] = (((wave * QPW + j) % Q_INSTR) * 1024 + lane * 16);
+    for (int j = 0; j < QPW; ++j) q_dst[j] = V_BYTES + ((wave * QPW + j) % Q_INSTR) * 1024;
+    uint32_t is_tile = blockIdx.x, is_slab = 0, is_stage = 0, is_count = 0;
+    uint32_t is_qslab = a.qpad * (GL_BK * 2);
+    uint32_t is_rbase = 0, is_last = 0;
 
-    auto issue = [&](uint32_t g) {
-        // clamp past-the-end steps to the last real one: keeps the per-wave DMA count uniform
-        const uint32_t gg = g < G ? g : G - 1;
-        const uint32_t ti = gg / a.nslab, s = gg - ti * a.nslab;
-        uint32_t rbase = a.row0 + (blockIdx.x + ti * gridDim.x) * BR;
-        uint32_t tile_last = last_row;
+    auto issue_enter_tile = [&]() {
         const char* qbase = reinterpret_cast<const char*>(a.Q16);
-        uint32_t qslab_bytes = a.qpad * (GL_BK * 2);
         if (TILED) {
-            const IvfTile td = a.tiles[blockIdx.x + ti * gridDim.x];  // uniform -> scalar loads
-            rbase = td.row0;
-            tile_last = td.row0 + td.nrows - 1;
+            const IvfTile td = a.tiles[is_tile];  // uniform -> scalar loads
+            is_rbase = td.row0;
+            is_last = td.row0 + td.nrows - 1;
             qbase += (size_t)td.qimg_off * 2;
-            qslab_bytes = BQ * (GL_BK * 2);
+            is_qslab = BQ * (GL_BK * 2);
+        } else {
+            is_rbase = a.row0 + is_tile * BR;
+            is_last = a.row1 - 1;
         }
-        char* stage = smem + (g % NS) * STAGE;
 #pragma unroll
         for (int j = 0; j < VPW; ++j) {
-            uint32_t row = rbase + v_row[j];
-            row = row < tile_last ? row : tile_last;
-            uint32_t col = s * GL_BK + v_col[j];
-            col = col < a.ld ? col : a.ld - 4;
-            const float* src = a.V + (size_t)row * a.ld + col;
-            if (a.debug_flags & 1)  // EXPERIMENT: what a tile-blocked HBM layout would read (wrong results)
-                src = a.V + ((size_t)(blockIdx.x + ti * gridDim.x) * a.nslab + s) * (BR * GL_BK) + (wave * VPW + j) * 256 + lane * 4;
+            uint32_t row = is_rbase + v_rowoff[j];
+            row = row < is_last ? row : is_last;  // clamped rows are masked in the epilogue
+            v_src[j] = a.V + (size_t)row * a.ld + v_col[j];
+        }
+#pragma unroll
+        for (int j = 0; j < QPW; ++j) q_src[j] = qbase + ((wave * QPW + j) % Q_INSTR) * 1024 + lane * 16;
+    };
+    auto issue = [&]() {
+        char* stage = smem + is_stage * STAGE;
+        const uint32_t koff = is_slab * GL_BK;
+#pragma unroll
+        for (int j = 0; j < VPW; ++j) {
+            const float* src = v_src[j] + koff;
+            if (ragged_k) {
+                uint32_t col = koff + v_col[j];
+                col = col < a.ld ? col : a.ld - 4;
+                src = v_src[j] - v_col[j] + col;
+            }
             glds16<NT_HINT>(src, stage + (wave * VPW + j) * 1024);
         }
-        const char* qsrc = qbase + (size_t)s * qslab_bytes;
+        const uint32_t qoff = is_slab * is_qslab;
 #pragma unroll
-        for (int j = 0; j < QPW; ++j)
-            glds16<0>(qsrc + q_off[j], stage + V_BYTES + ((wave * QPW + j) % Q_INSTR) * 1024);
+        for (int j = 0; j < QPW; ++j) glds16<0>(q_src[j] + qoff, stage + q_dst[j]);
+        // advance; past the end the last real step is re-issued (keeps the per-wave DMA count uniform)
+        is_stage = is_stage + 1 == NS ? 0 : is_stage + 1;
+        if (++is_count < G) {
+            if (++is_slab == a.nslab) {
+                is_slab = 0;
+                is_tile += gridDim.x;
+                issue_enter_tile();
+            }
+        }
     };
 
     f32x16 acc[TR][TQ];
@@ -648,52 +670,35 @@ __global__ void __launch_bounds__(WQ * WR * 64, (WQ * WR >= 8) ? (WQ * WR / 4) :
 #pragma unroll
     for (int j = 0; j < TQ; ++j) asm volatile("" : "+v"(c_qinv[j]), "+v"(c_thr[j]), "+v"(c_extra[j]));
 
-    // Ring protocol (two raw barriers per slab, NS-1 slabs always in flight):
-    //   compute(g) -> barrier A (everyone finished reading stage g%NS) -> refill it with slab g+NS
-    //   -> wait until at most (NS-1)*OPS of this wave's DMAs are outstanding (slab g+1 landed)
-    //   -> barrier B (everyone's pieces of slab g+1 landed).
-    // The refill is issued as soon as the stage is free — it does not wait for slab g+1 to arrive.
-    // One-barrier variant (default, measured faster): wait slab g -> barrier -> refill the stage
-    // computed last with slab g+NS-1 -> compute(g).
+    // Ring protocol: wait until at most (NS-2)*OPS of this wave's DMAs are outstanding (slab g landed)
+    // -> ONE raw barrier (everyone's pieces landed, everyone finished slab g-1) -> refill the stage
+    // that was computed last with slab g+NS-1 -> compute slab g.
+    issue_enter_tile();
 #pragma unroll
-    for (int g0 = 0; g0 < (TWO_BAR ? NS : NS - 1); ++g0) issue(g0);
-    if (TWO_BAR) {
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 1) * OPS) : "memory");
-        __builtin_amdgcn_s_barrier();
-    }
+    for (int g0 = 0; g0 < NS - 1; ++g0) issue();
 
-    uint32_t s_in_tile = 0, tile = blockIdx.x;
+    uint32_t s_in_tile = 0, tile = blockIdx.x, c_stage = 0;
     for (uint32_t g = 0; g < G; ++g) {
-        if (!TWO_BAR) {
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * OPS) : "memory");
-            __builtin_amdgcn_s_barrier();
-            issue(g + NS - 1);
-        }
-        const char* st = smem + (g % NS) * STAGE;
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * OPS) : "memory");
+        __builtin_amdgcn_s_barrier();
+        issue();
+
+        const char* st = smem + c_stage * STAGE;
+        c_stage = c_stage + 1 == NS ? 0 : c_stage + 1;
         if (!(a.debug_flags & 4)) {  // EXPERIMENT flag 4: DMA stream only, no LDS reads / MFMA
-            // Issue every LDS read of the slab first (one LDS latency per slab instead of one per
-            // fragment group), then convert + MFMA in consumption order.
-            f32x4 araw[GL_BK / 16][TR][2];
-            half8 bf[GL_BK / 16][TQ];
 #pragma unroll
             for (int kk = 0; kk < GL_BK / 16; ++kk) {
+                half8 bf[TQ];
+                const int lb = (kk * 2 + hi) ^ b_swz;
+#pragma unroll
+                for (int j = 0; j < TQ; ++j)
+                    bf[j] = *reinterpret_cast<const half8*>(st + b_base + j * 32 * (GL_BK * 2) + lb * 16);
                 const int la = (kk * 4 + hi * 2) ^ a_swz;  // physical slot of the first 16 B
 #pragma unroll
                 for (int i = 0; i < TR; ++i) {
                     const char* rp = st + a_base + i * 32 * (GL_BK * 4);
-                    araw[kk][i][0] = *reinterpret_cast<const f32x4*>(rp + la * 16);
-                    araw[kk][i][1] = *reinterpret_cast<const f32x4*>(rp + (la ^ 1) * 16);
-                }
-                const int lb = (kk * 2 + hi) ^ b_swz;
-#pragma unroll
-                for (int j = 0; j < TQ; ++j)
-                    bf[kk][j] = *reinterpret_cast<const half8*>(st + b_base + j * 32 * (GL_BK * 2) + lb * 16);
-            }
-#pragma unroll
-            for (int kk = 0; kk < GL_BK / 16; ++kk) {
-#pragma unroll
-                for (int i = 0; i < TR; ++i) {
-                    const f32x4 x0 = araw[kk][i][0], x1 = araw[kk][i][1];
+                    const f32x4 x0 = *reinterpret_cast<const f32x4*>(rp + la * 16);
+                    const f32x4 x1 = *reinterpret_cast<const f32x4*>(rp + (la ^ 1) * 16);
                     half8 h;
                     if (SCALE) {
                         h[0] = (_Float16)(x0[0] * a.sv); h[1] = (_Float16)(x0[1] * a.sv);
@@ -706,14 +711,9 @@ __global__ void __launch_bounds__(WQ * WR * 64, (WQ * WR >= 8) ? (WQ * WR / 4) :
                     }
 #pragma unroll
                     for (int j = 0; j < TQ; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h, bf[kk][j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h, bf[j], acc[i][j], 0, 0, 0);
                 }
             }
-        }
-
-        if (TWO_BAR) {
-            __builtin_amdgcn_s_barrier();   // A: stage g%NS is free
-            issue(g + NS);
         }
 
         if (++s_in_tile == a.nslab) {
@@ -757,11 +757,6 @@ __global__ void __launch_bounds__(WQ * WR * 64, (WQ * WR >= 8) ? (WQ * WR / 4) :
             }
             s_in_tile = 0;
             tile += gridDim.x;
-        }
-        // extra VM ops of the epilogue only make this wait conservative (in-order retirement)
-        if (TWO_BAR) {
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 1) * OPS) : "memory");
-            __builtin_amdgcn_s_barrier();   // B: slab g+1 is complete in LDS
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the clamped tail DMAs before the LDS is released

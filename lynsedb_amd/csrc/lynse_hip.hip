@@ -768,8 +768,7 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
                 } else if (tile_rows == 256) {
                     static const int waves16 = []() { const char* e = getenv("LYNSE_HIP_SCAN_W16"); return e ? atoi(e) : 2; }();
                     const uint32_t grid = std::min<uint32_t>(a.ntiles, (uint32_t)h->num_cu);
-                    if (waves16 == 1) LY_TRY((launch_scan_glds<4, 4, 2, 2, 3>(a, metric, scale, grid, st)));
-                    else if (waves16 == 2) LY_TRY((launch_scan_glds<2, 4, 4, 2, 3>(a, metric, scale, grid, st)));
+                    if (waves16 == 2) LY_TRY((launch_scan_glds<2, 4, 4, 2, 3>(a, metric, scale, grid, st)));
                     else if (waves16 == 3) LY_TRY((launch_scan_glds<1, 8, 8, 1, 3>(a, metric, scale, grid, st)));
                     else LY_TRY((launch_scan_glds<4, 2, 2, 4, 3>(a, metric, scale, grid, st)));
                 } else {
