@@ -584,9 +584,14 @@ __global__ void __launch_bounds__(WQ * WR * 64, (WQ * WR >= 8) ? (WQ * WR / 4) :
     uint32_t q_dst[QPW];
 #pragma unroll
     for (int j = 0; j < QPW; ++j) q_dst[j] = V_BYTES + ((wave * QPW + j) % Q_INSTR) * 1024;
-    uint32_t is_tile = blockIdx.x, is_slab = 0, is_stage = 0, is_count = 0;
+    uint32_t is_tile = blockIdx.x, is_slab = 0, is_stage = 0, is_count = 0, is_tileseq = 0;
     uint32_t is_qslab = a.qpad * (GL_BK * 2);
     uint32_t is_rbase = 0, is_last = 0;
+    // Per-row norms of a tile (L2: |v|^2, cosine: 1/|v|) travel by LDS-DMA too: one 1-KiB DMA per tile
+    // into a small ring after the stages — an ordinary load in the epilogue would drain the pipeline.
+    constexpr bool NORMS_LDS = !TILED && METRIC != M_IP;
+    constexpr int NORM_RING = NS * STAGE;
+    const float* norm_src = METRIC == M_L2 ? a.vn2 : a.vrinv;
 
     auto issue_enter_tile = [&]() {
         const char* qbase = reinterpret_cast<const char*>(a.Q16);
@@ -599,6 +604,11 @@ __global__ void __launch_bounds__(WQ * WR * 64, (WQ * WR >= 8) ? (WQ * WR / 4) :
         } else {
             is_rbase = a.row0 + is_tile * BR;
             is_last = a.row1 - 1;
+        }
+        if (NORMS_LDS) {
+            if (wave == 0)  // extra VM ops only make the counted waits more conservative (in-order retirement)
+                glds16<0>(norm_src + is_rbase + lane * 4, smem + NORM_RING + (is_tileseq % NS) * 1024);
+            ++is_tileseq;
         }
 #pragma unroll
         for (int j = 0; j < VPW; ++j) {
@@ -677,7 +687,7 @@ __global__ void __launch_bounds__(WQ * WR * 64, (WQ * WR >= 8) ? (WQ * WR / 4) :
 #pragma unroll
     for (int g0 = 0; g0 < NS - 1; ++g0) issue();
 
-    uint32_t s_in_tile = 0, tile = blockIdx.x, c_stage = 0;
+    uint32_t s_in_tile = 0, tile = blockIdx.x, c_stage = 0, c_tileseq = 0;
     for (uint32_t g = 0; g < G; ++g) {
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * OPS) : "memory");
         __builtin_amdgcn_s_barrier();
@@ -717,7 +727,9 @@ __global__ void __launch_bounds__(WQ * WR * 64, (WQ * WR >= 8) ? (WQ * WR / 4) :
         }
 
         if (++s_in_tile == a.nslab) {
-            // ---- epilogue of a finished tile
+            // ---- epilogue of a finished tile: score transform, threshold filter, candidate append.
+            // Two passes: (1) build a per-lane bit mask of passing rows per query column, (2) ONE
+            // returning atomic per (lane, column) reserves the slots, then the keys are written.
             uint32_t rbase = a.row0 + tile * BR;
             uint32_t row_end = a.row1;
             IvfTile td{};
@@ -726,6 +738,19 @@ __global__ void __launch_bounds__(WQ * WR * 64, (WQ * WR >= 8) ? (WQ * WR / 4) :
                 rbase = td.row0;
                 row_end = td.row0 + td.nrows;
             }
+            const float* nrm = reinterpret_cast<const float*>(smem + NORM_RING + (c_tileseq % NS) * 1024);
+            ++c_tileseq;
+            auto score = [&](int i, int j, int r, uint32_t m, bool rok) -> float {
+                float sc = acc[i][j][r] * c_qinv[j];
+                if (METRIC != M_IP) {
+                    float nv;
+                    if (NORMS_LDS) nv = nrm[m - rbase];
+                    else nv = rok ? (METRIC == M_L2 ? a.vn2[m] : a.vrinv[m]) : 0.0f;
+                    if (METRIC == M_L2) sc = nv - 2.0f * sc + c_extra[j];
+                    else sc = 1.0f - sc * nv * c_extra[j];
+                }
+                return sc;
+            };
 #pragma unroll
             for (int j = 0; j < TQ; ++j) {
                 uint32_t n = wq * (TQ * 32) + j * 32 + l32;
@@ -737,23 +762,46 @@ __global__ void __launch_bounds__(WQ * WR * 64, (WQ * WR >= 8) ? (WQ * WR / 4) :
                     if (METRIC == M_L2) c_extra[j] = c_ok[j] ? a.qn2[n] : 0.0f;
                     if (METRIC == M_COS) c_extra[j] = c_ok[j] ? a.qrinv[n] : 0.0f;
                 }
+                if (a.emit_all && !TILED) {  // stage 0: slot = row, no atomics
 #pragma unroll
-                for (int i = 0; i < TR; ++i) {
+                    for (int i = 0; i < TR; ++i)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const uint32_t m = rbase + wr * (TR * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                        const bool rok = m < row_end;
-                        float sc = acc[i][j][r] * c_qinv[j];
-                        if (METRIC == M_L2) sc = (rok ? a.vn2[m] : 0.0f) - 2.0f * sc + c_extra[j];
-                        if (METRIC == M_COS) sc = 1.0f - sc * (rok ? a.vrinv[m] : 0.0f) * c_extra[j];
-                        acc[i][j][r] = 0.0f;
-                        const bool pass = ASC ? (sc <= c_thr[j]) : (sc >= c_thr[j]);
-                        if (c_ok[j] && rok && (a.emit_all || pass)) {
-                            const uint32_t slot = (a.emit_all && !TILED) ? (m - a.row0) : atomicAdd(&a.count[n], 1u);
-                            if (slot < a.cap) a.cand[(size_t)n * a.cap + slot] = make_key(sc, m, ASC);
+                        for (int r = 0; r < 16; ++r) {
+                            const uint32_t m = rbase + wr * (TR * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                            const bool rok = m < row_end;
+                            const float sc = score(i, j, r, m, rok);
+                            if (c_ok[j] && rok && (m - a.row0) < a.cap)
+                                a.cand[(size_t)n * a.cap + (m - a.row0)] = make_key(sc, m, ASC);
+                        }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < TR; ++i) {  // one 32x32 block at a time keeps only 16 scores live
+                        uint32_t msk = 0;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const uint32_t m = rbase + wr * (TR * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                            const bool rok = m < row_end;
+                            const float sc = score(i, j, r, m, rok);
+                            const bool pass = ASC ? (sc <= c_thr[j]) : (sc >= c_thr[j]);
+                            if (c_ok[j] && rok && pass) msk |= 1u << r;
+                        }
+                        if (msk) {
+                            const uint32_t base = atomicAdd(&a.count[n], (uint32_t)__popc(msk));
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) {
+                                if ((msk >> r) & 1u) {
+                                    const uint32_t m = rbase + wr * (TR * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                                    const uint32_t slot = base + (uint32_t)__popc(msk & ((1u << r) - 1u));
+                                    if (slot < a.cap) a.cand[(size_t)n * a.cap + slot] = make_key(score(i, j, r, m, true), m, ASC);
+                                }
+                            }
                         }
                     }
                 }
+#pragma unroll
+                for (int i = 0; i < TR; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
             }
             s_in_tile = 0;
             tile += gridDim.x;

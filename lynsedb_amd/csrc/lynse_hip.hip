@@ -366,8 +366,11 @@ static int finalize_locked(lynse_hip_flat* h) {
     if (h->n > h->stats_capacity) {
         uint64_t cap = std::max<uint64_t>(h->n, h->capacity);
         float *a = nullptr, *b = nullptr;
-        LY_HIP(hipMalloc(&a, (size_t)cap * sizeof(float)));
-        LY_HIP(hipMalloc(&b, (size_t)cap * sizeof(float)));
+        // +256: the scan kernel's per-tile norm DMA reads a whole 256-row window
+        LY_HIP(hipMalloc(&a, ((size_t)cap + 256) * sizeof(float)));
+        LY_HIP(hipMalloc(&b, ((size_t)cap + 256) * sizeof(float)));
+        LY_HIP(hipMemsetAsync(a, 0, ((size_t)cap + 256) * sizeof(float), h->stream));
+        LY_HIP(hipMemsetAsync(b, 0, ((size_t)cap + 256) * sizeof(float), h->stream));
         if (h->n_stats) {
             LY_HIP(hipMemcpyAsync(a, h->vn2, (size_t)h->n_stats * 4, hipMemcpyDeviceToDevice, h->stream));
             LY_HIP(hipMemcpyAsync(b, h->vrinv, (size_t)h->n_stats * 4, hipMemcpyDeviceToDevice, h->stream));
@@ -631,7 +634,7 @@ static int launch_scan_glds(const ScanArgs& a, int metric, bool scale, uint32_t 
     constexpr int NT = WQ * WR * 64;
     constexpr int BQ = WQ * TQ * 32;
     constexpr int BR = WR * TR * 32;
-    const size_t lds = (size_t)NS * (BR * GL_BK * 4 + BQ * GL_BK * 2);
+    const size_t lds = (size_t)NS * (BR * GL_BK * 4 + BQ * GL_BK * 2) + (size_t)NS * 1024;  // + per-tile norm ring
     static bool attr_done[12] = {false};
     static const int nt_hint = []() { const char* e = getenv("LYNSE_HIP_SCAN_NT"); return e ? atoi(e) : 1; }();
     auto go = [&](auto kern, int slot) -> int {

@@ -176,7 +176,9 @@ class ShardedFlat:
         qn = (q * q).sum(1, keepdim=True)
         for r0 in range(0, n_local, chunk):
             nr = min(chunk, n_local - r0)
-            # rows come back from the library's own HBM copy (device-to-device)
+            # rows come back from the library's own HBM copy (device-to-device) on the LIBRARY's stream:
+            # torch work still reading `buf` from the previous chunk must be finished first
+            torch.cuda.synchronize()
             check(lib.lynse_hip_flat_copy_rows_device(self.index.handle, r0, nr, C.c_void_p(buf.data_ptr())))
             v = buf[:nr]
             s = q @ v.T
