@@ -155,10 +155,18 @@ def main():
         scan_s = prof["scan_us"] * 1e-6
         achieved = (prof["scan_bytes"] / scan_s / 1e9) if scan_s > 0 else 0.0
         launches = max(int(prof["scan_launches"]), 1)
+        traffic, traffic_note = None, "no PMC summary under profiles/"
+        try:  # HBM bytes per launch from the committed PMC pass (bench.py itself cannot run rocprofv3 --pmc)
+            pm = json.loads((ROOT / "profiles" / "r01_pmc_traffic.json").read_text())
+            traffic = int(prof["scan_bytes"] // launches * pm["ratio_hbm_over_algorithmic"])
+            traffic_note = "algorithmic bytes x %.4f (FETCH_SIZE, gfx950-corrected; %s)" % (
+                pm["ratio_hbm_over_algorithmic"], "profiles/r01_pmc_traffic.json")
+        except Exception:
+            pass
         roofline = {
             "bound": "hbm", "kernel": "k_scan_f16" if metric < 3 else "k_scan_binary",
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+            "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_note": traffic_note,
             "launches": launches, "avg_launch_us": round(prof["scan_us"] / launches, 2),
             "algorithmic_bytes_per_launch": int(prof["scan_bytes"] // launches),
             "note": "rank-0 shard; bytes = rows scanned x dim x 4 B, time = HIP events around each scan launch",

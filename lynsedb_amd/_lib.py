@@ -9,6 +9,14 @@ from __future__ import annotations
 import ctypes as C
 from pathlib import Path
 
+# PyTorch-ROCm bundles its own HIP runtime.  If liblynse_hip.so pulls in the system libamdhip64 first,
+# a later `import torch` in the same process finds "No HIP GPUs": load torch's runtime first so both
+# share one HIP runtime (torch is used by this package only for device memory / process groups).
+try:  # pragma: no cover - depends on the environment
+    import torch as _torch  # noqa: F401
+except ImportError:  # pure C-ABI use without torch is fine
+    _torch = None
+
 _HERE = Path(__file__).resolve().parent
 LIB_PATH = _HERE / "liblynse_hip.so"
 

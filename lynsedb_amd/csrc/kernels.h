@@ -698,6 +698,7 @@ __global__ void __launch_bounds__(WQ * WR * 64, (WQ * WR >= 8) ? (WQ * WR / 4) :
         if (!(a.debug_flags & 4)) {  // EXPERIMENT flag 4: DMA stream only, no LDS reads / MFMA
 #pragma unroll
             for (int kk = 0; kk < GL_BK / 16; ++kk) {
+                if ((a.debug_flags & 16) && kk == 1) break;  // EXPERIMENT: half the LDS reads + MFMAs
                 half8 bf[TQ];
                 const int lb = (kk * 2 + hi) ^ b_swz;
 #pragma unroll
@@ -719,9 +720,15 @@ __global__ void __launch_bounds__(WQ * WR * 64, (WQ * WR >= 8) ? (WQ * WR / 4) :
                         h[0] = (_Float16)x0[0]; h[1] = (_Float16)x0[1]; h[2] = (_Float16)x0[2]; h[3] = (_Float16)x0[3];
                         h[4] = (_Float16)x1[0]; h[5] = (_Float16)x1[1]; h[6] = (_Float16)x1[2]; h[7] = (_Float16)x1[3];
                     }
+                    if (a.debug_flags & 32) {  // EXPERIMENT: LDS reads + cvt only, no MFMA
+                        asm volatile("" ::"v"(h));
 #pragma unroll
-                    for (int j = 0; j < TQ; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h, bf[j], acc[i][j], 0, 0, 0);
+                        for (int j = 0; j < TQ; ++j) asm volatile("" ::"v"(bf[j]));
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < TQ; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h, bf[j], acc[i][j], 0, 0, 0);
+                    }
                 }
             }
         }

@@ -634,7 +634,7 @@ static int launch_scan_glds(const ScanArgs& a, int metric, bool scale, uint32_t 
     constexpr int NT = WQ * WR * 64;
     constexpr int BQ = WQ * TQ * 32;
     constexpr int BR = WR * TR * 32;
-    const size_t lds = (size_t)NS * (BR * GL_BK * 4 + BQ * GL_BK * 2) + (size_t)NS * 1024;  // + per-tile norm ring
+    const size_t lds = (size_t)NS * (BR * GL_BK * 4 + BQ * GL_BK * 2) + (metric == M_IP ? 0 : (size_t)NS * 1024);  // + per-tile norm ring
     static bool attr_done[12] = {false};
     static const int nt_hint = []() { const char* e = getenv("LYNSE_HIP_SCAN_NT"); return e ? atoi(e) : 1; }();
     auto go = [&](auto kern, int slot) -> int {
@@ -755,7 +755,8 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
             ScanArgs a{};
             a.V = h->rows; a.ld = h->ld; a.D = h->dim; a.row0 = s.r0; a.row1 = s.r1; a.Q16 = w.Q16;
             static const int big_rows = []() { const char* e = getenv("LYNSE_HIP_SCAN_BR"); return e ? atoi(e) : 256; }();
-            const uint32_t tile_rows = (glds && !small && big_rows == 256) ? 256u : (uint32_t)SCAN_BR;
+            uint32_t tile_rows = (glds && !small && big_rows == 256) ? 256u : (uint32_t)SCAN_BR;
+            if (glds && !small && big_rows == 192 && metric == M_IP) tile_rows = 192u;
             a.qpad = qpad; a.nq = nq; a.nslab = nslab; a.ntiles = (s.r1 - s.r0 + tile_rows - 1) / tile_rows;
             a.qinv = w.qinv; a.qn2 = w.qn2; a.qrinv = w.qrinv; a.thr = w.thr; a.vn2 = h->vn2; a.vrinv = h->vrinv;
             a.sv = h->sv; a.cand = w.cand; a.count = w.count; a.cap = w.cap; a.emit_all = emit_all ? 1 : 0;
@@ -768,6 +769,9 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
                 if (small) {
                     const uint32_t grid = std::min<uint32_t>(a.ntiles, (uint32_t)h->num_cu * 2);
                     LY_TRY((launch_scan_glds<1, 4, 1, 1, 4>(a, metric, scale, grid, st)));
+                } else if (tile_rows == 192) {
+                    const uint32_t grid = std::min<uint32_t>(a.ntiles, (uint32_t)h->num_cu);
+                    LY_TRY((launch_scan_glds<4, 2, 2, 3, 4>(a, metric, scale, grid, st)));
                 } else if (tile_rows == 256) {
                     static const int waves16 = []() { const char* e = getenv("LYNSE_HIP_SCAN_W16"); return e ? atoi(e) : 2; }();
                     const uint32_t grid = std::min<uint32_t>(a.ntiles, (uint32_t)h->num_cu);

@@ -323,3 +323,76 @@ def test_collection_surface_like_flat_search_bench(L, oracle, tmp_path):
     res = coll.search((query > 0.5).astype(f32), 5)
     e_ids, e_d = oracle.canonical_topk((query > 0.5).astype(f32), data, 5, HAM)
     assert np.array_equal(res.ids(), e_ids.astype(np.int64)) and np.array_equal(res.distances(), e_d)
+
+
+# ------------------------------------------------------------------ multi-GPU exchange pieces on one GPU
+
+@pytest.mark.parametrize("metric", [IP, L2, HAM])
+@pytest.mark.parametrize("world,nq,k", [(1, 3, 10), (2, 7, 10), (8, 256, 10), (8, 5, 100), (4, 33, 1)])
+def test_device_merge_matches_host_merge(L, oracle, metric, world, nq, k):
+    """k_merge (device k-way merge after the RCCL all-gather) == lynse_hip_merge_topk (host) == the
+    oracle's VectorStore::merge_results order, with ties and short blocks."""
+    import ctypes as C
+
+    import torch
+
+    from lynsedb_amd.sharded import ShardedFlat, block_layout
+
+    rng = np.random.default_rng(world * 100 + nq + k)
+    ro, do, co, total = block_layout(nq, k)
+    blocks, per_rank = [], []
+    for r in range(world):
+        rows = (rng.permutation(nq * k).reshape(nq, k).astype(np.uint64) * world + r)
+        d = rng.integers(0, 5, size=(nq, k)).astype(f32)  # heavy ties
+        d.sort(axis=1)
+        if metric == IP:
+            d = d[:, ::-1].copy()
+        c = rng.integers(0, k + 1, size=nq).astype(np.uint32)
+        per_rank.append((rows, d, c))
+        blocks.append(ShardedFlat.pack_block(rows, d, c))
+    gathered = torch.as_tensor(np.concatenate(blocks), device="cuda")
+    out_r = torch.zeros((nq, k), dtype=torch.int64, device="cuda")
+    out_d = torch.zeros((nq, k), dtype=torch.float32, device="cuda")
+    out_c = torch.zeros(nq, dtype=torch.int32, device="cuda")
+    L._lib.check(L._lib.lib.lynse_hip_merge_topk_device(
+        C.c_void_p(gathered.data_ptr()), total, ro, do, co, world, nq, k, metric, C.c_void_p(out_r.data_ptr()),
+        C.c_void_p(out_d.data_ptr()), C.c_void_p(out_c.data_ptr()), None))
+    torch.cuda.synchronize()
+    g_r, g_d, g_c = out_r.cpu().numpy().view(np.uint64), out_d.cpu().numpy(), out_c.cpu().numpy().view(np.uint32)
+    for q in range(nq):
+        ids = np.stack([per_rank[r][0][q] for r in range(world)])
+        ds = np.stack([per_rank[r][1][q] for r in range(world)])
+        cs = np.array([per_rank[r][2][q] for r in range(world)], np.uint32)
+        h_i, h_d = L.merge_topk(ids, ds, cs, k, metric)
+        flat_i = np.concatenate([ids[r, :cs[r]] for r in range(world)])
+        flat_d = np.concatenate([ds[r, :cs[r]] for r in range(world)])
+        o_i, o_d = oracle.merge_results(flat_i, flat_d, k, metric) if flat_i.size else (np.zeros(0, np.uint64), np.zeros(0, f32))
+        assert int(g_c[q]) == len(h_i) == len(o_i)
+        assert np.array_equal(g_r[q, :len(h_i)], h_i) and np.array_equal(h_i, o_i)
+        assert np.array_equal(g_d[q, :len(h_i)], h_d) and np.array_equal(h_d, o_d)
+
+
+def test_sharded_flat_world1_and_row_map(L, oracle):
+    """ShardedFlat on one rank (device-resident queries/outputs) + the shard row map g = l*stride+offset."""
+    import torch
+
+    from lynsedb_amd.sharded import ShardedFlat
+
+    rng = np.random.default_rng(12)
+    n, dim, k = 9000, 40, 10
+    data = rng.random((n, dim), dtype=f32)
+    sh = ShardedFlat(dim, rank=0, world=1, device=0, group=None)
+    sh.add_global_rows(data)
+    q = rng.random((6, dim), dtype=f32)
+    rows, dists, counts = sh.search(q, k, IP)
+    for i in range(6):
+        e_i, e_d = oracle.canonical_topk(q[i], data, k, IP)
+        assert np.array_equal(rows[i].astype(np.uint32), e_i) and np.array_equal(dists[i], e_d)
+    # emulate rank 1 of 3: local rows are global rows 1, 4, 7, ...; returned ids must be global
+    part = L.FlatIndex(None, dim, 0)
+    part.set_row_map(3, 1)
+    part.write(np.ascontiguousarray(data[1::3]))
+    r, d, c = part.search_batch_arrays(q[:2], k, "l2")
+    for i in range(2):
+        e_i, e_d = oracle.canonical_topk(q[i], np.ascontiguousarray(data[1::3]), k, L2)
+        assert np.array_equal(r[i], e_i.astype(np.uint64) * 3 + 1) and np.array_equal(d[i], e_d)
