@@ -12,7 +12,7 @@ RCCL all-gather and merged on the device: total work is fixed -> "scaling": "str
 Inputs (rows and queries) are resident in HBM before the timed region; the timed region is bracketed
 by barrier + torch.cuda.synchronize() and the MAX over ranks is reported.
 
-Extra objects on the JSON line: "roofline" (dominant kernel k_scan_f16 — algorithmic bytes / HIP-event
+Extra objects on the JSON line: "roofline" (dominant kernel k_scan_glds — algorithmic bytes / HIP-event
 duration measured on the launch stream during the timed region) and "cpu_baseline" (the oracle's
 restatement of the reference's rayon scan, timed on this host's cores over a bounded row sample).
 """
@@ -51,6 +51,8 @@ def parse_args():
     p.add_argument("--cpu-queries", type=int, default=8)
     p.add_argument("--no-verify", action="store_true")
     p.add_argument("--verify-queries", type=int, default=16)
+    p.add_argument("--stage0", type=int, default=0, help="override the stage-0 row count of the scan plan")
+    p.add_argument("--growth", type=int, default=0, help="override the stage growth factor of the scan plan")
     return p.parse_args()
 
 
@@ -92,6 +94,8 @@ def main():
     sh = ShardedFlat(D, rank=rank, world=world, device=local_rank, group=dist)
     n_local = (N - rank + world - 1) // world if N > rank else 0
     sh.index.reserve(max(n_local, 1))
+    if args.stage0 or args.growth:
+        sh.index.set_plan(args.stage0 or 4096, args.growth or 8, 8192)
     qrng = np.random.default_rng(args.seed + 7)
     q_rows = np.sort(qrng.integers(0, N, size=B))
     q_src = torch.empty((B, D), device=dev, dtype=torch.float32)
@@ -164,7 +168,7 @@ def main():
         except Exception:
             pass
         roofline = {
-            "bound": "hbm", "kernel": "k_scan_f16" if metric < 3 else "k_scan_binary",
+            "bound": "hbm", "kernel": "k_scan_glds" if metric < 3 else "k_scan_binary",
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_note": traffic_note,
             "launches": launches, "avg_launch_us": round(prof["scan_us"] / launches, 2),

@@ -320,6 +320,7 @@ struct ScanArgs {
     // f16 image starts at Q16 + qimg_off halves; local query n of the group is query pair_q[pair0+n]
     const struct IvfTile* tiles;
     const uint32_t* pair_q;
+    unsigned long long* dbg;  // debug_flags & 64: per-block phase cycle sums [block][wave][4]: wait, barrier, issue, compute
 };
 
 struct IvfTile {
@@ -619,23 +620,28 @@ __global__ void __launch_bounds__(WQ * WR * 64, (WQ * WR >= 8) ? (WQ * WR / 4) :
 #pragma unroll
         for (int j = 0; j < QPW; ++j) q_src[j] = qbase + ((wave * QPW + j) % Q_INSTR) * 1024 + lane * 16;
     };
-    auto issue = [&]() {
+    // One DMA piece (1 KiB per wave) of the slab at the issue position: pieces 0..VPW-1 are row pieces,
+    // VPW..OPS-1 query-image pieces.  Pieces are interleaved with the MFMA groups of the compute phase:
+    // a global_load_lds stalls ~100 cycles at issue when all waves fire at once (measured 500-1000
+    // cycles per slab right after the barrier) — behind MFMAs that stall is hidden.
+    auto issue_piece = [&](int p) {
         char* stage = smem + is_stage * STAGE;
-        const uint32_t koff = is_slab * GL_BK;
-#pragma unroll
-        for (int j = 0; j < VPW; ++j) {
-            const float* src = v_src[j] + koff;
+        if (p < VPW) {
+            const uint32_t koff = is_slab * GL_BK;
+            const float* src = v_src[p] + koff;
             if (ragged_k) {
-                uint32_t col = koff + v_col[j];
+                uint32_t col = koff + v_col[p];
                 col = col < a.ld ? col : a.ld - 4;
-                src = v_src[j] - v_col[j] + col;
+                src = v_src[p] - v_col[p] + col;
             }
-            glds16<NT_HINT>(src, stage + (wave * VPW + j) * 1024);
+            glds16<NT_HINT>(src, stage + (wave * VPW + p) * 1024);
+        } else {
+            const int j = p - VPW;
+            glds16<0>(q_src[j] + is_slab * is_qslab, stage + q_dst[j]);
         }
-        const uint32_t qoff = is_slab * is_qslab;
-#pragma unroll
-        for (int j = 0; j < QPW; ++j) glds16<0>(q_src[j] + qoff, stage + q_dst[j]);
-        // advance; past the end the last real step is re-issued (keeps the per-wave DMA count uniform)
+    };
+    auto issue_advance = [&]() {
+        // past the end the last real step is re-issued (keeps the per-wave DMA count uniform)
         is_stage = is_stage + 1 == NS ? 0 : is_stage + 1;
         if (++is_count < G) {
             if (++is_slab == a.nslab) {
@@ -644,6 +650,11 @@ __global__ void __launch_bounds__(WQ * WR * 64, (WQ * WR >= 8) ? (WQ * WR / 4) :
                 issue_enter_tile();
             }
         }
+    };
+    auto issue = [&]() {
+#pragma unroll
+        for (int p = 0; p < OPS; ++p) issue_piece(p);
+        issue_advance();
     };
 
     f32x16 acc[TR][TQ];
@@ -688,10 +699,14 @@ __global__ void __launch_bounds__(WQ * WR * 64, (WQ * WR >= 8) ? (WQ * WR / 4) :
     for (int g0 = 0; g0 < NS - 1; ++g0) issue();
 
     uint32_t s_in_tile = 0, tile = blockIdx.x, c_stage = 0, c_tileseq = 0;
+    const bool timing = (a.debug_flags & 64) && a.dbg;
+    unsigned long long t_wait = 0, t_bar = 0, t_issue = 0, t_comp = 0, tp = timing ? __builtin_amdgcn_s_memtime() : 0;
     for (uint32_t g = 0; g < G; ++g) {
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * OPS) : "memory");
+        if (timing) { const unsigned long long t = __builtin_amdgcn_s_memtime(); t_wait += t - tp; tp = t; }
         __builtin_amdgcn_s_barrier();
-        issue();
+        if (timing) { const unsigned long long t = __builtin_amdgcn_s_memtime(); t_bar += t - tp; tp = t; }
+        if (a.debug_flags & 4) issue();  // DMA-only experiment: no compute phase to interleave with
 
         const char* st = smem + c_stage * STAGE;
         c_stage = c_stage + 1 == NS ? 0 : c_stage + 1;
@@ -729,8 +744,29 @@ __global__ void __launch_bounds__(WQ * WR * 64, (WQ * WR >= 8) ? (WQ * WR / 4) :
                         for (int j = 0; j < TQ; ++j)
                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h, bf[j], acc[i][j], 0, 0, 0);
                     }
+                    // refill pieces scheduled behind this MFMA group (slot kk*TR+i of NSLOT)
+                    {
+                        constexpr int NSLOT = (GL_BK / 16) * TR;
+                        const int slot = kk * TR + i;
+                        if (a.debug_flags & 128) {  // EXPERIMENT: all pieces behind the first MFMA group
+                            if (slot == 0) {
+#pragma unroll
+                                for (int p = 0; p < OPS; ++p) issue_piece(p);
+                            }
+                        } else if (a.debug_flags & 256) {  // EXPERIMENT: all pieces behind the last MFMA group
+                            if (slot == NSLOT - 1) {
+#pragma unroll
+                                for (int p = 0; p < OPS; ++p) issue_piece(p);
+                            }
+                        } else {
+#pragma unroll
+                            for (int p = 0; p < OPS; ++p)
+                                if (p % NSLOT == slot) issue_piece(p);
+                        }
+                    }
                 }
             }
+            issue_advance();
         }
 
         if (++s_in_tile == a.nslab) {
@@ -813,6 +849,14 @@ __global__ void __launch_bounds__(WQ * WR * 64, (WQ * WR >= 8) ? (WQ * WR / 4) :
             s_in_tile = 0;
             tile += gridDim.x;
         }
+        if (timing) {
+            asm volatile("" ::"v"(acc[0][0][0]));
+            const unsigned long long t = __builtin_amdgcn_s_memtime(); t_comp += t - tp; tp = t;
+        }
+    }
+    if (timing && lane == 0) {
+        unsigned long long* o = a.dbg + ((size_t)blockIdx.x * NW + wave) * 4;
+        o[0] = t_wait; o[1] = t_bar; o[2] = t_issue; o[3] = t_comp;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the clamped tail DMAs before the LDS is released
 }

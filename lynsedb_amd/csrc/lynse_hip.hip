@@ -660,6 +660,12 @@ static int launch_scan_glds(const ScanArgs& a, int metric, bool scale, uint32_t 
 #undef LY_GO
 }
 
+static unsigned long long* g_dbg_ptr = nullptr;
+extern "C" int lynse_hip_debug_phase_cycles(unsigned long long* out, int n) {  // experiments only (not in the header)
+    if (!g_dbg_ptr) return 1;
+    return hipMemcpy(out, g_dbg_ptr, (size_t)n * 8, hipMemcpyDeviceToHost) == hipSuccess ? 0 : 2;
+}
+
 // 0 = LDS-DMA ring kernel (default), 1 / 2 = register-staged kernel with prefetch depth 1 / 2
 static int scan_variant() {
     static const int v = []() { const char* e = getenv("LYNSE_HIP_SCAN_VARIANT"); return e ? atoi(e) : 0; }();
@@ -763,6 +769,15 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
             static const int dbg = []() { const char* e = getenv("LYNSE_HIP_DEBUG_FLAGS"); return e ? atoi(e) : 0; }();
             a.debug_flags = dbg;
             if (dbg & 2) a.emit_all = 0;
+            if (dbg & 64) {  // phase timing of the LAST (largest) stage: 256 blocks x 8 waves x 4 counters, printed by the host
+                static unsigned long long* d_dbg = nullptr;
+                if (!d_dbg) LY_HIP(hipMalloc(&d_dbg, 4096 * 32 * 8));
+                LY_HIP(hipMemsetAsync(d_dbg, 0, 4096 * 32 * 8, st));
+                a.dbg = d_dbg;
+                if (si + 1 == plan.size()) {
+                    g_dbg_ptr = d_dbg;
+                }
+            }
             const int variant = scan_variant();
             if (glds) {
                 const bool scale = h->sv != 1.0f;
