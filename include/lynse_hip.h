@@ -179,7 +179,11 @@ int lynse_hip_merge_topk_device(const void *d_blocks, uint64_t block_bytes, uint
 
 /* Build from host rows with device k-means (kmeans.rs:74-139 semantics: FastRng(42) init,
  * Lloyd <= max_iter, empty-cluster reseed, final re-assign).  routing follows ivf.rs:81-87
- * (`l2_partitions` = 1 forces L2 Voronoi cells like IvfFlatMmap::build, ivf_flat_mmap.rs:98). */
+ * (`l2_partitions` = 1 forces L2 Voronoi cells like IvfFlatMmap::build, ivf_flat_mmap.rs:98).
+ * A binary metric (hamming / jaccard / dice / tanimoto) builds the IVF-*-BINARY mode
+ * (src/index/mod.rs:376-385, ivf.rs:147-175): BinaryQuantizer::fit on the device (quantizer/mod.rs:321-356:
+ * 0.5 for {0,1} corpora, else per-dimension median with midrange fallback), rows stored as their {0,1}
+ * codes + packed u64 words, k-means and routing with L2 on the codes, packed popcount list scans. */
 int lynse_hip_ivf_build(const float *rows, uint64_t n, uint32_t dim, uint32_t nlist,
                         uint32_t max_iter, int metric, int l2_partitions, int device,
                         lynse_hip_ivf **out);
@@ -187,6 +191,13 @@ int lynse_hip_ivf_build(const float *rows, uint64_t n, uint32_t dim, uint32_t nl
 int lynse_hip_ivf_load(const float *rows, uint64_t n, uint32_t dim, const float *centroids,
                        uint32_t nlist, const uint32_t *assignments, int metric, int device,
                        lynse_hip_ivf **out);
+/* Binary-metric load: `rows` are the RAW rows, binarised on the device with `thresholds` (dim floats,
+ * BinaryQuantizer state) before the slabs are laid out. */
+int lynse_hip_ivf_load_binary(const float *rows, uint64_t n, uint32_t dim, const float *centroids,
+                              uint32_t nlist, const uint32_t *assignments, int metric,
+                              const float *thresholds, int device, lynse_hip_ivf **out);
+/* Fitted BinaryQuantizer state of a binary index: thresholds[dim], already_binary flag. */
+int lynse_hip_ivf_thresholds(const lynse_hip_ivf *h, float *thresholds, int *already_binary);
 int lynse_hip_ivf_destroy(lynse_hip_ivf *h);
 uint64_t lynse_hip_ivf_len(const lynse_hip_ivf *h);
 uint32_t lynse_hip_ivf_nlist(const lynse_hip_ivf *h);

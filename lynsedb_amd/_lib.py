@@ -77,6 +77,8 @@ SIGNATURES = {
                                               C.c_uint64, C.c_uint32, C.c_int, _vp, _vp, _vp, _vp]),
     "lynse_hip_ivf_build": (C.c_int, [_vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_int, C.POINTER(_vp)]),
     "lynse_hip_ivf_load": (C.c_int, [_vp, C.c_uint64, C.c_uint32, _vp, C.c_uint32, _vp, C.c_int, C.c_int, C.POINTER(_vp)]),
+    "lynse_hip_ivf_load_binary": (C.c_int, [_vp, C.c_uint64, C.c_uint32, _vp, C.c_uint32, _vp, C.c_int, _vp, C.c_int, C.POINTER(_vp)]),
+    "lynse_hip_ivf_thresholds": (C.c_int, [_vp, _vp, C.POINTER(C.c_int)]),
     "lynse_hip_ivf_destroy": (C.c_int, [_vp]),
     "lynse_hip_ivf_len": (C.c_uint64, [_vp]),
     "lynse_hip_ivf_nlist": (C.c_uint32, [_vp]),

@@ -257,20 +257,32 @@ class IvfFlatIndex:
             raise IOError("IVF requires at least as many vectors as partitions")
         h = C.c_void_p()
         dev = default_device() if device is None else int(device)
+        if m >= 3:  # IVF-HAMMING/JACCARD-BINARY (src/index/mod.rs:376-385) is an IVFIndex mode: no IvfFlat L2 cells
+            l2_partitions = False
         check(lib.lynse_hip_ivf_build(_ptr(a), a.shape[0], dim, n_partitions, n_iters, m,
                                       1 if l2_partitions else 0, dev, C.byref(h)))
         return IvfFlatIndex(h, dim)
 
     @staticmethod
     def load(data, centroids, assignments, metric: str = "ip", device: Optional[int] = None,
-             ivfflat_routing: bool = False) -> "IvfFlatIndex":
-        """Assemble from given centroids + assignments (parity tests feed the oracle's k-means output)."""
+             ivfflat_routing: bool = False, thresholds=None) -> "IvfFlatIndex":
+        """Assemble from given centroids + assignments (parity tests feed the oracle's k-means output).
+        Binary metrics also take the BinaryQuantizer thresholds (`data` = the raw rows)."""
         m = metric_from_str(metric)
         a = _f32(data, 2, "data")
         c = _f32(centroids, 2, "centroids")
         asg = np.ascontiguousarray(assignments, dtype=np.uint32)
         h = C.c_void_p()
         dev = default_device() if device is None else int(device)
+        if m >= 3:
+            if thresholds is None:
+                raise ValueError("binary metrics need the BinaryQuantizer thresholds")
+            t = _f32(thresholds, 1, "thresholds")
+            if t.size != a.shape[1]:
+                raise ValueError("thresholds dimension mismatch")
+            check(lib.lynse_hip_ivf_load_binary(_ptr(a), a.shape[0], a.shape[1], _ptr(c), c.shape[0], _ptr(asg), m, _ptr(t),
+                                                dev, C.byref(h)))
+            return IvfFlatIndex(h, a.shape[1])
         check(lib.lynse_hip_ivf_load(_ptr(a), a.shape[0], a.shape[1], _ptr(c), c.shape[0], _ptr(asg), m, dev, C.byref(h)))
         idx = IvfFlatIndex(h, a.shape[1])
         if ivfflat_routing:
@@ -296,6 +308,13 @@ class IvfFlatIndex:
         orig = np.empty(n, np.uint32)
         check(lib.lynse_hip_ivf_export(self._h, _ptr(cen), _ptr(asg), _ptr(off), _ptr(orig)))
         return cen, asg, off, orig
+
+    def thresholds(self):
+        """Binary index: (BinaryQuantizer thresholds f32[dim], already_binary)."""
+        t = np.empty(self._dim, np.float32)
+        ab = C.c_int(0)
+        check(lib.lynse_hip_ivf_thresholds(self._h, _ptr(t), C.byref(ab)))
+        return t, bool(ab.value)
 
     def search_batch_arrays(self, queries, k: int, nprobe: int):
         q = _f32(queries, 2, "queries")

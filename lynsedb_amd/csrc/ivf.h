@@ -142,4 +142,181 @@ __global__ void __launch_bounds__(256) k_kmeans_minrank(const float* __restrict_
     if (g == 0 && rank < min_rank[row]) min_rank[row] = rank;
 }
 
+// ------------------------------------------------------------------------------------------------
+// BinaryQuantizer (src/quantizer/mod.rs:286-413) for IVF-*-BINARY.
+//   k_bq_colstats : per column min / max and "all values are 0 or 1" flag
+//   k_bq_median   : column[n/2] of the ascending-sorted column by 4-pass radix select on the
+//                   order-preserving u32 image of the floats (one workgroup per column)
+//   k_bq_binarize : out = value > threshold[d] ? 1 : 0   (decode(encode(x)), :359-393)
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_bq_colstats(const float* __restrict__ V, uint32_t ld, uint32_t D, uint64_t n,
+                                                     float* __restrict__ cmin, float* __restrict__ cmax,
+                                                     uint32_t* __restrict__ not_binary) {
+    __shared__ float smin[256], smax[256];
+    __shared__ uint32_t snb;
+    const uint32_t d = blockIdx.x;
+    if (threadIdx.x == 0) snb = 0;
+    __syncthreads();
+    float mn = LY_INF, mx = -LY_INF;
+    uint32_t nb = 0;
+    for (uint64_t i = threadIdx.x; i < n; i += 256) {
+        const float v = V[i * ld + d];
+        mn = fminf(mn, v);
+        mx = fmaxf(mx, v);
+        nb |= !(v == 0.0f || v == 1.0f);
+    }
+    smin[threadIdx.x] = mn;
+    smax[threadIdx.x] = mx;
+    if (nb) atomicOr(&snb, 1u);
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) {
+            smin[threadIdx.x] = fminf(smin[threadIdx.x], smin[threadIdx.x + o]);
+            smax[threadIdx.x] = fmaxf(smax[threadIdx.x], smax[threadIdx.x + o]);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        cmin[d] = smin[0];
+        cmax[d] = smax[0];
+        if (snb) atomicOr(not_binary, 1u);
+    }
+}
+
+__global__ void __launch_bounds__(256) k_bq_median(const float* __restrict__ V, uint32_t ld, uint32_t D, uint64_t n,
+                                                   float* __restrict__ med) {
+    __shared__ uint32_t hist[256];
+    __shared__ uint32_t s_prefix, s_mask;
+    __shared__ uint64_t s_rank;
+    const uint32_t d = blockIdx.x;
+    if (threadIdx.x == 0) { s_prefix = 0; s_mask = 0; s_rank = n / 2; }
+    for (int shift = 24; shift >= 0; shift -= 8) {
+        hist[threadIdx.x] = 0;
+        __syncthreads();
+        const uint32_t prefix = s_prefix, mask = s_mask;
+        for (uint64_t i = threadIdx.x; i < n; i += 256) {
+            float v = V[i * ld + d];
+            v = v + 0.0f;  // -0.0 and +0.0 compare equal in the reference's partial_cmp
+            const uint32_t u = f32_to_ord(v);
+            if ((u & mask) == prefix) atomicAdd(&hist[(u >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint64_t rank = s_rank, cum = 0;
+            uint32_t b = 0;
+            for (; b < 256; ++b) {
+                if (cum + hist[b] > rank) break;
+                cum += hist[b];
+            }
+            s_rank = rank - cum;
+            s_prefix = prefix | (b << shift);
+            s_mask = mask | (255u << shift);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) med[d] = ord_to_f32(s_prefix);
+}
+
+__global__ void __launch_bounds__(256) k_bq_binarize(const float* __restrict__ V, uint32_t ld_in, uint32_t D, uint64_t n,
+                                                     const float* __restrict__ thr, float* __restrict__ out, uint32_t ld_out) {
+    const uint64_t total = n * D;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t r = i / D;
+        const uint32_t d = (uint32_t)(i % D);
+        out[r * ld_out + d] = V[r * ld_in + d] > thr[d] ? 1.0f : 0.0f;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_scan_binary_tiled: packed-binary slab scan for IVF (work-list mode of k_scan_binary).  One
+// workgroup walks tiles; per tile the <=32 packed queries of the group and their thresholds are staged
+// in LDS; eight lanes own one row.  Non-strict threshold (slab order is not id order).
+// ------------------------------------------------------------------------------------------------
+struct BinTileArgs {
+    const uint64_t* P;
+    uint32_t W;
+    const uint64_t* QW;  // batch packed queries, nq x W
+    const IvfTile* tiles;
+    uint32_t ntiles;
+    const uint32_t* pair_q;
+    const uint32_t* orig;  // slab position -> original row: the keys carry ORIGINAL rows (no rescoring needs the position)
+    const float* thr;
+    uint64_t* cand;
+    uint32_t* count;
+    uint32_t cap;
+};
+
+template <int KIND>
+__global__ void __launch_bounds__(256) k_scan_binary_tiled(BinTileArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint64_t* qw = reinterpret_cast<uint64_t*>(smem);               // 32 * W
+    float* thr_l = reinterpret_cast<float*>(qw + (size_t)32 * a.W);   // 32
+    uint32_t* qid_l = reinterpret_cast<uint32_t*>(thr_l + 32);        // 32
+    const int tid = threadIdx.x, g = tid & 7;
+    const uint32_t nchunks = (a.W + 15) / 16;
+    for (uint32_t t = blockIdx.x; t < a.ntiles; t += gridDim.x) {
+        const IvfTile td = a.tiles[t];
+        __syncthreads();
+        for (uint32_t i = tid; i < td.nq; i += 256) {
+            const uint32_t q = a.pair_q[td.pair0 + i];
+            qid_l[i] = q;
+            thr_l[i] = a.thr[q];
+        }
+        __syncthreads();
+        for (uint32_t i = tid; i < td.nq * a.W; i += 256) qw[i] = a.QW[(size_t)qid_l[i / a.W] * a.W + (i % a.W)];
+        __syncthreads();
+        for (uint32_t rb = 0; rb < td.nrows; rb += 32) {
+            const uint32_t lr = rb + (tid >> 3);
+            const bool valid = lr < td.nrows;
+            const uint32_t row = td.row0 + lr;
+            uint64_t rw[2 * BIN_MAX_CHUNKS];
+#pragma unroll
+            for (int c = 0; c < BIN_MAX_CHUNKS; ++c) {
+                const uint32_t w0 = 2 * (g + 8 * c);
+                rw[2 * c] = (valid && (uint32_t)c < nchunks && w0 < a.W) ? a.P[(size_t)row * a.W + w0] : 0ull;
+                rw[2 * c + 1] = (valid && (uint32_t)c < nchunks && w0 + 1 < a.W) ? a.P[(size_t)row * a.W + w0 + 1] : 0ull;
+            }
+            uint32_t popr = 0;
+            if (KIND == 2) {
+#pragma unroll
+                for (int c = 0; c < 2 * BIN_MAX_CHUNKS; ++c) popr += __popcll(rw[c]);
+            }
+            for (uint32_t q = 0; q < td.nq; ++q) {
+                uint32_t c0 = 0, c1 = 0;
+#pragma unroll
+                for (int c = 0; c < BIN_MAX_CHUNKS; ++c) {
+                    const uint32_t w0 = 2 * (g + 8 * c);
+                    if ((uint32_t)c < nchunks) {
+                        const uint64_t x0 = w0 < a.W ? qw[(size_t)q * a.W + w0] : 0ull;
+                        const uint64_t x1 = w0 + 1 < a.W ? qw[(size_t)q * a.W + w0 + 1] : 0ull;
+                        if (KIND == 0) {
+                            c0 += __popcll(x0 ^ rw[2 * c]) + __popcll(x1 ^ rw[2 * c + 1]);
+                        } else if (KIND == 1) {
+                            c0 += __popcll(x0 & rw[2 * c]) + __popcll(x1 & rw[2 * c + 1]);
+                            c1 += __popcll(x0 | rw[2 * c]) + __popcll(x1 | rw[2 * c + 1]);
+                        } else {
+                            c0 += __popcll(x0 & rw[2 * c]) + __popcll(x1 & rw[2 * c + 1]);
+                            c1 += __popcll(x0) + __popcll(x1);
+                        }
+                    }
+                }
+                if (KIND == 2) c1 += popr;
+                c0 += __shfl_xor(c0, 1, 8); c0 += __shfl_xor(c0, 2, 8); c0 += __shfl_xor(c0, 4, 8);
+                if (KIND != 0) { c1 += __shfl_xor(c1, 1, 8); c1 += __shfl_xor(c1, 2, 8); c1 += __shfl_xor(c1, 4, 8); }
+                if (g == 0 && valid) {
+                    float dist;
+                    if (KIND == 0) dist = (float)c0;
+                    else if (KIND == 1) dist = c1 == 0 ? 0.0f : __fsub_rn(1.0f, __fdiv_rn((float)c0, (float)c1));
+                    else dist = c1 == 0 ? 0.0f : __fsub_rn(1.0f, __fdiv_rn((float)(2u * c0), (float)c1));
+                    if (dist <= thr_l[q]) {
+                        const uint32_t qid = qid_l[q];
+                        const uint32_t slot = atomicAdd(&a.count[qid], 1u);
+                        if (slot < a.cap) a.cand[(size_t)qid * a.cap + slot] = make_key(dist, a.orig[row], true);
+                    }
+                }
+            }
+        }
+    }
+}
+
 }  // namespace lynse

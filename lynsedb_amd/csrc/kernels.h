@@ -1017,7 +1017,7 @@ struct SelectArgs {
     uint32_t k, cap, keep_max;
     int metric, ip_form, exact;
     int emit_all_n;  // >=0: stage 0 wrote exactly this many keys per query
-    int keep_ties;   // IVF: key rows are slab positions, not ids -> an exact cut must keep every tie of the k-th score
+    int keep_ties;   // IVF: rows are not scanned in id order -> the cut must let ties of the k-th score through
     const float* Qf;
     const float* V;
     uint32_t ld, D;
@@ -1047,7 +1047,10 @@ __global__ void __launch_bounds__(NT) k_select(SelectArgs a) {
     if (n >= a.k && a.k > 0) {
         const float tau = key_score(keys[a.k - 1], asc);
         if (a.exact) {
-            thr_new = asc ? nextafterf(tau, -LY_INF) : nextafterf(tau, LY_INF);
+            // FLAT scans rows in ascending id order, so a later tie of the k-th score can never win: strict
+            // cut.  Packed-binary IVF scans slabs (keys carry ORIGINAL ids): a later tie with a smaller id
+            // must still get in -> non-strict cut.
+            thr_new = a.keep_ties ? tau : (asc ? nextafterf(tau, -LY_INF) : nextafterf(tau, LY_INF));
             keep = a.k;
         } else {
             const float m2 = a.marg2[q];

@@ -1080,6 +1080,38 @@ size_t lo_ivf_search(const float *query, const float *data, const uint64_t *pack
     return pool;
 }
 
+static int cmp_float_asc(const void *a, const void *b) {
+    return fcmp(*(const float *)a, *(const float *)b);
+}
+
+int lo_binary_fit(const float *data, size_t n, size_t dim, float *thresholds) { /* quantizer/mod.rs:321-357 */
+    for (size_t d = 0; d < dim; ++d) thresholds[d] = 0.5f;
+    if (n == 0 || dim == 0) return 1;
+    int already_binary = 1;
+    for (size_t i = 0; i < n * dim; ++i)
+        if (!(data[i] == 0.0f || data[i] == 1.0f)) { already_binary = 0; break; }
+    if (already_binary) return 1;
+    float *col = (float *)malloc(n * sizeof(float));
+    for (size_t d = 0; d < dim; ++d) {
+        for (size_t i = 0; i < n; ++i) col[i] = data[i * dim + d];
+        qsort(col, n, sizeof(float), cmp_float_asc);
+        float mn = col[0], mx = col[n - 1], med = col[n / 2];
+        if (med <= mn || med >= mx) {
+            float s = mn + mx;
+            thresholds[d] = 0.5f * s;
+        } else {
+            thresholds[d] = med;
+        }
+    }
+    free(col);
+    return 0;
+}
+
+void lo_binary_quantize(const float *data, size_t n, size_t dim, const float *thresholds, float *out) {
+    for (size_t i = 0; i < n; ++i)
+        for (size_t d = 0; d < dim; ++d) out[i * dim + d] = data[i * dim + d] > thresholds[d] ? 1.0f : 0.0f;
+}
+
 void lo_ivf_flat_layout(const uint32_t *assignments, size_t n, size_t nlist, uint64_t *offsets,
                         uint32_t *original_ids) { /* ivf_flat_mmap.rs:105-130 */
     uint64_t *sizes = (uint64_t *)calloc(nlist, sizeof(uint64_t));

@@ -136,6 +136,13 @@ size_t lo_ivf_search(const float *query, const float *data, const uint64_t *pack
                      size_t k, int metric, uint64_t *out_ids, float *out_dist,
                      uint32_t *out_probed /* nprobe, may be NULL */);
 
+/* BinaryQuantizer::fit (src/quantizer/mod.rs:321-357): returns 1 when the corpus is already {0,1}
+ * (threshold 0.5 everywhere), else fills per-dimension thresholds: the median column[n/2], or the
+ * midrange when the median equals the column min or max. */
+int lo_binary_fit(const float *data, size_t n, size_t dim, float *thresholds /* dim */);
+/* decode(encode(x)) (quantizer/mod.rs:359-393): out[i][d] = x[i][d] > thresholds[d] ? 1 : 0. */
+void lo_binary_quantize(const float *data, size_t n, size_t dim, const float *thresholds, float *out);
+
 /* IvfFlatMmap::build step 2-4 (ivf_flat_mmap.rs:105-130): slab layout from assignments. */
 void lo_ivf_flat_layout(const uint32_t *assignments, size_t n, size_t nlist,
                         uint64_t *offsets /* nlist+1 */, uint32_t *original_ids /* n */);

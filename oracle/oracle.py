@@ -78,6 +78,8 @@ class Oracle:
         s("lo_fastrng_stream", None, C.c_uint64, _sz, _f64p)
         s("lo_ivf_search", _sz, _f32p, _f32p, _u64p, _sz, _sz, _sz, _f32p, _sz, _u64p, _u32p, _sz,
           _sz, C.c_int, _u64p, _f32p, _u32p)
+        s("lo_binary_fit", C.c_int, _f32p, _sz, _sz, _f32p)
+        s("lo_binary_quantize", None, _f32p, _sz, _sz, _f32p, _f32p)
         s("lo_ivf_flat_layout", None, _u32p, _sz, _sz, _u64p, _u32p)
         s("lo_ivf_routing_dims", _sz, _f32p, _sz, _sz, _u32p)
         s("lo_ivf_flat_probe", _sz, _f32p, _f32p, _sz, _sz, _sz, C.c_int, _u32p, _sz, _u32p)
@@ -270,6 +272,20 @@ class Oracle:
                                      metric, ids.ctypes.data_as(_u64p), dist.ctypes.data_as(_f32p),
                                      probed.ctypes.data_as(_u32p))
         return ids[:cnt].copy(), dist[:cnt].copy(), probed[:min(nprobe, c.shape[0])].copy()
+
+    def binary_fit(self, data):
+        """BinaryQuantizer::fit -> (already_binary, thresholds[dim])."""
+        d, pd = self._f(data)
+        thr = np.zeros(d.shape[1], np.float32)
+        ab = self.lib.lo_binary_fit(pd, d.shape[0], d.shape[1], thr.ctypes.data_as(_f32p))
+        return bool(ab), thr
+
+    def binary_quantize(self, data, thresholds):
+        d, pd = self._f(np.atleast_2d(data))
+        t, pt = self._f(thresholds)
+        out = np.zeros_like(d)
+        self.lib.lo_binary_quantize(pd, d.shape[0], d.shape[1], pt, out.ctypes.data_as(_f32p))
+        return out
 
     def ivf_flat_layout(self, assignments, nlist):
         a, pa = self._u32(assignments)

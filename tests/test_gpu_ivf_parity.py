@@ -144,3 +144,99 @@ def test_ivf_build_recall_and_errors(L, oracle):
         idx.search(np.zeros(dim + 1, f32), 5, 4, "l2")
     with pytest.raises(ValueError, match="Unknown metric"):
         idx.search(np.zeros(dim, f32), 5, 4, "nope")
+
+
+# ------------------------------------------------------------------------- IVF-*-BINARY (ivf.rs:77-127)
+BIN_NAME = {O.HAMMING: "hamming", O.JACCARD: "jaccard", O.DICE: "dice", O.TANIMOTO: "tanimoto"}
+
+
+def check_ivf_binary(L, oracle, data, queries, nlist, nprobe, k, metric, build_on_device):
+    ab, thr = oracle.binary_fit(data)
+    enc = oracle.binary_quantize(data, thr)
+    packed = oracle.pack_binary(enc)
+    if build_on_device:
+        idx = L.IvfFlatIndex.build(None, data, data.shape[1], nlist, 20, BIN_NAME[metric], l2_partitions=False)
+        g_thr, g_ab = idx.thresholds()
+        assert g_ab == ab
+        assert np.array_equal(g_thr.view(np.uint32), thr.view(np.uint32)), (g_thr, thr)
+        cen, asg, off, orig = idx.export()
+        rows = orig
+        if data.shape[0] < 8192:  # deterministic k-means (sequential sums): bit-identical to the oracle's on the codes
+            e_cen, e_asg = oracle.kmeans_train(enc, nlist, 20, O.L2)
+            assert np.array_equal(e_asg, asg)
+            assert np.array_equal(e_cen.view(np.uint32), cen.view(np.uint32))
+    else:
+        cen, asg = oracle.kmeans_train(enc, nlist, 20, O.L2)
+        off, rows = oracle.lists_from_assignments(asg, cen.shape[0])
+        idx = L.IvfFlatIndex.load(data, cen, asg, BIN_NAME[metric], thresholds=thr)
+    g_rows, g_d, g_c = idx.search_batch_arrays(queries, k, nprobe)
+    for qi in range(queries.shape[0]):
+        eq = oracle.binary_quantize(queries[qi], thr)[0]
+        e_ids, e_d, _ = oracle.ivf_search(eq, enc, cen, off, rows, nprobe, k, metric, packed=packed)
+        c = int(g_c[qi])
+        assert c == len(e_ids), (qi, c, len(e_ids))
+        assert np.array_equal(g_d[qi, :c].view(np.uint32), e_d.view(np.uint32)), (qi, g_d[qi, :c], e_d)
+        assert np.array_equal(g_rows[qi, :c], e_ids), (qi, g_rows[qi, :c], e_ids)
+
+
+@pytest.mark.parametrize("metric", [O.HAMMING, O.JACCARD, O.DICE])
+@pytest.mark.parametrize("n,dim,nlist,nprobe,nq,k,kind", [
+    (2000, 64, 16, 4, 8, 10, "float"), (3000, 100, 32, 32, 5, 10, "float"), (5000, 256, 64, 8, 40, 20, "bits"),
+    (1500, 33, 8, 2, 3, 50, "float"), (6000, 1024, 32, 6, 33, 10, "bits"), (700, 130, 200, 9, 4, 10, "skew"),
+])
+def test_ivf_binary_parity_loaded(L, oracle, metric, n, dim, nlist, nprobe, nq, k, kind):
+    rng = np.random.default_rng(n * 3 + dim + nlist)
+    if kind == "bits":
+        data = (rng.random((n, dim)) < 0.3).astype(f32)
+        queries = data[rng.integers(0, n, nq)].copy()
+        flip = rng.random(queries.shape) < 0.05
+        queries = np.where(flip, 1 - queries, queries).astype(f32)
+    elif kind == "skew":  # many constant / two-valued columns: median == min or max -> midrange fallback
+        data = rng.integers(0, 3, (n, dim)).astype(f32)
+        data[:, ::4] = 7.0
+        data[:, 1::4] = (rng.random((n, dim))[:, 1::4] < 0.9).astype(f32) * 2
+        queries = data[rng.integers(0, n, nq)].copy()
+    else:
+        data = rng.standard_normal((n, dim)).astype(f32) * 3 + rng.standard_normal(dim).astype(f32)
+        queries = (data[rng.integers(0, n, nq)] + 0.5 * rng.standard_normal((nq, dim))).astype(f32)
+    check_ivf_binary(L, oracle, data, queries, nlist, nprobe, k, metric, build_on_device=False)
+
+
+@pytest.mark.parametrize("metric,n,dim,nlist,kind", [(O.HAMMING, 3000, 96, 24, "float"), (O.JACCARD, 2500, 128, 16, "bits"),
+                                                      (O.HAMMING, 20000, 64, 32, "float")])
+def test_ivf_binary_build_on_device(L, oracle, metric, n, dim, nlist, kind):
+    rng = np.random.default_rng(n + dim)
+    if kind == "bits":
+        data = (rng.random((n, dim)) < 0.4).astype(f32)
+    else:
+        data = (rng.standard_normal((n, dim)) * 2 + 1).astype(f32)
+    queries = data[rng.integers(0, n, 12)].copy()
+    check_ivf_binary(L, oracle, data, queries, nlist, 5, 10, metric, build_on_device=True)
+
+
+def test_ivf_hamming_binary_reference_kat(L, oracle):
+    # ivf.rs:641-679: n=256, dim=32, bit (i*17 + j*3) % 2 == 0, IVF(16 lists), nprobe=16 -> the flat Hamming distances
+    n, dim = 256, 32
+    i = np.arange(n)[:, None]
+    j = np.arange(dim)[None, :]
+    vectors = (((i * 17 + j * 3) % 2) == 0).astype(f32)
+    idx = L.IvfFlatIndex.build(None, vectors, dim, 16, 20, "hamming", l2_partitions=False)
+    thr, ab = idx.thresholds()
+    assert ab and np.all(thr == 0.5)
+    q = vectors[0]
+    exact = np.sort(np.array([oracle.compute_distance(q, vectors[r], O.HAMMING) for r in range(n)], f32), kind="stable")[:10]
+    ids, d = idx.search(q, 10, 16, "hamming")
+    assert np.array_equal(d, exact)
+    # ties are ordered by original row id (canonical order): the 10 smallest ids among the zero-distance rows
+    zero = np.nonzero(np.array([oracle.compute_distance(q, vectors[r], O.HAMMING) for r in range(n)]) == 0)[0]
+    assert np.array_equal(ids, zero[:10].astype(np.uint32))
+
+
+def test_ivf_binary_many_ties_and_large_lists(L, oracle):
+    # few distinct codes -> huge tie groups at the k-th distance; exercises the non-strict cut + overflow plan
+    rng = np.random.default_rng(5)
+    protos = (rng.random((12, 64)) < 0.5).astype(f32)
+    data = protos[rng.integers(0, 12, 30000)]
+    queries = protos[:6].copy()
+    queries[:, :3] = 1 - queries[:, :3]
+    check_ivf_binary(L, oracle, data, queries, 8, 8, 25, O.HAMMING, build_on_device=False)

@@ -419,3 +419,20 @@ def test_packed_search_matches_canonical(oracle):
             untied[1:] &= c[1][1:] != c[1][:-1]
             untied[:-1] &= c[1][:-1] != c[1][1:]
             assert np.array_equal(r[0][untied], c[0][untied])
+
+
+def test_binary_quantizer_kat(oracle):  # quantizer/mod.rs:738-773
+    f32 = np.float32
+    # default threshold 0.5
+    enc = oracle.binary_quantize(np.array([0.1, 0.9, 0.3, 0.7], f32), np.full(4, 0.5, f32))
+    assert enc[0].tolist() == [0.0, 1.0, 0.0, 1.0]
+    # fitted: col0 median==min -> midrange 5, col1 median 2, col2 median 5, col3 constant -> midrange 0
+    train = np.array([[0, 1, 0, 0], [0, 2, 5, 0], [10, 3, 10, 0]], f32)
+    ab, thr = oracle.binary_fit(train)
+    assert not ab and thr.tolist() == [5.0, 2.0, 5.0, 0.0]
+    assert oracle.binary_quantize(np.array([1.0, 2.5, 4.0, 1.0], f32), thr)[0].tolist() == [0.0, 1.0, 0.0, 1.0]
+    # balanced {0,1} data keeps the 0.5 cut
+    bits = np.array([[0, 1, 1, 0], [0, 1, 1, 0]], f32)
+    ab, thr = oracle.binary_fit(bits)
+    assert ab and np.all(thr == 0.5)
+    assert oracle.binary_quantize(bits[0], thr)[0].tolist() == [0.0, 1.0, 1.0, 0.0]
