@@ -952,6 +952,172 @@ __global__ void __launch_bounds__(256) k_scan_binary(BinArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_scan_binary_rows: the BATCHED packed-binary scan (nq >= a few).  With many queries the 8-lanes-per-
+// row kernel above is bound by its cross-lane reductions and LDS query reads, not by HBM; here ONE LANE
+// OWNS ONE ROW (its words stay in VGPRs, <= 2*WCAP dwords) and the query words arrive as SCALAR loads
+// (uniform address, constant address space -> s_load through the scalar cache), so a (row, query) pair
+// costs exactly one v_xor/v_and + one v_bcnt per 32 bits and nothing else: the VALU floor of the
+// problem (64 lane-ops per 1024-bit pair).  Jaccard / Dice use |x|q| = |x| + |q| - |x&q| (same
+// integers as flat_mmap.rs:1298-1334) and only run the correctly rounded division when a cheap
+// reciprocal estimate says the pair can pass the threshold.
+// ------------------------------------------------------------------------------------------------
+typedef const uint32_t __attribute__((address_space(4))) const_u32;
+typedef const float __attribute__((address_space(4))) const_f32;
+
+__global__ void __launch_bounds__(256) k_pad_words(const uint64_t* __restrict__ src, uint32_t W, uint64_t* __restrict__ dst,
+                                                   uint32_t wcap, uint32_t nq) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= nq * wcap) return;
+    const uint32_t q = i / wcap, w = i % wcap;
+    dst[i] = w < W ? src[(size_t)q * W + w] : 0ull;
+}
+
+constexpr int bin_rows_stride(int wcap) { return wcap * 8 + 16; }  // LDS row stride (bytes): +16 B keeps b128 row reads conflict-free
+
+template <int KIND, int WCAP, bool ODD>
+__global__ void __launch_bounds__(256) k_scan_binary_rows(BinArgs a) {
+    // a.QW holds the queries PADDED to WCAP words each (zero words beyond a.W).
+    // Each wave streams its 64 rows (one contiguous 64*W*8-byte span) with fully coalesced 16-B (8-B for odd W)
+    // pieces, parks them in a wave-private padded LDS tile and every lane then reads ITS row back: the transpose
+    // that turns coalesced HBM traffic into lane-per-row registers.  The pieces of the NEXT row block are
+    // fetched into registers before the query loop of the current one (software pipeline).
+    constexpr int RS = bin_rows_stride(WCAP);
+    constexpr int NPC = WCAP >= 2 ? WCAP / 2 : 1;  // 16-B pieces per lane per block (W even)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    char* tile = smem + (size_t)wave * 64 * RS;
+    const uint32_t W = a.W;
+    const_u32* Q32 = (const_u32*)(uintptr_t)a.QW;
+    const_f32* THR = (const_f32*)(uintptr_t)a.thr;
+    constexpr bool odd = ODD;             // the host dispatches on W & 1
+    constexpr bool PF = WCAP <= 32;       // software prefetch costs 2*WCAP staging VGPRs: not for the widest rows
+    const bool fast = !ODD && W == (uint32_t)WCAP && WCAP >= 2;
+    const uint32_t H = odd ? W : W / 2;       // pieces per row
+    const uint32_t step_row = 64 / H, step_in = 64 % H;
+
+    u32x4 nxt[ODD ? 1 : NPC];        // even W: 16-B pieces
+    uint64_t nxt8[ODD ? WCAP : 1];   // odd W: 8-B pieces
+    auto fetch = [&](uint32_t rb) {
+        const uint32_t wrow0 = rb + wave * 64;
+        const uint32_t nrows_w = wrow0 < a.row1 ? (a.row1 - wrow0 < 64u ? a.row1 - wrow0 : 64u) : 0u;
+        const uint32_t npieces = nrows_w * H;
+        const char* gbase = reinterpret_cast<const char*>(a.P + (size_t)wrow0 * W);
+        if constexpr (!odd) {
+#pragma unroll
+            for (int it = 0; it < NPC; ++it) {
+                const uint32_t p = lane + 64u * it;
+                nxt[it] = u32x4{0u, 0u, 0u, 0u};
+                if (p < npieces) nxt[it] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(gbase) + p);
+            }
+        } else {
+#pragma unroll
+            for (int it = 0; it < WCAP; ++it) {
+                const uint32_t p = lane + 64u * it;
+                nxt8[it] = 0ull;
+                if (p < npieces) nxt8[it] = __builtin_nontemporal_load(reinterpret_cast<const uint64_t*>(gbase) + p);
+            }
+        }
+    };
+    auto park = [&]() {  // registers -> LDS tile, row-major with the padded stride
+        if (fast) {
+            if constexpr (!odd) {
+                constexpr uint32_t HH = NPC;
+#pragma unroll
+                for (int it = 0; it < NPC; ++it) {
+                    const uint32_t p = lane + 64u * it;
+                    *reinterpret_cast<u32x4*>(tile + (p / HH) * RS + (p % HH) * 16) = nxt[it];
+                }
+            }
+        } else {
+            uint32_t prow = lane / H, pin = lane % H;
+            if constexpr (!odd) {
+#pragma unroll
+                for (int it = 0; it < NPC; ++it) {
+                    if (prow < 64u) *reinterpret_cast<u32x4*>(tile + prow * RS + pin * 16) = nxt[it];
+                    prow += step_row; pin += step_in;
+                    if (pin >= H) { pin -= H; prow += 1; }
+                }
+            } else {
+#pragma unroll
+                for (int it = 0; it < WCAP; ++it) {
+                    if (prow < 64u) *reinterpret_cast<uint64_t*>(tile + prow * RS + pin * 8) = nxt8[it];
+                    prow += step_row; pin += step_in;
+                    if (pin >= H) { pin -= H; prow += 1; }
+                }
+            }
+        }
+    };
+
+    uint32_t rb = a.row0 + blockIdx.x * 256;
+    if (PF && rb < a.row1) fetch(rb);
+    for (; rb < a.row1; rb += gridDim.x * 256) {
+        const uint32_t row = rb + wave * 64 + lane;
+        const bool valid = row < a.row1;
+        if (!PF) fetch(rb);
+        park();
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        uint32_t x[2 * WCAP];
+        if (WCAP >= 2) {
+#pragma unroll
+            for (int c = 0; c < WCAP / 2; ++c) {
+                u32x4 v = *reinterpret_cast<const u32x4*>(tile + lane * RS + c * 16);
+                if (!fast) {  // words beyond W were never written
+                    if ((uint32_t)(2 * c) >= W) { v[0] = 0; v[1] = 0; }
+                    if ((uint32_t)(2 * c + 1) >= W) { v[2] = 0; v[3] = 0; }
+                }
+                x[4 * c] = v[0]; x[4 * c + 1] = v[1]; x[4 * c + 2] = v[2]; x[4 * c + 3] = v[3];
+            }
+        } else {
+            const uint64_t v = *reinterpret_cast<const uint64_t*>(tile + lane * RS);
+            x[0] = (uint32_t)v; x[1] = (uint32_t)(v >> 32);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();  // the tile is rewritten by the next row block
+        const uint32_t rb_next = rb + gridDim.x * 256;
+        if (PF && rb_next < a.row1) fetch(rb_next);
+        uint32_t px = 0;
+        if (KIND != 0) {
+#pragma unroll
+            for (int i = 0; i < 2 * WCAP; ++i) px += __popc(x[i]);
+        }
+        for (uint32_t q = 0; q < a.nq; ++q) {
+            const_u32* qp = Q32 + (size_t)q * (2 * WCAP);
+            uint32_t c0 = 0, pq = 0;
+#pragma unroll
+            for (int i = 0; i < 2 * WCAP; ++i) {
+                const uint32_t qv = qp[i];
+                c0 += __popc(KIND == 0 ? (x[i] ^ qv) : (x[i] & qv));
+                if (KIND != 0) pq += __popc(qv);
+            }
+            const float thr = THR[q];
+            float dist = (float)c0;
+            bool pass;
+            if (KIND == 0) {
+                pass = dist <= thr;
+            } else {
+                const uint32_t den = KIND == 1 ? px + pq - c0 : px + pq;
+                const uint32_t num = KIND == 1 ? c0 : 2u * c0;
+                const float est = 1.0f - (float)num * __builtin_amdgcn_rcpf((float)den);  // |error| < 1e-6
+                pass = den == 0 || est <= thr + 2e-6f;
+            }
+            if (valid && (a.emit_all || pass)) {
+                if (KIND != 0) {
+                    const uint32_t den = KIND == 1 ? px + pq - c0 : px + pq;
+                    const uint32_t num = KIND == 1 ? c0 : 2u * c0;
+                    dist = den == 0 ? 0.0f : __fsub_rn(1.0f, __fdiv_rn((float)num, (float)den));
+                }
+                if (a.emit_all || dist <= thr) {
+                    const uint32_t slot = a.emit_all ? (row - a.row0) : atomicAdd(&a.count[q], 1u);
+                    if (slot < a.cap) a.cand[(size_t)q * a.cap + slot] = make_key(dist, row, true);
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Block-wide bitonic sort of npow2 u64 keys in LDS (ascending).
 // ------------------------------------------------------------------------------------------------
 template <int NT>

@@ -137,13 +137,14 @@ struct Workspace {
     size_t q16_halves = 0;
     float* Qf = nullptr;
     uint64_t* QW = nullptr;
+    uint64_t* QWp = nullptr;  // queries padded to a power-of-two word count (k_scan_binary_rows)
     uint64_t* out_rows = nullptr;
     float* out_dists = nullptr;
     uint32_t* out_counts = nullptr;
     unsigned long long* pool_total = nullptr;
     void release() {
         for (void* p : {(void*)cand, (void*)count, (void*)overflow, (void*)thr, (void*)qinv, (void*)qn2,
-                        (void*)qrinv, (void*)marg2, (void*)Q16, (void*)Qf, (void*)QW, (void*)out_rows,
+                        (void*)qrinv, (void*)marg2, (void*)Q16, (void*)Qf, (void*)QW, (void*)QWp, (void*)out_rows,
                         (void*)out_dists, (void*)out_counts, (void*)pool_total})
             if (p) (void)hipFree(p);
         *this = Workspace();
@@ -574,6 +575,11 @@ static int ensure_workspace(lynse_hip_flat* h, uint32_t k /* caller's k = output
     LY_HIP(hipMemset(w.Q16, 0, w.q16_halves * sizeof(_Float16)));
     LY_HIP(hipMalloc(&w.Qf, (size_t)QCHUNK * h->dim * 4));
     LY_HIP(hipMalloc(&w.QW, (size_t)QCHUNK * h->words * 8));
+    {
+        uint32_t wcap = 1;
+        while (wcap < h->words) wcap <<= 1;
+        LY_HIP(hipMalloc(&w.QWp, (size_t)QCHUNK * wcap * 8));
+    }
     LY_HIP(hipMalloc(&w.out_rows, (size_t)QCHUNK * w.kcap * 8));
     LY_HIP(hipMalloc(&w.out_dists, (size_t)QCHUNK * w.kcap * 4));
     LY_HIP(hipMalloc(&w.out_counts, QCHUNK * 4));
@@ -690,6 +696,40 @@ static int launch_scan_binary(const BinArgs& a, int metric, uint32_t grid, size_
     }
 }
 
+// lane-per-row batched kernel: WCAP = the power of two >= words
+template <int KIND>
+static int launch_scan_binary_rows_k(const BinArgs& a, uint32_t grid, hipStream_t st) {
+    static bool attr_done[12] = {false};
+    auto go = [&](auto kern, int wcap, int slot) -> int {
+        const size_t lds = (size_t)4 * 64 * bin_rows_stride(wcap);
+        if (!attr_done[slot]) { LY_TRY(set_max_lds(kern, lds)); attr_done[slot] = true; }
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a);
+        LY_HIP(hipGetLastError());
+        return LYNSE_OK;
+    };
+    if (a.W & 1u) {
+        if (a.W <= 1) return go(k_scan_binary_rows<KIND, 1, true>, 1, 0);
+        if (a.W <= 4) return go(k_scan_binary_rows<KIND, 4, true>, 4, 1);
+        if (a.W <= 8) return go(k_scan_binary_rows<KIND, 8, true>, 8, 2);
+        if (a.W <= 16) return go(k_scan_binary_rows<KIND, 16, true>, 16, 3);
+        if (a.W <= 32) return go(k_scan_binary_rows<KIND, 32, true>, 32, 4);
+        return go(k_scan_binary_rows<KIND, 64, true>, 64, 5);
+    }
+    if (a.W <= 2) return go(k_scan_binary_rows<KIND, 2, false>, 2, 6);
+    if (a.W <= 4) return go(k_scan_binary_rows<KIND, 4, false>, 4, 7);
+    if (a.W <= 8) return go(k_scan_binary_rows<KIND, 8, false>, 8, 8);
+    if (a.W <= 16) return go(k_scan_binary_rows<KIND, 16, false>, 16, 9);
+    if (a.W <= 32) return go(k_scan_binary_rows<KIND, 32, false>, 32, 10);
+    return go(k_scan_binary_rows<KIND, 64, false>, 64, 11);
+}
+static int launch_scan_binary_rows(const BinArgs& a, int metric, uint32_t grid, hipStream_t st) {
+    switch (metric) {
+    case M_HAMMING: return launch_scan_binary_rows_k<0>(a, grid, st);
+    case M_DICE: return launch_scan_binary_rows_k<2>(a, grid, st);
+    default: return launch_scan_binary_rows_k<1>(a, grid, st);
+    }
+}
+
 static int get_event(lynse_hip_flat* h, size_t idx, hipEvent_t* out) {
     while (h->ev_pool.size() <= idx) {
         hipEvent_t e;
@@ -753,10 +793,26 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
             BinArgs b{};
             b.P = h->packed; b.W = h->words; b.row0 = s.r0; b.row1 = s.r1; b.QW = w.QW; b.nq = nq;
             b.thr = w.thr; b.cand = w.cand; b.count = w.count; b.cap = w.cap; b.emit_all = emit_all ? 1 : 0;
-            const uint32_t groups = (s.r1 - s.r0 + 31) / 32;
-            const uint32_t grid = std::max<uint32_t>(1, std::min<uint32_t>(groups, (uint32_t)h->num_cu * 8));
-            const size_t lds = (size_t)nq * h->words * 8 + (size_t)nq * 4;
-            LY_TRY(launch_scan_binary(b, metric, grid, lds, st));
+            static const int rows_minq = []() { const char* e = getenv("LYNSE_HIP_BIN_ROWS_MINQ"); return e ? atoi(e) : 1; }();
+            if ((int)nq >= rows_minq) {  // batched: lane-per-row, scalar query words
+                uint32_t wcap = 1;
+                while (wcap < h->words) wcap <<= 1;
+                if (wcap != h->words) {
+                    if (si == 0) {
+                        hipLaunchKernelGGL(k_pad_words, dim3((nq * wcap + 255) / 256), dim3(256), 0, st, w.QW, h->words, w.QWp, wcap, nq);
+                        LY_HIP(hipGetLastError());
+                    }
+                    b.QW = w.QWp;
+                }
+                const uint32_t groups = (s.r1 - s.r0 + 255) / 256;
+                const uint32_t grid = std::max<uint32_t>(1, std::min<uint32_t>(groups, (uint32_t)h->num_cu * 8));
+                LY_TRY(launch_scan_binary_rows(b, metric, grid, st));
+            } else {
+                const uint32_t groups = (s.r1 - s.r0 + 31) / 32;
+                const uint32_t grid = std::max<uint32_t>(1, std::min<uint32_t>(groups, (uint32_t)h->num_cu * 8));
+                const size_t lds = (size_t)nq * h->words * 8 + (size_t)nq * 4;
+                LY_TRY(launch_scan_binary(b, metric, grid, lds, st));
+            }
         } else {
             ScanArgs a{};
             a.V = h->rows; a.ld = h->ld; a.D = h->dim; a.row0 = s.r0; a.row1 = s.r1; a.Q16 = w.Q16;

@@ -107,7 +107,7 @@ def c5():
     idx = L.FlatIndex(None, 1024, 0)
     idx.write_packed(words)
     out = {}
-    for nq in (1, 32):
+    for nq in (1, 2, 4, 8, 32, 256):
         qw = words[np.arange(nq) * 1000 + 7].copy()
         qw[:, 0] ^= np.uint64(0xFFFF)
         dq = torch.as_tensor(qw.view(np.int64), device=dev)
