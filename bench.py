@@ -12,7 +12,7 @@ RCCL all-gather and merged on the device: total work is fixed -> "scaling": "str
 Inputs (rows and queries) are resident in HBM before the timed region; the timed region is bracketed
 by barrier + torch.cuda.synchronize() and the MAX over ranks is reported.
 
-Extra objects on the JSON line: "roofline" (dominant kernel k_scan_glds — algorithmic bytes / HIP-event
+Extra objects on the JSON line: "roofline" (dominant kernel k_scan_h16 — algorithmic bytes / HIP-event
 duration measured on the launch stream during the timed region) and "cpu_baseline" (the oracle's
 restatement of the reference's rayon scan, timed on this host's cores over a bounded row sample).
 """
@@ -32,6 +32,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_F16_PEAK_TFLOPS = 2500.0  # dense f16/bf16 MFMA peak (no sparsity)
 GEN_BLOCK = 100_000     # rows per generation block (flat_search_bench.py:71-77 batches of 100k)
 
 
@@ -159,21 +160,33 @@ def main():
         scan_s = prof["scan_us"] * 1e-6
         achieved = (prof["scan_bytes"] / scan_s / 1e9) if scan_s > 0 else 0.0
         launches = max(int(prof["scan_launches"]), 1)
+        variant = int(os.environ.get("LYNSE_HIP_SCAN_VARIANT", "3"))
+        kernel = "k_scan_binary_rows" if metric >= 3 else {3: "k_scan_h16", 0: "k_scan_glds"}.get(variant, "k_scan_f16")
+        # k_scan_h16 streams the f16 shadow of the rows (2 B/element, built once at finalize): the HBM bytes it
+        # HAS to read are half the algorithmic f32 bytes of SURVEY 8(d); both rates are reported.
+        kernel_bytes = prof["scan_bytes"] // 2 if kernel == "k_scan_h16" else prof["scan_bytes"]
         traffic, traffic_note = None, "no PMC summary under profiles/"
         try:  # HBM bytes per launch from the committed PMC pass (bench.py itself cannot run rocprofv3 --pmc)
             pm = json.loads((ROOT / "profiles" / "r01_pmc_traffic.json").read_text())
+            pm = pm.get(kernel, pm if pm.get("kernel") == kernel else None)
             traffic = int(prof["scan_bytes"] // launches * pm["ratio_hbm_over_algorithmic"])
             traffic_note = "algorithmic bytes x %.4f (FETCH_SIZE, gfx950-corrected; %s)" % (
                 pm["ratio_hbm_over_algorithmic"], "profiles/r01_pmc_traffic.json")
         except Exception:
             pass
+        flops = 2.0 * B * prof["scan_rows"] * D if metric < 3 else 0.0
         roofline = {
-            "bound": "hbm", "kernel": "k_scan_glds" if metric < 3 else "k_scan_binary",
+            "bound": "hbm", "kernel": kernel,
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_note": traffic_note,
             "launches": launches, "avg_launch_us": round(prof["scan_us"] / launches, 2),
             "algorithmic_bytes_per_launch": int(prof["scan_bytes"] // launches),
-            "note": "rank-0 shard; bytes = rows scanned x dim x 4 B, time = HIP events around each scan launch",
+            "kernel_hbm_bytes_per_launch": int(kernel_bytes // launches),
+            "hbm_achieved": round(kernel_bytes / scan_s / 1e9, 1) if scan_s > 0 else 0.0,
+            "mfma_achieved_tflops": round(flops / scan_s / 1e12, 1) if scan_s > 0 else 0.0, "mfma_peak_tflops": MFMA_F16_PEAK_TFLOPS,
+            "note": "rank-0 shard; achieved = SURVEY 8(d) algorithmic bytes (rows scanned x dim x 4 B) / HIP-event time of the "
+                    "scan launches; k_scan_h16 reads a resident f16 copy of the rows, so its own HBM stream is "
+                    "kernel_hbm_bytes_per_launch (= hbm_achieved GB/s) and the kernel sits between the HBM and the f16 MFMA roof",
         }
         result = {
             "metric": "queries/sec, FLAT-%s %dx%d float32, batch=%d, k=%d" % (args.metric.upper(), N, D, B, K),

@@ -97,15 +97,18 @@ struct GatherPair {
 
 __global__ void __launch_bounds__(256) k_ivf_gather_q(const _Float16* __restrict__ base, uint32_t qpad,
                                                       _Float16* __restrict__ gimg, const GatherPair* __restrict__ pairs,
-                                                      uint32_t npairs, uint32_t nslab) {
-    const uint64_t total = (uint64_t)npairs * nslab * 4;
+                                                      uint32_t npairs, uint32_t nslab, uint32_t slots) {
+    // slots = 16-B slots per query per slab: 4 (layout 1, swizzle (q>>2)&3) or 8 (layout 2, swizzle (q>>1)&7)
+    const uint64_t total = (uint64_t)npairs * nslab * slots;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
-        const uint32_t l = (uint32_t)(i & 3);
-        const uint32_t s = (uint32_t)((i >> 2) % nslab);
-        const uint32_t p = (uint32_t)((i >> 2) / nslab);
+        const uint32_t l = (uint32_t)(i % slots);
+        const uint32_t s = (uint32_t)((i / slots) % nslab);
+        const uint32_t p = (uint32_t)((i / slots) / nslab);
         const GatherPair gp = pairs[p];
-        const u32x4* src = reinterpret_cast<const u32x4*>(base + (((size_t)s * qpad + gp.q) * 4 + (l ^ ((gp.q >> 2) & 3))) * 8);
-        u32x4* dst = reinterpret_cast<u32x4*>(gimg + gp.dst_off + (((size_t)s * 32 + gp.n) * 4 + (l ^ ((gp.n >> 2) & 3))) * 8);
+        const uint32_t sw_src = slots == 4 ? ((gp.q >> 2) & 3) : ((gp.q >> 1) & 7);
+        const uint32_t sw_dst = slots == 4 ? ((gp.n >> 2) & 3) : ((gp.n >> 1) & 7);
+        const u32x4* src = reinterpret_cast<const u32x4*>(base + (((size_t)s * qpad + gp.q) * slots + (l ^ sw_src)) * 8);
+        u32x4* dst = reinterpret_cast<u32x4*>(gimg + gp.dst_off + (((size_t)s * 32 + gp.n) * slots + (l ^ sw_dst)) * 8);
         *dst = *src;
     }
 }

@@ -193,7 +193,7 @@ __global__ void __launch_bounds__(256) k_pack_bits(const float* __restrict__ V, 
 struct PrepArgs {
     const float* Q;      // nq x D f32
     uint32_t D, nq, qpad, nslab;
-    int layout;          // 0: [slab64][q][72] (k_scan_f16)   1: [slab32][q][4 slots ^ ((q>>2)&3)][8] (k_scan_glds)
+    int layout;          // 0: [slab64][q][72] (k_scan_f16)   1: [slab32][q][4 slots ^ ((q>>2)&3)][8] (k_scan_glds)   2: [slab64][q][8 slots ^ ((q>>1)&7)][8] (k_scan_h16)
     int metric;
     float sv;            // row scale (power of two)
     float vmax, vmin;    // max / min-nonzero row norm
@@ -274,6 +274,15 @@ __global__ void __launch_bounds__(256) k_prep_queries(PrepArgs a) {
             const float x = i < a.D ? qv[i] * sq : 0.0f;
             a.Q16[((size_t)s * a.qpad + q) * SCAN_LDK + k] = (_Float16)x;
         }
+    } else if (a.layout == 2) {  // k_scan_h16: [slab64][q][8 slots ^ ((q>>1)&7)][8]
+        const uint32_t total = a.nslab * 64;
+        for (uint32_t i = tid; i < total; i += 256) {
+            const uint32_t s = i / 64, k = i % 64;
+            const uint32_t l = k >> 3, e = k & 7;
+            const uint32_t p = l ^ ((q >> 1) & 7);
+            const float x = i < a.D ? qv[i] * sq : 0.0f;
+            a.Q16[(((size_t)s * a.qpad + q) * 8 + p) * 8 + e] = (_Float16)x;
+        }
     } else {
         const uint32_t total = a.nslab * 32;
         for (uint32_t i = tid; i < total; i += 256) {
@@ -305,6 +314,8 @@ __global__ void __launch_bounds__(256) k_prep_queries(PrepArgs a) {
 struct ScanArgs {
     const float* V;
     uint32_t ld, D;
+    const _Float16* V16;  // k_scan_h16: f16 shadow of the rows, (half)(v * sv), pitch ld16 halves (multiple of 8), pad columns zero
+    uint32_t ld16;
     uint32_t row0, row1;  // stage rows [row0,row1)
     const _Float16* Q16;  // [nslab][qpad][72]
     uint32_t qpad, nq, nslab, ntiles;
@@ -859,6 +870,358 @@ __global__ void __launch_bounds__(WQ * WR * 64, (WQ * WR >= 8) ? (WQ * WR / 4) :
         o[0] = t_wait; o[1] = t_bar; o[2] = t_issue; o[3] = t_comp;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the clamped tail DMAs before the LDS is released
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_rows_to_f16: the f16 SHADOW of the f32 rows that k_scan_h16 streams: out[r][c] = (half)(v[r][c] * sv),
+// RNE — bit for bit the conversion k_scan_glds does in flight, done once per appended row at finalize.
+// One thread per 8 output halves (16 B); columns [D, ld16) are zero.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_rows_to_f16(const float* __restrict__ V, uint32_t ld, uint32_t D, uint64_t r0,
+                                                     uint64_t r1, float sv, _Float16* __restrict__ out, uint32_t ld16) {
+    const uint32_t cpr = ld16 / 8;  // 16-B chunks per row
+    const uint64_t total = (r1 - r0) * cpr;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t r = r0 + i / cpr;
+        const uint32_t c0 = (uint32_t)(i % cpr) * 8;
+        const float* src = V + r * ld + c0;
+        half8 h;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) h[e] = (c0 + e < D) ? (_Float16)(src[e] * sv) : (_Float16)0.0f;
+        *reinterpret_cast<half8*>(out + r * ld16 + c0) = h;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_scan_h16 — the hot kernel (default): k_scan_glds over the f16 shadow rows.
+//
+// The coarse pass only ever used the rows rounded to f16 (the certified margin E is built on exactly
+// that rounding), so the scan streams a resident f16 copy instead of converting f32 in flight: HALF
+// the HBM bytes per row, half the LDS bytes per MFMA operand, no cvt instructions.  Exactness is
+// untouched: survivors are rescored from the f32 rows in the reference's accumulation order.
+// Geometry: K slab = 64 halves = 128 B per row AND per query, so rows and query image share one LDS
+// format: 8 16-B slots per line, physical slot = logical ^ ((line>>1)&7) (applied on the DMA source
+// address for rows, pre-applied in the image for queries).  A and B fragments are single
+// ds_read_b128s.  Ring protocol as k_scan_glds, NS >= 2 stages.
+// ------------------------------------------------------------------------------------------------
+constexpr int HK = 64;  // K elements per slab
+
+// DBG (compile-time experiments, never launched by the product path): 1 no MFMA, 2 no LDS fragment reads,
+// 4 no query-image DMA, 8 no row DMA
+template <int WQ, int WR, int TQ, int TR, int METRIC, int NSV, int NSQ, int NT_HINT, bool TILED = false, bool RAG = true, int DBG = 0>
+__global__ void __launch_bounds__(WQ * WR * 64, (WQ * WR >= 8) ? (WQ * WR / 4) : 2) k_scan_h16(ScanArgs a) {
+    // Two LDS rings: NSV stages of row slabs (HBM latency: deeper) and NSQ <= NSV stages of query-image
+    // slabs (L2 latency) — 3 + 2 stages of 32 KiB fill the 160 KiB of a CU for the 256 x 256 tile.
+    constexpr int NW = WQ * WR;
+    constexpr int BQ = WQ * TQ * 32;
+    constexpr int BR = WR * TR * 32;
+    static_assert(NSQ >= 2 && NSV >= NSQ, "ring depths");
+    constexpr int LINE = HK * 2;              // bytes per row / query per slab
+    constexpr int V_BYTES = BR * LINE;
+    constexpr int Q_BYTES = BQ * LINE;
+    constexpr int V_INSTR = V_BYTES / 1024;
+    constexpr int Q_INSTR = Q_BYTES / 1024;
+    static_assert(V_INSTR % NW == 0, "row DMA split");
+    constexpr int VPW = V_INSTR / NW;
+    constexpr int QPW = (Q_INSTR + NW - 1) / NW;
+    constexpr int OPS = VPW + QPW;  // LDS-DMA instructions per wave per slab step: QPW query pieces, then VPW row pieces
+    constexpr int NSLOT = (HK / 16) * TR;  // MFMA groups per slab behind which the pieces are issued
+    static_assert(NSV == NSQ || OPS <= NSLOT, "unequal ring depths need the query pieces issued before the row pieces");
+    // step g needs rows(g) and queries(g): everything younger than queries(g) may still be in flight
+    constexpr int WAIT_OPS = (NSV > NSQ ? VPW : 0) + (NSQ - 2) * OPS;
+    constexpr int Q_RING = NSV * V_BYTES;
+    constexpr int NORM_RING = Q_RING + NSQ * Q_BYTES;
+    constexpr bool ASC = METRIC != M_IP;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wq = wave % WQ, wr = wave / WQ;
+
+    if (blockIdx.x >= a.ntiles) return;
+    const uint32_t my_tiles = (a.ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x;
+    const uint32_t G = my_tiles * a.nslab;
+    const bool ragged_k = RAG && (a.ld16 % HK) != 0;  // last slab reaches past ld16: clamp columns (they meet zeros in the query image)
+
+    uint32_t v_rowoff[VPW], v_col[VPW];
+#pragma unroll
+    for (int j = 0; j < VPW; ++j) {
+        const uint32_t r = (wave * VPW + j) * 8 + (lane >> 3);  // row inside the tile
+        v_rowoff[j] = r;
+        v_col[j] = ((lane & 7) ^ ((r >> 1) & 7)) * 8;            // physical 16-B slot -> logical f16 column
+    }
+    const _Float16* v_src[VPW];  // row pointers (incl. swizzled column) of the tile being issued
+    const char* q_src[QPW];
+    uint32_t q_piece[QPW];  // uniform
+#pragma unroll
+    for (int j = 0; j < QPW; ++j) q_piece[j] = ((wave * QPW + j) % Q_INSTR) * 1024;
+    // row stream position
+    uint32_t vs_tile = blockIdx.x, vs_slab = 0, vs_stage = 0, vs_count = 0, vs_tileseq = 0;
+    // query stream position
+    uint32_t qs_tile = blockIdx.x, qs_slab = 0, qs_stage = 0, qs_count = 0;
+    uint32_t qs_qslab = a.qpad * LINE;
+    constexpr bool NORMS_LDS = !TILED && METRIC != M_IP && (NORM_RING + (NSV + 1) * 1024 <= 160 * 1024);
+    constexpr int NORM_SLOTS = NSV + 1;
+    const float* norm_src = METRIC == M_L2 ? a.vn2 : a.vrinv;
+
+    auto v_enter_tile = [&]() {
+        uint32_t rbase, last;
+        if (TILED) {
+            const IvfTile td = a.tiles[vs_tile];
+            rbase = td.row0;
+            last = td.row0 + td.nrows - 1;
+        } else {
+            rbase = a.row0 + vs_tile * BR;
+            last = a.row1 - 1;
+        }
+        if (NORMS_LDS) {
+            static_assert(BR <= 256, "one 1-KiB norm DMA covers a tile");
+            if (wave == 0)  // extra VM ops only make the counted waits more conservative (in-order retirement)
+                glds16<0>(norm_src + rbase + lane * 4, smem + NORM_RING + (vs_tileseq % NORM_SLOTS) * 1024);
+            ++vs_tileseq;
+        }
+#pragma unroll
+        for (int j = 0; j < VPW; ++j) {
+            uint32_t row = rbase + v_rowoff[j];
+            row = row < last ? row : last;  // clamped rows are masked in the epilogue
+            v_src[j] = a.V16 + (size_t)row * a.ld16 + v_col[j];
+        }
+    };
+    auto q_enter_tile = [&]() {
+        const char* qbase = reinterpret_cast<const char*>(a.Q16);
+        if (TILED) {
+            const IvfTile td = a.tiles[qs_tile];
+            qbase += (size_t)td.qimg_off * 2;
+            qs_qslab = BQ * LINE;
+        }
+#pragma unroll
+        for (int j = 0; j < QPW; ++j) q_src[j] = qbase + q_piece[j] + lane * 16;
+    };
+    // piece p of a slab step: 0..QPW-1 query-image pieces, QPW..OPS-1 row pieces
+    auto issue_piece = [&](int p) {
+        if (p < QPW) {
+            if (!(DBG & 4)) glds16<0>(q_src[p] + qs_slab * qs_qslab, smem + Q_RING + qs_stage * Q_BYTES + q_piece[p]);
+        } else {
+            if (DBG & 8) return;
+            const int j = p - QPW;
+            const uint32_t koff = vs_slab * HK;
+            const _Float16* src = v_src[j] + koff;
+            if (ragged_k) {
+                uint32_t col = koff + v_col[j];
+                col = col < a.ld16 ? col : a.ld16 - 8;
+                src = v_src[j] - v_col[j] + col;
+            }
+            glds16<NT_HINT>(src, smem + vs_stage * V_BYTES + (wave * VPW + j) * 1024);
+        }
+    };
+    // past the end the last real step is re-issued (keeps the per-wave DMA count uniform)
+    auto v_advance = [&]() {
+        vs_stage = vs_stage + 1 == NSV ? 0 : vs_stage + 1;
+        if (++vs_count < G) {
+            if (++vs_slab == a.nslab) {
+                vs_slab = 0;
+                vs_tile += gridDim.x;
+                v_enter_tile();
+            }
+        }
+    };
+    auto q_advance = [&]() {
+        qs_stage = qs_stage + 1 == NSQ ? 0 : qs_stage + 1;
+        if (++qs_count < G) {
+            if (++qs_slab == a.nslab) {
+                qs_slab = 0;
+                if (TILED) {
+                    qs_tile += gridDim.x;
+                    q_enter_tile();
+                }
+            }
+        }
+    };
+
+    f32x16 acc[TR][TQ];
+#pragma unroll
+    for (int i = 0; i < TR; ++i)
+#pragma unroll
+        for (int j = 0; j < TQ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    const int l32 = lane & 31, hi = lane >> 5;
+    const int swz = (l32 >> 1) & 7;   // (line>>1)&7 — tile offsets are multiples of 32
+    const int a_base = (wr * (TR * 32) + l32) * LINE;
+    const int b_base = (wq * (TQ * 32) + l32) * LINE;
+
+    float c_qinv[TQ], c_thr[TQ], c_extra[TQ];
+    bool c_ok[TQ];
+#pragma unroll
+    for (int j = 0; j < TQ; ++j) {
+        const uint32_t n = wq * (TQ * 32) + j * 32 + l32;
+        c_ok[j] = !TILED && n < a.nq;
+        c_qinv[j] = c_ok[j] ? a.qinv[n] : 0.0f;
+        c_thr[j] = c_ok[j] ? a.thr[n] : 0.0f;
+        if (a.debug_flags & 2) c_thr[j] = ASC ? -LY_INF : LY_INF;
+        c_extra[j] = 0.0f;
+        if (METRIC == M_L2) c_extra[j] = c_ok[j] ? a.qn2[n] : 0.0f;
+        if (METRIC == M_COS) c_extra[j] = c_ok[j] ? a.qrinv[n] : 0.0f;
+    }
+#pragma unroll
+    for (int j = 0; j < TQ; ++j) asm volatile("" : "+v"(c_qinv[j]), "+v"(c_thr[j]), "+v"(c_extra[j]));
+
+    // Prologue: the issue order of the steady state (per step: queries(s+NSQ-1), then rows(s+NSV-1))
+    v_enter_tile();
+    q_enter_tile();
+#pragma unroll
+    for (int s0 = -(NSV - 1); s0 < 0; ++s0) {
+        if (s0 + NSQ - 1 >= 0) {
+#pragma unroll
+            for (int p = 0; p < QPW; ++p) issue_piece(p);
+            q_advance();
+        }
+#pragma unroll
+        for (int p = QPW; p < OPS; ++p) issue_piece(p);
+        v_advance();
+    }
+
+    uint32_t s_in_tile = 0, tile = blockIdx.x, cv_stage = 0, cq_stage = 0, c_tileseq = 0;
+    const bool timing = (a.debug_flags & 64) && a.dbg;
+    unsigned long long t_wait = 0, t_bar = 0, t_comp = 0, tp = timing ? __builtin_amdgcn_s_memtime() : 0;
+    for (uint32_t g = 0; g < G; ++g) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAIT_OPS) : "memory");
+        if (timing) { const unsigned long long t = __builtin_amdgcn_s_memtime(); t_wait += t - tp; tp = t; }
+        __builtin_amdgcn_s_barrier();
+        if (timing) { const unsigned long long t = __builtin_amdgcn_s_memtime(); t_bar += t - tp; tp = t; }
+
+        const char* stv = smem + cv_stage * V_BYTES;
+        const char* stq = smem + Q_RING + cq_stage * Q_BYTES;
+        cv_stage = cv_stage + 1 == NSV ? 0 : cv_stage + 1;
+        cq_stage = cq_stage + 1 == NSQ ? 0 : cq_stage + 1;
+        // Software pipeline over the four 16-wide k-steps: the fragments of step kk+1 are read from LDS
+        // while the MFMAs of step kk run (sched_barriers pin the order — left alone, the scheduler sinks
+        // every ds_read next to its first use and each MFMA group then waits out an LDS round trip).
+        half8 af[2][TR], bf[2][TQ];
+        auto load_frags = [&](int kk, int buf) {
+            const int ls = ((kk * 2 + hi) ^ swz) * 16;
+#pragma unroll
+            for (int j = 0; j < TQ; ++j) bf[buf][j] = *reinterpret_cast<const half8*>(stq + b_base + j * 32 * LINE + ls);
+#pragma unroll
+            for (int i = 0; i < TR; ++i) af[buf][i] = *reinterpret_cast<const half8*>(stv + a_base + i * 32 * LINE + ls);
+        };
+        if (!(DBG & 2) || g == 0) load_frags(0, 0);
+#pragma unroll
+        for (int kk = 0; kk < HK / 16; ++kk) {
+            const int cur = (DBG & 2) ? 0 : (kk & 1);
+            if (kk + 1 < HK / 16 && !(DBG & 2)) load_frags(kk + 1, cur ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < TR; ++i) {
+                if (DBG & 1) {
+                    asm volatile("" ::"v"(af[cur][i]));
+#pragma unroll
+                    for (int j = 0; j < TQ; ++j) asm volatile("" ::"v"(bf[cur][j]));
+                } else {
+#pragma unroll
+                    for (int j = 0; j < TQ; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[cur][i], bf[cur][j], acc[i][j], 0, 0, 0);
+                }
+                {   // refill pieces scheduled behind this MFMA group (slot kk*TR+i of NSLOT)
+                    const int slot = kk * TR + i;
+#pragma unroll
+                    for (int p = 0; p < OPS; ++p)
+                        if (p % NSLOT == slot) issue_piece(p);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        q_advance();
+        v_advance();
+
+        if (++s_in_tile == a.nslab) {
+            uint32_t rbase = a.row0 + tile * BR;
+            uint32_t row_end = a.row1;
+            IvfTile td{};
+            if (TILED) {
+                td = a.tiles[tile];
+                rbase = td.row0;
+                row_end = td.row0 + td.nrows;
+            }
+            const float* nrm = reinterpret_cast<const float*>(smem + NORM_RING + (c_tileseq % NORM_SLOTS) * 1024);
+            ++c_tileseq;
+            auto score = [&](int i, int j, int r, uint32_t m, bool rok) -> float {
+                float sc = acc[i][j][r] * c_qinv[j];
+                if (METRIC != M_IP) {
+                    float nv;
+                    if (NORMS_LDS) nv = nrm[m - rbase];
+                    else nv = rok ? (METRIC == M_L2 ? a.vn2[m] : a.vrinv[m]) : 0.0f;
+                    if (METRIC == M_L2) sc = nv - 2.0f * sc + c_extra[j];
+                    else sc = 1.0f - sc * nv * c_extra[j];
+                }
+                return sc;
+            };
+#pragma unroll
+            for (int j = 0; j < TQ; ++j) {
+                uint32_t n = wq * (TQ * 32) + j * 32 + l32;
+                if (TILED) {
+                    c_ok[j] = n < td.nq;
+                    n = c_ok[j] ? a.pair_q[td.pair0 + n] : 0u;
+                    c_qinv[j] = c_ok[j] ? a.qinv[n] : 0.0f;
+                    c_thr[j] = c_ok[j] ? a.thr[n] : 0.0f;
+                    if (METRIC == M_L2) c_extra[j] = c_ok[j] ? a.qn2[n] : 0.0f;
+                    if (METRIC == M_COS) c_extra[j] = c_ok[j] ? a.qrinv[n] : 0.0f;
+                }
+                if (a.emit_all && !TILED) {
+#pragma unroll
+                    for (int i = 0; i < TR; ++i)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const uint32_t m = rbase + wr * (TR * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                            const bool rok = m < row_end;
+                            const float sc = score(i, j, r, m, rok);
+                            if (c_ok[j] && rok && (m - a.row0) < a.cap)
+                                a.cand[(size_t)n * a.cap + (m - a.row0)] = make_key(sc, m, ASC);
+                        }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < TR; ++i) {
+                        uint32_t msk = 0;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const uint32_t m = rbase + wr * (TR * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                            const bool rok = m < row_end;
+                            const float sc = score(i, j, r, m, rok);
+                            const bool pass = ASC ? (sc <= c_thr[j]) : (sc >= c_thr[j]);
+                            if (c_ok[j] && rok && pass) msk |= 1u << r;
+                        }
+                        if (msk) {
+                            const uint32_t base = atomicAdd(&a.count[n], (uint32_t)__popc(msk));
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) {
+                                if ((msk >> r) & 1u) {
+                                    const uint32_t m = rbase + wr * (TR * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                                    const uint32_t slot = base + (uint32_t)__popc(msk & ((1u << r) - 1u));
+                                    if (slot < a.cap) a.cand[(size_t)n * a.cap + slot] = make_key(score(i, j, r, m, true), m, ASC);
+                                }
+                            }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < TR; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+            }
+            s_in_tile = 0;
+            tile += gridDim.x;
+        }
+        if (timing) {
+            asm volatile("" ::"v"(acc[0][0][0]));
+            const unsigned long long t = __builtin_amdgcn_s_memtime(); t_comp += t - tp; tp = t;
+        }
+    }
+    if (timing && lane == 0) {
+        unsigned long long* o = a.dbg + ((size_t)blockIdx.x * NW + wave) * 4;
+        o[0] = t_wait; o[1] = t_bar; o[2] = 0; o[3] = t_comp;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -160,6 +160,11 @@ struct lynse_hip_flat {
 
     uint64_t n = 0, capacity = 0;
     float* rows = nullptr;       // capacity x ld f32, row-major (pad columns zero)
+    // f16 shadow of the rows for the coarse scan (k_scan_h16): (half)(v * sv16), pitch ld16 halves, built at finalize
+    _Float16* rows16 = nullptr;
+    uint32_t ld16 = 0;
+    uint64_t n16 = 0, cap16 = 0;
+    float sv16 = 0.0f;
     uint64_t n_packed = 0, packed_capacity = 0;
     uint64_t* packed = nullptr;  // n x words u64
     bool packed_only = false;
@@ -201,6 +206,7 @@ extern "C" int lynse_hip_flat_create(uint32_t dim, int device, lynse_hip_flat** 
     auto* h = new lynse_hip_flat();
     h->dim = dim;
     h->ld = round_up(dim, 4);
+    h->ld16 = round_up(dim, 8);
     h->words = (dim + 63) / 64;
     h->device = device;
     hipDeviceProp_t prop;
@@ -229,7 +235,7 @@ extern "C" int lynse_hip_flat_destroy(lynse_hip_flat* h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     h->ws.release();
     for (auto e : h->ev_pool) (void)hipEventDestroy(e);
-    for (void* p : {(void*)h->rows, (void*)h->packed, (void*)h->vn2, (void*)h->vrinv, (void*)h->d_stats})
+    for (void* p : {(void*)h->rows, (void*)h->rows16, (void*)h->packed, (void*)h->vn2, (void*)h->vrinv, (void*)h->d_stats})
         if (p) (void)hipFree(p);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -362,6 +368,9 @@ extern "C" int lynse_hip_flat_append_packed_u64_device(lynse_hip_flat* h, const 
 }
 
 // Row statistics for rows [n_stats, n): norms + collection stats (locked by caller).
+static int ensure_shadow_locked(lynse_hip_flat* h);
+static int scan_variant();
+
 static int finalize_locked(lynse_hip_flat* h) {
     if (h->packed_only || h->n_stats == h->n) return LYNSE_OK;
     if (h->n > h->stats_capacity) {
@@ -403,6 +412,7 @@ static int finalize_locked(lynse_hip_flat* h) {
     // below u*|v| for every element that matters, and the hot loop saves the multiply
     h->sv = (e >= -6 && e <= 14) ? 1.0f : std::ldexp(1.0f, 13 - e);
     h->n_stats = h->n;
+    if (scan_variant() == 3) LY_TRY(ensure_shadow_locked(h));
     return LYNSE_OK;
 }
 
@@ -672,10 +682,89 @@ extern "C" int lynse_hip_debug_phase_cycles(unsigned long long* out, int n) {  /
     return hipMemcpy(out, g_dbg_ptr, (size_t)n * 8, hipMemcpyDeviceToHost) == hipSuccess ? 0 : 2;
 }
 
-// 0 = LDS-DMA ring kernel (default), 1 / 2 = register-staged kernel with prefetch depth 1 / 2
+// 3 = LDS-DMA ring kernel over the f16 shadow rows (default), 0 = LDS-DMA ring kernel over the f32 rows,
+// 1 / 2 = register-staged kernel with prefetch depth 1 / 2
 static int scan_variant() {
-    static const int v = []() { const char* e = getenv("LYNSE_HIP_SCAN_VARIANT"); return e ? atoi(e) : 0; }();
+    static const int v = []() { const char* e = getenv("LYNSE_HIP_SCAN_VARIANT"); return e ? atoi(e) : 3; }();
     return v;
+}
+
+// k_scan_h16 launcher: LDS = NSV row stages + NSQ query stages + the norm ring (NSV+1 slots of 1 KiB) when it fits
+template <int WQ, int WR, int TQ, int TR, int NSV, int NSQ, bool TILED>
+static int launch_scan_h16(const ScanArgs& a, int metric, uint32_t grid, hipStream_t st) {
+    constexpr int BQ = WQ * TQ * 32, BR = WR * TR * 32;
+    constexpr size_t rings = (size_t)(NSV * BR + NSQ * BQ) * (HK * 2);
+    const size_t lds = (rings + (NSV + 1) * 1024 <= 160 * 1024) ? rings + (NSV + 1) * 1024 : rings;
+    static bool attr_done[6] = {false};
+    auto go = [&](auto kern, int slot) -> int {
+        if (!attr_done[slot]) { LY_TRY(set_max_lds(kern, lds)); attr_done[slot] = true; }
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(WQ * WR * 64), lds, st, a);
+        LY_HIP(hipGetLastError());
+        return LYNSE_OK;
+    };
+    if (a.ld16 % HK == 0) {  // no ragged last slab: branch-free DMA issue
+        if constexpr (WQ == 2 && WR == 4 && !TILED) {  // timing experiments (LYNSE_HIP_DEBUG_FLAGS bits 16.. = DBG << 4)
+            if (metric == M_IP && (a.debug_flags >> 4) & 15) {
+                auto ex = [&](auto kern) -> int {
+                    LY_TRY(set_max_lds(kern, lds));
+                    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, a);
+                    return LYNSE_OK;
+                };
+                switch ((a.debug_flags >> 4) & 15) {
+                case 1: LY_TRY(ex(k_scan_h16<WQ, WR, TQ, TR, M_IP, NSV, NSQ, 2, TILED, false, 1>)); break;
+                case 2: LY_TRY(ex(k_scan_h16<WQ, WR, TQ, TR, M_IP, NSV, NSQ, 2, TILED, false, 2>)); break;
+                case 3: LY_TRY(ex(k_scan_h16<WQ, WR, TQ, TR, M_IP, NSV, NSQ, 2, TILED, false, 3>)); break;
+                case 7: LY_TRY(ex(k_scan_h16<WQ, WR, TQ, TR, M_IP, NSV, NSQ, 2, TILED, false, 7>)); break;
+                case 11: LY_TRY(ex(k_scan_h16<WQ, WR, TQ, TR, M_IP, NSV, NSQ, 2, TILED, false, 11>)); break;
+                case 12: LY_TRY(ex(k_scan_h16<WQ, WR, TQ, TR, M_IP, NSV, NSQ, 2, TILED, false, 12>)); break;
+                case 15: LY_TRY(ex(k_scan_h16<WQ, WR, TQ, TR, M_IP, NSV, NSQ, 2, TILED, false, 15>)); break;
+                case 14: LY_TRY(ex(k_scan_h16<WQ, WR, TQ, TR, M_IP, NSV, NSQ, 2, TILED, false, 14>)); break;
+                case 13: LY_TRY(ex(k_scan_h16<WQ, WR, TQ, TR, M_IP, NSV, NSQ, 2, TILED, false, 13>)); break;
+                default: return set_error(LYNSE_ERR_INVALID_ARGUMENT, "unknown experiment");
+                }
+                LY_HIP(hipGetLastError());
+                return LYNSE_OK;
+            }
+        }
+        switch (metric) {
+        case M_IP: return go(k_scan_h16<WQ, WR, TQ, TR, M_IP, NSV, NSQ, 2, TILED, false>, 3);
+        case M_L2: return go(k_scan_h16<WQ, WR, TQ, TR, M_L2, NSV, NSQ, 2, TILED, false>, 4);
+        default: return go(k_scan_h16<WQ, WR, TQ, TR, M_COS, NSV, NSQ, 2, TILED, false>, 5);
+        }
+    }
+    switch (metric) {
+    case M_IP: return go(k_scan_h16<WQ, WR, TQ, TR, M_IP, NSV, NSQ, 2, TILED, true>, 0);
+    case M_L2: return go(k_scan_h16<WQ, WR, TQ, TR, M_L2, NSV, NSQ, 2, TILED, true>, 1);
+    default: return go(k_scan_h16<WQ, WR, TQ, TR, M_COS, NSV, NSQ, 2, TILED, true>, 2);
+    }
+}
+
+// f16 shadow rows [n16, n) (all rows again when the scale changed)
+static int ensure_shadow_locked(lynse_hip_flat* h) {
+    if (h->packed_only || h->n == 0) return LYNSE_OK;
+    if (h->cap16 < h->n) {
+        const uint64_t cap = std::max<uint64_t>(h->capacity, h->n);
+        _Float16* nr = nullptr;
+        LY_HIP(hipMalloc(&nr, (size_t)cap * h->ld16 * sizeof(_Float16) + 256));
+        if (h->rows16 && h->n16 && h->sv16 == h->sv)
+            LY_HIP(hipMemcpyAsync(nr, h->rows16, (size_t)h->n16 * h->ld16 * sizeof(_Float16), hipMemcpyDeviceToDevice, h->stream));
+        LY_HIP(hipStreamSynchronize(h->stream));
+        if (h->rows16) (void)hipFree(h->rows16);
+        h->rows16 = nr;
+        h->cap16 = cap;
+    }
+    if (h->sv16 != h->sv) h->n16 = 0;
+    if (h->n16 < h->n) {
+        const uint64_t chunks = (h->n - h->n16) * (h->ld16 / 8);
+        const uint32_t blocks = (uint32_t)std::min<uint64_t>((chunks + 255) / 256, (uint64_t)h->num_cu * 32);
+        hipLaunchKernelGGL(k_rows_to_f16, dim3(std::max<uint32_t>(blocks, 1)), dim3(256), 0, h->stream, h->rows, h->ld, h->dim,
+                           h->n16, h->n, h->sv, h->rows16, h->ld16);
+        LY_HIP(hipGetLastError());
+        LY_HIP(hipStreamSynchronize(h->stream));
+    }
+    h->n16 = h->n;
+    h->sv16 = h->sv;
+    return LYNSE_OK;
 }
 
 static int launch_scan_binary(const BinArgs& a, int metric, uint32_t grid, size_t lds, hipStream_t st) {
@@ -747,8 +836,9 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
     Workspace& w = h->ws;
     const bool binary = metric >= M_HAMMING;
     const bool asc = metric_ascending(metric);
+    const bool h16 = scan_variant() == 3;
     const bool glds = scan_variant() == 0;
-    const uint32_t nslab = glds ? (h->dim + GL_BK - 1) / GL_BK : (h->dim + SCAN_BK - 1) / SCAN_BK;
+    const uint32_t nslab = glds ? (h->dim + GL_BK - 1) / GL_BK : (h->dim + SCAN_BK - 1) / SCAN_BK;  // h16: HK == SCAN_BK == 64
     const bool small = nq <= SCAN_BQ_SMALL;
     const uint32_t qpad = small ? SCAN_BQ_SMALL : SCAN_BQ_LARGE;
     int ip_form = h->ip_form;
@@ -769,9 +859,9 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
         LY_HIP(hipStreamSynchronize(st));  // thr0 is a stack/heap temporary
     } else {
         // queries with index >= nq inside the padded tile must be finite: zero the image
-        LY_HIP(hipMemsetAsync(w.Q16, 0, (size_t)nslab * qpad * (glds ? GL_BK : SCAN_LDK) * sizeof(_Float16), st));
+        LY_HIP(hipMemsetAsync(w.Q16, 0, (size_t)nslab * qpad * (glds ? GL_BK : (h16 ? HK : SCAN_LDK)) * sizeof(_Float16), st));
         PrepArgs p{};
-        p.Q = w.Qf; p.D = h->dim; p.nq = nq; p.qpad = qpad; p.nslab = nslab; p.metric = metric; p.layout = glds ? 1 : 0;
+        p.Q = w.Qf; p.D = h->dim; p.nq = nq; p.qpad = qpad; p.nslab = nslab; p.metric = metric; p.layout = glds ? 1 : (h16 ? 2 : 0);
         p.sv = h->sv; p.vmax = h->vmax; p.vmin = h->vmin; p.cos_degenerate = h->cos_degenerate;
         p.Q16 = w.Q16; p.qinv = w.qinv; p.qn2 = w.qn2; p.qrinv = w.qrinv; p.marg2 = w.marg2; p.thr = w.thr;
         p.count = w.count; p.overflow = w.overflow;
@@ -818,6 +908,8 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
             a.V = h->rows; a.ld = h->ld; a.D = h->dim; a.row0 = s.r0; a.row1 = s.r1; a.Q16 = w.Q16;
             static const int big_rows = []() { const char* e = getenv("LYNSE_HIP_SCAN_BR"); return e ? atoi(e) : 256; }();
             uint32_t tile_rows = (glds && !small && big_rows == 256) ? 256u : (uint32_t)SCAN_BR;
+            if (h16) tile_rows = small ? 128u : 256u;
+            a.V16 = h->rows16; a.ld16 = h->ld16;
             if (glds && !small && big_rows == 192 && metric == M_IP) tile_rows = 192u;
             a.qpad = qpad; a.nq = nq; a.nslab = nslab; a.ntiles = (s.r1 - s.r0 + tile_rows - 1) / tile_rows;
             a.qinv = w.qinv; a.qn2 = w.qn2; a.qrinv = w.qrinv; a.thr = w.thr; a.vn2 = h->vn2; a.vrinv = h->vrinv;
@@ -835,7 +927,21 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
                 }
             }
             const int variant = scan_variant();
-            if (glds) {
+            if (h16) {
+                if (small) {
+                    const uint32_t grid = std::min<uint32_t>(a.ntiles, (uint32_t)h->num_cu * 2);
+                    LY_TRY((launch_scan_h16<1, 4, 1, 1, 3, 3, false>(a, metric, grid, st)));
+                } else {
+                    // measured on MI355X (10M x 768, 256 queries): IP is fastest with the 3+2-stage split rings, L2 / cosine
+                    // (norm ring in LDS, more registers in the epilogue) with <4,2,2,4> waves and 2+2 stages
+                    static const int w16env = []() { const char* e = getenv("LYNSE_HIP_SCAN_W16"); return e ? atoi(e) : -1; }();
+                    const int waves16 = w16env >= 0 ? w16env : (metric == M_IP ? 3 : 0);
+                    const uint32_t grid = std::min<uint32_t>(a.ntiles, (uint32_t)h->num_cu);
+                    if (waves16 == 2) LY_TRY((launch_scan_h16<2, 4, 4, 2, 2, 2, false>(a, metric, grid, st)));
+                    else if (waves16 == 3) LY_TRY((launch_scan_h16<2, 4, 4, 2, 3, 2, false>(a, metric, grid, st)));
+                    else LY_TRY((launch_scan_h16<4, 2, 2, 4, 2, 2, false>(a, metric, grid, st)));
+                }
+            } else if (glds) {
                 const bool scale = h->sv != 1.0f;
                 if (small) {
                     const uint32_t grid = std::min<uint32_t>(a.ntiles, (uint32_t)h->num_cu * 2);

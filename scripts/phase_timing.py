@@ -16,7 +16,7 @@ out = np.zeros(256 * 8 * 4, np.uint64)
 rc = L._lib.lib.lynse_hip_debug_phase_cycles(out.ctypes.data_as(C.c_void_p), out.size)
 a = out.reshape(256, 8, 4).astype(np.float64)
 tiles = (N - 2097152 + 255) // 256
-iters = tiles / 256 * 24
+iters = tiles / 256 * (12 if os.environ.get("LYNSE_HIP_SCAN_VARIANT", "3") == "3" else 24)
 print("rc", rc, "iters/block ~", iters)
 names = ["wait_vmcnt", "barrier", "issue", "compute"]
 for w in (0, 3, 7):
