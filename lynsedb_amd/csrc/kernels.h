@@ -316,6 +316,9 @@ struct ScanArgs {
     uint32_t ld, D;
     const _Float16* V16;  // k_scan_h16: f16 shadow of the rows, (half)(v * sv), pitch ld16 halves (multiple of 8), pad columns zero
     uint32_t ld16;
+    // k_scan_h16 sample stage: tile t starts at row0 + t * tile_stride (0 = contiguous tiles).  Later stages skip the
+    // emission of the skip_tiles sample tiles (rows [t * skip_stride, +BR), t < skip_tiles) — they are already candidates.
+    uint32_t tile_stride, skip_stride, skip_tiles;
     uint32_t row0, row1;  // stage rows [row0,row1)
     const _Float16* Q16;  // [nslab][qpad][72]
     uint32_t qpad, nq, nslab, ntiles;
@@ -941,6 +944,7 @@ __global__ void __launch_bounds__(WQ * WR * 64, (WQ * WR >= 8) ? (WQ * WR / 4) :
     if (blockIdx.x >= a.ntiles) return;
     const uint32_t my_tiles = (a.ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x;
     const uint32_t G = my_tiles * a.nslab;
+    const uint32_t tstride = a.tile_stride ? a.tile_stride : (uint32_t)BR;
     const bool ragged_k = RAG && (a.ld16 % HK) != 0;  // last slab reaches past ld16: clamp columns (they meet zeros in the query image)
 
     uint32_t v_rowoff[VPW], v_col[VPW];
@@ -971,7 +975,7 @@ __global__ void __launch_bounds__(WQ * WR * 64, (WQ * WR >= 8) ? (WQ * WR / 4) :
             rbase = td.row0;
             last = td.row0 + td.nrows - 1;
         } else {
-            rbase = a.row0 + vs_tile * BR;
+            rbase = a.row0 + vs_tile * tstride;
             last = a.row1 - 1;
         }
         if (NORMS_LDS) {
@@ -1136,13 +1140,15 @@ __global__ void __launch_bounds__(WQ * WR * 64, (WQ * WR >= 8) ? (WQ * WR / 4) :
         v_advance();
 
         if (++s_in_tile == a.nslab) {
-            uint32_t rbase = a.row0 + tile * BR;
+            uint32_t rbase = a.row0 + tile * tstride;
             uint32_t row_end = a.row1;
             IvfTile td{};
             if (TILED) {
                 td = a.tiles[tile];
                 rbase = td.row0;
                 row_end = td.row0 + td.nrows;
+            } else if (a.skip_stride && rbase % a.skip_stride == 0 && rbase / a.skip_stride < a.skip_tiles) {
+                row_end = rbase;  // a sample tile: its rows were emitted by the sample stage
             }
             const float* nrm = reinterpret_cast<const float*>(smem + NORM_RING + (c_tileseq % NORM_SLOTS) * 1024);
             ++c_tileseq;
@@ -1176,8 +1182,9 @@ __global__ void __launch_bounds__(WQ * WR * 64, (WQ * WR >= 8) ? (WQ * WR / 4) :
                             const uint32_t m = rbase + wr * (TR * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
                             const bool rok = m < row_end;
                             const float sc = score(i, j, r, m, rok);
-                            if (c_ok[j] && rok && (m - a.row0) < a.cap)
-                                a.cand[(size_t)n * a.cap + (m - a.row0)] = make_key(sc, m, ASC);
+                            const uint32_t slot = tile * BR + (m - rbase);  // dense over the (possibly strided) tiles
+                            if (c_ok[j] && rok && slot < a.cap)
+                                a.cand[(size_t)n * a.cap + slot] = make_key(sc, m, ASC);
                         }
                 } else {
 #pragma unroll
@@ -1552,69 +1559,163 @@ struct SelectArgs {
     uint32_t ld, D;
 };
 
+// k_select finds the k-th best key with an 8-pass MSB radix select over the keys in LDS (256-bin
+// histograms, wave-aggregated LDS atomics, one-wave prefix scan) instead of sorting them: the survivors
+// only have to be FOUND, k_final orders them once at the end.  (A full bitonic sort of 8192 keys cost
+// 97 us per stage; the radix select is ~10x cheaper.)  The rare compaction path (more than keep_max
+// survivors: rescore exactly, cut to the exact top-k) still sorts.
 template <int NT>
 __global__ void __launch_bounds__(NT) k_select(SelectArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint64_t* keys = reinterpret_cast<uint64_t*>(smem);
-    __shared__ uint32_t s_keep;
+    __shared__ uint32_t hist[256];
+    __shared__ uint32_t s_keep, s_rank;
+    __shared__ uint64_t s_prefix;
     const uint32_t q = blockIdx.x;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63;
     const bool asc = metric_ascending(a.metric);
     uint32_t n = a.emit_all_n >= 0 ? (uint32_t)a.emit_all_n : a.count[q];
     if (n > a.cap) {
         if (tid == 0) a.overflow[q] = 1u;
         n = a.cap;
     }
-    uint32_t np2 = next_pow2(n < 2 ? 2 : n);
-    const uint64_t* src = a.cand + (size_t)q * a.cap;
-    for (uint32_t i = tid; i < np2; i += NT) keys[i] = i < n ? src[i] : KEY_SENTINEL;
-    if (tid == 0) s_keep = 0;
-    bitonic_sort_lds<NT>(keys, np2, tid);
+    uint64_t* gkeys = a.cand + (size_t)q * a.cap;
+    if (n < a.k || a.k == 0) {  // fewer than k candidates so far: keep all, the threshold stays open
+        if (tid == 0) {
+            a.count[q] = n;
+            a.thr[q] = asc ? LY_INF : -LY_INF;
+        }
+        return;
+    }
+    for (uint32_t i = tid; i < n; i += NT) keys[i] = gkeys[i];
+    if (tid == 0) { s_keep = 0; s_prefix = 0; s_rank = a.k - 1; }
+    __syncthreads();
 
-    float thr_new = asc ? LY_INF : -LY_INF;
-    uint32_t keep = n;
-    if (n >= a.k && a.k > 0) {
-        const float tau = key_score(keys[a.k - 1], asc);
-        if (a.exact) {
-            // FLAT scans rows in ascending id order, so a later tie of the k-th score can never win: strict
-            // cut.  Packed-binary IVF scans slabs (keys carry ORIGINAL ids): a later tie with a smaller id
-            // must still get in -> non-strict cut.
-            thr_new = a.keep_ties ? tau : (asc ? nextafterf(tau, -LY_INF) : nextafterf(tau, LY_INF));
-            keep = a.k;
-        } else {
-            const float m2 = a.marg2[q];
-            thr_new = asc ? tau + m2 : tau - m2;
-            uint32_t local = 0;
-            for (uint32_t i = tid; i < n; i += NT) {
-                const float s = key_score(keys[i], asc);
-                local += (asc ? (s <= thr_new) : (s >= thr_new)) ? 1u : 0u;
-            }
-            if (local) atomicAdd(&s_keep, local);
-            __syncthreads();
-            keep = s_keep;
-            if (keep < a.k) keep = a.k;  // NaN-free safety: never drop the current top-k
-            if (keep > a.keep_max) {
-                rescore_keys<NT>(keys, keep, a.metric, a.ip_form, a.Qf + (size_t)q * a.D, a.V, a.ld, a.D, asc, tid);
-                for (uint32_t i = keep + tid; i < np2; i += NT) keys[i] = KEY_SENTINEL;
-                bitonic_sort_lds<NT>(keys, np2, tid);
-                const float xk = key_score(keys[a.k - 1], asc);
-                uint32_t kept = a.k;
-                if (a.keep_ties) {
-                    if (tid == 0) s_keep = 0;
-                    __syncthreads();
-                    uint32_t ties = 0;
-                    for (uint32_t i = a.k + tid; i < keep; i += NT) ties += key_score(keys[i], asc) == xk ? 1u : 0u;
-                    if (ties) atomicAdd(&s_keep, ties);
-                    __syncthreads();
-                    kept += s_keep;
-                }
-                keep = kept;
-                thr_new = asc ? xk + m2 : xk - m2;
+    // ---- k-th smallest key (keys are unique: the low word is the row)
+    for (int shift = 56; shift >= 0; shift -= 8) {
+        if (tid < 256) hist[tid] = 0;
+        __syncthreads();
+        const uint64_t prefix = s_prefix;
+        const uint64_t himask = shift == 56 ? 0ull : (~0ull << (shift + 8));
+        for (uint32_t i0 = 0; i0 < n; i0 += NT) {
+            const uint32_t i = i0 + tid;
+            const bool on = i < n && (keys[i] & himask) == prefix;
+            const uint32_t bin = on ? (uint32_t)(keys[i] >> shift) & 255u : 0u;
+            // the high bytes of the scores are (nearly) the same for every key: one atomic per wave for the
+            // first lane's bin, plain atomics for the lanes that differ
+            const uint64_t act = __ballot(on);
+            if (act) {
+                const int leader = __builtin_ctzll(act);
+                const uint32_t first = __shfl(bin, leader, 64);
+                const uint64_t same = __ballot(on && bin == first);
+                if (lane == leader) atomicAdd(&hist[first], (uint32_t)__popcll(same));
+                if (on && bin != first) atomicAdd(&hist[bin], 1u);
             }
         }
+        __syncthreads();
+        if (tid < 64) {  // one wave: 4 bins per lane, inclusive scan over lanes, the bucket holding the rank
+            const uint32_t rank = s_rank;
+            const uint32_t h0 = hist[4 * lane], h1 = hist[4 * lane + 1], h2 = hist[4 * lane + 2], h3 = hist[4 * lane + 3];
+            const uint32_t sum = h0 + h1 + h2 + h3;
+            uint32_t incl = sum;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t up = __shfl_up(incl, o, 64);
+                if (lane >= o) incl += up;
+            }
+            const uint32_t excl = incl - sum;
+            if (excl <= rank && rank < incl) {
+                uint32_t r = rank - excl, b = 4 * lane;
+                if (r >= h0) { r -= h0; ++b; if (r >= h1) { r -= h1; ++b; if (r >= h2) { r -= h2; ++b; } } }
+                s_rank = r;
+                s_prefix = prefix | ((uint64_t)b << shift);
+            }
+        }
+        __syncthreads();
     }
-    uint64_t* dst = a.cand + (size_t)q * a.cap;
-    for (uint32_t i = tid; i < keep; i += NT) dst[i] = keys[i];
+    const uint64_t kth = s_prefix;
+    const float tau = key_score(kth, asc);
+
+    float thr_new;
+    uint32_t keep;
+    bool sorted_path = false;
+    if (a.exact) {
+        // FLAT scans rows in ascending id order, so a later tie of the k-th score can never win: strict
+        // cut.  Packed-binary IVF scans slabs (keys carry ORIGINAL ids): a later tie with a smaller id
+        // must still get in -> non-strict cut.
+        thr_new = a.keep_ties ? tau : (asc ? nextafterf(tau, -LY_INF) : nextafterf(tau, LY_INF));
+        keep = a.k;
+    } else {
+        const float m2 = a.marg2[q];
+        thr_new = asc ? tau + m2 : tau - m2;
+        uint32_t local = 0;
+        for (uint32_t i = tid; i < n; i += NT) {
+            const float sc = key_score(keys[i], asc);
+            local += (keys[i] <= kth || (asc ? (sc <= thr_new) : (sc >= thr_new))) ? 1u : 0u;
+        }
+        for (int o = 32; o > 0; o >>= 1) local += __shfl_xor(local, o, 64);
+        if (lane == 0 && local) atomicAdd(&s_keep, local);
+        __syncthreads();
+        keep = s_keep;
+        sorted_path = keep > a.keep_max;
+    }
+
+    if (sorted_path) {
+        // ---- compaction: too many survivors (huge margins / massive ties): rescore them exactly and cut to the
+        // exact top-k (+ ties of the k-th score when rows are not scanned in id order)
+        const float m2 = a.marg2[q];
+        const uint32_t np2 = next_pow2(n < 2 ? 2 : n);
+        __syncthreads();
+        for (uint32_t i = n + tid; i < np2; i += NT) keys[i] = KEY_SENTINEL;
+        bitonic_sort_lds<NT>(keys, np2, tid);  // survivors are a prefix of the sorted keys
+        rescore_keys<NT>(keys, keep, a.metric, a.ip_form, a.Qf + (size_t)q * a.D, a.V, a.ld, a.D, asc, tid);
+        for (uint32_t i = keep + tid; i < np2; i += NT) keys[i] = KEY_SENTINEL;
+        bitonic_sort_lds<NT>(keys, np2, tid);
+        const float xk = key_score(keys[a.k - 1], asc);
+        uint32_t kept = a.k;
+        if (a.keep_ties) {
+            if (tid == 0) s_keep = 0;
+            __syncthreads();
+            uint32_t ties = 0;
+            for (uint32_t i = a.k + tid; i < keep; i += NT) ties += key_score(keys[i], asc) == xk ? 1u : 0u;
+            if (ties) atomicAdd(&s_keep, ties);
+            __syncthreads();
+            kept += s_keep;
+        }
+        for (uint32_t i = tid; i < kept; i += NT) gkeys[i] = keys[i];
+        if (tid == 0) {
+            a.count[q] = kept;
+            a.thr[q] = asc ? xk + m2 : xk - m2;
+        }
+        return;
+    }
+
+    // ---- write the survivors back, compacted (order is irrelevant: one atomic per wave reserves the slots)
+    __syncthreads();
+    if (tid == 0) s_keep = 0;
+    __syncthreads();
+    for (uint32_t i0 = 0; i0 < n; i0 += NT) {
+        const uint32_t i = i0 + tid;
+        bool pass = false;
+        uint64_t key = 0;
+        if (i < n) {
+            key = keys[i];
+            if (a.exact) {
+                pass = key <= kth;
+            } else {
+                const float sc = key_score(key, asc);
+                pass = key <= kth || (asc ? (sc <= thr_new) : (sc >= thr_new));
+            }
+        }
+        const uint64_t m = __ballot(pass);
+        if (m) {
+            uint32_t base = 0;
+            const int leader = __builtin_ctzll(m);
+            if (lane == leader) base = atomicAdd(&s_keep, (uint32_t)__popcll(m));
+            base = __shfl(base, leader, 64);
+            if (pass) gkeys[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = key;
+        }
+    }
     if (tid == 0) {
         a.count[q] = keep;
         a.thr[q] = thr_new;

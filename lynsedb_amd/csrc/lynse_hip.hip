@@ -178,7 +178,7 @@ struct lynse_hip_flat {
 
     uint64_t row_stride = 1, row_offset = 0;
     int ip_form = LYNSE_IPFORM_AUTO;
-    uint32_t stage0_rows = 4096, growth = 8, cap = 8192;
+    uint32_t stage0_rows = 4096, growth = 8, cap = 16384;
 
     Workspace ws;
 
@@ -598,16 +598,48 @@ static int ensure_workspace(lynse_hip_flat* h, uint32_t k /* caller's k = output
     return LYNSE_OK;
 }
 
-struct Stage { uint32_t r0, r1; };
+struct Stage {
+    uint32_t r0, r1;
+    uint32_t sample_tiles = 0, sample_stride = 0;  // sample stage: sample_tiles tiles of tile_rows rows at t * sample_stride
+};
 
-static std::vector<Stage> make_plan(const lynse_hip_flat* h, uint32_t k, bool safe) {
+// level 0: sampled plan (k_scan_h16 only) — stage 0 scans `cap/2` rows taken as evenly spread tiles, so the first
+//          threshold is representative of the whole shard whatever the insertion order (a collection sorted by
+//          similarity to the query would overflow every stage of the contiguous plan); the following stages grow
+//          by min(16, cap/(8k)) — measured best on 10M and 1.25M rows (larger growth: fewer launches but thousands
+//          of emitted keys per query in the first full stage);
+// level 1: contiguous plan [0,S0) [S0,8*S0) ... (all other kernels; retry after an overflow of level 0);
+// level 2: exhaustive plan, stages of cap/2 rows — cannot overflow.
+static std::vector<Stage> make_plan(const lynse_hip_flat* h, uint32_t k, int level, uint32_t tile_rows) {
     std::vector<Stage> plan;
     const uint64_t n = h->n;
     if (n == 0) return plan;
-    if (safe) {
+    if (level >= 2) {
         const uint32_t step = h->cap / 2;
         for (uint64_t r = 0; r < n; r += step) plan.push_back({(uint32_t)r, (uint32_t)std::min<uint64_t>(n, r + step)});
         return plan;
+    }
+    if (level == 0 && tile_rows && n > 4ull * h->cap) {
+        const uint32_t S = h->cap / 2;
+        const uint32_t nt = S / tile_rows;
+        const uint64_t stride = (n - tile_rows) / (nt - 1) / tile_rows * tile_rows;
+        if (stride > tile_rows) {
+            Stage s0{0u, (uint32_t)n};
+            s0.sample_tiles = nt;
+            s0.sample_stride = (uint32_t)stride;
+            plan.push_back(s0);
+            static const uint64_t gmax = []() { const char* e = getenv("LYNSE_HIP_SAMPLE_GROWTH"); return e ? (uint64_t)atoi(e) : 16ull; }();
+            const uint64_t g = std::max<uint64_t>(2, std::min<uint64_t>(gmax, h->cap / (8ull * std::max<uint32_t>(k, 1))));
+            uint64_t seen = S, b = 0;
+            while (b < n) {
+                uint64_t nb = std::min<uint64_t>(n, (seen * g + tile_rows - 1) / tile_rows * tile_rows);
+                if (n - nb < nb / 8) nb = n;  // do not leave a sliver for an extra launch
+                plan.push_back({(uint32_t)b, (uint32_t)nb});
+                seen = nb;
+                b = nb;
+            }
+            return plan;
+        }
     }
     uint64_t s0 = std::max<uint64_t>(h->stage0_rows, std::min<uint64_t>(h->cap, 4ull * k));
     s0 = std::min<uint64_t>(std::min<uint64_t>(s0, h->cap), n);
@@ -830,9 +862,9 @@ static int get_event(lynse_hip_flat* h, size_t idx, hipEvent_t* out) {
 }
 
 // One chunk (<= QCHUNK queries) whose inputs are already in the workspace (Qf for float metrics,
-// QW for binary).  Results land in ws.out_*.  `safe` selects the exhaustive plan.
-static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k, int metric, bool safe, hipStream_t st,
-                     size_t* ev_used, std::vector<std::pair<size_t, uint64_t>>* scan_events) {
+// QW for binary).  Results land in ws.out_*.  `level` selects the stage plan (make_plan).
+static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k, int metric, int level, hipStream_t st,
+                     size_t* ev_used, std::vector<std::pair<size_t, uint64_t>>* scan_events, bool* sampled_plan) {
     Workspace& w = h->ws;
     const bool binary = metric >= M_HAMMING;
     const bool asc = metric_ascending(metric);
@@ -869,7 +901,12 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
         LY_HIP(hipGetLastError());
     }
 
-    const std::vector<Stage> plan = make_plan(h, k, safe);
+    // the sampled plan needs the strided-tile support of k_scan_h16; every other kernel starts at level 1
+    const uint32_t plan_tile = (h16 && !binary) ? (small ? 128u : 256u) : 0u;
+    static const int no_sample = []() { const char* e = getenv("LYNSE_HIP_NO_SAMPLE_PLAN"); return e ? atoi(e) : 0; }();
+    const std::vector<Stage> plan = make_plan(h, k, (level == 0 && (!plan_tile || no_sample)) ? 1 : level, plan_tile);
+    const Stage sample = (!plan.empty() && plan[0].sample_tiles) ? plan[0] : Stage{0, 0};
+    *sampled_plan = sample.sample_tiles != 0;
     for (size_t si = 0; si < plan.size(); ++si) {
         const Stage s = plan[si];
         const bool emit_all = si == 0;
@@ -906,12 +943,15 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
         } else {
             ScanArgs a{};
             a.V = h->rows; a.ld = h->ld; a.D = h->dim; a.row0 = s.r0; a.row1 = s.r1; a.Q16 = w.Q16;
+            a.tile_stride = s.sample_stride;  // 0 = contiguous
+            if (!s.sample_tiles && sample.sample_tiles) { a.skip_stride = sample.sample_stride; a.skip_tiles = sample.sample_tiles; }
             static const int big_rows = []() { const char* e = getenv("LYNSE_HIP_SCAN_BR"); return e ? atoi(e) : 256; }();
             uint32_t tile_rows = (glds && !small && big_rows == 256) ? 256u : (uint32_t)SCAN_BR;
             if (h16) tile_rows = small ? 128u : 256u;
             a.V16 = h->rows16; a.ld16 = h->ld16;
             if (glds && !small && big_rows == 192 && metric == M_IP) tile_rows = 192u;
             a.qpad = qpad; a.nq = nq; a.nslab = nslab; a.ntiles = (s.r1 - s.r0 + tile_rows - 1) / tile_rows;
+            if (s.sample_tiles) a.ntiles = s.sample_tiles;
             a.qinv = w.qinv; a.qn2 = w.qn2; a.qrinv = w.qrinv; a.thr = w.thr; a.vn2 = h->vn2; a.vrinv = h->vrinv;
             a.sv = h->sv; a.cand = w.cand; a.count = w.count; a.cap = w.cap; a.emit_all = emit_all ? 1 : 0;
             static const int dbg = []() { const char* e = getenv("LYNSE_HIP_DEBUG_FLAGS"); return e ? atoi(e) : 0; }();
@@ -971,12 +1011,13 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
         }
         if (h->profiling) {
             LY_HIP(hipEventRecord(e1, st));
-            scan_events->push_back({*ev_used - 2, (uint64_t)(s.r1 - s.r0)});
+            scan_events->push_back({*ev_used - 2, s.sample_tiles ? (uint64_t)s.sample_tiles * plan_tile : (uint64_t)(s.r1 - s.r0)});
         }
         SelectArgs sa{};
         sa.cand = w.cand; sa.count = w.count; sa.overflow = w.overflow; sa.thr = w.thr; sa.marg2 = w.marg2;
         sa.k = k; sa.cap = w.cap; sa.keep_max = w.cap / 2; sa.metric = metric; sa.ip_form = ip_form;
-        sa.exact = binary ? 1 : 0; sa.emit_all_n = emit_all ? (int)(s.r1 - s.r0) : -1;
+        sa.exact = binary ? 1 : 0;
+        sa.emit_all_n = emit_all ? (s.sample_tiles ? (int)(s.sample_tiles * plan_tile) : (int)(s.r1 - s.r0)) : -1;
         sa.Qf = w.Qf; sa.V = h->rows; sa.ld = h->ld; sa.D = h->dim;
         hipLaunchKernelGGL(k_select<SEL_NT>, dim3(nq), dim3(SEL_NT), (size_t)w.cap * 8, st, sa);
         LY_HIP(hipGetLastError());
@@ -1056,18 +1097,18 @@ static int search_impl(lynse_hip_flat* h, const void* q_src, bool packed_queries
         } else {
             LY_HIP(hipMemcpyAsync(w.Qf, (const float*)q_src + q0 * h->dim, (size_t)nqc * h->dim * 4, in_kind, st));
         }
-        bool safe = false;
-        for (int attempt = 0; attempt < 2; ++attempt) {
-            LY_TRY(run_chunk(h, nqc, kk, k, metric, safe, st, &ev_used, &scan_events));
+        for (int level = 0; level < 3; ++level) {  // sampled plan -> contiguous plan -> exhaustive plan (make_plan)
+            bool sampled = false;
+            LY_TRY(run_chunk(h, nqc, kk, k, metric, level, st, &ev_used, &scan_events, &sampled));
             std::vector<uint32_t> ovf(nqc);
             LY_HIP(hipMemcpyAsync(ovf.data(), w.overflow, nqc * 4, hipMemcpyDeviceToHost, st));
             LY_HIP(hipStreamSynchronize(st));
             uint32_t nov = 0;
             for (uint32_t v : ovf) nov += v ? 1 : 0;
             if (nov == 0) break;
-            if (safe) return set_error(LYNSE_ERR_INTERNAL, "candidate overflow on the exhaustive plan");
+            if (level == 2) return set_error(LYNSE_ERR_INTERNAL, "candidate overflow on the exhaustive plan");
             fallback_queries += nov;
-            safe = true;  // rerun the chunk on the exhaustive plan
+            if (level == 0 && !sampled) level = 1;  // level 1 would repeat the same contiguous plan
         }
         // outputs: workspace rows are [nqc][kk]; caller layout is [nq][k]
         LY_HIP(hipMemcpyAsync(out_rows + q0 * k, w.out_rows, (size_t)nqc * k * 8, out_kind, st));
