@@ -125,6 +125,17 @@ int lynse_hip_flat_read_packed(lynse_hip_flat *h, uint64_t first, uint64_t n, ui
 int lynse_hip_flat_search_f32(lynse_hip_flat *h, const float *queries, uint64_t nq, uint32_t k,
                               int metric, uint64_t *out_rows, float *out_dists,
                               uint32_t *out_counts);
+/* FlatMmap::search_filtered (src/storage/flat_mmap.rs:491-815; VectorStore::search_filtered
+ * vector_store.rs:1006-1040; Collection brute_force_search_filtered engine.rs:5541-5566): top-k among the rows
+ * listed in `subset_rows` (local row indices of this shard, host memory; ids >= len are skipped like the
+ * reference skips them, duplicates count once).  k is clamped to min(k, n_subset, len) (:501).  One subset serves
+ * the whole batch.  Binary metrics pack the f32 queries (pack_binary_query).  The subset becomes a row bitmask on
+ * the device — the reference's own bitset strategy (:672-679) — applied in the scan epilogue; distances use the
+ * single-row kernels as the reference does on this path (:553-560), results are in canonical (distance, row)
+ * order. */
+int lynse_hip_flat_search_filtered_f32(lynse_hip_flat *h, const float *queries, uint64_t nq, uint32_t k,
+                                       int metric, const uint64_t *subset_rows, uint64_t n_subset,
+                                       uint64_t *out_rows, float *out_dists, uint32_t *out_counts);
 /* Same with every buffer already resident in this handle's device memory; enqueued on `stream`
  * (a hipStream_t, NULL = the handle's own non-blocking stream) and synchronised before returning.
  * Device inputs of every *_device entry must be COMPLETE when the call is made (synchronise the

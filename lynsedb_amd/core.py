@@ -175,6 +175,28 @@ class FlatIndex:
         check(lib.lynse_hip_flat_search_f32(self._h, _ptr(q), nq, k, m, _ptr(rows), _ptr(dists), _ptr(counts)))
         return rows[:, :k], dists[:, :k], counts
 
+    def search_filtered_batch_arrays(self, queries, k: int, metric, subset_rows):
+        """`FlatMmap::search_filtered` (flat_mmap.rs:491-815) for a batch sharing one subset of row indices."""
+        m = metric if isinstance(metric, int) else metric_from_str(metric)
+        q = _f32(queries, 2, "queries")
+        if q.shape[1] != self._dim:
+            raise ValueError(f"query dimension mismatch: expected {self._dim}, got {q.shape[1]}")
+        sub = np.ascontiguousarray(np.asarray(subset_rows).reshape(-1), dtype=np.uint64)
+        nq, k = q.shape[0], int(k)
+        rows = np.empty((nq, max(k, 1)), np.uint64)
+        dists = np.empty((nq, max(k, 1)), np.float32)
+        counts = np.zeros(nq, np.uint32)
+        check(lib.lynse_hip_flat_search_filtered_f32(self._h, _ptr(q), nq, k, m, _ptr(sub) if sub.size else None, sub.size,
+                                                     _ptr(rows), _ptr(dists), _ptr(counts)))
+        return rows[:, :k], dists[:, :k], counts
+
+    def search_filtered(self, query, k: int, metric, subset_rows):
+        """-> (rows u32[], distances f32[]) among `subset_rows` only."""
+        q = _f32(query, 1, "query")
+        rows, dists, counts = self.search_filtered_batch_arrays(q.reshape(1, -1), k, metric, subset_rows)
+        c = int(counts[0])
+        return rows[0, :c].astype(np.uint32), dists[0, :c].copy()
+
     def search_packed_arrays(self, query_words, k: int, metric):
         m = metric if isinstance(metric, int) else metric_from_str(metric)
         qw = np.ascontiguousarray(query_words, dtype=np.uint64)

@@ -319,6 +319,10 @@ struct ScanArgs {
     // k_scan_h16 sample stage: tile t starts at row0 + t * tile_stride (0 = contiguous tiles).  Later stages skip the
     // emission of the skip_tiles sample tiles (rows [t * skip_stride, +BR), t < skip_tiles) — they are already candidates.
     uint32_t tile_stride, skip_stride, skip_tiles;
+    // filtered search (FlatMmap::search_filtered): bit r of mask = row r is in the subset (32-bit words; stage
+    // boundaries are multiples of 32).  Rows outside the subset are never emitted; the emit-all stage writes
+    // KEY_SENTINEL into their slots and k_select drops those.  nullptr = unfiltered.
+    const uint32_t* mask;
     uint32_t row0, row1;  // stage rows [row0,row1)
     const _Float16* Q16;  // [nslab][qpad][72]
     uint32_t qpad, nq, nslab, ntiles;
@@ -1176,24 +1180,29 @@ __global__ void __launch_bounds__(WQ * WR * 64, (WQ * WR >= 8) ? (WQ * WR / 4) :
                 }
                 if (a.emit_all && !TILED) {
 #pragma unroll
-                    for (int i = 0; i < TR; ++i)
+                    for (int i = 0; i < TR; ++i) {
+                        const uint32_t mw = a.mask ? a.mask[(rbase + wr * (TR * 32) + i * 32) >> 5] : 0xffffffffu;
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
-                            const uint32_t m = rbase + wr * (TR * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                            const uint32_t bit = (r & 3) + 8 * (r >> 2) + 4 * hi;
+                            const uint32_t m = rbase + wr * (TR * 32) + i * 32 + bit;
                             const bool rok = m < row_end;
                             const float sc = score(i, j, r, m, rok);
                             const uint32_t slot = tile * BR + (m - rbase);  // dense over the (possibly strided) tiles
                             if (c_ok[j] && rok && slot < a.cap)
-                                a.cand[(size_t)n * a.cap + slot] = make_key(sc, m, ASC);
+                                a.cand[(size_t)n * a.cap + slot] = ((mw >> bit) & 1u) ? make_key(sc, m, ASC) : KEY_SENTINEL;
                         }
+                    }
                 } else {
 #pragma unroll
                     for (int i = 0; i < TR; ++i) {
                         uint32_t msk = 0;
+                        const uint32_t mw = (!TILED && a.mask) ? a.mask[(rbase + wr * (TR * 32) + i * 32) >> 5] : 0xffffffffu;
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
-                            const uint32_t m = rbase + wr * (TR * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                            const bool rok = m < row_end;
+                            const uint32_t bit = (r & 3) + 8 * (r >> 2) + 4 * hi;
+                            const uint32_t m = rbase + wr * (TR * 32) + i * 32 + bit;
+                            const bool rok = m < row_end && ((mw >> bit) & 1u);
                             const float sc = score(i, j, r, m, rok);
                             const bool pass = ASC ? (sc <= c_thr[j]) : (sc >= c_thr[j]);
                             if (c_ok[j] && rok && pass) msk |= 1u << r;
@@ -1250,6 +1259,7 @@ struct BinArgs {
     uint32_t cap;
     int emit_all;
     int strict_unused;
+    const uint32_t* mask;  // filtered search: bit r = row r is in the subset (k_scan_binary_rows only)
 };
 
 constexpr int BIN_MAX_CHUNKS = 4;  // 4 chunks x 8 lanes x 2 words = 64 words = 4096 bits
@@ -1333,6 +1343,16 @@ __global__ void __launch_bounds__(256) k_scan_binary(BinArgs a) {
 // ------------------------------------------------------------------------------------------------
 typedef const uint32_t __attribute__((address_space(4))) const_u32;
 typedef const float __attribute__((address_space(4))) const_f32;
+
+// subset row ids -> row bitmask (FlatMmap::search_filtered builds the same bitset, flat_mmap.rs:672-679);
+// ids >= n are skipped like the reference skips them.  The mask must be zeroed first.
+__global__ void __launch_bounds__(256) k_mask_build(const uint64_t* __restrict__ subset, uint64_t m, uint64_t n,
+                                                    uint32_t* __restrict__ mask) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t r = subset[i];
+        if (r < n) atomicOr(&mask[r >> 5], 1u << (r & 31));
+    }
+}
 
 __global__ void __launch_bounds__(256) k_pad_words(const uint64_t* __restrict__ src, uint32_t W, uint64_t* __restrict__ dst,
                                                    uint32_t wcap, uint32_t nq) {
@@ -1447,6 +1467,7 @@ __global__ void __launch_bounds__(256) k_scan_binary_rows(BinArgs a) {
         __builtin_amdgcn_wave_barrier();  // the tile is rewritten by the next row block
         const uint32_t rb_next = rb + gridDim.x * 256;
         if (PF && rb_next < a.row1) fetch(rb_next);
+        const bool in_subset = !a.mask || (valid && ((a.mask[row >> 5] >> (row & 31)) & 1u));
         uint32_t px = 0;
         if (KIND != 0) {
 #pragma unroll
@@ -1472,7 +1493,7 @@ __global__ void __launch_bounds__(256) k_scan_binary_rows(BinArgs a) {
                 const float est = 1.0f - (float)num * __builtin_amdgcn_rcpf((float)den);  // |error| < 1e-6
                 pass = den == 0 || est <= thr + 2e-6f;
             }
-            if (valid && (a.emit_all || pass)) {
+            if (valid && (a.emit_all || (pass && in_subset))) {
                 if (KIND != 0) {
                     const uint32_t den = KIND == 1 ? px + pq - c0 : px + pq;
                     const uint32_t num = KIND == 1 ? c0 : 2u * c0;
@@ -1480,7 +1501,7 @@ __global__ void __launch_bounds__(256) k_scan_binary_rows(BinArgs a) {
                 }
                 if (a.emit_all || dist <= thr) {
                     const uint32_t slot = a.emit_all ? (row - a.row0) : atomicAdd(&a.count[q], 1u);
-                    if (slot < a.cap) a.cand[(size_t)q * a.cap + slot] = make_key(dist, row, true);
+                    if (slot < a.cap) a.cand[(size_t)q * a.cap + slot] = in_subset ? make_key(dist, row, true) : KEY_SENTINEL;
                 }
             }
         }
@@ -1554,6 +1575,7 @@ struct SelectArgs {
     int metric, ip_form, exact;
     int emit_all_n;  // >=0: stage 0 wrote exactly this many keys per query
     int keep_ties;   // IVF: rows are not scanned in id order -> the cut must let ties of the k-th score through
+    int drop_sentinels;  // filtered search: the emit-all stage wrote KEY_SENTINEL for rows outside the subset
     const float* Qf;
     const float* V;
     uint32_t ld, D;
@@ -1580,14 +1602,39 @@ __global__ void __launch_bounds__(NT) k_select(SelectArgs a) {
         n = a.cap;
     }
     uint64_t* gkeys = a.cand + (size_t)q * a.cap;
+    bool compacted = false;
+    if (a.drop_sentinels && a.emit_all_n >= 0) {  // load + drop the slots of rows outside the subset
+        if (tid == 0) s_keep = 0;
+        __syncthreads();
+        for (uint32_t i0 = 0; i0 < n; i0 += NT) {
+            const uint32_t i = i0 + tid;
+            const uint64_t key = i < n ? gkeys[i] : KEY_SENTINEL;
+            const bool real = key != KEY_SENTINEL;
+            const uint64_t m = __ballot(real);
+            if (m) {
+                uint32_t base = 0;
+                const int leader = __builtin_ctzll(m);
+                if (lane == leader) base = atomicAdd(&s_keep, (uint32_t)__popcll(m));
+                base = __shfl(base, leader, 64);
+                if (real) keys[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = key;
+            }
+        }
+        __syncthreads();
+        n = s_keep;
+        compacted = true;
+        __syncthreads();
+    }
     if (n < a.k || a.k == 0) {  // fewer than k candidates so far: keep all, the threshold stays open
+        if (compacted)
+            for (uint32_t i = tid; i < n; i += NT) gkeys[i] = keys[i];
         if (tid == 0) {
             a.count[q] = n;
             a.thr[q] = asc ? LY_INF : -LY_INF;
         }
         return;
     }
-    for (uint32_t i = tid; i < n; i += NT) keys[i] = gkeys[i];
+    if (!compacted)
+        for (uint32_t i = tid; i < n; i += NT) keys[i] = gkeys[i];
     if (tid == 0) { s_keep = 0; s_prefix = 0; s_rank = a.k - 1; }
     __syncthreads();
 

@@ -181,6 +181,11 @@ struct lynse_hip_flat {
     uint32_t stage0_rows = 4096, growth = 8, cap = 16384;
 
     Workspace ws;
+    // filtered search: row bitmask of the current subset + staging for the subset ids
+    uint32_t* d_mask = nullptr;
+    uint64_t mask_words = 0;
+    uint64_t* d_subset = nullptr;
+    uint64_t subset_cap = 0;
 
     bool profiling = false;
     lynse_hip_profile prof{};
@@ -235,7 +240,8 @@ extern "C" int lynse_hip_flat_destroy(lynse_hip_flat* h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     h->ws.release();
     for (auto e : h->ev_pool) (void)hipEventDestroy(e);
-    for (void* p : {(void*)h->rows, (void*)h->rows16, (void*)h->packed, (void*)h->vn2, (void*)h->vrinv, (void*)h->d_stats})
+    for (void* p : {(void*)h->rows, (void*)h->rows16, (void*)h->packed, (void*)h->vn2, (void*)h->vrinv, (void*)h->d_stats,
+                    (void*)h->d_mask, (void*)h->d_subset})
         if (p) (void)hipFree(p);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -642,6 +648,7 @@ static std::vector<Stage> make_plan(const lynse_hip_flat* h, uint32_t k, int lev
         }
     }
     uint64_t s0 = std::max<uint64_t>(h->stage0_rows, std::min<uint64_t>(h->cap, 4ull * k));
+    s0 = (s0 + 255) / 256 * 256;  // stage boundaries on 256-row tiles (mask words, tile grid of the sample stage)
     s0 = std::min<uint64_t>(std::min<uint64_t>(s0, h->cap), n);
     uint64_t g = std::max<uint64_t>(2, std::min<uint64_t>(h->growth, h->cap / (4ull * std::max<uint32_t>(k, 1))));
     uint64_t b = s0;
@@ -864,7 +871,8 @@ static int get_event(lynse_hip_flat* h, size_t idx, hipEvent_t* out) {
 // One chunk (<= QCHUNK queries) whose inputs are already in the workspace (Qf for float metrics,
 // QW for binary).  Results land in ws.out_*.  `level` selects the stage plan (make_plan).
 static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k, int metric, int level, hipStream_t st,
-                     size_t* ev_used, std::vector<std::pair<size_t, uint64_t>>* scan_events, bool* sampled_plan) {
+                     size_t* ev_used, std::vector<std::pair<size_t, uint64_t>>* scan_events, bool* sampled_plan,
+                     const uint32_t* mask = nullptr) {
     Workspace& w = h->ws;
     const bool binary = metric >= M_HAMMING;
     const bool asc = metric_ascending(metric);
@@ -875,6 +883,7 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
     const uint32_t qpad = small ? SCAN_BQ_SMALL : SCAN_BQ_LARGE;
     int ip_form = h->ip_form;
     if (ip_form == LYNSE_IPFORM_AUTO) ip_form = h->n < 4096 ? LYNSE_IPFORM_SINGLE : LYNSE_IPFORM_BATCH8;
+    if (mask) ip_form = LYNSE_IPFORM_SINGLE;  // search_filtered scores every row with the single-row kernels (flat_mmap.rs:553-560)
 
     static bool sel_attr = false;
     if (!sel_attr) {
@@ -920,8 +929,9 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
             BinArgs b{};
             b.P = h->packed; b.W = h->words; b.row0 = s.r0; b.row1 = s.r1; b.QW = w.QW; b.nq = nq;
             b.thr = w.thr; b.cand = w.cand; b.count = w.count; b.cap = w.cap; b.emit_all = emit_all ? 1 : 0;
+            b.mask = mask;
             static const int rows_minq = []() { const char* e = getenv("LYNSE_HIP_BIN_ROWS_MINQ"); return e ? atoi(e) : 1; }();
-            if ((int)nq >= rows_minq) {  // batched: lane-per-row, scalar query words
+            if ((int)nq >= rows_minq || mask) {  // batched: lane-per-row, scalar query words
                 uint32_t wcap = 1;
                 while (wcap < h->words) wcap <<= 1;
                 if (wcap != h->words) {
@@ -943,6 +953,7 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
         } else {
             ScanArgs a{};
             a.V = h->rows; a.ld = h->ld; a.D = h->dim; a.row0 = s.r0; a.row1 = s.r1; a.Q16 = w.Q16;
+            a.mask = mask;
             a.tile_stride = s.sample_stride;  // 0 = contiguous
             if (!s.sample_tiles && sample.sample_tiles) { a.skip_stride = sample.sample_stride; a.skip_tiles = sample.sample_tiles; }
             static const int big_rows = []() { const char* e = getenv("LYNSE_HIP_SCAN_BR"); return e ? atoi(e) : 256; }();
@@ -1017,6 +1028,7 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
         sa.cand = w.cand; sa.count = w.count; sa.overflow = w.overflow; sa.thr = w.thr; sa.marg2 = w.marg2;
         sa.k = k; sa.cap = w.cap; sa.keep_max = w.cap / 2; sa.metric = metric; sa.ip_form = ip_form;
         sa.exact = binary ? 1 : 0;
+        sa.drop_sentinels = (mask && emit_all) ? 1 : 0;
         sa.emit_all_n = emit_all ? (s.sample_tiles ? (int)(s.sample_tiles * plan_tile) : (int)(s.r1 - s.r0)) : -1;
         sa.Qf = w.Qf; sa.V = h->rows; sa.ld = h->ld; sa.D = h->dim;
         hipLaunchKernelGGL(k_select<SEL_NT>, dim3(nq), dim3(SEL_NT), (size_t)w.cap * 8, st, sa);
@@ -1038,7 +1050,8 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
 // (pre-packed).  Sources and destinations are host or device pointers according to `on_device`.
 static int search_impl(lynse_hip_flat* h, const void* q_src, bool packed_queries, uint64_t nq, uint32_t k,
                        int metric, uint64_t* out_rows, float* out_dists, uint32_t* out_counts,
-                       bool on_device, hipStream_t user_stream) {
+                       bool on_device, hipStream_t user_stream, const uint64_t* subset = nullptr, uint64_t n_subset = 0,
+                       bool filtered = false) {
     if (!h) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "handle is NULL");
     if (!metric_valid(metric)) return set_error(LYNSE_ERR_UNKNOWN_METRIC, "Unknown metric id");
     if (nq == 0) return LYNSE_OK;
@@ -1053,14 +1066,18 @@ static int search_impl(lynse_hip_flat* h, const void* q_src, bool packed_queries
     if (packed_queries && !binary) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "packed queries need a binary metric");
     if (!binary && h->packed_only) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "store holds packed rows; float metrics unavailable");
 
-    // empty store or k == 0 -> empty results, not an error (flat_mmap.rs:832-835)
-    if (h->n == 0 || k == 0) {
+    if (filtered && !binary && scan_variant() != 3)
+        return set_error(LYNSE_ERR_UNSUPPORTED, "filtered search needs the default scan kernel (LYNSE_HIP_SCAN_VARIANT=3)");
+    if (filtered && n_subset && !subset) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "subset is NULL");
+    // empty store, k == 0 or an empty subset -> empty results, not an error (flat_mmap.rs:832-835, :498-500)
+    if (h->n == 0 || k == 0 || (filtered && n_subset == 0)) {
         if (on_device) LY_HIP(hipMemsetAsync(out_counts, 0, nq * 4, st));
         else memset(out_counts, 0, nq * 4);
         if (on_device) LY_HIP(hipStreamSynchronize(st));
         return LYNSE_OK;
     }
-    const uint32_t kk = (uint32_t)std::min<uint64_t>(k, h->n);  // k.min(n), flat_mmap.rs:836
+    uint32_t kk = (uint32_t)std::min<uint64_t>(k, h->n);  // k.min(n), flat_mmap.rs:836
+    if (filtered) kk = (uint32_t)std::min<uint64_t>(kk, n_subset);  // k.min(subset.len()), flat_mmap.rs:501
     if (h->n > h->cap && kk > h->cap / 4)
         return set_error(LYNSE_ERR_UNSUPPORTED, "k > cap/4 with more rows than the candidate capacity is not supported yet");
     if (binary && h->words > 16u * BIN_MAX_CHUNKS)
@@ -1072,6 +1089,28 @@ static int search_impl(lynse_hip_flat* h, const void* q_src, bool packed_queries
     else LY_TRY(finalize_locked(h));
     LY_TRY(ensure_workspace(h, k));
     Workspace& w = h->ws;
+    hipStream_t st0 = user_stream ? user_stream : h->stream;
+    if (filtered) {  // subset ids -> row bitmask on the device (the reference's bitset, flat_mmap.rs:672-679)
+        const uint64_t words = (std::max<uint64_t>(h->n, h->capacity) + 511) / 32 + 8;
+        if (words > h->mask_words) {
+            if (h->d_mask) (void)hipFree(h->d_mask);
+            h->d_mask = nullptr;
+            LY_HIP(hipMalloc(&h->d_mask, words * 4));
+            h->mask_words = words;
+        }
+        if (n_subset > h->subset_cap) {
+            if (h->d_subset) (void)hipFree(h->d_subset);
+            h->d_subset = nullptr;
+            LY_HIP(hipMalloc(&h->d_subset, n_subset * 8));
+            h->subset_cap = n_subset;
+        }
+        LY_HIP(hipMemsetAsync(h->d_mask, 0, h->mask_words * 4, st0));
+        LY_HIP(hipMemcpyAsync(h->d_subset, subset, n_subset * 8, hipMemcpyHostToDevice, st0));
+        const uint32_t blocks = (uint32_t)std::min<uint64_t>((n_subset + 255) / 256, (uint64_t)h->num_cu * 8);
+        hipLaunchKernelGGL(k_mask_build, dim3(std::max<uint32_t>(blocks, 1)), dim3(256), 0, st0, h->d_subset, n_subset, h->n, h->d_mask);
+        LY_HIP(hipGetLastError());
+    }
+    const uint32_t* mask = filtered ? h->d_mask : nullptr;
 
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     size_t ev_used = 0;
@@ -1099,7 +1138,7 @@ static int search_impl(lynse_hip_flat* h, const void* q_src, bool packed_queries
         }
         for (int level = 0; level < 3; ++level) {  // sampled plan -> contiguous plan -> exhaustive plan (make_plan)
             bool sampled = false;
-            LY_TRY(run_chunk(h, nqc, kk, k, metric, level, st, &ev_used, &scan_events, &sampled));
+            LY_TRY(run_chunk(h, nqc, kk, k, metric, level, st, &ev_used, &scan_events, &sampled, mask));
             std::vector<uint32_t> ovf(nqc);
             LY_HIP(hipMemcpyAsync(ovf.data(), w.overflow, nqc * 4, hipMemcpyDeviceToHost, st));
             LY_HIP(hipStreamSynchronize(st));
@@ -1141,6 +1180,12 @@ static int search_impl(lynse_hip_flat* h, const void* q_src, bool packed_queries
 extern "C" int lynse_hip_flat_search_f32(lynse_hip_flat* h, const float* queries, uint64_t nq, uint32_t k, int metric,
                                          uint64_t* out_rows, float* out_dists, uint32_t* out_counts) {
     return search_impl(h, queries, false, nq, k, metric, out_rows, out_dists, out_counts, false, nullptr);
+}
+
+extern "C" int lynse_hip_flat_search_filtered_f32(lynse_hip_flat* h, const float* queries, uint64_t nq, uint32_t k, int metric,
+                                                  const uint64_t* subset_rows, uint64_t n_subset, uint64_t* out_rows,
+                                                  float* out_dists, uint32_t* out_counts) {
+    return search_impl(h, queries, false, nq, k, metric, out_rows, out_dists, out_counts, false, nullptr, subset_rows, n_subset, true);
 }
 
 extern "C" int lynse_hip_flat_search_f32_device(lynse_hip_flat* h, const float* d_queries, uint64_t nq, uint32_t k,

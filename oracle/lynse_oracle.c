@@ -877,6 +877,130 @@ size_t lo_canonical_topk_packed(const uint64_t *query, const uint64_t *rows, siz
     return r;
 }
 
+/* ------------------------------------------------------------- filtered search */
+
+/* FlatMmap::search_filtered (flat_mmap.rs:491-815), f32 rows / packed-binary rows.
+ * k = min(k, m) (:504); rows >= n are skipped; subsets of <= 50,000 ids take the direct random-access
+ * loop in SUBSET order (direct_access_topk :5223-5274), larger ones the bitset scan in ROW order,
+ * chunked like the unfiltered scan (fused_topk_parallel_filtered :5439-5556; n < 4096 sequential).
+ * Every distance uses the SINGLE-row kernels (simd::inner_product_f32 ...).  Packed metrics always
+ * take the subset-order loop with strict `<` admission (packed_binary_search_filtered :1411-1444). */
+size_t lo_flat_search_filtered(const float *query, const float *cands, size_t dim, size_t n, size_t k,
+                               int metric, const uint64_t *subset, size_t m, int n_threads,
+                               uint32_t *out_idx, float *out_dist) {
+    if (n == 0 || k == 0 || m == 0) return 0;
+    if (k > m) k = m;
+    int asc = lo_metric_is_ascending(metric);
+    entry_t *buf = (entry_t *)malloc(k * sizeof(entry_t));
+    topk_t t;
+    size_t len = 0;
+    if (m <= 50000) {
+        topk_init(&t, buf, k, asc);
+        for (size_t j = 0; j < m; ++j) {
+            size_t idx = (size_t)subset[j];
+            if (idx >= n) continue;
+            topk_offer(&t, lo_compute_distance(query, cands + idx * dim, dim, metric), (uint32_t)idx);
+        }
+        topk_finish(&t);
+        len = t.len;
+    } else {
+        uint64_t max_id = 0;
+        for (size_t j = 0; j < m; ++j) if (subset[j] > max_id) max_id = subset[j];
+        size_t words = (size_t)(max_id / 64) + 1;
+        uint64_t *bits = (uint64_t *)calloc(words, 8);
+        for (size_t j = 0; j < m; ++j)
+            if (subset[j] < n) bits[subset[j] / 64] |= 1ull << (subset[j] % 64);
+        if (n < 4096) {
+            topk_init(&t, buf, k, asc);
+            for (size_t i = 0; i < n; ++i) {
+                if (i > max_id || !((bits[i / 64] >> (i % 64)) & 1)) continue;
+                topk_offer(&t, lo_compute_distance(query, cands + i * dim, dim, metric), (uint32_t)i);
+            }
+            topk_finish(&t);
+            len = t.len;
+        } else {
+            size_t T = n_threads > 0 ? (size_t)n_threads : 1;
+            size_t chunk = n / T;
+            if (chunk < 512) chunk = 512;
+            size_t n_chunks = (n + chunk - 1) / chunk;
+            entry_t *pool = (entry_t *)malloc(n_chunks * k * sizeof(entry_t));
+            entry_t **outs = (entry_t **)malloc(n_chunks * sizeof(entry_t *));
+            size_t *lens = (size_t *)calloc(n_chunks, sizeof(size_t));
+            for (size_t c = 0; c < n_chunks; ++c) {
+                outs[c] = pool + c * k;
+                topk_t tc;
+                topk_init(&tc, outs[c], k, asc);
+                size_t end = (c + 1) * chunk < n ? (c + 1) * chunk : n;
+                for (size_t i = c * chunk; i < end; ++i) {
+                    if (i > max_id || !((bits[i / 64] >> (i % 64)) & 1)) continue;
+                    topk_offer(&tc, lo_compute_distance(query, cands + i * dim, dim, metric), (uint32_t)i);
+                }
+                topk_finish(&tc);
+                lens[c] = tc.len;
+            }
+            len = merge_topk_results(outs, lens, n_chunks, k, asc, buf);
+            free(lens); free(outs); free(pool);
+        }
+        free(bits);
+    }
+    for (size_t i = 0; i < len; ++i) { out_idx[i] = buf[i].idx; out_dist[i] = buf[i].dist; }
+    free(buf);
+    return len;
+}
+
+size_t lo_packed_search_filtered(const uint64_t *query, const uint64_t *rows, size_t words, size_t n,
+                                 size_t k, int metric, const uint64_t *subset, size_t m,
+                                 uint32_t *out_idx, float *out_dist) {
+    if (n == 0 || k == 0 || m == 0) return 0;
+    if (k > m) k = m;
+    packed_fn f = packed_distance_fn(metric);
+    entry_t *buf = (entry_t *)malloc(k * sizeof(entry_t));
+    topk_t t;
+    topk_init(&t, buf, k, 1);
+    for (size_t j = 0; j < m; ++j) {
+        size_t idx = (size_t)subset[j];
+        if (idx >= n) continue;
+        topk_offer(&t, f(query, rows + idx * words, words), (uint32_t)idx);
+    }
+    size_t len = t.len; /* no final sort of an under-full result (:1441-1443) */
+    for (size_t i = 0; i < len; ++i) { out_idx[i] = buf[i].idx; out_dist[i] = buf[i].dist; }
+    free(buf);
+    return len;
+}
+
+/* Canonical filtered answer: the subset as a SET of valid rows, exact single-row-kernel distances,
+ * (distance, row) order, k = min(k, m) like the reference. */
+static int cmp_u64(const void *a, const void *b) {
+    uint64_t x = *(const uint64_t *)a, y = *(const uint64_t *)b;
+    return x < y ? -1 : x > y;
+}
+size_t lo_canonical_topk_filtered(const float *query, const float *cands, const uint64_t *packed_query,
+                                  const uint64_t *packed_rows, size_t words, size_t dim, size_t n,
+                                  size_t k, int metric, const uint64_t *subset, size_t m,
+                                  uint32_t *out_idx, float *out_dist) {
+    if (n == 0 || k == 0 || m == 0) return 0;
+    if (k > m) k = m;
+    uint64_t *ids = (uint64_t *)malloc(m * 8);
+    memcpy(ids, subset, m * 8);
+    qsort(ids, m, 8, cmp_u64);
+    size_t u = 0;
+    for (size_t j = 0; j < m; ++j)
+        if (ids[j] < n && (u == 0 || ids[u - 1] != ids[j])) ids[u++] = ids[j];
+    cpair_t *p = (cpair_t *)malloc((u ? u : 1) * sizeof(cpair_t));
+    packed_fn f = packed_rows ? packed_distance_fn(metric) : NULL;
+    for (size_t j = 0; j < u; ++j) {
+        p[j].id = ids[j];
+        p[j].d = packed_rows ? f(packed_query, packed_rows + ids[j] * words, words)
+                             : lo_compute_distance(query, cands + ids[j] * dim, dim, metric);
+    }
+    g_cmp_asc = lo_metric_is_ascending(metric);
+    qsort(p, u, sizeof(cpair_t), cmp_canonical);
+    if (k > u) k = u;
+    for (size_t i = 0; i < k; ++i) { out_idx[i] = (uint32_t)p[i].id; out_dist[i] = p[i].d; }
+    free(p); free(ids);
+    return k;
+}
+
 /* vector_store.rs:953-970 */
 size_t lo_merge_results(const uint64_t *ids, const float *dists, size_t n, size_t k, int metric,
                         uint64_t *out_ids, float *out_dists) {

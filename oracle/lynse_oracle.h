@@ -108,6 +108,17 @@ void lo_all_distances(const float *query, const float *cands, size_t dim, size_t
 
 /* VectorStore::merge_results (vector_store.rs:953-970) / engine merge
  * (engine.rs:3402-3414): sort (dist by metric order, id asc), truncate. */
+/* FlatMmap::search_filtered (flat_mmap.rs:491-815) and its canonical (set, (distance,row) order) answer */
+size_t lo_flat_search_filtered(const float *query, const float *cands, size_t dim, size_t n, size_t k,
+                               int metric, const uint64_t *subset, size_t m, int n_threads,
+                               uint32_t *out_idx, float *out_dist);
+size_t lo_packed_search_filtered(const uint64_t *query, const uint64_t *rows, size_t words, size_t n,
+                                 size_t k, int metric, const uint64_t *subset, size_t m,
+                                 uint32_t *out_idx, float *out_dist);
+size_t lo_canonical_topk_filtered(const float *query, const float *cands, const uint64_t *packed_query,
+                                  const uint64_t *packed_rows, size_t words, size_t dim, size_t n,
+                                  size_t k, int metric, const uint64_t *subset, size_t m,
+                                  uint32_t *out_idx, float *out_dist);
 size_t lo_merge_results(const uint64_t *ids, const float *dists, size_t n, size_t k, int metric,
                         uint64_t *out_ids, float *out_dists);
 

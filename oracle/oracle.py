@@ -71,6 +71,9 @@ class Oracle:
             s(n, _sz, _u64p, _u64p, _sz, _sz, _sz, C.c_int, C.c_int, _u32p, _f32p)
         s("lo_canonical_topk", _sz, _f32p, _f32p, _sz, _sz, _sz, C.c_int, C.c_int, _u32p, _f32p)
         s("lo_canonical_topk_packed", _sz, _u64p, _u64p, _sz, _sz, _sz, C.c_int, _u32p, _f32p)
+        s("lo_flat_search_filtered", _sz, _f32p, _f32p, _sz, _sz, _sz, C.c_int, _u64p, _sz, C.c_int, _u32p, _f32p)
+        s("lo_packed_search_filtered", _sz, _u64p, _u64p, _sz, _sz, _sz, C.c_int, _u64p, _sz, _u32p, _f32p)
+        s("lo_canonical_topk_filtered", _sz, _f32p, _f32p, _u64p, _u64p, _sz, _sz, _sz, _sz, C.c_int, _u64p, _sz, _u32p, _f32p)
         s("lo_all_distances", None, _f32p, _f32p, _sz, _sz, C.c_int, C.c_int, _f32p)
         s("lo_merge_results", _sz, _u64p, _f32p, _sz, _sz, C.c_int, _u64p, _f32p)
         s("lo_kmeans_train", _sz, _f32p, _sz, _sz, _sz, _sz, C.c_int, _f32p, _u32p)
@@ -201,6 +204,34 @@ class Oracle:
         r, pr = self._u64(rows_words)
         n, w = r.shape
         return self._topk_call(self.lib.lo_canonical_topk_packed, k, pq, pr, w, n, k, metric)
+
+    def flat_search_filtered(self, query, cands, k, metric, subset, n_threads=8):
+        """FlatMmap::search_filtered on f32 rows, the reference's policy (subset order / chunk order)."""
+        q, pq = self._f(query)
+        c, pc = self._f(cands)
+        n, dim = c.shape
+        sub, ps = self._u64(np.asarray(subset, np.uint64).reshape(-1))
+        return self._topk_call(self.lib.lo_flat_search_filtered, k, pq, pc, dim, n, k, metric, ps, sub.size, n_threads)
+
+    def packed_search_filtered(self, query_words, rows_words, k, metric, subset):
+        q, pq = self._u64(query_words)
+        r, pr = self._u64(rows_words)
+        n, w = r.shape
+        sub, ps = self._u64(np.asarray(subset, np.uint64).reshape(-1))
+        return self._topk_call(self.lib.lo_packed_search_filtered, k, pq, pr, w, n, k, metric, ps, sub.size)
+
+    def canonical_topk_filtered(self, query, cands, k, metric, subset, packed_query=None, packed_rows=None):
+        """The subset as a set of valid rows, exact single-row-kernel distances, (distance, row) order."""
+        sub, ps = self._u64(np.asarray(subset, np.uint64).reshape(-1))
+        if packed_rows is not None:
+            pqw, ppq = self._u64(packed_query)
+            pr, ppr = self._u64(packed_rows)
+            n, w = pr.shape
+            return self._topk_call(self.lib.lo_canonical_topk_filtered, k, None, None, ppq, ppr, w, 0, n, k, metric, ps, sub.size)
+        q, pq = self._f(query)
+        c, pc = self._f(cands)
+        n, dim = c.shape
+        return self._topk_call(self.lib.lo_canonical_topk_filtered, k, pq, pc, None, None, 0, dim, n, k, metric, ps, sub.size)
 
     def all_distances(self, query, cands, metric, ip_form=IPFORM_AUTO):
         q, pq = self._f(query)

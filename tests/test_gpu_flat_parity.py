@@ -396,3 +396,76 @@ def test_sharded_flat_world1_and_row_map(L, oracle):
     for i in range(2):
         e_i, e_d = oracle.canonical_topk(q[i], np.ascontiguousarray(data[1::3]), k, L2)
         assert np.array_equal(r[i], e_i.astype(np.uint64) * 3 + 1) and np.array_equal(d[i], e_d)
+
+
+# ------------------------------------------------------------------ filtered search
+@pytest.mark.parametrize("metric", [O.IP, O.L2, O.COS])
+@pytest.mark.parametrize("n,dim,m,k,nq", [
+    (200, 4, 1, 1, 1), (5000, 32, 50, 10, 3), (5000, 32, 2500, 10, 5), (20000, 64, 10000, 25, 40),
+    (70000, 48, 60000, 10, 9), (70000, 48, 7, 10, 2), (150000, 24, 100000, 100, 4), (3000, 17, 3000, 8, 33),
+])
+def test_filtered_search_parity(L, oracle, metric, n, dim, m, k, nq):
+    rng = np.random.default_rng(n + dim + m)
+    data = rng.standard_normal((n, dim)).astype(f32)
+    queries = (data[rng.integers(0, n, nq)] + 0.1 * rng.standard_normal((nq, dim))).astype(f32)
+    subset = np.sort(rng.choice(n, m, replace=False)).astype(np.uint64)
+    idx = L.FlatIndex(None, dim, 0)
+    idx.write(data)
+    rows, dists, counts = idx.search_filtered_batch_arrays(queries, k, NAME[metric], subset)
+    for qi in range(nq):
+        e_ids, e_d = oracle.canonical_topk_filtered(queries[qi], data, k, metric, subset)
+        c = int(counts[qi])
+        assert c == len(e_ids) == min(k, m)
+        assert np.array_equal(dists[qi, :c].view(np.uint32), e_d.view(np.uint32)), (qi, dists[qi, :c], e_d)
+        assert np.array_equal(rows[qi, :c].astype(np.uint32), e_ids)
+        # continuous random data has no exact ties: the reference's own policy gives the same answer
+        r_ids, r_d = oracle.flat_search_filtered(queries[qi], data, k, metric, subset)
+        assert np.array_equal(r_ids, e_ids) and np.array_equal(r_d.view(np.uint32), e_d.view(np.uint32))
+
+
+def test_filtered_search_reference_kat_and_edges(L, oracle):
+    # vector_store.rs:1309-1329: 200 rows of dim 4 (0..399 written twice), L2, subset [100] -> row 100
+    data = np.concatenate([np.arange(400, dtype=f32)] * 2).reshape(200, 4)
+    idx = L.FlatIndex(None, 4, 0)
+    idx.write(data)
+    q = np.array([0, 1, 2, 3], f32)
+    ids, d = idx.search_filtered(q, 1, "l2", [100])
+    assert ids.tolist() == [100] and d.tolist() == [0.0]
+    # empty subset -> empty; ids >= n are skipped; duplicates count once; k is clamped to the subset length
+    ids, d = idx.search_filtered(q, 5, "l2", [])
+    assert ids.size == 0
+    ids, d = idx.search_filtered(q, 5, "l2", [7, 7, 1000, 3, 7])
+    e_ids, e_d = oracle.canonical_topk_filtered(q, data, 5, O.L2, [7, 7, 1000, 3, 7])
+    assert np.array_equal(ids, e_ids) and np.array_equal(d, e_d) and sorted(ids.tolist()) == [3, 7]
+    # massive ties inside the subset: canonical (distance, row) order
+    data2 = np.tile(np.array([[1, 0, 0, 0], [0, 1, 0, 0]], f32), (20000, 1))
+    idx2 = L.FlatIndex(None, 4, 0)
+    idx2.write(data2)
+    subset = np.arange(1, 40000, 2, dtype=np.uint64)  # all the [0,1,0,0] rows
+    ids, d = idx2.search_filtered(np.array([0, 1, 0, 0], f32), 10, "ip", subset)
+    assert ids.tolist() == list(range(1, 21, 2)) and np.all(d == 1.0)
+
+
+@pytest.mark.parametrize("metric", [O.HAMMING, O.JACCARD, O.DICE])
+@pytest.mark.parametrize("n,dim,m,k,nq", [(6000, 128, 3000, 10, 4), (50000, 256, 200, 5, 2), (40000, 100, 30000, 50, 35)])
+def test_filtered_binary_search_parity(L, oracle, metric, n, dim, m, k, nq):
+    rng = np.random.default_rng(n + dim + m + metric)
+    data = (rng.random((n, dim)) < 0.4).astype(f32)
+    queries = data[rng.integers(0, n, nq)].copy()
+    flip = rng.random(queries.shape) < 0.1
+    queries = np.where(flip, 1 - queries, queries).astype(f32)
+    subset = np.sort(rng.choice(n, m, replace=False)).astype(np.uint64)
+    idx = L.FlatIndex(None, dim, 0)
+    idx.write(data)
+    rows, dists, counts = idx.search_filtered_batch_arrays(queries, k, NAME[metric], subset)
+    words = oracle.pack_binary(data)
+    for qi in range(nq):
+        qw = oracle.pack_binary(queries[qi].reshape(1, -1))[0]
+        e_ids, e_d = oracle.canonical_topk_filtered(None, None, k, metric, subset, packed_query=qw, packed_rows=words)
+        c = int(counts[qi])
+        assert c == len(e_ids)
+        assert np.array_equal(dists[qi, :c].view(np.uint32), e_d.view(np.uint32))
+        assert np.array_equal(rows[qi, :c].astype(np.uint32), e_ids)
+        # the reference's strict subset-order admission keeps the earliest rows among ties == canonical for a sorted subset
+        r_ids, r_d = oracle.packed_search_filtered(qw, words, k, metric, subset)
+        assert np.array_equal(r_d, e_d) and np.array_equal(r_ids, e_ids)

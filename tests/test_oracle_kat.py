@@ -436,3 +436,24 @@ def test_binary_quantizer_kat(oracle):  # quantizer/mod.rs:738-773
     ab, thr = oracle.binary_fit(bits)
     assert ab and np.all(thr == 0.5)
     assert oracle.binary_quantize(bits[0], thr)[0].tolist() == [0.0, 1.0, 1.0, 0.0]
+
+
+def test_filtered_search_kat_and_policies(oracle):  # vector_store.rs:1309-1329, flat_mmap.rs:491-815
+    f32 = np.float32
+    data = np.concatenate([np.arange(400, dtype=f32)] * 2).reshape(200, 4)
+    q = np.array([0, 1, 2, 3], f32)
+    ids, d = oracle.flat_search_filtered(q, data, 1, O.L2, [100])
+    assert ids.tolist() == [100] and d.tolist() == [0.0]
+    # direct path (<= 50,000 ids, subset order) and bitset path (> 50,000, row order) agree with the canonical answer
+    rng = np.random.default_rng(3)
+    big = rng.standard_normal((60000, 8)).astype(f32)
+    qq = rng.standard_normal(8).astype(f32)
+    for m in (10, 4000, 55000):
+        sub = np.sort(rng.choice(60000, m, replace=False)).astype(np.uint64)
+        for metric in (O.IP, O.L2, O.COS):
+            a = oracle.flat_search_filtered(qq, big, 7, metric, sub)
+            b = oracle.canonical_topk_filtered(qq, big, 7, metric, sub)
+            assert np.array_equal(a[0], b[0]) and np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32))
+    # k is clamped to the subset length; rows >= n are skipped
+    ids, d = oracle.flat_search_filtered(q, data, 5, O.L2, [3, 1000])
+    assert ids.tolist() == [3]
