@@ -136,6 +136,12 @@ int lynse_hip_flat_search_f32(lynse_hip_flat *h, const float *queries, uint64_t 
 int lynse_hip_flat_search_filtered_f32(lynse_hip_flat *h, const float *queries, uint64_t nq, uint32_t k,
                                        int metric, const uint64_t *subset_rows, uint64_t n_subset,
                                        uint64_t *out_rows, float *out_dists, uint32_t *out_counts);
+/* Same with the subset as the reference's BitSet words (src/storage/bitset.rs:15-24: bit r of word r/64, LSB first;
+ * SearchParams.subset, engine.rs:5541-5566).  Bits at or beyond len are ignored. */
+int lynse_hip_flat_search_filtered_bitset_f32(lynse_hip_flat *h, const float *queries, uint64_t nq,
+                                              uint32_t k, int metric, const uint64_t *bitset_words,
+                                              uint64_t n_words, uint64_t *out_rows, float *out_dists,
+                                              uint32_t *out_counts);
 /* Same with every buffer already resident in this handle's device memory; enqueued on `stream`
  * (a hipStream_t, NULL = the handle's own non-blocking stream) and synchronised before returning.
  * Device inputs of every *_device entry must be COMPLETE when the call is made (synchronise the

@@ -64,6 +64,7 @@ SIGNATURES = {
     "lynse_hip_flat_read_packed": (C.c_int, [_vp, C.c_uint64, C.c_uint64, _vp]),
     "lynse_hip_flat_search_f32": (C.c_int, [_vp, _vp, C.c_uint64, C.c_uint32, C.c_int, _vp, _vp, _vp]),
     "lynse_hip_flat_search_filtered_f32": (C.c_int, [_vp, _vp, C.c_uint64, C.c_uint32, C.c_int, _vp, C.c_uint64, _vp, _vp, _vp]),
+    "lynse_hip_flat_search_filtered_bitset_f32": (C.c_int, [_vp, _vp, C.c_uint64, C.c_uint32, C.c_int, _vp, C.c_uint64, _vp, _vp, _vp]),
     "lynse_hip_flat_search_f32_device": (C.c_int, [_vp, _vp, C.c_uint64, C.c_uint32, C.c_int, _vp, _vp, _vp, _vp]),
     "lynse_hip_flat_search_packed_u64": (C.c_int, [_vp, _vp, C.c_uint64, C.c_uint32, C.c_int, _vp, _vp, _vp]),
     "lynse_hip_flat_search_packed_u64_device": (C.c_int, [_vp, _vp, C.c_uint64, C.c_uint32, C.c_int, _vp, _vp, _vp, _vp]),

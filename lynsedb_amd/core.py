@@ -190,6 +190,21 @@ class FlatIndex:
                                                      _ptr(rows), _ptr(dists), _ptr(counts)))
         return rows[:, :k], dists[:, :k], counts
 
+    def search_filtered_bitset_batch_arrays(self, queries, k: int, metric, bitset_words):
+        """Same with the subset given as the reference's BitSet words (u64, bit r of word r // 64)."""
+        m = metric if isinstance(metric, int) else metric_from_str(metric)
+        q = _f32(queries, 2, "queries")
+        if q.shape[1] != self._dim:
+            raise ValueError(f"query dimension mismatch: expected {self._dim}, got {q.shape[1]}")
+        words = np.ascontiguousarray(np.asarray(bitset_words).reshape(-1), dtype=np.uint64)
+        nq, k = q.shape[0], int(k)
+        rows = np.empty((nq, max(k, 1)), np.uint64)
+        dists = np.empty((nq, max(k, 1)), np.float32)
+        counts = np.zeros(nq, np.uint32)
+        check(lib.lynse_hip_flat_search_filtered_bitset_f32(self._h, _ptr(q), nq, k, m, _ptr(words) if words.size else None,
+                                                            words.size, _ptr(rows), _ptr(dists), _ptr(counts)))
+        return rows[:, :k], dists[:, :k], counts
+
     def search_filtered(self, query, k: int, metric, subset_rows):
         """-> (rows u32[], distances f32[]) among `subset_rows` only."""
         q = _f32(query, 1, "query")

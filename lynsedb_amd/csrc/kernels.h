@@ -323,6 +323,7 @@ struct ScanArgs {
     // boundaries are multiples of 32).  Rows outside the subset are never emitted; the emit-all stage writes
     // KEY_SENTINEL into their slots and k_select drops those.  nullptr = unfiltered.
     const uint32_t* mask;
+    const uint32_t* row_ids;  // gathered filtered search: tile row m is original row row_ids[m] (keys carry the original row)
     uint32_t row0, row1;  // stage rows [row0,row1)
     const _Float16* Q16;  // [nslab][qpad][72]
     uint32_t qpad, nq, nslab, ntiles;
@@ -1190,7 +1191,8 @@ __global__ void __launch_bounds__(WQ * WR * 64, (WQ * WR >= 8) ? (WQ * WR / 4) :
                             const float sc = score(i, j, r, m, rok);
                             const uint32_t slot = tile * BR + (m - rbase);  // dense over the (possibly strided) tiles
                             if (c_ok[j] && rok && slot < a.cap)
-                                a.cand[(size_t)n * a.cap + slot] = ((mw >> bit) & 1u) ? make_key(sc, m, ASC) : KEY_SENTINEL;
+                                a.cand[(size_t)n * a.cap + slot] =
+                                    ((mw >> bit) & 1u) ? make_key(sc, (!TILED && a.row_ids) ? a.row_ids[m] : m, ASC) : KEY_SENTINEL;
                         }
                     }
                 } else {
@@ -1214,7 +1216,8 @@ __global__ void __launch_bounds__(WQ * WR * 64, (WQ * WR >= 8) ? (WQ * WR / 4) :
                                 if ((msk >> r) & 1u) {
                                     const uint32_t m = rbase + wr * (TR * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
                                     const uint32_t slot = base + (uint32_t)__popc(msk & ((1u << r) - 1u));
-                                    if (slot < a.cap) a.cand[(size_t)n * a.cap + slot] = make_key(score(i, j, r, m, true), m, ASC);
+                                    if (slot < a.cap)
+                                        a.cand[(size_t)n * a.cap + slot] = make_key(score(i, j, r, m, true), (!TILED && a.row_ids) ? a.row_ids[m] : m, ASC);
                                 }
                             }
                         }
@@ -1351,6 +1354,68 @@ __global__ void __launch_bounds__(256) k_mask_build(const uint64_t* __restrict__
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (uint64_t)gridDim.x * blockDim.x) {
         const uint64_t r = subset[i];
         if (r < n) atomicOr(&mask[r >> 5], 1u << (r & 31));
+    }
+}
+
+// BitSet words -> ascending row ids on the device (BitSet::to_vec): block b owns 256 words; pass 1 counts the
+// set bits of each block, pass 2 (one block) turns the counts into offsets, pass 3 writes the ids.
+__global__ void __launch_bounds__(256) k_bits_count(const uint64_t* __restrict__ words, uint64_t n_words, uint64_t n,
+                                                    uint32_t* __restrict__ block_counts) {
+    __shared__ uint32_t red[4];
+    const uint64_t w = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    uint64_t bits = w < n_words ? words[w] : 0ull;
+    if (w * 64 + 64 > n) bits = w * 64 >= n ? 0ull : (bits & ((1ull << (n - w * 64)) - 1ull));
+    uint32_t c = (uint32_t)__popcll(bits);
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) block_counts[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ void __launch_bounds__(1024) k_bits_offsets(uint32_t* __restrict__ block_counts, uint32_t nblocks) {
+    // in-place exclusive scan by one block (nblocks <= a few thousand: 10M rows = 611 blocks)
+    __shared__ uint32_t part[1024];
+    const uint32_t per = (nblocks + 1023) / 1024;
+    const uint32_t b0 = threadIdx.x * per;
+    uint32_t sum = 0;
+    for (uint32_t i = 0; i < per && b0 + i < nblocks; ++i) sum += block_counts[b0 + i];
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    for (uint32_t o = 1; o < 1024; o <<= 1) {
+        const uint32_t v = threadIdx.x >= o ? part[threadIdx.x - o] : 0u;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    uint32_t run = part[threadIdx.x] - sum;
+    for (uint32_t i = 0; i < per && b0 + i < nblocks; ++i) {
+        const uint32_t c = block_counts[b0 + i];
+        block_counts[b0 + i] = run;
+        run += c;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_bits_expand(const uint64_t* __restrict__ words, uint64_t n_words, uint64_t n,
+                                                     const uint32_t* __restrict__ block_offsets, uint64_t* __restrict__ ids) {
+    __shared__ uint32_t wave_base[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint64_t w = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    uint64_t bits = w < n_words ? words[w] : 0ull;
+    if (w * 64 + 64 > n) bits = w * 64 >= n ? 0ull : (bits & ((1ull << (n - w * 64)) - 1ull));
+    const uint32_t c = (uint32_t)__popcll(bits);
+    uint32_t incl = c;
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t up = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += up;
+    }
+    if (lane == 63) wave_base[wave] = incl;
+    __syncthreads();
+    uint32_t base = block_offsets[blockIdx.x];
+    for (int i = 0; i < wave; ++i) base += wave_base[i];
+    uint32_t pos = base + incl - c;
+    while (bits) {
+        ids[pos++] = w * 64 + (uint64_t)__builtin_ctzll(bits);
+        bits &= bits - 1;
     }
 }
 
@@ -1555,6 +1620,37 @@ __device__ __forceinline__ void rescore_keys(uint64_t* keys, uint32_t n, int met
 }
 
 // ------------------------------------------------------------------------------------------------
+// Gather kernels of the "few matches" strategy of FlatMmap::search_filtered (direct_access_topk,
+// flat_mmap.rs:5223-5274 — O(matches), no full scan): the listed rows of the f16 shadow (and their
+// norms) are copied into a compact temporary store that the ordinary pipeline scans; the scan emits
+// ORIGINAL row ids (ScanArgs::row_ids), so select / exact rescoring / final order work on the f32
+// source rows unchanged.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_gather_rows16(const _Float16* __restrict__ src, uint32_t ld16,
+                                                       const uint64_t* __restrict__ ids, uint64_t m,
+                                                       _Float16* __restrict__ dst) {
+    const uint32_t cpr = ld16 / 8;
+    const uint64_t total = m * cpr;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t j = i / cpr;
+        const uint32_t c = (uint32_t)(i % cpr) * 8;
+        *reinterpret_cast<u32x4*>(dst + j * ld16 + c) = *reinterpret_cast<const u32x4*>(src + ids[j] * ld16 + c);
+    }
+}
+
+__global__ void __launch_bounds__(256) k_gather_norms(const float* __restrict__ vn2, const float* __restrict__ vrinv,
+                                                      const uint64_t* __restrict__ ids, uint64_t m,
+                                                      float* __restrict__ o_vn2, float* __restrict__ o_vrinv,
+                                                      uint32_t* __restrict__ o_ids32) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t r = ids[i];
+        o_vn2[i] = vn2[r];
+        o_vrinv[i] = vrinv[r];
+        o_ids32[i] = (uint32_t)r;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // k_select: one block per query after each scan stage.  Sorts the candidate keys, sets the new
 // per-query threshold and prunes.
 //   float metrics: thr = tau -/+ 2E (tau = k-th best coarse score so far).  Any row whose exact
@@ -1603,7 +1699,7 @@ __global__ void __launch_bounds__(NT) k_select(SelectArgs a) {
     }
     uint64_t* gkeys = a.cand + (size_t)q * a.cap;
     bool compacted = false;
-    if (a.drop_sentinels && a.emit_all_n >= 0) {  // load + drop the slots of rows outside the subset
+    if (a.drop_sentinels) {  // load + drop the slots of rows outside the subset
         if (tid == 0) s_keep = 0;
         __syncthreads();
         for (uint32_t i0 = 0; i0 < n; i0 += NT) {

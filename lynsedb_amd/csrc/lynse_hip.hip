@@ -186,6 +186,11 @@ struct lynse_hip_flat {
     uint64_t mask_words = 0;
     uint64_t* d_subset = nullptr;
     uint64_t subset_cap = 0;
+    // gathered ("few matches") filtered path: compact copy of the listed shadow rows, their norms and 32-bit ids
+    _Float16* g_rows16 = nullptr;
+    float *g_vn2 = nullptr, *g_vrinv = nullptr;
+    uint32_t* g_ids32 = nullptr;
+    uint64_t g_cap = 0;
 
     bool profiling = false;
     lynse_hip_profile prof{};
@@ -241,7 +246,7 @@ extern "C" int lynse_hip_flat_destroy(lynse_hip_flat* h) {
     h->ws.release();
     for (auto e : h->ev_pool) (void)hipEventDestroy(e);
     for (void* p : {(void*)h->rows, (void*)h->rows16, (void*)h->packed, (void*)h->vn2, (void*)h->vrinv, (void*)h->d_stats,
-                    (void*)h->d_mask, (void*)h->d_subset})
+                    (void*)h->d_mask, (void*)h->d_subset, (void*)h->g_rows16, (void*)h->g_vn2, (void*)h->g_vrinv, (void*)h->g_ids32})
         if (p) (void)hipFree(p);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -872,7 +877,7 @@ static int get_event(lynse_hip_flat* h, size_t idx, hipEvent_t* out) {
 // QW for binary).  Results land in ws.out_*.  `level` selects the stage plan (make_plan).
 static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k, int metric, int level, hipStream_t st,
                      size_t* ev_used, std::vector<std::pair<size_t, uint64_t>>* scan_events, bool* sampled_plan,
-                     const uint32_t* mask = nullptr) {
+                     const uint32_t* mask = nullptr, const uint32_t* row_ids = nullptr) {
     Workspace& w = h->ws;
     const bool binary = metric >= M_HAMMING;
     const bool asc = metric_ascending(metric);
@@ -883,7 +888,7 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
     const uint32_t qpad = small ? SCAN_BQ_SMALL : SCAN_BQ_LARGE;
     int ip_form = h->ip_form;
     if (ip_form == LYNSE_IPFORM_AUTO) ip_form = h->n < 4096 ? LYNSE_IPFORM_SINGLE : LYNSE_IPFORM_BATCH8;
-    if (mask) ip_form = LYNSE_IPFORM_SINGLE;  // search_filtered scores every row with the single-row kernels (flat_mmap.rs:553-560)
+    if (mask || row_ids) ip_form = LYNSE_IPFORM_SINGLE;  // search_filtered scores every row with the single-row kernels (flat_mmap.rs:553-560)
 
     static bool sel_attr = false;
     if (!sel_attr) {
@@ -954,6 +959,7 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
             ScanArgs a{};
             a.V = h->rows; a.ld = h->ld; a.D = h->dim; a.row0 = s.r0; a.row1 = s.r1; a.Q16 = w.Q16;
             a.mask = mask;
+            a.row_ids = row_ids;
             a.tile_stride = s.sample_stride;  // 0 = contiguous
             if (!s.sample_tiles && sample.sample_tiles) { a.skip_stride = sample.sample_stride; a.skip_tiles = sample.sample_tiles; }
             static const int big_rows = []() { const char* e = getenv("LYNSE_HIP_SCAN_BR"); return e ? atoi(e) : 256; }();
@@ -1051,7 +1057,9 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
 static int search_impl(lynse_hip_flat* h, const void* q_src, bool packed_queries, uint64_t nq, uint32_t k,
                        int metric, uint64_t* out_rows, float* out_dists, uint32_t* out_counts,
                        bool on_device, hipStream_t user_stream, const uint64_t* subset = nullptr, uint64_t n_subset = 0,
-                       bool filtered = false) {
+                       bool filtered = false, const uint64_t* bitset_words = nullptr, uint64_t n_words = 0) {
+    // filtered: the subset is either a list of row ids (`subset`, n_subset) or BitSet words (`bitset_words`; n_subset =
+    // number of set bits below len, counted by the caller)
     if (!h) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "handle is NULL");
     if (!metric_valid(metric)) return set_error(LYNSE_ERR_UNKNOWN_METRIC, "Unknown metric id");
     if (nq == 0) return LYNSE_OK;
@@ -1068,7 +1076,7 @@ static int search_impl(lynse_hip_flat* h, const void* q_src, bool packed_queries
 
     if (filtered && !binary && scan_variant() != 3)
         return set_error(LYNSE_ERR_UNSUPPORTED, "filtered search needs the default scan kernel (LYNSE_HIP_SCAN_VARIANT=3)");
-    if (filtered && n_subset && !subset) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "subset is NULL");
+    if (filtered && n_subset && !subset && !bitset_words) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "subset is NULL");
     // empty store, k == 0 or an empty subset -> empty results, not an error (flat_mmap.rs:832-835, :498-500)
     if (h->n == 0 || k == 0 || (filtered && n_subset == 0)) {
         if (on_device) LY_HIP(hipMemsetAsync(out_counts, 0, nq * 4, st));
@@ -1090,27 +1098,120 @@ static int search_impl(lynse_hip_flat* h, const void* q_src, bool packed_queries
     LY_TRY(ensure_workspace(h, k));
     Workspace& w = h->ws;
     hipStream_t st0 = user_stream ? user_stream : h->stream;
-    if (filtered) {  // subset ids -> row bitmask on the device (the reference's bitset, flat_mmap.rs:672-679)
-        const uint64_t words = (std::max<uint64_t>(h->n, h->capacity) + 511) / 32 + 8;
-        if (words > h->mask_words) {
-            if (h->d_mask) (void)hipFree(h->d_mask);
-            h->d_mask = nullptr;
-            LY_HIP(hipMalloc(&h->d_mask, words * 4));
-            h->mask_words = words;
-        }
-        if (n_subset > h->subset_cap) {
+    bool direct = false;
+    std::vector<uint64_t> sorted_subset;
+    if (filtered) {
+        // strategy (flat_mmap.rs:549-556 switches at a fixed 50,000 ids): gather the listed shadow rows and scan only
+        // those when that is cheaper than a masked scan of the whole shard — bytes over measured rates on MI355X
+        const double rate = nq <= SCAN_BQ_SMALL ? 6.0e12 : 3.4e12;
+        const double chunks = (double)((nq + QCHUNK - 1) / QCHUNK);
+        const double row_b = (double)h->dim * 2.0;
+        const double c_direct = (double)n_subset * row_b * 2.0 / 2.5e12 + (double)n_subset * row_b / rate * chunks + 120e-6;
+        const double c_scan = (double)h->n * row_b / rate * chunks + 80e-6;
+        const char* fe = getenv("LYNSE_HIP_FILTER_STRATEGY");  // tests: 1 = gathered rows, 2 = masked scan (read per call)
+        const int force = fe ? atoi(fe) : 0;
+        direct = !binary && (double)n_subset * row_b <= 8e9 && (force == 1 || (force == 0 && c_direct < c_scan));
+        if (n_subset > h->subset_cap && (direct || !bitset_words)) {
             if (h->d_subset) (void)hipFree(h->d_subset);
             h->d_subset = nullptr;
             LY_HIP(hipMalloc(&h->d_subset, n_subset * 8));
             h->subset_cap = n_subset;
         }
-        LY_HIP(hipMemsetAsync(h->d_mask, 0, h->mask_words * 4, st0));
-        LY_HIP(hipMemcpyAsync(h->d_subset, subset, n_subset * 8, hipMemcpyHostToDevice, st0));
-        const uint32_t blocks = (uint32_t)std::min<uint64_t>((n_subset + 255) / 256, (uint64_t)h->num_cu * 8);
-        hipLaunchKernelGGL(k_mask_build, dim3(std::max<uint32_t>(blocks, 1)), dim3(256), 0, st0, h->d_subset, n_subset, h->n, h->d_mask);
-        LY_HIP(hipGetLastError());
+        bool ids_on_device = false;
+        if (bitset_words && direct) {  // BitSet::to_vec on the device: upload the words (they double as scratch in d_mask), expand
+            const uint64_t nw = std::min<uint64_t>(n_words, (h->n + 63) / 64);
+            const uint64_t words32 = (std::max<uint64_t>(h->n, h->capacity) + 511) / 32 + 8;
+            const uint32_t nblocks = (uint32_t)((nw + 255) / 256);
+            if (words32 + nblocks + 16 > h->mask_words) {
+                if (h->d_mask) (void)hipFree(h->d_mask);
+                h->d_mask = nullptr;
+                LY_HIP(hipMalloc(&h->d_mask, (words32 + nblocks + 16) * 4));
+                h->mask_words = words32 + nblocks + 16;
+            }
+            if (n_subset > h->subset_cap) {
+                if (h->d_subset) (void)hipFree(h->d_subset);
+                h->d_subset = nullptr;
+                LY_HIP(hipMalloc(&h->d_subset, n_subset * 8));
+                h->subset_cap = n_subset;
+            }
+            uint32_t* d_counts = h->d_mask + words32;
+            LY_HIP(hipMemcpyAsync(h->d_mask, bitset_words, nw * 8, hipMemcpyHostToDevice, st0));
+            const uint64_t* d_words = reinterpret_cast<const uint64_t*>(h->d_mask);
+            hipLaunchKernelGGL(k_bits_count, dim3(nblocks), dim3(256), 0, st0, d_words, nw, h->n, d_counts);
+            hipLaunchKernelGGL(k_bits_offsets, dim3(1), dim3(1024), 0, st0, d_counts, nblocks);
+            hipLaunchKernelGGL(k_bits_expand, dim3(nblocks), dim3(256), 0, st0, d_words, nw, h->n, d_counts, h->d_subset);
+            LY_HIP(hipGetLastError());
+            ids_on_device = true;
+        }
+        const uint64_t* src = subset;
+        if (direct && n_subset && !ids_on_device) {  // the direct path needs a set: sort + unique unless already strictly ascending (a BitSet's to_vec is)
+            bool ascending = subset[n_subset - 1] < h->n;  // and every id valid
+            for (uint64_t i = 1; i < n_subset && ascending; ++i) ascending = subset[i - 1] < subset[i];
+            if (!ascending) {
+                sorted_subset.assign(subset, subset + n_subset);
+                std::sort(sorted_subset.begin(), sorted_subset.end());
+                sorted_subset.erase(std::unique(sorted_subset.begin(), sorted_subset.end()), sorted_subset.end());
+                while (!sorted_subset.empty() && sorted_subset.back() >= h->n) sorted_subset.pop_back();  // rows >= n are skipped (:5243)
+                src = sorted_subset.data();
+                n_subset = sorted_subset.size();
+            }
+        }
+        if (src && n_subset && !ids_on_device) LY_HIP(hipMemcpyAsync(h->d_subset, src, n_subset * 8, hipMemcpyHostToDevice, st0));
+        if (!direct) {  // subset ids -> row bitmask on the device (the reference's bitset, flat_mmap.rs:672-679)
+            const uint64_t words = (std::max<uint64_t>(h->n, h->capacity) + 511) / 32 + 8;
+            if (words > h->mask_words) {
+                if (h->d_mask) (void)hipFree(h->d_mask);
+                h->d_mask = nullptr;
+                LY_HIP(hipMalloc(&h->d_mask, words * 4));
+                h->mask_words = words;
+            }
+            LY_HIP(hipMemsetAsync(h->d_mask, 0, h->mask_words * 4, st0));
+            if (bitset_words) {  // the caller's BitSet words ARE the mask (u64 LE = two u32 words); bits >= len never match a row
+                const uint64_t bytes = std::min<uint64_t>(n_words * 8, (h->n + 63) / 64 * 8);
+                LY_HIP(hipMemcpyAsync(h->d_mask, bitset_words, bytes, hipMemcpyHostToDevice, st0));
+            } else {
+                const uint32_t blocks = (uint32_t)std::min<uint64_t>((n_subset + 255) / 256, (uint64_t)h->num_cu * 8);
+                hipLaunchKernelGGL(k_mask_build, dim3(std::max<uint32_t>(blocks, 1)), dim3(256), 0, st0, h->d_subset, n_subset, h->n, h->d_mask);
+                LY_HIP(hipGetLastError());
+            }
+        }
+        if (direct && n_subset) {  // compact copy of the listed shadow rows + norms + 32-bit ids
+            if (n_subset > h->g_cap) {
+                for (void* p : {(void*)h->g_rows16, (void*)h->g_vn2, (void*)h->g_vrinv, (void*)h->g_ids32})
+                    if (p) (void)hipFree(p);
+                h->g_rows16 = nullptr; h->g_vn2 = h->g_vrinv = nullptr; h->g_ids32 = nullptr; h->g_cap = 0;
+                LY_HIP(hipMalloc(&h->g_rows16, (size_t)n_subset * h->ld16 * 2 + 256));
+                LY_HIP(hipMalloc(&h->g_vn2, ((size_t)n_subset + 256) * 4));
+                LY_HIP(hipMalloc(&h->g_vrinv, ((size_t)n_subset + 256) * 4));
+                LY_HIP(hipMalloc(&h->g_ids32, ((size_t)n_subset + 256) * 4));
+                LY_HIP(hipMemsetAsync(h->g_vn2, 0, ((size_t)n_subset + 256) * 4, st0));
+                LY_HIP(hipMemsetAsync(h->g_vrinv, 0, ((size_t)n_subset + 256) * 4, st0));
+                h->g_cap = n_subset;
+            }
+            const uint64_t pieces = n_subset * (h->ld16 / 8);
+            hipLaunchKernelGGL(k_gather_rows16, dim3((uint32_t)std::min<uint64_t>((pieces + 255) / 256, (uint64_t)h->num_cu * 32)), dim3(256), 0,
+                               st0, h->rows16, h->ld16, h->d_subset, n_subset, h->g_rows16);
+            LY_HIP(hipGetLastError());
+            hipLaunchKernelGGL(k_gather_norms, dim3((uint32_t)std::min<uint64_t>((n_subset + 255) / 256, (uint64_t)h->num_cu * 8)), dim3(256), 0,
+                               st0, h->vn2, h->vrinv, h->d_subset, n_subset, h->g_vn2, h->g_vrinv, h->g_ids32);
+            LY_HIP(hipGetLastError());
+        }
+        LY_HIP(hipStreamSynchronize(st0));  // `subset` / sorted_subset are caller / stack memory
+        if (direct && n_subset == 0) {  // every listed row was out of range
+            if (on_device) LY_HIP(hipMemsetAsync(out_counts, 0, nq * 4, st0));
+            else memset(out_counts, 0, nq * 4);
+            if (on_device) LY_HIP(hipStreamSynchronize(st0));
+            return LYNSE_OK;
+        }
     }
-    const uint32_t* mask = filtered ? h->d_mask : nullptr;
+    const uint32_t* mask = (filtered && !direct) ? h->d_mask : nullptr;
+    // the gathered path scans the compact store through the ordinary pipeline: point the scan-side fields of the handle
+    // at it for the duration of this call (the mutex is held); rescoring keeps using the f32 source rows by original id
+    struct ViewGuard {
+        lynse_hip_flat* h; bool on; _Float16* r16; uint64_t n; float *vn2, *vrinv;
+        ~ViewGuard() { if (on) { h->rows16 = r16; h->n = n; h->vn2 = vn2; h->vrinv = vrinv; } }
+    } view{h, direct, h->rows16, h->n, h->vn2, h->vrinv};
+    if (direct) { h->rows16 = h->g_rows16; h->n = n_subset; h->vn2 = h->g_vn2; h->vrinv = h->g_vrinv; }
 
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     size_t ev_used = 0;
@@ -1138,7 +1239,7 @@ static int search_impl(lynse_hip_flat* h, const void* q_src, bool packed_queries
         }
         for (int level = 0; level < 3; ++level) {  // sampled plan -> contiguous plan -> exhaustive plan (make_plan)
             bool sampled = false;
-            LY_TRY(run_chunk(h, nqc, kk, k, metric, level, st, &ev_used, &scan_events, &sampled, mask));
+            LY_TRY(run_chunk(h, nqc, kk, k, metric, level, st, &ev_used, &scan_events, &sampled, mask, direct ? h->g_ids32 : nullptr));
             std::vector<uint32_t> ovf(nqc);
             LY_HIP(hipMemcpyAsync(ovf.data(), w.overflow, nqc * 4, hipMemcpyDeviceToHost, st));
             LY_HIP(hipStreamSynchronize(st));
@@ -1186,6 +1287,20 @@ extern "C" int lynse_hip_flat_search_filtered_f32(lynse_hip_flat* h, const float
                                                   const uint64_t* subset_rows, uint64_t n_subset, uint64_t* out_rows,
                                                   float* out_dists, uint32_t* out_counts) {
     return search_impl(h, queries, false, nq, k, metric, out_rows, out_dists, out_counts, false, nullptr, subset_rows, n_subset, true);
+}
+
+extern "C" int lynse_hip_flat_search_filtered_bitset_f32(lynse_hip_flat* h, const float* queries, uint64_t nq, uint32_t k, int metric,
+                                                         const uint64_t* bitset_words, uint64_t n_words, uint64_t* out_rows,
+                                                         float* out_dists, uint32_t* out_counts) {
+    if (!h) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "handle is NULL");
+    if (n_words && !bitset_words) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "bitset is NULL");
+    const uint64_t n = lynse_hip_flat_len(h);
+    uint64_t count = 0;  // BitSet::count() restricted to rows below len
+    const uint64_t full = std::min<uint64_t>(n_words, n / 64);
+    for (uint64_t w = 0; w < full; ++w) count += (uint64_t)__builtin_popcountll(bitset_words[w]);
+    if (full < n_words && (n % 64)) count += (uint64_t)__builtin_popcountll(bitset_words[full] & ((1ull << (n % 64)) - 1ull));
+    return search_impl(h, queries, false, nq, k, metric, out_rows, out_dists, out_counts, false, nullptr, nullptr, count, true,
+                       bitset_words, n_words);
 }
 
 extern "C" int lynse_hip_flat_search_f32_device(lynse_hip_flat* h, const float* d_queries, uint64_t nq, uint32_t k,

@@ -170,6 +170,38 @@ def small():
     return {"config": "FLAT-IP 4000000x768 small batches (k=10)", **out}
 
 
+def filtered():
+    """Filtered FLAT-IP (docs/comparisons/vector_database_benchmarks.md:64-66, :99-101 quote 0.178 ms at 100k and 2.16 ms at 1M
+    on the reference's CPU path): single query, k=10, subsets of 10 % and 50 % of the rows, through the host API
+    (subset ids travel host -> device on every call); plus 10M x 768 with 256 queries."""
+    out = {}
+    rng = np.random.default_rng(42)
+    for n, dim, nq in ((100_000, 128, 1), (1_000_000, 128, 1), (10_000_000, 768, 256)):
+        idx = L.FlatIndex(None, dim, 0)
+        idx.reserve(n)
+        g = torch.Generator(device=dev)
+        g.manual_seed(n)
+        for b in range(0, n, 500_000):
+            idx.write_device(torch.rand((min(500_000, n - b), dim), generator=g, device=dev))
+        idx.finalize()
+        qs = np.ascontiguousarray(rng.random((nq, dim), dtype=np.float32))
+        for frac in (0.001, 0.1, 0.5):
+            m = int(n * frac)
+            subset = np.sort(rng.choice(n, m, replace=False)).astype(np.uint64)
+            words = np.zeros((n + 63) // 64, np.uint64)
+            np.bitwise_or.at(words, (subset // 64).astype(np.int64), np.uint64(1) << (subset % np.uint64(64)))
+            res = {}
+            for api, fn in (("ids", lambda: idx.search_filtered_batch_arrays(qs, 10, "ip", subset)),
+                            ("bitset", lambda: idx.search_filtered_bitset_batch_arrays(qs, 10, "ip", words))):
+                med, best = timeit(fn, 3, 10)
+                rows, d, c = fn()
+                ok = bool(np.isin(rows[0, :int(c[0])], subset).all() and int(c[0]) == 10)
+                res[api] = {"median_ms": round(med * 1e3, 3), "qps": round(nq / med, 1), "subset_ok": ok}
+            out[f"{n}x{dim}_nq{nq}_sel{frac}"] = res
+        del idx
+    return {"config": "filtered FLAT-IP, k=10 (host API, subset ids uploaded per call)", **out}
+
+
 if __name__ == "__main__":
     todo = sys.argv[1:] or ["c1", "c3", "c5", "small", "c4"]
     for name in todo:

@@ -399,12 +399,17 @@ def test_sharded_flat_world1_and_row_map(L, oracle):
 
 
 # ------------------------------------------------------------------ filtered search
+@pytest.mark.parametrize("strategy", ["auto", "direct", "mask"])
 @pytest.mark.parametrize("metric", [O.IP, O.L2, O.COS])
 @pytest.mark.parametrize("n,dim,m,k,nq", [
     (200, 4, 1, 1, 1), (5000, 32, 50, 10, 3), (5000, 32, 2500, 10, 5), (20000, 64, 10000, 25, 40),
     (70000, 48, 60000, 10, 9), (70000, 48, 7, 10, 2), (150000, 24, 100000, 100, 4), (3000, 17, 3000, 8, 33),
+    (60000, 1100, 20000, 10, 2),
 ])
-def test_filtered_search_parity(L, oracle, metric, n, dim, m, k, nq):
+def test_filtered_search_parity(L, oracle, metric, n, dim, m, k, nq, strategy, monkeypatch):
+    # "direct" = exact scores of the listed rows (<= 50,000 ids), "mask" = bitmask applied in the scan epilogue
+    if strategy != "auto":
+        monkeypatch.setenv("LYNSE_HIP_FILTER_STRATEGY", "1" if strategy == "direct" else "2")
     rng = np.random.default_rng(n + dim + m)
     data = rng.standard_normal((n, dim)).astype(f32)
     queries = (data[rng.integers(0, n, nq)] + 0.1 * rng.standard_normal((nq, dim))).astype(f32)
@@ -469,3 +474,27 @@ def test_filtered_binary_search_parity(L, oracle, metric, n, dim, m, k, nq):
         # the reference's strict subset-order admission keeps the earliest rows among ties == canonical for a sorted subset
         r_ids, r_d = oracle.packed_search_filtered(qw, words, k, metric, subset)
         assert np.array_equal(r_d, e_d) and np.array_equal(r_ids, e_ids)
+
+
+@pytest.mark.parametrize("strategy", ["auto", "direct", "mask"])
+def test_filtered_search_bitset_words(L, oracle, strategy, monkeypatch):
+    # SearchParams.subset is a BitSet (u64 words, bit r of word r // 64): same answer as the id-list entry point;
+    # "direct" expands the words to row ids on the device, "mask" uses them as the scan mask
+    if strategy != "auto":
+        monkeypatch.setenv("LYNSE_HIP_FILTER_STRATEGY", "1" if strategy == "direct" else "2")
+    rng = np.random.default_rng(11)
+    n, dim = 30000, 40
+    data = rng.standard_normal((n, dim)).astype(f32)
+    queries = rng.standard_normal((6, dim)).astype(f32)
+    member = rng.random(n) < 0.3
+    words = np.zeros((n + 63) // 64 + 2, np.uint64)  # two spare words with bits beyond len set: must be ignored
+    ids = np.nonzero(member)[0].astype(np.uint64)
+    np.bitwise_or.at(words, (ids // 64).astype(np.int64), np.uint64(1) << (ids % np.uint64(64)))
+    words[-1] = np.uint64(0xFFFF)
+    idx = L.FlatIndex(None, dim, 0)
+    idx.write(data)
+    rows, dists, counts = idx.search_filtered_bitset_batch_arrays(queries, 12, "l2", words)
+    for qi in range(queries.shape[0]):
+        e_ids, e_d = oracle.canonical_topk_filtered(queries[qi], data, 12, O.L2, ids)
+        assert int(counts[qi]) == 12
+        assert np.array_equal(rows[qi].astype(np.uint32), e_ids) and np.array_equal(dists[qi].view(np.uint32), e_d.view(np.uint32))
