@@ -232,6 +232,12 @@ int lynse_hip_ivf_set_routing(lynse_hip_ivf *h, int ivfflat_routing);
 int lynse_hip_ivf_search_f32(lynse_hip_ivf *h, const float *queries, uint64_t nq, uint32_t k,
                              uint32_t nprobe, uint64_t *out_rows, float *out_dists,
                              uint32_t *out_counts);
+/* IVFIndex::search with SearchParams.subset (ivf.rs:251-265): the rows of the probed lists are intersected with
+ * `subset_rows` (original row ids, host memory); a query whose probed lists hold no subset row is answered from the
+ * whole corpus restricted to the subset, as the reference does.  One subset per batch. */
+int lynse_hip_ivf_search_filtered_f32(lynse_hip_ivf *h, const float *queries, uint64_t nq, uint32_t k,
+                                      uint32_t nprobe, const uint64_t *subset_rows, uint64_t n_subset,
+                                      uint64_t *out_rows, float *out_dists, uint32_t *out_counts);
 int lynse_hip_ivf_profile_enable(lynse_hip_ivf *h, int on);
 int lynse_hip_ivf_profile_get(lynse_hip_ivf *h, lynse_hip_profile *out, int reset);
 

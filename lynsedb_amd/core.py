@@ -364,6 +364,20 @@ class IvfFlatIndex:
         check(lib.lynse_hip_ivf_search_f32(self._h, _ptr(q), nq, k, int(nprobe), _ptr(rows), _ptr(dists), _ptr(counts)))
         return rows[:, :k], dists[:, :k], counts
 
+    def search_filtered_batch_arrays(self, queries, k: int, nprobe: int, subset_rows):
+        """`IVFIndex::search` with `SearchParams.subset` (ivf.rs:251-265), one subset for the batch."""
+        q = _f32(queries, 2, "queries")
+        if q.shape[1] != self._dim:
+            raise ValueError(f"query dimension mismatch: expected {self._dim}, got {q.shape[1]}")
+        sub = np.ascontiguousarray(np.asarray(subset_rows).reshape(-1), dtype=np.uint64)
+        nq, k = q.shape[0], int(k)
+        rows = np.empty((nq, max(k, 1)), np.uint64)
+        dists = np.empty((nq, max(k, 1)), np.float32)
+        counts = np.zeros(nq, np.uint32)
+        check(lib.lynse_hip_ivf_search_filtered_f32(self._h, _ptr(q), nq, k, int(nprobe), _ptr(sub) if sub.size else None, sub.size,
+                                                    _ptr(rows), _ptr(dists), _ptr(counts)))
+        return rows[:, :k], dists[:, :k], counts
+
     def search(self, query, k: int = 10, nprobe: int = 10, metric: str = "ip"):
         metric_from_str(metric)  # validates like the reference (ValueError on unknown names)
         q = _f32(query, 1, "query")

@@ -243,6 +243,7 @@ struct BinTileArgs {
     uint32_t ntiles;
     const uint32_t* pair_q;
     const uint32_t* orig;  // slab position -> original row: the keys carry ORIGINAL rows (no rescoring needs the position)
+    const uint32_t* mask;  // subset filter by slab position (nullptr = none)
     const float* thr;
     uint64_t* cand;
     uint32_t* count;
@@ -311,7 +312,7 @@ __global__ void __launch_bounds__(256) k_scan_binary_tiled(BinTileArgs a) {
                     if (KIND == 0) dist = (float)c0;
                     else if (KIND == 1) dist = c1 == 0 ? 0.0f : __fsub_rn(1.0f, __fdiv_rn((float)c0, (float)c1));
                     else dist = c1 == 0 ? 0.0f : __fsub_rn(1.0f, __fdiv_rn((float)(2u * c0), (float)c1));
-                    if (dist <= thr_l[q]) {
+                    if (dist <= thr_l[q] && (!a.mask || ((a.mask[row >> 5] >> (row & 31)) & 1u))) {
                         const uint32_t qid = qid_l[q];
                         const uint32_t slot = atomicAdd(&a.count[qid], 1u);
                         if (slot < a.cap) a.cand[(size_t)qid * a.cap + slot] = make_key(dist, a.orig[row], true);

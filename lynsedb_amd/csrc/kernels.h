@@ -1206,7 +1206,9 @@ __global__ void __launch_bounds__(WQ * WR * 64, (WQ * WR >= 8) ? (WQ * WR / 4) :
                             const uint32_t m = rbase + wr * (TR * 32) + i * 32 + bit;
                             const bool rok = m < row_end && ((mw >> bit) & 1u);
                             const float sc = score(i, j, r, m, rok);
-                            const bool pass = ASC ? (sc <= c_thr[j]) : (sc >= c_thr[j]);
+                            bool pass = ASC ? (sc <= c_thr[j]) : (sc >= c_thr[j]);
+                            if (TILED && a.mask && c_ok[j] && rok && pass)  // IVF subset filter: mask by slab position, looked up
+                                pass = (a.mask[m >> 5] >> (m & 31)) & 1u;     // only for rows that beat the threshold
                             if (c_ok[j] && rok && pass) msk |= 1u << r;
                         }
                         if (msk) {
@@ -1354,6 +1356,15 @@ __global__ void __launch_bounds__(256) k_mask_build(const uint64_t* __restrict__
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (uint64_t)gridDim.x * blockDim.x) {
         const uint64_t r = subset[i];
         if (r < n) atomicOr(&mask[r >> 5], 1u << (r & 31));
+    }
+}
+
+// IVF subset filter: the slab-position mask of a row mask (slab position p holds original row orig[p])
+__global__ void __launch_bounds__(256) k_mask_permute(const uint32_t* __restrict__ rowmask, const uint32_t* __restrict__ orig,
+                                                      uint64_t n, uint32_t* __restrict__ slabmask) {
+    for (uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t r = orig[p];
+        if ((rowmask[r >> 5] >> (r & 31)) & 1u) atomicOr(&slabmask[p >> 5], 1u << (p & 31));
     }
 }
 

@@ -1144,10 +1144,40 @@ static int cmp_rank_stable(const void *pa, const void *pb) { /* stable sort_by e
     return (a->i < b->i) ? -1 : (a->i > b->i) ? 1 : 0;
 }
 
+static size_t ivf_search_impl(const float *query, const float *data, const uint64_t *packed, size_t words,
+                     size_t dim, size_t n, const float *centroids, size_t nlist,
+                     const uint64_t *list_offsets, const uint32_t *list_rows, size_t nprobe,
+                     size_t k, int metric, const uint8_t *in_subset, uint64_t *out_ids, float *out_dist,
+                     uint32_t *out_probed);
+
 size_t lo_ivf_search(const float *query, const float *data, const uint64_t *packed, size_t words,
                      size_t dim, size_t n, const float *centroids, size_t nlist,
                      const uint64_t *list_offsets, const uint32_t *list_rows, size_t nprobe,
                      size_t k, int metric, uint64_t *out_ids, float *out_dist,
+                     uint32_t *out_probed) {
+    return ivf_search_impl(query, data, packed, words, dim, n, centroids, nlist, list_offsets, list_rows, nprobe, k,
+                           metric, NULL, out_ids, out_dist, out_probed);
+}
+
+/* IVFIndex::search with SearchParams.subset (ivf.rs:251-265): probed candidates are intersected with the
+ * subset; when nothing is left the whole corpus restricted to the subset is scored instead. */
+size_t lo_ivf_search_filtered(const float *query, const float *data, const uint64_t *packed, size_t words,
+                              size_t dim, size_t n, const float *centroids, size_t nlist,
+                              const uint64_t *list_offsets, const uint32_t *list_rows, size_t nprobe,
+                              size_t k, int metric, const uint64_t *subset, size_t m, uint64_t *out_ids,
+                              float *out_dist) {
+    uint8_t *in = (uint8_t *)calloc(n ? n : 1, 1);
+    for (size_t j = 0; j < m; ++j) if (subset[j] < n) in[subset[j]] = 1;
+    size_t r = ivf_search_impl(query, data, packed, words, dim, n, centroids, nlist, list_offsets, list_rows, nprobe, k,
+                               metric, in, out_ids, out_dist, NULL);
+    free(in);
+    return r;
+}
+
+static size_t ivf_search_impl(const float *query, const float *data, const uint64_t *packed, size_t words,
+                     size_t dim, size_t n, const float *centroids, size_t nlist,
+                     const uint64_t *list_offsets, const uint32_t *list_rows, size_t nprobe,
+                     size_t k, int metric, const uint8_t *in_subset, uint64_t *out_ids, float *out_dist,
                      uint32_t *out_probed) { /* ivf.rs:181-348 */
     if (n == 0) return 0;
     if (nprobe < 1) nprobe = 1; /* :192-196 (caller resolves the stored default) */
@@ -1170,19 +1200,20 @@ size_t lo_ivf_search(const float *query, const float *data, const uint64_t *pack
         if (out_probed) out_probed[p] = cd[p].i;
         total += (size_t)(list_offsets[cd[p].i + 1] - list_offsets[cd[p].i]);
     }
-    uint32_t *cand;
-    if (total == 0) { /* :258-265 fall back to the full corpus */
-        total = n;
-        cand = (uint32_t *)malloc(n * sizeof(uint32_t));
-        for (size_t i = 0; i < n; ++i) cand[i] = (uint32_t)i;
-    } else {
-        cand = (uint32_t *)malloc(total * sizeof(uint32_t));
+    uint32_t *cand = (uint32_t *)malloc((total > n ? total : n) * sizeof(uint32_t) + 4);
+    {
         size_t w = 0;
         for (size_t p = 0; p < np; ++p)
             for (uint64_t j = list_offsets[cd[p].i]; j < list_offsets[cd[p].i + 1]; ++j)
-                cand[w++] = list_rows[j];
+                if (!in_subset || in_subset[list_rows[j]]) cand[w++] = list_rows[j]; /* :251-256 retain */
+        total = w;
+    }
+    if (total == 0) { /* :258-265 fall back to the (filtered) full corpus */
+        for (size_t i = 0; i < n; ++i)
+            if (!in_subset || in_subset[i]) cand[total++] = (uint32_t)i;
     }
     free(cd);
+    if (total == 0) { free(cand); return 0; } /* :267-269 */
     size_t pool = k < total ? k : total; /* :271-275, no exact-rerank for None/Binary */
     cpair_t *sc = (cpair_t *)malloc(total * sizeof(cpair_t));
     uint64_t *pq = NULL;

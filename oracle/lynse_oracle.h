@@ -141,6 +141,11 @@ void lo_fastrng_stream(uint64_t seed, size_t count, double *out);
  * kmeans.rs:317-345).  `packed` may be NULL for float metrics.  Final order is
  * canonical (distance, row id), which equals the reference for distinct
  * distances (its sort_unstable leaves ties unpinned).  Returns count. */
+size_t lo_ivf_search_filtered(const float *query, const float *data, const uint64_t *packed, size_t words,
+                              size_t dim, size_t n, const float *centroids, size_t nlist,
+                              const uint64_t *list_offsets, const uint32_t *list_rows, size_t nprobe,
+                              size_t k, int metric, const uint64_t *subset, size_t m, uint64_t *out_ids,
+                              float *out_dist);
 size_t lo_ivf_search(const float *query, const float *data, const uint64_t *packed, size_t words,
                      size_t dim, size_t n, const float *centroids, size_t nlist,
                      const uint64_t *list_offsets, const uint32_t *list_rows, size_t nprobe,

@@ -81,6 +81,8 @@ class Oracle:
         s("lo_fastrng_stream", None, C.c_uint64, _sz, _f64p)
         s("lo_ivf_search", _sz, _f32p, _f32p, _u64p, _sz, _sz, _sz, _f32p, _sz, _u64p, _u32p, _sz,
           _sz, C.c_int, _u64p, _f32p, _u32p)
+        s("lo_ivf_search_filtered", _sz, _f32p, _f32p, _u64p, _sz, _sz, _sz, _f32p, _sz, _u64p, _u32p, _sz,
+          _sz, C.c_int, _u64p, _sz, _u64p, _f32p)
         s("lo_binary_fit", C.c_int, _f32p, _sz, _sz, _f32p)
         s("lo_binary_quantize", None, _f32p, _sz, _sz, _f32p, _f32p)
         s("lo_ivf_flat_layout", None, _u32p, _sz, _sz, _u64p, _u32p)
@@ -303,6 +305,27 @@ class Oracle:
                                      metric, ids.ctypes.data_as(_u64p), dist.ctypes.data_as(_f32p),
                                      probed.ctypes.data_as(_u32p))
         return ids[:cnt].copy(), dist[:cnt].copy(), probed[:min(nprobe, c.shape[0])].copy()
+
+    def ivf_search_filtered(self, query, data, centroids, list_offsets, list_rows, nprobe, k, metric, subset,
+                            packed=None):
+        """IVFIndex::search with SearchParams.subset (ivf.rs:251-265)."""
+        q, pq = self._f(query)
+        d, pd = self._f(data)
+        c, pc = self._f(centroids)
+        lo, plo = self._u64(list_offsets)
+        lr, plr = self._u32(list_rows)
+        sub, ps = self._u64(np.asarray(subset, np.uint64).reshape(-1))
+        n, dim = d.shape
+        if packed is not None:
+            pk, ppk = self._u64(packed)
+            words = pk.shape[1]
+        else:
+            ppk, words = None, 0
+        ids = np.zeros(max(k, 1), np.uint64)
+        dist = np.zeros(max(k, 1), np.float32)
+        cnt = self.lib.lo_ivf_search_filtered(pq, pd, ppk, words, dim, n, pc, c.shape[0], plo, plr, nprobe, k, metric,
+                                              ps, sub.size, ids.ctypes.data_as(_u64p), dist.ctypes.data_as(_f32p))
+        return ids[:cnt].copy(), dist[:cnt].copy()
 
     def binary_fit(self, data):
         """BinaryQuantizer::fit -> (already_binary, thresholds[dim])."""

@@ -240,3 +240,45 @@ def test_ivf_binary_many_ties_and_large_lists(L, oracle):
     queries = protos[:6].copy()
     queries[:, :3] = 1 - queries[:, :3]
     check_ivf_binary(L, oracle, data, queries, 8, 8, 25, O.HAMMING, build_on_device=False)
+
+
+# ---------------------------------------------------------------- SearchParams.subset (ivf.rs:251-265)
+@pytest.mark.parametrize("metric", [IP, L2, COS, O.HAMMING])
+@pytest.mark.parametrize("n,dim,nlist,nprobe,nq,k,frac", [
+    (3000, 24, 16, 3, 10, 10, 0.3), (6000, 64, 64, 8, 33, 10, 0.05), (5000, 32, 32, 2, 6, 20, 0.002), (2000, 16, 8, 8, 4, 5, 0.9),
+])
+def test_ivf_filtered_parity(L, oracle, metric, n, dim, nlist, nprobe, nq, k, frac):
+    rng = np.random.default_rng(n + dim + nlist + int(frac * 1000))
+    binary = metric == O.HAMMING
+    if binary:
+        data = (rng.random((n, dim)) < 0.35).astype(f32)
+        queries = data[rng.integers(0, n, nq)].copy()
+        thr = np.full(dim, 0.5, f32)
+        enc = data
+        packed = oracle.pack_binary(enc)
+        cen, asg = oracle.kmeans_train(enc, nlist, 20, O.L2)
+        off, rows = oracle.lists_from_assignments(asg, cen.shape[0])
+        idx = L.IvfFlatIndex.load(data, cen, asg, "hamming", thresholds=thr)
+    else:
+        centers = rng.standard_normal((max(nlist // 2, 2), dim)).astype(f32)
+        data = (centers[rng.integers(0, centers.shape[0], n)] + 0.3 * rng.standard_normal((n, dim))).astype(f32)
+        queries = (data[rng.integers(0, n, nq)] + 0.05 * rng.standard_normal((nq, dim))).astype(f32)
+        cen, asg, off, rows = oracle_ivf(oracle, data, nlist, metric)
+        idx = L.IvfFlatIndex.load(data, cen, asg, NAME[metric])
+        packed = None
+    m = max(1, int(n * frac))
+    subset = np.sort(rng.choice(n, m, replace=False)).astype(np.uint64)
+    g_rows, g_d, g_c = idx.search_filtered_batch_arrays(queries, k, nprobe, subset)
+    fell_back = 0
+    for qi in range(nq):
+        e_ids, e_d = oracle.ivf_search_filtered(queries[qi], data, cen, off, rows, nprobe, k, metric, subset, packed=packed)
+        c = int(g_c[qi])
+        assert c == len(e_ids), (qi, c, len(e_ids))
+        assert np.array_equal(g_d[qi, :c].view(np.uint32), e_d.view(np.uint32)), (qi, g_d[qi, :c], e_d)
+        assert np.array_equal(g_rows[qi, :c], e_ids), (qi, g_rows[qi, :c], e_ids)
+        assert np.isin(g_rows[qi, :c], subset).all()
+    # empty subset / all-invalid subset -> no results
+    _, _, c0 = idx.search_filtered_batch_arrays(queries[:2], k, nprobe, [])
+    assert c0.tolist() == [0, 0]
+    _, _, c1 = idx.search_filtered_batch_arrays(queries[:2], k, nprobe, [n + 5])
+    assert c1.tolist() == [0, 0]
