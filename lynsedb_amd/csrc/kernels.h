@@ -915,8 +915,10 @@ __global__ void __launch_bounds__(256) k_rows_to_f16(const float* __restrict__ V
 constexpr int HK = 64;  // K elements per slab
 
 // DBG (compile-time experiments, never launched by the product path): 1 no MFMA, 2 no LDS fragment reads,
-// 4 no query-image DMA, 8 no row DMA
-template <int WQ, int WR, int TQ, int TR, int METRIC, int NSV, int NSQ, int NT_HINT, bool TILED = false, bool RAG = true, int DBG = 0>
+// 4 no query-image DMA, 8 no row DMA.  FILT compiles the subset-filter paths in (mask / row_ids of ScanArgs): they
+// cost registers the unfiltered kernel does not have to spare (56 B/lane of scratch and 13 % of its speed when they
+// were runtime branches).
+template <int WQ, int WR, int TQ, int TR, int METRIC, int NSV, int NSQ, int NT_HINT, bool TILED = false, bool RAG = true, int DBG = 0, bool FILT = false>
 __global__ void __launch_bounds__(WQ * WR * 64, (WQ * WR >= 8) ? (WQ * WR / 4) : 2) k_scan_h16(ScanArgs a) {
     // Two LDS rings: NSV stages of row slabs (HBM latency: deeper) and NSQ <= NSV stages of query-image
     // slabs (L2 latency) — 3 + 2 stages of 32 KiB fill the 160 KiB of a CU for the 256 x 256 tile.
@@ -1182,7 +1184,7 @@ __global__ void __launch_bounds__(WQ * WR * 64, (WQ * WR >= 8) ? (WQ * WR / 4) :
                 if (a.emit_all && !TILED) {
 #pragma unroll
                     for (int i = 0; i < TR; ++i) {
-                        const uint32_t mw = a.mask ? a.mask[(rbase + wr * (TR * 32) + i * 32) >> 5] : 0xffffffffu;
+                        const uint32_t mw = (FILT && a.mask) ? a.mask[(rbase + wr * (TR * 32) + i * 32) >> 5] : 0xffffffffu;
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
                             const uint32_t bit = (r & 3) + 8 * (r >> 2) + 4 * hi;
@@ -1192,14 +1194,14 @@ __global__ void __launch_bounds__(WQ * WR * 64, (WQ * WR >= 8) ? (WQ * WR / 4) :
                             const uint32_t slot = tile * BR + (m - rbase);  // dense over the (possibly strided) tiles
                             if (c_ok[j] && rok && slot < a.cap)
                                 a.cand[(size_t)n * a.cap + slot] =
-                                    ((mw >> bit) & 1u) ? make_key(sc, (!TILED && a.row_ids) ? a.row_ids[m] : m, ASC) : KEY_SENTINEL;
+                                    ((mw >> bit) & 1u) ? make_key(sc, (FILT && !TILED && a.row_ids) ? a.row_ids[m] : m, ASC) : KEY_SENTINEL;
                         }
                     }
                 } else {
 #pragma unroll
                     for (int i = 0; i < TR; ++i) {
                         uint32_t msk = 0;
-                        const uint32_t mw = (!TILED && a.mask) ? a.mask[(rbase + wr * (TR * 32) + i * 32) >> 5] : 0xffffffffu;
+                        const uint32_t mw = (FILT && !TILED && a.mask) ? a.mask[(rbase + wr * (TR * 32) + i * 32) >> 5] : 0xffffffffu;
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
                             const uint32_t bit = (r & 3) + 8 * (r >> 2) + 4 * hi;
@@ -1207,7 +1209,7 @@ __global__ void __launch_bounds__(WQ * WR * 64, (WQ * WR >= 8) ? (WQ * WR / 4) :
                             const bool rok = m < row_end && ((mw >> bit) & 1u);
                             const float sc = score(i, j, r, m, rok);
                             bool pass = ASC ? (sc <= c_thr[j]) : (sc >= c_thr[j]);
-                            if (TILED && a.mask && c_ok[j] && rok && pass)  // IVF subset filter: mask by slab position, looked up
+                            if (FILT && TILED && a.mask && c_ok[j] && rok && pass)  // IVF subset filter: mask by slab position, looked up
                                 pass = (a.mask[m >> 5] >> (m & 31)) & 1u;     // only for rows that beat the threshold
                             if (c_ok[j] && rok && pass) msk |= 1u << r;
                         }
@@ -1219,7 +1221,7 @@ __global__ void __launch_bounds__(WQ * WR * 64, (WQ * WR >= 8) ? (WQ * WR / 4) :
                                     const uint32_t m = rbase + wr * (TR * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
                                     const uint32_t slot = base + (uint32_t)__popc(msk & ((1u << r) - 1u));
                                     if (slot < a.cap)
-                                        a.cand[(size_t)n * a.cap + slot] = make_key(score(i, j, r, m, true), (!TILED && a.row_ids) ? a.row_ids[m] : m, ASC);
+                                        a.cand[(size_t)n * a.cap + slot] = make_key(score(i, j, r, m, true), (FILT && !TILED && a.row_ids) ? a.row_ids[m] : m, ASC);
                                 }
                             }
                         }

@@ -631,7 +631,8 @@ static std::vector<Stage> make_plan(const lynse_hip_flat* h, uint32_t k, int lev
         return plan;
     }
     if (level == 0 && tile_rows && n > 4ull * h->cap) {
-        const uint32_t S = h->cap / 2;
+        static const uint32_t s_env = []() { const char* e = getenv("LYNSE_HIP_SAMPLE_ROWS"); return e ? (uint32_t)atoi(e) : 0u; }();
+        const uint32_t S = s_env ? std::min<uint32_t>(s_env, h->cap / 2) : h->cap / 2;
         const uint32_t nt = S / tile_rows;
         const uint64_t stride = (n - tile_rows) / (nt - 1) / tile_rows * tile_rows;
         if (stride > tile_rows) {
@@ -739,14 +740,15 @@ static int launch_scan_h16(const ScanArgs& a, int metric, uint32_t grid, hipStre
     constexpr int BQ = WQ * TQ * 32, BR = WR * TR * 32;
     constexpr size_t rings = (size_t)(NSV * BR + NSQ * BQ) * (HK * 2);
     const size_t lds = (rings + (NSV + 1) * 1024 <= 160 * 1024) ? rings + (NSV + 1) * 1024 : rings;
-    static bool attr_done[6] = {false};
+    static bool attr_done[9] = {false};
     auto go = [&](auto kern, int slot) -> int {
         if (!attr_done[slot]) { LY_TRY(set_max_lds(kern, lds)); attr_done[slot] = true; }
         hipLaunchKernelGGL(kern, dim3(grid), dim3(WQ * WR * 64), lds, st, a);
         LY_HIP(hipGetLastError());
         return LYNSE_OK;
     };
-    if (a.ld16 % HK == 0) {  // no ragged last slab: branch-free DMA issue
+    const bool filt = a.mask != nullptr || a.row_ids != nullptr;
+    if (a.ld16 % HK == 0 && !filt) {  // no ragged last slab: branch-free DMA issue
         if constexpr (WQ == 2 && WR == 4 && !TILED) {  // timing experiments (LYNSE_HIP_DEBUG_FLAGS bits 16.. = DBG << 4)
             if (metric == M_IP && (a.debug_flags >> 4) & 15) {
                 auto ex = [&](auto kern) -> int {
@@ -774,6 +776,13 @@ static int launch_scan_h16(const ScanArgs& a, int metric, uint32_t grid, hipStre
         case M_IP: return go(k_scan_h16<WQ, WR, TQ, TR, M_IP, NSV, NSQ, 2, TILED, false>, 3);
         case M_L2: return go(k_scan_h16<WQ, WR, TQ, TR, M_L2, NSV, NSQ, 2, TILED, false>, 4);
         default: return go(k_scan_h16<WQ, WR, TQ, TR, M_COS, NSV, NSQ, 2, TILED, false>, 5);
+        }
+    }
+    if (filt) {  // subset filter compiled in (always the ragged-capable variant: one instantiation per metric)
+        switch (metric) {
+        case M_IP: return go(k_scan_h16<WQ, WR, TQ, TR, M_IP, NSV, NSQ, 2, TILED, true, 0, true>, 6);
+        case M_L2: return go(k_scan_h16<WQ, WR, TQ, TR, M_L2, NSV, NSQ, 2, TILED, true, 0, true>, 7);
+        default: return go(k_scan_h16<WQ, WR, TQ, TR, M_COS, NSV, NSQ, 2, TILED, true, 0, true>, 8);
         }
     }
     switch (metric) {

@@ -144,3 +144,29 @@ def test_sift_vecs_reader_matches_golden(golden_dir, tmp_path):
     with pytest.raises(ValueError):
         (tmp_path / "e.fvecs").write_bytes(b"")
         read_fvecs(tmp_path / "e.fvecs")
+
+
+def test_hot_kernels_have_no_scratch_spills():
+    """The build records every kernel's register / scratch usage; the unfiltered scan kernels of the default path must
+    not spill (spills in k_scan_h16 cost 10-15 % of the headline throughput)."""
+    import re
+    from pathlib import Path
+
+    import lynsedb_amd  # noqa: F401  (build() has produced the library and the resource report)
+
+    rep = Path(lynsedb_amd.__file__).parent / "csrc" / "resource_usage.txt"
+    if not rep.exists():
+        pytest.skip("resource report not produced by this build")
+    text = rep.read_text()
+    blocks = re.findall(r"Function Name: (\S+).*?ScratchSize \[bytes/lane\]: (\d+)", text, flags=re.S)
+    assert blocks, "no resource remarks in the report"
+    seen = 0
+    for name, scratch in blocks:
+        # k_scan_h16<..., RAG=false, DBG=0, FILT=false>: the large (2,4,4,2 / 4,2,2,4) and small (1,4,1,1) default kernels
+        if "k_scan_h16" in name and name.endswith("Lb0ELi0ELb0EEEvNS_8ScanArgsE"):
+            seen += 1
+            assert int(scratch) == 0, (name, scratch)
+        if "k_scan_binary_rows" in name and "ILi0ELi16ELb0" in name:
+            seen += 1
+            assert int(scratch) == 0, (name, scratch)
+    assert seen >= 6
