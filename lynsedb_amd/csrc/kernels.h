@@ -919,7 +919,7 @@ constexpr int HK = 64;  // K elements per slab
 // cost registers the unfiltered kernel does not have to spare (56 B/lane of scratch and 13 % of its speed when they
 // were runtime branches).
 template <int WQ, int WR, int TQ, int TR, int METRIC, int NSV, int NSQ, int NT_HINT, bool TILED = false, bool RAG = true, int DBG = 0, bool FILT = false>
-__global__ void __launch_bounds__(WQ * WR * 64, (WQ * WR >= 8) ? (WQ * WR / 4) : 2) k_scan_h16(ScanArgs a) {
+__global__ void __launch_bounds__(WQ * WR * 64, (TQ * TR >= 16) ? 1 : ((WQ * WR >= 8) ? (WQ * WR / 4) : 2)) k_scan_h16(ScanArgs a) {
     // Two LDS rings: NSV stages of row slabs (HBM latency: deeper) and NSQ <= NSV stages of query-image
     // slabs (L2 latency) — 3 + 2 stages of 32 KiB fill the 160 KiB of a CU for the 256 x 256 tile.
     constexpr int NW = WQ * WR;

@@ -753,7 +753,7 @@ static int launch_scan_h16(const ScanArgs& a, int metric, uint32_t grid, hipStre
             if (metric == M_IP && (a.debug_flags >> 4) & 15) {
                 auto ex = [&](auto kern) -> int {
                     LY_TRY(set_max_lds(kern, lds));
-                    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, a);
+                    hipLaunchKernelGGL(kern, dim3(grid), dim3(WQ * WR * 64), lds, st, a);
                     return LYNSE_OK;
                 };
                 switch ((a.debug_flags >> 4) & 15) {
