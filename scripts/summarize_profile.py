@@ -40,16 +40,17 @@ if pmc.exists():
             "(MI355X_MICROARCH.md §HBM) — corrected = FETCH_SIZE x 1024 x 2."
             + (" k_scan_h16 reads the f16 shadow rows: kernel bytes = rows x 768 x 2, algorithmic (SURVEY 8d) = rows x 768 x 4." if h16 else ""), "",
             "| dispatch | stage rows | FETCH_SIZE KiB | corrected GB | kernel GB | algorithmic GB | hbm / kernel | hbm / algorithmic |", "|---|---|---|---|---|---|---|---|"]
-    plan = [4096, 32768 - 4096, 262144 - 32768, 2000000 - 262144]
+    # stage plan of bench.py --rows 2000000: f32 scan = contiguous stages; h16 = sampled plan (8192 sample rows, growth 16)
+    plan = [8192, 131072, 2000000 - 131072] if h16 else [4096, 32768 - 4096, 262144 - 32768, 2000000 - 262144]
     rows = [r for r in csv.DictReader(open(pmc)) if r["Counter_Name"] == "FETCH_SIZE"]
     last = None
     for i, r in enumerate(rows):
-        n = plan[i % 4]
+        n = plan[i % len(plan)]
         alg = n * 768 * 4 / 1e9
         ker = alg / 2 if h16 else alg
         corr = float(r["Counter_Value"]) * 1024 * 2 / 1e9
         out.append(f"| {r['Dispatch_Id']} | {n} | {float(r['Counter_Value']):.0f} | {corr:.4f} | {ker:.4f} | {alg:.4f} | {corr/ker:.3f} | {corr/alg:.3f} |")
-        if i % 4 == 3:
+        if i % len(plan) == len(plan) - 1:
             last = (n, alg, corr)
     out.append("")
     if last:
