@@ -498,3 +498,27 @@ def test_filtered_search_bitset_words(L, oracle, strategy, monkeypatch):
         e_ids, e_d = oracle.canonical_topk_filtered(queries[qi], data, 12, O.L2, ids)
         assert int(counts[qi]) == 12
         assert np.array_equal(rows[qi].astype(np.uint32), e_ids) and np.array_equal(dists[qi].view(np.uint32), e_d.view(np.uint32))
+
+
+@pytest.mark.parametrize("metric", [O.IP, O.L2])
+def test_insertion_ordered_shard_needs_no_fallback(L, oracle, metric):
+    # rows sorted so that every later row is a better match than all earlier ones: the contiguous stage plan would
+    # overflow at every stage; the sampled first stage gives a representative threshold and no query falls back
+    rng = np.random.default_rng(77)
+    n, dim, nq, k = 300_000, 16, 40, 10
+    data = rng.standard_normal((n, dim)).astype(f32)
+    q0 = rng.standard_normal(dim).astype(f32)
+    s = data @ q0 if metric == O.IP else -((data - q0) ** 2).sum(1)
+    data = np.ascontiguousarray(data[np.argsort(s, kind="stable")])
+    queries = (q0 + 0.01 * rng.standard_normal((nq, dim))).astype(f32)
+    idx = L.FlatIndex(None, dim, 0)
+    idx.write(data)
+    idx.profile_enable(True)
+    idx.profile_get(reset=True)
+    rows, dists, counts = idx.search_batch_arrays(queries, k, NAME[metric])
+    prof = idx.profile_get(reset=True)
+    assert prof["fallback_queries"] == 0
+    for qi in (0, 7, 39):
+        e_ids, e_d = oracle.canonical_topk(queries[qi], data, k, metric)
+        assert np.array_equal(rows[qi].astype(np.uint32), e_ids)
+        assert np.array_equal(dists[qi].view(np.uint32), e_d.view(np.uint32))
