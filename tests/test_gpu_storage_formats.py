@@ -1,0 +1,71 @@
+"""GPU: a collection directory / IvfFlat file pair in the reference's on-disk formats is opened into HBM and searched;
+results equal the oracle's on the same bytes."""
+import numpy as np
+import pytest
+
+import oracle as O
+from lynsedb_amd import storage as S
+
+pytestmark = pytest.mark.gpu
+f32 = np.float32
+
+
+@pytest.fixture(scope="module")
+def L():
+    import lynsedb_amd as L_
+
+    assert L_._lib.device_count() >= 1
+    return L_
+
+
+def test_open_segmented_collection_and_search(L, oracle, tmp_path):
+    # vector_store.rs:1309-1329: rows 0..399 written twice (segment target 1024 B) -> 200 rows in two segments
+    data = np.arange(400, dtype=f32).reshape(100, 4)
+    S.write_flat_collection(tmp_path, [data, data], ids=np.arange(1000, 1200, dtype=np.uint64), segment_target_bytes=1024)
+    idx, id_map, m = S.open_flat_collection(tmp_path, 4)
+    assert len(idx) == 200 and len(m.segments) == 2
+    q = np.array([0, 1, 2, 3], f32)
+    ids, d = idx.search(q, 1, "l2")
+    assert ids.tolist() == [0]  # canonical tie-break: rows 0 and 100 are identical, the lower row wins
+    ids, d = idx.search_filtered(q, 1, "l2", [100])
+    assert ids.tolist() == [100] and S.rows_to_user_ids(ids, id_map).tolist() == [1100]
+    # a larger random collection split over several segments
+    rng = np.random.default_rng(3)
+    big = rng.standard_normal((5000, 24)).astype(f32)
+    S.write_flat_collection(tmp_path / "big", [big[:1800], big[1800:1900], big[1900:]], segment_target_bytes=100_000)
+    idx2, id_map2, m2 = S.open_flat_collection(tmp_path / "big", 24)
+    assert len(m2.segments) >= 2 and len(idx2) == 5000 and id_map2.size == 0
+    qs = rng.standard_normal((5, 24)).astype(f32)
+    rows, dists, counts = idx2.search_batch_arrays(qs, 10, "ip")
+    for i in range(5):
+        e_ids, e_d = oracle.canonical_topk(qs[i], big, 10, O.IP)
+        assert np.array_equal(rows[i].astype(np.uint32), e_ids) and np.array_equal(dists[i].view(np.uint32), e_d.view(np.uint32))
+    assert S.rows_to_user_ids(rows[0], id_map2).tolist() == rows[0].tolist()
+
+
+@pytest.mark.parametrize("metric", ["ip", "l2"])
+def test_ivf_flat_files_roundtrip(L, oracle, tmp_path, metric):
+    # IvfFlatMmap::build writes <data> (slab order) + <data>.ivf_meta.bin; reopen (ivf_flat_mmap.rs:752-773) and search
+    rng = np.random.default_rng(9)
+    n, dim, nlist = 3000, 16, 24
+    centers = rng.standard_normal((12, dim)).astype(f32)
+    data = (centers[rng.integers(0, 12, n)] + 0.2 * rng.standard_normal((n, dim))).astype(f32)
+    built = L.IvfFlatIndex.build(None, data, dim, nlist, 10, metric, l2_partitions=True)
+    meta = S.save_ivf_flat(tmp_path / "vecs.bin", built, data)
+    assert (tmp_path / "vecs.ivf_meta.bin").exists()
+    assert meta.partition_offsets[-1] == n and sorted(meta.original_ids.tolist()) == list(range(n))
+    slab = np.fromfile(tmp_path / "vecs.bin", "<f4").reshape(n, dim)
+    assert np.array_equal(slab, data[meta.original_ids.astype(np.int64)])  # rows physically grouped by partition
+    reopened = S.open_ivf_flat(tmp_path / "vecs.bin", metric)
+    cen2, asg2, off2, orig2 = reopened.export()
+    assert np.array_equal(off2, meta.partition_offsets) and np.array_equal(orig2, meta.original_ids)
+    qs = (data[rng.integers(0, n, 6)] + 0.05 * rng.standard_normal((6, dim))).astype(f32)
+    a = built.search_batch_arrays(qs, 10, 4)
+    b = reopened.search_batch_arrays(qs, 10, 4)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32))
+    mid = O.IP if metric == "ip" else O.L2
+    rd = oracle.ivf_routing_dims(meta.centroids)
+    for i in range(6):
+        e_ids, e_d = oracle.ivf_flat_search(qs[i], slab, meta.centroids, meta.partition_offsets, meta.original_ids, 4, 10, mid, routing_dims=rd)
+        c = int(b[2][i])
+        assert np.array_equal(b[0][i, :c].astype(np.uint64), np.asarray(e_ids, np.uint64)) and np.array_equal(b[1][i, :c].view(np.uint32), e_d.view(np.uint32))

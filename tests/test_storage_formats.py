@@ -1,0 +1,88 @@
+"""On-disk formats of the reference: manifest / segments / id_map / ivf_meta — host logic, CPU only.
+Known-answer cases transcribed from the reference's own tests (src/storage/vector_store.rs:1269-1399)."""
+import json
+
+import numpy as np
+import pytest
+
+from lynsedb_amd import storage as S
+
+f32 = np.float32
+
+
+def test_manifest_rejects_escaping_and_missing_segment_paths(tmp_path):  # vector_store.rs:1269-1307
+    col = tmp_path / "collection"
+    col.mkdir()
+    (tmp_path / "outside.bin").write_bytes(bytes(16))
+    m = {"version": 1, "generation": 1, "id_map_file": "id_map.bin", "segments": [{"file": "../outside.bin", "rows": 1}]}
+    (col / S.VECTOR_MANIFEST_FILE).write_text(json.dumps(m))
+    with pytest.raises(S.StorageError, match="safe relative path"):
+        S.load_manifest(col, 4)
+    m["segments"][0]["file"] = "vector_segments/missing.bin"
+    (col / S.VECTOR_MANIFEST_FILE).write_text(json.dumps(m))
+    with pytest.raises(S.StorageError, match="is unavailable"):
+        S.load_manifest(col, 4)
+    for bad in ("/abs.bin", "", "a/./b.bin", "a//b.bin"):
+        with pytest.raises(S.StorageError):
+            S.validate_manifest_path(bad, "segment path")
+    m["version"] = 2
+    (col / S.VECTOR_MANIFEST_FILE).write_text(json.dumps(m))
+    with pytest.raises(S.StorageError, match="newer than supported"):
+        S.load_manifest(col, 4)
+
+
+def test_legacy_partial_row_is_trimmed(tmp_path):  # vector_store.rs:1386-1398
+    (tmp_path / "vectors.bin").write_bytes(np.ones(8, "<f4").tobytes() + bytes([1, 2, 3]))
+    m = S.load_manifest(tmp_path, 4)
+    assert [(s.file, s.rows) for s in m.segments] == [("vectors.bin", 2)]
+    segs = list(S.read_segments(tmp_path, 4))
+    assert len(segs) == 1 and segs[0][0] == 0 and segs[0][1].shape == (2, 4)
+    assert S.load_manifest(tmp_path / "nothing_here", 4).segments == []
+
+
+def test_segmented_write_layout_matches_reference_naming(tmp_path):  # vector_store.rs:1309-1318 (target 1024 B in tests)
+    data = np.arange(400, dtype=f32).reshape(100, 4)
+    m = S.write_flat_collection(tmp_path, [data, data], segment_target_bytes=1024)
+    # 100 rows x 16 B = 1600 B > 1024: every write opens a segment; the first one is vectors.bin, the manifest appears with the second
+    assert [s.file for s in m.segments] == ["vectors.bin", "vector_segments/seg-00000000000000000002-000001.bin"]
+    assert [s.rows for s in m.segments] == [100, 100] and m.generation == 2
+    on_disk = json.loads((tmp_path / S.VECTOR_MANIFEST_FILE).read_text())
+    assert on_disk["version"] == 1 and on_disk["id_map_file"] == "id_map.bin" and len(on_disk["segments"]) == 2
+    back = S.load_manifest(tmp_path, 4)
+    assert [(s.file, s.rows) for s in back.segments] == [(s.file, s.rows) for s in m.segments]
+    rows = np.concatenate([a for _, a in S.read_segments(tmp_path, 4)])
+    assert rows.shape == (200, 4) and np.array_equal(rows[100:], data)
+    # small batches append to the current segment until the target size is reached
+    m2 = S.write_flat_collection(tmp_path / "b", [data[:10], data[10:30], data[30:]], segment_target_bytes=1024)
+    assert [(s.file, s.rows) for s in m2.segments] == [("vectors.bin", 30), ("vector_segments/seg-00000000000000000002-000001.bin", 70)]
+
+
+def test_id_map_roundtrip_and_fallback(tmp_path):  # engine.rs:2588-2617, :3071-3074
+    ids = np.array([10, 11, 500, 7], np.uint64)
+    S.write_flat_collection(tmp_path, [np.zeros((4, 2), f32)], ids=ids)
+    raw = (tmp_path / "id_map.bin").read_bytes()
+    assert raw == ids.astype("<u8").tobytes()
+    (tmp_path / "id_map.bin").write_bytes(raw + b"\x01\x02")  # partial trailing bytes are ignored
+    got = S.load_id_map(tmp_path / "id_map.bin")
+    assert np.array_equal(got, ids)
+    assert S.rows_to_user_ids(np.array([2, 0, 9]), got).tolist() == [500, 10, 9]  # rows past the map are their own id
+    assert S.load_id_map(tmp_path / "missing.bin").size == 0
+
+
+def test_ivf_meta_roundtrip(tmp_path):  # ivf_flat_mmap.rs:448-530
+    rng = np.random.default_rng(1)
+    meta = S.IvfMeta(3, 5, 2, rng.standard_normal((2, 3)).astype(f32), np.array([0, 2, 5], np.uint64), np.array([4, 1, 0, 2, 3], np.uint32))
+    p = S.ivf_meta_path(tmp_path / "vecs.bin")
+    assert p.name == "vecs.ivf_meta.bin"
+    S.save_ivf_meta(p, meta)
+    raw = p.read_bytes()
+    assert len(raw) == 24 + 2 * 3 * 4 + 3 * 8 + 5 * 4
+    assert np.frombuffer(raw[:24], "<u8").tolist() == [3, 5, 2]
+    back = S.load_ivf_meta(p)
+    assert (back.dim, back.n_vectors, back.n_partitions) == (3, 5, 2)
+    assert np.array_equal(back.centroids, meta.centroids) and np.array_equal(back.partition_offsets, meta.partition_offsets)
+    assert np.array_equal(back.original_ids, meta.original_ids)
+    assert S.ivf_assignments_from_meta(back).tolist() == [1, 0, 1, 1, 0]
+    p.write_bytes(raw[:-3])
+    with pytest.raises(IOError):
+        S.load_ivf_meta(p)
