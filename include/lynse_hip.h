@@ -241,6 +241,30 @@ int lynse_hip_ivf_search_filtered_f32(lynse_hip_ivf *h, const float *queries, ui
 int lynse_hip_ivf_profile_enable(lynse_hip_ivf *h, int on);
 int lynse_hip_ivf_profile_get(lynse_hip_ivf *h, lynse_hip_profile *out, int reset);
 
+/* ---- shard-node glue around a search (host only, no device work) ---- */
+
+/* Collection::filter_tombstoned_limit (src/engine.rs:3286-3308): drop the tombstoned ids, keep the order, at most
+ * `limit` pairs.  Outputs hold min(n, limit) entries. */
+int lynse_hip_filter_tombstoned_limit(const uint64_t *ids, const float *dists, uint64_t n,
+                                      const uint64_t *tombstones, uint64_t n_tombstones, uint64_t limit,
+                                      uint64_t *out_ids, float *out_dists, uint64_t *out_n);
+/* Collection::merge_row_results (src/engine.rs:3363-3418): flushed + pending rows.  Duplicate ids keep the better
+ * distance; order (distance in metric order, id); truncated to `limit` — except that an empty side returns the other
+ * side untouched, as the reference does.  Outputs hold n_left + n_right entries. */
+int lynse_hip_merge_row_results(const uint64_t *left_ids, const float *left_dists, uint64_t n_left,
+                                const uint64_t *right_ids, const float *right_dists, uint64_t n_right,
+                                uint64_t limit, int metric, uint64_t *out_ids, float *out_dists,
+                                uint64_t *out_n);
+/* encode_search_result_binary (src/rpc.rs:1156-1177): [u32 n][n x u64 id][n x f32 distance][u32 fields_len][fields
+ * JSON], little endian — the block a shard returns to the coordinator.  *out_len = bytes needed / written. */
+int lynse_hip_encode_search_result(const uint64_t *ids, const float *dists, uint32_t n,
+                                   const uint8_t *fields_json, uint32_t fields_len, uint8_t *buf,
+                                   uint64_t cap, uint64_t *out_len);
+/* decode_search_result_binary (src/cluster.rs:404-435) at `offset` of a frame that may hold several blocks. */
+int lynse_hip_decode_search_result(const uint8_t *buf, uint64_t len, uint64_t offset, uint64_t *out_ids,
+                                   float *out_dists, uint32_t cap_n, uint32_t *out_n,
+                                   uint64_t *fields_offset, uint32_t *fields_len, uint64_t *next_offset);
+
 #ifdef __cplusplus
 }
 #endif

@@ -90,6 +90,11 @@ SIGNATURES = {
     "lynse_hip_ivf_search_f32": (C.c_int, [_vp, _vp, C.c_uint64, C.c_uint32, C.c_uint32, _vp, _vp, _vp]),
     "lynse_hip_ivf_search_filtered_f32": (C.c_int, [_vp, _vp, C.c_uint64, C.c_uint32, C.c_uint32, _vp, C.c_uint64, _vp, _vp, _vp]),
     "lynse_hip_ivf_profile_enable": (C.c_int, [_vp, C.c_int]),
+    "lynse_hip_filter_tombstoned_limit": (C.c_int, [_vp, _vp, C.c_uint64, _vp, C.c_uint64, C.c_uint64, _vp, _vp, C.POINTER(C.c_uint64)]),
+    "lynse_hip_merge_row_results": (C.c_int, [_vp, _vp, C.c_uint64, _vp, _vp, C.c_uint64, C.c_uint64, C.c_int, _vp, _vp, C.POINTER(C.c_uint64)]),
+    "lynse_hip_encode_search_result": (C.c_int, [_vp, _vp, C.c_uint32, _vp, C.c_uint32, _vp, C.c_uint64, C.POINTER(C.c_uint64)]),
+    "lynse_hip_decode_search_result": (C.c_int, [_vp, C.c_uint64, C.c_uint64, _vp, _vp, C.c_uint32, C.POINTER(C.c_uint32),
+                                                C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]),
     "lynse_hip_ivf_profile_get": (C.c_int, [_vp, C.POINTER(Profile), C.c_int]),
 }
 

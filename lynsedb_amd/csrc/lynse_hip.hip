@@ -1435,3 +1435,4 @@ extern "C" int lynse_hip_merge_topk_device(const void* d_blocks, uint64_t block_
 }
 
 #include "ivf_host.inc"
+#include "shard_host.inc"

@@ -69,3 +69,28 @@ def test_ivf_flat_files_roundtrip(L, oracle, tmp_path, metric):
         e_ids, e_d = oracle.ivf_flat_search(qs[i], slab, meta.centroids, meta.partition_offsets, meta.original_ids, 4, 10, mid, routing_dims=rd)
         c = int(b[2][i])
         assert np.array_equal(b[0][i, :c].astype(np.uint64), np.asarray(e_ids, np.uint64)) and np.array_equal(b[1][i, :c].view(np.uint32), e_d.view(np.uint32))
+
+
+def test_flushed_plus_pending_rows_and_tombstones(L, oracle):
+    # Collection::search tail (src/engine.rs:4797-4822): flushed rows from the store, pending rows scored with
+    # top_k_search, merge_row_results, then filter_tombstoned_limit — equals a brute-force answer over the live rows
+    from lynsedb_amd import shard_node as N
+
+    rng = np.random.default_rng(21)
+    dim, n_flushed, n_pending, k = 20, 4000, 300, 10
+    allrows = rng.standard_normal((n_flushed + n_pending, dim)).astype(f32)
+    idx = L.FlatIndex(None, dim, 0)
+    idx.write(allrows[:n_flushed])
+    pending_rows = np.arange(n_flushed, n_flushed + n_pending, dtype=np.uint64)
+    tomb = rng.choice(n_flushed + n_pending, 400, replace=False).astype(np.uint64)
+    for qi in range(4):
+        q = rng.standard_normal(dim).astype(f32)
+        search_k = k + tomb.size  # the engine over-fetches by the tombstone count
+        f_ids, f_d = idx.search(q, search_k, "l2")
+        p_idx, p_d = L.py_top_k_search(q, allrows[n_flushed:], "l2", search_k)
+        m_ids, m_d = N.merge_row_results(f_ids, f_d, pending_rows[p_idx.astype(np.int64)], p_d, search_k, "l2")
+        ids, d = N.filter_tombstoned_limit(m_ids, m_d, tomb, k)
+        live = np.setdiff1d(np.arange(n_flushed + n_pending), tomb.astype(np.int64))
+        e_ids, e_d = oracle.canonical_topk(q, allrows[live], k, O.L2, O.IPFORM_SINGLE)
+        assert np.array_equal(ids, live[e_ids.astype(np.int64)].astype(np.uint64))
+        assert np.allclose(d, e_d, rtol=1e-6, atol=0)
