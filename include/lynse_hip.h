@@ -60,7 +60,11 @@ enum {
 };
 
 /* IP accumulation form of the exact rescoring pass. */
-enum { LYNSE_IPFORM_AUTO = 0, LYNSE_IPFORM_SINGLE = 1, LYNSE_IPFORM_BATCH8 = 2 };
+enum { LYNSE_IPFORM_AUTO = 0, LYNSE_IPFORM_SINGLE = 1, LYNSE_IPFORM_BATCH8 = 2,
+       LYNSE_IPFORM_F16SEQ = 3 /* f16 storage: sequential sums of simd.rs:805-846 (set by the dtype, not by set_ip_form) */ };
+
+/* Storage dtype of a float shard (src/storage/dtype.rs:6-29). */
+enum { LYNSE_DTYPE_F32 = 0, LYNSE_DTYPE_F16 = 1 };
 
 typedef struct lynse_hip_flat lynse_hip_flat; /* one HBM-resident FLAT shard: replaces FlatMmap */
 typedef struct lynse_hip_ivf lynse_hip_ivf;   /* IVF-Flat over cluster slabs: replaces IVFIndex / IvfFlatMmap */
@@ -105,6 +109,12 @@ int lynse_hip_flat_append_f32_device(lynse_hip_flat *h, const float *d_rows, uin
 int lynse_hip_flat_append_packed_u64(lynse_hip_flat *h, const uint64_t *words, uint64_t n);
 int lynse_hip_flat_append_packed_u64_device(lynse_hip_flat *h, const uint64_t *d_words, uint64_t n);
 /* Row statistics for newly appended rows (norms, scale).  Idempotent. */
+/* VectorDtype::F16 storage (FlatMmap with dtype F16, flat_mmap.rs:187-221, search :905-908): appended f32 rows are
+ * rounded through f16 (RNE) like `encode_f32_slice_as_le_bytes`, `append_f16_bits` takes the file's u16 words as they
+ * are, and every distance follows the reference's f16 kernels (sequential f32 sums, simd.rs:805-846).  Must be called
+ * on an empty shard.  ip / l2 / cosine (+ the packed-binary metrics, which only see value > 0.5). */
+int lynse_hip_flat_set_dtype(lynse_hip_flat *h, int dtype);
+int lynse_hip_flat_append_f16_bits(lynse_hip_flat *h, const uint16_t *rows, uint64_t n);
 int lynse_hip_flat_finalize(lynse_hip_flat *h);
 /* Returned row = local_row * stride + offset (multi-GPU shards; default 1, 0). */
 int lynse_hip_flat_set_row_map(lynse_hip_flat *h, uint64_t stride, uint64_t offset);

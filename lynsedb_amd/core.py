@@ -83,17 +83,39 @@ class FlatIndex:
     flat_mmap.rs:89-109) it is loaded.
     """
 
-    def __init__(self, path: Optional[str], dim: int, device: Optional[int] = None):
+    def __init__(self, path: Optional[str], dim: int, device: Optional[int] = None, dtype: str = "f32"):
         self._h = C.c_void_p()
         self._dim = int(dim)
         dev = default_device() if device is None else int(device)
+        d = dtype.strip().lower()  # VectorDtype::parse (src/storage/dtype.rs:12-21)
+        if d in ("f32", "float32", "float"):
+            self.dtype = "f32"
+        elif d in ("f16", "float16", "half", "fp16"):
+            self.dtype = "f16"
+        else:
+            raise ValueError(f"unsupported vector dtype '{dtype}'; expected float32/f32 or float16/f16")
         check(lib.lynse_hip_flat_create(self._dim, dev, C.byref(self._h)))
+        if self.dtype == "f16":
+            check(lib.lynse_hip_flat_set_dtype(self._h, 1))
         self.path = path
         if path and os.path.exists(path) and os.path.getsize(path) > 0:
-            data = np.fromfile(path, dtype="<f4")
-            if data.size % self._dim:
-                raise IOError("vector file size is not a multiple of the row size")
-            self.write(data.reshape(-1, self._dim))
+            if self.dtype == "f16":
+                bits = np.fromfile(path, dtype="<u2")
+                if bits.size % self._dim:
+                    raise IOError("vector file size is not a multiple of the row size")
+                self.write_f16_bits(bits.reshape(-1, self._dim))
+            else:
+                data = np.fromfile(path, dtype="<f4")
+                if data.size % self._dim:
+                    raise IOError("vector file size is not a multiple of the row size")
+                self.write(data.reshape(-1, self._dim))
+
+    def write_f16_bits(self, bits) -> None:
+        """Append rows given as IEEE binary16 words — the bytes of an F16 segment file (flat_mmap.rs:187-221)."""
+        b = np.ascontiguousarray(bits, dtype=np.uint16)
+        if b.ndim != 2 or b.shape[1] != self._dim:
+            raise ValueError(f"data dimension mismatch: expected {self._dim}")
+        check(lib.lynse_hip_flat_append_f16_bits(self._h, _ptr(b), b.shape[0]))
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None

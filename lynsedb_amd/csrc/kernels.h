@@ -39,8 +39,42 @@ __device__ __forceinline__ float hsum8(float a) {
     return t;
 }
 
+// f16 storage (VectorDtype::F16): simd::inner_product_f16 / l2_squared_f16 / cosine_distance_f16 (simd.rs:805-846) are
+// plain sequential f32 sums over the decoded row, separate multiply and add.  One lane does the chain, the 8-lane
+// group gets the result.
+__device__ __forceinline__ float exact_score_f16seq(int metric, const float* __restrict__ q, const float* __restrict__ v,
+                                                    uint32_t D, int g) {
+    float r = 0.0f;
+    if (g == 0) {
+        if (metric == M_IP) {
+            float sum = 0.0f;
+            for (uint32_t i = 0; i < D; ++i) sum = __fadd_rn(sum, __fmul_rn(q[i], v[i]));
+            r = sum;
+        } else if (metric == M_L2) {
+            float sum = 0.0f;
+            for (uint32_t i = 0; i < D; ++i) {
+                const float d = __fsub_rn(q[i], v[i]);
+                sum = __fadd_rn(sum, __fmul_rn(d, d));
+            }
+            r = sum;
+        } else {
+            float dot = 0.0f, nq = 0.0f, nc = 0.0f;
+            for (uint32_t i = 0; i < D; ++i) {
+                const float a = q[i], c = v[i];
+                dot = __fadd_rn(dot, __fmul_rn(a, c));
+                nq = __fadd_rn(nq, __fmul_rn(a, a));
+                nc = __fadd_rn(nc, __fmul_rn(c, c));
+            }
+            if (nq == 0.0f || nc == 0.0f) r = 1.0f;
+            else r = __fsub_rn(1.0f, __fdiv_rn(dot, __fmul_rn(__builtin_sqrtf(nq), __builtin_sqrtf(nc))));
+        }
+    }
+    return __shfl(r, 0, 8);
+}
+
 __device__ __forceinline__ float exact_score(int metric, int ip_form, const float* __restrict__ q,
                                              const float* __restrict__ v, uint32_t D, int g) {
+    if (ip_form == LYNSE_IPFORM_F16SEQ) return exact_score_f16seq(metric, q, v, D, g);
     const uint32_t chunks = D / 8, rem = D % 8, base = chunks * 8;
     if (metric == M_IP && ip_form == LYNSE_IPFORM_BATCH8) {
         float acc = 0.0f;
@@ -878,6 +912,15 @@ __global__ void __launch_bounds__(WQ * WR * 64, (WQ * WR >= 8) ? (WQ * WR / 4) :
         o[0] = t_wait; o[1] = t_bar; o[2] = t_issue; o[3] = t_comp;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the clamped tail DMAs before the LDS is released
+}
+
+// f16 storage: rows [r0,r1) <- f16::to_f32(f16::from_f32(row)) in place (encode_f32_slice_as_le_bytes F16, RNE)
+__global__ void __launch_bounds__(256) k_round_rows_f16(float* __restrict__ V, uint32_t ld, uint32_t D, uint64_t r0, uint64_t r1) {
+    const uint64_t total = (r1 - r0) * D;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
+        float* p = V + (r0 + i / D) * ld + (i % D);
+        *p = (float)(_Float16)*p;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------

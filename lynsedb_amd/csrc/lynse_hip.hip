@@ -178,6 +178,7 @@ struct lynse_hip_flat {
 
     uint64_t row_stride = 1, row_offset = 0;
     int ip_form = LYNSE_IPFORM_AUTO;
+    int dtype = LYNSE_DTYPE_F32;  // F16: rows hold f16-representable values, distances use the f16 kernels' sequential sums
     uint32_t stage0_rows = 4096, growth = 8, cap = 16384;
 
     Workspace ws;
@@ -342,8 +343,39 @@ static int append_f32_impl(lynse_hip_flat* h, const float* src, uint64_t n, hipM
         }
         (void)hipFree(stage);
     }
+    if (h->dtype == LYNSE_DTYPE_F16) {  // what the F16 segment file keeps of these rows
+        const uint64_t total = n * h->dim;
+        hipLaunchKernelGGL(k_round_rows_f16, dim3((uint32_t)std::min<uint64_t>((total + 255) / 256, (uint64_t)h->num_cu * 32)), dim3(256), 0,
+                           h->stream, h->rows, h->ld, h->dim, h->n, h->n + n);
+        LY_HIP(hipGetLastError());
+    }
     LY_HIP(hipStreamSynchronize(h->stream));
     h->n += n;
+    return LYNSE_OK;
+}
+
+extern "C" int lynse_hip_flat_set_dtype(lynse_hip_flat* h, int dtype) {
+    if (!h || (dtype != LYNSE_DTYPE_F32 && dtype != LYNSE_DTYPE_F16)) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "bad dtype");
+    std::lock_guard<std::mutex> lk(h->mu);
+    if (h->n || h->packed_only) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "the dtype is fixed once rows are stored");
+    h->dtype = dtype;
+    return LYNSE_OK;
+}
+
+extern "C" int lynse_hip_flat_append_f16_bits(lynse_hip_flat* h, const uint16_t* rows, uint64_t n) {
+    if (!h) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "handle is NULL");
+    if (h->dtype != LYNSE_DTYPE_F16) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "append_f16_bits needs an F16 shard (lynse_hip_flat_set_dtype)");
+    if (n == 0) return LYNSE_OK;
+    if (!rows) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "rows is NULL");
+    // decode on the host in bounded chunks (f16 -> f32 is exact), then the ordinary append
+    const uint64_t chunk = std::max<uint64_t>(1, (64ull << 20) / ((uint64_t)h->dim * 4));
+    std::vector<float> buf((size_t)std::min<uint64_t>(chunk, n) * h->dim);
+    for (uint64_t r = 0; r < n; r += chunk) {
+        const uint64_t nr = std::min<uint64_t>(chunk, n - r);
+        const _Float16* src = reinterpret_cast<const _Float16*>(rows + r * h->dim);
+        for (uint64_t i = 0; i < nr * h->dim; ++i) buf[i] = (float)src[i];
+        LY_TRY(append_f32_impl(h, buf.data(), nr, hipMemcpyHostToDevice));
+    }
     return LYNSE_OK;
 }
 
@@ -897,7 +929,8 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
     const uint32_t qpad = small ? SCAN_BQ_SMALL : SCAN_BQ_LARGE;
     int ip_form = h->ip_form;
     if (ip_form == LYNSE_IPFORM_AUTO) ip_form = h->n < 4096 ? LYNSE_IPFORM_SINGLE : LYNSE_IPFORM_BATCH8;
-    if (mask || row_ids) ip_form = LYNSE_IPFORM_SINGLE;  // search_filtered scores every row with the single-row kernels (flat_mmap.rs:553-560)
+    if (mask || row_ids) ip_form = LYNSE_IPFORM_SINGLE;
+    if (h->dtype == LYNSE_DTYPE_F16) ip_form = LYNSE_IPFORM_F16SEQ;  // every f16 path of the reference uses the sequential kernels  // search_filtered scores every row with the single-row kernels (flat_mmap.rs:553-560)
 
     static bool sel_attr = false;
     if (!sel_attr) {

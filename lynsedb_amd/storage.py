@@ -123,16 +123,15 @@ def rows_to_user_ids(rows: np.ndarray, id_map: np.ndarray) -> np.ndarray:
 
 
 def read_segments(collection_path, dim: int, dtype: str = "f32"):
-    """Yield (first_global_row, rows f32[n, dim]) per segment in manifest order (global row = concatenation order,
-    vector_store.rs:1016-1037)."""
-    if dtype_width(dtype) != 4:
-        raise NotImplementedError("f16 segment files are SURVEY §8 row f3 (the reference scores them with its f16 kernels)")
+    """Yield (first_global_row, rows[n, dim]) per segment in manifest order (global row = concatenation order,
+    vector_store.rs:1016-1037): f32 values, or the u16 words of an F16 store."""
     root = Path(collection_path)
     m = load_manifest(root, dim, dtype)
+    f16 = dtype_width(dtype) == 2  # F16 segments: the rows come back as their u16 words (FlatIndex.write_f16_bits)
     base = 0
     for s in m.segments:
         if s.rows:
-            a = np.fromfile(root / s.file, dtype="<f4", count=s.rows * dim).reshape(s.rows, dim)
+            a = np.fromfile(root / s.file, dtype="<u2" if f16 else "<f4", count=s.rows * dim).reshape(s.rows, dim)
             yield base, a
         base += s.rows
 
@@ -143,18 +142,22 @@ def open_flat_collection(collection_path, dim: int, dtype: str = "f32", device: 
     from .core import FlatIndex
 
     m = load_manifest(collection_path, dim, dtype)
-    idx = FlatIndex(None, dim, device)
+    f16 = dtype_width(dtype) == 2
+    idx = FlatIndex(None, dim, device, dtype="f16" if f16 else "f32")
     total = sum(s.rows for s in m.segments)
     if total:
         idx.reserve(total)
     for _, rows in read_segments(collection_path, dim, dtype):
-        idx.write(rows)
+        if f16:
+            idx.write_f16_bits(rows)
+        else:
+            idx.write(rows)
     id_map = load_id_map(Path(collection_path) / m.id_map_file)
     return idx, id_map, m
 
 
 def write_flat_collection(collection_path, batches: Sequence[np.ndarray], ids: Optional[np.ndarray] = None,
-                          segment_target_bytes: int = DEFAULT_SEGMENT_TARGET_BYTES) -> VectorManifest:
+                          segment_target_bytes: int = DEFAULT_SEGMENT_TARGET_BYTES, dtype: str = "f32") -> VectorManifest:
     """Append `batches` the way VectorStore::write does (append_encoded_bytes, vector_store.rs:379-445): the first
     segment is `vectors.bin`; a batch that does not fit the current segment's target size opens
     `vector_segments/seg-{generation+1:020}-{index:06}.bin`; the manifest file appears with the second segment."""
@@ -163,8 +166,9 @@ def write_flat_collection(collection_path, batches: Sequence[np.ndarray], ids: O
     mpath = root / VECTOR_MANIFEST_FILE
     m = VectorManifest()
     for b in batches:
-        a = np.ascontiguousarray(b, dtype="<f4")
-        row_width = a.shape[1] * 4
+        # encode_f32_slice_as_le_bytes (src/storage/dtype.rs): F16 rounds to nearest even
+        a = np.ascontiguousarray(b, dtype="<f4") if dtype_width(dtype) == 4 else np.ascontiguousarray(np.asarray(b, np.float32).astype("<f2"))
+        row_width = a.shape[1] * dtype_width(dtype)
         target = max(segment_target_bytes, row_width)
         data = a.tobytes()
         fits = bool(m.segments) and m.segments[-1].rows * row_width + len(data) <= target

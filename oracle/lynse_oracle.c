@@ -877,6 +877,81 @@ size_t lo_canonical_topk_packed(const uint64_t *query, const uint64_t *rows, siz
     return r;
 }
 
+/* ------------------------------------------------------------- f16 storage (VectorDtype::F16) */
+
+/* simd::inner_product_f16 / l2_squared_f16 / cosine_distance_f16 (src/distance/simd.rs:805-846): plain sequential
+ * f32 sums over the DECODED f16 candidate (`cand` holds f16::to_f32 values), separate multiply and add. */
+float lo_distance_f16(const float *query, const float *cand, size_t dim, int metric) {
+    if (metric == LO_IP) {
+        float sum = 0.0f;
+        for (size_t i = 0; i < dim; ++i) { float p = query[i] * cand[i]; sum = sum + p; }
+        return sum;
+    }
+    if (metric == LO_L2) {
+        float sum = 0.0f;
+        for (size_t i = 0; i < dim; ++i) { float d = query[i] - cand[i]; float p = d * d; sum = sum + p; }
+        return sum;
+    }
+    float dot = 0.0f, nq = 0.0f, nc = 0.0f;
+    for (size_t i = 0; i < dim; ++i) {
+        float q = query[i], c = cand[i];
+        float a = q * c; dot = dot + a;
+        float b = q * q; nq = nq + b;
+        float e = c * c; nc = nc + e;
+    }
+    if (nq == 0.0f || nc == 0.0f) return 1.0f;
+    float den = sqrtf(nq) * sqrtf(nc);
+    return 1.0f - dot / den;
+}
+
+/* f32 -> f16 -> f32, round to nearest even: encode_f32_slice_as_le_bytes(.., F16) + f16::to_f32 (src/storage/dtype.rs) */
+static uint16_t f32_to_f16_bits(float f) { /* IEEE binary16, round to nearest even (half::f16::from_f32) */
+    uint32_t x;
+    memcpy(&x, &f, 4);
+    uint32_t sign = (x >> 16) & 0x8000u, exp = (x >> 23) & 0xffu, man = x & 0x7fffffu;
+    if (exp == 0xff) return (uint16_t)(sign | 0x7c00u | (man ? (0x200u | (man >> 13)) : 0u)); /* inf / nan */
+    int e = (int)exp - 127 + 15;
+    if (e >= 31) return (uint16_t)(sign | 0x7c00u);                                             /* overflow -> inf */
+    if (e <= 0) {                                                                                /* subnormal / zero */
+        if (e < -10) return (uint16_t)sign;
+        man |= 0x800000u;
+        uint32_t shift = (uint32_t)(14 - e);
+        uint32_t half = man >> shift, rem = man & ((1u << shift) - 1u), mid = 1u << (shift - 1);
+        if (rem > mid || (rem == mid && (half & 1u))) half += 1;
+        return (uint16_t)(sign | half);
+    }
+    uint32_t half = ((uint32_t)e << 10) | (man >> 13), rem = man & 0x1fffu;
+    if (rem > 0x1000u || (rem == 0x1000u && (half & 1u))) half += 1; /* may carry into the exponent (-> inf): correct */
+    return (uint16_t)(sign | half);
+}
+static float f16_bits_to_f32(uint16_t h) {
+    uint32_t sign = ((uint32_t)h & 0x8000u) << 16, exp = (h >> 10) & 0x1fu, man = h & 0x3ffu, x;
+    if (exp == 0) {
+        if (man == 0) x = sign;
+        else { int e = -1; do { ++e; man <<= 1; } while (!(man & 0x400u)); x = sign | ((uint32_t)(127 - 15 - e) << 23) | ((man & 0x3ffu) << 13); }
+    } else if (exp == 31) x = sign | 0x7f800000u | (man << 13);
+    else x = sign | ((exp - 15 + 127) << 23) | (man << 13);
+    float f;
+    memcpy(&f, &x, 4);
+    return f;
+}
+void lo_round_f16(const float *in, size_t n, float *out) {
+    for (size_t i = 0; i < n; ++i) out[i] = f16_bits_to_f32(f32_to_f16_bits(in[i]));
+}
+void lo_f16_bits(const float *in, size_t n, uint16_t *out) {
+    for (size_t i = 0; i < n; ++i) out[i] = f32_to_f16_bits(in[i]);
+}
+
+size_t lo_canonical_topk_f16(const float *query, const float *cands_decoded, size_t dim, size_t n, size_t k,
+                             int metric, uint32_t *out_idx, float *out_dist) {
+    if (n == 0 || k == 0) return 0;
+    float *d = (float *)malloc(n * sizeof(float));
+    for (size_t i = 0; i < n; ++i) d[i] = lo_distance_f16(query, cands_decoded + i * dim, dim, metric);
+    size_t r = canonical_from_dists(d, n, k, metric, out_idx, out_dist);
+    free(d);
+    return r;
+}
+
 /* ------------------------------------------------------------- filtered search */
 
 /* FlatMmap::search_filtered (flat_mmap.rs:491-815), f32 rows / packed-binary rows.

@@ -108,6 +108,12 @@ void lo_all_distances(const float *query, const float *cands, size_t dim, size_t
 
 /* VectorStore::merge_results (vector_store.rs:953-970) / engine merge
  * (engine.rs:3402-3414): sort (dist by metric order, id asc), truncate. */
+/* f16 storage (VectorDtype::F16): sequential-sum kernels of simd.rs:805-846 on decoded rows */
+float lo_distance_f16(const float *query, const float *cand, size_t dim, int metric);
+void lo_round_f16(const float *in, size_t n, float *out);
+void lo_f16_bits(const float *in, size_t n, uint16_t *out);
+size_t lo_canonical_topk_f16(const float *query, const float *cands_decoded, size_t dim, size_t n, size_t k,
+                             int metric, uint32_t *out_idx, float *out_dist);
 /* FlatMmap::search_filtered (flat_mmap.rs:491-815) and its canonical (set, (distance,row) order) answer */
 size_t lo_flat_search_filtered(const float *query, const float *cands, size_t dim, size_t n, size_t k,
                                int metric, const uint64_t *subset, size_t m, int n_threads,

@@ -71,6 +71,9 @@ class Oracle:
             s(n, _sz, _u64p, _u64p, _sz, _sz, _sz, C.c_int, C.c_int, _u32p, _f32p)
         s("lo_canonical_topk", _sz, _f32p, _f32p, _sz, _sz, _sz, C.c_int, C.c_int, _u32p, _f32p)
         s("lo_canonical_topk_packed", _sz, _u64p, _u64p, _sz, _sz, _sz, C.c_int, _u32p, _f32p)
+        s("lo_distance_f16", C.c_float, _f32p, _f32p, _sz, C.c_int)
+        s("lo_round_f16", None, _f32p, _sz, _f32p)
+        s("lo_canonical_topk_f16", _sz, _f32p, _f32p, _sz, _sz, _sz, C.c_int, _u32p, _f32p)
         s("lo_flat_search_filtered", _sz, _f32p, _f32p, _sz, _sz, _sz, C.c_int, _u64p, _sz, C.c_int, _u32p, _f32p)
         s("lo_packed_search_filtered", _sz, _u64p, _u64p, _sz, _sz, _sz, C.c_int, _u64p, _sz, _u32p, _f32p)
         s("lo_canonical_topk_filtered", _sz, _f32p, _f32p, _u64p, _u64p, _sz, _sz, _sz, _sz, C.c_int, _u64p, _sz, _u32p, _f32p)
@@ -206,6 +209,25 @@ class Oracle:
         r, pr = self._u64(rows_words)
         n, w = r.shape
         return self._topk_call(self.lib.lo_canonical_topk_packed, k, pq, pr, w, n, k, metric)
+
+    def round_f16(self, a):
+        """f32 -> f16 -> f32 (RNE): what VectorDtype::F16 storage keeps of a row."""
+        x, px = self._f(np.asarray(a, np.float32).reshape(-1))
+        out = np.zeros_like(x)
+        self.lib.lo_round_f16(px, x.size, out.ctypes.data_as(_f32p))
+        return out.reshape(np.asarray(a).shape)
+
+    def distance_f16(self, query, cand_decoded, metric):
+        q, pq = self._f(query)
+        c, pc = self._f(cand_decoded)
+        return float(self.lib.lo_distance_f16(pq, pc, q.size, metric))
+
+    def canonical_topk_f16(self, query, cands_decoded, k, metric):
+        """Search over f16-stored rows: sequential-sum kernels (simd.rs:805-846), canonical (distance, row) order."""
+        q, pq = self._f(query)
+        c, pc = self._f(cands_decoded)
+        n, dim = c.shape
+        return self._topk_call(self.lib.lo_canonical_topk_f16, k, pq, pc, dim, n, k, metric)
 
     def flat_search_filtered(self, query, cands, k, metric, subset, n_threads=8):
         """FlatMmap::search_filtered on f32 rows, the reference's policy (subset order / chunk order)."""

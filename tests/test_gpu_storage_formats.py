@@ -94,3 +94,46 @@ def test_flushed_plus_pending_rows_and_tombstones(L, oracle):
         e_ids, e_d = oracle.canonical_topk(q, allrows[live], k, O.L2, O.IPFORM_SINGLE)
         assert np.array_equal(ids, live[e_ids.astype(np.int64)].astype(np.uint64))
         assert np.allclose(d, e_d, rtol=1e-6, atol=0)
+
+
+# ------------------------------------------------------------------ VectorDtype::F16 storage
+@pytest.mark.parametrize("metric,name", [(O.IP, "ip"), (O.L2, "l2"), (O.COS, "cosine")])
+@pytest.mark.parametrize("n,dim,nq,k", [(3000, 24, 5, 10), (40000, 100, 33, 10), (90000, 33, 3, 25)])
+def test_f16_storage_search_parity(L, oracle, metric, name, n, dim, nq, k):
+    # rows live as f16 (rounded like encode_f32_slice_as_le_bytes); distances follow simd::*_f16 (sequential f32 sums)
+    rng = np.random.default_rng(n + dim)
+    data = (rng.standard_normal((n, dim)) * 3).astype(f32)
+    data[5] = 0  # a zero row: cosine distance 1.0 by the `== 0` rule of cosine_distance_f16
+    queries = (data[rng.integers(0, n, nq)] + 0.1 * rng.standard_normal((nq, dim))).astype(f32)
+    decoded = oracle.round_f16(data)
+    idx = L.FlatIndex(None, dim, 0, dtype="f16")
+    idx.write(data[: n // 2])                                          # f32 in: rounded on the device
+    idx.write_f16_bits(data[n // 2:].astype(np.float16).view(np.uint16))  # the bytes of an F16 segment file
+    assert np.array_equal(idx.read_rows(0, n), decoded)
+    rows, dists, counts = idx.search_batch_arrays(queries, k, name)
+    for qi in range(nq):
+        e_ids, e_d = oracle.canonical_topk_f16(queries[qi], decoded, k, metric)
+        assert np.array_equal(rows[qi].astype(np.uint32), e_ids), (qi, rows[qi], e_ids)
+        assert np.array_equal(dists[qi].view(np.uint32), e_d.view(np.uint32)), (qi, dists[qi], e_d)
+    # filtered search on the f16 store (search_filtered_f16, flat_mmap.rs:5329-5437) uses the same kernels
+    subset = np.sort(rng.choice(n, n // 3, replace=False)).astype(np.uint64)
+    frows, fd, fc = idx.search_filtered_batch_arrays(queries[:2], k, name, subset)
+    for qi in range(2):
+        sub_ids, sub_d = oracle.canonical_topk_f16(queries[qi], decoded[subset.astype(np.int64)], k, metric)
+        assert np.array_equal(frows[qi], subset[sub_ids.astype(np.int64)]) and np.array_equal(fd[qi].view(np.uint32), sub_d.view(np.uint32))
+
+
+def test_open_f16_collection(L, oracle, tmp_path):
+    rng = np.random.default_rng(5)
+    data = rng.standard_normal((2500, 12)).astype(f32)
+    S.write_flat_collection(tmp_path, [data[:1000], data[1000:]], segment_target_bytes=20_000, dtype="f16")
+    m = S.load_manifest(tmp_path, 12, "f16")
+    assert sum(s.rows for s in m.segments) == 2500 and len(m.segments) == 2
+    idx, id_map, _ = S.open_flat_collection(tmp_path, 12, "float16")
+    assert idx.dtype == "f16" and len(idx) == 2500
+    q = rng.standard_normal(12).astype(f32)
+    ids, d = idx.search(q, 7, "l2")
+    e_ids, e_d = oracle.canonical_topk_f16(q, oracle.round_f16(data), 7, O.L2)
+    assert np.array_equal(ids, e_ids) and np.array_equal(d.view(np.uint32), e_d.view(np.uint32))
+    with pytest.raises(ValueError):
+        L.FlatIndex(None, 4, 0, dtype="int8")

@@ -457,3 +457,30 @@ def test_filtered_search_kat_and_policies(oracle):  # vector_store.rs:1309-1329,
     # k is clamped to the subset length; rows >= n are skipped
     ids, d = oracle.flat_search_filtered(q, data, 5, O.L2, [3, 1000])
     assert ids.tolist() == [3]
+
+
+def test_f16_storage_kernels(oracle, oracle_portable):  # simd.rs:805-846, dtype.rs encode/decode
+    f32 = np.float32
+    rng = np.random.default_rng(8)
+    x = np.concatenate([rng.standard_normal(5000).astype(f32) * 50, np.array([0, -0.0, 65504, 65520, 1e-8, 6e-8, 2.98e-8, 3e-8], f32)])
+    with np.errstate(over="ignore"):
+        ref = x.astype(np.float16).astype(f32)
+    assert np.array_equal(oracle.round_f16(x), ref) and np.array_equal(oracle_portable.round_f16(x), ref)
+    q = rng.standard_normal(37).astype(f32)
+    c = oracle.round_f16(rng.standard_normal(37).astype(f32))
+    # sequential f32 accumulation, separate multiply and add (numpy float32 scalars round after every operation)
+    s = f32(0)
+    for a, b in zip(q, c):
+        s = f32(s + f32(a * b))
+    assert oracle.distance_f16(q, c, O.IP) == float(s) == oracle_portable.distance_f16(q, c, O.IP)
+    s = f32(0)
+    for a, b in zip(q, c):
+        d = f32(a - b)
+        s = f32(s + f32(d * d))
+    assert oracle.distance_f16(q, c, O.L2) == float(s)
+    dot = nq = nc = f32(0)
+    for a, b in zip(q, c):
+        dot = f32(dot + f32(a * b)); nq = f32(nq + f32(a * a)); nc = f32(nc + f32(b * b))
+    expect = f32(1) - f32(dot / f32(np.sqrt(nq) * np.sqrt(nc)))
+    assert oracle.distance_f16(q, c, O.COS) == float(expect)
+    assert oracle.distance_f16(q, np.zeros(37, f32), O.COS) == 1.0 and oracle.distance_f16(np.zeros(37, f32), c, O.COS) == 1.0
