@@ -235,7 +235,9 @@ int lynse_hip_ivf_export(const lynse_hip_ivf *h, float *centroids, uint32_t *ass
 int lynse_hip_ivf_set_row_map(lynse_hip_ivf *h, uint64_t stride, uint64_t offset);
 /* Probe selection semantics: 0 = IVFIndex (rank every centroid, ivf.rs:227-249, empty-probe fallback
  * :258-265); 1 = IvfFlatMmap (IP 16-dim shortlist heuristic, ivf_flat_mmap.rs:381-421).  build() sets
- * it from `l2_partitions`, load() defaults to 0. */
+ * it from `l2_partitions`, load() defaults to 0.  2 = keep the current routing but never fall back to the whole corpus
+ * when the probed lists are empty: one ROW SHARD of a larger index must not answer from rows outside the probed lists
+ * just because its own part of them is empty. */
 int lynse_hip_ivf_set_routing(lynse_hip_ivf *h, int ivfflat_routing);
 /* IVFIndex::search (ivf.rs:181-348): rank all centroids with the routing metric, scan the nprobe
  * nearest lists, exact top-k of the probed rows.  nprobe == 0 -> 1 (ivf.rs:192-196). */

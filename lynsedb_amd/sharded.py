@@ -215,3 +215,81 @@ class ShardedFlat:
         return {"queries": nverify, "recall_at_k": round(strict / (nverify * k), 6),
                 "recall_at_k_tolerant": round(tolerant / (nverify * k), 6),
                 "max_rel_score_diff_vs_torch_fp32": float("%.3g" % rel), "reference": "torch fp32 matmul top-k (GPU)"}
+
+
+class ShardedIvf:
+    """IVF-Flat over a row-sharded collection (BASELINE config 4): every rank holds the rows g % world == rank of EVERY
+    inverted list (same centroids everywhere), routes the batch identically, scans its part of the probed lists, and the
+    per-rank (distance, row) candidates are exchanged and merged exactly like ShardedFlat's.  The union over the ranks
+    of "rows of the probed lists" is the single-index candidate set, so results equal an unsharded IVF index built
+    from the same centroids + assignments.  The shards run with the empty-probe fallback of ivf.rs:258-265 switched off
+    (`lynse_hip_ivf_set_routing(h, 2)`): a shard whose part of the probed lists is empty contributes nothing."""
+
+    def __init__(self, dim: int, rank: int = 0, world: int = 1, device: Optional[int] = None, group=None):
+        self.dim, self.rank, self.world, self.device = dim, rank, world, device
+        self.dist = group
+        self.index = None
+
+    @staticmethod
+    def assign(rows: np.ndarray, centroids: np.ndarray, metric: str, device: Optional[int] = None) -> np.ndarray:
+        """kmeans::assign_metric (kmeans.rs:237-264) on the device: nearest centroid per row = a FLAT k=1 search of the
+        rows against the centroid matrix with the single-row kernels (first smaller rank wins = canonical order)."""
+        cen = FlatIndex(None, centroids.shape[1], device)
+        cen.write(np.ascontiguousarray(centroids, np.float32))
+        check(lib.lynse_hip_flat_set_ip_form(cen.handle, 1))
+        out = np.empty(rows.shape[0], np.uint32)
+        for r0 in range(0, rows.shape[0], 65536):
+            ids, _, _ = cen.search_batch_arrays(rows[r0:r0 + 65536], 1, metric)
+            out[r0:r0 + ids.shape[0]] = ids[:, 0].astype(np.uint32)
+        return out
+
+    def load_global(self, data: np.ndarray, centroids: np.ndarray, assignments: np.ndarray, metric: str,
+                    ivfflat_routing: bool = False, first_global_row: int = 0) -> None:
+        """Keep this rank's share of `data` (global rows first_global_row...) with the given global centroids/assignments."""
+        first = (self.rank - first_global_row) % self.world
+        self.load_local(np.ascontiguousarray(data[first::self.world]), centroids, np.ascontiguousarray(assignments[first::self.world]),
+                        metric, ivfflat_routing)
+
+    def load_local(self, local_rows: np.ndarray, centroids: np.ndarray, local_assignments: Optional[np.ndarray], metric: str,
+                   ivfflat_routing: bool = False) -> None:
+        from .core import IvfFlatIndex
+
+        if local_assignments is None:
+            local_assignments = self.assign(local_rows, centroids, "l2" if ivfflat_routing else metric, self.device)
+        self.index = IvfFlatIndex.load(local_rows, centroids, local_assignments, metric, device=self.device, ivfflat_routing=ivfflat_routing)
+        check(lib.lynse_hip_ivf_set_row_map(self.index._h, self.world, self.rank))
+        if self.world > 1:
+            check(lib.lynse_hip_ivf_set_routing(self.index._h, 2))
+        self.metric = metric
+
+    def search_local(self, queries: np.ndarray, k: int, nprobe: int):
+        """This rank's candidates: global row ids (local row l -> l * world + rank), canonical order."""
+        return self.index.search_batch_arrays(queries, k, nprobe)
+
+    def search(self, queries: np.ndarray, k: int, nprobe: int):
+        """Whole-collection answer on every rank: local scan, one all-gather of the result blocks, k-way merge."""
+        from .core import metric_from_str
+
+        rows, dists, counts = self.search_local(queries, k, nprobe)
+        if self.world == 1:
+            return rows, dists, counts
+        nq = rows.shape[0]
+        m = metric_from_str(self.metric)
+        rows_p = np.full((nq, k), np.iinfo(np.uint64).max, np.uint64)
+        dists_p = np.zeros((nq, k), np.float32)
+        rows_p[:, :rows.shape[1]], dists_p[:, :dists.shape[1]] = rows, dists
+        backend = self.dist.get_backend() if hasattr(self.dist, "get_backend") else "gloo"
+        if backend == "nccl":  # RCCL moves device memory: stage the 12 B/candidate block in HBM, merge on the device
+            import torch
+
+            dev = torch.device("cuda", self.device if self.device is not None else 0)
+            out = ShardOutputs(nq, k, self.world, dev)
+            out.local.copy_(torch.from_numpy(ShardedFlat.pack_block(rows_p, dists_p, counts)))
+            self.dist.all_gather_into_tensor(out.gathered, out.local)
+            check(lib.lynse_hip_merge_topk_device(C.c_void_p(out.gathered.data_ptr()), out.block_bytes, out.rows_off, out.dists_off,
+                                                  out.counts_off, self.world, nq, k, m, C.c_void_p(out.rows.data_ptr()),
+                                                  C.c_void_p(out.dists.data_ptr()), C.c_void_p(out.counts.data_ptr()),
+                                                  C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+            torch.cuda.synchronize()
+            return (out.rows.cpu().numpy().view(np.uint64), out.dists.cpu().numpy(), out.counts.cpu().numpy().view(np.uint32))
+        return ShardedFlat.allgather_merge_host(self.dist, self.world, rows_p, dists_p, counts, k, m)

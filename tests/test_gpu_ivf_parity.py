@@ -282,3 +282,36 @@ def test_ivf_filtered_parity(L, oracle, metric, n, dim, nlist, nprobe, nq, k, fr
     assert c0.tolist() == [0, 0]
     _, _, c1 = idx.search_filtered_batch_arrays(queries[:2], k, nprobe, [n + 5])
     assert c1.tolist() == [0, 0]
+
+
+@pytest.mark.parametrize("metric", [IP, L2])
+@pytest.mark.parametrize("world", [2, 4])
+def test_row_sharded_ivf_equals_single_index(L, oracle, metric, world):
+    # BASELINE config 4 in miniature: the shards of lynsedb_amd.sharded.ShardedIvf (all in this process, one GPU)
+    # searched separately + the k-way merge of the exchange step == the unsharded index == the oracle
+    from lynsedb_amd.sharded import ShardedIvf
+
+    rng = np.random.default_rng(world * 7 + metric)
+    n, dim, nlist, nprobe, nq, k = 6000, 32, 48, 5, 12, 10
+    centers = rng.standard_normal((20, dim)).astype(f32)
+    data = (centers[rng.integers(0, 20, n)] + 0.3 * rng.standard_normal((n, dim))).astype(f32)
+    queries = (data[rng.integers(0, n, nq)] + 0.05 * rng.standard_normal((nq, dim))).astype(f32)
+    cen, asg, off, rows = oracle_ivf(oracle, data, nlist, metric)
+    # device-side assignment (kmeans::assign_metric) agrees with the oracle's
+    assert np.array_equal(ShardedIvf.assign(data, cen, NAME[metric]), oracle.kmeans_assign(data, cen, metric))
+    shards = []
+    for r in range(world):
+        s = ShardedIvf(dim, rank=r, world=world, device=0)
+        s.load_global(data, cen, asg, NAME[metric])
+        shards.append(s)
+    parts = [s.search_local(queries, k, nprobe) for s in shards]
+    for qi in range(nq):
+        cand_r = np.full((world, k), np.iinfo(np.uint64).max, np.uint64)
+        cand_d = np.zeros((world, k), f32)
+        cnt = np.zeros(world, np.uint32)
+        for r, (pr, pd, pc) in enumerate(parts):
+            c = int(pc[qi])
+            cand_r[r, :c], cand_d[r, :c], cnt[r] = pr[qi, :c], pd[qi, :c], c
+        ids, d = L.merge_topk(cand_r, cand_d, cnt, k, metric)
+        e_ids, e_d, _ = oracle.ivf_search(queries[qi], data, cen, off, rows, nprobe, k, metric)
+        assert np.array_equal(ids, e_ids) and np.array_equal(d.view(np.uint32), e_d.view(np.uint32))

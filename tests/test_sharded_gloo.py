@@ -74,3 +74,65 @@ def test_allgather_merge_world2(metric):
     ret = mgr.dict()
     mp.spawn(_worker, args=(world, port, metric, ret), nprocs=world, join=True)
     assert dict(ret) == {0: True, 1: True}
+
+
+def _ivf_worker(rank, world, port, ret):
+    """Row-sharded IVF (BASELINE config 4): each rank answers from ITS rows of the probed lists (CPU oracle stands in for
+    the per-shard GPU scan), ShardedIvf.search does the exchange + merge; the result must equal the unsharded index."""
+    sys.path.insert(0, str(ROOT))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+
+    import oracle as O
+    from lynsedb_amd.sharded import ShardedIvf
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        orc = O.get()
+        rng = np.random.default_rng(99)
+        n, dim, nlist, nprobe, nq, k = 2000, 16, 12, 3, 6, 8
+        data = rng.standard_normal((n, dim)).astype(np.float32)
+        queries = rng.standard_normal((nq, dim)).astype(np.float32)
+        cen, asg = orc.kmeans_train(data, nlist, 10, O.L2)
+        off, rows = orc.lists_from_assignments(asg, cen.shape[0])
+        mine = np.arange(rank, n, world)
+        l_off, l_rows = orc.lists_from_assignments(asg[mine], cen.shape[0])
+
+        class _Shard(ShardedIvf):  # the GPU scan of the local shard, restated with the oracle
+            def search_local(self, q, k_, nprobe_):
+                r = np.full((q.shape[0], k_), np.iinfo(np.uint64).max, np.uint64)
+                d = np.zeros((q.shape[0], k_), np.float32)
+                c = np.zeros(q.shape[0], np.uint32)
+                for i in range(q.shape[0]):
+                    # probed lists come from the GLOBAL centroids; an empty local part contributes nothing (no fallback)
+                    _, _, probed = orc.ivf_search(q[i], data, cen, off, rows, nprobe_, k_, O.L2)
+                    cand = np.concatenate([l_rows[int(l_off[p]):int(l_off[p + 1])] for p in probed]).astype(np.int64)
+                    if cand.size:
+                        ids, dd = orc.canonical_topk(q[i], data[mine][cand], k_, O.L2, O.IPFORM_SINGLE)
+                        g = mine[cand[ids.astype(np.int64)]]
+                        order = np.lexsort((g, dd))
+                        r[i, :len(ids)], d[i, :len(ids)], c[i] = g[order], dd[order], len(ids)
+                return r, d, c
+
+        s = _Shard(dim, rank=rank, world=world, group=dist)
+        s.metric = "l2"
+        m_rows, m_d, m_c = s.search(queries, k, nprobe)
+        ok = True
+        for i in range(nq):
+            e_ids, e_d, _ = orc.ivf_search(queries[i], data, cen, off, rows, nprobe, k, O.L2)
+            ok &= int(m_c[i]) == len(e_ids) and np.array_equal(m_rows[i, :len(e_ids)], e_ids) and np.array_equal(m_d[i, :len(e_ids)], e_d)
+        ret[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_ivf_exchange_world2():
+    import torch.multiprocessing as mp
+
+    world = 2
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_ivf_worker, args=(world, port, ret), nprocs=world, join=True)
+    assert dict(ret) == {0: True, 1: True}
