@@ -74,6 +74,7 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    local_rank %= torch.cuda.device_count()  # (a 1-GPU box can still smoke-test the N>1 code path with LYNSE_BENCH_BACKEND=gloo)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     os.environ["LYNSE_HIP_DEVICE"] = str(local_rank)
@@ -83,7 +84,11 @@ def main():
 
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)  # "nccl" is RCCL on ROCm
+        backend = os.environ.get("LYNSE_BENCH_BACKEND", "nccl")  # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=backend)
 
     import lynsedb_amd as L
     from lynsedb_amd.sharded import ShardedFlat
