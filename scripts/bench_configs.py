@@ -122,9 +122,10 @@ def c5():
     return {"config": "C5 slice: Hamming 12500000x1024-bit, k=50", **out}
 
 
-def c4():
-    """IVF-Flat IP, a reduced slice of config 4: 2M x 768 clustered unit vectors, nlist=1024, nprobe=32, k=10."""
-    n, dim, K = 2_000_000, 768, 1024
+def c4(n=2_000_000, K=1024):
+    """IVF-Flat IP, a reduced slice of config 4: 2M x 768 clustered unit vectors, nlist=1024, nprobe=32, k=10
+    (c4full: one GPU's 6.25M-row share of the 50M x 768, nlist=4096 configuration)."""
+    dim = 768
     rng = np.random.default_rng(7)
     centers = rng.standard_normal((K, dim)).astype(np.float32)
     centers /= np.linalg.norm(centers, axis=1, keepdims=True)
@@ -144,8 +145,18 @@ def c4():
     flat.write(data)
     frows, fd, fc = flat.search_batch_arrays(qs, 10, "ip")
     rec = np.mean([len(set(rows[i].tolist()) & set(frows[i].tolist())) / 10 for i in range(64)])
-    return {"config": "C4 slice: IVF-IP 2000000x768 nlist=1024 nprobe=32 k=10, batch 64 (host API)", "build_s": round(build_s, 1),
-            "median_ms": round(med * 1e3, 2), "qps": round(64 / med, 1), "recall_at_10_vs_flat": round(float(rec), 4)}
+    out = {"config": "C4 slice: IVF-IP %dx768 nlist=%d nprobe=32 k=10, batch 64 (host API)" % (n, K), "build_s": round(build_s, 1),
+           "median_ms": round(med * 1e3, 2), "qps": round(64 / med, 1), "recall_at_10_vs_flat": round(float(rec), 4)}
+    for nq in (1, 256):
+        qq = np.ascontiguousarray(np.tile(qs, (4, 1))[:nq])
+        m2, _ = timeit(lambda: ivf.search_batch_arrays(qq, 10, 32), 2, 5)
+        f2, _ = timeit(lambda: flat.search_batch_arrays(qq, 10, "ip"), 2, 5)
+        out["nq%d" % nq] = {"ivf_ms": round(m2 * 1e3, 3), "ivf_qps": round(nq / m2, 1), "flat_ms": round(f2 * 1e3, 3)}
+    return out
+
+
+def c4full():
+    return c4(6_250_000, 4096)
 
 
 def small():
