@@ -77,8 +77,18 @@ __device__ __forceinline__ float exact_score(int metric, int ip_form, const floa
     if (ip_form == LYNSE_IPFORM_F16SEQ) return exact_score_f16seq(metric, q, v, D, g);
     const uint32_t chunks = D / 8, rem = D % 8, base = chunks * 8;
     if (metric == M_IP && ip_form == LYNSE_IPFORM_BATCH8) {
+        // loads are issued eight steps at a time (the FMA chain keeps the reference's order): one candidate is a chain
+        // of D/8 dependent FMAs, and waiting out a global-load round trip per step made k_final latency-bound
         float acc = 0.0f;
-        for (uint32_t i = 0; i < chunks; ++i) acc = __fmaf_rn(q[i * 8 + g], v[i * 8 + g], acc);
+        uint32_t i = 0;
+        for (; i + 8 <= chunks; i += 8) {
+            float a[8], b[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { a[u] = q[(i + u) * 8 + g]; b[u] = v[(i + u) * 8 + g]; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc = __fmaf_rn(a[u], b[u], acc);
+        }
+        for (; i < chunks; ++i) acc = __fmaf_rn(q[i * 8 + g], v[i * 8 + g], acc);
         float sum = hsum8(acc);
         for (uint32_t i = 0; i < rem; ++i) sum = __fadd_rn(sum, __fmul_rn(q[base + i], v[base + i]));
         return sum;
@@ -87,7 +97,24 @@ __device__ __forceinline__ float exact_score(int metric, int ip_form, const floa
         const bool l2 = metric == M_L2;
         const uint32_t dbl = chunks / 2, single = chunks % 2;
         float acc0 = 0.0f, acc1 = 0.0f;
-        for (uint32_t i = 0; i < dbl; ++i) {
+        uint32_t i = 0;
+        for (; i + 4 <= dbl; i += 4) {
+            float a[8], b[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { a[u] = q[i * 16 + u * 8 + g]; b[u] = v[i * 16 + u * 8 + g]; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (l2) {
+                    const float d0 = __fsub_rn(a[2 * u], b[2 * u]), d1 = __fsub_rn(a[2 * u + 1], b[2 * u + 1]);
+                    acc0 = __fmaf_rn(d0, d0, acc0);
+                    acc1 = __fmaf_rn(d1, d1, acc1);
+                } else {
+                    acc0 = __fmaf_rn(a[2 * u], b[2 * u], acc0);
+                    acc1 = __fmaf_rn(a[2 * u + 1], b[2 * u + 1], acc1);
+                }
+            }
+        }
+        for (; i < dbl; ++i) {
             float a0 = q[i * 16 + g], b0 = v[i * 16 + g];
             float a1 = q[i * 16 + 8 + g], b1 = v[i * 16 + 8 + g];
             if (l2) {
@@ -121,7 +148,19 @@ __device__ __forceinline__ float exact_score(int metric, int ip_form, const floa
     }
     // cosine distance
     float d = 0.0f, x = 0.0f, y = 0.0f;
-    for (uint32_t i = 0; i < chunks; ++i) {
+    uint32_t i = 0;
+    for (; i + 8 <= chunks; i += 8) {
+        float a8[8], b8[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { a8[u] = q[(i + u) * 8 + g]; b8[u] = v[(i + u) * 8 + g]; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            d = __fmaf_rn(a8[u], b8[u], d);
+            x = __fmaf_rn(a8[u], a8[u], x);
+            y = __fmaf_rn(b8[u], b8[u], y);
+        }
+    }
+    for (; i < chunks; ++i) {
         float a = q[i * 8 + g], b = v[i * 8 + g];
         d = __fmaf_rn(a, b, d);
         x = __fmaf_rn(a, a, x);

@@ -798,6 +798,8 @@ static int launch_scan_h16(const ScanArgs& a, int metric, uint32_t grid, hipStre
                 case 15: LY_TRY(ex(k_scan_h16<WQ, WR, TQ, TR, M_IP, NSV, NSQ, 2, TILED, false, 15>)); break;
                 case 14: LY_TRY(ex(k_scan_h16<WQ, WR, TQ, TR, M_IP, NSV, NSQ, 2, TILED, false, 14>)); break;
                 case 13: LY_TRY(ex(k_scan_h16<WQ, WR, TQ, TR, M_IP, NSV, NSQ, 2, TILED, false, 13>)); break;
+                case 4: LY_TRY(ex(k_scan_h16<WQ, WR, TQ, TR, M_IP, NSV, NSQ, 2, TILED, false, 4>)); break;
+                case 8: LY_TRY(ex(k_scan_h16<WQ, WR, TQ, TR, M_IP, NSV, NSQ, 2, TILED, false, 8>)); break;
                 default: return set_error(LYNSE_ERR_INVALID_ARGUMENT, "unknown experiment");
                 }
                 LY_HIP(hipGetLastError());
