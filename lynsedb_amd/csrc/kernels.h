@@ -1829,8 +1829,10 @@ __global__ void __launch_bounds__(NT) k_select(SelectArgs a) {
     if (tid == 0) { s_keep = 0; s_prefix = 0; s_rank = a.k - 1; }
     __syncthreads();
 
-    // ---- k-th smallest key (keys are unique: the low word is the row)
-    for (int shift = 56; shift >= 0; shift -= 8) {
+    // ---- k-th smallest key (keys are unique: the low word is the row).  Float metrics only need the k-th SCORE (every
+    // tie of it survives the margin cut anyway): four passes over the score word instead of eight over the whole key.
+    const int last_shift = a.exact ? 0 : 32;
+    for (int shift = 56; shift >= last_shift; shift -= 8) {
         if (tid < 256) hist[tid] = 0;
         __syncthreads();
         const uint64_t prefix = s_prefix;
@@ -1871,7 +1873,7 @@ __global__ void __launch_bounds__(NT) k_select(SelectArgs a) {
         }
         __syncthreads();
     }
-    const uint64_t kth = s_prefix;
+    const uint64_t kth = a.exact ? s_prefix : (s_prefix | 0xffffffffull);  // float: every row of the k-th score counts as <= kth
     const float tau = key_score(kth, asc);
 
     float thr_new;
