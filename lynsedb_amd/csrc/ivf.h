@@ -1,5 +1,6 @@
-// ivf.h — IVF-Flat kernels: centroid routing, per-group query image gather, k-means helpers.
-// The slab scan itself is k_scan_glds in work-list (TILED) mode (kernels.h).
+// ivf.h — IVF-Flat kernels: centroid routing (heuristic mode; the exact mode is a FLAT search over the centroids),
+// per-group query image gather, k-means helpers, BinaryQuantizer fit, tiled packed-binary list scan.
+// The float slab scan itself is k_scan_h16 in work-list (TILED) mode (kernels.h).
 #pragma once
 #include "kernels.h"
 

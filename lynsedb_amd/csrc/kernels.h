@@ -1,15 +1,17 @@
 // kernels.h — hand-written HIP kernels for CDNA4 (gfx950, wave64) of the FLAT scan pipeline.
 //
 // Pipeline for a batch of queries against one HBM-resident shard:
-//   k_prep_queries   per-query scale / norms / certified error margin, f16 query image
-//   k_scan_f16       THE HOT KERNEL: rows streamed once from HBM (f32, coalesced 256-B row pieces),
-//                    converted to f16 in flight, staged through LDS, Q·Vᵀ on MFMA 32x32x16 f16,
-//                    threshold-filter epilogue appending (score,row) keys per query
-//   k_scan_binary    packed-binary rows: xor/and/or + popcount, same filter epilogue (exact ints)
-//   k_select         per-query LDS bitonic sort of the candidate keys, new threshold, prune
-//   k_final          exact rescoring of the survivors in the REFERENCE's accumulation order
-//                    (bit-exact with src/distance/simd.rs AVX2 kernels), final sort, output
-//   k_row_stats / k_pack_bits   one-time per appended row range
+//   k_prep_queries        per-query scale / norms / certified error margin, f16 query image
+//   k_scan_h16            THE HOT KERNEL (default): the f16 shadow rows streamed once from HBM by LDS-DMA, Q·Vᵀ on
+//                         MFMA 32x32x16 f16, threshold-filter epilogue appending (score,row) keys per query
+//   k_scan_glds / _f16    its predecessors over the f32 rows (LDS-DMA ring / register-staged), kept as A/B references
+//   k_scan_binary_rows    packed-binary rows: lane-per-row xor/and + popcount with scalar query words (exact ints);
+//   k_scan_binary         the 8-lanes-per-row predecessor
+//   k_select              per query: radix-select the k-th best candidate key in LDS, new threshold, prune
+//   k_final               exact rescoring of the survivors in the REFERENCE's accumulation order
+//                         (bit-exact with src/distance/simd.rs AVX2 kernels), final sort, output
+//   k_row_stats / k_rows_to_f16 / k_pack_bits   one-time per appended row range
+//   filtered search: k_mask_build, k_bits_*, k_gather_rows16 / k_gather_norms;  multi-GPU: k_merge
 #pragma once
 
 #include "common.h"
