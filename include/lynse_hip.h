@@ -152,6 +152,18 @@ int lynse_hip_flat_search_filtered_bitset_f32(lynse_hip_flat *h, const float *qu
                                               uint32_t k, int metric, const uint64_t *bitset_words,
                                               uint64_t n_words, uint64_t *out_rows, float *out_dists,
                                               uint32_t *out_counts);
+/* FLAT-*-SQ8 (`use_sq8`, src/storage/flat_mmap.rs:891-905, sq8_two_pass_search :5868-5926): pass 1 ranks ALL rows by the
+ * integer score of their per-dimension u8 codes (u32 dot for ip, u32 squared L2 for l2 and cosine; SQ8Data :5676-5750,
+ * built lazily like ensure_sq8 and rebuilt after appends) and keeps n_cand = max(20 k, 200) rows (cosine max(100 k, 500));
+ * pass 2 rescores those exactly with the single-row f32 kernels and returns the best k.  Approximate by design: a true
+ * neighbour outside the n_cand best codes is lost, exactly as in the reference.  Ties at the n_cand cut and between equal
+ * exact distances are broken by row id (the reference leaves them to heap / unstable-sort order).  Other metrics take the
+ * ordinary exact path, as `use_sq8` does. */
+int lynse_hip_flat_search_sq8_f32(lynse_hip_flat *h, const float *queries, uint64_t nq, uint32_t k,
+                                  int metric, uint64_t *out_rows, float *out_dists,
+                                  uint32_t *out_counts);
+/* The SQ8 quantiser state (per-dimension minimum and scale = 255 / range, 0 for a constant dimension). */
+int lynse_hip_flat_sq8_params(lynse_hip_flat *h, float *mins, float *scales);
 /* Same with every buffer already resident in this handle's device memory; enqueued on `stream`
  * (a hipStream_t, NULL = the handle's own non-blocking stream) and synchronised before returning.
  * Device inputs of every *_device entry must be COMPLETE when the call is made (synchronise the

@@ -63,6 +63,8 @@ SIGNATURES = {
     "lynse_hip_flat_copy_rows_device": (C.c_int, [_vp, C.c_uint64, C.c_uint64, _vp]),
     "lynse_hip_flat_read_packed": (C.c_int, [_vp, C.c_uint64, C.c_uint64, _vp]),
     "lynse_hip_flat_search_f32": (C.c_int, [_vp, _vp, C.c_uint64, C.c_uint32, C.c_int, _vp, _vp, _vp]),
+    "lynse_hip_flat_search_sq8_f32": (C.c_int, [_vp, _vp, C.c_uint64, C.c_uint32, C.c_int, _vp, _vp, _vp]),
+    "lynse_hip_flat_sq8_params": (C.c_int, [_vp, _vp, _vp]),
     "lynse_hip_flat_set_dtype": (C.c_int, [_vp, C.c_int]),
     "lynse_hip_flat_append_f16_bits": (C.c_int, [_vp, _vp, C.c_uint64]),
     "lynse_hip_flat_search_filtered_f32": (C.c_int, [_vp, _vp, C.c_uint64, C.c_uint32, C.c_int, _vp, C.c_uint64, _vp, _vp, _vp]),

@@ -197,6 +197,24 @@ class FlatIndex:
         check(lib.lynse_hip_flat_search_f32(self._h, _ptr(q), nq, k, m, _ptr(rows), _ptr(dists), _ptr(counts)))
         return rows[:, :k], dists[:, :k], counts
 
+    def search_sq8_batch_arrays(self, queries, k: int, metric):
+        """`FlatMmap::search(.., use_sq8 = true, ..)` — the FLAT-*-SQ8 index modes (flat_mmap.rs:891-905, :5868-5926)."""
+        m = metric if isinstance(metric, int) else metric_from_str(metric)
+        q = _f32(queries, 2, "queries")
+        if q.shape[1] != self._dim:
+            raise ValueError(f"query dimension mismatch: expected {self._dim}, got {q.shape[1]}")
+        nq, k = q.shape[0], int(k)
+        rows = np.empty((nq, max(k, 1)), np.uint64)
+        dists = np.empty((nq, max(k, 1)), np.float32)
+        counts = np.zeros(nq, np.uint32)
+        check(lib.lynse_hip_flat_search_sq8_f32(self._h, _ptr(q), nq, k, m, _ptr(rows), _ptr(dists), _ptr(counts)))
+        return rows[:, :k], dists[:, :k], counts
+
+    def sq8_params(self):
+        mins, scales = np.empty(self._dim, np.float32), np.empty(self._dim, np.float32)
+        check(lib.lynse_hip_flat_sq8_params(self._h, _ptr(mins), _ptr(scales)))
+        return mins, scales
+
     def search_filtered_batch_arrays(self, queries, k: int, metric, subset_rows):
         """`FlatMmap::search_filtered` (flat_mmap.rs:491-815) for a batch sharing one subset of row indices."""
         m = metric if isinstance(metric, int) else metric_from_str(metric)

@@ -1002,10 +1002,17 @@ constexpr int HK = 64;  // K elements per slab
 // 4 no query-image DMA, 8 no row DMA.  FILT compiles the subset-filter paths in (mask / row_ids of ScanArgs): they
 // cost registers the unfiltered kernel does not have to spare (56 B/lane of scratch and 13 % of its speed when they
 // were runtime branches).
-template <int WQ, int WR, int TQ, int TR, int METRIC, int NSV, int NSQ, int NT_HINT, bool TILED = false, bool RAG = true, int DBG = 0, bool FILT = false>
+template <int WQ, int WR, int TQ, int TR, int METRIC, int NSV, int NSQ, int NT_HINT, bool TILED = false, bool RAG = true, int DBG = 0, bool FILT = false,
+          bool I8 = false>
 __global__ void __launch_bounds__(WQ * WR * 64, (TQ * TR >= 16) ? 1 : ((WQ * WR >= 8) ? (WQ * WR / 4) : 2)) k_scan_h16(ScanArgs a) {
     // Two LDS rings: NSV stages of row slabs (HBM latency: deeper) and NSQ <= NSV stages of query-image
     // slabs (L2 latency) — 3 + 2 stages of 32 KiB fill the 160 KiB of a CU for the 256 x 256 tile.
+    // I8 = SQ8 pass 1 (FLAT-*-SQ8): rows and query image are signed bytes (code - 128), a slab is 128 elements = the same
+    // 128 B per line, the MFMA is v_mfma_i32_32x32x32_i8 (exact integers), the epilogue rebuilds the u32 score of the
+    // reference's u8 kernels (flat_mmap.rs:5847-5863) from the i8 dot product and per-row / per-query sums.
+    constexpr int ES = I8 ? 1 : 2;          // element size in bytes
+    constexpr int KS = 128 / ES;            // elements per slab
+    constexpr int EPS = 16 / ES;            // elements per 16-B slot
     constexpr int NW = WQ * WR;
     constexpr int BQ = WQ * TQ * 32;
     constexpr int BR = WR * TR * 32;
@@ -1036,16 +1043,16 @@ __global__ void __launch_bounds__(WQ * WR * 64, (TQ * TR >= 16) ? 1 : ((WQ * WR 
     const uint32_t my_tiles = (a.ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x;
     const uint32_t G = my_tiles * a.nslab;
     const uint32_t tstride = a.tile_stride ? a.tile_stride : (uint32_t)BR;
-    const bool ragged_k = RAG && (a.ld16 % HK) != 0;  // last slab reaches past ld16: clamp columns (they meet zeros in the query image)
+    const bool ragged_k = RAG && (a.ld16 % KS) != 0;  // last slab reaches past ld16: clamp columns (they meet zeros in the query image)
 
     uint32_t v_rowoff[VPW], v_col[VPW];
 #pragma unroll
     for (int j = 0; j < VPW; ++j) {
         const uint32_t r = (wave * VPW + j) * 8 + (lane >> 3);  // row inside the tile
         v_rowoff[j] = r;
-        v_col[j] = ((lane & 7) ^ ((r >> 1) & 7)) * 8;            // physical 16-B slot -> logical f16 column
+        v_col[j] = ((lane & 7) ^ ((r >> 1) & 7)) * EPS;          // physical 16-B slot -> logical element column
     }
-    const _Float16* v_src[VPW];  // row pointers (incl. swizzled column) of the tile being issued
+    const char* v_src[VPW];  // row pointers (incl. swizzled column) of the tile being issued
     const char* q_src[QPW];
     uint32_t q_piece[QPW];  // uniform
 #pragma unroll
@@ -1055,9 +1062,9 @@ __global__ void __launch_bounds__(WQ * WR * 64, (TQ * TR >= 16) ? 1 : ((WQ * WR 
     // query stream position
     uint32_t qs_tile = blockIdx.x, qs_slab = 0, qs_stage = 0, qs_count = 0;
     uint32_t qs_qslab = a.qpad * LINE;
-    constexpr bool NORMS_LDS = !TILED && METRIC != M_IP && (NORM_RING + (NSV + 1) * 1024 <= 160 * 1024);
+    constexpr bool NORMS_LDS = !TILED && (METRIC != M_IP || I8) && (NORM_RING + (NSV + 1) * 1024 <= 160 * 1024);
     constexpr int NORM_SLOTS = NSV + 1;
-    const float* norm_src = METRIC == M_L2 ? a.vn2 : a.vrinv;
+    const float* norm_src = (METRIC == M_L2 || I8) ? a.vn2 : a.vrinv;  // I8: a.vn2 carries the per-row int sums
 
     auto v_enter_tile = [&]() {
         uint32_t rbase, last;
@@ -1079,7 +1086,7 @@ __global__ void __launch_bounds__(WQ * WR * 64, (TQ * TR >= 16) ? 1 : ((WQ * WR 
         for (int j = 0; j < VPW; ++j) {
             uint32_t row = rbase + v_rowoff[j];
             row = row < last ? row : last;  // clamped rows are masked in the epilogue
-            v_src[j] = a.V16 + (size_t)row * a.ld16 + v_col[j];
+            v_src[j] = reinterpret_cast<const char*>(a.V16) + ((size_t)row * a.ld16 + v_col[j]) * ES;
         }
     };
     auto q_enter_tile = [&]() {
@@ -1099,12 +1106,12 @@ __global__ void __launch_bounds__(WQ * WR * 64, (TQ * TR >= 16) ? 1 : ((WQ * WR 
         } else {
             if (DBG & 8) return;
             const int j = p - QPW;
-            const uint32_t koff = vs_slab * HK;
-            const _Float16* src = v_src[j] + koff;
+            const uint32_t koff = vs_slab * KS;
+            const char* src = v_src[j] + (size_t)koff * ES;
             if (ragged_k) {
                 uint32_t col = koff + v_col[j];
-                col = col < a.ld16 ? col : a.ld16 - 8;
-                src = v_src[j] - v_col[j] + col;
+                col = col < a.ld16 ? col : a.ld16 - EPS;
+                src = v_src[j] + ((size_t)col - v_col[j]) * ES;
             }
             glds16<NT_HINT>(src, smem + vs_stage * V_BYTES + (wave * VPW + j) * 1024);
         }
@@ -1156,8 +1163,8 @@ __global__ void __launch_bounds__(WQ * WR * 64, (TQ * TR >= 16) ? 1 : ((WQ * WR 
         c_thr[j] = c_ok[j] ? a.thr[n] : 0.0f;
         if (a.debug_flags & 2) c_thr[j] = ASC ? -LY_INF : LY_INF;
         c_extra[j] = 0.0f;
-        if (METRIC == M_L2) c_extra[j] = c_ok[j] ? a.qn2[n] : 0.0f;
-        if (METRIC == M_COS) c_extra[j] = c_ok[j] ? a.qrinv[n] : 0.0f;
+        if (METRIC == M_L2 || I8) c_extra[j] = c_ok[j] ? a.qn2[n] : 0.0f;  // I8: the per-query integer constant, as bits
+        if (METRIC == M_COS && !I8) c_extra[j] = c_ok[j] ? a.qrinv[n] : 0.0f;
     }
 #pragma unroll
     for (int j = 0; j < TQ; ++j) asm volatile("" : "+v"(c_qinv[j]), "+v"(c_thr[j]), "+v"(c_extra[j]));
@@ -1215,8 +1222,17 @@ __global__ void __launch_bounds__(WQ * WR * 64, (TQ * TR >= 16) ? 1 : ((WQ * WR 
                     for (int j = 0; j < TQ; ++j) asm volatile("" ::"v"(bf[cur][j]));
                 } else {
 #pragma unroll
-                    for (int j = 0; j < TQ; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[cur][i], bf[cur][j], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < TQ; ++j) {
+                        if constexpr (I8) {
+                            typedef int i32x4 __attribute__((ext_vector_type(4)));
+                            typedef int i32x16 __attribute__((ext_vector_type(16)));
+                            acc[i][j] = __builtin_bit_cast(f32x16, __builtin_amdgcn_mfma_i32_32x32x32_i8(
+                                __builtin_bit_cast(i32x4, af[cur][i]), __builtin_bit_cast(i32x4, bf[cur][j]),
+                                __builtin_bit_cast(i32x16, acc[i][j]), 0, 0, 0));
+                        } else {
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[cur][i], bf[cur][j], acc[i][j], 0, 0, 0);
+                        }
+                    }
                 }
                 {   // refill pieces scheduled behind this MFMA group (slot kk*TR+i of NSLOT)
                     const int slot = kk * TR + i;
@@ -1244,6 +1260,15 @@ __global__ void __launch_bounds__(WQ * WR * 64, (TQ * TR >= 16) ? 1 : ((WQ * WR 
             const float* nrm = reinterpret_cast<const float*>(smem + NORM_RING + (c_tileseq % NORM_SLOTS) * 1024);
             ++c_tileseq;
             auto score = [&](int i, int j, int r, uint32_t m, bool rok) -> float {
+                if constexpr (I8) {
+                    // dot of the u8 codes = i8 dot + 128 (sum q' + sum r') + 16384 D; squared L2 = sum q'^2 + sum r'^2 - 2 dot
+                    const float accv = acc[i][j][r];
+                    const int dotp = __float_as_int(accv);
+                    const int rowsum = NORMS_LDS ? __float_as_int(nrm[m - rbase]) : (rok ? __float_as_int(a.vn2[m]) : 0);
+                    const int qconst = __float_as_int(c_extra[j]);
+                    const uint32_t u = METRIC == M_IP ? (uint32_t)(dotp + qconst + 128 * rowsum) : (uint32_t)(qconst + rowsum - 2 * dotp);
+                    return (float)u;  // `dist_fn(..) as f32` (flat_mmap.rs:5956)
+                }
                 float sc = acc[i][j][r] * c_qinv[j];
                 if (METRIC != M_IP) {
                     float nv;
@@ -1329,6 +1354,105 @@ __global__ void __launch_bounds__(WQ * WR * 64, (TQ * TR >= 16) ? 1 : ((WQ * WR 
         o[0] = t_wait; o[1] = t_bar; o[2] = 0; o[3] = t_comp;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// ------------------------------------------------------------------------------------------------
+// SQ8 (FLAT-*-SQ8, flat_mmap.rs:5676-5750): per-dimension min / max over all rows, codes
+// clamp(round((v - min) * scale), 0, 255) stored as code - 128 (signed byte for the i8 MFMA), per-row sums of the
+// signed codes and of their squares, and the same for the queries.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_sq8_minmax(const float* __restrict__ V, uint32_t ld, uint32_t D, uint64_t n,
+                                                    uint32_t* __restrict__ omin, uint32_t* __restrict__ omax) {
+    // thread = one dimension (coalesced across the row), block = a strip of rows; `<` / `>` updates like the reference
+    // (NaN never replaces), merged with atomics on the order-preserving image
+    const uint64_t rows_per_block = (n + gridDim.y - 1) / gridDim.y;
+    const uint64_t r0 = (uint64_t)blockIdx.y * rows_per_block, r1 = r0 + rows_per_block < n ? r0 + rows_per_block : n;
+    const uint32_t d = blockIdx.x * 256 + threadIdx.x;
+    if (d >= D) return;
+    float mn = LY_INF, mx = -LY_INF;
+    for (uint64_t r = r0; r < r1; ++r) {
+        const float v = V[r * ld + d];
+        if (v < mn) mn = v;
+        if (v > mx) mx = v;
+    }
+    atomicMin(&omin[d], f32_to_ord(mn));
+    atomicMax(&omax[d], f32_to_ord(mx));
+}
+
+__global__ void __launch_bounds__(256) k_sq8_scales(const uint32_t* __restrict__ omin, const uint32_t* __restrict__ omax, uint32_t D,
+                                                    float* __restrict__ mins, float* __restrict__ scales) {
+    const uint32_t d = blockIdx.x * 256 + threadIdx.x;
+    if (d >= D) return;
+    const float mn = ord_to_f32(omin[d]), mx = ord_to_f32(omax[d]);
+    const float range = __fsub_rn(mx, mn);
+    mins[d] = mn;
+    scales[d] = range > 1e-30f ? __fdiv_rn(255.0f, range) : 0.0f;
+}
+
+__device__ __forceinline__ int sq8_code(float v, float mn, float sc) {
+    float q = roundf(__fmul_rn(__fsub_rn(v, mn), sc));  // f32::round: half away from zero
+    if (!(q == q)) return 0;
+    q = q < 0.0f ? 0.0f : (q > 255.0f ? 255.0f : q);
+    return (int)q;
+}
+
+// one wave per row (or query): codes - 128 into `out` (pitch ld8, pad columns 0), sum and sum of squares of the signed codes
+__global__ void __launch_bounds__(256) k_sq8_quantize(const float* __restrict__ V, uint32_t ld, uint32_t D, uint64_t n,
+                                                      const float* __restrict__ mins, const float* __restrict__ scales,
+                                                      int8_t* __restrict__ out, uint32_t ld8, int* __restrict__ sums,
+                                                      int* __restrict__ sums2) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    for (uint64_t row = wave; row < n; row += nwaves) {
+        int s1 = 0, s2 = 0;
+        for (uint32_t d = lane; d < ld8; d += 64) {
+            int c = 0;
+            if (d < D) {
+                c = sq8_code(V[row * ld + d], mins[d], scales[d]) - 128;
+                s1 += c;
+                s2 += c * c;
+            }
+            out[row * ld8 + d] = (int8_t)c;
+        }
+        for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+        if (lane == 0) { sums[row] = s1; sums2[row] = s2; }
+    }
+}
+
+// query side of SQ8 pass 1: one block per query.  Image layout = k_scan_h16's ([slab of 128][q][8 slots ^ ((q>>1)&7)][16 B]),
+// qconst = the per-query integer of the score (IP: 128 * sum q' + 16384 * D; L2: sum q'^2), thresholds open.
+__global__ void __launch_bounds__(256) k_sq8_prep_queries(const float* __restrict__ Q, uint32_t D, uint32_t qpad, uint32_t nslab,
+                                                          const float* __restrict__ mins, const float* __restrict__ scales,
+                                                          int8_t* __restrict__ img, float* __restrict__ qconst, float* __restrict__ thr,
+                                                          uint32_t* __restrict__ count, uint32_t* __restrict__ overflow, int ip) {
+    __shared__ int red[2][4];
+    const uint32_t q = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int s1 = 0, s2 = 0;
+    const uint32_t total = nslab * 128;
+    for (uint32_t i = tid; i < total; i += 256) {
+        int c = 0;
+        if (i < D) {
+            c = sq8_code(Q[(size_t)q * D + i], mins[i], scales[i]) - 128;
+            s1 += c;
+            s2 += c * c;
+        }
+        const uint32_t s = i / 128, k = i % 128, l = k >> 4, e = k & 15, p = l ^ ((q >> 1) & 7);
+        img[(((size_t)s * qpad + q) * 8 + p) * 16 + e] = (int8_t)c;
+    }
+    for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+    if (lane == 0) { red[0][wave] = s1; red[1][wave] = s2; }
+    __syncthreads();
+    if (tid == 0) {
+        s1 = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+        s2 = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+        const int c = ip ? 128 * s1 + 16384 * (int)D : s2;
+        qconst[q] = __builtin_bit_cast(float, c);
+        thr[q] = ip ? -LY_INF : LY_INF;
+        count[q] = 0u;
+        overflow[q] = 0u;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------

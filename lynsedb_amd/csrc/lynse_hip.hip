@@ -187,6 +187,13 @@ struct lynse_hip_flat {
     uint64_t mask_words = 0;
     uint64_t* d_subset = nullptr;
     uint64_t subset_cap = 0;
+    // SQ8 two-pass mode (FLAT-*-SQ8): signed codes (code - 128), per-dimension min / scale, per-row sums; built lazily
+    int8_t* sq8 = nullptr;
+    uint32_t ld8 = 0;
+    uint64_t n_sq8 = 0, sq8_cap = 0;
+    float *sq8_mins = nullptr, *sq8_scales = nullptr;
+    int *sq8_sum = nullptr, *sq8_sum2 = nullptr;
+    uint32_t* sq8_mm = nullptr;  // 2 x dim ordered-int min / max
     // gathered ("few matches") filtered path: compact copy of the listed shadow rows, their norms and 32-bit ids
     _Float16* g_rows16 = nullptr;
     float *g_vn2 = nullptr, *g_vrinv = nullptr;
@@ -218,6 +225,7 @@ extern "C" int lynse_hip_flat_create(uint32_t dim, int device, lynse_hip_flat** 
     h->dim = dim;
     h->ld = round_up(dim, 4);
     h->ld16 = round_up(dim, 8);
+    h->ld8 = round_up(dim, 16);
     h->words = (dim + 63) / 64;
     h->device = device;
     hipDeviceProp_t prop;
@@ -247,7 +255,8 @@ extern "C" int lynse_hip_flat_destroy(lynse_hip_flat* h) {
     h->ws.release();
     for (auto e : h->ev_pool) (void)hipEventDestroy(e);
     for (void* p : {(void*)h->rows, (void*)h->rows16, (void*)h->packed, (void*)h->vn2, (void*)h->vrinv, (void*)h->d_stats,
-                    (void*)h->d_mask, (void*)h->d_subset, (void*)h->g_rows16, (void*)h->g_vn2, (void*)h->g_vrinv, (void*)h->g_ids32})
+                    (void*)h->d_mask, (void*)h->d_subset, (void*)h->g_rows16, (void*)h->g_vn2, (void*)h->g_vrinv, (void*)h->g_ids32,
+                    (void*)h->sq8, (void*)h->sq8_mins, (void*)h->sq8_scales, (void*)h->sq8_sum, (void*)h->sq8_sum2, (void*)h->sq8_mm})
         if (p) (void)hipFree(p);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -1093,6 +1102,166 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
     hipLaunchKernelGGL(k_final<SEL_NT>, dim3(nq), dim3(SEL_NT), (size_t)w.cap * 8, st, fa);
     LY_HIP(hipGetLastError());
     (void)asc;
+    return LYNSE_OK;
+}
+
+// ------------------------------------------------------------------------------ SQ8 two-pass ----
+// ensure_sq8 (flat_mmap.rs:375-386) + SQ8Data::from_f32_parallel (:5685-5737): (re)built over ALL rows whenever rows were
+// appended since the last build (min / max are collection-wide).
+static int ensure_sq8_locked(lynse_hip_flat* h) {
+    if (h->n_sq8 == h->n && h->sq8) return LYNSE_OK;
+    if (h->sq8_cap < h->n) {
+        for (void* p : {(void*)h->sq8, (void*)h->sq8_sum, (void*)h->sq8_sum2})
+            if (p) (void)hipFree(p);
+        h->sq8 = nullptr; h->sq8_sum = nullptr; h->sq8_sum2 = nullptr;
+        const uint64_t cap = std::max<uint64_t>(h->capacity, h->n);
+        LY_HIP(hipMalloc(&h->sq8, (size_t)cap * h->ld8 + 256));
+        LY_HIP(hipMalloc(&h->sq8_sum, ((size_t)cap + 256) * 4));
+        LY_HIP(hipMalloc(&h->sq8_sum2, ((size_t)cap + 256) * 4));
+        LY_HIP(hipMemsetAsync(h->sq8_sum, 0, ((size_t)cap + 256) * 4, h->stream));
+        LY_HIP(hipMemsetAsync(h->sq8_sum2, 0, ((size_t)cap + 256) * 4, h->stream));
+        h->sq8_cap = cap;
+    }
+    if (!h->sq8_mins) {
+        LY_HIP(hipMalloc(&h->sq8_mins, (size_t)h->dim * 4));
+        LY_HIP(hipMalloc(&h->sq8_scales, (size_t)h->dim * 4));
+        LY_HIP(hipMalloc(&h->sq8_mm, (size_t)h->dim * 8));
+    }
+    std::vector<uint32_t> init((size_t)h->dim * 2);
+    for (uint32_t d = 0; d < h->dim; ++d) { init[d] = f32_to_ord(INFINITY); init[h->dim + d] = f32_to_ord(-INFINITY); }
+    LY_HIP(hipMemcpyAsync(h->sq8_mm, init.data(), init.size() * 4, hipMemcpyHostToDevice, h->stream));
+    const uint32_t gx = (h->dim + 255) / 256;
+    const uint32_t gy = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(h->n / 256, 1), (uint64_t)h->num_cu * 8);
+    hipLaunchKernelGGL(k_sq8_minmax, dim3(gx, gy), dim3(256), 0, h->stream, h->rows, h->ld, h->dim, h->n, h->sq8_mm, h->sq8_mm + h->dim);
+    hipLaunchKernelGGL(k_sq8_scales, dim3(gx), dim3(256), 0, h->stream, h->sq8_mm, h->sq8_mm + h->dim, h->dim, h->sq8_mins, h->sq8_scales);
+    hipLaunchKernelGGL(k_sq8_quantize, dim3((uint32_t)std::min<uint64_t>((h->n + 3) / 4, (uint64_t)h->num_cu * 16)), dim3(256), 0, h->stream,
+                       h->rows, h->ld, h->dim, h->n, h->sq8_mins, h->sq8_scales, h->sq8, h->ld8, h->sq8_sum, h->sq8_sum2);
+    LY_HIP(hipGetLastError());
+    LY_HIP(hipStreamSynchronize(h->stream));  // `init` is a temporary
+    h->n_sq8 = h->n;
+    return LYNSE_OK;
+}
+
+extern "C" int lynse_hip_flat_sq8_params(lynse_hip_flat* h, float* mins, float* scales) {
+    if (!h) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "handle is NULL");
+    std::lock_guard<std::mutex> lk(h->mu);
+    LY_TRY(use_device(h));
+    if (h->packed_only || h->n == 0) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "no f32 rows");
+    LY_TRY(finalize_locked(h));
+    LY_TRY(ensure_sq8_locked(h));
+    if (mins) LY_HIP(hipMemcpy(mins, h->sq8_mins, (size_t)h->dim * 4, hipMemcpyDeviceToHost));
+    if (scales) LY_HIP(hipMemcpy(scales, h->sq8_scales, (size_t)h->dim * 4, hipMemcpyDeviceToHost));
+    return LYNSE_OK;
+}
+
+// sq8_two_pass_search (flat_mmap.rs:5868-5926) for one chunk of <= 256 queries (queries in ws.Qf): pass 1 = exact integer
+// scores of the u8 codes on the i8 MFMA, exact top-n_cand in (score, row) order with the staged strict thresholds of the
+// packed-binary path; pass 2 = exact f32 rescoring of the n_cand rows, (distance, row) order, top k.
+static int run_chunk_sq8(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k, uint32_t n_cand, int metric, int level, hipStream_t st) {
+    Workspace& w = h->ws;
+    const bool ip = metric == M_IP;
+    const int m1 = ip ? M_IP : M_L2;  // cosine ranks the codes by squared L2 too (:5887-5890)
+    const uint32_t nslab = (h->dim + 127) / 128, qpad = SCAN_BQ_LARGE;
+    static bool attr = false;
+    if (!attr) {
+        LY_TRY(set_max_lds(k_select<SEL_NT>, 16384 * 8));
+        LY_TRY(set_max_lds(k_final<SEL_NT>, 16384 * 8));
+        attr = true;
+    }
+    LY_HIP(hipMemsetAsync(w.Q16, 0, (size_t)nslab * qpad * 128, st));
+    hipLaunchKernelGGL(k_sq8_prep_queries, dim3(nq), dim3(256), 0, st, w.Qf, h->dim, qpad, nslab, h->sq8_mins, h->sq8_scales,
+                       reinterpret_cast<int8_t*>(w.Q16), w.qn2, w.thr, w.count, w.overflow, ip ? 1 : 0);
+    LY_HIP(hipGetLastError());
+    const std::vector<Stage> plan = make_plan(h, n_cand, level >= 2 ? 2 : 1, 0);  // contiguous stages: rows in ascending order
+    for (size_t si = 0; si < plan.size(); ++si) {
+        const Stage s = plan[si];
+        ScanArgs a{};
+        a.V16 = reinterpret_cast<const _Float16*>(h->sq8); a.ld16 = h->ld8; a.D = h->dim; a.row0 = s.r0; a.row1 = s.r1;
+        a.Q16 = w.Q16; a.qpad = qpad; a.nq = nq; a.nslab = nslab; a.ntiles = (s.r1 - s.r0 + 255) / 256;
+        a.qinv = w.qinv; a.qn2 = w.qn2; a.qrinv = w.qrinv; a.thr = w.thr;
+        a.vn2 = reinterpret_cast<const float*>(ip ? h->sq8_sum : h->sq8_sum2); a.vrinv = a.vn2;
+        a.sv = 1.0f; a.cand = w.cand; a.count = w.count; a.cap = w.cap; a.emit_all = si == 0 ? 1 : 0;
+        const uint32_t grid = std::min<uint32_t>(a.ntiles, (uint32_t)h->num_cu);
+        constexpr size_t lds = (size_t)(2 * 256 + 2 * 256) * 128 + 3 * 1024;
+        static bool a2[2] = {false, false};
+        if (ip) {
+            auto kern = k_scan_h16<4, 2, 2, 4, M_IP, 2, 2, 2, false, true, 0, false, true>;
+            if (!a2[0]) { LY_TRY(set_max_lds(kern, lds)); a2[0] = true; }
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, a);
+        } else {
+            auto kern = k_scan_h16<4, 2, 2, 4, M_L2, 2, 2, 2, false, true, 0, false, true>;
+            if (!a2[1]) { LY_TRY(set_max_lds(kern, lds)); a2[1] = true; }
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, a);
+        }
+        LY_HIP(hipGetLastError());
+        SelectArgs sa{};
+        sa.cand = w.cand; sa.count = w.count; sa.overflow = w.overflow; sa.thr = w.thr; sa.marg2 = w.marg2;
+        sa.k = n_cand; sa.cap = w.cap; sa.keep_max = w.cap / 2; sa.metric = m1; sa.ip_form = LYNSE_IPFORM_SINGLE;
+        sa.exact = 1; sa.emit_all_n = si == 0 ? (int)(s.r1 - s.r0) : -1;
+        sa.Qf = w.Qf; sa.V = h->rows; sa.ld = h->ld; sa.D = h->dim;
+        hipLaunchKernelGGL(k_select<SEL_NT>, dim3(nq), dim3(SEL_NT), (size_t)w.cap * 8, st, sa);
+        LY_HIP(hipGetLastError());
+    }
+    FinalArgs fa{};
+    fa.cand = w.cand; fa.count = w.count; fa.k = k; fa.out_k = out_k; fa.cap = w.cap; fa.metric = metric;
+    fa.ip_form = LYNSE_IPFORM_SINGLE;  // pass 2 uses simd::inner_product_f32 & co (:5899-5906)
+    fa.exact = 0; fa.Qf = w.Qf; fa.V = h->rows; fa.ld = h->ld; fa.D = h->dim;
+    fa.row_stride = h->row_stride; fa.row_offset = h->row_offset;
+    fa.out_rows = w.out_rows; fa.out_dists = w.out_dists; fa.out_counts = w.out_counts; fa.pool_total = nullptr;
+    const char* dbg = getenv("LYNSE_HIP_SQ8_PASS1");  // tests: return the pass-1 ranking (integer scores) instead of rescoring
+    if (dbg && atoi(dbg)) {
+        fa.metric = m1;
+    } else {
+        hipLaunchKernelGGL(k_rescore_pool<256>, dim3(nq, nq >= 64 ? 4 : 32), dim3(256), 0, st, fa);
+        LY_HIP(hipGetLastError());
+    }
+    fa.exact = 1;
+    hipLaunchKernelGGL(k_final<SEL_NT>, dim3(nq), dim3(SEL_NT), (size_t)w.cap * 8, st, fa);
+    LY_HIP(hipGetLastError());
+    return LYNSE_OK;
+}
+
+extern "C" int lynse_hip_flat_search_sq8_f32(lynse_hip_flat* h, const float* queries, uint64_t nq, uint32_t k, int metric,
+                                             uint64_t* out_rows, float* out_dists, uint32_t* out_counts) {
+    if (!h) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "handle is NULL");
+    if (!metric_valid(metric)) return set_error(LYNSE_ERR_UNKNOWN_METRIC, "Unknown metric id");
+    // use_sq8 only changes ip / l2 / cosine (flat_mmap.rs:891-896); every other metric takes the ordinary path
+    if (metric > M_COS) return lynse_hip_flat_search_f32(h, queries, nq, k, metric, out_rows, out_dists, out_counts);
+    if (nq == 0) return LYNSE_OK;
+    if (!queries || !out_counts || (k && (!out_rows || !out_dists))) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "NULL argument");
+    std::lock_guard<std::mutex> lk(h->mu);
+    LY_TRY(use_device(h));
+    if (h->packed_only) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "store holds packed rows; float metrics unavailable");
+    if (h->dtype != LYNSE_DTYPE_F32) return set_error(LYNSE_ERR_UNSUPPORTED, "SQ8 mode on an F16 shard is not supported");
+    if (h->n == 0 || k == 0) { memset(out_counts, 0, nq * 4); return LYNSE_OK; }
+    const uint32_t kk = (uint32_t)std::min<uint64_t>(k, h->n);
+    uint64_t n_cand = metric == M_COS ? std::max<uint64_t>((uint64_t)kk * 100, 500) : std::max<uint64_t>((uint64_t)kk * 20, 200);  // :5883-5893
+    n_cand = std::min<uint64_t>(n_cand, h->n);
+    LY_TRY(finalize_locked(h));
+    LY_TRY(ensure_workspace(h, k));
+    if (h->n > h->cap && n_cand > h->cap / 4)
+        return set_error(LYNSE_ERR_UNSUPPORTED, "SQ8 candidate count (k * 20, cosine k * 100) exceeds cap/4");
+    LY_TRY(ensure_sq8_locked(h));
+    Workspace& w = h->ws;
+    hipStream_t st = h->stream;
+    for (uint64_t q0 = 0; q0 < nq; q0 += QCHUNK) {
+        const uint32_t nqc = (uint32_t)std::min<uint64_t>(QCHUNK, nq - q0);
+        LY_HIP(hipMemcpyAsync(w.Qf, queries + q0 * h->dim, (size_t)nqc * h->dim * 4, hipMemcpyHostToDevice, st));
+        for (int level = 1; level < 3; ++level) {
+            LY_TRY(run_chunk_sq8(h, nqc, kk, k, (uint32_t)n_cand, metric, level, st));
+            std::vector<uint32_t> ovf(nqc);
+            LY_HIP(hipMemcpyAsync(ovf.data(), w.overflow, nqc * 4, hipMemcpyDeviceToHost, st));
+            LY_HIP(hipStreamSynchronize(st));
+            uint32_t nov = 0;
+            for (uint32_t v : ovf) nov += v ? 1 : 0;
+            if (nov == 0) break;
+            if (level == 2) return set_error(LYNSE_ERR_INTERNAL, "candidate overflow on the exhaustive plan");
+        }
+        LY_HIP(hipMemcpyAsync(out_rows + q0 * k, w.out_rows, (size_t)nqc * k * 8, hipMemcpyDeviceToHost, st));
+        LY_HIP(hipMemcpyAsync(out_dists + q0 * k, w.out_dists, (size_t)nqc * k * 4, hipMemcpyDeviceToHost, st));
+        LY_HIP(hipMemcpyAsync(out_counts + q0, w.out_counts, nqc * 4, hipMemcpyDeviceToHost, st));
+        LY_HIP(hipStreamSynchronize(st));
+    }
     return LYNSE_OK;
 }
 

@@ -952,6 +952,90 @@ size_t lo_canonical_topk_f16(const float *query, const float *cands_decoded, siz
     return r;
 }
 
+/* ------------------------------------------------------------- SQ8 two-pass FLAT (FLAT-*-SQ8) */
+
+/* SQ8Data::from_f32_parallel (flat_mmap.rs:5685-5737): per-dimension min / scale = 255/(max-min) (0 when the range is
+ * <= 1e-30), codes = clamp(round((v - min) * scale), 0, 255) with f32::round (half away from zero). */
+void lo_sq8_fit(const float *data, size_t n, size_t dim, float *mins, float *scales) {
+    float *maxs = (float *)malloc(dim * sizeof(float));
+    for (size_t d = 0; d < dim; ++d) { mins[d] = INFINITY; maxs[d] = -INFINITY; }
+    for (size_t v = 0; v < n; ++v)
+        for (size_t d = 0; d < dim; ++d) {
+            float val = data[v * dim + d];
+            if (val < mins[d]) mins[d] = val;
+            if (val > maxs[d]) maxs[d] = val;
+        }
+    for (size_t d = 0; d < dim; ++d) {
+        float range = maxs[d] - mins[d];
+        scales[d] = range > 1e-30f ? 255.0f / range : 0.0f;
+    }
+    free(maxs);
+}
+
+static inline uint8_t sq8_code(float val, float mn, float sc) {
+    float t = val - mn;
+    float q = roundf(t * sc);
+    if (!(q == q)) return 0;   /* NaN: clamp keeps NaN, `as u8` saturates it to 0 */
+    if (q < 0.0f) q = 0.0f;
+    if (q > 255.0f) q = 255.0f;
+    return (uint8_t)q;
+}
+
+void lo_sq8_quantize(const float *data, size_t n, size_t dim, const float *mins, const float *scales,
+                     uint8_t *out) { /* also SQ8Data::quantize_query (:5741-5750) with n = 1 */
+    for (size_t v = 0; v < n; ++v)
+        for (size_t d = 0; d < dim; ++d) out[v * dim + d] = sq8_code(data[v * dim + d], mins[d], scales[d]);
+}
+
+typedef struct { float s; uint32_t row; } sq8c_t;
+static int g_sq8_asc;
+static int cmp_sq8(const void *a, const void *b) {
+    const sq8c_t *x = (const sq8c_t *)a, *y = (const sq8c_t *)b;
+    if (x->s != y->s) return g_sq8_asc ? (x->s < y->s ? -1 : 1) : (x->s > y->s ? -1 : 1);
+    return x->row < y->row ? -1 : x->row > y->row;
+}
+
+/* sq8_two_pass_search (flat_mmap.rs:5868-5926): pass 1 = integer scores over the u8 codes (u32 dot for IP, u32 squared
+ * L2 for L2 AND cosine), converted to f32 like `dist_fn(..) as f32`, top n_cand = max(k*20, 200) (cosine: max(k*100, 500)),
+ * capped at n; pass 2 = exact single-row-kernel distances of the candidates, sorted, truncated to k.
+ * The reference cuts ties at the n_cand boundary (and orders equal exact distances) by heap / unstable-sort accident;
+ * this is the CANONICAL variant: (score, row ascending) at the cut, (distance, row ascending) at the end. */
+size_t lo_sq8_search_canonical(const float *query, const float *cands, const uint8_t *codes, const float *mins,
+                               const float *scales, size_t dim, size_t n, size_t k, int metric,
+                               uint32_t *out_idx, float *out_dist) {
+    if (n == 0 || k == 0) return 0;
+    if (k > n) k = n; /* FlatMmap::search clamps k first (flat_mmap.rs:836) */
+    uint8_t *qu = (uint8_t *)malloc(dim);
+    lo_sq8_quantize(query, 1, dim, mins, scales, qu);
+    int ip = metric == LO_IP;
+    size_t n_cand = ip || metric == LO_L2 ? k * 20 : k * 100;
+    size_t floor_c = (ip || metric == LO_L2) ? 200 : 500;
+    if (n_cand < floor_c) n_cand = floor_c;
+    if (n_cand > n) n_cand = n;
+    sq8c_t *sc = (sq8c_t *)malloc(n * sizeof(sq8c_t));
+    for (size_t i = 0; i < n; ++i) {
+        const uint8_t *r = codes + i * dim;
+        uint32_t acc = 0;
+        if (ip) for (size_t d = 0; d < dim; ++d) acc += (uint32_t)qu[d] * (uint32_t)r[d];
+        else for (size_t d = 0; d < dim; ++d) { int32_t df = (int32_t)qu[d] - (int32_t)r[d]; acc += (uint32_t)(df * df); }
+        sc[i].s = (float)acc;
+        sc[i].row = (uint32_t)i;
+    }
+    g_sq8_asc = !ip;
+    qsort(sc, n, sizeof(sq8c_t), cmp_sq8);
+    cpair_t *p = (cpair_t *)malloc(n_cand * sizeof(cpair_t));
+    for (size_t i = 0; i < n_cand; ++i) {
+        p[i].id = sc[i].row;
+        p[i].d = lo_compute_distance(query, cands + (size_t)sc[i].row * dim, dim, metric);
+    }
+    g_cmp_asc = lo_metric_is_ascending(metric);
+    qsort(p, n_cand, sizeof(cpair_t), cmp_canonical);
+    if (k > n_cand) k = n_cand;
+    for (size_t i = 0; i < k; ++i) { out_idx[i] = (uint32_t)p[i].id; out_dist[i] = p[i].d; }
+    free(p); free(sc); free(qu);
+    return k;
+}
+
 /* ------------------------------------------------------------- filtered search */
 
 /* FlatMmap::search_filtered (flat_mmap.rs:491-815), f32 rows / packed-binary rows.

@@ -108,6 +108,12 @@ void lo_all_distances(const float *query, const float *cands, size_t dim, size_t
 
 /* VectorStore::merge_results (vector_store.rs:953-970) / engine merge
  * (engine.rs:3402-3414): sort (dist by metric order, id asc), truncate. */
+/* SQ8 two-pass FLAT (flat_mmap.rs:5676-5926): fit / quantize / canonical two-pass search */
+void lo_sq8_fit(const float *data, size_t n, size_t dim, float *mins, float *scales);
+void lo_sq8_quantize(const float *data, size_t n, size_t dim, const float *mins, const float *scales, uint8_t *out);
+size_t lo_sq8_search_canonical(const float *query, const float *cands, const uint8_t *codes, const float *mins,
+                               const float *scales, size_t dim, size_t n, size_t k, int metric,
+                               uint32_t *out_idx, float *out_dist);
 /* f16 storage (VectorDtype::F16): sequential-sum kernels of simd.rs:805-846 on decoded rows */
 float lo_distance_f16(const float *query, const float *cand, size_t dim, int metric);
 void lo_round_f16(const float *in, size_t n, float *out);

@@ -71,6 +71,10 @@ class Oracle:
             s(n, _sz, _u64p, _u64p, _sz, _sz, _sz, C.c_int, C.c_int, _u32p, _f32p)
         s("lo_canonical_topk", _sz, _f32p, _f32p, _sz, _sz, _sz, C.c_int, C.c_int, _u32p, _f32p)
         s("lo_canonical_topk_packed", _sz, _u64p, _u64p, _sz, _sz, _sz, C.c_int, _u32p, _f32p)
+        _u8p = C.POINTER(C.c_uint8)
+        s("lo_sq8_fit", None, _f32p, _sz, _sz, _f32p, _f32p)
+        s("lo_sq8_quantize", None, _f32p, _sz, _sz, _f32p, _f32p, _u8p)
+        s("lo_sq8_search_canonical", _sz, _f32p, _f32p, _u8p, _f32p, _f32p, _sz, _sz, _sz, C.c_int, _u32p, _f32p)
         s("lo_distance_f16", C.c_float, _f32p, _f32p, _sz, C.c_int)
         s("lo_round_f16", None, _f32p, _sz, _f32p)
         s("lo_canonical_topk_f16", _sz, _f32p, _f32p, _sz, _sz, _sz, C.c_int, _u32p, _f32p)
@@ -209,6 +213,26 @@ class Oracle:
         r, pr = self._u64(rows_words)
         n, w = r.shape
         return self._topk_call(self.lib.lo_canonical_topk_packed, k, pq, pr, w, n, k, metric)
+
+    def sq8_fit(self, data):
+        """SQ8Data::from_f32_parallel -> (mins f32[dim], scales f32[dim], codes u8[n, dim])."""
+        d, pd = self._f(data)
+        n, dim = d.shape
+        mins, scales = np.zeros(dim, np.float32), np.zeros(dim, np.float32)
+        self.lib.lo_sq8_fit(pd, n, dim, mins.ctypes.data_as(_f32p), scales.ctypes.data_as(_f32p))
+        codes = np.zeros((n, dim), np.uint8)
+        self.lib.lo_sq8_quantize(pd, n, dim, mins.ctypes.data_as(_f32p), scales.ctypes.data_as(_f32p),
+                                 codes.ctypes.data_as(C.POINTER(C.c_uint8)))
+        return mins, scales, codes
+
+    def sq8_search(self, query, data, mins, scales, codes, k, metric):
+        """sq8_two_pass_search, canonical tie handling (see lo_sq8_search_canonical)."""
+        q, pq = self._f(query)
+        d, pd = self._f(data)
+        n, dim = d.shape
+        c = np.ascontiguousarray(codes, np.uint8)
+        return self._topk_call(self.lib.lo_sq8_search_canonical, k, pq, pd, c.ctypes.data_as(C.POINTER(C.c_uint8)),
+                               mins.ctypes.data_as(_f32p), scales.ctypes.data_as(_f32p), dim, n, k, metric)
 
     def round_f16(self, a):
         """f32 -> f16 -> f32 (RNE): what VectorDtype::F16 storage keeps of a row."""

@@ -181,6 +181,33 @@ def small():
     return {"config": "FLAT-IP 4000000x768 small batches (k=10)", **out}
 
 
+def sq8():
+    """FLAT-IP-SQ8 / FLAT-L2-SQ8 (two-pass mode) on 10M x 768 uniform rows, 256 queries, k=10: time and recall@10 against the
+    exact search of the same index (the mode is approximate by design)."""
+    n, dim, nq = 10_000_000, 768, 256
+    idx = L.FlatIndex(None, dim, 0)
+    idx.reserve(n)
+    g = torch.Generator(device=dev)
+    g.manual_seed(3)
+    for b in range(0, n, 500_000):
+        idx.write_device(torch.rand((500_000, dim), generator=g, device=dev))
+    idx.finalize()
+    qs = np.ascontiguousarray(idx.read_rows(12345, nq) + 0.03 * np.random.default_rng(1).standard_normal((nq, dim)).astype(np.float32))
+    out = {}
+    t0 = time.perf_counter()
+    idx.sq8_params()
+    torch.cuda.synchronize()
+    out["build_s"] = round(time.perf_counter() - t0, 3)
+    for name in ("ip", "l2"):
+        med, best = timeit(lambda: idx.search_sq8_batch_arrays(qs, 10, name), 2, 6)
+        ex, _ = timeit(lambda: idx.search_batch_arrays(qs, 10, name), 2, 6)
+        r1 = idx.search_sq8_batch_arrays(qs, 10, name)[0]
+        r2 = idx.search_batch_arrays(qs, 10, name)[0]
+        rec = np.mean([len(set(r1[i].tolist()) & set(r2[i].tolist())) / 10 for i in range(nq)])
+        out[name] = {"sq8_ms": round(med * 1e3, 3), "sq8_qps": round(nq / med, 1), "exact_ms": round(ex * 1e3, 3), "recall_at_10_vs_exact": round(float(rec), 4)}
+    return {"config": "FLAT-*-SQ8 two-pass, 10000000x768, 256 queries, k=10 (host API)", **out}
+
+
 def filtered():
     """Filtered FLAT-IP (docs/comparisons/vector_database_benchmarks.md:64-66, :99-101 quote 0.178 ms at 100k and 2.16 ms at 1M
     on the reference's CPU path): single query, k=10, subsets of 10 % and 50 % of the rows, through the host API

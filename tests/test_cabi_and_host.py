@@ -166,7 +166,7 @@ def test_hot_kernels_have_no_scratch_spills():
         defaults = ("k_scan_h16ILi2ELi4ELi4ELi2ELi0ELi3ELi2E",   # IP: <2,4,4,2>, 3+2-stage rings
                     "k_scan_h16ILi4ELi2ELi2ELi4ELi1ELi2ELi2E", "k_scan_h16ILi4ELi2ELi2ELi4ELi2ELi2ELi2E",  # L2 / cosine
                     "k_scan_h16ILi1ELi4ELi1ELi1E")               # <= 32 queries and the IVF work-list kernel
-        if any(d in name for d in defaults) and name.endswith("Lb0ELi0ELb0EEEvNS_8ScanArgsE"):
+        if any(d in name for d in defaults) and name.endswith("Lb0ELi0ELb0ELb0EEEvNS_8ScanArgsE"):
             seen += 1
             assert int(scratch) == 0, (name, scratch)
         if "k_scan_binary_rows" in name and "ILi0ELi16ELb0" in name:

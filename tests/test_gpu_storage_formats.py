@@ -137,3 +137,41 @@ def test_open_f16_collection(L, oracle, tmp_path):
     assert np.array_equal(ids, e_ids) and np.array_equal(d.view(np.uint32), e_d.view(np.uint32))
     with pytest.raises(ValueError):
         L.FlatIndex(None, 4, 0, dtype="int8")
+
+
+# ------------------------------------------------------------------ FLAT-*-SQ8 two-pass mode
+@pytest.mark.parametrize("metric,name", [(O.IP, "ip"), (O.L2, "l2"), (O.COS, "cosine")])
+@pytest.mark.parametrize("n,dim,nq,k,kind", [(3000, 32, 6, 10, "normal"), (40000, 96, 33, 5, "normal"), (70000, 40, 4, 10, "positive"),
+                                             (150, 16, 3, 10, "normal"), (25000, 130, 5, 3, "const")])
+def test_sq8_two_pass_parity(L, oracle, metric, name, n, dim, nq, k, kind):
+    rng = np.random.default_rng(n + dim + metric)
+    if kind == "positive":
+        data = rng.random((n, dim)).astype(f32)
+    else:
+        data = rng.standard_normal((n, dim)).astype(f32)
+    if kind == "const":
+        data[:, 3] = 1.5      # constant dimension: scale 0, code 0
+        data[:, 7] *= 1e-20   # range below 1e-30
+    queries = (data[rng.integers(0, n, nq)] + 0.05 * rng.standard_normal((nq, dim))).astype(f32)
+    queries[0] *= 3  # a query outside the rows' range: codes clamp to 0 / 255
+    idx = L.FlatIndex(None, dim, 0)
+    idx.write(data)
+    mins, scales, codes = oracle.sq8_fit(data)
+    g_mins, g_scales = idx.sq8_params()
+    assert np.array_equal(g_mins.view(np.uint32), mins.view(np.uint32)) and np.array_equal(g_scales.view(np.uint32), scales.view(np.uint32))
+    rows, dists, counts = idx.search_sq8_batch_arrays(queries, k, name)
+    for qi in range(nq):
+        e_ids, e_d = oracle.sq8_search(queries[qi], data, mins, scales, codes, k, metric)
+        c = int(counts[qi])
+        assert c == len(e_ids)
+        assert np.array_equal(rows[qi, :c].astype(np.uint32), e_ids), (qi, rows[qi, :c], e_ids)
+        assert np.array_equal(dists[qi, :c].view(np.uint32), e_d.view(np.uint32))
+    # appending rows changes the collection-wide min / max: the codes are rebuilt (ensure_sq8 after a write)
+    extra = (rng.standard_normal((500, dim)) * 4).astype(f32)
+    idx.write(extra)
+    both = np.concatenate([data, extra])
+    mins2, scales2, codes2 = oracle.sq8_fit(both)
+    rows, dists, counts = idx.search_sq8_batch_arrays(queries[:2], k, name)
+    for qi in range(2):
+        e_ids, e_d = oracle.sq8_search(queries[qi], both, mins2, scales2, codes2, k, metric)
+        assert np.array_equal(rows[qi, :len(e_ids)].astype(np.uint32), e_ids) and np.array_equal(dists[qi, :len(e_ids)].view(np.uint32), e_d.view(np.uint32))
