@@ -484,3 +484,26 @@ def test_f16_storage_kernels(oracle, oracle_portable):  # simd.rs:805-846, dtype
     expect = f32(1) - f32(dot / f32(np.sqrt(nq) * np.sqrt(nc)))
     assert oracle.distance_f16(q, c, O.COS) == float(expect)
     assert oracle.distance_f16(q, np.zeros(37, f32), O.COS) == 1.0 and oracle.distance_f16(np.zeros(37, f32), c, O.COS) == 1.0
+
+
+def test_sq8_fit_and_codes(oracle, oracle_portable):  # flat_mmap.rs:5685-5750
+    f32 = np.float32
+    rng = np.random.default_rng(4)
+    data = rng.standard_normal((500, 9)).astype(f32)
+    data[:, 2] = 0.25          # constant dimension -> scale 0 -> code 0
+    mins, scales, codes = oracle.sq8_fit(data)
+    assert np.array_equal(mins, data.min(0)) and scales[2] == 0.0 and np.all(codes[:, 2] == 0)
+    rngs = data.max(0) - data.min(0)
+    exp_scales = np.where(rngs > 1e-30, f32(255.0) / rngs, f32(0)).astype(f32)
+    assert np.array_equal(scales, exp_scales)
+    t = ((data - mins) * scales).astype(f32)
+    exp = np.clip(np.where(t >= 0, np.floor(t + f32(0.5)), np.ceil(t - f32(0.5))), 0, 255).astype(np.uint8)  # round half away from zero
+    assert np.array_equal(codes, exp)
+    assert codes.min() == 0 and codes.max() == 255
+    m2, s2, c2 = oracle_portable.sq8_fit(data)
+    assert np.array_equal(c2, codes) and np.array_equal(s2, scales)
+    # two-pass search: with n <= n_cand every row is a candidate -> the exact answer
+    q = data[3] + f32(0.01)
+    ids, d = oracle.sq8_search(q, data[:150], *oracle.sq8_fit(data[:150]), 5, O.L2)
+    e_ids, e_d = oracle.canonical_topk(q, data[:150], 5, O.L2, O.IPFORM_SINGLE)
+    assert np.array_equal(ids, e_ids) and np.array_equal(d, e_d)
