@@ -494,7 +494,8 @@ def test_sq8_fit_and_codes(oracle, oracle_portable):  # flat_mmap.rs:5685-5750
     mins, scales, codes = oracle.sq8_fit(data)
     assert np.array_equal(mins, data.min(0)) and scales[2] == 0.0 and np.all(codes[:, 2] == 0)
     rngs = data.max(0) - data.min(0)
-    exp_scales = np.where(rngs > 1e-30, f32(255.0) / rngs, f32(0)).astype(f32)
+    with np.errstate(divide="ignore"):
+        exp_scales = np.where(rngs > 1e-30, f32(255.0) / rngs, f32(0)).astype(f32)
     assert np.array_equal(scales, exp_scales)
     t = ((data - mins) * scales).astype(f32)
     exp = np.clip(np.where(t >= 0, np.floor(t + f32(0.5)), np.ceil(t - f32(0.5))), 0, 255).astype(np.uint8)  # round half away from zero
