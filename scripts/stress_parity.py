@@ -1,0 +1,76 @@
+#!/usr/bin/env python3
+"""Randomised parity sweep (GPU): FLAT exact / filtered / SQ8 / f16-dtype / binary searches with random shapes against the
+oracle.  Usage: python scripts/stress_parity.py [seconds] [seed] -> prints the number of cases and any mismatch."""
+import sys, time
+from pathlib import Path
+import numpy as np
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+import lynsedb_amd as L  # noqa: E402
+import oracle as O  # noqa: E402
+
+orc = O.get()
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+NAME = {O.IP: "ip", O.L2: "l2", O.COS: "cosine", O.HAMMING: "hamming", O.JACCARD: "jaccard", O.DICE: "dice"}
+t0, cases, bad = time.time(), 0, []
+while time.time() - t0 < budget:
+    n = int(rng.choice([1, 7, 300, 4097, 20000, 70001, 200000]))
+    dim = int(rng.choice([1, 3, 8, 17, 64, 100, 128, 200, 384]))
+    nq = int(rng.choice([1, 2, 31, 33, 70, 256, 300]))
+    k = int(rng.choice([1, 5, 10, 64, 300]))
+    mode = str(rng.choice(["exact", "filtered", "sq8", "f16", "binary"]))
+    metric = int(rng.choice([O.IP, O.L2, O.COS])) if mode != "binary" else int(rng.choice([O.HAMMING, O.JACCARD, O.DICE]))
+    if n * dim > 40_000_000:
+        continue
+    kind = rng.integers(0, 3)
+    if mode == "binary":
+        data = (rng.random((n, dim)) < 0.4).astype(np.float32)
+    elif kind == 0:
+        data = rng.standard_normal((n, dim)).astype(np.float32)
+    elif kind == 1:
+        data = rng.integers(0, 3, (n, dim)).astype(np.float32)  # heavy exact ties
+    else:
+        data = (rng.random((n, dim)) * rng.choice([1e-3, 1.0, 300.0])).astype(np.float32)
+    queries = data[rng.integers(0, n, nq)] + (0.1 * rng.standard_normal((nq, dim)).astype(np.float32) if mode != "binary" else 0)
+    queries = np.ascontiguousarray(queries, np.float32)
+    try:
+        if mode == "f16":
+            idx = L.FlatIndex(None, dim, 0, dtype="f16")
+            idx.write(data)
+            dec = orc.round_f16(data)
+            rows, dists, counts = idx.search_batch_arrays(queries, k, NAME[metric])
+            check = lambda qi: orc.canonical_topk_f16(queries[qi], dec, k, metric)  # noqa: E731
+        else:
+            idx = L.FlatIndex(None, dim, 0)
+            idx.write(data)
+            if mode == "exact":
+                rows, dists, counts = idx.search_batch_arrays(queries, k, NAME[metric])
+                check = lambda qi: orc.canonical_topk(queries[qi], data, k, metric)  # noqa: E731
+            elif mode == "binary":
+                rows, dists, counts = idx.search_batch_arrays(queries, k, NAME[metric])
+                words = orc.pack_binary(data)
+                check = lambda qi: orc.canonical_topk_packed(orc.pack_binary(queries[qi].reshape(1, -1))[0], words, k, metric)  # noqa: E731
+            elif mode == "filtered":
+                m = int(rng.integers(1, n + 1))
+                subset = np.sort(rng.choice(n, m, replace=False)).astype(np.uint64)
+                rows, dists, counts = idx.search_filtered_batch_arrays(queries, k, NAME[metric], subset)
+                check = lambda qi: orc.canonical_topk_filtered(queries[qi], data, k, metric, subset)  # noqa: E731
+            else:
+                if (20 * k if metric != O.COS else 100 * k) > 4096 and n > 16384:
+                    continue
+                mins, scales, codes = orc.sq8_fit(data)
+                rows, dists, counts = idx.search_sq8_batch_arrays(queries, k, NAME[metric])
+                check = lambda qi: orc.sq8_search(queries[qi], data, mins, scales, codes, k, metric)  # noqa: E731
+        for qi in sorted(set([0, nq - 1, int(rng.integers(0, nq))])):
+            e_ids, e_d = check(qi)
+            c = int(counts[qi])
+            if c != len(e_ids) or not np.array_equal(rows[qi, :c].astype(np.uint32), e_ids) or not np.array_equal(dists[qi, :c].view(np.uint32), e_d.view(np.uint32)):
+                bad.append((mode, NAME[metric], n, dim, nq, k, int(kind), qi))
+                break
+    except Exception as e:  # noqa: BLE001
+        if "not supported" not in str(e):
+            bad.append((mode, NAME[metric], n, dim, nq, k, int(kind), "EXC " + str(e)[:80]))
+    cases += 1
+print("cases", cases, "mismatches", len(bad))
+for b in bad[:20]:
+    print("  ", b)
