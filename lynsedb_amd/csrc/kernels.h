@@ -1290,7 +1290,46 @@ __global__ void __launch_bounds__(WQ * WR * 64, (TQ * TR >= 16) ? 1 : ((WQ * WR 
                     if (METRIC == M_L2) c_extra[j] = c_ok[j] ? a.qn2[n] : 0.0f;
                     if (METRIC == M_COS) c_extra[j] = c_ok[j] ? a.qrinv[n] : 0.0f;
                 }
-                if (a.emit_all && !TILED) {
+                if (WR >= 4 && a.emit_all == 2 && !TILED) {  // (compiled out of the <4,2,2,4> tiling: it would spill there)
+                    // threshold-only sample stage: each lane keeps the best LM of its TR*16 rows for this query column
+                    // (4 WR keys per tile and query) and writes only those.  k_select turns the k-th best of them into a
+                    // valid threshold and keeps no candidate: the sample tiles are scanned again by the ordinary stages.
+                    // (Emitting all 256 x 256 scores of a tile cost as much as computing them.)  The host uses this mode only when the best
+                    // tile alone supplies k keys (k <= 4 WR), so even a shard sorted by score gets a threshold from its best tile.
+                    constexpr int LM = 2;  // 4 WR keys per tile and query: 16 for the <.,4,.,.> tilings, 8 for <4,2,2,4>
+                    float bs[LM];
+                    uint32_t bm[LM];
+#pragma unroll
+                    for (int t = 0; t < LM; ++t) { bs[t] = ASC ? LY_INF : -LY_INF; bm[t] = 0xffffffffu; }
+#pragma unroll
+                    for (int i = 0; i < TR; ++i) {
+                        const uint32_t mw = (FILT && a.mask) ? a.mask[(rbase + wr * (TR * 32) + i * 32) >> 5] : 0xffffffffu;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const uint32_t bit = (r & 3) + 8 * (r >> 2) + 4 * hi;
+                            uint32_t m = rbase + wr * (TR * 32) + i * 32 + bit;
+                            float sc = score(i, j, r, m, m < row_end);
+                            const bool ok = m < row_end && ((mw >> bit) & 1u);
+                            if (!ok) { sc = ASC ? LY_INF : -LY_INF; m = 0xffffffffu; }
+#pragma unroll
+                            for (int t = 0; t < LM; ++t) {  // insertion into the sorted best-LM list
+                                const bool better = bm[t] == 0xffffffffu ? m != 0xffffffffu : (m != 0xffffffffu && (ASC ? sc < bs[t] : sc > bs[t]));
+                                const float ts = bs[t];
+                                const uint32_t tm = bm[t];
+                                bs[t] = better ? sc : ts;
+                                bm[t] = better ? m : tm;
+                                sc = better ? ts : sc;
+                                m = better ? tm : m;
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int t = 0; t < LM; ++t) {
+                        const uint64_t key = bm[t] == 0xffffffffu ? KEY_SENTINEL : make_key(bs[t], (FILT && a.row_ids) ? a.row_ids[bm[t]] : bm[t], ASC);
+                        const uint32_t slot = (tile * (2 * WR) + 2 * wr + hi) * LM + t;
+                        if (c_ok[j] && slot < a.cap) a.cand[(size_t)n * a.cap + slot] = key;
+                    }
+                } else if (a.emit_all && !TILED) {
 #pragma unroll
                     for (int i = 0; i < TR; ++i) {
                         const uint32_t mw = (FILT && a.mask) ? a.mask[(rbase + wr * (TR * 32) + i * 32) >> 5] : 0xffffffffu;
@@ -1893,6 +1932,7 @@ struct SelectArgs {
     int emit_all_n;  // >=0: stage 0 wrote exactly this many keys per query
     int keep_ties;   // IVF: rows are not scanned in id order -> the cut must let ties of the k-th score through
     int drop_sentinels;  // filtered search: the emit-all stage wrote KEY_SENTINEL for rows outside the subset
+    int threshold_only;  // lane-max sample stage: derive the threshold, keep NO candidate (the rows are scanned again)
     const float* Qf;
     const float* V;
     uint32_t ld, D;
@@ -1942,12 +1982,11 @@ __global__ void __launch_bounds__(NT) k_select(SelectArgs a) {
         __syncthreads();
     }
     if (n < a.k || a.k == 0) {  // fewer than k candidates so far: keep all, the threshold stays open
-        if (compacted)
+        if (compacted && !a.threshold_only)
             for (uint32_t i = tid; i < n; i += NT) gkeys[i] = keys[i];
-        if (tid == 0) {
-            a.count[q] = n;
-            a.thr[q] = asc ? LY_INF : -LY_INF;
-        }
+        // the threshold is left as it is: open (set by the prep kernel) until a select has seen k keys — or already valid
+        // for the whole shard when the threshold-only sample stage set it
+        if (tid == 0) a.count[q] = a.threshold_only ? 0u : n;
         return;
     }
     if (!compacted)
@@ -2005,6 +2044,14 @@ __global__ void __launch_bounds__(NT) k_select(SelectArgs a) {
     float thr_new;
     uint32_t keep;
     bool sorted_path = false;
+    if (a.threshold_only) {  // k rows at least as good as tau exist: tau -/+ 2E is a valid cut for every row of the shard
+        if (tid == 0) {
+            a.count[q] = 0u;
+            const float m2 = a.exact ? 0.0f : a.marg2[q];
+            a.thr[q] = asc ? tau + m2 : tau - m2;
+        }
+        return;
+    }
     if (a.exact) {
         // FLAT scans rows in ascending id order, so a later tie of the k-th score can never win: strict
         // cut.  Packed-binary IVF scans slabs (keys carry ORIGINAL ids): a later tie with a smaller id

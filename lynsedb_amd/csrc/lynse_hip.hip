@@ -974,6 +974,16 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
     const std::vector<Stage> plan = make_plan(h, k, (level == 0 && (!plan_tile || no_sample)) ? 1 : level, plan_tile);
     const Stage sample = (!plan.empty() && plan[0].sample_tiles) ? plan[0] : Stage{0, 0};
     *sampled_plan = sample.sample_tiles != 0;
+    // wave tiling of the 256 x 256 tile (measured on MI355X, 10M x 768, 256 queries): IP is fastest with <2,4,4,2> and the
+    // 3+2-stage split rings, L2 / cosine (norm ring in LDS, more registers in the epilogue) with <4,2,2,4> and 2+2 stages
+    static const int w16env = []() { const char* e = getenv("LYNSE_HIP_SCAN_W16"); return e ? atoi(e) : -1; }();
+    const int waves16 = w16env >= 0 ? w16env : (metric == M_IP ? 3 : 0);
+    // sampled plan: the sample stage only has to produce a threshold -> one key per lane (its best row) instead of every
+    // score, as long as that leaves comfortably more than k keys per query (2 WR keys per tile and query)
+    const uint32_t sample_keys_per_tile = (small || waves16 != 0) ? 16u : 0u;  // 2 WR lanes per query and tile x their best 2 rows (WR = 4 tilings only)
+    static const int no_lane_max = []() { const char* e = getenv("LYNSE_HIP_NO_LANE_MAX"); return e ? atoi(e) : 0; }();
+    // k <= keys per tile: the best sample tile alone supplies k keys (a shard sorted by score still gets a tight threshold)
+    const bool sample_threshold_only = h16 && !binary && sample.sample_tiles && !no_lane_max && k <= sample_keys_per_tile;
     for (size_t si = 0; si < plan.size(); ++si) {
         const Stage s = plan[si];
         const bool emit_all = si == 0;
@@ -1014,7 +1024,7 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
             a.mask = mask;
             a.row_ids = row_ids;
             a.tile_stride = s.sample_stride;  // 0 = contiguous
-            if (!s.sample_tiles && sample.sample_tiles) { a.skip_stride = sample.sample_stride; a.skip_tiles = sample.sample_tiles; }
+            if (!s.sample_tiles && sample.sample_tiles && !sample_threshold_only) { a.skip_stride = sample.sample_stride; a.skip_tiles = sample.sample_tiles; }
             static const int big_rows = []() { const char* e = getenv("LYNSE_HIP_SCAN_BR"); return e ? atoi(e) : 256; }();
             uint32_t tile_rows = (glds && !small && big_rows == 256) ? 256u : (uint32_t)SCAN_BR;
             if (h16) tile_rows = small ? 128u : 256u;
@@ -1024,6 +1034,9 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
             if (s.sample_tiles) a.ntiles = s.sample_tiles;
             a.qinv = w.qinv; a.qn2 = w.qn2; a.qrinv = w.qrinv; a.thr = w.thr; a.vn2 = h->vn2; a.vrinv = h->vrinv;
             a.sv = h->sv; a.cand = w.cand; a.count = w.count; a.cap = w.cap; a.emit_all = emit_all ? 1 : 0;
+            // sampled plan: the sample stage only has to produce a threshold -> one key per lane (its best row) instead of
+            // every score, as long as that leaves at least k keys per query
+            if (sample_threshold_only && s.sample_tiles) a.emit_all = 2;
             static const int dbg = []() { const char* e = getenv("LYNSE_HIP_DEBUG_FLAGS"); return e ? atoi(e) : 0; }();
             a.debug_flags = dbg;
             if (dbg & 2) a.emit_all = 0;
@@ -1042,10 +1055,6 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
                     const uint32_t grid = std::min<uint32_t>(a.ntiles, (uint32_t)h->num_cu * 2);
                     LY_TRY((launch_scan_h16<1, 4, 1, 1, 3, 3, false>(a, metric, grid, st)));
                 } else {
-                    // measured on MI355X (10M x 768, 256 queries): IP is fastest with the 3+2-stage split rings, L2 / cosine
-                    // (norm ring in LDS, more registers in the epilogue) with <4,2,2,4> waves and 2+2 stages
-                    static const int w16env = []() { const char* e = getenv("LYNSE_HIP_SCAN_W16"); return e ? atoi(e) : -1; }();
-                    const int waves16 = w16env >= 0 ? w16env : (metric == M_IP ? 3 : 0);
                     const uint32_t grid = std::min<uint32_t>(a.ntiles, (uint32_t)h->num_cu);
                     if (waves16 == 2) LY_TRY((launch_scan_h16<2, 4, 4, 2, 2, 2, false>(a, metric, grid, st)));
                     else if (waves16 == 3) LY_TRY((launch_scan_h16<2, 4, 4, 2, 3, 2, false>(a, metric, grid, st)));
@@ -1089,6 +1098,11 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
         sa.exact = binary ? 1 : 0;
         sa.drop_sentinels = (mask && emit_all) ? 1 : 0;
         sa.emit_all_n = emit_all ? (s.sample_tiles ? (int)(s.sample_tiles * plan_tile) : (int)(s.r1 - s.r0)) : -1;
+        if (!binary && emit_all && sample_threshold_only) {
+            sa.threshold_only = 1;
+            sa.drop_sentinels = 1;  // a lane whose rows are all masked / out of range wrote the sentinel
+            sa.emit_all_n = (int)(s.sample_tiles * sample_keys_per_tile);
+        }
         sa.Qf = w.Qf; sa.V = h->rows; sa.ld = h->ld; sa.D = h->dim;
         hipLaunchKernelGGL(k_select<SEL_NT>, dim3(nq), dim3(SEL_NT), (size_t)w.cap * 8, st, sa);
         LY_HIP(hipGetLastError());
