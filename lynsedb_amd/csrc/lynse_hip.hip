@@ -662,7 +662,7 @@ struct Stage {
 //          of emitted keys per query in the first full stage);
 // level 1: contiguous plan [0,S0) [S0,8*S0) ... (all other kernels; retry after an overflow of level 0);
 // level 2: exhaustive plan, stages of cap/2 rows — cannot overflow.
-static std::vector<Stage> make_plan(const lynse_hip_flat* h, uint32_t k, int level, uint32_t tile_rows) {
+static std::vector<Stage> make_plan(const lynse_hip_flat* h, uint32_t k, int level, uint32_t tile_rows, bool threshold_only_sample = false) {
     std::vector<Stage> plan;
     const uint64_t n = h->n;
     if (n == 0) return plan;
@@ -673,7 +673,16 @@ static std::vector<Stage> make_plan(const lynse_hip_flat* h, uint32_t k, int lev
     }
     if (level == 0 && tile_rows && n > 4ull * h->cap) {
         static const uint32_t s_env = []() { const char* e = getenv("LYNSE_HIP_SAMPLE_ROWS"); return e ? (uint32_t)atoi(e) : 0u; }();
-        const uint32_t S = s_env ? std::min<uint32_t>(s_env, h->cap / 2) : h->cap / 2;
+        // emit-all sample: every sample row becomes a key (S <= cap / 2).  Threshold-only sample: 16 keys per tile, and a
+        // tile per CU costs the same latency as 32 tiles — a larger sample gives a tighter first threshold for free
+        // (its rows are scanned again: keep it <= n / 16).
+        uint32_t S = s_env ? std::min<uint32_t>(s_env, h->cap / 2) : h->cap / 2;
+        if (threshold_only_sample) {
+            static const uint32_t big_env = []() { const char* e = getenv("LYNSE_HIP_SAMPLE_ROWS_TO"); return e ? (uint32_t)atoi(e) : 0u; }();
+            const uint64_t want = big_env ? big_env : (uint64_t)h->num_cu * tile_rows;
+            S = (uint32_t)std::max<uint64_t>(S, std::min<uint64_t>(std::min<uint64_t>(want, n / 16), (uint64_t)h->cap / 16 * tile_rows));
+            S = S / tile_rows * tile_rows;
+        }
         const uint32_t nt = S / tile_rows;
         const uint64_t stride = (n - tile_rows) / (nt - 1) / tile_rows * tile_rows;
         if (stride > tile_rows) {
@@ -681,7 +690,8 @@ static std::vector<Stage> make_plan(const lynse_hip_flat* h, uint32_t k, int lev
             s0.sample_tiles = nt;
             s0.sample_stride = (uint32_t)stride;
             plan.push_back(s0);
-            static const uint64_t gmax = []() { const char* e = getenv("LYNSE_HIP_SAMPLE_GROWTH"); return e ? (uint64_t)atoi(e) : 16ull; }();
+            static const uint64_t genv = []() { const char* e = getenv("LYNSE_HIP_SAMPLE_GROWTH"); return e ? (uint64_t)atoi(e) : 0ull; }();
+            const uint64_t gmax = genv ? genv : (threshold_only_sample ? 32ull : 16ull);  // measured best on 10M and 1.25M rows
             const uint64_t g = std::max<uint64_t>(2, std::min<uint64_t>(gmax, h->cap / (8ull * std::max<uint32_t>(k, 1))));
             uint64_t seen = S, b = 0;
             while (b < n) {
@@ -971,13 +981,15 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
     // the sampled plan needs the strided-tile support of k_scan_h16; every other kernel starts at level 1
     const uint32_t plan_tile = (h16 && !binary) ? (small ? 128u : 256u) : 0u;
     static const int no_sample = []() { const char* e = getenv("LYNSE_HIP_NO_SAMPLE_PLAN"); return e ? atoi(e) : 0; }();
-    const std::vector<Stage> plan = make_plan(h, k, (level == 0 && (!plan_tile || no_sample)) ? 1 : level, plan_tile);
-    const Stage sample = (!plan.empty() && plan[0].sample_tiles) ? plan[0] : Stage{0, 0};
-    *sampled_plan = sample.sample_tiles != 0;
     // wave tiling of the 256 x 256 tile (measured on MI355X, 10M x 768, 256 queries): IP is fastest with <2,4,4,2> and the
     // 3+2-stage split rings, L2 / cosine (norm ring in LDS, more registers in the epilogue) with <4,2,2,4> and 2+2 stages
     static const int w16env = []() { const char* e = getenv("LYNSE_HIP_SCAN_W16"); return e ? atoi(e) : -1; }();
     const int waves16 = w16env >= 0 ? w16env : (metric == M_IP ? 3 : 0);
+    static const int no_lane_max0 = []() { const char* e = getenv("LYNSE_HIP_NO_LANE_MAX"); return e ? atoi(e) : 0; }();
+    const bool can_threshold_only = h16 && !binary && !no_lane_max0 && (small || waves16 != 0) && k <= 16;
+    const std::vector<Stage> plan = make_plan(h, k, (level == 0 && (!plan_tile || no_sample)) ? 1 : level, plan_tile, can_threshold_only);
+    const Stage sample = (!plan.empty() && plan[0].sample_tiles) ? plan[0] : Stage{0, 0};
+    *sampled_plan = sample.sample_tiles != 0;
     // sampled plan: the sample stage only has to produce a threshold -> one key per lane (its best row) instead of every
     // score, as long as that leaves comfortably more than k keys per query (2 WR keys per tile and query)
     const uint32_t sample_keys_per_tile = (small || waves16 != 0) ? 16u : 0u;  // 2 WR lanes per query and tile x their best 2 rows (WR = 4 tilings only)
