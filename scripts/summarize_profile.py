@@ -40,8 +40,8 @@ if pmc.exists():
             "(MI355X_MICROARCH.md §HBM) — corrected = FETCH_SIZE x 1024 x 2."
             + (" k_scan_h16 reads the f16 shadow rows: kernel bytes = rows x 768 x 2, algorithmic (SURVEY 8d) = rows x 768 x 4." if h16 else ""), "",
             "| dispatch | stage rows | FETCH_SIZE KiB | corrected GB | kernel GB | algorithmic GB | hbm / kernel | hbm / algorithmic |", "|---|---|---|---|---|---|---|---|"]
-    # stage plan of bench.py --rows 2000000: f32 scan = contiguous stages; h16 = sampled plan (8192 sample rows, growth 16)
-    plan = [8192, 131072, 2000000 - 131072] if h16 else [4096, 32768 - 4096, 262144 - 32768, 2000000 - 262144]
+    # stage plan of bench.py --rows 2000000: f32 scan = contiguous stages; h16 = sampled plan (one 256-row tile per CU, then everything)
+    plan = [65536, 2000000] if h16 else [4096, 32768 - 4096, 262144 - 32768, 2000000 - 262144]
     rows = [r for r in csv.DictReader(open(pmc)) if r["Counter_Name"] == "FETCH_SIZE"]
     last = None
     for i, r in enumerate(rows):
