@@ -14,7 +14,7 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 NAME = {O.IP: "ip", O.L2: "l2", O.COS: "cosine", O.HAMMING: "hamming", O.JACCARD: "jaccard", O.DICE: "dice"}
 t0, cases, bad = time.time(), 0, []
 while time.time() - t0 < budget:
-    n = int(rng.choice([1, 7, 300, 4097, 20000, 70001, 200000]))
+    n = int(rng.choice([1, 7, 300, 4097, 20000, 70001, 200000, 600000, 1100000]))
     dim = int(rng.choice([1, 3, 8, 17, 64, 100, 128, 200, 384]))
     nq = int(rng.choice([1, 2, 31, 33, 70, 256, 300]))
     k = int(rng.choice([1, 5, 10, 64, 300]))
