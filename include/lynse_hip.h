@@ -183,7 +183,9 @@ int lynse_hip_flat_search_packed_u64_device(lynse_hip_flat *h, const uint64_t *d
 /* Profiling: when enabled, searches bracket the scan kernel with HIP events on its stream. */
 int lynse_hip_flat_profile_enable(lynse_hip_flat *h, int on);
 int lynse_hip_flat_profile_get(lynse_hip_flat *h, lynse_hip_profile *out, int reset);
-/* Tuning knobs (defaults are fine): stage-0 rows, stage growth factor, candidate capacity. */
+/* Tuning knobs (defaults are fine): first-stage rows and growth factor of the contiguous stage plan (the fallback of the
+ * default sampled plan), candidate capacity per query (power of two in [256, 16384], default 16384; k <= cap / 4 when the
+ * shard holds more than cap rows). */
 int lynse_hip_flat_set_plan(lynse_hip_flat *h, uint32_t stage0_rows, uint32_t growth, uint32_t cap);
 
 /* ---- stand-alone functions (src/python/mod.rs:2161-2223) ---- */
