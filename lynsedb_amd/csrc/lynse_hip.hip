@@ -800,6 +800,7 @@ static int launch_scan_h16(const ScanArgs& a, int metric, uint32_t grid, hipStre
     };
     const bool filt = a.mask != nullptr || a.row_ids != nullptr;
     if (a.ld16 % HK == 0 && !filt) {  // no ragged last slab: branch-free DMA issue
+#ifdef LYNSE_EXPERIMENTS
         if constexpr (WQ == 2 && WR == 4 && !TILED) {  // timing experiments (LYNSE_HIP_DEBUG_FLAGS bits 16.. = DBG << 4)
             if (metric == M_IP && (a.debug_flags >> 4) & 15) {
                 auto ex = [&](auto kern) -> int {
@@ -825,6 +826,7 @@ static int launch_scan_h16(const ScanArgs& a, int metric, uint32_t grid, hipStre
                 return LYNSE_OK;
             }
         }
+#endif
         switch (metric) {
         case M_IP: return go(k_scan_h16<WQ, WR, TQ, TR, M_IP, NSV, NSQ, 2, TILED, false>, 3);
         case M_L2: return go(k_scan_h16<WQ, WR, TQ, TR, M_L2, NSV, NSQ, 2, TILED, false>, 4);
@@ -1068,8 +1070,11 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
                     LY_TRY((launch_scan_h16<1, 4, 1, 1, 3, 3, false>(a, metric, grid, st)));
                 } else {
                     const uint32_t grid = std::min<uint32_t>(a.ntiles, (uint32_t)h->num_cu);
+#ifdef LYNSE_EXPERIMENTS
                     if (waves16 == 2) LY_TRY((launch_scan_h16<2, 4, 4, 2, 2, 2, false>(a, metric, grid, st)));
-                    else if (waves16 == 3) LY_TRY((launch_scan_h16<2, 4, 4, 2, 3, 2, false>(a, metric, grid, st)));
+                    else
+#endif
+                    if (waves16 == 3 || waves16 == 2) LY_TRY((launch_scan_h16<2, 4, 4, 2, 3, 2, false>(a, metric, grid, st)));
                     else LY_TRY((launch_scan_h16<4, 2, 2, 4, 2, 2, false>(a, metric, grid, st)));
                 }
             } else if (glds) {
@@ -1077,27 +1082,44 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
                 if (small) {
                     const uint32_t grid = std::min<uint32_t>(a.ntiles, (uint32_t)h->num_cu * 2);
                     LY_TRY((launch_scan_glds<1, 4, 1, 1, 4>(a, metric, scale, grid, st)));
+#ifdef LYNSE_EXPERIMENTS
                 } else if (tile_rows == 192) {
                     const uint32_t grid = std::min<uint32_t>(a.ntiles, (uint32_t)h->num_cu);
                     LY_TRY((launch_scan_glds<4, 2, 2, 3, 4>(a, metric, scale, grid, st)));
+#endif
                 } else if (tile_rows == 256) {
                     static const int waves16 = []() { const char* e = getenv("LYNSE_HIP_SCAN_W16"); return e ? atoi(e) : 2; }();
                     const uint32_t grid = std::min<uint32_t>(a.ntiles, (uint32_t)h->num_cu);
-                    if (waves16 == 2) LY_TRY((launch_scan_glds<2, 4, 4, 2, 3>(a, metric, scale, grid, st)));
-                    else if (waves16 == 3) LY_TRY((launch_scan_glds<1, 8, 8, 1, 3>(a, metric, scale, grid, st)));
-                    else LY_TRY((launch_scan_glds<4, 2, 2, 4, 3>(a, metric, scale, grid, st)));
+                    (void)waves16;
+#ifdef LYNSE_EXPERIMENTS
+                    if (waves16 == 3) LY_TRY((launch_scan_glds<1, 8, 8, 1, 3>(a, metric, scale, grid, st)));
+                    else if (waves16 == 0) LY_TRY((launch_scan_glds<4, 2, 2, 4, 3>(a, metric, scale, grid, st)));
+                    else
+#endif
+                    LY_TRY((launch_scan_glds<2, 4, 4, 2, 3>(a, metric, scale, grid, st)));
                 } else {
+#ifdef LYNSE_EXPERIMENTS
                     const uint32_t grid = std::min<uint32_t>(a.ntiles, (uint32_t)h->num_cu);
                     LY_TRY((launch_scan_glds<4, 2, 2, 2, 4>(a, metric, scale, grid, st)));
+#else
+                    return set_error(LYNSE_ERR_UNSUPPORTED, "this tile size of the f32 scan needs a build with -DLYNSE_EXPERIMENTS (make EXPERIMENTS=1)");
+#endif
                 }
-            } else if (small) {
-                const uint32_t grid = std::min<uint32_t>(a.ntiles, (uint32_t)h->num_cu * 3);
-                if (variant == 1) LY_TRY((launch_scan<1, 4, 1, 1, 1>(h, a, metric, grid, st)));
-                else LY_TRY((launch_scan<1, 4, 1, 1, 2>(h, a, metric, grid, st)));
             } else {
-                const uint32_t grid = std::min<uint32_t>(a.ntiles, (uint32_t)h->num_cu);
-                if (variant == 1) LY_TRY((launch_scan<4, 2, 2, 2, 1>(h, a, metric, grid, st)));
-                else LY_TRY((launch_scan<4, 2, 2, 2, 2>(h, a, metric, grid, st)));
+#ifdef LYNSE_EXPERIMENTS
+                if (small) {
+                    const uint32_t grid = std::min<uint32_t>(a.ntiles, (uint32_t)h->num_cu * 3);
+                    if (variant == 1) LY_TRY((launch_scan<1, 4, 1, 1, 1>(h, a, metric, grid, st)));
+                    else LY_TRY((launch_scan<1, 4, 1, 1, 2>(h, a, metric, grid, st)));
+                } else {
+                    const uint32_t grid = std::min<uint32_t>(a.ntiles, (uint32_t)h->num_cu);
+                    if (variant == 1) LY_TRY((launch_scan<4, 2, 2, 2, 1>(h, a, metric, grid, st)));
+                    else LY_TRY((launch_scan<4, 2, 2, 2, 2>(h, a, metric, grid, st)));
+                }
+#else
+                (void)variant;
+                return set_error(LYNSE_ERR_UNSUPPORTED, "the register-staged scan variants need a build with -DLYNSE_EXPERIMENTS (make EXPERIMENTS=1)");
+#endif
             }
         }
         if (h->profiling) {
