@@ -1,0 +1,78 @@
+#!/usr/bin/env python3
+"""Randomised IVF parity sweep (GPU): IVFIndex / IvfFlat / binary / subset-filtered searches against the oracle on the same
+centroids + assignments.  Usage: python scripts/stress_ivf.py [seconds] [seed]"""
+import sys, time
+from pathlib import Path
+import numpy as np
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+import lynsedb_amd as L  # noqa: E402
+import oracle as O  # noqa: E402
+
+orc = O.get()
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+NAME = {O.IP: "ip", O.L2: "l2", O.COS: "cosine", O.HAMMING: "hamming", O.JACCARD: "jaccard"}
+t0, cases, bad = time.time(), 0, []
+compared, skipped = {}, 0
+while time.time() - t0 < budget:
+    n = int(rng.choice([50, 700, 3000, 9000]))
+    dim = int(rng.choice([4, 16, 33, 64, 100]))
+    nlist = int(rng.choice([1, 2, 8, 40, 130]))
+    nprobe = int(rng.choice([1, 2, 5, 16, 200]))
+    nq = int(rng.choice([1, 3, 40, 70]))
+    k = int(rng.choice([1, 10, 40]))
+    mode = str(rng.choice(["ivfindex", "ivfflat", "binary", "filtered"]))
+    metric = int(rng.choice([O.IP, O.L2, O.COS])) if mode != "binary" else int(rng.choice([O.HAMMING, O.JACCARD]))
+    if mode == "binary":
+        data = (rng.random((n, dim)) < 0.4).astype(np.float32)
+        queries = data[rng.integers(0, n, nq)].copy()
+    else:
+        centers = rng.standard_normal((max(nlist // 2, 2), dim)).astype(np.float32)
+        data = (centers[rng.integers(0, centers.shape[0], n)] + 0.3 * rng.standard_normal((n, dim))).astype(np.float32)
+        queries = (data[rng.integers(0, n, nq)] + 0.05 * rng.standard_normal((nq, dim))).astype(np.float32)
+    try:
+        if mode == "ivfflat":
+            if n < nlist or nlist < 1:
+                continue
+            cen, asg = orc.kmeans_train(data, nlist, 8, O.L2)
+            off, orig = orc.ivf_flat_layout(asg, cen.shape[0])
+            slab = data[orig.astype(np.int64)]
+            idx = L.IvfFlatIndex.load(data, cen, asg, NAME[metric], ivfflat_routing=True)
+            rd = orc.ivf_routing_dims(cen)
+            g = idx.search_batch_arrays(queries, k, nprobe)
+            check = lambda qi: orc.ivf_flat_search(queries[qi], slab, cen, off, orig, nprobe, k, metric, routing_dims=rd)  # noqa: E731
+        elif mode == "binary":
+            cen, asg = orc.kmeans_train(data, nlist, 8, O.L2)
+            off, rows = orc.lists_from_assignments(asg, cen.shape[0])
+            packed = orc.pack_binary(data)
+            idx = L.IvfFlatIndex.load(data, cen, asg, NAME[metric], thresholds=np.full(dim, 0.5, np.float32))
+            g = idx.search_batch_arrays(queries, k, nprobe)
+            check = lambda qi: orc.ivf_search(queries[qi], data, cen, off, rows, nprobe, k, metric, packed=packed)[:2]  # noqa: E731
+        else:
+            cen, asg = orc.kmeans_train(data, nlist, 8, metric)
+            off, rows = orc.lists_from_assignments(asg, cen.shape[0])
+            idx = L.IvfFlatIndex.load(data, cen, asg, NAME[metric])
+            if mode == "filtered":
+                m = int(rng.integers(1, n + 1))
+                subset = np.sort(rng.choice(n, m, replace=False)).astype(np.uint64)
+                g = idx.search_filtered_batch_arrays(queries, k, nprobe, subset)
+                check = lambda qi: orc.ivf_search_filtered(queries[qi], data, cen, off, rows, nprobe, k, metric, subset)  # noqa: E731
+            else:
+                g = idx.search_batch_arrays(queries, k, nprobe)
+                check = lambda qi: orc.ivf_search(queries[qi], data, cen, off, rows, nprobe, k, metric)[:2]  # noqa: E731
+        compared[mode] = compared.get(mode, 0) + 1
+        for qi in sorted(set([0, nq - 1])):
+            e_ids, e_d = check(qi)
+            c = int(g[2][qi])
+            if c != len(e_ids) or not np.array_equal(g[0][qi, :c].astype(np.uint64), np.asarray(e_ids, np.uint64)) or not np.array_equal(g[1][qi, :c].view(np.uint32), e_d.view(np.uint32)):
+                bad.append((mode, NAME[metric], n, dim, nlist, nprobe, nq, k, qi))
+                break
+    except Exception as e:  # noqa: BLE001
+        if "not supported" not in str(e) and "too large" not in str(e):
+            bad.append((mode, NAME[metric], n, dim, nlist, nprobe, nq, k, "EXC " + str(e)[:80]))
+        else:
+            skipped += 1
+    cases += 1
+print("cases", cases, "compared", compared, "unsupported", skipped, "mismatches", len(bad))
+for b in bad[:20]:
+    print("  ", b)
