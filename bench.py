@@ -204,6 +204,9 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None,
             "dtype": "f32" if metric < 3 else "u64", "data": "synthetic",
+            "dtype_note": ("returned distances are exact f32 (reference accumulation order, bit-identical to the oracle); "
+                           "the scan is an f16-MFMA prefilter with a certified error margin, survivors are rescored from "
+                           "the f32 rows") if metric < 3 else "popcount over packed u64 words",
             "config": {"workload": "FLAT-%s %dx%d f32 uniform[0,1), %d queries = perturbed rows, k=%d"
                                    % (args.metric.upper(), N, D, B, K),
                        "rows_per_gpu": n_local, "sharding": "row %% %d" % world,
