@@ -140,10 +140,12 @@ struct Workspace {
     uint64_t* QWp = nullptr;  // queries padded to a power-of-two word count (k_scan_binary_rows)
     uint64_t* out_rows = nullptr;
     float* out_dists = nullptr;
-    uint32_t* out_counts = nullptr;
+    uint32_t* out_counts = nullptr;  // out_counts[QCHUNK] and overflow[QCHUNK] share one allocation: one readback for both
+    uint32_t* h_hdr = nullptr;       // pinned host mirror of that pair
     unsigned long long* pool_total = nullptr;
     void release() {
-        for (void* p : {(void*)cand, (void*)count, (void*)overflow, (void*)thr, (void*)qinv, (void*)qn2,
+        if (h_hdr) (void)hipHostFree(h_hdr);
+        for (void* p : {(void*)cand, (void*)count, (void*)thr, (void*)qinv, (void*)qn2,
                         (void*)qrinv, (void*)marg2, (void*)Q16, (void*)Qf, (void*)QW, (void*)QWp, (void*)out_rows,
                         (void*)out_dists, (void*)out_counts, (void*)pool_total})
             if (p) (void)hipFree(p);
@@ -626,7 +628,6 @@ static int ensure_workspace(lynse_hip_flat* h, uint32_t k /* caller's k = output
     w.kcap = std::max<uint32_t>(k, 128);
     LY_HIP(hipMalloc(&w.cand, (size_t)QCHUNK * w.cap * 8));
     LY_HIP(hipMalloc(&w.count, QCHUNK * 4));
-    LY_HIP(hipMalloc(&w.overflow, QCHUNK * 4));
     LY_HIP(hipMalloc(&w.thr, QCHUNK * 4));
     LY_HIP(hipMalloc(&w.qinv, QCHUNK * 4));
     LY_HIP(hipMalloc(&w.qn2, QCHUNK * 4));
@@ -644,7 +645,9 @@ static int ensure_workspace(lynse_hip_flat* h, uint32_t k /* caller's k = output
     }
     LY_HIP(hipMalloc(&w.out_rows, (size_t)QCHUNK * w.kcap * 8));
     LY_HIP(hipMalloc(&w.out_dists, (size_t)QCHUNK * w.kcap * 4));
-    LY_HIP(hipMalloc(&w.out_counts, QCHUNK * 4));
+    LY_HIP(hipMalloc(&w.out_counts, 2 * QCHUNK * 4));
+    w.overflow = w.out_counts + QCHUNK;
+    LY_HIP(hipHostMalloc(&w.h_hdr, 2 * QCHUNK * 4, hipHostMallocDefault));
     LY_HIP(hipMalloc(&w.pool_total, 8));
     LY_HIP(hipMemset(w.pool_total, 0, 8));
     return LYNSE_OK;
@@ -1501,21 +1504,21 @@ static int search_impl(lynse_hip_flat* h, const void* q_src, bool packed_queries
         for (int level = 0; level < 3; ++level) {  // sampled plan -> contiguous plan -> exhaustive plan (make_plan)
             bool sampled = false;
             LY_TRY(run_chunk(h, nqc, kk, k, metric, level, st, &ev_used, &scan_events, &sampled, mask, direct ? h->g_ids32 : nullptr));
-            std::vector<uint32_t> ovf(nqc);
-            LY_HIP(hipMemcpyAsync(ovf.data(), w.overflow, nqc * 4, hipMemcpyDeviceToHost, st));
+            // outputs are copied speculatively with the overflow flags — one synchronisation per chunk; a retry on the
+            // next plan level overwrites them in stream order.  Workspace rows are [nqc][kk]; caller layout is [nq][k]
+            LY_HIP(hipMemcpyAsync(out_rows + q0 * k, w.out_rows, (size_t)nqc * k * 8, out_kind, st));
+            LY_HIP(hipMemcpyAsync(out_dists + q0 * k, w.out_dists, (size_t)nqc * k * 4, out_kind, st));
+            if (on_device) LY_HIP(hipMemcpyAsync(out_counts + q0, w.out_counts, nqc * 4, out_kind, st));
+            LY_HIP(hipMemcpyAsync(w.h_hdr, w.out_counts, 2 * QCHUNK * 4, hipMemcpyDeviceToHost, st));  // counts + overflow flags
             LY_HIP(hipStreamSynchronize(st));
             uint32_t nov = 0;
-            for (uint32_t v : ovf) nov += v ? 1 : 0;
+            for (uint32_t i = 0; i < nqc; ++i) nov += w.h_hdr[QCHUNK + i] ? 1 : 0;
             if (nov == 0) break;
             if (level == 2) return set_error(LYNSE_ERR_INTERNAL, "candidate overflow on the exhaustive plan");
             fallback_queries += nov;
             if (level == 0 && !sampled) level = 1;  // level 1 would repeat the same contiguous plan
         }
-        // outputs: workspace rows are [nqc][kk]; caller layout is [nq][k]
-        LY_HIP(hipMemcpyAsync(out_rows + q0 * k, w.out_rows, (size_t)nqc * k * 8, out_kind, st));
-        LY_HIP(hipMemcpyAsync(out_dists + q0 * k, w.out_dists, (size_t)nqc * k * 4, out_kind, st));
-        LY_HIP(hipMemcpyAsync(out_counts + q0, w.out_counts, nqc * 4, out_kind, st));
-        LY_HIP(hipStreamSynchronize(st));
+        if (!on_device) memcpy(out_counts + q0, w.h_hdr, nqc * 4);
     }
 
     if (h->profiling) {
