@@ -1300,18 +1300,16 @@ extern "C" int lynse_hip_flat_search_sq8_f32(lynse_hip_flat* h, const float* que
         LY_HIP(hipMemcpyAsync(w.Qf, queries + q0 * h->dim, (size_t)nqc * h->dim * 4, hipMemcpyHostToDevice, st));
         for (int level = 1; level < 3; ++level) {
             LY_TRY(run_chunk_sq8(h, nqc, kk, k, (uint32_t)n_cand, metric, level, st));
-            std::vector<uint32_t> ovf(nqc);
-            LY_HIP(hipMemcpyAsync(ovf.data(), w.overflow, nqc * 4, hipMemcpyDeviceToHost, st));
+            LY_HIP(hipMemcpyAsync(out_rows + q0 * k, w.out_rows, (size_t)nqc * k * 8, hipMemcpyDeviceToHost, st));  // speculative, as in search_impl
+            LY_HIP(hipMemcpyAsync(out_dists + q0 * k, w.out_dists, (size_t)nqc * k * 4, hipMemcpyDeviceToHost, st));
+            LY_HIP(hipMemcpyAsync(w.h_hdr, w.out_counts, 2 * QCHUNK * 4, hipMemcpyDeviceToHost, st));  // counts + overflow flags
             LY_HIP(hipStreamSynchronize(st));
             uint32_t nov = 0;
-            for (uint32_t v : ovf) nov += v ? 1 : 0;
+            for (uint32_t i = 0; i < nqc; ++i) nov += w.h_hdr[QCHUNK + i] ? 1 : 0;
             if (nov == 0) break;
             if (level == 2) return set_error(LYNSE_ERR_INTERNAL, "candidate overflow on the exhaustive plan");
         }
-        LY_HIP(hipMemcpyAsync(out_rows + q0 * k, w.out_rows, (size_t)nqc * k * 8, hipMemcpyDeviceToHost, st));
-        LY_HIP(hipMemcpyAsync(out_dists + q0 * k, w.out_dists, (size_t)nqc * k * 4, hipMemcpyDeviceToHost, st));
-        LY_HIP(hipMemcpyAsync(out_counts + q0, w.out_counts, nqc * 4, hipMemcpyDeviceToHost, st));
-        LY_HIP(hipStreamSynchronize(st));
+        memcpy(out_counts + q0, w.h_hdr, nqc * 4);
     }
     return LYNSE_OK;
 }
