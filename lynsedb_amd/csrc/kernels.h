@@ -1259,6 +1259,9 @@ __global__ void __launch_bounds__(WQ * WR * 64, (TQ * TR >= 16) ? 1 : ((WQ * WR 
             }
             const float* nrm = reinterpret_cast<const float*>(smem + NORM_RING + (c_tileseq % NORM_SLOTS) * 1024);
             ++c_tileseq;
+            uint32_t mw_t[TR];  // subset filter: the tile's mask words, loaded once per tile (not once per query column: each load
+#pragma unroll          // would pay the full memory latency behind the candidate stores)
+            for (int i = 0; i < TR; ++i) mw_t[i] = (FILT && !TILED && a.mask) ? a.mask[(rbase + wr * (TR * 32) + i * 32) >> 5] : 0xffffffffu;
             auto score = [&](int i, int j, int r, uint32_t m, bool rok) -> float {
                 if constexpr (I8) {
                     // dot of the u8 codes = i8 dot + 128 (sum q' + sum r') + 16384 D; squared L2 = sum q'^2 + sum r'^2 - 2 dot
@@ -1290,7 +1293,7 @@ __global__ void __launch_bounds__(WQ * WR * 64, (TQ * TR >= 16) ? 1 : ((WQ * WR 
                     if (METRIC == M_L2) c_extra[j] = c_ok[j] ? a.qn2[n] : 0.0f;
                     if (METRIC == M_COS) c_extra[j] = c_ok[j] ? a.qrinv[n] : 0.0f;
                 }
-                if (WR >= 4 && a.emit_all == 2 && !TILED) {  // (compiled out of the <4,2,2,4> tiling: it would spill there)
+                if (WR >= 4 && !FILT && a.emit_all == 2 && !TILED) {  // (compiled out of the <4,2,2,4> tiling and the subset-filter variants: it would spill there)
                     // threshold-only sample stage: each lane keeps the best LM of its TR*16 rows for this query column
                     // (4 WR keys per tile and query) and writes only those.  k_select turns the k-th best of them into a
                     // valid threshold and keeps no candidate: the sample tiles are scanned again by the ordinary stages.
@@ -1303,7 +1306,7 @@ __global__ void __launch_bounds__(WQ * WR * 64, (TQ * TR >= 16) ? 1 : ((WQ * WR 
                     for (int t = 0; t < LM; ++t) { bs[t] = ASC ? LY_INF : -LY_INF; bm[t] = 0xffffffffu; }
 #pragma unroll
                     for (int i = 0; i < TR; ++i) {
-                        const uint32_t mw = (FILT && a.mask) ? a.mask[(rbase + wr * (TR * 32) + i * 32) >> 5] : 0xffffffffu;
+                        const uint32_t mw = mw_t[i];
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
                             const uint32_t bit = (r & 3) + 8 * (r >> 2) + 4 * hi;
@@ -1332,7 +1335,7 @@ __global__ void __launch_bounds__(WQ * WR * 64, (TQ * TR >= 16) ? 1 : ((WQ * WR 
                 } else if (a.emit_all && !TILED) {
 #pragma unroll
                     for (int i = 0; i < TR; ++i) {
-                        const uint32_t mw = (FILT && a.mask) ? a.mask[(rbase + wr * (TR * 32) + i * 32) >> 5] : 0xffffffffu;
+                        const uint32_t mw = mw_t[i];
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
                             const uint32_t bit = (r & 3) + 8 * (r >> 2) + 4 * hi;
@@ -1349,7 +1352,7 @@ __global__ void __launch_bounds__(WQ * WR * 64, (TQ * TR >= 16) ? 1 : ((WQ * WR 
 #pragma unroll
                     for (int i = 0; i < TR; ++i) {
                         uint32_t msk = 0;
-                        const uint32_t mw = (FILT && !TILED && a.mask) ? a.mask[(rbase + wr * (TR * 32) + i * 32) >> 5] : 0xffffffffu;
+                        const uint32_t mw = mw_t[i];
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
                             const uint32_t bit = (r & 3) + 8 * (r >> 2) + 4 * hi;

@@ -989,9 +989,12 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
     // wave tiling of the 256 x 256 tile (measured on MI355X, 10M x 768, 256 queries): IP is fastest with <2,4,4,2> and the
     // 3+2-stage split rings, L2 / cosine (norm ring in LDS, more registers in the epilogue) with <4,2,2,4> and 2+2 stages
     static const int w16env = []() { const char* e = getenv("LYNSE_HIP_SCAN_W16"); return e ? atoi(e) : -1; }();
-    const int waves16 = w16env >= 0 ? w16env : (metric == M_IP ? 3 : 0);
+    const bool filt = mask != nullptr || row_ids != nullptr;
+    // (the subset-filter variants of <2,4,4,2> spill 96 B into the MFMA loop: masked 10M x 768 scan 7.5 ms vs 4.9 ms with <4,2,2,4>)
+    const int waves16 = w16env >= 0 ? w16env : ((metric == M_IP && !filt) ? 3 : 0);
     static const int no_lane_max0 = []() { const char* e = getenv("LYNSE_HIP_NO_LANE_MAX"); return e ? atoi(e) : 0; }();
-    const bool can_threshold_only = h16 && !binary && !no_lane_max0 && (small || waves16 != 0) && k <= 16;
+    // the subset-filter kernel variants carry no lane-max code (registers)
+    const bool can_threshold_only = h16 && !binary && !filt && !no_lane_max0 && (small || waves16 != 0) && k <= 16;
     const std::vector<Stage> plan = make_plan(h, k, (level == 0 && (!plan_tile || no_sample)) ? 1 : level, plan_tile, can_threshold_only);
     const Stage sample = (!plan.empty() && plan[0].sample_tiles) ? plan[0] : Stage{0, 0};
     *sampled_plan = sample.sample_tiles != 0;
@@ -1000,7 +1003,7 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
     const uint32_t sample_keys_per_tile = (small || waves16 != 0) ? 16u : 0u;  // 2 WR lanes per query and tile x their best 2 rows (WR = 4 tilings only)
     static const int no_lane_max = []() { const char* e = getenv("LYNSE_HIP_NO_LANE_MAX"); return e ? atoi(e) : 0; }();
     // k <= keys per tile: the best sample tile alone supplies k keys (a shard sorted by score still gets a tight threshold)
-    const bool sample_threshold_only = h16 && !binary && sample.sample_tiles && !no_lane_max && k <= sample_keys_per_tile;
+    const bool sample_threshold_only = h16 && !binary && !filt && sample.sample_tiles && !no_lane_max && k <= sample_keys_per_tile;
     for (size_t si = 0; si < plan.size(); ++si) {
         const Stage s = plan[si];
         const bool emit_all = si == 0;
