@@ -128,6 +128,8 @@ extern "C" int lynse_hip_metric_is_binary(int metric) { return (metric >= M_HAMM
 static bool metric_valid(int m) { return m >= M_IP && m <= M_TANIMOTO; }
 
 // ------------------------------------------------------------------------------------ handle ----
+constexpr size_t H_OUT_BYTES = 96 * 1024;  // results up to this size come back through pinned memory (no pageable-copy stalls)
+
 struct Workspace {
     uint32_t qcap = 0, cap = 0, D = 0, W = 0, kcap = 0;
     uint64_t* cand = nullptr;
@@ -142,9 +144,11 @@ struct Workspace {
     float* out_dists = nullptr;
     uint32_t* out_counts = nullptr;  // out_counts[QCHUNK] and overflow[QCHUNK] share one allocation: one readback for both
     uint32_t* h_hdr = nullptr;       // pinned host mirror of that pair
+    uint8_t* h_out = nullptr;        // pinned staging for small host-API results (rows then dists), H_OUT_BYTES
     unsigned long long* pool_total = nullptr;
     void release() {
         if (h_hdr) (void)hipHostFree(h_hdr);
+        if (h_out) (void)hipHostFree(h_out);
         for (void* p : {(void*)cand, (void*)count, (void*)thr, (void*)qinv, (void*)qn2,
                         (void*)qrinv, (void*)marg2, (void*)Q16, (void*)Qf, (void*)QW, (void*)QWp, (void*)out_rows,
                         (void*)out_dists, (void*)out_counts, (void*)pool_total})
@@ -648,6 +652,7 @@ static int ensure_workspace(lynse_hip_flat* h, uint32_t k /* caller's k = output
     LY_HIP(hipMalloc(&w.out_counts, 2 * QCHUNK * 4));
     w.overflow = w.out_counts + QCHUNK;
     LY_HIP(hipHostMalloc(&w.h_hdr, 2 * QCHUNK * 4, hipHostMallocDefault));
+    LY_HIP(hipHostMalloc(&w.h_out, H_OUT_BYTES, hipHostMallocDefault));
     LY_HIP(hipMalloc(&w.pool_total, 8));
     LY_HIP(hipMemset(w.pool_total, 0, 8));
     return LYNSE_OK;
@@ -1507,14 +1512,19 @@ static int search_impl(lynse_hip_flat* h, const void* q_src, bool packed_queries
             LY_TRY(run_chunk(h, nqc, kk, k, metric, level, st, &ev_used, &scan_events, &sampled, mask, direct ? h->g_ids32 : nullptr));
             // outputs are copied speculatively with the overflow flags — one synchronisation per chunk; a retry on the
             // next plan level overwrites them in stream order.  Workspace rows are [nqc][kk]; caller layout is [nq][k]
-            LY_HIP(hipMemcpyAsync(out_rows + q0 * k, w.out_rows, (size_t)nqc * k * 8, out_kind, st));
-            LY_HIP(hipMemcpyAsync(out_dists + q0 * k, w.out_dists, (size_t)nqc * k * 4, out_kind, st));
+            const size_t rows_b = (size_t)nqc * k * 8, dists_b = (size_t)nqc * k * 4;
+            const bool staged = !on_device && rows_b + dists_b <= H_OUT_BYTES;
+            LY_HIP(hipMemcpyAsync(staged ? (void*)w.h_out : (void*)(out_rows + q0 * k), w.out_rows, rows_b, out_kind, st));
+            LY_HIP(hipMemcpyAsync(staged ? (void*)(w.h_out + rows_b) : (void*)(out_dists + q0 * k), w.out_dists, dists_b, out_kind, st));
             if (on_device) LY_HIP(hipMemcpyAsync(out_counts + q0, w.out_counts, nqc * 4, out_kind, st));
             LY_HIP(hipMemcpyAsync(w.h_hdr, w.out_counts, 2 * QCHUNK * 4, hipMemcpyDeviceToHost, st));  // counts + overflow flags
             LY_HIP(hipStreamSynchronize(st));
             uint32_t nov = 0;
             for (uint32_t i = 0; i < nqc; ++i) nov += w.h_hdr[QCHUNK + i] ? 1 : 0;
-            if (nov == 0) break;
+            if (nov == 0) {
+                if (staged) { memcpy(out_rows + q0 * k, w.h_out, rows_b); memcpy(out_dists + q0 * k, w.h_out + rows_b, dists_b); }
+                break;
+            }
             if (level == 2) return set_error(LYNSE_ERR_INTERNAL, "candidate overflow on the exhaustive plan");
             fallback_queries += nov;
             if (level == 0 && !sampled) level = 1;  // level 1 would repeat the same contiguous plan
