@@ -405,6 +405,7 @@ struct ScanArgs {
     const float *qinv, *qn2, *qrinv, *thr;
     const float *vn2, *vrinv;
     float sv;
+    float vmax2;  // max squared row norm of the store: rounding slack of the L2 pre-filter (0 = unknown -> pre-filter off)
     uint64_t* cand;
     uint32_t* count;
     uint32_t cap;
@@ -423,6 +424,7 @@ struct IvfTile {
     uint32_t pair0, nq;
 };
 
+#ifdef LYNSE_EXPERIMENTS  // the register-staged predecessor (A/B reference only: make EXPERIMENTS=1)
 template <int WQ, int WR, int TQ, int TR, int METRIC, int PD>
 __global__ void __launch_bounds__(WQ * WR * 64, 2) k_scan_f16(ScanArgs a) {
     constexpr int NT = WQ * WR * 64;
@@ -610,6 +612,7 @@ __global__ void __launch_bounds__(WQ * WR * 64, 2) k_scan_f16(ScanArgs a) {
     }
 }
 
+#endif  // LYNSE_EXPERIMENTS
 // ------------------------------------------------------------------------------------------------
 // k_scan_glds — the hot kernel, LDS-DMA edition (default).
 //
@@ -634,6 +637,7 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
                                      (__attribute__((address_space(3))) void*)lds_dst, 16, 0, AUX);
 }
 
+#ifdef LYNSE_EXPERIMENTS  // the f32-row LDS-DMA predecessor of k_scan_h16 (A/B reference only: make EXPERIMENTS=1)
 // NS ring stages; NT_HINT = 2 marks the row stream non-temporal (each row byte is read once per
 // batch by exactly one CU), the query image keeps the default policy (re-read by every CU from L2).
 // TILED = work-list mode for IVF slabs (tile descriptors + per-group query images).
@@ -954,6 +958,7 @@ __global__ void __launch_bounds__(WQ * WR * 64, (WQ * WR >= 8) ? (WQ * WR / 4) :
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the clamped tail DMAs before the LDS is released
 }
+#endif  // LYNSE_EXPERIMENTS
 
 // f16 storage: rows [r0,r1) <- f16::to_f32(f16::from_f32(row)) in place (encode_f32_slice_as_le_bytes F16, RNE)
 __global__ void __launch_bounds__(256) k_round_rows_f16(float* __restrict__ V, uint32_t ld, uint32_t D, uint64_t r0, uint64_t r1) {
@@ -1045,18 +1050,20 @@ __global__ void __launch_bounds__(WQ * WR * 64, (TQ * TR >= 16) ? 1 : ((WQ * WR 
     const uint32_t tstride = a.tile_stride ? a.tile_stride : (uint32_t)BR;
     const bool ragged_k = RAG && (a.ld16 % KS) != 0;  // last slab reaches past ld16: clamp columns (they meet zeros in the query image)
 
-    uint32_t v_rowoff[VPW], v_col[VPW];
-#pragma unroll
-    for (int j = 0; j < VPW; ++j) {
-        const uint32_t r = (wave * VPW + j) * 8 + (lane >> 3);  // row inside the tile
-        v_rowoff[j] = r;
-        v_col[j] = ((lane & 7) ^ ((r >> 1) & 7)) * EPS;          // physical 16-B slot -> logical element column
-    }
-    const char* v_src[VPW];  // row pointers (incl. swizzled column) of the tile being issued
-    const char* q_src[QPW];
+    // DMA addressing: every source address is a UNIFORM 64-bit base (tile / slab / piece: SGPRs) plus a 32-bit per-lane
+    // byte offset (one VGPR per piece) — the saddr form of global_load_lds.  (64-bit per-lane pointers cost 16 VGPRs
+    // more; the 256 x 256 IP tiling has none to spare.)
+    uint32_t v_off[VPW];       // row pieces: ((row slot, clamped to the last valid row) * ld16 + swizzled column) * ES
+    const char* v_base = nullptr;  // uniform: first row of the tile being issued
+    const char* q_base = nullptr;  // uniform: query image of the tile being issued
+    const uint32_t q_lane = lane * 16;
     uint32_t q_piece[QPW];  // uniform
 #pragma unroll
     for (int j = 0; j < QPW; ++j) q_piece[j] = ((wave * QPW + j) % Q_INSTR) * 1024;
+    auto v_swz_col = [&](int j) -> uint32_t {  // physical 16-B slot -> logical element column of this lane's piece
+        const uint32_t r = (wave * VPW + j) * 8 + (lane >> 3);
+        return ((lane & 7) ^ ((r >> 1) & 7)) * EPS;
+    };
     // row stream position
     uint32_t vs_tile = blockIdx.x, vs_slab = 0, vs_stage = 0, vs_count = 0, vs_tileseq = 0;
     // query stream position
@@ -1082,38 +1089,41 @@ __global__ void __launch_bounds__(WQ * WR * 64, (TQ * TR >= 16) ? 1 : ((WQ * WR 
                 glds16<0>(norm_src + rbase + lane * 4, smem + NORM_RING + (vs_tileseq % NORM_SLOTS) * 1024);
             ++vs_tileseq;
         }
+        v_base = reinterpret_cast<const char*>(a.V16) + (size_t)rbase * a.ld16 * ES;
+        const uint32_t span = last - rbase;  // rows past `last` re-read it (masked in the epilogue)
 #pragma unroll
         for (int j = 0; j < VPW; ++j) {
-            uint32_t row = rbase + v_rowoff[j];
-            row = row < last ? row : last;  // clamped rows are masked in the epilogue
-            v_src[j] = reinterpret_cast<const char*>(a.V16) + ((size_t)row * a.ld16 + v_col[j]) * ES;
+            uint32_t r = (wave * VPW + j) * 8 + (lane >> 3);  // row slot inside the tile
+            r = r < span ? r : span;
+            v_off[j] = (r * a.ld16 + v_swz_col(j)) * ES;
         }
     };
     auto q_enter_tile = [&]() {
-        const char* qbase = reinterpret_cast<const char*>(a.Q16);
+        q_base = reinterpret_cast<const char*>(a.Q16);
         if (TILED) {
             const IvfTile td = a.tiles[qs_tile];
-            qbase += (size_t)td.qimg_off * 2;
+            q_base += (size_t)td.qimg_off * 2;
             qs_qslab = BQ * LINE;
         }
-#pragma unroll
-        for (int j = 0; j < QPW; ++j) q_src[j] = qbase + q_piece[j] + lane * 16;
     };
     // piece p of a slab step: 0..QPW-1 query-image pieces, QPW..OPS-1 row pieces
     auto issue_piece = [&](int p) {
         if (p < QPW) {
-            if (!(DBG & 4)) glds16<0>(q_src[p] + qs_slab * qs_qslab, smem + Q_RING + qs_stage * Q_BYTES + q_piece[p]);
+            if (!(DBG & 4)) glds16<0>(q_base + ((size_t)qs_slab * qs_qslab + q_piece[p]) + q_lane, smem + Q_RING + qs_stage * Q_BYTES + q_piece[p]);
         } else {
             if (DBG & 8) return;
             const int j = p - QPW;
             const uint32_t koff = vs_slab * KS;
-            const char* src = v_src[j] + (size_t)koff * ES;
-            if (ragged_k) {
-                uint32_t col = koff + v_col[j];
+            uint32_t off = v_off[j];
+            if (ragged_k) {  // the last slab reaches past ld16: clamp the column (it meets zeros in the query image)
+                const uint32_t c0 = v_swz_col(j);
+                uint32_t col = koff + c0;
                 col = col < a.ld16 ? col : a.ld16 - EPS;
-                src = v_src[j] + ((size_t)col - v_col[j]) * ES;
+                off = v_off[j] + (col - koff - c0) * ES;   // (wraps for clamped columns: 32-bit arithmetic, added below)
+                glds16<NT_HINT>(v_base + (size_t)koff * ES + (size_t)(int64_t)(int32_t)(off - v_off[j]) + v_off[j], smem + vs_stage * V_BYTES + (wave * VPW + j) * 1024);
+                return;
             }
-            glds16<NT_HINT>(src, smem + vs_stage * V_BYTES + (wave * VPW + j) * 1024);
+            glds16<NT_HINT>(v_base + (size_t)koff * ES + off, smem + vs_stage * V_BYTES + (wave * VPW + j) * 1024);
         }
     };
     // past the end the last real step is re-issued (keeps the per-wave DMA count uniform)
@@ -1153,21 +1163,53 @@ __global__ void __launch_bounds__(WQ * WR * 64, (TQ * TR >= 16) ? 1 : ((WQ * WR 
     const int a_base = (wr * (TR * 32) + l32) * LINE;
     const int b_base = (wq * (TQ * 32) + l32) * LINE;
 
-    float c_qinv[TQ], c_thr[TQ], c_extra[TQ];
+    // Per-query constants kept in registers across the MFMA loop: 1 / scale, |q|^2 or 1 / |q|, and c_pre — the threshold
+    // of LEVEL 1 of the two-level epilogue filter.  Level 1 reduces the accumulators of a query column to ONE value that
+    // is monotone in the score (IP: the raw accumulator; L2: 2 q.v - |v|^2; cosine: q.v / |v|) with v_max3 and compares
+    // it with the per-query threshold mapped into that space and LOOSENED by more than the rounding differences between
+    // this form and the exact score expression: level 1 never rejects a row level 2 would accept.  Only column blocks with
+    // a hit run level 2 (the exact expression against the exact threshold, re-read from memory, + emission).
+    // c_pre = -inf: always run level 2.
+    float c_qinv[TQ], c_pre[TQ], c_extra[TQ];
     bool c_ok[TQ];
+    auto set_pre = [&](int j, float thr) {
+        float pre = -LY_INF;
+        if (!I8 && c_ok[j]) {
+            const float qi = c_qinv[j];
+            if (METRIC == M_IP) {
+                pre = thr / qi;                                   // qinv is a power of two: exact
+                pre = pre - fabsf(pre) * 1e-6f;
+            } else if (METRIC == M_L2) {
+                const float qn2 = c_extra[j];
+                pre = (qn2 - thr) - 2e-6f * (qn2 + fabsf(thr) + a.vmax2);
+                if (!(a.vmax2 > 0.0f)) pre = -LY_INF;
+            } else {
+                const float den = qi * c_extra[j];                // qinv / |q|
+                pre = ((1.0f - thr) - 1e-6f * (1.0f + fabsf(thr))) / den;
+                pre = pre - fabsf(pre) * 2e-6f;
+                if (!(den > 0.0f)) pre = -LY_INF;
+            }
+            if (!(fabsf(pre) < 3.0e38f)) pre = -LY_INF;           // inf / NaN (open threshold, overflow): no pre-filter
+        }
+        c_pre[j] = pre;
+    };
+    auto load_thr = [&](int j, uint32_t n) -> float {
+        float thr = c_ok[j] ? a.thr[n] : 0.0f;
+        if (a.debug_flags & 2) thr = ASC ? -LY_INF : LY_INF;
+        return thr;
+    };
 #pragma unroll
     for (int j = 0; j < TQ; ++j) {
         const uint32_t n = wq * (TQ * 32) + j * 32 + l32;
         c_ok[j] = !TILED && n < a.nq;
         c_qinv[j] = c_ok[j] ? a.qinv[n] : 0.0f;
-        c_thr[j] = c_ok[j] ? a.thr[n] : 0.0f;
-        if (a.debug_flags & 2) c_thr[j] = ASC ? -LY_INF : LY_INF;
         c_extra[j] = 0.0f;
         if (METRIC == M_L2 || I8) c_extra[j] = c_ok[j] ? a.qn2[n] : 0.0f;  // I8: the per-query integer constant, as bits
         if (METRIC == M_COS && !I8) c_extra[j] = c_ok[j] ? a.qrinv[n] : 0.0f;
+        set_pre(j, load_thr(j, n));
     }
 #pragma unroll
-    for (int j = 0; j < TQ; ++j) asm volatile("" : "+v"(c_qinv[j]), "+v"(c_thr[j]), "+v"(c_extra[j]));
+    for (int j = 0; j < TQ; ++j) asm volatile("" : "+v"(c_qinv[j]), "+v"(c_pre[j]), "+v"(c_extra[j]));
 
     // Prologue: the issue order of the steady state (per step: queries(s+NSQ-1), then rows(s+NSV-1))
     v_enter_tile();
@@ -1289,9 +1331,9 @@ __global__ void __launch_bounds__(WQ * WR * 64, (TQ * TR >= 16) ? 1 : ((WQ * WR 
                     c_ok[j] = n < td.nq;
                     n = c_ok[j] ? a.pair_q[td.pair0 + n] : 0u;
                     c_qinv[j] = c_ok[j] ? a.qinv[n] : 0.0f;
-                    c_thr[j] = c_ok[j] ? a.thr[n] : 0.0f;
                     if (METRIC == M_L2) c_extra[j] = c_ok[j] ? a.qn2[n] : 0.0f;
                     if (METRIC == M_COS) c_extra[j] = c_ok[j] ? a.qrinv[n] : 0.0f;
+                    set_pre(j, load_thr(j, n));
                 }
                 if (WR >= 4 && !FILT && a.emit_all == 2 && !TILED) {  // (compiled out of the <4,2,2,4> tiling and the subset-filter variants: it would spill there)
                     // threshold-only sample stage: each lane keeps the best LM of its TR*16 rows for this query column
@@ -1349,6 +1391,41 @@ __global__ void __launch_bounds__(WQ * WR * 64, (TQ * TR >= 16) ? 1 : ((WQ * WR 
                         }
                     }
                 } else {
+                    // ---- level 1
+                    float best = -LY_INF;
+                    if constexpr (!I8) {
+#pragma unroll
+                        for (int i = 0; i < TR; ++i) {
+#pragma unroll
+                            for (int g4 = 0; g4 < 4; ++g4) {
+                                float nv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+                                if constexpr (METRIC != M_IP) {
+                                    const uint32_t off = wr * (TR * 32) + i * 32 + 8 * g4 + 4 * hi;  // rows off .. off+3 <-> r = 4 g4 .. 4 g4 + 3
+                                    if (NORMS_LDS) {
+                                        const f32x4 t4 = *reinterpret_cast<const f32x4*>(nrm + off);
+                                        nv[0] = t4[0]; nv[1] = t4[1]; nv[2] = t4[2]; nv[3] = t4[3];
+                                    } else {
+#pragma unroll
+                                        for (int e = 0; e < 4; ++e) {
+                                            const uint32_t m = rbase + off + e;
+                                            nv[e] = m < row_end ? (METRIC == M_L2 ? a.vn2[m] : a.vrinv[m]) : 0.0f;
+                                        }
+                                    }
+                                }
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) {
+                                    float pv = acc[i][j][4 * g4 + e];
+                                    if (METRIC == M_L2) pv = __fmaf_rn(pv, 2.0f * c_qinv[j], -nv[e]);
+                                    if (METRIC == M_COS) pv = pv * nv[e];
+                                    best = fmaxf(best, pv);
+                                }
+                            }
+                        }
+                    }
+                    const bool hit = c_ok[j] && (I8 || best >= c_pre[j]);
+                    if (__ballot(hit) != 0ull) {
+                    // ---- level 2: the exact expression against the exact threshold
+                    const float e_thr = load_thr(j, n);
 #pragma unroll
                     for (int i = 0; i < TR; ++i) {
                         uint32_t msk = 0;
@@ -1359,7 +1436,7 @@ __global__ void __launch_bounds__(WQ * WR * 64, (TQ * TR >= 16) ? 1 : ((WQ * WR 
                             const uint32_t m = rbase + wr * (TR * 32) + i * 32 + bit;
                             const bool rok = m < row_end && ((mw >> bit) & 1u);
                             const float sc = score(i, j, r, m, rok);
-                            bool pass = ASC ? (sc <= c_thr[j]) : (sc >= c_thr[j]);
+                            bool pass = ASC ? (sc <= e_thr) : (sc >= e_thr);
                             if (FILT && TILED && a.mask && c_ok[j] && rok && pass)  // IVF subset filter: mask by slab position, looked up
                                 pass = (a.mask[m >> 5] >> (m & 31)) & 1u;     // only for rows that beat the threshold
                             if (c_ok[j] && rok && pass) msk |= 1u << r;
@@ -1376,6 +1453,7 @@ __global__ void __launch_bounds__(WQ * WR * 64, (TQ * TR >= 16) ? 1 : ((WQ * WR 
                                 }
                             }
                         }
+                    }
                     }
                 }
 #pragma unroll

@@ -726,6 +726,7 @@ static std::vector<Stage> make_plan(const lynse_hip_flat* h, uint32_t k, int lev
     return plan;
 }
 
+#ifdef LYNSE_EXPERIMENTS  // launchers of the superseded scan kernels (A/B references)
 template <int WQ, int WR, int TQ, int TR, int PD>
 static int launch_scan(lynse_hip_flat* h, const ScanArgs& a, int metric, uint32_t grid, hipStream_t st) {
     constexpr int NT = WQ * WR * 64;
@@ -780,6 +781,8 @@ static int launch_scan_glds(const ScanArgs& a, int metric, bool scale, uint32_t 
 #undef LY_GO
 }
 
+#endif  // LYNSE_EXPERIMENTS
+
 static unsigned long long* g_dbg_ptr = nullptr;
 extern "C" int lynse_hip_debug_phase_cycles(unsigned long long* out, int n) {  // experiments only (not in the header)
     if (!g_dbg_ptr) return 1;
@@ -789,8 +792,12 @@ extern "C" int lynse_hip_debug_phase_cycles(unsigned long long* out, int n) {  /
 // 3 = LDS-DMA ring kernel over the f16 shadow rows (default), 0 = LDS-DMA ring kernel over the f32 rows,
 // 1 / 2 = register-staged kernel with prefetch depth 1 / 2
 static int scan_variant() {
+#ifdef LYNSE_EXPERIMENTS
     static const int v = []() { const char* e = getenv("LYNSE_HIP_SCAN_VARIANT"); return e ? atoi(e) : 3; }();
     return v;
+#else
+    return 3;  // the superseded variants are only compiled with make EXPERIMENTS=1
+#endif
 }
 
 // k_scan_h16 launcher: LDS = NSV row stages + NSQ query stages + the norm ring (NSV+1 slots of 1 KiB) when it fits
@@ -1058,7 +1065,7 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
             a.qpad = qpad; a.nq = nq; a.nslab = nslab; a.ntiles = (s.r1 - s.r0 + tile_rows - 1) / tile_rows;
             if (s.sample_tiles) a.ntiles = s.sample_tiles;
             a.qinv = w.qinv; a.qn2 = w.qn2; a.qrinv = w.qrinv; a.thr = w.thr; a.vn2 = h->vn2; a.vrinv = h->vrinv;
-            a.sv = h->sv; a.cand = w.cand; a.count = w.count; a.cap = w.cap; a.emit_all = emit_all ? 1 : 0;
+            a.sv = h->sv; a.vmax2 = h->vmax * h->vmax; a.cand = w.cand; a.count = w.count; a.cap = w.cap; a.emit_all = emit_all ? 1 : 0;
             // sampled plan: the sample stage only has to produce a threshold -> one key per lane (its best row) instead of
             // every score, as long as that leaves at least k keys per query
             if (sample_threshold_only && s.sample_tiles) a.emit_all = 2;
@@ -1088,36 +1095,27 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
                     if (waves16 == 3 || waves16 == 2) LY_TRY((launch_scan_h16<2, 4, 4, 2, 3, 2, false>(a, metric, grid, st)));
                     else LY_TRY((launch_scan_h16<4, 2, 2, 4, 2, 2, false>(a, metric, grid, st)));
                 }
-            } else if (glds) {
+            }
+#ifdef LYNSE_EXPERIMENTS
+            else if (glds) {
                 const bool scale = h->sv != 1.0f;
                 if (small) {
                     const uint32_t grid = std::min<uint32_t>(a.ntiles, (uint32_t)h->num_cu * 2);
                     LY_TRY((launch_scan_glds<1, 4, 1, 1, 4>(a, metric, scale, grid, st)));
-#ifdef LYNSE_EXPERIMENTS
                 } else if (tile_rows == 192) {
                     const uint32_t grid = std::min<uint32_t>(a.ntiles, (uint32_t)h->num_cu);
                     LY_TRY((launch_scan_glds<4, 2, 2, 3, 4>(a, metric, scale, grid, st)));
-#endif
                 } else if (tile_rows == 256) {
-                    static const int waves16 = []() { const char* e = getenv("LYNSE_HIP_SCAN_W16"); return e ? atoi(e) : 2; }();
+                    static const int gw16 = []() { const char* e = getenv("LYNSE_HIP_SCAN_W16"); return e ? atoi(e) : 2; }();
                     const uint32_t grid = std::min<uint32_t>(a.ntiles, (uint32_t)h->num_cu);
-                    (void)waves16;
-#ifdef LYNSE_EXPERIMENTS
-                    if (waves16 == 3) LY_TRY((launch_scan_glds<1, 8, 8, 1, 3>(a, metric, scale, grid, st)));
-                    else if (waves16 == 0) LY_TRY((launch_scan_glds<4, 2, 2, 4, 3>(a, metric, scale, grid, st)));
-                    else
-#endif
-                    LY_TRY((launch_scan_glds<2, 4, 4, 2, 3>(a, metric, scale, grid, st)));
+                    if (gw16 == 3) LY_TRY((launch_scan_glds<1, 8, 8, 1, 3>(a, metric, scale, grid, st)));
+                    else if (gw16 == 0) LY_TRY((launch_scan_glds<4, 2, 2, 4, 3>(a, metric, scale, grid, st)));
+                    else LY_TRY((launch_scan_glds<2, 4, 4, 2, 3>(a, metric, scale, grid, st)));
                 } else {
-#ifdef LYNSE_EXPERIMENTS
                     const uint32_t grid = std::min<uint32_t>(a.ntiles, (uint32_t)h->num_cu);
                     LY_TRY((launch_scan_glds<4, 2, 2, 2, 4>(a, metric, scale, grid, st)));
-#else
-                    return set_error(LYNSE_ERR_UNSUPPORTED, "this tile size of the f32 scan needs a build with -DLYNSE_EXPERIMENTS (make EXPERIMENTS=1)");
-#endif
                 }
             } else {
-#ifdef LYNSE_EXPERIMENTS
                 if (small) {
                     const uint32_t grid = std::min<uint32_t>(a.ntiles, (uint32_t)h->num_cu * 3);
                     if (variant == 1) LY_TRY((launch_scan<1, 4, 1, 1, 1>(h, a, metric, grid, st)));
@@ -1127,11 +1125,9 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
                     if (variant == 1) LY_TRY((launch_scan<4, 2, 2, 2, 1>(h, a, metric, grid, st)));
                     else LY_TRY((launch_scan<4, 2, 2, 2, 2>(h, a, metric, grid, st)));
                 }
-#else
-                (void)variant;
-                return set_error(LYNSE_ERR_UNSUPPORTED, "the register-staged scan variants need a build with -DLYNSE_EXPERIMENTS (make EXPERIMENTS=1)");
-#endif
             }
+#endif
+            (void)variant;
         }
         if (h->profiling) {
             LY_HIP(hipEventRecord(e1, st));
