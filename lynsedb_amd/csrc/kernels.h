@@ -406,6 +406,14 @@ struct ScanArgs {
     const float *vn2, *vrinv;
     float sv;
     float vmax2;  // max squared row norm of the store: rounding slack of the L2 pre-filter (0 = unknown -> pre-filter off)
+    // Segmented emission (threshold stages of the FLAT scan, not the IVF work-list mode): every (workgroup, row-wave) owns
+    // a private segment of `seg` key slots per query in candB — slots are handed out from a per-lane register counter, no
+    // atomic and no wait in the epilogue; at the end each wave stores its per-query counts (u8) to segcnt[q][segment] and
+    // k_select gathers.  A segment that would overflow falls back to the shared region of `cand` (returning atomic on
+    // count[q]) for that block.  seg == 0: every key goes through the atomic path.
+    uint64_t* candB;     // [q][nseg][seg]
+    uint8_t* segcnt;     // [q][nseg]
+    uint32_t seg, nseg;
     uint64_t* cand;
     uint32_t* count;
     uint32_t cap;
@@ -1150,6 +1158,8 @@ __global__ void __launch_bounds__(WQ * WR * 64, (TQ * TR >= 16) ? 1 : ((WQ * WR 
         }
     };
 
+    uint32_t segpk = 0;  // segmented emission: this lane's TQ per-query slot counters, 8 bits each
+    static_assert(TQ <= 4, "packed segment counters");
     f32x16 acc[TR][TQ];
 #pragma unroll
     for (int i = 0; i < TR; ++i)
@@ -1424,8 +1434,9 @@ __global__ void __launch_bounds__(WQ * WR * 64, (TQ * TR >= 16) ? 1 : ((WQ * WR 
                     }
                     const bool hit = c_ok[j] && (I8 || best >= c_pre[j]);
                     if (__ballot(hit) != 0ull) {
-                    // ---- level 2: the exact expression against the exact threshold
+                    // ---- level 2: the exact expression against the exact threshold; pass masks of the block's TR x 16 rows
                     const float e_thr = load_thr(j, n);
+                    uint32_t mk[TR], tot = 0;
 #pragma unroll
                     for (int i = 0; i < TR; ++i) {
                         uint32_t msk = 0;
@@ -1441,15 +1452,43 @@ __global__ void __launch_bounds__(WQ * WR * 64, (TQ * TR >= 16) ? 1 : ((WQ * WR 
                                 pass = (a.mask[m >> 5] >> (m & 31)) & 1u;     // only for rows that beat the threshold
                             if (c_ok[j] && rok && pass) msk |= 1u << r;
                         }
-                        if (msk) {
-                            const uint32_t base = atomicAdd(&a.count[n], (uint32_t)__popc(msk));
+                        mk[i] = msk;
+                        tot += (uint32_t)__popc(msk);
+                    }
+                    // slots: the private segment of this (workgroup, row-wave) while it has room — the two half-waves share a
+                    // query column, lanes 0..31 take the first slots — else ONE reservation in the shared region
+                    uint64_t* dst = a.cand + (size_t)n * a.cap;
+                    uint32_t slot = 0, limit = 0;
+                    bool segmented = false;
+                    if (!TILED && a.seg) {
+                        const uint32_t other = (uint32_t)__shfl_xor((int)tot, 32, 64);
+                        const uint32_t c = (segpk >> (8 * j)) & 0xffu;
+                        const uint32_t both = tot + other;
+                        if (c + both <= a.seg) {
+                            segmented = true;
+                            dst = a.candB + ((size_t)n * a.nseg + (blockIdx.x * WR + wr)) * a.seg;
+                            slot = c + (hi ? other : 0u);
+                            limit = a.seg;
+                            segpk += both << (8 * j);
+                        }
+                    }
+                    if (!segmented && tot) {
+                        slot = atomicAdd(&a.count[n], tot);
+                        limit = a.cap;
+                    }
+                    if (tot) {
 #pragma unroll
-                            for (int r = 0; r < 16; ++r) {
-                                if ((msk >> r) & 1u) {
-                                    const uint32_t m = rbase + wr * (TR * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                                    const uint32_t slot = base + (uint32_t)__popc(msk & ((1u << r) - 1u));
-                                    if (slot < a.cap)
-                                        a.cand[(size_t)n * a.cap + slot] = make_key(score(i, j, r, m, true), (FILT && !TILED && a.row_ids) ? a.row_ids[m] : m, ASC);
+                        for (int i = 0; i < TR; ++i) {
+                            const uint32_t msk = mk[i];
+                            if (msk) {
+#pragma unroll
+                                for (int r = 0; r < 16; ++r) {
+                                    if ((msk >> r) & 1u) {
+                                        const uint32_t m = rbase + wr * (TR * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                                        if (slot < limit)
+                                            dst[slot] = make_key(score(i, j, r, m, true), (FILT && !TILED && a.row_ids) ? a.row_ids[m] : m, ASC);
+                                        ++slot;
+                                    }
                                 }
                             }
                         }
@@ -1472,6 +1511,13 @@ __global__ void __launch_bounds__(WQ * WR * 64, (TQ * TR >= 16) ? 1 : ((WQ * WR 
     if (timing && lane == 0) {
         unsigned long long* o = a.dbg + ((size_t)blockIdx.x * NW + wave) * 4;
         o[0] = t_wait; o[1] = t_bar; o[2] = 0; o[3] = t_comp;
+    }
+    if (!TILED && a.seg && hi == 0) {
+#pragma unroll
+        for (int j = 0; j < TQ; ++j) {
+            const uint32_t n = wq * (TQ * 32) + j * 32 + l32;
+            if (n < a.nq) a.segcnt[(size_t)n * a.nseg + (blockIdx.x * WR + wr)] = (uint8_t)((segpk >> (8 * j)) & 0xffu);
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
@@ -2014,6 +2060,11 @@ struct SelectArgs {
     int keep_ties;   // IVF: rows are not scanned in id order -> the cut must let ties of the k-th score through
     int drop_sentinels;  // filtered search: the emit-all stage wrote KEY_SENTINEL for rows outside the subset
     int threshold_only;  // lane-max sample stage: derive the threshold, keep NO candidate (the rows are scanned again)
+    // segmented emission of the scan stage that ran before this select (ScanArgs::candB / segcnt): nseg segments of
+    // `seg` slots per query, segcnt[q][s] keys in segment s.  nseg == 0: none.
+    const uint64_t* candB;
+    const uint8_t* segcnt;
+    uint32_t seg, nseg;
     const float* Qf;
     const float* V;
     uint32_t ld, D;
@@ -2060,6 +2111,47 @@ __global__ void __launch_bounds__(NT) k_select(SelectArgs a) {
         __syncthreads();
         n = s_keep;
         compacted = true;
+        __syncthreads();
+    }
+    if (a.nseg) {  // gather the private segments of the scan stage behind the keys of the shared region
+        __shared__ uint32_t s_wsum[NT / 64];
+        if (!compacted)
+            for (uint32_t i = tid; i < n; i += NT) keys[i] = gkeys[i];
+        const uint32_t per = (a.nseg + NT - 1) / NT;
+        const uint32_t s0 = tid * per < a.nseg ? tid * per : a.nseg;
+        const uint32_t s1 = s0 + per < a.nseg ? s0 + per : a.nseg;
+        const uint8_t* sc = a.segcnt + (size_t)q * a.nseg;
+        uint32_t mine = 0;
+        for (uint32_t sgm = s0; sgm < s1; ++sgm) mine += sc[sgm];
+        uint32_t incl = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t up = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += up;
+        }
+        if (lane == 63) s_wsum[tid >> 6] = incl;
+        __syncthreads();
+        uint32_t wbase = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < NT / 64; ++w) {
+            const uint32_t ws = s_wsum[w];
+            if (w < (tid >> 6)) wbase += ws;
+            total += ws;
+        }
+        uint32_t off = n + wbase + incl - mine;
+        for (uint32_t sgm = s0; sgm < s1; ++sgm) {
+            const uint32_t c = sc[sgm];
+            const uint64_t* src = a.candB + ((size_t)q * a.nseg + sgm) * a.seg;
+            for (uint32_t i = 0; i < c; ++i, ++off)
+                if (off < a.cap) keys[off] = src[i];
+        }
+        if (n + total > a.cap) {
+            if (tid == 0) a.overflow[q] = 1u;
+            n = a.cap;
+        } else {
+            n += total;
+        }
+        compacted = true;  // the keys live in LDS only: every exit below writes them back
         __syncthreads();
     }
     if (n < a.k || a.k == 0) {  // fewer than k candidates so far: keep all, the threshold stays open

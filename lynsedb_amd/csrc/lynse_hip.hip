@@ -133,6 +133,8 @@ constexpr size_t H_OUT_BYTES = 96 * 1024;  // results up to this size come back 
 struct Workspace {
     uint32_t qcap = 0, cap = 0, D = 0, W = 0, kcap = 0;
     uint64_t* cand = nullptr;
+    uint64_t* candB = nullptr;   // segmented emission: [QCHUNK][SEG_KEYS] keys (ScanArgs::candB)
+    uint8_t* segcnt = nullptr;   // [QCHUNK][SEG_MAX] per-segment key counts
     uint32_t *count = nullptr, *overflow = nullptr;
     float *thr = nullptr, *qinv = nullptr, *qn2 = nullptr, *qrinv = nullptr, *marg2 = nullptr;
     _Float16* Q16 = nullptr;
@@ -149,7 +151,7 @@ struct Workspace {
     void release() {
         if (h_hdr) (void)hipHostFree(h_hdr);
         if (h_out) (void)hipHostFree(h_out);
-        for (void* p : {(void*)cand, (void*)count, (void*)thr, (void*)qinv, (void*)qn2,
+        for (void* p : {(void*)cand, (void*)candB, (void*)segcnt, (void*)count, (void*)thr, (void*)qinv, (void*)qn2,
                         (void*)qrinv, (void*)marg2, (void*)Q16, (void*)Qf, (void*)QW, (void*)QWp, (void*)out_rows,
                         (void*)out_dists, (void*)out_counts, (void*)pool_total})
             if (p) (void)hipFree(p);
@@ -611,6 +613,17 @@ extern "C" int lynse_hip_flat_profile_get(lynse_hip_flat* h, lynse_hip_profile* 
 // ------------------------------------------------------------------------------------- search ----
 constexpr uint32_t QCHUNK = 256;
 constexpr int SEL_NT = 512;
+constexpr uint32_t SEG_KEYS = 32768;  // keys per query in the segmented-emission buffer
+constexpr uint32_t SEG_MAX = 2048;    // most segments per query (grid x row-waves: 512 x 4 for the <= 32-query kernel)
+
+// segments of one scan launch: grid x WR of min(255, SEG_KEYS / nseg) slots
+static void seg_geometry(uint32_t grid, uint32_t wr, uint32_t* nseg, uint32_t* seg) {
+    *nseg = grid * wr;
+    *seg = 0;
+    static const int off = []() { const char* e = getenv("LYNSE_HIP_NO_SEGMENTS"); return e ? atoi(e) : 0; }();
+    if (off || *nseg == 0 || *nseg > SEG_MAX) { *nseg = 0; return; }
+    *seg = std::min<uint32_t>(255u, SEG_KEYS / *nseg);
+}
 
 static size_t scan_lds_bytes(int bq) { return (size_t)2 * (SCAN_BR + bq) * SCAN_LDK * sizeof(_Float16); }
 
@@ -631,6 +644,8 @@ static int ensure_workspace(lynse_hip_flat* h, uint32_t k /* caller's k = output
     w.W = h->words;
     w.kcap = std::max<uint32_t>(k, 128);
     LY_HIP(hipMalloc(&w.cand, (size_t)QCHUNK * w.cap * 8));
+    LY_HIP(hipMalloc(&w.candB, (size_t)QCHUNK * SEG_KEYS * 8));
+    LY_HIP(hipMalloc(&w.segcnt, (size_t)QCHUNK * SEG_MAX));
     LY_HIP(hipMalloc(&w.count, QCHUNK * 4));
     LY_HIP(hipMalloc(&w.thr, QCHUNK * 4));
     LY_HIP(hipMalloc(&w.qinv, QCHUNK * 4));
@@ -1025,6 +1040,7 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
             LY_TRY(get_event(h, (*ev_used)++, &e1));
             LY_HIP(hipEventRecord(e0, st));
         }
+        uint32_t st_nseg = 0, st_seg = 0;  // segmented emission of this stage (k_select gathers)
         if (binary) {
             BinArgs b{};
             b.P = h->packed; b.W = h->words; b.row0 = s.r0; b.row1 = s.r1; b.QW = w.QW; b.nq = nq;
@@ -1083,11 +1099,14 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
             }
             const int variant = scan_variant();
             if (h16) {
+                a.candB = w.candB; a.segcnt = w.segcnt;
                 if (small) {
                     const uint32_t grid = std::min<uint32_t>(a.ntiles, (uint32_t)h->num_cu * 2);
+                    if (!a.emit_all) seg_geometry(grid, 4, &a.nseg, &a.seg);
                     LY_TRY((launch_scan_h16<1, 4, 1, 1, 3, 3, false>(a, metric, grid, st)));
                 } else {
                     const uint32_t grid = std::min<uint32_t>(a.ntiles, (uint32_t)h->num_cu);
+                    if (!a.emit_all) seg_geometry(grid, (waves16 == 3 || waves16 == 2) ? 4 : 2, &a.nseg, &a.seg);
 #ifdef LYNSE_EXPERIMENTS
                     if (waves16 == 2) LY_TRY((launch_scan_h16<2, 4, 4, 2, 2, 2, false>(a, metric, grid, st)));
                     else
@@ -1128,6 +1147,7 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
             }
 #endif
             (void)variant;
+            st_nseg = a.seg ? a.nseg : 0; st_seg = a.seg;
         }
         if (h->profiling) {
             LY_HIP(hipEventRecord(e1, st));
@@ -1145,6 +1165,7 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
             sa.emit_all_n = (int)(s.sample_tiles * sample_keys_per_tile);
         }
         sa.Qf = w.Qf; sa.V = h->rows; sa.ld = h->ld; sa.D = h->dim;
+        sa.candB = w.candB; sa.segcnt = w.segcnt; sa.seg = st_seg; sa.nseg = st_nseg;
         hipLaunchKernelGGL(k_select<SEL_NT>, dim3(nq), dim3(SEL_NT), (size_t)w.cap * 8, st, sa);
         LY_HIP(hipGetLastError());
     }
@@ -1237,6 +1258,8 @@ static int run_chunk_sq8(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t ou
         a.vn2 = reinterpret_cast<const float*>(ip ? h->sq8_sum : h->sq8_sum2); a.vrinv = a.vn2;
         a.sv = 1.0f; a.cand = w.cand; a.count = w.count; a.cap = w.cap; a.emit_all = si == 0 ? 1 : 0;
         const uint32_t grid = std::min<uint32_t>(a.ntiles, (uint32_t)h->num_cu);
+        a.candB = w.candB; a.segcnt = w.segcnt;
+        if (!a.emit_all) seg_geometry(grid, 2, &a.nseg, &a.seg);
         constexpr size_t lds = (size_t)(2 * 256 + 2 * 256) * 128 + 3 * 1024;
         static bool a2[2] = {false, false};
         if (ip) {
@@ -1254,6 +1277,7 @@ static int run_chunk_sq8(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t ou
         sa.k = n_cand; sa.cap = w.cap; sa.keep_max = w.cap / 2; sa.metric = m1; sa.ip_form = LYNSE_IPFORM_SINGLE;
         sa.exact = 1; sa.emit_all_n = si == 0 ? (int)(s.r1 - s.r0) : -1;
         sa.Qf = w.Qf; sa.V = h->rows; sa.ld = h->ld; sa.D = h->dim;
+        sa.candB = w.candB; sa.segcnt = w.segcnt; sa.seg = a.seg; sa.nseg = a.seg ? a.nseg : 0;
         hipLaunchKernelGGL(k_select<SEL_NT>, dim3(nq), dim3(SEL_NT), (size_t)w.cap * 8, st, sa);
         LY_HIP(hipGetLastError());
     }
