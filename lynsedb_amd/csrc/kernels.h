@@ -1016,13 +1016,20 @@ constexpr int HK = 64;  // K elements per slab
 // cost registers the unfiltered kernel does not have to spare (56 B/lane of scratch and 13 % of its speed when they
 // were runtime branches).
 template <int WQ, int WR, int TQ, int TR, int METRIC, int NSV, int NSQ, int NT_HINT, bool TILED = false, bool RAG = true, int DBG = 0, bool FILT = false,
-          bool I8 = false>
+          int I8Q = 0>
 __global__ void __launch_bounds__(WQ * WR * 64, (TQ * TR >= 16) ? 1 : ((WQ * WR >= 8) ? (WQ * WR / 4) : 2)) k_scan_h16(ScanArgs a) {
     // Two LDS rings: NSV stages of row slabs (HBM latency: deeper) and NSQ <= NSV stages of query-image
     // slabs (L2 latency) — 3 + 2 stages of 32 KiB fill the 160 KiB of a CU for the 256 x 256 tile.
     // I8 = SQ8 pass 1 (FLAT-*-SQ8): rows and query image are signed bytes (code - 128), a slab is 128 elements = the same
     // 128 B per line, the MFMA is v_mfma_i32_32x32x32_i8 (exact integers), the epilogue rebuilds the u32 score of the
     // reference's u8 kernels (flat_mmap.rs:5847-5863) from the i8 dot product and per-row / per-query sums.
+    // I8Q = 2: CERTIFIED int8 coarse pass (FLAT-IP): rows are the same SQ8 codes, the query image is the symmetric int8
+    // image of w = q / scale (k_i8c_prep_queries); coarse score = B_q + s_q * (int dot), with a certified bound on its
+    // distance to the reference-order f32 score — half the HBM / LDS-DMA bytes and half the MFMA time of
+    // the f16 shadow; survivors are rescored exactly from the f32 rows as always.
+    constexpr bool I8 = I8Q != 0;           // int8 operands (SQ8 pass 1 or the certified coarse pass)
+    constexpr bool I8C = I8Q == 2;
+    static_assert(!I8C || METRIC == M_IP, "certified int8 coarse pass: IP only");
     constexpr int ES = I8 ? 1 : 2;          // element size in bytes
     constexpr int KS = 128 / ES;            // elements per slab
     constexpr int EPS = 16 / ES;            // elements per 16-B slot
@@ -1077,7 +1084,7 @@ __global__ void __launch_bounds__(WQ * WR * 64, (TQ * TR >= 16) ? 1 : ((WQ * WR 
     // query stream position
     uint32_t qs_tile = blockIdx.x, qs_slab = 0, qs_stage = 0, qs_count = 0;
     uint32_t qs_qslab = a.qpad * LINE;
-    constexpr bool NORMS_LDS = !TILED && (METRIC != M_IP || I8) && (NORM_RING + (NSV + 1) * 1024 <= 160 * 1024);
+    constexpr bool NORMS_LDS = !TILED && !I8C && (METRIC != M_IP || I8) && (NORM_RING + (NSV + 1) * 1024 <= 160 * 1024);
     constexpr int NORM_SLOTS = NSV + 1;
     const float* norm_src = (METRIC == M_L2 || I8) ? a.vn2 : a.vrinv;  // I8: a.vn2 carries the per-row int sums
 
@@ -1184,6 +1191,13 @@ __global__ void __launch_bounds__(WQ * WR * 64, (TQ * TR >= 16) ? 1 : ((WQ * WR 
     bool c_ok[TQ];
     auto set_pre = [&](int j, float thr) {
         float pre = -LY_INF;
+        if (I8C && c_ok[j]) {  // score = B_q + s_q * dot >= thr  <=>  dot >= (thr - B_q) / s_q: an integer compare, loosened by 2
+            const float t = (thr - c_extra[j]) / c_qinv[j] - 2.0f;
+            int ti = -2147483647 - 1;
+            if (t > 2.0e9f) ti = 2147483647;
+            else if (t > -2.0e9f) ti = (int)floorf(t);   // (NaN / -inf: stays at INT_MIN = always level 2)
+            pre = __int_as_float(ti);
+        }
         if (!I8 && c_ok[j]) {
             const float qi = c_qinv[j];
             if (METRIC == M_IP) {
@@ -1201,6 +1215,7 @@ __global__ void __launch_bounds__(WQ * WR * 64, (TQ * TR >= 16) ? 1 : ((WQ * WR 
             }
             if (!(fabsf(pre) < 3.0e38f)) pre = -LY_INF;           // inf / NaN (open threshold, overflow): no pre-filter
         }
+        if (I8C && !c_ok[j]) pre = __int_as_float(-2147483647 - 1);
         c_pre[j] = pre;
     };
     auto load_thr = [&](int j, uint32_t n) -> float {
@@ -1214,7 +1229,7 @@ __global__ void __launch_bounds__(WQ * WR * 64, (TQ * TR >= 16) ? 1 : ((WQ * WR 
         c_ok[j] = !TILED && n < a.nq;
         c_qinv[j] = c_ok[j] ? a.qinv[n] : 0.0f;
         c_extra[j] = 0.0f;
-        if (METRIC == M_L2 || I8) c_extra[j] = c_ok[j] ? a.qn2[n] : 0.0f;  // I8: the per-query integer constant, as bits
+        if (METRIC == M_L2 || I8) c_extra[j] = c_ok[j] ? a.qn2[n] : 0.0f;  // SQ8: the per-query integer constant, as bits; I8C: B_q
         if (METRIC == M_COS && !I8) c_extra[j] = c_ok[j] ? a.qrinv[n] : 0.0f;
         set_pre(j, load_thr(j, n));
     }
@@ -1315,7 +1330,9 @@ __global__ void __launch_bounds__(WQ * WR * 64, (TQ * TR >= 16) ? 1 : ((WQ * WR 
 #pragma unroll          // would pay the full memory latency behind the candidate stores)
             for (int i = 0; i < TR; ++i) mw_t[i] = (FILT && !TILED && a.mask) ? a.mask[(rbase + wr * (TR * 32) + i * 32) >> 5] : 0xffffffffu;
             auto score = [&](int i, int j, int r, uint32_t m, bool rok) -> float {
-                if constexpr (I8) {
+                if constexpr (I8C) {
+                    return c_extra[j] + c_qinv[j] * (float)__float_as_int(acc[i][j][r]);  // B_q + s_q * dot (separate mul / add)
+                } else if constexpr (I8) {
                     // dot of the u8 codes = i8 dot + 128 (sum q' + sum r') + 16384 D; squared L2 = sum q'^2 + sum r'^2 - 2 dot
                     const float accv = acc[i][j][r];
                     const int dotp = __float_as_int(accv);
@@ -1403,6 +1420,17 @@ __global__ void __launch_bounds__(WQ * WR * 64, (TQ * TR >= 16) ? 1 : ((WQ * WR 
                 } else {
                     // ---- level 1
                     float best = -LY_INF;
+                    if constexpr (I8C) {  // integer accumulators against the integer threshold
+                        int bi = -2147483647 - 1;
+#pragma unroll
+                        for (int i = 0; i < TR; ++i)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) {
+                                const int v = __float_as_int(acc[i][j][r]);
+                                bi = bi > v ? bi : v;
+                            }
+                        best = (bi >= __float_as_int(c_pre[j])) ? LY_INF : -LY_INF;
+                    }
                     if constexpr (!I8) {
 #pragma unroll
                         for (int i = 0; i < TR; ++i) {
@@ -1432,7 +1460,7 @@ __global__ void __launch_bounds__(WQ * WR * 64, (TQ * TR >= 16) ? 1 : ((WQ * WR 
                             }
                         }
                     }
-                    const bool hit = c_ok[j] && (I8 || best >= c_pre[j]);
+                    const bool hit = c_ok[j] && (I8C ? best > 0.0f : (I8 || best >= c_pre[j]));
                     if (__ballot(hit) != 0ull) {
                     // ---- level 2: the exact expression against the exact threshold; pass masks of the block's TR x 16 rows
                     const float e_thr = load_thr(j, n);
@@ -1566,23 +1594,35 @@ __device__ __forceinline__ int sq8_code(float v, float mn, float sc) {
 __global__ void __launch_bounds__(256) k_sq8_quantize(const float* __restrict__ V, uint32_t ld, uint32_t D, uint64_t n,
                                                       const float* __restrict__ mins, const float* __restrict__ scales,
                                                       int8_t* __restrict__ out, uint32_t ld8, int* __restrict__ sums,
-                                                      int* __restrict__ sums2) {
+                                                      int* __restrict__ sums2, uint32_t* __restrict__ stats) {
+    // stats[0] = max over rows of sum |code - 128| (the query-quantisation term of the certified int8 bound),
+    // stats[1] = number of non-finite elements (the certified int8 coarse pass is only valid without them)
     const int lane = threadIdx.x & 63;
     const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    uint32_t a1max = 0, nonfinite = 0;
     for (uint64_t row = wave; row < n; row += nwaves) {
-        int s1 = 0, s2 = 0;
+        int s1 = 0, s2 = 0, l1 = 0;
         for (uint32_t d = lane; d < ld8; d += 64) {
             int c = 0;
             if (d < D) {
-                c = sq8_code(V[row * ld + d], mins[d], scales[d]) - 128;
+                const float v = V[row * ld + d];
+                if (!(fabsf(v) < LY_INF)) nonfinite += 1;
+                c = sq8_code(v, mins[d], scales[d]) - 128;
                 s1 += c;
                 s2 += c * c;
+                l1 += c < 0 ? -c : c;
             }
             out[row * ld8 + d] = (int8_t)c;
         }
-        for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+        for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); l1 += __shfl_xor(l1, o, 64); }
         if (lane == 0) { sums[row] = s1; sums2[row] = s2; }
+        a1max = a1max > (uint32_t)l1 ? a1max : (uint32_t)l1;
+    }
+    for (int o = 32; o > 0; o >>= 1) nonfinite += __shfl_xor(nonfinite, o, 64);
+    if (lane == 0 && stats) {
+        atomicMax(&stats[0], a1max);
+        if (nonfinite) atomicAdd(&stats[1], nonfinite);
     }
 }
 
@@ -1618,6 +1658,102 @@ __global__ void __launch_bounds__(256) k_sq8_prep_queries(const float* __restric
         thr[q] = ip ? -LY_INF : LY_INF;
         count[q] = 0u;
         overflow[q] = 0u;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_i8c_prep_queries — query side of the CERTIFIED int8 coarse pass (FLAT-IP, k_scan_h16<.., I8Q = 2>).
+//
+// Rows are the SQ8 codes: v_d = min_d + (code_d + eps_d) / scale_d with |eps_d| <= 0.50004 (round + the two f32 roundings
+// of (v - min) * scale; exact for a constant dimension, scale_d = 0, up to its 1e-30 range).  With w_d = q_d / scale_d
+// (0 for constant dimensions), c'_d = code_d - 128 (what the shard stores) and the symmetric int8 image
+// w_d = s_q (u_d + eta_d), u_d = rint(w_d / s_q) in [-127, 127], |eta_d| <= 0.5:
+//     q . v = [sum q_d min_d + 128 sum w_d]  +  s_q sum u_d c'_d  +  s_q sum eta_d c'_d  +  sum w_d eps_d
+//           =            B_q                 +  s_q * (int dot)   +  (|.| <= 0.5 s_q A1)  +  (|.| <= 0.50004 sum |w_d|)
+// A1 = max over rows of sum |c'_d| (k_sq8_quantize).  The kernel evaluates B_q + s_q * dot in f32 (two roundings) and the
+// reference's own f32 accumulation differs from the real dot product by <= gamma |q| |v|: both go into E as well.
+// Everything per query is accumulated in f64 (products of f32 are exact there).  marg2 = 2 E like k_prep_queries.
+// Image layout = k_sq8_prep_queries ([slab of 128][q][8 slots ^ ((q>>1)&7)][16 B]).
+// ------------------------------------------------------------------------------------------------
+struct I8cPrepArgs {
+    const float* Q;
+    uint32_t D, qpad, nslab;
+    const float *mins, *scales;
+    uint32_t a1;         // max row L1 norm of the signed codes
+    float vmax;          // max row norm
+    int8_t* img;
+    float *sq, *bq, *marg2, *thr;  // s_q -> ScanArgs::qinv, B_q -> ScanArgs::qn2
+    uint32_t *count, *overflow;
+};
+
+__global__ void __launch_bounds__(256) k_i8c_prep_queries(I8cPrepArgs a) {
+    __shared__ double red[5][4];
+    __shared__ float s_sq;
+    const uint32_t q = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* qv = a.Q + (size_t)q * a.D;
+    double wmax = 0.0, sw = 0.0, swabs = 0.0, sqm = 0.0, s2 = 0.0;
+    for (uint32_t i = tid; i < a.D; i += 256) {
+        const double x = (double)qv[i];
+        const float sc = a.scales[i];
+        const double w = sc > 0.0f ? x / (double)sc : 0.0;
+        wmax = fmax(wmax, fabs(w));
+        sw += w;
+        swabs += fabs(w);
+        sqm += x * (double)a.mins[i];
+        s2 += x * x;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        wmax = fmax(wmax, __shfl_xor(wmax, o, 64));
+        sw += __shfl_xor(sw, o, 64);
+        swabs += __shfl_xor(swabs, o, 64);
+        sqm += __shfl_xor(sqm, o, 64);
+        s2 += __shfl_xor(s2, o, 64);
+    }
+    if (lane == 0) { red[0][wave] = wmax; red[1][wave] = sw; red[2][wave] = swabs; red[3][wave] = sqm; red[4][wave] = s2; }
+    __syncthreads();
+    if (tid == 0) {
+        wmax = fmax(fmax(red[0][0], red[0][1]), fmax(red[0][2], red[0][3]));
+        sw = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+        swabs = (red[2][0] + red[2][1]) + (red[2][2] + red[2][3]);
+        sqm = (red[3][0] + red[3][1]) + (red[3][2] + red[3][3]);
+        s2 = (red[4][0] + red[4][1]) + (red[4][2] + red[4][3]);
+        float sq = 1.0f;
+        if (wmax > 0.0 && wmax < 1.0e30) {
+            sq = (float)(wmax / 127.0);
+            if ((double)sq * 127.0 < wmax) sq = nextafterf(sq, LY_INF);  // |w_d| / s_q <= 127 for every d
+            if (!(sq > 0.0f)) sq = 1.1754944e-38f;
+        }
+        s_sq = sq;
+        const double bq = sqm + 128.0 * sw;
+        const float bqf = (float)bq;
+        const double a1 = (double)a.a1;
+        const double gam = 10.0 * (double)a.D * 5.9604645e-8;  // reference f32 accumulation order vs the real dot product
+        double E = 0.5001 * swabs + 0.5001 * (double)sq * a1 + 2.5e-7 * (fabs(bq) + 127.0 * (double)sq * a1) +
+                   gam * sqrt(s2) * (double)a.vmax;
+        E *= 1.02;
+        if (!(wmax < 1.0e30) || !(E == E) || E > 3.0e38) E = 3.0e38;
+        a.sq[q] = sq;
+        a.bq[q] = bqf;
+        a.marg2[q] = (float)(2.0 * E);
+        a.thr[q] = -LY_INF;
+        a.count[q] = 0u;
+        a.overflow[q] = 0u;
+    }
+    __syncthreads();
+    const double inv = 1.0 / (double)s_sq;
+    const uint32_t total = a.nslab * 128;
+    for (uint32_t i = tid; i < total; i += 256) {
+        int u = 0;
+        if (i < a.D) {
+            const float sc = a.scales[i];
+            const double w = sc > 0.0f ? (double)qv[i] / (double)sc : 0.0;
+            double r = rint(w * inv);
+            r = r < -127.0 ? -127.0 : (r > 127.0 ? 127.0 : r);
+            u = (r == r) ? (int)r : 0;
+        }
+        const uint32_t s = i / 128, k = i % 128, l = k >> 4, e = k & 15, p = l ^ ((q >> 1) & 7);
+        a.img[(((size_t)s * a.qpad + q) * 8 + p) * 16 + e] = (int8_t)u;
     }
 }
 

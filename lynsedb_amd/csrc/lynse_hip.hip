@@ -202,6 +202,11 @@ struct lynse_hip_flat {
     float *sq8_mins = nullptr, *sq8_scales = nullptr;
     int *sq8_sum = nullptr, *sq8_sum2 = nullptr;
     uint32_t* sq8_mm = nullptr;  // 2 x dim ordered-int min / max
+    uint32_t* sq8_stats = nullptr;  // [0] max row L1 of the signed codes, [1] non-finite elements (k_sq8_quantize)
+    uint32_t sq8_a1 = 0;
+    bool sq8_finite = false;
+    // certified int8 coarse pass (FLAT-IP batches of 33..256 queries): -1 = off (env / strikes), else overflow strikes so far
+    int i8c_strikes = 0;
     // gathered ("few matches") filtered path: compact copy of the listed shadow rows, their norms and 32-bit ids
     _Float16* g_rows16 = nullptr;
     float *g_vn2 = nullptr, *g_vrinv = nullptr;
@@ -264,7 +269,7 @@ extern "C" int lynse_hip_flat_destroy(lynse_hip_flat* h) {
     for (auto e : h->ev_pool) (void)hipEventDestroy(e);
     for (void* p : {(void*)h->rows, (void*)h->rows16, (void*)h->packed, (void*)h->vn2, (void*)h->vrinv, (void*)h->d_stats,
                     (void*)h->d_mask, (void*)h->d_subset, (void*)h->g_rows16, (void*)h->g_vn2, (void*)h->g_vrinv, (void*)h->g_ids32,
-                    (void*)h->sq8, (void*)h->sq8_mins, (void*)h->sq8_scales, (void*)h->sq8_sum, (void*)h->sq8_sum2, (void*)h->sq8_mm})
+                    (void*)h->sq8, (void*)h->sq8_mins, (void*)h->sq8_scales, (void*)h->sq8_sum, (void*)h->sq8_sum2, (void*)h->sq8_mm, (void*)h->sq8_stats})
         if (p) (void)hipFree(p);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -877,6 +882,20 @@ static int launch_scan_h16(const ScanArgs& a, int metric, uint32_t grid, hipStre
     }
 }
 
+// certified int8 coarse pass: the 256 x 256 IP tiling with 3 + 2-stage rings over 128-element slabs
+static int launch_scan_i8c(const ScanArgs& a, uint32_t grid, hipStream_t st) {
+    constexpr size_t lds = (size_t)(3 * 256 + 2 * 256) * 128;
+    static bool attr_done[2] = {false, false};
+    auto go = [&](auto kern, int slot) -> int {
+        if (!attr_done[slot]) { LY_TRY(set_max_lds(kern, lds)); attr_done[slot] = true; }
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, a);
+        LY_HIP(hipGetLastError());
+        return LYNSE_OK;
+    };
+    if (a.ld16 % 128 == 0) return go(k_scan_h16<2, 4, 4, 2, M_IP, 3, 2, 2, false, false, 0, false, 2>, 0);
+    return go(k_scan_h16<2, 4, 4, 2, M_IP, 3, 2, 2, false, true, 0, false, 2>, 1);
+}
+
 // f16 shadow rows [n16, n) (all rows again when the scale changed)
 static int ensure_shadow_locked(lynse_hip_flat* h) {
     if (h->packed_only || h->n == 0) return LYNSE_OK;
@@ -971,13 +990,15 @@ static int get_event(lynse_hip_flat* h, size_t idx, hipEvent_t* out) {
 // QW for binary).  Results land in ws.out_*.  `level` selects the stage plan (make_plan).
 static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k, int metric, int level, hipStream_t st,
                      size_t* ev_used, std::vector<std::pair<size_t, uint64_t>>* scan_events, bool* sampled_plan,
-                     const uint32_t* mask = nullptr, const uint32_t* row_ids = nullptr) {
+                     const uint32_t* mask = nullptr, const uint32_t* row_ids = nullptr, bool i8c = false) {
+    // i8c: the coarse pass streams the SQ8 codes (1 B / element) against the symmetric int8 query image with a certified
+    // error bound (k_i8c_prep_queries) instead of the f16 shadow — FLAT-IP batches of 33..256 queries
     Workspace& w = h->ws;
     const bool binary = metric >= M_HAMMING;
     const bool asc = metric_ascending(metric);
     const bool h16 = scan_variant() == 3;
     const bool glds = scan_variant() == 0;
-    const uint32_t nslab = glds ? (h->dim + GL_BK - 1) / GL_BK : (h->dim + SCAN_BK - 1) / SCAN_BK;  // h16: HK == SCAN_BK == 64
+    const uint32_t nslab = i8c ? (h->dim + 127) / 128 : glds ? (h->dim + GL_BK - 1) / GL_BK : (h->dim + SCAN_BK - 1) / SCAN_BK;  // h16: HK == SCAN_BK == 64
     const bool small = nq <= SCAN_BQ_SMALL;
     const uint32_t qpad = small ? SCAN_BQ_SMALL : SCAN_BQ_LARGE;
     int ip_form = h->ip_form;
@@ -998,6 +1019,14 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
         LY_HIP(hipMemsetAsync(w.count, 0, nq * 4, st));
         LY_HIP(hipMemsetAsync(w.overflow, 0, nq * 4, st));
         LY_HIP(hipStreamSynchronize(st));  // thr0 is a stack/heap temporary
+    } else if (i8c) {
+        LY_HIP(hipMemsetAsync(w.Q16, 0, (size_t)nslab * qpad * 128, st));
+        I8cPrepArgs p{};
+        p.Q = w.Qf; p.D = h->dim; p.qpad = qpad; p.nslab = nslab; p.mins = h->sq8_mins; p.scales = h->sq8_scales;
+        p.a1 = h->sq8_a1; p.vmax = h->vmax; p.img = reinterpret_cast<int8_t*>(w.Q16);
+        p.sq = w.qinv; p.bq = w.qn2; p.marg2 = w.marg2; p.thr = w.thr; p.count = w.count; p.overflow = w.overflow;
+        hipLaunchKernelGGL(k_i8c_prep_queries, dim3(nq), dim3(256), 0, st, p);
+        LY_HIP(hipGetLastError());
     } else {
         // queries with index >= nq inside the padded tile must be finite: zero the image
         LY_HIP(hipMemsetAsync(w.Q16, 0, (size_t)nslab * qpad * (glds ? GL_BK : (h16 ? HK : SCAN_LDK)) * sizeof(_Float16), st));
@@ -1018,10 +1047,13 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
     static const int w16env = []() { const char* e = getenv("LYNSE_HIP_SCAN_W16"); return e ? atoi(e) : -1; }();
     const bool filt = mask != nullptr || row_ids != nullptr;
     // (the subset-filter variants of <2,4,4,2> spill 96 B into the MFMA loop: masked 10M x 768 scan 7.5 ms vs 4.9 ms with <4,2,2,4>)
-    const int waves16 = w16env >= 0 ? w16env : ((metric == M_IP && !filt) ? 3 : 0);
+    const int waves16 = i8c ? 3 : (w16env >= 0 ? w16env : ((metric == M_IP && !filt) ? 3 : 0));
     static const int no_lane_max0 = []() { const char* e = getenv("LYNSE_HIP_NO_LANE_MAX"); return e ? atoi(e) : 0; }();
     // the subset-filter kernel variants carry no lane-max code (registers)
-    const bool can_threshold_only = h16 && !binary && !filt && !no_lane_max0 && (small || waves16 != 0) && k <= 16;
+    // (k <= 16: the best tile alone supplies k keys, so even a shard sorted by score gets a tight threshold from its best
+    // sample tile; up to k = 128 the sample as a whole supplies >= 8 k keys — a clustered shard may then overflow the first
+    // stage and fall back to the contiguous plan)
+    const bool can_threshold_only = h16 && !binary && !filt && !no_lane_max0 && (small || waves16 != 0) && k <= 128;
     const std::vector<Stage> plan = make_plan(h, k, (level == 0 && (!plan_tile || no_sample)) ? 1 : level, plan_tile, can_threshold_only);
     const Stage sample = (!plan.empty() && plan[0].sample_tiles) ? plan[0] : Stage{0, 0};
     *sampled_plan = sample.sample_tiles != 0;
@@ -1030,7 +1062,8 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
     const uint32_t sample_keys_per_tile = (small || waves16 != 0) ? 16u : 0u;  // 2 WR lanes per query and tile x their best 2 rows (WR = 4 tilings only)
     static const int no_lane_max = []() { const char* e = getenv("LYNSE_HIP_NO_LANE_MAX"); return e ? atoi(e) : 0; }();
     // k <= keys per tile: the best sample tile alone supplies k keys (a shard sorted by score still gets a tight threshold)
-    const bool sample_threshold_only = h16 && !binary && !filt && sample.sample_tiles && !no_lane_max && k <= sample_keys_per_tile;
+    const bool sample_threshold_only = h16 && !binary && !filt && sample.sample_tiles && !no_lane_max && sample_keys_per_tile &&
+                                       (k <= sample_keys_per_tile || (uint64_t)sample.sample_tiles * sample_keys_per_tile >= 8ull * k);
     for (size_t si = 0; si < plan.size(); ++si) {
         const Stage s = plan[si];
         const bool emit_all = si == 0;
@@ -1077,6 +1110,7 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
             uint32_t tile_rows = (glds && !small && big_rows == 256) ? 256u : (uint32_t)SCAN_BR;
             if (h16) tile_rows = small ? 128u : 256u;
             a.V16 = h->rows16; a.ld16 = h->ld16;
+            if (i8c) { a.V16 = reinterpret_cast<const _Float16*>(h->sq8); a.ld16 = h->ld8; }
             if (glds && !small && big_rows == 192 && metric == M_IP) tile_rows = 192u;
             a.qpad = qpad; a.nq = nq; a.nslab = nslab; a.ntiles = (s.r1 - s.r0 + tile_rows - 1) / tile_rows;
             if (s.sample_tiles) a.ntiles = s.sample_tiles;
@@ -1098,7 +1132,12 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
                 }
             }
             const int variant = scan_variant();
-            if (h16) {
+            if (i8c) {
+                a.candB = w.candB; a.segcnt = w.segcnt;
+                const uint32_t grid = std::min<uint32_t>(a.ntiles, (uint32_t)h->num_cu);
+                if (!a.emit_all) seg_geometry(grid, 4, &a.nseg, &a.seg);
+                LY_TRY(launch_scan_i8c(a, grid, st));
+            } else if (h16) {
                 a.candB = w.candB; a.segcnt = w.segcnt;
                 if (small) {
                     const uint32_t grid = std::min<uint32_t>(a.ntiles, (uint32_t)h->num_cu * 2);
@@ -1175,6 +1214,11 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
     fa.row_stride = h->row_stride; fa.row_offset = h->row_offset;
     fa.out_rows = w.out_rows; fa.out_dists = w.out_dists; fa.out_counts = w.out_counts;
     fa.pool_total = h->profiling ? w.pool_total : nullptr;
+    if (i8c) {  // a few hundred survivors per query inside the int8 margin: spread their exact rescoring over the chip
+        hipLaunchKernelGGL(k_rescore_pool<256>, dim3(nq, 4), dim3(256), 0, st, fa);
+        LY_HIP(hipGetLastError());
+        fa.exact = 1;
+    }
     hipLaunchKernelGGL(k_final<SEL_NT>, dim3(nq), dim3(SEL_NT), (size_t)w.cap * 8, st, fa);
     LY_HIP(hipGetLastError());
     (void)asc;
@@ -1202,7 +1246,9 @@ static int ensure_sq8_locked(lynse_hip_flat* h) {
         LY_HIP(hipMalloc(&h->sq8_mins, (size_t)h->dim * 4));
         LY_HIP(hipMalloc(&h->sq8_scales, (size_t)h->dim * 4));
         LY_HIP(hipMalloc(&h->sq8_mm, (size_t)h->dim * 8));
+        LY_HIP(hipMalloc(&h->sq8_stats, 8));
     }
+    LY_HIP(hipMemsetAsync(h->sq8_stats, 0, 8, h->stream));
     std::vector<uint32_t> init((size_t)h->dim * 2);
     for (uint32_t d = 0; d < h->dim; ++d) { init[d] = f32_to_ord(INFINITY); init[h->dim + d] = f32_to_ord(-INFINITY); }
     LY_HIP(hipMemcpyAsync(h->sq8_mm, init.data(), init.size() * 4, hipMemcpyHostToDevice, h->stream));
@@ -1211,9 +1257,13 @@ static int ensure_sq8_locked(lynse_hip_flat* h) {
     hipLaunchKernelGGL(k_sq8_minmax, dim3(gx, gy), dim3(256), 0, h->stream, h->rows, h->ld, h->dim, h->n, h->sq8_mm, h->sq8_mm + h->dim);
     hipLaunchKernelGGL(k_sq8_scales, dim3(gx), dim3(256), 0, h->stream, h->sq8_mm, h->sq8_mm + h->dim, h->dim, h->sq8_mins, h->sq8_scales);
     hipLaunchKernelGGL(k_sq8_quantize, dim3((uint32_t)std::min<uint64_t>((h->n + 3) / 4, (uint64_t)h->num_cu * 16)), dim3(256), 0, h->stream,
-                       h->rows, h->ld, h->dim, h->n, h->sq8_mins, h->sq8_scales, h->sq8, h->ld8, h->sq8_sum, h->sq8_sum2);
+                       h->rows, h->ld, h->dim, h->n, h->sq8_mins, h->sq8_scales, h->sq8, h->ld8, h->sq8_sum, h->sq8_sum2, h->sq8_stats);
     LY_HIP(hipGetLastError());
+    uint32_t qst[2] = {0, 0};
+    LY_HIP(hipMemcpyAsync(qst, h->sq8_stats, 8, hipMemcpyDeviceToHost, h->stream));
     LY_HIP(hipStreamSynchronize(h->stream));  // `init` is a temporary
+    h->sq8_a1 = qst[0];
+    h->sq8_finite = qst[1] == 0;
     h->n_sq8 = h->n;
     return LYNSE_OK;
 }
@@ -1263,11 +1313,11 @@ static int run_chunk_sq8(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t ou
         constexpr size_t lds = (size_t)(2 * 256 + 2 * 256) * 128 + 3 * 1024;
         static bool a2[2] = {false, false};
         if (ip) {
-            auto kern = k_scan_h16<4, 2, 2, 4, M_IP, 2, 2, 2, false, true, 0, false, true>;
+            auto kern = k_scan_h16<4, 2, 2, 4, M_IP, 2, 2, 2, false, true, 0, false, 1>;
             if (!a2[0]) { LY_TRY(set_max_lds(kern, lds)); a2[0] = true; }
             hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, a);
         } else {
-            auto kern = k_scan_h16<4, 2, 2, 4, M_L2, 2, 2, 2, false, true, 0, false, true>;
+            auto kern = k_scan_h16<4, 2, 2, 4, M_L2, 2, 2, 2, false, true, 0, false, 1>;
             if (!a2[1]) { LY_TRY(set_max_lds(kern, lds)); a2[1] = true; }
             hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, a);
         }
@@ -1527,9 +1577,19 @@ static int search_impl(lynse_hip_flat* h, const void* q_src, bool packed_queries
         } else {
             LY_HIP(hipMemcpyAsync(w.Qf, (const float*)q_src + q0 * h->dim, (size_t)nqc * h->dim * 4, in_kind, st));
         }
+        // certified int8 coarse pass: FLAT-IP batches of 33..256 queries over an f32 shard with finite values (auto: shards
+        // of >= 64K rows; LYNSE_HIP_COARSE=i8 / f16 forces / disables it).  An overflow first retries the f16 coarse pass;
+        // three such strikes turn the int8 pass off for this handle (margins too wide for this data).
+        static const int coarse_env = []() { const char* e = getenv("LYNSE_HIP_COARSE"); return !e ? 0 : (!strcmp(e, "i8") ? 2 : (!strcmp(e, "f16") ? 1 : 0)); }();
+        bool i8c = metric == M_IP && !filtered && nqc > SCAN_BQ_SMALL && h->dtype == LYNSE_DTYPE_F32 && scan_variant() == 3 &&
+                   coarse_env != 1 && h->i8c_strikes >= 0 && h->i8c_strikes < 3 && (coarse_env == 2 || h->n >= 65536);
+        if (i8c) {
+            LY_TRY(ensure_sq8_locked(h));
+            if (!h->sq8_finite) { h->i8c_strikes = -1; i8c = false; }
+        }
         for (int level = 0; level < 3; ++level) {  // sampled plan -> contiguous plan -> exhaustive plan (make_plan)
             bool sampled = false;
-            LY_TRY(run_chunk(h, nqc, kk, k, metric, level, st, &ev_used, &scan_events, &sampled, mask, direct ? h->g_ids32 : nullptr));
+            LY_TRY(run_chunk(h, nqc, kk, k, metric, level, st, &ev_used, &scan_events, &sampled, mask, direct ? h->g_ids32 : nullptr, i8c));
             // outputs are copied speculatively with the overflow flags — one synchronisation per chunk; a retry on the
             // next plan level overwrites them in stream order.  Workspace rows are [nqc][kk]; caller layout is [nq][k]
             const size_t rows_b = (size_t)nqc * k * 8, dists_b = (size_t)nqc * k * 4;
@@ -1547,6 +1607,12 @@ static int search_impl(lynse_hip_flat* h, const void* q_src, bool packed_queries
             }
             if (level == 2) return set_error(LYNSE_ERR_INTERNAL, "candidate overflow on the exhaustive plan");
             fallback_queries += nov;
+            if (i8c) {  // same plan level again with the f16 coarse pass
+                i8c = false;
+                h->i8c_strikes += 1;
+                --level;
+                continue;
+            }
             if (level == 0 && !sampled) level = 1;  // level 1 would repeat the same contiguous plan
         }
         if (!on_device) memcpy(out_counts + q0, w.h_hdr, nqc * 4);
