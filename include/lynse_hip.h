@@ -258,6 +258,12 @@ int lynse_hip_ivf_set_routing(lynse_hip_ivf *h, int ivfflat_routing);
 int lynse_hip_ivf_search_f32(lynse_hip_ivf *h, const float *queries, uint64_t nq, uint32_t k,
                              uint32_t nprobe, uint64_t *out_rows, float *out_dists,
                              uint32_t *out_counts);
+/* IvfFlatMmap::search(query, k, nprobe, metric) (src/storage/ivf_flat_mmap.rs:225-305; PyIvfFlatIndex.search,
+ * src/python/mod.rs:2130-2155): the metric of the CALL drives centroid routing, scoring and the sort direction (the
+ * partitions are metric-agnostic).  Float indexes take ip / l2 / cosine; a binary index only its build metric. */
+int lynse_hip_ivf_search_metric_f32(lynse_hip_ivf *h, const float *queries, uint64_t nq, uint32_t k,
+                                    uint32_t nprobe, int metric, uint64_t *out_rows, float *out_dists,
+                                    uint32_t *out_counts);
 /* IVFIndex::search with SearchParams.subset (ivf.rs:251-265): the rows of the probed lists are intersected with
  * `subset_rows` (original row ids, host memory); a query whose probed lists hold no subset row is answered from the
  * whole corpus restricted to the subset, as the reference does.  One subset per batch. */

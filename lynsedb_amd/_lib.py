@@ -92,6 +92,7 @@ SIGNATURES = {
     "lynse_hip_ivf_set_row_map": (C.c_int, [_vp, C.c_uint64, C.c_uint64]),
     "lynse_hip_ivf_set_routing": (C.c_int, [_vp, C.c_int]),
     "lynse_hip_ivf_search_f32": (C.c_int, [_vp, _vp, C.c_uint64, C.c_uint32, C.c_uint32, _vp, _vp, _vp]),
+    "lynse_hip_ivf_search_metric_f32": (C.c_int, [_vp, _vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int, _vp, _vp, _vp]),
     "lynse_hip_ivf_search_filtered_f32": (C.c_int, [_vp, _vp, C.c_uint64, C.c_uint32, C.c_uint32, _vp, C.c_uint64, _vp, _vp, _vp]),
     "lynse_hip_ivf_profile_enable": (C.c_int, [_vp, C.c_int]),
     "lynse_hip_filter_tombstoned_limit": (C.c_int, [_vp, _vp, C.c_uint64, _vp, C.c_uint64, C.c_uint64, _vp, _vp, C.POINTER(C.c_uint64)]),
@@ -123,6 +124,10 @@ class LynseHipError(RuntimeError):
         self.code = code
 
 
+class LynseUnsupportedError(LynseHipError, NotImplementedError):
+    """LYNSE_ERR_UNSUPPORTED: valid in the reference, outside what this library implements (e.g. the metric 'l1')."""
+
+
 def last_error() -> str:
     buf = C.create_string_buffer(1024)
     lib.lynse_hip_last_error(buf, 1024)
@@ -138,6 +143,8 @@ def check(code: int) -> None:
         raise ValueError(msg)
     if code == ERR_OUT_OF_MEMORY:
         raise MemoryError(msg)
+    if code == ERR_UNSUPPORTED:
+        raise LynseUnsupportedError(code, msg)
     raise LynseHipError(code, msg)
 
 

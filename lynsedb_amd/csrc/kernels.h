@@ -1016,7 +1016,7 @@ constexpr int HK = 64;  // K elements per slab
 // cost registers the unfiltered kernel does not have to spare (56 B/lane of scratch and 13 % of its speed when they
 // were runtime branches).
 template <int WQ, int WR, int TQ, int TR, int METRIC, int NSV, int NSQ, int NT_HINT, bool TILED = false, bool RAG = true, int DBG = 0, bool FILT = false,
-          int I8Q = 0>
+          int I8Q = 0, int EMIT = -1>
 __global__ void __launch_bounds__(WQ * WR * 64, (TQ * TR >= 16) ? 1 : ((WQ * WR >= 8) ? (WQ * WR / 4) : 2)) k_scan_h16(ScanArgs a) {
     // Two LDS rings: NSV stages of row slabs (HBM latency: deeper) and NSQ <= NSV stages of query-image
     // slabs (L2 latency) — 3 + 2 stages of 32 KiB fill the 160 KiB of a CU for the 256 x 256 tile.
@@ -1180,33 +1180,36 @@ __global__ void __launch_bounds__(WQ * WR * 64, (TQ * TR >= 16) ? 1 : ((WQ * WR 
     const int a_base = (wr * (TR * 32) + l32) * LINE;
     const int b_base = (wq * (TQ * 32) + l32) * LINE;
 
-    // Per-query constants kept in registers across the MFMA loop: 1 / scale, |q|^2 or 1 / |q|, and c_pre — the threshold
-    // of LEVEL 1 of the two-level epilogue filter.  Level 1 reduces the accumulators of a query column to ONE value that
-    // is monotone in the score (IP: the raw accumulator; L2: 2 q.v - |v|^2; cosine: q.v / |v|) with v_max3 and compares
-    // it with the per-query threshold mapped into that space and LOOSENED by more than the rounding differences between
-    // this form and the exact score expression: level 1 never rejects a row level 2 would accept.  Only column blocks with
-    // a hit run level 2 (the exact expression against the exact threshold, re-read from memory, + emission).
+    // Epilogue-only kernel arguments are re-read from the kernarg segment through a laundered pointer when a tile's
+    // epilogue starts: kept live across the MFMA loop they fill the SGPR file (106 of 106), push uniform loop state into
+    // VGPRs and from there into scratch — whose reloads sit behind s_waitcnt vmcnt(0) and drain the DMA ring.
+    typedef const __attribute__((address_space(4))) ScanArgs* EpiArgsPtr;
+    auto epi_args = [&]() -> EpiArgsPtr {
+        EpiArgsPtr p = (EpiArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(p));
+        return p;
+    };
+    // Per-query constants of the two-level epilogue filter, (re)loaded per tile in the epilogue (NOT kept in registers
+    // across the MFMA loop: 12+ VGPRs the 256 x 256 tilings do not have): 1 / scale (I8C: s_q), |q|^2 or 1 / |q| (I8C: B_q),
+    // and c_pre — the threshold of LEVEL 1.  Level 1 reduces the accumulators of a query column to ONE value that is
+    // monotone in the score and compares it with the per-query threshold:
+    //   IP (f16 and certified int8): the score expression itself is monotone non-decreasing in the accumulator
+    //       (acc * qinv with qinv > 0; B_q + s_q * dot with s_q >= 0), so level 1 evaluates the EXACT expression on the
+    //       column maximum — it rejects a block iff level 2 would reject every row of it;
+    //   L2 / cosine: 2 q.v - |v|^2 resp. q.v / |v| against the threshold mapped into that space and LOOSENED by more than
+    //       the rounding differences between this form and the exact expression: never rejects a row level 2 would accept.
+    // Only column blocks with a hit run level 2 (the exact expression against the exact threshold + emission).
     // c_pre = -inf: always run level 2.
-    float c_qinv[TQ], c_pre[TQ], c_extra[TQ];
+    float c_qinv[TQ], c_pre[TQ], c_extra[TQ], c_thr[TQ];
     bool c_ok[TQ];
-    auto set_pre = [&](int j, float thr) {
+    auto set_pre = [&](int j, float thr, float vmax2) {
         float pre = -LY_INF;
-        if (I8C && c_ok[j]) {  // score = B_q + s_q * dot >= thr  <=>  dot >= (thr - B_q) / s_q: an integer compare, loosened by 2
-            const float t = (thr - c_extra[j]) / c_qinv[j] - 2.0f;
-            int ti = -2147483647 - 1;
-            if (t > 2.0e9f) ti = 2147483647;
-            else if (t > -2.0e9f) ti = (int)floorf(t);   // (NaN / -inf: stays at INT_MIN = always level 2)
-            pre = __int_as_float(ti);
-        }
-        if (!I8 && c_ok[j]) {
+        if (!I8 && METRIC != M_IP && c_ok[j]) {
             const float qi = c_qinv[j];
-            if (METRIC == M_IP) {
-                pre = thr / qi;                                   // qinv is a power of two: exact
-                pre = pre - fabsf(pre) * 1e-6f;
-            } else if (METRIC == M_L2) {
+            if (METRIC == M_L2) {
                 const float qn2 = c_extra[j];
-                pre = (qn2 - thr) - 2e-6f * (qn2 + fabsf(thr) + a.vmax2);
-                if (!(a.vmax2 > 0.0f)) pre = -LY_INF;
+                pre = (qn2 - thr) - 2e-6f * (qn2 + fabsf(thr) + vmax2);
+                if (!(vmax2 > 0.0f)) pre = -LY_INF;
             } else {
                 const float den = qi * c_extra[j];                // qinv / |q|
                 pre = ((1.0f - thr) - 1e-6f * (1.0f + fabsf(thr))) / den;
@@ -1215,26 +1218,8 @@ __global__ void __launch_bounds__(WQ * WR * 64, (TQ * TR >= 16) ? 1 : ((WQ * WR 
             }
             if (!(fabsf(pre) < 3.0e38f)) pre = -LY_INF;           // inf / NaN (open threshold, overflow): no pre-filter
         }
-        if (I8C && !c_ok[j]) pre = __int_as_float(-2147483647 - 1);
         c_pre[j] = pre;
     };
-    auto load_thr = [&](int j, uint32_t n) -> float {
-        float thr = c_ok[j] ? a.thr[n] : 0.0f;
-        if (a.debug_flags & 2) thr = ASC ? -LY_INF : LY_INF;
-        return thr;
-    };
-#pragma unroll
-    for (int j = 0; j < TQ; ++j) {
-        const uint32_t n = wq * (TQ * 32) + j * 32 + l32;
-        c_ok[j] = !TILED && n < a.nq;
-        c_qinv[j] = c_ok[j] ? a.qinv[n] : 0.0f;
-        c_extra[j] = 0.0f;
-        if (METRIC == M_L2 || I8) c_extra[j] = c_ok[j] ? a.qn2[n] : 0.0f;  // SQ8: the per-query integer constant, as bits; I8C: B_q
-        if (METRIC == M_COS && !I8) c_extra[j] = c_ok[j] ? a.qrinv[n] : 0.0f;
-        set_pre(j, load_thr(j, n));
-    }
-#pragma unroll
-    for (int j = 0; j < TQ; ++j) asm volatile("" : "+v"(c_qinv[j]), "+v"(c_pre[j]), "+v"(c_extra[j]));
 
     // Prologue: the issue order of the steady state (per step: queries(s+NSQ-1), then rows(s+NSV-1))
     v_enter_tile();
@@ -1252,7 +1237,11 @@ __global__ void __launch_bounds__(WQ * WR * 64, (TQ * TR >= 16) ? 1 : ((WQ * WR 
     }
 
     uint32_t s_in_tile = 0, tile = blockIdx.x, cv_stage = 0, cq_stage = 0, c_tileseq = 0;
+#ifdef LYNSE_EXPERIMENTS
     const bool timing = (a.debug_flags & 64) && a.dbg;
+#else
+    constexpr bool timing = false;  // (phase timing lives in the EXPERIMENTS build: its flag and counters cost SGPRs in the hot loop)
+#endif
     unsigned long long t_wait = 0, t_bar = 0, t_comp = 0, tp = timing ? __builtin_amdgcn_s_memtime() : 0;
     for (uint32_t g = 0; g < G; ++g) {
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAIT_OPS) : "memory");
@@ -1314,21 +1303,27 @@ __global__ void __launch_bounds__(WQ * WR * 64, (TQ * TR >= 16) ? 1 : ((WQ * WR 
         v_advance();
 
         if (++s_in_tile == a.nslab) {
-            uint32_t rbase = a.row0 + tile * tstride;
-            uint32_t row_end = a.row1;
+            const EpiArgsPtr ea = epi_args();
+            uint32_t rbase = ea->row0 + tile * tstride;
+            uint32_t row_end = ea->row1;
             IvfTile td{};
             if (TILED) {
-                td = a.tiles[tile];
+                td = ea->tiles[tile];
                 rbase = td.row0;
                 row_end = td.row0 + td.nrows;
-            } else if (a.skip_stride && rbase % a.skip_stride == 0 && rbase / a.skip_stride < a.skip_tiles) {
+            } else if (ea->skip_stride && rbase % ea->skip_stride == 0 && rbase / ea->skip_stride < ea->skip_tiles) {
                 row_end = rbase;  // a sample tile: its rows were emitted by the sample stage
             }
             const float* nrm = reinterpret_cast<const float*>(smem + NORM_RING + (c_tileseq % NORM_SLOTS) * 1024);
             ++c_tileseq;
             uint32_t mw_t[TR];  // subset filter: the tile's mask words, loaded once per tile (not once per query column: each load
 #pragma unroll          // would pay the full memory latency behind the candidate stores)
-            for (int i = 0; i < TR; ++i) mw_t[i] = (FILT && !TILED && a.mask) ? a.mask[(rbase + wr * (TR * 32) + i * 32) >> 5] : 0xffffffffu;
+            for (int i = 0; i < TR; ++i) mw_t[i] = (FILT && !TILED && ea->mask) ? ea->mask[(rbase + wr * (TR * 32) + i * 32) >> 5] : 0xffffffffu;
+            const float e_vmax2 = (!I8 && METRIC == M_L2) ? ea->vmax2 : 0.0f;
+            // EMIT >= 0: the emission mode is a compile-time constant (0 threshold stages, 1 emit-all, 2 lane-max sample) — the
+            // 256 x 256 tilings compile ONE epilogue per kernel: with all three in one body the row-index terms of the
+            // emit-all / lane-max branches are hoisted across the unrolled column loop and spill (600 B / lane).
+            const int e_emit_all = TILED ? 0 : (EMIT >= 0 ? EMIT : ea->emit_all);
             auto score = [&](int i, int j, int r, uint32_t m, bool rok) -> float {
                 if constexpr (I8C) {
                     return c_extra[j] + c_qinv[j] * (float)__float_as_int(acc[i][j][r]);  // B_q + s_q * dot (separate mul / add)
@@ -1336,7 +1331,7 @@ __global__ void __launch_bounds__(WQ * WR * 64, (TQ * TR >= 16) ? 1 : ((WQ * WR 
                     // dot of the u8 codes = i8 dot + 128 (sum q' + sum r') + 16384 D; squared L2 = sum q'^2 + sum r'^2 - 2 dot
                     const float accv = acc[i][j][r];
                     const int dotp = __float_as_int(accv);
-                    const int rowsum = NORMS_LDS ? __float_as_int(nrm[m - rbase]) : (rok ? __float_as_int(a.vn2[m]) : 0);
+                    const int rowsum = NORMS_LDS ? __float_as_int(nrm[m - rbase]) : (rok ? __float_as_int(ea->vn2[m]) : 0);
                     const int qconst = __float_as_int(c_extra[j]);
                     const uint32_t u = METRIC == M_IP ? (uint32_t)(dotp + qconst + 128 * rowsum) : (uint32_t)(qconst + rowsum - 2 * dotp);
                     return (float)u;  // `dist_fn(..) as f32` (flat_mmap.rs:5956)
@@ -1345,7 +1340,7 @@ __global__ void __launch_bounds__(WQ * WR * 64, (TQ * TR >= 16) ? 1 : ((WQ * WR 
                 if (METRIC != M_IP) {
                     float nv;
                     if (NORMS_LDS) nv = nrm[m - rbase];
-                    else nv = rok ? (METRIC == M_L2 ? a.vn2[m] : a.vrinv[m]) : 0.0f;
+                    else nv = rok ? (METRIC == M_L2 ? ea->vn2[m] : ea->vrinv[m]) : 0.0f;
                     if (METRIC == M_L2) sc = nv - 2.0f * sc + c_extra[j];
                     else sc = 1.0f - sc * nv * c_extra[j];
                 }
@@ -1353,16 +1348,25 @@ __global__ void __launch_bounds__(WQ * WR * 64, (TQ * TR >= 16) ? 1 : ((WQ * WR 
             };
 #pragma unroll
             for (int j = 0; j < TQ; ++j) {
-                uint32_t n = wq * (TQ * 32) + j * 32 + l32;
+                uint32_t rb = __builtin_amdgcn_readfirstlane(rbase);  // (uniform) opaque per column block: keeps the row-index terms of the TR x 16 rows from being hoisted out of
+                asm volatile("" : "+s"(rb));  // the unrolled column loop (all live at once: hundreds of bytes of scratch per lane)
+                uint32_t n = wq * (TQ * 32) + j * 32 + l32;  // this lane's query of column block j (TILED: through the group's pair list)
                 if (TILED) {
                     c_ok[j] = n < td.nq;
-                    n = c_ok[j] ? a.pair_q[td.pair0 + n] : 0u;
-                    c_qinv[j] = c_ok[j] ? a.qinv[n] : 0.0f;
-                    if (METRIC == M_L2) c_extra[j] = c_ok[j] ? a.qn2[n] : 0.0f;
-                    if (METRIC == M_COS) c_extra[j] = c_ok[j] ? a.qrinv[n] : 0.0f;
-                    set_pre(j, load_thr(j, n));
+                    n = c_ok[j] ? ea->pair_q[td.pair0 + n] : 0u;
+                } else {
+                    c_ok[j] = n < ea->nq;
                 }
-                if (WR >= 4 && !FILT && a.emit_all == 2 && !TILED) {  // (compiled out of the <4,2,2,4> tiling and the subset-filter variants: it would spill there)
+                c_qinv[j] = c_ok[j] ? ea->qinv[n] : 0.0f;
+                c_extra[j] = 0.0f;
+                if (METRIC == M_L2 || I8) c_extra[j] = c_ok[j] ? ea->qn2[n] : 0.0f;  // SQ8: the per-query integer constant, as bits; I8C: B_q
+                if (METRIC == M_COS && !I8) c_extra[j] = c_ok[j] ? ea->qrinv[n] : 0.0f;
+                c_thr[j] = c_ok[j] ? ea->thr[n] : 0.0f;
+#ifdef LYNSE_EXPERIMENTS
+                if (ea->debug_flags & 2) c_thr[j] = ASC ? -LY_INF : LY_INF;
+#endif
+                set_pre(j, c_thr[j], e_vmax2);
+                if (WR >= 4 && !FILT && e_emit_all == 2 && !TILED) {  // (compiled out of the <4,2,2,4> tiling and the subset-filter variants: it would spill there)
                     // threshold-only sample stage: each lane keeps the best LM of its TR*16 rows for this query column
                     // (4 WR keys per tile and query) and writes only those.  k_select turns the k-th best of them into a
                     // valid threshold and keeps no candidate: the sample tiles are scanned again by the ordinary stages.
@@ -1379,7 +1383,7 @@ __global__ void __launch_bounds__(WQ * WR * 64, (TQ * TR >= 16) ? 1 : ((WQ * WR 
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
                             const uint32_t bit = (r & 3) + 8 * (r >> 2) + 4 * hi;
-                            uint32_t m = rbase + wr * (TR * 32) + i * 32 + bit;
+                            uint32_t m = rb + wr * (TR * 32) + i * 32 + bit;
                             float sc = score(i, j, r, m, m < row_end);
                             const bool ok = m < row_end && ((mw >> bit) & 1u);
                             if (!ok) { sc = ASC ? LY_INF : -LY_INF; m = 0xffffffffu; }
@@ -1397,24 +1401,24 @@ __global__ void __launch_bounds__(WQ * WR * 64, (TQ * TR >= 16) ? 1 : ((WQ * WR 
                     }
 #pragma unroll
                     for (int t = 0; t < LM; ++t) {
-                        const uint64_t key = bm[t] == 0xffffffffu ? KEY_SENTINEL : make_key(bs[t], (FILT && a.row_ids) ? a.row_ids[bm[t]] : bm[t], ASC);
+                        const uint64_t key = bm[t] == 0xffffffffu ? KEY_SENTINEL : make_key(bs[t], (FILT && ea->row_ids) ? ea->row_ids[bm[t]] : bm[t], ASC);
                         const uint32_t slot = (tile * (2 * WR) + 2 * wr + hi) * LM + t;
-                        if (c_ok[j] && slot < a.cap) a.cand[(size_t)n * a.cap + slot] = key;
+                        if (c_ok[j] && slot < ea->cap) ea->cand[(size_t)n * ea->cap + slot] = key;
                     }
-                } else if (a.emit_all && !TILED) {
+                } else if (e_emit_all && !TILED) {
 #pragma unroll
                     for (int i = 0; i < TR; ++i) {
                         const uint32_t mw = mw_t[i];
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
                             const uint32_t bit = (r & 3) + 8 * (r >> 2) + 4 * hi;
-                            const uint32_t m = rbase + wr * (TR * 32) + i * 32 + bit;
+                            const uint32_t m = rb + wr * (TR * 32) + i * 32 + bit;
                             const bool rok = m < row_end;
                             const float sc = score(i, j, r, m, rok);
-                            const uint32_t slot = tile * BR + (m - rbase);  // dense over the (possibly strided) tiles
-                            if (c_ok[j] && rok && slot < a.cap)
-                                a.cand[(size_t)n * a.cap + slot] =
-                                    ((mw >> bit) & 1u) ? make_key(sc, (FILT && !TILED && a.row_ids) ? a.row_ids[m] : m, ASC) : KEY_SENTINEL;
+                            const uint32_t slot = tile * BR + (m - rb);  // dense over the (possibly strided) tiles
+                            if (c_ok[j] && rok && slot < ea->cap)
+                                ea->cand[(size_t)n * ea->cap + slot] =
+                                    ((mw >> bit) & 1u) ? make_key(sc, (FILT && !TILED && ea->row_ids) ? ea->row_ids[m] : m, ASC) : KEY_SENTINEL;
                         }
                     }
                 } else {
@@ -1429,7 +1433,8 @@ __global__ void __launch_bounds__(WQ * WR * 64, (TQ * TR >= 16) ? 1 : ((WQ * WR 
                                 const int v = __float_as_int(acc[i][j][r]);
                                 bi = bi > v ? bi : v;
                             }
-                        best = (bi >= __float_as_int(c_pre[j])) ? LY_INF : -LY_INF;
+                        // the exact score expression on the column maximum (monotone: s_q >= 0)
+                        best = c_extra[j] + c_qinv[j] * (float)bi;
                     }
                     if constexpr (!I8) {
 #pragma unroll
@@ -1446,7 +1451,7 @@ __global__ void __launch_bounds__(WQ * WR * 64, (TQ * TR >= 16) ? 1 : ((WQ * WR 
 #pragma unroll
                                         for (int e = 0; e < 4; ++e) {
                                             const uint32_t m = rbase + off + e;
-                                            nv[e] = m < row_end ? (METRIC == M_L2 ? a.vn2[m] : a.vrinv[m]) : 0.0f;
+                                            nv[e] = m < row_end ? (METRIC == M_L2 ? ea->vn2[m] : ea->vrinv[m]) : 0.0f;
                                         }
                                     }
                                 }
@@ -1460,10 +1465,11 @@ __global__ void __launch_bounds__(WQ * WR * 64, (TQ * TR >= 16) ? 1 : ((WQ * WR 
                             }
                         }
                     }
-                    const bool hit = c_ok[j] && (I8C ? best > 0.0f : (I8 || best >= c_pre[j]));
+                    if constexpr (!I8 && METRIC == M_IP) best = best * c_qinv[j];  // the exact expression on the column maximum (qinv > 0)
+                    const bool hit = c_ok[j] && ((I8C || (!I8 && METRIC == M_IP)) ? best >= c_thr[j] : (I8 || best >= c_pre[j]));
                     if (__ballot(hit) != 0ull) {
                     // ---- level 2: the exact expression against the exact threshold; pass masks of the block's TR x 16 rows
-                    const float e_thr = load_thr(j, n);
+                    const float e_thr = c_thr[j];
                     uint32_t mk[TR], tot = 0;
 #pragma unroll
                     for (int i = 0; i < TR; ++i) {
@@ -1472,12 +1478,12 @@ __global__ void __launch_bounds__(WQ * WR * 64, (TQ * TR >= 16) ? 1 : ((WQ * WR 
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
                             const uint32_t bit = (r & 3) + 8 * (r >> 2) + 4 * hi;
-                            const uint32_t m = rbase + wr * (TR * 32) + i * 32 + bit;
+                            const uint32_t m = rb + wr * (TR * 32) + i * 32 + bit;
                             const bool rok = m < row_end && ((mw >> bit) & 1u);
                             const float sc = score(i, j, r, m, rok);
                             bool pass = ASC ? (sc <= e_thr) : (sc >= e_thr);
-                            if (FILT && TILED && a.mask && c_ok[j] && rok && pass)  // IVF subset filter: mask by slab position, looked up
-                                pass = (a.mask[m >> 5] >> (m & 31)) & 1u;     // only for rows that beat the threshold
+                            if (FILT && TILED && ea->mask && c_ok[j] && rok && pass)  // IVF subset filter: mask by slab position, looked up
+                                pass = (ea->mask[m >> 5] >> (m & 31)) & 1u;     // only for rows that beat the threshold
                             if (c_ok[j] && rok && pass) msk |= 1u << r;
                         }
                         mk[i] = msk;
@@ -1485,24 +1491,25 @@ __global__ void __launch_bounds__(WQ * WR * 64, (TQ * TR >= 16) ? 1 : ((WQ * WR 
                     }
                     // slots: the private segment of this (workgroup, row-wave) while it has room — the two half-waves share a
                     // query column, lanes 0..31 take the first slots — else ONE reservation in the shared region
-                    uint64_t* dst = a.cand + (size_t)n * a.cap;
+                    uint64_t* dst = ea->cand + (size_t)n * ea->cap;
                     uint32_t slot = 0, limit = 0;
                     bool segmented = false;
-                    if (!TILED && a.seg) {
+                    const uint32_t e_seg = TILED ? 0u : ea->seg;
+                    if (!TILED && e_seg) {
                         const uint32_t other = (uint32_t)__shfl_xor((int)tot, 32, 64);
                         const uint32_t c = (segpk >> (8 * j)) & 0xffu;
                         const uint32_t both = tot + other;
-                        if (c + both <= a.seg) {
+                        if (c + both <= e_seg) {
                             segmented = true;
-                            dst = a.candB + ((size_t)n * a.nseg + (blockIdx.x * WR + wr)) * a.seg;
+                            dst = ea->candB + ((size_t)n * ea->nseg + (blockIdx.x * WR + wr)) * e_seg;
                             slot = c + (hi ? other : 0u);
-                            limit = a.seg;
+                            limit = e_seg;
                             segpk += both << (8 * j);
                         }
                     }
                     if (!segmented && tot) {
-                        slot = atomicAdd(&a.count[n], tot);
-                        limit = a.cap;
+                        slot = atomicAdd(&ea->count[n], tot);
+                        limit = ea->cap;
                     }
                     if (tot) {
 #pragma unroll
@@ -1514,7 +1521,7 @@ __global__ void __launch_bounds__(WQ * WR * 64, (TQ * TR >= 16) ? 1 : ((WQ * WR 
                                     if ((msk >> r) & 1u) {
                                         const uint32_t m = rbase + wr * (TR * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
                                         if (slot < limit)
-                                            dst[slot] = make_key(score(i, j, r, m, true), (FILT && !TILED && a.row_ids) ? a.row_ids[m] : m, ASC);
+                                            dst[slot] = make_key(score(i, j, r, m, true), (FILT && !TILED && ea->row_ids) ? ea->row_ids[m] : m, ASC);
                                         ++slot;
                                     }
                                 }
@@ -1536,15 +1543,20 @@ __global__ void __launch_bounds__(WQ * WR * 64, (TQ * TR >= 16) ? 1 : ((WQ * WR 
             const unsigned long long t = __builtin_amdgcn_s_memtime(); t_comp += t - tp; tp = t;
         }
     }
+#ifdef LYNSE_EXPERIMENTS
     if (timing && lane == 0) {
         unsigned long long* o = a.dbg + ((size_t)blockIdx.x * NW + wave) * 4;
         o[0] = t_wait; o[1] = t_bar; o[2] = 0; o[3] = t_comp;
     }
-    if (!TILED && a.seg && hi == 0) {
+#endif
+    if (!TILED) {
+        const EpiArgsPtr ea = epi_args();
+        if (ea->seg && hi == 0) {
 #pragma unroll
-        for (int j = 0; j < TQ; ++j) {
-            const uint32_t n = wq * (TQ * 32) + j * 32 + l32;
-            if (n < a.nq) a.segcnt[(size_t)n * a.nseg + (blockIdx.x * WR + wr)] = (uint8_t)((segpk >> (8 * j)) & 0xffu);
+            for (int j = 0; j < TQ; ++j) {
+                const uint32_t n = wq * (TQ * 32) + j * 32 + l32;
+                if (n < ea->nq) ea->segcnt[(size_t)n * ea->nseg + (blockIdx.x * WR + wr)] = (uint8_t)((segpk >> (8 * j)) & 0xffu);
+            }
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -12,6 +12,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "kernels.h"
@@ -85,6 +86,14 @@ extern "C" int lynse_hip_metric_from_str(const char* name, int* out) {  // dista
     };
     for (auto& t : tab)
         if (s == t.n) { *out = t.m; return LYNSE_OK; }
+    // valid names of the reference's other nine metrics (distance/mod.rs:46-60): recognised, but not part of this path
+    for (const char* o : {"l1", "manhattan", "cityblock", "haversine", "haversine_m", "haversine-m", "geo", "correlation", "pearson",
+                          "hellinger", "wasserstein", "wasserstein1d", "wasserstein_1d", "wasserstein-1d", "emd", "jensen_shannon",
+                          "jensen-shannon", "jensenshannon", "js", "chebyshev", "chebychev", "linf", "l_inf", "l-infinity", "canberra",
+                          "bray_curtis", "bray-curtis", "braycurtis"})
+        if (s == o)
+            return set_error(LYNSE_ERR_UNSUPPORTED, std::string("metric '") + name + "' is a LynseDB metric outside the GPU FLAT / IVF path "
+                                                    "(supported: ip, l2, cosine, hamming, jaccard, dice, tanimoto)");
     return set_error(LYNSE_ERR_UNKNOWN_METRIC, std::string("Unknown metric: ") + name);
 }
 
@@ -102,8 +111,10 @@ extern "C" int lynse_hip_metric_from_index_mode(const char* mode, int* out) {  /
     }
     auto has = [&](const char* v) { return std::find(tok.begin(), tok.end(), v) != tok.end(); };
     // metric families outside this path take precedence in the reference's chain
+    if ((has("JENSEN") && has("SHANNON")) || (has("BRAY") && has("CURTIS")))
+        return set_error(LYNSE_ERR_UNSUPPORTED, std::string("index mode names a LynseDB metric outside the GPU FLAT / IVF path: ") + mode);
     for (const char* o : {"JENSENSHANNON", "JS", "CHEBYSHEV", "CHEBYCHEV", "LINF", "CANBERRA", "BRAYCURTIS"})
-        if (has(o)) return set_error(LYNSE_ERR_UNKNOWN_METRIC, std::string("metric out of scope: ") + mode);
+        if (has(o)) return set_error(LYNSE_ERR_UNSUPPORTED, std::string("index mode names a LynseDB metric outside the GPU FLAT / IVF path: ") + mode);
     int m = -1;
     if (has("TANIMOTO")) m = M_TANIMOTO;
     else if (has("JACCARD")) m = M_JACCARD;
@@ -112,7 +123,7 @@ extern "C" int lynse_hip_metric_from_index_mode(const char* mode, int* out) {  /
     else {
         for (const char* o : {"HAVERSINE", "GEO", "CORRELATION", "PEARSON", "HELLINGER", "WASSERSTEIN",
                               "WASSERSTEIN1D", "EMD", "L1", "MANHATTAN", "CITYBLOCK"})
-            if (has(o)) return set_error(LYNSE_ERR_UNKNOWN_METRIC, std::string("metric out of scope: ") + mode);
+            if (has(o)) return set_error(LYNSE_ERR_UNSUPPORTED, std::string("index mode names a LynseDB metric outside the GPU FLAT / IVF path: ") + mode);
         if (has("L2") || has("L2SQ")) m = M_L2;
         else if (has("COS") || has("COSINE")) m = M_COS;
         else if (has("IP")) m = M_IP;
@@ -820,13 +831,17 @@ static int scan_variant() {
 #endif
 }
 
-// k_scan_h16 launcher: LDS = NSV row stages + NSQ query stages + the norm ring (NSV+1 slots of 1 KiB) when it fits
+// k_scan_h16 launcher: LDS = NSV row stages + NSQ query stages + the norm ring (NSV+1 slots of 1 KiB) when it fits.
+// The 256 x 256 tilings compile ONE epilogue per emission mode (EMIT template parameter: 0 threshold stages, 1 emit-all
+// first stage, 2 lane-max sample stage — one body with all three spills, kernels.h) and only the tiling / metric pairs
+// the product path uses: <2,4,4,2> for unfiltered IP, <4,2,2,4> for L2 / cosine and every subset-filtered scan.
+// The <= 32-query kernel and the IVF work-list kernel (<1,4,1,1>) keep the runtime emission switch (no spills there).
 template <int WQ, int WR, int TQ, int TR, int NSV, int NSQ, bool TILED>
 static int launch_scan_h16(const ScanArgs& a, int metric, uint32_t grid, hipStream_t st) {
     constexpr int BQ = WQ * TQ * 32, BR = WR * TR * 32;
     constexpr size_t rings = (size_t)(NSV * BR + NSQ * BQ) * (HK * 2);
     const size_t lds = (rings + (NSV + 1) * 1024 <= 160 * 1024) ? rings + (NSV + 1) * 1024 : rings;
-    static bool attr_done[9] = {false};
+    static bool attr_done[32] = {false};
     auto go = [&](auto kern, int slot) -> int {
         if (!attr_done[slot]) { LY_TRY(set_max_lds(kern, lds)); attr_done[slot] = true; }
         hipLaunchKernelGGL(kern, dim3(grid), dim3(WQ * WR * 64), lds, st, a);
@@ -834,66 +849,116 @@ static int launch_scan_h16(const ScanArgs& a, int metric, uint32_t grid, hipStre
         return LYNSE_OK;
     };
     const bool filt = a.mask != nullptr || a.row_ids != nullptr;
-    if (a.ld16 % HK == 0 && !filt) {  // no ragged last slab: branch-free DMA issue
+    const bool ragged = a.ld16 % HK != 0;
 #ifdef LYNSE_EXPERIMENTS
-        if constexpr (WQ == 2 && WR == 4 && !TILED) {  // timing experiments (LYNSE_HIP_DEBUG_FLAGS bits 16.. = DBG << 4)
-            if (metric == M_IP && (a.debug_flags >> 4) & 15) {
-                auto ex = [&](auto kern) -> int {
-                    LY_TRY(set_max_lds(kern, lds));
-                    hipLaunchKernelGGL(kern, dim3(grid), dim3(WQ * WR * 64), lds, st, a);
-                    return LYNSE_OK;
-                };
-                switch ((a.debug_flags >> 4) & 15) {
-                case 1: LY_TRY(ex(k_scan_h16<WQ, WR, TQ, TR, M_IP, NSV, NSQ, 2, TILED, false, 1>)); break;
-                case 2: LY_TRY(ex(k_scan_h16<WQ, WR, TQ, TR, M_IP, NSV, NSQ, 2, TILED, false, 2>)); break;
-                case 3: LY_TRY(ex(k_scan_h16<WQ, WR, TQ, TR, M_IP, NSV, NSQ, 2, TILED, false, 3>)); break;
-                case 7: LY_TRY(ex(k_scan_h16<WQ, WR, TQ, TR, M_IP, NSV, NSQ, 2, TILED, false, 7>)); break;
-                case 11: LY_TRY(ex(k_scan_h16<WQ, WR, TQ, TR, M_IP, NSV, NSQ, 2, TILED, false, 11>)); break;
-                case 12: LY_TRY(ex(k_scan_h16<WQ, WR, TQ, TR, M_IP, NSV, NSQ, 2, TILED, false, 12>)); break;
-                case 15: LY_TRY(ex(k_scan_h16<WQ, WR, TQ, TR, M_IP, NSV, NSQ, 2, TILED, false, 15>)); break;
-                case 14: LY_TRY(ex(k_scan_h16<WQ, WR, TQ, TR, M_IP, NSV, NSQ, 2, TILED, false, 14>)); break;
-                case 13: LY_TRY(ex(k_scan_h16<WQ, WR, TQ, TR, M_IP, NSV, NSQ, 2, TILED, false, 13>)); break;
-                case 4: LY_TRY(ex(k_scan_h16<WQ, WR, TQ, TR, M_IP, NSV, NSQ, 2, TILED, false, 4>)); break;
-                case 8: LY_TRY(ex(k_scan_h16<WQ, WR, TQ, TR, M_IP, NSV, NSQ, 2, TILED, false, 8>)); break;
-                default: return set_error(LYNSE_ERR_INVALID_ARGUMENT, "unknown experiment");
-                }
-                LY_HIP(hipGetLastError());
+    if constexpr (WQ == 2 && WR == 4 && !TILED) {  // timing experiments (LYNSE_HIP_DEBUG_FLAGS bits 16.. = DBG << 4)
+        if (metric == M_IP && !filt && !ragged && ((a.debug_flags >> 4) & 15)) {
+            auto ex = [&](auto kern) -> int {
+                LY_TRY(set_max_lds(kern, lds));
+                hipLaunchKernelGGL(kern, dim3(grid), dim3(WQ * WR * 64), lds, st, a);
                 return LYNSE_OK;
+            };
+            switch ((a.debug_flags >> 4) & 15) {
+            case 1: LY_TRY(ex(k_scan_h16<WQ, WR, TQ, TR, M_IP, NSV, NSQ, 2, TILED, false, 1>)); break;
+            case 2: LY_TRY(ex(k_scan_h16<WQ, WR, TQ, TR, M_IP, NSV, NSQ, 2, TILED, false, 2>)); break;
+            case 3: LY_TRY(ex(k_scan_h16<WQ, WR, TQ, TR, M_IP, NSV, NSQ, 2, TILED, false, 3>)); break;
+            case 7: LY_TRY(ex(k_scan_h16<WQ, WR, TQ, TR, M_IP, NSV, NSQ, 2, TILED, false, 7>)); break;
+            case 11: LY_TRY(ex(k_scan_h16<WQ, WR, TQ, TR, M_IP, NSV, NSQ, 2, TILED, false, 11>)); break;
+            case 12: LY_TRY(ex(k_scan_h16<WQ, WR, TQ, TR, M_IP, NSV, NSQ, 2, TILED, false, 12>)); break;
+            case 15: LY_TRY(ex(k_scan_h16<WQ, WR, TQ, TR, M_IP, NSV, NSQ, 2, TILED, false, 15>)); break;
+            case 14: LY_TRY(ex(k_scan_h16<WQ, WR, TQ, TR, M_IP, NSV, NSQ, 2, TILED, false, 14>)); break;
+            case 13: LY_TRY(ex(k_scan_h16<WQ, WR, TQ, TR, M_IP, NSV, NSQ, 2, TILED, false, 13>)); break;
+            case 4: LY_TRY(ex(k_scan_h16<WQ, WR, TQ, TR, M_IP, NSV, NSQ, 2, TILED, false, 4>)); break;
+            case 8: LY_TRY(ex(k_scan_h16<WQ, WR, TQ, TR, M_IP, NSV, NSQ, 2, TILED, false, 8>)); break;
+            default: return set_error(LYNSE_ERR_INVALID_ARGUMENT, "unknown experiment");
+            }
+            LY_HIP(hipGetLastError());
+            return LYNSE_OK;
+        }
+    }
+#endif
+    if constexpr (WQ * WR == 8 && !TILED) {
+        // one kernel per (metric, ragged / filter variant, emission mode)
+        auto by_emit = [&](auto mtag, auto ragtag, auto filtag, int base) -> int {
+            constexpr int M = decltype(mtag)::value;
+            constexpr bool RG = decltype(ragtag)::value, FL = decltype(filtag)::value;
+            if (a.emit_all == 0) return go(k_scan_h16<WQ, WR, TQ, TR, M, NSV, NSQ, 2, false, RG, 0, FL, 0, 0>, base);
+            if constexpr (WR >= 4 && !FL) {  // (the lane-max sample stage exists for the unfiltered <., 4, ., .> tilings only)
+                if (a.emit_all == 2) return go(k_scan_h16<WQ, WR, TQ, TR, M, NSV, NSQ, 2, false, RG, 0, FL, 0, 2>, base + 2);
+            }
+            return go(k_scan_h16<WQ, WR, TQ, TR, M, NSV, NSQ, 2, false, RG, 0, FL, 0, 1>, base + 1);
+        };
+        auto by_variant = [&](auto mtag, int base) -> int {
+            if (filt) {  // subset filter compiled in (always the ragged-capable variant)
+                if constexpr (WR >= 4) return set_error(LYNSE_ERR_INTERNAL, "subset-filtered scans run on the <4,2,2,4> tiling");
+                else return by_emit(mtag, std::true_type{}, std::true_type{}, base + 6);
+            }
+            if (ragged) return by_emit(mtag, std::true_type{}, std::false_type{}, base + 3);
+            return by_emit(mtag, std::false_type{}, std::false_type{}, base);  // no ragged last slab: branch-free DMA issue
+        };
+        if constexpr (WR >= 4) {  // <2,4,4,2>: unfiltered IP only
+#ifndef LYNSE_EXPERIMENTS
+            if (metric != M_IP) return set_error(LYNSE_ERR_INTERNAL, "the <2,4,4,2> tiling is compiled for IP only");
+#else
+            if (metric == M_L2) return by_variant(std::integral_constant<int, M_L2>{}, 9);
+            if (metric == M_COS) return by_variant(std::integral_constant<int, M_COS>{}, 18);
+#endif
+            return by_variant(std::integral_constant<int, M_IP>{}, 0);
+        } else {
+            switch (metric) {
+            case M_IP:
+#ifndef LYNSE_EXPERIMENTS
+                if (!filt) return set_error(LYNSE_ERR_INTERNAL, "unfiltered IP scans run on the <2,4,4,2> tiling");
+                return by_emit(std::integral_constant<int, M_IP>{}, std::true_type{}, std::true_type{}, 6);
+#else
+                return by_variant(std::integral_constant<int, M_IP>{}, 0);
+#endif
+            case M_L2: return by_variant(std::integral_constant<int, M_L2>{}, 9);
+            default: return by_variant(std::integral_constant<int, M_COS>{}, 18);
             }
         }
-#endif
-        switch (metric) {
-        case M_IP: return go(k_scan_h16<WQ, WR, TQ, TR, M_IP, NSV, NSQ, 2, TILED, false>, 3);
-        case M_L2: return go(k_scan_h16<WQ, WR, TQ, TR, M_L2, NSV, NSQ, 2, TILED, false>, 4);
-        default: return go(k_scan_h16<WQ, WR, TQ, TR, M_COS, NSV, NSQ, 2, TILED, false>, 5);
+    } else {
+        if (!ragged && !filt) {
+            switch (metric) {
+            case M_IP: return go(k_scan_h16<WQ, WR, TQ, TR, M_IP, NSV, NSQ, 2, TILED, false>, 3);
+            case M_L2: return go(k_scan_h16<WQ, WR, TQ, TR, M_L2, NSV, NSQ, 2, TILED, false>, 4);
+            default: return go(k_scan_h16<WQ, WR, TQ, TR, M_COS, NSV, NSQ, 2, TILED, false>, 5);
+            }
         }
-    }
-    if (filt) {  // subset filter compiled in (always the ragged-capable variant: one instantiation per metric)
-        switch (metric) {
-        case M_IP: return go(k_scan_h16<WQ, WR, TQ, TR, M_IP, NSV, NSQ, 2, TILED, true, 0, true>, 6);
-        case M_L2: return go(k_scan_h16<WQ, WR, TQ, TR, M_L2, NSV, NSQ, 2, TILED, true, 0, true>, 7);
-        default: return go(k_scan_h16<WQ, WR, TQ, TR, M_COS, NSV, NSQ, 2, TILED, true, 0, true>, 8);
+        if (filt) {  // subset filter compiled in (always the ragged-capable variant: one instantiation per metric)
+            switch (metric) {
+            case M_IP: return go(k_scan_h16<WQ, WR, TQ, TR, M_IP, NSV, NSQ, 2, TILED, true, 0, true>, 6);
+            case M_L2: return go(k_scan_h16<WQ, WR, TQ, TR, M_L2, NSV, NSQ, 2, TILED, true, 0, true>, 7);
+            default: return go(k_scan_h16<WQ, WR, TQ, TR, M_COS, NSV, NSQ, 2, TILED, true, 0, true>, 8);
+            }
         }
-    }
-    switch (metric) {
-    case M_IP: return go(k_scan_h16<WQ, WR, TQ, TR, M_IP, NSV, NSQ, 2, TILED, true>, 0);
-    case M_L2: return go(k_scan_h16<WQ, WR, TQ, TR, M_L2, NSV, NSQ, 2, TILED, true>, 1);
-    default: return go(k_scan_h16<WQ, WR, TQ, TR, M_COS, NSV, NSQ, 2, TILED, true>, 2);
+        switch (metric) {
+        case M_IP: return go(k_scan_h16<WQ, WR, TQ, TR, M_IP, NSV, NSQ, 2, TILED, true>, 0);
+        case M_L2: return go(k_scan_h16<WQ, WR, TQ, TR, M_L2, NSV, NSQ, 2, TILED, true>, 1);
+        default: return go(k_scan_h16<WQ, WR, TQ, TR, M_COS, NSV, NSQ, 2, TILED, true>, 2);
+        }
     }
 }
 
-// certified int8 coarse pass: the 256 x 256 IP tiling with 3 + 2-stage rings over 128-element slabs
+// certified int8 coarse pass: the 256 x 256 IP tiling with 3 + 2-stage rings over 128-element slabs, one kernel per
+// (ragged last slab, emission mode)
 static int launch_scan_i8c(const ScanArgs& a, uint32_t grid, hipStream_t st) {
     constexpr size_t lds = (size_t)(3 * 256 + 2 * 256) * 128;
-    static bool attr_done[2] = {false, false};
+    static bool attr_done[6] = {false};
     auto go = [&](auto kern, int slot) -> int {
         if (!attr_done[slot]) { LY_TRY(set_max_lds(kern, lds)); attr_done[slot] = true; }
         hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, a);
         LY_HIP(hipGetLastError());
         return LYNSE_OK;
     };
-    if (a.ld16 % 128 == 0) return go(k_scan_h16<2, 4, 4, 2, M_IP, 3, 2, 2, false, false, 0, false, 2>, 0);
-    return go(k_scan_h16<2, 4, 4, 2, M_IP, 3, 2, 2, false, true, 0, false, 2>, 1);
+    if (a.ld16 % 128 == 0) {
+        if (a.emit_all == 0) return go(k_scan_h16<2, 4, 4, 2, M_IP, 3, 2, 2, false, false, 0, false, 2, 0>, 0);
+        if (a.emit_all == 1) return go(k_scan_h16<2, 4, 4, 2, M_IP, 3, 2, 2, false, false, 0, false, 2, 1>, 1);
+        return go(k_scan_h16<2, 4, 4, 2, M_IP, 3, 2, 2, false, false, 0, false, 2, 2>, 2);
+    }
+    if (a.emit_all == 0) return go(k_scan_h16<2, 4, 4, 2, M_IP, 3, 2, 2, false, true, 0, false, 2, 0>, 3);
+    if (a.emit_all == 1) return go(k_scan_h16<2, 4, 4, 2, M_IP, 3, 2, 2, false, true, 0, false, 2, 1>, 4);
+    return go(k_scan_h16<2, 4, 4, 2, M_IP, 3, 2, 2, false, true, 0, false, 2, 2>, 5);
 }
 
 // f16 shadow rows [n16, n) (all rows again when the scale changed)
@@ -1044,7 +1109,11 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
     static const int no_sample = []() { const char* e = getenv("LYNSE_HIP_NO_SAMPLE_PLAN"); return e ? atoi(e) : 0; }();
     // wave tiling of the 256 x 256 tile (measured on MI355X, 10M x 768, 256 queries): IP is fastest with <2,4,4,2> and the
     // 3+2-stage split rings, L2 / cosine (norm ring in LDS, more registers in the epilogue) with <4,2,2,4> and 2+2 stages
+#ifdef LYNSE_EXPERIMENTS
     static const int w16env = []() { const char* e = getenv("LYNSE_HIP_SCAN_W16"); return e ? atoi(e) : -1; }();
+#else
+    constexpr int w16env = -1;  // (the product build compiles each tiling only for the metrics it is the default of)
+#endif
     const bool filt = mask != nullptr || row_ids != nullptr;
     // (the subset-filter variants of <2,4,4,2> spill 96 B into the MFMA loop: masked 10M x 768 scan 7.5 ms vs 4.9 ms with <4,2,2,4>)
     const int waves16 = i8c ? 3 : (w16env >= 0 ? w16env : ((metric == M_IP && !filt) ? 3 : 0));
