@@ -33,6 +33,7 @@ import torch  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F16_PEAK_TFLOPS = 2500.0  # dense f16/bf16 MFMA peak (no sparsity)
+MFMA_I8_PEAK_TOPS = 5000.0     # dense int8 MFMA: twice the f16 rate (MI355X_MICROARCH.md: i8 = 2x K per instruction at the same issue rate)
 GEN_BLOCK = 100_000     # rows per generation block (flat_search_bench.py:71-77 batches of 100k)
 
 
@@ -168,35 +169,55 @@ def main():
         # (The launches of a step also re-scan the 65536 sample rows of the first stage: time counted, bytes not.)
         row_bytes = D * 4 if metric < 3 else ((D + 63) // 64) * 8
         alg_bytes = float(n_local) * row_bytes * args.steps
-        achieved = (alg_bytes / scan_s / 1e9) if scan_s > 0 else 0.0
+        alg_gbps = (alg_bytes / scan_s / 1e9) if scan_s > 0 else 0.0
         prof["scan_bytes"] = int(alg_bytes)
-        variant = int(os.environ.get("LYNSE_HIP_SCAN_VARIANT", "3"))
-        kernel = "k_scan_binary_rows" if metric >= 3 else {3: "k_scan_h16", 0: "k_scan_glds"}.get(variant, "k_scan_f16")
-        # k_scan_h16 streams the f16 shadow of the rows (2 B/element, built once at finalize): the HBM bytes it
-        # HAS to read are half the algorithmic f32 bytes of SURVEY 8(d); both rates are reported.
-        kernel_bytes = prof["scan_bytes"] // 2 if kernel == "k_scan_h16" else prof["scan_bytes"]
-        traffic, traffic_note = None, "no PMC summary under profiles/"
+        plan = int(prof.get("last_plan", 0))
+        i8c = bool(plan & 4)
+        # What the dominant kernel physically streams per row: the certified int8 coarse pass reads the 1-byte SQ8 codes,
+        # the f16 coarse pass the 2-byte shadow (both resident copies built once at finalize); binary metrics the packed words.
+        if metric >= 3:
+            kernel, elem_bytes, mfma_peak, mfma_unit = "k_scan_binary_rows", None, None, None
+            kernel_bytes = alg_bytes
+        elif i8c:
+            kernel, elem_bytes, mfma_peak, mfma_unit = "k_scan_h16<2,4,4,2,IP,i8c>", 1, MFMA_I8_PEAK_TOPS, "TOP/s"
+            kernel_bytes = float(n_local) * (-(-D // 16) * 16) * args.steps
+        else:
+            kernel, elem_bytes, mfma_peak, mfma_unit = "k_scan_h16<f16>", 2, MFMA_F16_PEAK_TFLOPS, "TFLOP/s"
+            kernel_bytes = float(n_local) * (-(-D // 8) * 8) * 2 * args.steps
+        hbm_gbps = (kernel_bytes / scan_s / 1e9) if scan_s > 0 else 0.0
+        # matrix work of the launches (sample rows included: they are really multiplied)
+        ops = 2.0 * B * prof["scan_rows"] * D if metric < 3 else 0.0
+        mfma_rate = (ops / scan_s / 1e12) if scan_s > 0 else 0.0
+        frac_hbm = hbm_gbps / HBM_PEAK_GBPS
+        frac_mfma = (mfma_rate / mfma_peak) if mfma_peak else 0.0
+        traffic, traffic_note = None, "no PMC summary under profiles/ for this kernel"
         try:  # HBM bytes per launch from the committed PMC pass (bench.py itself cannot run rocprofv3 --pmc)
-            pm = json.loads((ROOT / "profiles" / "r01_pmc_traffic.json").read_text())
-            pm = pm.get(kernel, pm if pm.get("kernel") == kernel else None)
-            traffic = int(prof["scan_bytes"] // launches * pm["ratio_hbm_over_algorithmic"])
-            traffic_note = "algorithmic bytes x %.4f (FETCH_SIZE, gfx950-corrected; %s)" % (
-                pm["ratio_hbm_over_algorithmic"], "profiles/r01_pmc_traffic.json")
+            pm = json.loads((ROOT / "profiles" / "r02_pmc_traffic.json").read_text())
+            pm = pm["i8c" if i8c else ("binary" if metric >= 3 else "f16")]
+            traffic = int(kernel_bytes / launches * pm["ratio_hbm_over_kernel_bytes"])
+            traffic_note = "kernel stream bytes x %.4f (FETCH_SIZE, gfx950-corrected x2; %s)" % (
+                pm["ratio_hbm_over_kernel_bytes"], "profiles/r02_pmc_traffic.json")
         except Exception:
             pass
-        flops = 2.0 * B * prof["scan_rows"] * D if metric < 3 else 0.0
+        hbm_bound = frac_hbm >= frac_mfma
         roofline = {
-            "bound": "hbm", "kernel": kernel,
-            "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_note": traffic_note,
+            # the binding PHYSICAL resource of the dominant kernel: bytes it streams / 8 TB/s vs matrix ops / dense MFMA peak
+            "bound": "hbm" if hbm_bound else "mfma", "kernel": kernel,
+            "achieved": round(hbm_gbps if hbm_bound else mfma_rate, 1),
+            "peak": HBM_PEAK_GBPS if hbm_bound else mfma_peak, "unit": "GB/s" if hbm_bound else mfma_unit,
+            "frac": round(max(frac_hbm, frac_mfma), 4), "traffic": traffic, "traffic_note": traffic_note,
+            "hbm": {"achieved": round(hbm_gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(frac_hbm, 4),
+                    "bytes_per_launch": int(kernel_bytes // launches), "element_bytes": elem_bytes},
+            "mfma": {"achieved": round(mfma_rate, 1), "peak": mfma_peak, "unit": mfma_unit, "frac": round(frac_mfma, 4)},
+            # SURVEY 8(d) accounting: algorithmic f32 bytes (rows x dim x 4 B per step) / the same HIP-event time.  NOT a
+            # roofline for this design (the kernel never reads the f32 rows): kept as the figure 8(d) defines.
+            "algorithmic": {"achieved": round(alg_gbps, 1), "unit": "GB/s", "frac_of_hbm_peak": round(alg_gbps / HBM_PEAK_GBPS, 4),
+                            "bytes_per_launch": int(alg_bytes // launches)},
             "launches": launches, "avg_launch_us": round(prof["scan_us"] / launches, 2),
-            "algorithmic_bytes_per_launch": int(prof["scan_bytes"] // launches), "launches_per_step": round(launches / max(args.steps, 1), 2),
-            "kernel_hbm_bytes_per_launch": int(kernel_bytes // launches),
-            "hbm_achieved": round(kernel_bytes / scan_s / 1e9, 1) if scan_s > 0 else 0.0,
-            "mfma_achieved_tflops": round(flops / scan_s / 1e12, 1) if scan_s > 0 else 0.0, "mfma_peak_tflops": MFMA_F16_PEAK_TFLOPS,
-            "note": "rank-0 shard; achieved = SURVEY 8(d) algorithmic bytes (rows scanned x dim x 4 B) / HIP-event time of the "
-                    "scan launches; k_scan_h16 reads a resident f16 copy of the rows, so its own HBM stream is "
-                    "kernel_hbm_bytes_per_launch (= hbm_achieved GB/s) and the kernel sits between the HBM and the f16 MFMA roof",
+            "launches_per_step": round(launches / max(args.steps, 1), 2),
+            "plan": {"sampled": bool(plan & 1), "threshold_only_sample": bool(plan & 2), "int8_coarse_pass": i8c,
+                     "segmented_emission": bool(plan & 8), "stages": (plan >> 8) & 0xff, "tiling": hex((plan >> 16) & 0xff)},
+            "note": "rank-0 shard; time = sum of HIP-event durations of the scan launches on the launch stream inside the timed region",
         }
         result = {
             "metric": "queries/sec, FLAT-%s %dx%d float32, batch=%d, k=%d" % (args.metric.upper(), N, D, B, K),
@@ -205,8 +226,8 @@ def main():
             "scaling": "strong", "vs_baseline": None,
             "dtype": "f32" if metric < 3 else "u64", "data": "synthetic",
             "dtype_note": ("returned distances are exact f32 (reference accumulation order, bit-identical to the oracle); "
-                           "the scan is an f16-MFMA prefilter with a certified error margin, survivors are rescored from "
-                           "the f32 rows") if metric < 3 else "popcount over packed u64 words",
+                           "the scan is a certified %s MFMA prefilter (per-query error bound), survivors are rescored "
+                           "from the f32 rows" % ("int8" if i8c else "f16")) if metric < 3 else "popcount over packed u64 words",
             "config": {"workload": "FLAT-%s %dx%d f32 uniform[0,1), %d queries = perturbed rows, k=%d"
                                    % (args.metric.upper(), N, D, B, K),
                        "rows_per_gpu": n_local, "sharding": "row %% %d" % world,

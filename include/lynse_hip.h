@@ -80,6 +80,11 @@ typedef struct lynse_hip_profile {
     double total_us;          /* whole pipeline, first launch -> last launch */
     uint64_t fallback_queries;/* queries re-run on the exhaustive safe plan */
     uint64_t pool_entries;    /* candidates rescored exactly (sum over queries) */
+    uint64_t last_plan;       /* plan of the last profiled float chunk: bit 0 sampled stage plan, bit 1 threshold-only
+                                 (lane-max) sample stage, bit 2 certified int8 coarse pass, bit 3 segmented emission,
+                                 bit 4 <= 32-query kernel, bits 8..15 number of scan stages, bits 16..23 wave tiling
+                                 (0x24 = <2,4,4,2>, 0x42 = <4,2,2,4>, 0x14 = <1,4,1,1>) — lets a test pin the kernel
+                                 instantiation a benchmark configuration runs */
 } lynse_hip_profile;
 
 /* ---- library ---- */

@@ -31,7 +31,7 @@ IPFORM_AUTO, IPFORM_SINGLE, IPFORM_BATCH8 = 0, 1, 2
 class Profile(C.Structure):
     _fields_ = [("searches", C.c_uint64), ("scan_launches", C.c_uint64), ("scan_us", C.c_double),
                 ("scan_rows", C.c_uint64), ("scan_bytes", C.c_uint64), ("total_us", C.c_double),
-                ("fallback_queries", C.c_uint64), ("pool_entries", C.c_uint64)]
+                ("fallback_queries", C.c_uint64), ("pool_entries", C.c_uint64), ("last_plan", C.c_uint64)]
 
 
 _f32p, _u32p, _u64p = C.POINTER(C.c_float), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)

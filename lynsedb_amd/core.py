@@ -324,7 +324,7 @@ class IvfFlatIndex:
     @staticmethod
     def build(path, data, dim: int, n_partitions: int = 256, n_iters: int = 20, metric: str = "ip",
               device: Optional[int] = None, l2_partitions: bool = True) -> "IvfFlatIndex":
-        m = metric_from_str(metric)
+        m = metric if isinstance(metric, int) else metric_from_str(metric)
         a = _f32(data, 2, "data")
         if a.shape[1] != dim:
             raise ValueError(f"data dimension mismatch: expected {dim}, got {a.shape[1]}")
@@ -418,12 +418,27 @@ class IvfFlatIndex:
                                                     _ptr(rows), _ptr(dists), _ptr(counts)))
         return rows[:, :k], dists[:, :k], counts
 
+    def search_metric_batch_arrays(self, queries, k: int, nprobe: int, metric):
+        """`IvfFlatMmap::search(query, k, nprobe, metric)` (ivf_flat_mmap.rs:225-305): the metric of the CALL drives the
+        centroid routing, the scoring and the sort direction — the partitions are metric-agnostic."""
+        m = metric if isinstance(metric, int) else metric_from_str(metric)
+        q = _f32(queries, 2, "queries")
+        if q.shape[1] != self._dim:
+            raise ValueError(f"query dimension mismatch: expected {self._dim}, got {q.shape[1]}")
+        nq, k = q.shape[0], int(k)
+        rows = np.empty((nq, max(k, 1)), np.uint64)
+        dists = np.empty((nq, max(k, 1)), np.float32)
+        counts = np.zeros(nq, np.uint32)
+        check(lib.lynse_hip_ivf_search_metric_f32(self._h, _ptr(q), nq, k, int(nprobe), m, _ptr(rows), _ptr(dists), _ptr(counts)))
+        return rows[:, :k], dists[:, :k], counts
+
     def search(self, query, k: int = 10, nprobe: int = 10, metric: str = "ip"):
-        metric_from_str(metric)  # validates like the reference (ValueError on unknown names)
+        """PyIvfFlatIndex.search (src/python/mod.rs:2130-2155): `metric` is the metric of this search."""
+        m = metric_from_str(metric)  # ValueError on unknown names, like the reference
         q = _f32(query, 1, "query")
         if q.size != self._dim:
             raise ValueError(f"query dimension mismatch: expected {self._dim}, got {q.size}")
-        rows, dists, counts = self.search_batch_arrays(q.reshape(1, -1), k, nprobe)
+        rows, dists, counts = self.search_metric_batch_arrays(q.reshape(1, -1), k, nprobe, m)
         c = int(counts[0])
         return rows[0, :c].astype(np.uint32), dists[0, :c].copy()
 
@@ -505,25 +520,72 @@ class SearchResult:
         return f"SearchResult(n={len(self)}, k={self._k}, dim={self._dim}, index={self._mode})"
 
 
+PENDING_INGEST_FLUSH_ROWS = 10_000              # src/engine.rs:93
+PENDING_INGEST_FLUSH_BYTES = 32 * 1024 * 1024   # src/engine.rs:94
+
+
+class BitSet:
+    """Row subset in the reference's layout (src/storage/bitset.rs): u64 words, bit r of word r // 64 = row r."""
+
+    def __init__(self, n_rows: int, words: Optional[np.ndarray] = None):
+        self.n_rows = int(n_rows)
+        nw = (self.n_rows + 63) // 64
+        self.words = np.zeros(nw, np.uint64) if words is None else np.ascontiguousarray(words, dtype=np.uint64)
+        if self.words.size != nw:
+            raise ValueError("BitSet words do not match the row count")
+
+    @staticmethod
+    def from_rows(rows, n_rows: int) -> "BitSet":
+        b = BitSet(n_rows)
+        r = np.unique(np.asarray(rows, dtype=np.uint64).reshape(-1))
+        r = r[r < np.uint64(n_rows)]
+        np.bitwise_or.at(b.words, (r >> np.uint64(6)).astype(np.int64), np.uint64(1) << (r & np.uint64(63)))
+        return b
+
+    def count(self) -> int:
+        return int(np.unpackbits(self.words.view(np.uint8)).sum())
+
+    def contains(self, row: int) -> bool:
+        return 0 <= row < self.n_rows and bool((int(self.words[row >> 6]) >> (row & 63)) & 1)
+
+    def to_vec(self) -> np.ndarray:
+        bits = np.unpackbits(self.words.view(np.uint8), bitorder="little")
+        return np.nonzero(bits)[0].astype(np.uint64)
+
+
 class Collection:
-    """The search-path subset of `lynse._core.Collection` (engine.rs Collection)."""
+    """The search-path subset of `lynse._core.Collection` (engine.rs Collection): buffered ingest, commit, index build
+    and `search / batch_search` = `search_with_precomputed_filter` (src/engine.rs:4718-4833): k inflated by the
+    tombstone count, the index / flat / subset-filtered search over the flushed rows on the GPU, the pending (not yet
+    flushed) rows scored with `top_k_search`, `merge_row_results`, row -> user id, `filter_tombstoned_limit`.
+
+    The reference resolves `where_expr` to a row BitSet through its field store (out of scope); the
+    precomputed filter itself is in scope and is passed here as `subset=` (a `BitSet` or an array of row indices)."""
 
     def __init__(self, name: str, dim: int, device: Optional[int] = None):
         self._name, self._dim = name, int(dim)
         self._device = device
         self._flat = FlatIndex(None, dim, device)
-        self._ids: list = []           # row -> user id (engine.rs:3071-3073)
-        self._id_arrays: list = []
+        self._id_arrays: list = []     # row -> user id (engine.rs:3071-3073)
         self._index_mode = "FLAT-IP"   # resolve_metric default IP (engine.rs:5529-5534)
         self._metric = _lib.METRIC_IP
         self._ivf: Optional[IvfFlatIndex] = None
+        self._ivf_rows = 0              # rows the IVF index was built over
+        self._ivf_params: dict = {}
         self._ivf_nprobe = 32           # IndexBuildOptions default (src/index/mod.rs:498-655)
-        self._pending: list = []
+        self._pending_vecs: list = []   # PendingIngestBuffer (engine.rs:125, :190-245)
+        self._pending_ids: list = []
+        self._pending_rows = 0
+        self._tombstone: set = set()    # user ids (engine.rs:3182-3194)
 
     def name(self) -> str:
         return self._name
 
+    # -- ingest -------------------------------------------------------------------------------
     def add_items(self, vectors, ids: Sequence[int], fields=None) -> None:
+        """Buffered like the reference (engine.rs:3886-3900): rows wait in the pending buffer until it holds
+        PENDING_INGEST_FLUSH_ROWS rows / PENDING_INGEST_FLUSH_BYTES bytes, or until commit(); searches see them through
+        `pending_search`."""
         a = _f32(vectors, 2, "vectors")
         if a.shape[1] != self._dim:
             raise RuntimeError(f"Dimension mismatch: expected {self._dim}, got {a.shape[1]}")
@@ -531,68 +593,179 @@ class Collection:
             raise RuntimeError("ids length must match the number of vectors")
         if fields is not None:
             raise NotImplementedError("field metadata is outside the FLAT/IVF hot path (SURVEY.md §2 #20)")
-        self._flat.write(a)
-        self._id_arrays.append(np.asarray(ids, dtype=np.int64))
+        if a.shape[0] == 0:
+            return
+        self._pending_vecs.append(np.array(a, dtype=np.float32, copy=True))
+        self._pending_ids.append(np.asarray(ids, dtype=np.int64).copy())
+        self._pending_rows += a.shape[0]
+        if self._pending_rows >= PENDING_INGEST_FLUSH_ROWS or self._pending_rows * self._dim * 4 >= PENDING_INGEST_FLUSH_BYTES:
+            self._flush_pending()
+
+    def pending_len(self) -> int:
+        return self._pending_rows
+
+    def _flush_pending(self) -> None:  # Collection::flush_pending_ingest (engine.rs:3573-3590)
+        for a, i in zip(self._pending_vecs, self._pending_ids):
+            self._flat.write(a)
+            self._id_arrays.append(i)
+        self._pending_vecs, self._pending_ids, self._pending_rows = [], [], 0
 
     def commit(self) -> None:
+        self._flush_pending()
         self._flat.finalize()
 
     def shape(self):
-        return (len(self._flat), self._dim)
+        return (len(self._flat) + self._pending_rows, self._dim)
 
     def _id_map(self) -> np.ndarray:
         if len(self._id_arrays) != 1:
             self._id_arrays = [np.concatenate(self._id_arrays) if self._id_arrays else np.zeros(0, np.int64)]
         return self._id_arrays[0]
 
+    # -- soft deletes (engine.rs:3182-3284) -----------------------------------------------------
+    def delete_items(self, ids: Iterable[int]) -> None:
+        self._tombstone.update(int(i) for i in ids)
+
+    def restore_items(self, ids: Iterable[int]) -> None:
+        self._tombstone.difference_update(int(i) for i in ids)
+
+    def list_deleted_ids(self) -> list:
+        return sorted(self._tombstone)
+
+    # -- index --------------------------------------------------------------------------------
     def build_index(self, index_type: str, params: Optional[dict] = None) -> None:
-        """Collection::build_index_with_build_options (engine.rs:4515-4655): FLAT-* keeps no index object
-        (engine.rs:4559-4567); IVF-* trains a k-means IVF (engine.rs:4616-4627)."""
+        """Collection::build_index_with_build_options (engine.rs:4515-4655): flushes the pending rows (:4521); FLAT-*
+        keeps no index object (engine.rs:4559-4567; `FLAT-*-SQ8` switches the flat scan to the SQ8 two-pass mode,
+        flat_mmap.rs:891-905); IVF-* trains a k-means IVFIndex (engine.rs:4616-4627), `IVF-{HAMMING,JACCARD}-BINARY`
+        the binary-quantised one (src/index/mod.rs:376-385)."""
         mode = str(index_type).upper()
         try:
             metric = metric_from_index_mode(mode)
+        except NotImplementedError:
+            raise
         except ValueError as e:
             raise RuntimeError(str(e))
         params = dict(params or {})
+        self._flush_pending()
         if mode.startswith("FLAT"):
+            if any(t in mode.split("-") for t in ("PQ", "RABITQ", "POLARVEC")):
+                raise NotImplementedError("PQ / RaBitQ / PolarVec flat modes are outside this path (SURVEY.md §2)")
             self._ivf = None
         elif mode.startswith("IVF"):
-            if any(t in mode for t in ("SQ8", "PQ")):
+            if any(t in mode.split("-") for t in ("SQ8", "PQ")):
                 raise NotImplementedError("quantized IVF variants are outside this path")
-            nlist = int(params.get("n_clusters", 256))
+            self._ivf_params = {"n_clusters": int(params.get("n_clusters", 256))}
             self._ivf_nprobe = int(params.get("nprobe", 32))
-            data = self._flat.read_rows(0, len(self._flat))
-            self._ivf = IvfFlatIndex.build(None, data, self._dim, min(nlist, max(len(self._flat), 1)), 20,
-                                           "ip" if metric == _lib.METRIC_IP else
-                                           {1: "l2", 2: "cosine"}.get(metric, "l2"),
-                                           device=self._device, l2_partitions=False)
+            self._index_mode, self._metric = mode, metric
+            self._build_ivf()
         else:
             raise NotImplementedError(f"index type {index_type} is outside the FLAT/IVF hot path")
         self._index_mode, self._metric = mode, metric
 
-    def _wrap(self, rows, dists, count, k) -> SearchResult:
-        ids = self._id_map()[rows[:count].astype(np.int64)]
-        return SearchResult(ids, dists[:count].copy(), self._index_mode, self._dim, k)
+    def _build_ivf(self) -> None:
+        n = len(self._flat)
+        data = self._flat.read_rows(0, n)
+        nlist = min(self._ivf_params["n_clusters"], max(n, 1))
+        # the metric id goes through as it is: binary metrics build the IVF-*-BINARY mode, float metrics an IVFIndex
+        # trained with its routing metric (ivf.rs:163-170)
+        self._ivf = IvfFlatIndex.build(None, data, self._dim, nlist, 20, int(self._metric), device=self._device, l2_partitions=False)
+        self._ivf_rows = n
+
+    def _use_sq8(self) -> bool:  # Collection::resolve_use_sq8 (engine.rs:4684-4689)
+        return "SQ8" in self._index_mode.upper()
+
+    # -- search -------------------------------------------------------------------------------
+    def _subset_rows(self, subset) -> Optional[np.ndarray]:
+        if subset is None:
+            return None
+        if isinstance(subset, BitSet):
+            return subset.to_vec()
+        return np.unique(np.asarray(subset, dtype=np.uint64).reshape(-1))
+
+    def _pending_search(self, query: np.ndarray, k: int, subset_rows: Optional[np.ndarray]):
+        """Collection::pending_search (engine.rs:3310-3361): the un-flushed rows, scored with `top_k_search`."""
+        if k == 0 or self._pending_rows == 0:
+            return np.zeros(0, np.uint64), np.zeros(0, np.float32)
+        data = np.concatenate(self._pending_vecs) if len(self._pending_vecs) > 1 else self._pending_vecs[0]
+        row_offsets = np.arange(len(self._flat), len(self._flat) + data.shape[0], dtype=np.uint64)
+        if subset_rows is not None:
+            keep = np.isin(row_offsets, subset_rows)
+            data, row_offsets = np.ascontiguousarray(data[keep]), row_offsets[keep]
+        if row_offsets.size == 0:
+            return np.zeros(0, np.uint64), np.zeros(0, np.float32)
+        idx, dists = py_top_k_search(query, data, _METRIC_NAMES[self._metric], k)
+        return row_offsets[idx.astype(np.int64)], dists
+
+    def _user_ids(self, rows: np.ndarray) -> np.ndarray:
+        """row_to_user_id (engine.rs:3071-3073) over flushed and pending rows."""
+        rows = rows.astype(np.int64)
+        n_flat = len(self._flat)
+        if self._pending_rows == 0:
+            return self._id_map()[rows]
+        ids = np.concatenate([self._id_map()] + self._pending_ids)
+        assert ids.size == n_flat + self._pending_rows
+        return ids[rows]
+
+    def _base_search(self, q: np.ndarray, search_k: int, nprobe: int, subset_rows: Optional[np.ndarray]):
+        """The device part of search_with_precomputed_filter for a batch sharing one subset -> rows, dists, counts."""
+        nq = q.shape[0]
+        if len(self._flat) == 0 or search_k == 0:
+            return np.zeros((nq, 0), np.uint64), np.zeros((nq, 0), np.float32), np.zeros(nq, np.uint32)
+        if self._ivf is not None:
+            if self._ivf_rows != len(self._flat):
+                self._build_ivf()  # rows were committed after the build (the reference inserts them incrementally; here: retrain)
+            np_ = self._ivf_nprobe if not nprobe else int(nprobe)  # nprobe == 0 -> the build default (engine.rs:4743-4746)
+            if subset_rows is not None:
+                if subset_rows.size == 0:
+                    return np.zeros((nq, 0), np.uint64), np.zeros((nq, 0), np.float32), np.zeros(nq, np.uint32)
+                return self._ivf.search_filtered_batch_arrays(q, search_k, np_, subset_rows)
+            return self._ivf.search_batch_arrays(q, search_k, np_)
+        if subset_rows is not None:  # brute_force_search_filtered (engine.rs:5541-5566): always the exact filtered scan
+            if subset_rows.size == 0:
+                return np.zeros((nq, 0), np.uint64), np.zeros((nq, 0), np.float32), np.zeros(nq, np.uint32)
+            return self._flat.search_filtered_batch_arrays(q, search_k, self._metric, subset_rows)
+        if self._use_sq8() and self._metric in (_lib.METRIC_IP, _lib.METRIC_L2, _lib.METRIC_COSINE):
+            return self._flat.search_sq8_batch_arrays(q, search_k, self._metric)
+        return self._flat.search_batch_arrays(q, search_k, self._metric)
 
     def search(self, vector, k: Optional[int] = None, where_expr: Optional[str] = None,
-               nprobe: Optional[int] = None, approx: Optional[bool] = None, eps: Optional[float] = None) -> SearchResult:
-        res = self.batch_search(np.asarray(vector, dtype=np.float32).reshape(1, -1), k, where_expr, nprobe)
+               nprobe: Optional[int] = None, approx: Optional[bool] = None, eps: Optional[float] = None,
+               subset=None) -> SearchResult:
+        res = self.batch_search(np.asarray(vector, dtype=np.float32).reshape(1, -1), k, where_expr, nprobe, subset=subset)
         return res[0]
 
     def batch_search(self, vectors, k: Optional[int] = None, where_expr: Optional[str] = None,
-                     nprobe: Optional[int] = None) -> list:
+                     nprobe: Optional[int] = None, subset=None) -> list:
+        """Collection::batch_search (engine.rs:5352-5498): one shared filter, every query through
+        `search_with_precomputed_filter`; the flushed rows of the whole batch are scanned in ONE pass on the GPU."""
         if where_expr:
-            raise NotImplementedError("filtered search is a 'next' row (SURVEY.md §8f #1)")
+            raise NotImplementedError("`where_expr` needs the field store (out of scope, SURVEY.md §2); pass the resolved "
+                                      "row filter as subset=BitSet | row indices (search_with_precomputed_filter)")
         k = 10 if k is None else int(k)
         q = _f32(vectors, 2, "vectors")
         if q.shape[1] != self._dim:  # engine.rs:4707-4712 -> wrapped as RuntimeError (src/python/mod.rs:1190)
             raise RuntimeError(f"Dimension mismatch: expected {self._dim}, got {q.shape[1]}")
-        if self._ivf is not None:
-            np_ = self._ivf_nprobe if not nprobe else int(nprobe)
-            rows, dists, counts = self._ivf.search_batch_arrays(q, k, np_)
-        else:
-            rows, dists, counts = self._flat.search_batch_arrays(q, k, self._metric)
-        return [self._wrap(rows[i], dists[i], int(counts[i]), k) for i in range(q.shape[0])]
+        from .shard_node import filter_tombstoned_limit, merge_row_results
+
+        subset_rows = self._subset_rows(subset)
+        tomb = np.fromiter(self._tombstone, dtype=np.uint64, count=len(self._tombstone))
+        search_k = k if tomb.size == 0 else k + int(tomb.size)   # engine.rs:4735-4747
+        rows, dists, counts = self._base_search(q, search_k, int(nprobe or 0), subset_rows)
+        out = []
+        for i in range(q.shape[0]):
+            c = int(counts[i])
+            r_i, d_i = rows[i, :c].astype(np.uint64), dists[i, :c]
+            if self._pending_rows:
+                p_r, p_d = self._pending_search(q[i], search_k, subset_rows)
+                r_i, d_i = merge_row_results(r_i, d_i, p_r, p_d, search_k, self._metric)   # engine.rs:4800-4813
+            ids = self._user_ids(r_i).astype(np.uint64)
+            ids, d_i = filter_tombstoned_limit(ids, d_i, tomb, k)                              # engine.rs:4819-4820
+            out.append(SearchResult(ids.astype(np.int64), np.asarray(d_i, np.float32), self._index_mode, self._dim, k))
+        return out
+
+
+_METRIC_NAMES = {_lib.METRIC_IP: "ip", _lib.METRIC_L2: "l2", _lib.METRIC_COSINE: "cosine", _lib.METRIC_HAMMING: "hamming",
+                 _lib.METRIC_JACCARD: "jaccard", _lib.METRIC_DICE: "dice", _lib.METRIC_TANIMOTO: "tanimoto"}
 
 
 class DatabaseManager:

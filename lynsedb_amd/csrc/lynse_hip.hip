@@ -1133,6 +1133,7 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
     // k <= keys per tile: the best sample tile alone supplies k keys (a shard sorted by score still gets a tight threshold)
     const bool sample_threshold_only = h16 && !binary && !filt && sample.sample_tiles && !no_lane_max && sample_keys_per_tile &&
                                        (k <= sample_keys_per_tile || (uint64_t)sample.sample_tiles * sample_keys_per_tile >= 8ull * k);
+    bool plan_used_segments = false;
     for (size_t si = 0; si < plan.size(); ++si) {
         const Stage s = plan[si];
         const bool emit_all = si == 0;
@@ -1256,6 +1257,7 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
 #endif
             (void)variant;
             st_nseg = a.seg ? a.nseg : 0; st_seg = a.seg;
+            plan_used_segments = plan_used_segments || a.seg != 0;
         }
         if (h->profiling) {
             LY_HIP(hipEventRecord(e1, st));
@@ -1276,6 +1278,11 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
         sa.candB = w.candB; sa.segcnt = w.segcnt; sa.seg = st_seg; sa.nseg = st_nseg;
         hipLaunchKernelGGL(k_select<SEL_NT>, dim3(nq), dim3(SEL_NT), (size_t)w.cap * 8, st, sa);
         LY_HIP(hipGetLastError());
+    }
+    if (h->profiling && !binary) {
+        const uint64_t tiling = small ? 0x14u : ((waves16 == 3 || waves16 == 2) ? 0x24u : 0x42u);
+        h->prof.last_plan = (sample.sample_tiles ? 1u : 0u) | ((sample.sample_tiles && sample_threshold_only) ? 2u : 0u) | (i8c ? 4u : 0u) |
+                            (plan_used_segments ? 8u : 0u) | (small ? 16u : 0u) | ((uint64_t)(plan.size() & 0xff) << 8) | (tiling << 16);
     }
     FinalArgs fa{};
     fa.cand = w.cand; fa.count = w.count; fa.k = k; fa.out_k = out_k; fa.cap = w.cap; fa.metric = metric; fa.ip_form = ip_form;

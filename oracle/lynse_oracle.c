@@ -643,6 +643,116 @@ static void *scan_worker(void *arg) {
     return NULL;
 }
 
+/* ---- persistent worker pool (the timed CPU baseline only) ----
+ * The reference scans on rayon's GLOBAL pool (RAYON_NUM_THREADS; scripts/perf_gate_local.py:218 defaults it to 4): threads
+ * are created once, not per query.  lo_pool_start(n) creates n workers pinned to cpus 0..n-1 and parked on a condition
+ * variable; while the pool runs, the *_mt entry points hand chunk ci to worker ci % n (static, so the worker that
+ * first-touched a chunk of the sample in lo_fill_uniform_mt is the one that scans it).  Results do not depend on the
+ * pool: chunking and merge order are those of run_chunked either way. */
+static struct {
+    pthread_t *th; int n; int started;
+    pthread_mutex_t mu; pthread_cond_t cv_go, cv_done;
+    unsigned long gen; int pending, stop;
+    void (*fn)(void *arg, int worker, int n_workers); void *arg;
+} g_pool = {0};
+
+typedef struct { int id; } pool_worker_t;
+
+static void *pool_main(void *p) {
+    const int id = ((pool_worker_t *)p)->id;
+    free(p);
+    unsigned long seen = 0;
+    for (;;) {
+        pthread_mutex_lock(&g_pool.mu);
+        while (g_pool.gen == seen && !g_pool.stop) pthread_cond_wait(&g_pool.cv_go, &g_pool.mu);
+        if (g_pool.stop) { pthread_mutex_unlock(&g_pool.mu); return NULL; }
+        seen = g_pool.gen;
+        void (*fn)(void *, int, int) = g_pool.fn;
+        void *arg = g_pool.arg;
+        const int n = g_pool.n;
+        pthread_mutex_unlock(&g_pool.mu);
+        fn(arg, id, n);
+        pthread_mutex_lock(&g_pool.mu);
+        if (--g_pool.pending == 0) pthread_cond_signal(&g_pool.cv_done);
+        pthread_mutex_unlock(&g_pool.mu);
+    }
+}
+
+void lo_pool_stop(void) {
+    if (!g_pool.started) return;
+    pthread_mutex_lock(&g_pool.mu);
+    g_pool.stop = 1;
+    pthread_cond_broadcast(&g_pool.cv_go);
+    pthread_mutex_unlock(&g_pool.mu);
+    for (int i = 0; i < g_pool.n; ++i) pthread_join(g_pool.th[i], NULL);
+    free(g_pool.th);
+    pthread_mutex_destroy(&g_pool.mu); pthread_cond_destroy(&g_pool.cv_go); pthread_cond_destroy(&g_pool.cv_done);
+    memset(&g_pool, 0, sizeof g_pool);
+}
+
+int lo_pool_start(int n_threads) {
+    lo_pool_stop();
+    if (n_threads < 1) return 0;
+    pthread_mutex_init(&g_pool.mu, NULL); pthread_cond_init(&g_pool.cv_go, NULL); pthread_cond_init(&g_pool.cv_done, NULL);
+    g_pool.th = (pthread_t *)malloc((size_t)n_threads * sizeof(pthread_t));
+    g_pool.n = n_threads;
+    const long ncpu = sysconf(_SC_NPROCESSORS_ONLN);
+    for (int i = 0; i < n_threads; ++i) {
+        pool_worker_t *w = (pool_worker_t *)malloc(sizeof *w);
+        w->id = i;
+        pthread_create(&g_pool.th[i], NULL, pool_main, w);
+        if (ncpu > 0) {  /* best effort: keeps a worker (and the pages it first-touched) on one NUMA node */
+            cpu_set_t set;
+            CPU_ZERO(&set);
+            CPU_SET((int)(i % ncpu), &set);
+            (void)pthread_setaffinity_np(g_pool.th[i], sizeof set, &set);
+        }
+    }
+    g_pool.started = 1;
+    return n_threads;
+}
+
+static void pool_run(void (*fn)(void *, int, int), void *arg) {
+    pthread_mutex_lock(&g_pool.mu);
+    g_pool.fn = fn; g_pool.arg = arg; g_pool.pending = g_pool.n; g_pool.gen += 1;
+    pthread_cond_broadcast(&g_pool.cv_go);
+    while (g_pool.pending) pthread_cond_wait(&g_pool.cv_done, &g_pool.mu);
+    pthread_mutex_unlock(&g_pool.mu);
+}
+
+static void pool_scan(void *arg, int worker, int n_workers) {
+    scan_t *s = (scan_t *)arg;
+    for (size_t ci = (size_t)worker; ci < s->n_chunks; ci += (size_t)n_workers) scan_one_chunk(s, ci);
+}
+
+typedef struct { float *dst; size_t n, dim, chunk_rows; uint64_t seed; } fill_t;
+
+static void pool_fill(void *arg, int worker, int n_workers) {
+    fill_t *f = (fill_t *)arg;
+    const size_t n_chunks = (f->n + f->chunk_rows - 1) / f->chunk_rows;
+    for (size_t ci = (size_t)worker; ci < n_chunks; ci += (size_t)n_workers) {
+        const size_t r0 = ci * f->chunk_rows, r1 = r0 + f->chunk_rows < f->n ? r0 + f->chunk_rows : f->n;
+        uint64_t x = f->seed * 0x9E3779B97F4A7C15ull + (uint64_t)ci * 0xD1B54A32D192ED03ull + 1;
+        float *p = f->dst + r0 * f->dim;
+        for (size_t i = 0, m = (r1 - r0) * f->dim; i < m; ++i) {  /* xorshift64*: uniform [0,1) with 24 random bits */
+            x ^= x >> 12; x ^= x << 25; x ^= x >> 27;
+            p[i] = (float)((x * 0x2545F4914F6CDD1Dull) >> 40) * (1.0f / 16777216.0f);
+        }
+    }
+}
+
+/* Fill an UNTOUCHED buffer with uniform [0,1) rows using the pool, chunked exactly like the scan (n / threads rows, at
+ * least 512): every page is first touched by the worker that will scan it.  Needs a running pool. */
+int lo_fill_uniform_mt(float *dst, size_t n, size_t dim, uint64_t seed) {
+    if (!g_pool.started || !dst) return -1;
+    fill_t f;
+    f.dst = dst; f.n = n; f.dim = dim; f.seed = seed;
+    f.chunk_rows = n / (size_t)g_pool.n;
+    if (f.chunk_rows < 512) f.chunk_rows = 512;
+    pool_run(pool_fill, &f);
+    return 0;
+}
+
 static size_t run_chunked(scan_t *s, int n_threads, int real_threads, uint32_t *out_idx,
                           float *out_dist) {
     size_t min_chunk = s->prow ? 1024 : 512; /* flat_mmap.rs:1379 / :4857 */
@@ -655,7 +765,9 @@ static size_t run_chunked(scan_t *s, int n_threads, int real_threads, uint32_t *
     entry_t *pool = (entry_t *)malloc(s->n_chunks * s->k * sizeof(entry_t));
     for (size_t i = 0; i < s->n_chunks; ++i) s->chunk_out[i] = pool + i * s->k;
     s->next = 0;
-    if (real_threads && t > 1) {
+    if (real_threads && t > 1 && g_pool.started && (size_t)g_pool.n == t) {
+        pool_run(pool_scan, s);  /* persistent pool (timed baseline) */
+    } else if (real_threads && t > 1) {
         pthread_t *th = (pthread_t *)malloc(t * sizeof(pthread_t));
         for (size_t i = 0; i < t; ++i) pthread_create(&th[i], NULL, scan_worker, s);
         for (size_t i = 0; i < t; ++i) pthread_join(th[i], NULL);

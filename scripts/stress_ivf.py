@@ -9,12 +9,15 @@ import lynsedb_amd as L  # noqa: E402
 import oracle as O  # noqa: E402
 
 orc = O.get()
-budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+# first argument: seconds, or "c<N>" = exactly N cases (machine-independent case list for a given seed)
+_a1 = sys.argv[1] if len(sys.argv) > 1 else "60"
+max_cases = int(_a1[1:]) if _a1.startswith("c") else None
+budget = float("inf") if max_cases is not None else float(_a1)
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 NAME = {O.IP: "ip", O.L2: "l2", O.COS: "cosine", O.HAMMING: "hamming", O.JACCARD: "jaccard"}
 t0, cases, bad = time.time(), 0, []
 compared, skipped = {}, 0
-while time.time() - t0 < budget:
+while time.time() - t0 < budget and (max_cases is None or cases < max_cases):
     n = int(rng.choice([50, 700, 3000, 9000]))
     dim = int(rng.choice([4, 16, 33, 64, 100]))
     nlist = int(rng.choice([1, 2, 8, 40, 130]))

@@ -1,0 +1,177 @@
+"""Deterministic `-m gpu` oracle tests of the BASELINE.json configurations at sizes that reach the SAME kernel
+instantiations and stage plans the benchmark times (VERDICT r1 "next round" item 1).  Every case goes through the C-ABI,
+is compared bit for bit (ids and f32 distance bits) with the CPU oracle on a fixed set of queries, and pins the plan it
+ran through `profile_get()["last_plan"]` (include/lynse_hip.h):
+
+  C2  FLAT-IP 2.4M x 768, 256 queries, k=10 : certified int8 coarse pass on the <2,4,4,2> tiling, sampled plan with the
+      threshold-only (lane-max) sample stage + 2 threshold stages = 3 scan launches, no fallback — the kernels
+      bench.py times (flat_mmap.rs:4845-4982)
+  C3  FLAT-L2 SIFT-like 1M x 128, 256 queries, k=100 : <4,2,2,4> tiling, emit-all sampled plan (benchmarks/sift_io.py:87-89)
+  C4  IVF-IP 768-d, nlist=4096, nprobe=32, 520k rows: centroid store right at the 4096-row single / batch-8 boundary,
+      nprobe >= nlist, subset-filtered (src/index/ivf.rs:181-348)
+  C5  Hamming 10M x 1024-bit, k=50, nq in {1, 256}: massive ties at the k-th distance (flat_mmap.rs:1345-1409)
+"""
+import numpy as np
+import pytest
+
+import oracle as O
+
+pytestmark = pytest.mark.gpu
+f32 = np.float32
+
+PLAN_SAMPLED, PLAN_THRESHOLD_ONLY, PLAN_I8C, PLAN_SEGMENTS, PLAN_SMALL = 1, 2, 4, 8, 16
+
+
+def plan_fields(p):
+    lp = int(p["last_plan"])
+    return lp & 0xff, (lp >> 8) & 0xff, (lp >> 16) & 0xff   # flags, stages, tiling
+
+
+@pytest.fixture(scope="module")
+def L():
+    import lynsedb_amd as L_
+
+    assert L_._lib.device_count() >= 1
+    return L_
+
+
+def assert_rows_equal(oracle_res, rows, dists, count, tag):
+    e_ids, e_d = oracle_res
+    c = int(count)
+    assert c == len(e_ids), (tag, c, len(e_ids))
+    assert np.array_equal(dists[:c].view(np.uint32), e_d.view(np.uint32)), (tag, dists[:c], e_d)
+    assert np.array_equal(rows[:c].astype(np.uint64), e_ids.astype(np.uint64)), (tag, rows[:c], e_ids)
+
+
+def test_c2_flat_ip_768_batch256_runs_the_benchmarked_kernels(L, oracle):
+    n, dim, nq, k = 2_400_000, 768, 256, 10
+    rng = np.random.default_rng(42)
+    idx = L.FlatIndex(None, dim)
+    idx.reserve(n)
+    data = np.empty((n, dim), f32)
+    for b in range(0, n, 200_000):        # uniform[0,1) f32 in blocks, like flat_search_bench.py:71-77 / bench.py
+        e = min(n, b + 200_000)
+        rng.random(out=data[b:e], dtype=f32)
+        idx.write(data[b:e])
+    q_rows = np.sort(rng.integers(0, n, nq))
+    queries = (data[q_rows] + 0.03 * rng.standard_normal((nq, dim)).astype(f32)).astype(f32)
+    idx.finalize()
+    idx.search_batch_arrays(queries, k, "ip")          # first call builds the SQ8 codes of the int8 coarse pass
+    idx.profile_enable(True)
+    idx.profile_get(reset=True)
+    rows, dists, counts = idx.search_batch_arrays(queries, k, "ip")
+    p = idx.profile_get(reset=True)
+    flags, stages, tiling = plan_fields(p)
+    assert p["fallback_queries"] == 0
+    assert p["scan_launches"] == 3 and stages == 3, p
+    assert tiling == 0x24, hex(tiling)
+    assert flags & PLAN_SAMPLED and flags & PLAN_THRESHOLD_ONLY and flags & PLAN_I8C and flags & PLAN_SEGMENTS, bin(flags)
+    check = [0, 1, 2, 31, 32, 100, 128, 200, 254, 255]  # both wave columns, every 32-query column block of the tile
+    for qi in check:
+        assert_rows_equal(oracle.canonical_topk(queries[qi], data, k, O.IP), rows[qi], dists[qi], counts[qi], ("c2", qi))
+        assert rows[qi, 0] == q_rows[qi]                   # the perturbed source row wins
+    # other batch sizes give the same answers: 40 queries (same kernels, mostly empty query columns) and 8 queries
+    # (the <= 32-query kernel over the f16 shadow)
+    r40, d40, c40 = idx.search_batch_arrays(queries[:40], k, "ip")
+    assert np.array_equal(r40, rows[:40]) and np.array_equal(d40.view(np.uint32), dists[:40].view(np.uint32))
+    r8, d8, c8 = idx.search_batch_arrays(queries[:8], k, "ip")
+    p8 = idx.profile_get(reset=True)
+    assert plan_fields(p8)[0] & PLAN_SMALL and plan_fields(p8)[2] == 0x14
+    assert np.array_equal(r8, rows[:8]) and np.array_equal(d8.view(np.uint32), dists[:8].view(np.uint32))
+
+
+def test_c3_flat_l2_sift_like_1m_k100(L, oracle):
+    from lynsedb_amd.datasets import sift_like
+
+    n, dim, nq, k = 1_000_000, 128, 256, 100
+    data = sift_like(n, dim, 42)
+    queries = sift_like(nq, dim, 43)
+    idx = L.FlatIndex(None, dim)
+    idx.write(data)
+    idx.finalize()
+    idx.profile_enable(True)
+    idx.profile_get(reset=True)
+    rows, dists, counts = idx.search_batch_arrays(queries, k, "l2")
+    p = idx.profile_get(reset=True)
+    flags, stages, tiling = plan_fields(p)
+    assert p["fallback_queries"] == 0 and tiling == 0x42 and flags & PLAN_SAMPLED and stages >= 2, (p, bin(flags))
+    for qi in (0, 1, 63, 64, 127, 128, 200, 255):
+        assert_rows_equal(oracle.canonical_topk(queries[qi], data, k, O.L2), rows[qi], dists[qi], counts[qi], ("c3", qi))
+    # integer-valued data: squared distances are exact integers and tie often — the canonical (distance, row) order decides
+    assert np.all(dists[0] == np.round(dists[0]))
+    # IP and cosine over the same store, k=100 (IP: lane-max sample up to k = 128 on the <2,4,4,2> tiling)
+    for name, metric in (("ip", O.IP), ("cosine", O.COS)):
+        r, d, c = idx.search_batch_arrays(queries, k, name)
+        pp = idx.profile_get(reset=True)
+        assert pp["fallback_queries"] == 0
+        for qi in (0, 100, 255):
+            assert_rows_equal(oracle.canonical_topk(queries[qi], data, k, metric), r[qi], d[qi], c[qi], ("c3", name, qi))
+
+
+def test_c4_ivf_ip_768_nlist4096_nprobe32(L, oracle):
+    n, dim, nlist, nprobe, k = 520_000, 768, 4096, 32, 10
+    rng = np.random.default_rng(7)        # benchmarks/ivf_kmeans_baseline.py:45-55 recipe: unit centers + sigma 0.03 noise
+    K = 1024
+    centers = rng.standard_normal((K, dim)).astype(f32)
+    centers /= np.linalg.norm(centers, axis=1, keepdims=True)
+    data = np.empty((n, dim), f32)
+    for b in range(0, n, 65536):
+        e = min(n, b + 65536)
+        data[b:e] = centers[np.arange(b, e) % K] + 0.03 * rng.standard_normal((e - b, dim)).astype(f32)
+    built = L.IvfFlatIndex.build(None, data, dim, nlist, 2, "ip", l2_partitions=False)   # device k-means, 2 Lloyd rounds
+    cen, asg, off_slab, orig = built.export()
+    assert cen.shape == (nlist, dim) and asg.size == n
+    del built
+    # parity definition: the same centroids + assignments in -> the same probes / candidates / results out
+    idx = L.IvfFlatIndex.load(data, cen, asg, "ip")
+    off, rows_l = oracle.lists_from_assignments(asg, nlist)
+    nq = 64
+    queries = (data[rng.integers(0, n, nq)] + 0.02 * rng.standard_normal((nq, dim)).astype(f32)).astype(f32)
+    g_rows, g_d, g_c = idx.search_batch_arrays(queries, k, nprobe)
+    for qi in (0, 1, 7, 31, 32, 33, 50, 63):
+        e_ids, e_d, _ = oracle.ivf_search(queries[qi], data, cen, off, rows_l, nprobe, k, O.IP)
+        assert_rows_equal((e_ids, e_d), g_rows[qi], g_d[qi], g_c[qi], ("c4", qi))
+    # single query (config 4 latency shape) and nprobe >= nlist (every list probed = exact search in IVF order)
+    r1, d1, c1 = idx.search_batch_arrays(queries[5:6], k, nprobe)
+    e_ids, e_d, _ = oracle.ivf_search(queries[5], data, cen, off, rows_l, nprobe, k, O.IP)
+    assert_rows_equal((e_ids, e_d), r1[0], d1[0], c1[0], ("c4 single", 5))
+    for np_all in (nlist, nlist + 17):
+        ra, da, ca = idx.search_batch_arrays(queries[:3], k, np_all)
+        for qi in range(3):
+            e_ids, e_d, _ = oracle.ivf_search(queries[qi], data, cen, off, rows_l, np_all, k, O.IP)
+            assert_rows_equal((e_ids, e_d), ra[qi], da[qi], ca[qi], ("c4 all", np_all, qi))
+            assert_rows_equal(oracle.canonical_topk(queries[qi], data, k, O.IP, ip_form=O.IPFORM_SINGLE), ra[qi], da[qi], ca[qi],
+                              ("c4 all vs flat", qi))
+    # subset-filtered (SearchParams.subset, ivf.rs:251-265): 10 % of the rows
+    subset = np.sort(rng.choice(n, n // 10, replace=False)).astype(np.uint64)
+    rf, df, cf = idx.search_filtered_batch_arrays(queries[:12], k, nprobe, subset)
+    for qi in (0, 5, 11):
+        e_ids, e_d = oracle.ivf_search_filtered(queries[qi], data, cen, off, rows_l, nprobe, k, O.IP, subset)
+        assert_rows_equal((e_ids, e_d), rf[qi], df[qi], cf[qi], ("c4 filtered", qi))
+
+
+@pytest.mark.parametrize("nq", [1, 256])
+def test_c5_hamming_10m_1024bit_k50(L, oracle, nq):
+    from lynsedb_amd.datasets import packed_bernoulli
+
+    n, bits, k = 10_000_000, 1024, 50
+    words = packed_bernoulli(n, bits, 0.5, 42)
+    idx = L.FlatIndex(None, bits)
+    for b in range(0, n, 2_500_000):
+        idx.write_packed(words[b:b + 2_500_000])
+    idx.finalize()
+    rng = np.random.default_rng(9)
+    qw = words[rng.integers(0, n, nq)].copy()
+    flip = packed_bernoulli(nq, bits, 0.5, 10) & packed_bernoulli(nq, bits, 0.5, 11) & packed_bernoulli(nq, bits, 0.5, 12)
+    qw ^= flip                                              # ~12 % of the bits flipped: the source row stays the best hit
+    idx.profile_enable(True)
+    rows, dists, counts = idx.search_packed_arrays(qw, k, "hamming")
+    p = idx.profile_get(reset=True)
+    assert p["fallback_queries"] == 0
+    for qi in sorted({0, nq // 3, nq // 2, nq - 1}):
+        assert_rows_equal(oracle.canonical_topk_packed(qw[qi], words, k, O.HAMMING), rows[qi], dists[qi], counts[qi], ("c5", nq, qi))
+    assert np.all(dists == np.round(dists))
+    if nq == 1:   # Tanimoto / Dice on the same fingerprints (the sparse-fingerprint use of config 5)
+        for name, metric in (("tanimoto", O.JACCARD), ("dice", O.DICE)):
+            r, d, c = idx.search_packed_arrays(qw, k, name)
+            assert_rows_equal(oracle.canonical_topk_packed(qw[0], words, k, metric), r[0], d[0], c[0], ("c5", name))
