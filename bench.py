@@ -12,9 +12,11 @@ RCCL all-gather and merged on the device: total work is fixed -> "scaling": "str
 Inputs (rows and queries) are resident in HBM before the timed region; the timed region is bracketed
 by barrier + torch.cuda.synchronize() and the MAX over ranks is reported.
 
-Extra objects on the JSON line: "roofline" (dominant kernel k_scan_h16 — algorithmic bytes / HIP-event
-duration measured on the launch stream during the timed region) and "cpu_baseline" (the oracle's
-restatement of the reference's rayon scan, timed on this host's cores over a bounded row sample).
+Extra objects on the JSON line: "roofline" (dominant kernel k_scan_h16: the bytes it physically streams and its matrix
+ops over the HIP-event duration of its launches on the launch stream inside the timed region, against 8 TB/s and the
+dense MFMA peak — the larger fraction names the bound; the SURVEY 8(d) algorithmic-f32-bytes figure rides along) and
+"cpu_baseline" (the oracle's restatement of the reference's rayon scan on a persistent pinned pool, timed on this host's
+cores over a bounded row sample: all threads and 4 threads).
 """
 from __future__ import annotations
 
@@ -50,7 +52,8 @@ def parse_args():
     p.add_argument("--seed", type=int, default=42)
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-sample-rows", type=int, default=1_000_000)
-    p.add_argument("--cpu-queries", type=int, default=8)
+    p.add_argument("--cpu-queries", type=int, default=30, help="timed CPU queries (flat_search_bench.py:94-97: 30 trials)")
+    p.add_argument("--cpu-warmup", type=int, default=20, help="CPU warm-up queries (flat_search_bench.py:88-91: 20)")
     p.add_argument("--no-verify", action="store_true")
     p.add_argument("--verify-queries", type=int, default=16)
     p.add_argument("--stage0", type=int, default=0, help="override the stage-0 row count of the scan plan")
@@ -249,36 +252,64 @@ def main():
 
 
 def cpu_baseline(args, N, D, K, metric):
-    """The oracle's restatement of the reference's chunked rayon scan (flat_mmap.rs:4845-4982), timed on
-    this host's cores over a bounded row sample; one full pass per query, as the reference's
-    batch_search loops queries sequentially (engine.rs:5484-5496)."""
+    """The oracle's restatement of the reference's chunked rayon scan (flat_mmap.rs:4845-4982; chunks of
+    max(n / threads, 512) rows, AVX2+FMA batch-8 kernel, per-chunk top-k, serial merge) timed on this host's cores over a
+    bounded row sample: a PERSISTENT pinned worker pool (rayon's global pool is created once, not per query), the sample
+    first-touched by the workers that scan it, 20 warm-ups / 30 timed queries like benchmarks/flat_search_bench.py:88-97,
+    one full pass per query as the reference's batch_search loops queries (engine.rs:5484-5496).  Reported for all host
+    threads and for 4 threads (the reference's own gates default RAYON_NUM_THREADS to 4, scripts/perf_gate_local.py:218)."""
+    import shutil
+    import subprocess
+
     import oracle as O
 
     orc = O.get()
     cores = os.cpu_count() or 1
     sample = min(N, args.cpu_sample_rows)
+    warm, trials = args.cpu_warmup, args.cpu_queries
     rng = np.random.default_rng(args.seed)
-    data = rng.random((sample, D), dtype=np.float32)
-    qs = data[rng.integers(0, sample, size=args.cpu_queries)] + 0.03 * rng.standard_normal((args.cpu_queries, D)).astype(np.float32)
-    if metric >= 3:
-        words = orc.pack_binary(data)
-        qw = orc.pack_binary(qs)
-        orc.packed_binary_search(qw[0], words, K, metric, n_threads=cores, mt=True)
-        t0 = time.perf_counter()
-        for i in range(args.cpu_queries):
-            orc.packed_binary_search(qw[i], words, K, metric, n_threads=cores, mt=True)
-    else:
-        orc.flat_search(qs[0], data, K, metric, n_threads=cores, mt=True)  # warm-up
-        t0 = time.perf_counter()
-        for i in range(args.cpu_queries):
-            orc.flat_search(qs[i], data, K, metric, n_threads=cores, mt=True)
-    per_query_sample = (time.perf_counter() - t0) / args.cpu_queries
-    per_query_full = per_query_sample * (N / sample)
-    return {"value": round(1.0 / per_query_full, 3), "unit": "queries/s", "cores": cores, "kind": "port",
-            "sample": "%d queries x %d-row sample (of %d), %d threads, time scaled by rows ratio; "
-                      "%.1f ms/query on the sample = %.1f GB/s" % (
-                          args.cpu_queries, sample, N, cores, per_query_sample * 1e3,
-                          sample * D * 4 / per_query_sample / 1e9)}
+
+    def timed(threads):
+        orc.pool_start(threads)
+        try:
+            data = orc.fill_uniform_mt(sample, D, args.seed)
+            qs = data[rng.integers(0, sample, size=warm + trials)] + 0.03 * rng.standard_normal((warm + trials, D)).astype(np.float32)
+            if metric >= 3:
+                words = orc.pack_binary(data)
+                qw = orc.pack_binary(qs)
+                run = lambda i: orc.packed_binary_search(qw[i], words, K, metric, n_threads=threads, mt=True)  # noqa: E731
+                nbytes = words.nbytes
+            else:
+                run = lambda i: orc.flat_search(qs[i], data, K, metric, n_threads=threads, mt=True)  # noqa: E731
+                nbytes = data.nbytes
+            for i in range(warm):
+                run(i)
+            ts = []
+            for i in range(warm, warm + trials):
+                t0 = time.perf_counter()
+                run(i)
+                ts.append(time.perf_counter() - t0)
+            ts.sort()
+            med = ts[len(ts) // 2]
+            return {"threads": threads, "median_ms_per_query_on_sample": round(med * 1e3, 3), "GBps": round(nbytes / med / 1e9, 1),
+                    "queries_per_s_full_size": round(1.0 / (med * (N / sample)), 3)}
+        finally:
+            orc.pool_stop()
+
+    full = timed(cores)
+    four = timed(min(4, cores))
+    cargo = shutil.which("cargo")
+    if cargo:
+        try:
+            cargo = subprocess.run([cargo, "--version"], capture_output=True, text=True, timeout=10).stdout.strip()
+        except Exception:  # noqa: BLE001
+            cargo = "present, --version failed"
+    return {"value": full["queries_per_s_full_size"], "unit": "queries/s", "cores": cores, "kind": "port",
+            "sample": "%d-row sample (of %d) first-touched by the pool, %d warm-ups + %d timed queries, median; time scaled by the "
+                      "rows ratio; %.1f ms/query on the sample = %.1f GB/s on %d threads" % (
+                          sample, N, warm, trials, full["median_ms_per_query_on_sample"], full["GBps"], cores),
+            "all_threads": full, "threads_4": four,
+            "reference_build": "cargo: %s (the Rust reference cannot be built on this box; the port restates its scan)" % (cargo or "not found")}
 
 
 if __name__ == "__main__":

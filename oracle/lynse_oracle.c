@@ -20,6 +20,8 @@
 #include <ctype.h>
 #include <math.h>
 #include <pthread.h>
+#include <sched.h>
+#include <unistd.h>
 #include <stdlib.h>
 #include <string.h>
 

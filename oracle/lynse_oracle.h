@@ -93,6 +93,14 @@ size_t lo_packed_binary_search_mt(const uint64_t *query, const uint64_t *rows, s
                                   size_t n, size_t k, int metric, int n_threads,
                                   uint32_t *out_idx, float *out_dist);
 
+/* Persistent worker pool for the TIMED CPU baseline (bench.py cpu_baseline): the reference scans on rayon's global pool
+ * (created once; RAYON_NUM_THREADS), not on threads spawned per query.  While a pool of exactly `n_threads` workers
+ * runs, lo_flat_search_mt / lo_packed_binary_search_mt(.., n_threads, ..) use it (chunk ci -> worker ci % n); results
+ * are unchanged.  lo_fill_uniform_mt first-touches an untouched buffer with the same chunking (NUMA-local pages). */
+int lo_pool_start(int n_threads);
+void lo_pool_stop(void);
+int lo_fill_uniform_mt(float *dst, size_t n, size_t dim, uint64_t seed);
+
 /* Canonical exact top-k: every row scored with the reference kernel
  * (ip_form selects the IP accumulation form), total order (distance in metric
  * order, then row ascending) — the order VectorStore::merge_results imposes

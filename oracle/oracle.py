@@ -69,6 +69,9 @@ class Oracle:
             s(n, _sz, _f32p, _f32p, _sz, _sz, _sz, C.c_int, C.c_int, _u32p, _f32p)
         for n in ("lo_packed_binary_search", "lo_packed_binary_search_mt"):
             s(n, _sz, _u64p, _u64p, _sz, _sz, _sz, C.c_int, C.c_int, _u32p, _f32p)
+        s("lo_pool_start", C.c_int, C.c_int)
+        s("lo_pool_stop", None)
+        s("lo_fill_uniform_mt", C.c_int, _f32p, _sz, _sz, C.c_uint64)
         s("lo_canonical_topk", _sz, _f32p, _f32p, _sz, _sz, _sz, C.c_int, C.c_int, _u32p, _f32p)
         s("lo_canonical_topk_packed", _sz, _u64p, _u64p, _sz, _sz, _sz, C.c_int, _u32p, _f32p)
         _u8p = C.POINTER(C.c_uint8)
@@ -194,6 +197,20 @@ class Oracle:
         n, dim = (c.shape if c.ndim == 2 else (0, q.size))
         fn = self.lib.lo_flat_search_mt if mt else self.lib.lo_flat_search
         return self._topk_call(fn, k, pq, pc, dim, n, k, metric, n_threads)
+
+    # -- persistent pool of the timed CPU baseline (rayon's global pool) ---------------------------
+    def pool_start(self, n_threads: int) -> int:
+        return int(self.lib.lo_pool_start(int(n_threads)))
+
+    def pool_stop(self) -> None:
+        self.lib.lo_pool_stop()
+
+    def fill_uniform_mt(self, rows: int, dim: int, seed: int) -> np.ndarray:
+        """uniform [0,1) f32 rows, every page first-touched by the pool worker that will scan it."""
+        a = np.empty((rows, dim), np.float32)
+        if self.lib.lo_fill_uniform_mt(a.ctypes.data_as(_f32p), rows, dim, seed) != 0:
+            raise RuntimeError("lo_fill_uniform_mt needs a running pool (pool_start)")
+        return a
 
     def packed_binary_search(self, query_words, rows_words, k, metric, n_threads=8, mt=False):
         q, pq = self._u64(query_words)
