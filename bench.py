@@ -102,6 +102,9 @@ def main():
 
     # ---- build the shard: rows g with g % world == rank, generated block-wise on the device
     sh = ShardedFlat(D, rank=rank, world=world, device=local_rank, group=dist)
+    native = False
+    if world > 1 and os.environ.get("LYNSE_BENCH_EXCHANGE", "native") == "native" and (dist is None or dist.get_backend() == "nccl"):
+        native = sh.enable_native_comm()   # RCCL inside the library; falls back to torch.distributed's all-gather
     n_local = (N - rank + world - 1) // world if N > rank else 0
     sh.index.reserve(max(n_local, 1))
     if args.stage0 or args.growth:
@@ -234,7 +237,9 @@ def main():
             "config": {"workload": "FLAT-%s %dx%d f32 uniform[0,1), %d queries = perturbed rows, k=%d"
                                    % (args.metric.upper(), N, D, B, K),
                        "rows_per_gpu": n_local, "sharding": "row %% %d" % world,
-                       "exchange": "rccl all_gather of %d B/rank" % (B * K * 12) if world > 1 else "none",
+                       "exchange": ("rccl all_gather of %d B/rank, %s" % (B * K * 12 + B * 4, "inside the library (C-ABI), one stream" if native
+                                    else "through torch.distributed (%s)" % (sh.comm_error or os.environ.get("LYNSE_BENCH_BACKEND", "nccl")))) if world > 1 else "none",
+                       "rccl_ranks_seen": (sh.ranks_seen if native else None),
                        "build_s": round(build_s, 1)},
             "roofline": roofline,
             "pipeline_us_per_step": round(prof["total_us"] / max(prof["searches"], 1), 1),
@@ -269,7 +274,7 @@ def cpu_baseline(args, N, D, K, metric):
     warm, trials = args.cpu_warmup, args.cpu_queries
     rng = np.random.default_rng(args.seed)
 
-    def timed(threads):
+    def timed(threads, warm, trials):
         orc.pool_start(threads)
         try:
             data = orc.fill_uniform_mt(sample, D, args.seed)
@@ -296,8 +301,14 @@ def cpu_baseline(args, N, D, K, metric):
         finally:
             orc.pool_stop()
 
-    full = timed(cores)
-    four = timed(min(4, cores))
+    # the thread count that serves this host best (a container's CPU quota can make "all threads" slower than a few):
+    # a short sweep (3 warm-ups + 7 queries each), then the full protocol at the winner and at 4 threads
+    usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else cores
+    sweep = [timed(t, 3, 7) for t in sorted({t for t in (4, 8, 16, 32, 64, 128, usable) if t <= usable})]
+    best_t = max(sweep, key=lambda r: r["GBps"])["threads"]
+    full = timed(best_t, warm, trials)
+    four = timed(min(4, usable), warm, trials)
+    cores = best_t
     cargo = shutil.which("cargo")
     if cargo:
         try:
@@ -306,9 +317,10 @@ def cpu_baseline(args, N, D, K, metric):
             cargo = "present, --version failed"
     return {"value": full["queries_per_s_full_size"], "unit": "queries/s", "cores": cores, "kind": "port",
             "sample": "%d-row sample (of %d) first-touched by the pool, %d warm-ups + %d timed queries, median; time scaled by the "
-                      "rows ratio; %.1f ms/query on the sample = %.1f GB/s on %d threads" % (
+                      "rows ratio; %.1f ms/query on the sample = %.1f GB/s on %d threads (best of the sweep)" % (
                           sample, N, warm, trials, full["median_ms_per_query_on_sample"], full["GBps"], cores),
-            "all_threads": full, "threads_4": four,
+            "best_threads": full, "threads_4": four, "host_threads": usable,
+            "thread_sweep_GBps": {str(r["threads"]): r["GBps"] for r in sweep},
             "reference_build": "cargo: %s (the Rust reference cannot be built on this box; the port restates its scan)" % (cargo or "not found")}
 
 

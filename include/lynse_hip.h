@@ -278,6 +278,36 @@ int lynse_hip_ivf_search_filtered_f32(lynse_hip_ivf *h, const float *queries, ui
 int lynse_hip_ivf_profile_enable(lynse_hip_ivf *h, int on);
 int lynse_hip_ivf_profile_get(lynse_hip_ivf *h, lynse_hip_profile *out, int reset);
 
+/* ---- multi-GPU exchange: one process per GPU, rows sharded, RCCL all-gather over xGMI ----
+ *
+ * Stands where the reference's TCP scatter / gather stands: fan-out of the batch to every shard (src/cluster.rs:101-123,
+ * :173-217), the result block a shard returns (src/rpc.rs:1156-1177), the coordinator's merge (src/cluster.rs:327-393).
+ * RCCL is bound at run time (dlopen; no link-time dependency): lynse_hip_comm_load_rccl(path) names the copy to use — a
+ * host process that already carries one (PyTorch) passes its path so the process keeps ONE RCCL — else librccl.so.1 of
+ * the loader path.  Bootstrap: rank 0 calls lynse_hip_comm_unique_id, the launcher hands the 128 bytes to every rank
+ * (torch.distributed, MPI, a file), every rank calls lynse_hip_comm_create. */
+typedef struct lynse_hip_comm lynse_hip_comm;
+int lynse_hip_comm_load_rccl(const char *path /* NULL = search */);
+int lynse_hip_comm_unique_id(uint8_t *id128);
+int lynse_hip_comm_create(const uint8_t *id128, int rank, int world, int device, lynse_hip_comm **out);
+int lynse_hip_comm_destroy(lynse_hip_comm *c);
+int lynse_hip_comm_rank(const lynse_hip_comm *c);
+int lynse_hip_comm_world(const lynse_hip_comm *c);
+/* Self-check: all-reduce(sum) of one word per rank; *out must equal the world size on every rank. */
+int lynse_hip_comm_ranks_seen(lynse_hip_comm *c, int *out);
+/* Whole-collection search of a row-sharded collection (a COLLECTIVE: every rank calls it with the same nq / k / metric):
+ * scan of this rank's shard -> ncclAllGather of the fixed-size per-rank blocks [rows u64 | dists f32 | counts u32]
+ * (nq*k*12 + nq*4 bytes) -> device k-way merge in the canonical (distance, global row) order, stream-ordered on the
+ * shard's stream with no host synchronisation between the three.  Rows are global through the shard's row map
+ * (lynse_hip_flat_set_row_map).  Outputs are device memory, identical on every rank, complete on return. */
+int lynse_hip_flat_search_sharded_f32_device(lynse_hip_flat *h, lynse_hip_comm *c, const float *d_queries,
+                                             uint64_t nq, uint32_t k, int metric, uint64_t *d_out_rows,
+                                             float *d_out_dists, uint32_t *d_out_counts);
+int lynse_hip_flat_search_sharded_packed_u64_device(lynse_hip_flat *h, lynse_hip_comm *c,
+                                                    const uint64_t *d_query_words, uint64_t nq, uint32_t k,
+                                                    int metric, uint64_t *d_out_rows, float *d_out_dists,
+                                                    uint32_t *d_out_counts);
+
 /* ---- shard-node glue around a search (host only, no device work) ---- */
 
 /* Collection::filter_tombstoned_limit (src/engine.rs:3286-3308): drop the tombstoned ids, keep the order, at most

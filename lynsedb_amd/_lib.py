@@ -101,6 +101,15 @@ SIGNATURES = {
     "lynse_hip_decode_search_result": (C.c_int, [_vp, C.c_uint64, C.c_uint64, _vp, _vp, C.c_uint32, C.POINTER(C.c_uint32),
                                                 C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]),
     "lynse_hip_ivf_profile_get": (C.c_int, [_vp, C.POINTER(Profile), C.c_int]),
+    "lynse_hip_comm_load_rccl": (C.c_int, [C.c_char_p]),
+    "lynse_hip_comm_unique_id": (C.c_int, [_vp]),
+    "lynse_hip_comm_create": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.POINTER(_vp)]),
+    "lynse_hip_comm_destroy": (C.c_int, [_vp]),
+    "lynse_hip_comm_rank": (C.c_int, [_vp]),
+    "lynse_hip_comm_world": (C.c_int, [_vp]),
+    "lynse_hip_comm_ranks_seen": (C.c_int, [_vp, C.POINTER(C.c_int)]),
+    "lynse_hip_flat_search_sharded_f32_device": (C.c_int, [_vp, _vp, _vp, C.c_uint64, C.c_uint32, C.c_int, _vp, _vp, _vp]),
+    "lynse_hip_flat_search_sharded_packed_u64_device": (C.c_int, [_vp, _vp, _vp, C.c_uint64, C.c_uint32, C.c_int, _vp, _vp, _vp]),
 }
 
 if not LIB_PATH.exists():

@@ -1016,7 +1016,7 @@ constexpr int HK = 64;  // K elements per slab
 // cost registers the unfiltered kernel does not have to spare (56 B/lane of scratch and 13 % of its speed when they
 // were runtime branches).
 template <int WQ, int WR, int TQ, int TR, int METRIC, int NSV, int NSQ, int NT_HINT, bool TILED = false, bool RAG = true, int DBG = 0, bool FILT = false,
-          int I8Q = 0, int EMIT = -1>
+          int I8Q = 0, int EMIT = -1, int PLACE = 0>
 __global__ void __launch_bounds__(WQ * WR * 64, (TQ * TR >= 16) ? 1 : ((WQ * WR >= 8) ? (WQ * WR / 4) : 2)) k_scan_h16(ScanArgs a) {
     // Two LDS rings: NSV stages of row slabs (HBM latency: deeper) and NSQ <= NSV stages of query-image
     // slabs (L2 latency) — 3 + 2 stages of 32 KiB fill the 160 KiB of a CU for the 256 x 256 tile.
@@ -1124,7 +1124,13 @@ __global__ void __launch_bounds__(WQ * WR * 64, (TQ * TR >= 16) ? 1 : ((WQ * WR 
     // piece p of a slab step: 0..QPW-1 query-image pieces, QPW..OPS-1 row pieces
     auto issue_piece = [&](int p) {
         if (p < QPW) {
-            if (!(DBG & 4)) glds16<0>(q_base + ((size_t)qs_slab * qs_qslab + q_piece[p]) + q_lane, smem + Q_RING + qs_stage * Q_BYTES + q_piece[p]);
+            // saddr form like the row pieces: uniform 64-bit base (SGPRs) + the lane's 32-bit byte offset.  (Left to itself the
+            // compiler keeps the uniform slab counter in a VGPR and issues the 64-bit-per-lane address form: ~110 cycles of
+            // issue per instruction instead of ~13, measured with s_memtime around the four pieces of a slab step.)
+            const uint32_t q_uni = __builtin_amdgcn_readfirstlane(qs_slab * qs_qslab + q_piece[p]);
+            uint32_t ql = q_lane;
+            asm volatile("" : "+v"(ql));  // opaque: keeps `q_base + q_lane` from being hoisted into a 64-bit VGPR pair (which forces the VGPR-address form)
+            if (!(DBG & 4)) glds16<0>(q_base + (size_t)q_uni + ql, smem + Q_RING + qs_stage * Q_BYTES + q_piece[p]);
         } else {
             if (DBG & 8) return;
             const int j = p - QPW;
@@ -1242,7 +1248,7 @@ __global__ void __launch_bounds__(WQ * WR * 64, (TQ * TR >= 16) ? 1 : ((WQ * WR 
 #else
     constexpr bool timing = false;  // (phase timing lives in the EXPERIMENTS build: its flag and counters cost SGPRs in the hot loop)
 #endif
-    unsigned long long t_wait = 0, t_bar = 0, t_comp = 0, tp = timing ? __builtin_amdgcn_s_memtime() : 0;
+    unsigned long long t_wait = 0, t_bar = 0, t_comp = 0, t_iq = 0, t_iv = 0, tp = timing ? __builtin_amdgcn_s_memtime() : 0;
     for (uint32_t g = 0; g < G; ++g) {
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAIT_OPS) : "memory");
         if (timing) { const unsigned long long t = __builtin_amdgcn_s_memtime(); t_wait += t - tp; tp = t; }
@@ -1294,7 +1300,18 @@ __global__ void __launch_bounds__(WQ * WR * 64, (TQ * TR >= 16) ? 1 : ((WQ * WR 
                     const int slot = kk * TR + i;
 #pragma unroll
                     for (int p = 0; p < OPS; ++p)
-                        if (p % NSLOT == slot) issue_piece(p);
+                        if (PLACE == 0 ? (p % NSLOT == slot)                                   // spread: one piece behind every MFMA group
+                                       : PLACE == 1 ? (slot == 0)                              // all pieces behind the first MFMA group
+                                                    : (slot == ((wave < NW / 2) ? 0 : NSLOT / 2))) {  // half the waves early, half mid-phase
+                            if (timing) {  // (experiments) issue time of this DMA instruction: query-image vs row pieces
+                                const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+                                issue_piece(p);
+                                const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+                                if (p < QPW) t_iq += t1 - t0; else t_iv += t1 - t0;
+                            } else {
+                                issue_piece(p);
+                            }
+                        }
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -1546,7 +1563,7 @@ __global__ void __launch_bounds__(WQ * WR * 64, (TQ * TR >= 16) ? 1 : ((WQ * WR 
 #ifdef LYNSE_EXPERIMENTS
     if (timing && lane == 0) {
         unsigned long long* o = a.dbg + ((size_t)blockIdx.x * NW + wave) * 4;
-        o[0] = t_wait; o[1] = t_bar; o[2] = 0; o[3] = t_comp;
+        o[0] = t_wait; o[1] = t_bar; o[2] = (t_iq << 32) | (t_iv & 0xffffffffull); o[3] = t_comp;
     }
 #endif
     if (!TILED) {

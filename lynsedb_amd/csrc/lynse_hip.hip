@@ -851,14 +851,14 @@ static int launch_scan_h16(const ScanArgs& a, int metric, uint32_t grid, hipStre
     const bool filt = a.mask != nullptr || a.row_ids != nullptr;
     const bool ragged = a.ld16 % HK != 0;
 #ifdef LYNSE_EXPERIMENTS
-    if constexpr (WQ == 2 && WR == 4 && !TILED) {  // timing experiments (LYNSE_HIP_DEBUG_FLAGS bits 16.. = DBG << 4)
-        if (metric == M_IP && !filt && !ragged && ((a.debug_flags >> 4) & 15)) {
+    if constexpr (WQ == 2 && WR == 4 && !TILED) {  // timing experiments (LYNSE_HIP_DEBUG_FLAGS bits 8..11 = DBG << 8)
+        if (metric == M_IP && !filt && !ragged && ((a.debug_flags >> 8) & 15)) {
             auto ex = [&](auto kern) -> int {
                 LY_TRY(set_max_lds(kern, lds));
                 hipLaunchKernelGGL(kern, dim3(grid), dim3(WQ * WR * 64), lds, st, a);
                 return LYNSE_OK;
             };
-            switch ((a.debug_flags >> 4) & 15) {
+            switch ((a.debug_flags >> 8) & 15) {
             case 1: LY_TRY(ex(k_scan_h16<WQ, WR, TQ, TR, M_IP, NSV, NSQ, 2, TILED, false, 1>)); break;
             case 2: LY_TRY(ex(k_scan_h16<WQ, WR, TQ, TR, M_IP, NSV, NSQ, 2, TILED, false, 2>)); break;
             case 3: LY_TRY(ex(k_scan_h16<WQ, WR, TQ, TR, M_IP, NSV, NSQ, 2, TILED, false, 3>)); break;
@@ -951,7 +951,34 @@ static int launch_scan_i8c(const ScanArgs& a, uint32_t grid, hipStream_t st) {
         LY_HIP(hipGetLastError());
         return LYNSE_OK;
     };
+#ifdef LYNSE_EXPERIMENTS
+    if (a.ld16 % 128 == 0 && a.emit_all == 0 && ((a.debug_flags >> 8) & 15)) {  // timing experiments: DBG variants of the int8 kernel
+        auto ex = [&](auto kern) -> int {
+            LY_TRY(set_max_lds(kern, lds));
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, a);
+            LY_HIP(hipGetLastError());
+            return LYNSE_OK;
+        };
+        switch ((a.debug_flags >> 8) & 15) {
+        case 3: return ex(k_scan_h16<2, 4, 4, 2, M_IP, 3, 2, 2, false, false, 3, false, 2, 0>);    // DMA only
+        case 4: return ex(k_scan_h16<2, 4, 4, 2, M_IP, 3, 2, 2, false, false, 4, false, 2, 0>);    // no query-image DMA
+        case 8: return ex(k_scan_h16<2, 4, 4, 2, M_IP, 3, 2, 2, false, false, 8, false, 2, 0>);    // no row DMA
+        case 12: return ex(k_scan_h16<2, 4, 4, 2, M_IP, 3, 2, 2, false, false, 12, false, 2, 0>);  // MFMA + LDS reads only
+        case 7: return ex(k_scan_h16<2, 4, 4, 2, M_IP, 3, 2, 2, false, false, 7, false, 2, 0>);    // row DMA only
+        case 11: return ex(k_scan_h16<2, 4, 4, 2, M_IP, 3, 2, 2, false, false, 11, false, 2, 0>);  // query DMA only
+        case 1: return ex(k_scan_h16<2, 4, 4, 2, M_IP, 3, 2, 2, false, false, 1, false, 2, 0>);    // no MFMA (DMA + LDS reads)
+        case 13: return ex(k_scan_h16<2, 4, 4, 2, M_IP, 3, 2, 2, false, false, 13, false, 2, 0>);  // LDS reads only
+        case 14: return ex(k_scan_h16<2, 4, 4, 2, M_IP, 3, 2, 2, false, false, 14, false, 2, 0>);  // MFMA only
+        case 2: return ex(k_scan_h16<2, 4, 4, 2, M_IP, 3, 2, 2, false, false, 2, false, 2, 0>);    // no LDS reads (DMA + MFMA)
+        default: return set_error(LYNSE_ERR_INVALID_ARGUMENT, "unknown experiment");
+        }
+    }
+#endif
     if (a.ld16 % 128 == 0) {
+        static const int place = []() { const char* e = getenv("LYNSE_HIP_PLACE"); return e ? atoi(e) : 0; }();
+        static bool pattr[2] = {false, false};
+        if (a.emit_all == 0 && place == 1) { auto k = k_scan_h16<2, 4, 4, 2, M_IP, 3, 2, 2, false, false, 0, false, 2, 0, 1>; if (!pattr[0]) { LY_TRY(set_max_lds(k, lds)); pattr[0] = true; } hipLaunchKernelGGL(k, dim3(grid), dim3(512), lds, st, a); LY_HIP(hipGetLastError()); return LYNSE_OK; }
+        if (a.emit_all == 0 && place == 2) { auto k = k_scan_h16<2, 4, 4, 2, M_IP, 3, 2, 2, false, false, 0, false, 2, 0, 2>; if (!pattr[1]) { LY_TRY(set_max_lds(k, lds)); pattr[1] = true; } hipLaunchKernelGGL(k, dim3(grid), dim3(512), lds, st, a); LY_HIP(hipGetLastError()); return LYNSE_OK; }
         if (a.emit_all == 0) return go(k_scan_h16<2, 4, 4, 2, M_IP, 3, 2, 2, false, false, 0, false, 2, 0>, 0);
         if (a.emit_all == 1) return go(k_scan_h16<2, 4, 4, 2, M_IP, 3, 2, 2, false, false, 0, false, 2, 1>, 1);
         return go(k_scan_h16<2, 4, 4, 2, M_IP, 3, 2, 2, false, false, 0, false, 2, 2>, 2);
@@ -1864,3 +1891,4 @@ extern "C" int lynse_hip_merge_topk_device(const void* d_blocks, uint64_t block_
 
 #include "ivf_host.inc"
 #include "shard_host.inc"
+#include "comm_host.inc"

@@ -29,6 +29,65 @@ def shard_of_row(global_row: int, world: int) -> int:
     return global_row % world
 
 
+BUCKET_COUNT = 4096  # python/lynse/cluster.py:1273 (ShardMap default)
+
+
+def hash_u64(value: str) -> int:
+    """`_hash_u64` of the reference's cluster router (python/lynse/cluster.py:156-158): blake2b, 8-byte digest read as a little-endian u64."""
+    import hashlib
+
+    return int.from_bytes(hashlib.blake2b(value.encode("utf-8"), digest_size=8).digest(), "little", signed=False)
+
+
+def bucket_of_id(database: str, collection: str, item_id, bucket_count: int = BUCKET_COUNT) -> int:
+    """The reference's partition rule for an item: blake2b64("{db}/{coll}/{id}") % bucket_count (cluster.py:1364-1370)."""
+    return hash_u64(f"{database}/{collection}/{item_id}") % bucket_count
+
+
+def shard_of_id(database: str, collection: str, item_id, world: int, bucket_count: int = BUCKET_COUNT) -> int:
+    """bucket -> shard group: `bucket_to_group[b] = groups[b % n_groups]` (cluster.py:1273) — here group g = rank g."""
+    return bucket_of_id(database, collection, item_id, bucket_count) % world
+
+
+class NativeComm:
+    """RCCL communicator behind the C-ABI (include/lynse_hip.h, multi-GPU section).  `dist` (torch.distributed) is only the
+    launcher: it carries rank 0's 128-byte unique id to the other ranks."""
+
+    def __init__(self, dist, rank: int, world: int, device: int):
+        import os
+
+        import torch
+
+        self._c = C.c_void_p()
+        rccl = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")  # ONE RCCL per process: torch's copy
+        check(lib.lynse_hip_comm_load_rccl(rccl.encode() if os.path.exists(rccl) else None))
+        uid = np.zeros(128, np.uint8)
+        if rank == 0:
+            check(lib.lynse_hip_comm_unique_id(uid.ctypes.data_as(C.c_void_p)))
+        if world > 1:
+            backend = dist.get_backend()
+            t = torch.from_numpy(uid)
+            t = t.to(torch.device("cuda", device)) if backend == "nccl" else t
+            dist.broadcast(t, src=0)
+            uid = t.cpu().numpy()
+        check(lib.lynse_hip_comm_create(uid.ctypes.data_as(C.c_void_p), rank, world, device, C.byref(self._c)))
+        self.rank, self.world, self.device = rank, world, device
+
+    def ranks_seen(self) -> int:
+        n = C.c_int(0)
+        check(lib.lynse_hip_comm_ranks_seen(self._c, C.byref(n)))
+        return n.value
+
+    @property
+    def handle(self):
+        return self._c
+
+    def __del__(self):
+        c, self._c = getattr(self, "_c", None), None
+        if c:
+            lib.lynse_hip_comm_destroy(c)
+
+
 def block_layout(nq: int, k: int):
     """Byte layout of one rank's result block (the RCCL message; cf. the 12 B/candidate TCP block of
     src/rpc.rs:1156-1177)."""
@@ -63,6 +122,33 @@ class ShardedFlat:
         self.dist = group  # the torch.distributed module (or None when world == 1)
         self.index = FlatIndex(None, dim, device)
         self.index.set_row_map(world, rank)
+        self.comm: Optional[NativeComm] = None   # the exchange behind the C-ABI (enable_native_comm)
+        self.comm_error: Optional[str] = None
+        self.ranks_seen: Optional[int] = None
+
+    def enable_native_comm(self) -> bool:
+        """Create the RCCL communicator inside the library (scan -> ncclAllGather -> merge on one stream, no torch in the
+        data path).  Returns False — and keeps the torch.distributed exchange — when RCCL cannot be set up; the reason is
+        kept in `comm_error`.  Collective: every rank calls it."""
+        try:
+            comm = NativeComm(self.dist, self.rank, self.world, self.index_device())
+            seen = comm.ranks_seen()   # collective self-check (all-reduce of 1 per rank)
+            self.ranks_seen = seen
+            if seen != self.world:
+                raise RuntimeError(f"communicator self-check saw {seen} of {self.world} ranks")
+            self.comm = comm
+        except Exception as e:  # noqa: BLE001  (device errors, missing RCCL)
+            self.comm, self.comm_error = None, f"{type(e).__name__}: {e}"
+        if self.world > 1 and self.dist is not None:  # agree: the exchange is a collective, all ranks take the same path
+            import torch
+
+            ok = torch.tensor([1 if self.comm is not None else 0], dtype=torch.int32)
+            if self.dist.get_backend() == "nccl":
+                ok = ok.to(torch.device("cuda", self.index_device()))
+            self.dist.all_reduce(ok, op=self.dist.ReduceOp.MIN)
+            if int(ok.item()) == 0:
+                self.comm = None
+        return self.comm is not None
 
     # -- data ------------------------------------------------------------------------------------
     def add_global_rows(self, data: np.ndarray, first_global_row: int = 0) -> None:
@@ -71,6 +157,17 @@ class ShardedFlat:
         mine = np.ascontiguousarray(data[first::self.world])
         if mine.shape[0]:
             self.index.write(mine)
+
+    def add_items_hashed(self, data: np.ndarray, ids, database: str, collection: str) -> np.ndarray:
+        """The reference's placement rule instead of row % world: item `id` lives on the shard of its bucket,
+        blake2b64("{db}/{coll}/{id}") % 4096 -> bucket % world (python/lynse/cluster.py:156-158, :1273, :1364-1370).
+        Appends this rank's items and returns their ids in local row order (the caller's local-row -> id map; the
+        exchange then carries ids, not rows: set the row map to identity and translate after the merge)."""
+        ids = np.asarray(ids)
+        mine = np.fromiter((shard_of_id(database, collection, int(i), self.world) == self.rank for i in ids), bool, len(ids))
+        if mine.any():
+            self.index.write(np.ascontiguousarray(np.asarray(data, np.float32)[mine]))
+        return ids[mine]
 
     def alloc_outputs(self, nq: int, k: int) -> ShardOutputs:
         import torch
@@ -91,6 +188,11 @@ class ShardedFlat:
             check(lib.lynse_hip_flat_search_f32_device(
                 self.index.handle, C.c_void_p(d_queries.data_ptr()), nq, k, metric, C.c_void_p(out.rows.data_ptr()),
                 C.c_void_p(out.dists.data_ptr()), C.c_void_p(out.counts.data_ptr()), None))
+            return
+        if self.comm is not None:  # scan -> ncclAllGather -> k_merge inside the library, one stream
+            check(lib.lynse_hip_flat_search_sharded_f32_device(
+                self.index.handle, self.comm.handle, C.c_void_p(d_queries.data_ptr()), nq, k, metric,
+                C.c_void_p(out.rows.data_ptr()), C.c_void_p(out.dists.data_ptr()), C.c_void_p(out.counts.data_ptr())))
             return
         pr, pd, pc = out.local_ptrs()
         check(lib.lynse_hip_flat_search_f32_device(self.index.handle, C.c_void_p(d_queries.data_ptr()), nq, k,

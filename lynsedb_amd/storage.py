@@ -25,6 +25,7 @@ VECTOR_MANIFEST_FILE = "vector_manifest.json"      # vector_store.rs:24
 VECTOR_MANIFEST_VERSION = 1                        # :25
 SEGMENT_DIR = "vector_segments"                    # :26
 DEFAULT_ID_MAP_FILE = "id_map.bin"                 # :27
+UPDATE_JOURNAL_FILE = "vector_updates.wal"         # :28
 DEFAULT_SEGMENT_TARGET_BYTES = 256 * 1024 * 1024   # :32
 
 
@@ -74,6 +75,12 @@ def load_manifest(collection_path, dim: int, dtype: str = "f32") -> VectorManife
     paths, and take every segment's row count from its FILE LENGTH (a partial trailing row is ignored)."""
     root = Path(collection_path)
     row_width = dim * dtype_width(dtype)
+    if (root / UPDATE_JOURNAL_FILE).exists():
+        # VectorStore::has_pending_updates (vector_store.rs:682-687): in-place row updates that were journalled but not yet
+        # applied to the segment files.  Replaying the journal is the storage engine's job (out of scope); serving the
+        # segments as they are would silently return stale rows.
+        raise StorageError(f"{root / UPDATE_JOURNAL_FILE} exists: the collection has pending row updates that were not applied to "
+                           "its segment files; open it with LynseDB once (the journal is replayed on open) before loading it here")
     mpath = root / VECTOR_MANIFEST_FILE
     if mpath.exists():
         try:
@@ -164,7 +171,14 @@ def write_flat_collection(collection_path, batches: Sequence[np.ndarray], ids: O
     root = Path(collection_path)
     root.mkdir(parents=True, exist_ok=True)
     mpath = root / VECTOR_MANIFEST_FILE
+    batches = list(batches)
     m = VectorManifest()
+    if batches and (mpath.exists() or (root / "vectors.bin").exists()):
+        # an existing collection is APPENDED to, like VectorStore::write: start from its manifest (row counts from the file
+        # lengths), never truncate its segments
+        m = load_manifest(root, int(np.asarray(batches[0]).shape[1]), dtype)
+    elif mpath.exists() or (root / "vectors.bin").exists():
+        return load_manifest(root, 0, dtype)
     for b in batches:
         # encode_f32_slice_as_le_bytes (src/storage/dtype.rs): F16 rounds to nearest even
         a = np.ascontiguousarray(b, dtype="<f4") if dtype_width(dtype) == 4 else np.ascontiguousarray(np.asarray(b, np.float32).astype("<f2"))
@@ -188,8 +202,9 @@ def write_flat_collection(collection_path, batches: Sequence[np.ndarray], ids: O
             with open(root / m.segments[-1].file, "ab") as f:
                 f.write(data)
             m.segments[-1].rows += a.shape[0]
-    if ids is not None:
-        (root / m.id_map_file).write_bytes(np.ascontiguousarray(ids, dtype="<u8").tobytes())
+    if ids is not None:  # append_id_map_path (engine.rs:3058-3067): ids of the appended rows go to the end of the map
+        with open(root / m.id_map_file, "ab") as f:
+            f.write(np.ascontiguousarray(ids, dtype="<u8").tobytes())
     return m
 
 
@@ -249,9 +264,10 @@ def open_ivf_flat(data_path, metric: str = "ip", device: Optional[int] = None):
     from .core import IvfFlatIndex
 
     meta = load_ivf_meta(ivf_meta_path(data_path))
-    slab = np.fromfile(data_path, dtype="<f4", count=meta.n_vectors * meta.dim).reshape(meta.n_vectors, meta.dim)
-    if slab.shape[0] != meta.n_vectors:
+    slab = np.fromfile(data_path, dtype="<f4", count=meta.n_vectors * meta.dim)
+    if slab.size != meta.n_vectors * meta.dim:
         raise IOError("IVF data file is shorter than its metadata")
+    slab = slab.reshape(meta.n_vectors, meta.dim)
     original = np.empty_like(slab)
     original[meta.original_ids.astype(np.int64)] = slab  # back to original row order; load() rebuilds the same slabs
     return IvfFlatIndex.load(original, meta.centroids, ivf_assignments_from_meta(meta), metric, device=device, ivfflat_routing=True)

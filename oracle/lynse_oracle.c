@@ -698,7 +698,13 @@ int lo_pool_start(int n_threads) {
     pthread_mutex_init(&g_pool.mu, NULL); pthread_cond_init(&g_pool.cv_go, NULL); pthread_cond_init(&g_pool.cv_done, NULL);
     g_pool.th = (pthread_t *)malloc((size_t)n_threads * sizeof(pthread_t));
     g_pool.n = n_threads;
-    const long ncpu = sysconf(_SC_NPROCESSORS_ONLN);
+    /* the cpus this process may run on (a container's cpuset can be narrower than the machine) */
+    cpu_set_t allowed;
+    int cpus[CPU_SETSIZE], ncpu = 0;
+    CPU_ZERO(&allowed);
+    if (sched_getaffinity(0, sizeof allowed, &allowed) == 0)
+        for (int c = 0; c < CPU_SETSIZE; ++c)
+            if (CPU_ISSET(c, &allowed)) cpus[ncpu++] = c;
     for (int i = 0; i < n_threads; ++i) {
         pool_worker_t *w = (pool_worker_t *)malloc(sizeof *w);
         w->id = i;
@@ -706,7 +712,7 @@ int lo_pool_start(int n_threads) {
         if (ncpu > 0) {  /* best effort: keeps a worker (and the pages it first-touched) on one NUMA node */
             cpu_set_t set;
             CPU_ZERO(&set);
-            CPU_SET((int)(i % ncpu), &set);
+            CPU_SET(cpus[i % ncpu], &set);
             (void)pthread_setaffinity_np(g_pool.th[i], sizeof set, &set);
         }
     }

@@ -188,3 +188,20 @@ def test_hot_kernels_have_no_scratch_spills():
             assert int(scratch) == 0, (name, scratch)
     assert all(v >= 1 for v in hot.values()), hot   # the kernels bench.py / the BASELINE configs run were all seen
     assert seen >= 20
+
+
+def test_reference_partition_rule_matches_the_golden_hashes(golden_dir):
+    """blake2b64("{db}/{coll}/{id}") % 4096 -> bucket % world (python/lynse/cluster.py:156-158, :1273, :1364-1370): the
+    values were captured from the reference's own `_hash_u64` (tests/golden/make_python_reference_vectors.py)."""
+    import json
+
+    from lynsedb_amd.sharded import bucket_of_id, hash_u64, shard_of_id
+
+    g = json.loads((golden_dir / "python_reference_vectors.json").read_text())["hash_u64"]
+    assert len(g) >= 4
+    for e in g:
+        assert hash_u64(e["key"]) == int(e["hash"]), e
+        db, coll, item = e["key"].split("/")
+        assert bucket_of_id(db, coll, item) == e["bucket4096"]
+        for world in (1, 2, 4, 8):
+            assert shard_of_id(db, coll, item, world) == e["bucket4096"] % world

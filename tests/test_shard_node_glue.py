@@ -59,3 +59,29 @@ def test_result_block_codec_roundtrip():  # cluster.rs:738-749
     bad[16:20] = (10_000).to_bytes(4, "little")
     with pytest.raises(Exception, match="exceeds frame"):
         N.decode_search_result(bytes(bad), 0)
+
+
+def test_merge_row_results_with_nan_distances_is_a_total_order():
+    """NaN distances (vectors holding NaN) must not reach std::sort through a comparator that is not a strict weak order:
+    real distances come first in metric order, NaN entries last, ids ascending inside equal keys."""
+    import numpy as np
+
+    from lynsedb_amd import shard_node as N
+
+    nan = float("nan")
+    rng = np.random.default_rng(0)
+    for asc_metric in ("l2", "ip"):
+        ids_l = np.arange(0, 400, dtype=np.uint64)
+        d_l = rng.random(400).astype(np.float32)
+        d_l[::7] = nan
+        ids_r = np.arange(300, 700, dtype=np.uint64)
+        d_r = rng.random(400).astype(np.float32)
+        d_r[::5] = nan
+        ids, d = N.merge_row_results(ids_l, d_l, ids_r, d_r, 10_000, asc_metric)
+        assert len(set(ids.tolist())) == ids.size == 700
+        real = ~np.isnan(d)
+        k = int(real.sum())
+        assert real[:k].all() and not real[k:].any()                      # NaN last
+        key = d[:k] if asc_metric == "l2" else -d[:k]
+        assert np.all(np.diff(key) >= 0)
+        assert np.all(np.diff(ids[k:].astype(np.int64)) > 0)              # ids ascending among the NaN entries

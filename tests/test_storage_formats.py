@@ -86,3 +86,40 @@ def test_ivf_meta_roundtrip(tmp_path):  # ivf_flat_mmap.rs:448-530
     p.write_bytes(raw[:-3])
     with pytest.raises(IOError):
         S.load_ivf_meta(p)
+
+
+def test_pending_update_journal_is_refused(tmp_path):  # vector_store.rs:28, :682-687
+    data = np.arange(40, dtype=f32).reshape(10, 4)
+    S.write_flat_collection(tmp_path, [data])
+    assert S.load_manifest(tmp_path, 4).segments[0].rows == 10
+    (tmp_path / S.UPDATE_JOURNAL_FILE).write_bytes(b"\x00" * 16)
+    with pytest.raises(S.StorageError, match="pending row updates"):
+        S.load_manifest(tmp_path, 4)
+    with pytest.raises(S.StorageError):
+        list(S.read_segments(tmp_path, 4))
+
+
+def test_write_appends_to_an_existing_collection(tmp_path):  # VectorStore::write appends (vector_store.rs:379-445)
+    a = np.arange(40, dtype=f32).reshape(10, 4)
+    b = a + 100
+    S.write_flat_collection(tmp_path, [a], ids=np.arange(10, dtype=np.uint64))
+    m = S.write_flat_collection(tmp_path, [b], ids=np.arange(50, 60, dtype=np.uint64))   # second call: must not truncate
+    assert sum(s.rows for s in m.segments) == 20
+    rows = np.concatenate([x for _, x in S.read_segments(tmp_path, 4)])
+    assert np.array_equal(rows, np.concatenate([a, b]))
+    assert S.load_id_map(tmp_path / "id_map.bin").tolist() == list(range(10)) + list(range(50, 60))
+    # ... also across the segment boundary, with the manifest on disk
+    c = a + 1000
+    m = S.write_flat_collection(tmp_path, [c], segment_target_bytes=64)
+    assert [s.rows for s in m.segments] == [20, 10] and (tmp_path / S.VECTOR_MANIFEST_FILE).exists()
+    rows = np.concatenate([x for _, x in S.read_segments(tmp_path, 4)])
+    assert np.array_equal(rows, np.concatenate([a, b, c]))
+
+
+def test_open_ivf_flat_reports_a_short_data_file(tmp_path):  # ivf_flat_mmap.rs:161-223
+    meta = S.IvfMeta(3, 5, 2, np.zeros((2, 3), f32), np.array([0, 2, 5], np.uint64), np.array([4, 1, 0, 2, 3], np.uint32))
+    data = tmp_path / "vecs.bin"
+    S.save_ivf_meta(S.ivf_meta_path(data), meta)
+    data.write_bytes(np.zeros(4 * 3, "<f4").tobytes())   # 4 rows instead of 5
+    with pytest.raises(IOError, match="shorter than its metadata"):
+        S.open_ivf_flat(data)
