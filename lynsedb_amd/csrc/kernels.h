@@ -418,6 +418,7 @@ struct ScanArgs {
     uint32_t* count;
     uint32_t cap;
     int emit_all;
+    int dense;        // host-side dispatch only: this threshold stage expects many survivors per block -> the DENSE epilogue
     int debug_flags;  // timing experiments only: 1 = linear (blocked-layout-like) row addressing, 2 = no emission
     // work-list mode (IVF slabs): tile t covers rows [tiles[t].row0, +nrows) for the query group whose
     // f16 image starts at Q16 + qimg_off halves; local query n of the group is query pair_q[pair0+n]
@@ -1016,7 +1017,7 @@ constexpr int HK = 64;  // K elements per slab
 // cost registers the unfiltered kernel does not have to spare (56 B/lane of scratch and 13 % of its speed when they
 // were runtime branches).
 template <int WQ, int WR, int TQ, int TR, int METRIC, int NSV, int NSQ, int NT_HINT, bool TILED = false, bool RAG = true, int DBG = 0, bool FILT = false,
-          int I8Q = 0, int EMIT = -1, int PLACE = 0>
+          int I8Q = 0, int EMIT = -1, int PLACE = 0, bool DENSE = false>
 __global__ void __launch_bounds__(WQ * WR * 64, (TQ * TR >= 16) ? 1 : ((WQ * WR >= 8) ? (WQ * WR / 4) : 2)) k_scan_h16(ScanArgs a) {
     // Two LDS rings: NSV stages of row slabs (HBM latency: deeper) and NSQ <= NSV stages of query-image
     // slabs (L2 latency) — 3 + 2 stages of 32 KiB fill the 160 KiB of a CU for the 256 x 256 tile.
@@ -1383,7 +1384,7 @@ __global__ void __launch_bounds__(WQ * WR * 64, (TQ * TR >= 16) ? 1 : ((WQ * WR 
                 if (ea->debug_flags & 2) c_thr[j] = ASC ? -LY_INF : LY_INF;
 #endif
                 set_pre(j, c_thr[j], e_vmax2);
-                if (WR >= 4 && !FILT && e_emit_all == 2 && !TILED) {  // (compiled out of the <4,2,2,4> tiling and the subset-filter variants: it would spill there)
+                if ((WR >= 4 || EMIT == 2) && !FILT && e_emit_all == 2 && !TILED) {  // (runtime-EMIT bodies of the <4,2,2,4> tiling and the subset-filter variants leave it out: it would spill there)
                     // threshold-only sample stage: each lane keeps the best LM of its TR*16 rows for this query column
                     // (4 WR keys per tile and query) and writes only those.  k_select turns the k-th best of them into a
                     // valid threshold and keeps no candidate: the sample tiles are scanned again by the ordinary stages.
@@ -1438,6 +1439,65 @@ __global__ void __launch_bounds__(WQ * WR * 64, (TQ * TR >= 16) ? 1 : ((WQ * WR 
                                     ((mw >> bit) & 1u) ? make_key(sc, (FILT && !TILED && ea->row_ids) ? ea->row_ids[m] : m, ASC) : KEY_SENTINEL;
                         }
                     }
+                } else if (DENSE && !I8 && !TILED && !FILT) {
+                    // ---- DENSE threshold stage (many survivors per block: large k over few rows seen so far, e.g. k = 100 on 1M
+                    // rows).  The two-level filter degenerates there — nearly every 32-query x TR*32-row block holds a survivor,
+                    // so level 2 (exact expression + pass masks for all TR x 16 values) runs on top of level 1 almost always.
+                    // One pass instead: per accumulator the level-1 value against the LOOSENED threshold (2 VALU + a wave-level
+                    // branch); only elements some lane passes run the exact expression, the exact threshold and the store.
+                    // Slots: every lane owns one private segment of `seg` slots (segments are per (workgroup, row-wave, wave half):
+                    // no counts to agree on between the two half-waves of a query column); a full segment falls back to the shared
+                    // region (returning atomic).
+                    const uint32_t e_seg = ea->seg;
+                    uint32_t cnt = (segpk >> (8 * j)) & 0xffu;
+                    uint64_t* segdst = ea->candB + ((size_t)n * ea->nseg + ((blockIdx.x * WR + wr) * 2 + hi)) * e_seg;
+                    const float thr_e = c_thr[j], pre_e = c_ok[j] ? (METRIC == M_IP ? c_thr[j] : c_pre[j]) : LY_INF;  // (IP: the level-1 value is the score itself)
+#pragma unroll
+                    for (int i = 0; i < TR; ++i) {
+#pragma unroll
+                        for (int g4 = 0; g4 < 4; ++g4) {
+                            float nv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+                            const uint32_t off = wr * (TR * 32) + i * 32 + 8 * g4 + 4 * hi;  // rows off .. off+3 <-> r = 4 g4 .. 4 g4 + 3
+                            if constexpr (METRIC != M_IP) {
+                                if (NORMS_LDS) {
+                                    const f32x4 t4 = *reinterpret_cast<const f32x4*>(nrm + off);
+                                    nv[0] = t4[0]; nv[1] = t4[1]; nv[2] = t4[2]; nv[3] = t4[3];
+                                } else {
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) {
+                                        const uint32_t m = rb + off + e;
+                                        nv[e] = m < row_end ? (METRIC == M_L2 ? ea->vn2[m] : ea->vrinv[m]) : 0.0f;
+                                    }
+                                }
+                            }
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const int r = 4 * g4 + e;
+                                float pv = acc[i][j][r];
+                                if (METRIC == M_L2) pv = __fmaf_rn(pv, 2.0f * c_qinv[j], -nv[e]);
+                                if (METRIC == M_COS) pv = pv * nv[e];
+                                if (METRIC == M_IP) pv = pv * c_qinv[j];
+                                if (pv >= pre_e) {
+                                    const uint32_t m = rb + off + e;
+                                    float sc = acc[i][j][r] * c_qinv[j];
+                                    if (METRIC == M_L2) sc = nv[e] - 2.0f * sc + c_extra[j];
+                                    if (METRIC == M_COS) sc = 1.0f - sc * nv[e] * c_extra[j];
+                                    const bool pass = m < row_end && (ASC ? (sc <= thr_e) : (sc >= thr_e));
+                                    if (pass) {
+                                        const uint64_t key = make_key(sc, m, ASC);
+                                        if (cnt < e_seg) {
+                                            segdst[cnt] = key;
+                                            ++cnt;
+                                        } else {
+                                            const uint32_t slot = atomicAdd(&ea->count[n], 1u);
+                                            if (slot < ea->cap) ea->cand[(size_t)n * ea->cap + slot] = key;
+                                        }
+                                    }
+                                }
+                            }
+                        }
+                    }
+                    segpk = (segpk & ~(0xffu << (8 * j))) | (cnt << (8 * j));
                 } else {
                     // ---- level 1
                     float best = -LY_INF;
@@ -1568,11 +1628,12 @@ __global__ void __launch_bounds__(WQ * WR * 64, (TQ * TR >= 16) ? 1 : ((WQ * WR 
 #endif
     if (!TILED) {
         const EpiArgsPtr ea = epi_args();
-        if (ea->seg && hi == 0) {
+        if (ea->seg && (hi == 0 || DENSE)) {  // DENSE: one segment per wave half (the lane's own), else one per row-wave
 #pragma unroll
             for (int j = 0; j < TQ; ++j) {
                 const uint32_t n = wq * (TQ * 32) + j * 32 + l32;
-                if (n < ea->nq) ea->segcnt[(size_t)n * ea->nseg + (blockIdx.x * WR + wr)] = (uint8_t)((segpk >> (8 * j)) & 0xffu);
+                const uint32_t sgm = DENSE ? (blockIdx.x * WR + wr) * 2 + hi : blockIdx.x * WR + wr;
+                if (n < ea->nq) ea->segcnt[(size_t)n * ea->nseg + sgm] = (uint8_t)((segpk >> (8 * j)) & 0xffu);
             }
         }
     }

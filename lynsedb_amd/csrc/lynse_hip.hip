@@ -841,7 +841,7 @@ static int launch_scan_h16(const ScanArgs& a, int metric, uint32_t grid, hipStre
     constexpr int BQ = WQ * TQ * 32, BR = WR * TR * 32;
     constexpr size_t rings = (size_t)(NSV * BR + NSQ * BQ) * (HK * 2);
     const size_t lds = (rings + (NSV + 1) * 1024 <= 160 * 1024) ? rings + (NSV + 1) * 1024 : rings;
-    static bool attr_done[32] = {false};
+    static bool attr_done[64] = {false};
     auto go = [&](auto kern, int slot) -> int {
         if (!attr_done[slot]) { LY_TRY(set_max_lds(kern, lds)); attr_done[slot] = true; }
         hipLaunchKernelGGL(kern, dim3(grid), dim3(WQ * WR * 64), lds, st, a);
@@ -882,8 +882,11 @@ static int launch_scan_h16(const ScanArgs& a, int metric, uint32_t grid, hipStre
         auto by_emit = [&](auto mtag, auto ragtag, auto filtag, int base) -> int {
             constexpr int M = decltype(mtag)::value;
             constexpr bool RG = decltype(ragtag)::value, FL = decltype(filtag)::value;
+            if constexpr (WR < 4 && !FL && M != M_IP) {  // many survivors per block expected: one-pass epilogue (kernels.h, DENSE)
+                if (a.emit_all == 0 && a.dense) return go(k_scan_h16<WQ, WR, TQ, TR, M, NSV, NSQ, 2, false, RG, 0, FL, 0, 0, 0, true>, base + 27 + (RG ? 1 : 0));
+            }
             if (a.emit_all == 0) return go(k_scan_h16<WQ, WR, TQ, TR, M, NSV, NSQ, 2, false, RG, 0, FL, 0, 0>, base);
-            if constexpr (WR >= 4 && !FL) {  // (the lane-max sample stage exists for the unfiltered <., 4, ., .> tilings only)
+            if constexpr (!FL) {  // (the lane-max sample stage exists for the unfiltered tilings only)
                 if (a.emit_all == 2) return go(k_scan_h16<WQ, WR, TQ, TR, M, NSV, NSQ, 2, false, RG, 0, FL, 0, 2>, base + 2);
             }
             return go(k_scan_h16<WQ, WR, TQ, TR, M, NSV, NSQ, 2, false, RG, 0, FL, 0, 1>, base + 1);
@@ -1149,13 +1152,13 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
     // (k <= 16: the best tile alone supplies k keys, so even a shard sorted by score gets a tight threshold from its best
     // sample tile; up to k = 128 the sample as a whole supplies >= 8 k keys — a clustered shard may then overflow the first
     // stage and fall back to the contiguous plan)
-    const bool can_threshold_only = h16 && !binary && !filt && !no_lane_max0 && (small || waves16 != 0) && k <= 128;
+    const bool can_threshold_only = h16 && !binary && !filt && !no_lane_max0 && k <= 128;
     const std::vector<Stage> plan = make_plan(h, k, (level == 0 && (!plan_tile || no_sample)) ? 1 : level, plan_tile, can_threshold_only);
     const Stage sample = (!plan.empty() && plan[0].sample_tiles) ? plan[0] : Stage{0, 0};
     *sampled_plan = sample.sample_tiles != 0;
     // sampled plan: the sample stage only has to produce a threshold -> one key per lane (its best row) instead of every
     // score, as long as that leaves comfortably more than k keys per query (2 WR keys per tile and query)
-    const uint32_t sample_keys_per_tile = (small || waves16 != 0) ? 16u : 0u;  // 2 WR lanes per query and tile x their best 2 rows (WR = 4 tilings only)
+    const uint32_t sample_keys_per_tile = (small || waves16 != 0) ? 16u : 8u;  // 2 WR lanes per query and tile x their best 2 rows (WR = 4: 16, <4,2,2,4>: 8)
     static const int no_lane_max = []() { const char* e = getenv("LYNSE_HIP_NO_LANE_MAX"); return e ? atoi(e) : 0; }();
     // k <= keys per tile: the best sample tile alone supplies k keys (a shard sorted by score still gets a tight threshold)
     const bool sample_threshold_only = h16 && !binary && !filt && sample.sample_tiles && !no_lane_max && sample_keys_per_tile &&
@@ -1242,7 +1245,14 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
                     LY_TRY((launch_scan_h16<1, 4, 1, 1, 3, 3, false>(a, metric, grid, st)));
                 } else {
                     const uint32_t grid = std::min<uint32_t>(a.ntiles, (uint32_t)h->num_cu);
-                    if (!a.emit_all) seg_geometry(grid, (waves16 == 3 || waves16 == 2) ? 4 : 2, &a.nseg, &a.seg);
+                    // DENSE epilogue (<4,2,2,4>, L2 / cosine, unfiltered): the expected share of passing (row, query) pairs of this
+                    // stage is k / rows-seen-before; above ~5e-5 nearly every 32 x 128 block holds a survivor and the two-level
+                    // filter only adds work (C3: k = 100 after 8K / 139K rows).  Its segments are per wave half.
+                    static const int dense_env = []() { const char* e = getenv("LYNSE_HIP_DENSE"); return e ? atoi(e) : -1; }();
+                    const uint64_t seen_before = s.sample_tiles ? 0 : (sample.sample_tiles ? std::max<uint64_t>((uint64_t)sample.sample_tiles * plan_tile, s.r0) : s.r0);
+                    a.dense = (!a.emit_all && waves16 == 0 && metric != M_IP && !filt && seen_before &&
+                               (dense_env >= 0 ? dense_env != 0 : (uint64_t)k * 20000ull > seen_before)) ? 1 : 0;
+                    if (!a.emit_all) seg_geometry(grid, a.dense ? 4 : ((waves16 == 3 || waves16 == 2) ? 4 : 2), &a.nseg, &a.seg);
 #ifdef LYNSE_EXPERIMENTS
                     if (waves16 == 2) LY_TRY((launch_scan_h16<2, 4, 4, 2, 2, 2, false>(a, metric, grid, st)));
                     else
