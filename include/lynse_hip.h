@@ -82,7 +82,7 @@ typedef struct lynse_hip_profile {
     uint64_t pool_entries;    /* candidates rescored exactly (sum over queries) */
     uint64_t last_plan;       /* plan of the last profiled float chunk: bit 0 sampled stage plan, bit 1 threshold-only
                                  (lane-max) sample stage, bit 2 certified int8 coarse pass, bit 3 segmented emission,
-                                 bit 4 <= 32-query kernel, bits 8..15 number of scan stages, bits 16..23 wave tiling
+                                 bit 4 <= 32-query kernel, bit 5 fused single-launch search (k_small_search), bits 8..15 number of scan stages, bits 16..23 wave tiling
                                  (0x24 = <2,4,4,2>, 0x42 = <4,2,2,4>, 0x14 = <1,4,1,1>) — lets a test pin the kernel
                                  instantiation a benchmark configuration runs */
 } lynse_hip_profile;
@@ -191,6 +191,11 @@ int lynse_hip_flat_profile_get(lynse_hip_flat *h, lynse_hip_profile *out, int re
 /* Tuning knobs (defaults are fine): first-stage rows and growth factor of the contiguous stage plan (the fallback of the
  * default sampled plan), candidate capacity per query (power of two in [256, 16384], default 16384; k <= cap / 4 when the
  * shard holds more than cap rows). */
+/* Few queries (<= 4) over a small shard (<= 64 MB of rows) with k <= 64 are answered by ONE fused launch
+ * (k_small_search: exact scores straight from the f32 rows, per-wave top-k in registers, last-workgroup merge) instead
+ * of the staged pipeline — the single-query latency path (flat_search_bench.py: 100k x 128, k = 10).  Results are
+ * identical; on = 0 forces the staged pipeline (tests, A/B). */
+int lynse_hip_flat_set_fused_search(lynse_hip_flat *h, int on);
 int lynse_hip_flat_set_plan(lynse_hip_flat *h, uint32_t stage0_rows, uint32_t growth, uint32_t cap);
 
 /* ---- stand-alone functions (src/python/mod.rs:2161-2223) ---- */

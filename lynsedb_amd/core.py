@@ -170,6 +170,10 @@ class FlatIndex:
     def set_ip_form(self, form: int) -> None:
         check(lib.lynse_hip_flat_set_ip_form(self._h, int(form)))
 
+    def set_fused_search(self, on: bool = True) -> None:
+        """on=False forces the staged pipeline for small shards / few queries (the fused single-launch search is the default)."""
+        check(lib.lynse_hip_flat_set_fused_search(self._h, 1 if on else 0))
+
     def set_plan(self, stage0_rows: int = 4096, growth: int = 8, cap: int = 8192) -> None:
         check(lib.lynse_hip_flat_set_plan(self._h, stage0_rows, growth, cap))
 

@@ -2540,6 +2540,156 @@ __global__ void __launch_bounds__(NT) k_select(SelectArgs a) {
 // rows (u64, after the shard row map), distances (f32) and the count.  Output order is the
 // canonical (distance, row ascending) order of vector_store.rs:953-970.
 // ------------------------------------------------------------------------------------------------
+// ------------------------------------------------------------------------------------------------
+// k_small_search — the whole search in ONE launch, for a few queries over a shard small enough that launch latency,
+// not bandwidth, is the cost (config 1: FLAT-IP 100k x 128, one query, k = 10 — the staged pipeline spends ~20 us
+// scanning and ~50 us in eight dependent launches).  Every row is scored EXACTLY from the f32 rows with the reference's
+// accumulation order (exact_score, 8 lanes per row) — no coarse pass, no margin, no rescoring; each wave keeps its k best
+// keys in registers (one key per lane, sorted; insertion = one shuffle), a workgroup merges its waves by rank, and the
+// LAST workgroup to finish (atomic ticket) merges the per-workgroup lists with k rounds of a block-wide minimum and writes
+// the outputs in the canonical (distance, row) order.  Limits: k <= 64, nq <= SMALL_MAX_Q, gridDim.x <= SMALL_NT.
+// ------------------------------------------------------------------------------------------------
+constexpr int SMALL_NT = 512;     // 8 waves per workgroup
+constexpr int SMALL_MAX_Q = 4;
+constexpr int SMALL_MAX_K = 64;
+
+struct SmallArgs {
+    const float* V;          // rows
+    uint32_t ld, D;
+    uint32_t n;
+    const float* Qf;         // nq x D
+    uint32_t nq, k, out_k;
+    int metric, ip_form;
+    uint64_t row_stride, row_offset;
+    uint64_t* part;          // [gridDim.x][nq][k] sorted keys of every workgroup
+    uint32_t* ticket;        // arrival counter (left at zero)
+    uint64_t* out_rows;
+    float* out_dists;
+    uint32_t* out_counts;
+    uint32_t* overflow;      // cleared: this path cannot overflow
+};
+
+__device__ __forceinline__ uint64_t shfl_up_u64(uint64_t v, int d) {
+    const uint32_t lo = (uint32_t)__shfl_up((int)(uint32_t)v, d, 64), hi = (uint32_t)__shfl_up((int)(uint32_t)(v >> 32), d, 64);
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint64_t shfl_u64(uint64_t v, int src) {
+    const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)v, src, 64), hi = (uint32_t)__shfl((int)(uint32_t)(v >> 32), src, 64);
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint64_t shfl_xor_u64(uint64_t v, int m) {
+    const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, m, 64), hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), m, 64);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+__global__ void __launch_bounds__(SMALL_NT) k_small_search(SmallArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* qs = reinterpret_cast<float*>(smem);                                   // D floats: the query being scanned
+    uint64_t* wl = reinterpret_cast<uint64_t*>(smem + (size_t)((a.D + 3) / 4 * 4) * 4);  // [8 waves][64] keys; later the merge lists
+    __shared__ uint32_t s_last;
+    __shared__ uint64_t s_red[SMALL_NT / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane & 7, grp = lane >> 3;
+    const bool asc = a.metric != M_IP;
+    const uint32_t k = a.k;
+    constexpr int NWAVE = SMALL_NT / 64;
+    const uint32_t rows_per_pass = gridDim.x * NWAVE * 16;   // a group of 8 lanes scores TWO rows per pass (two load streams in flight)
+    for (uint32_t q = 0; q < a.nq; ++q) {
+        __syncthreads();
+        for (uint32_t i = tid; i < a.D; i += SMALL_NT) qs[i] = a.Qf[(size_t)q * a.D + i];
+        __syncthreads();
+        uint64_t L = KEY_SENTINEL;  // lane j holds the wave's j-th best key (ascending = best first)
+        uint64_t thr = KEY_SENTINEL;
+        auto offer = [&](uint64_t key) {
+            unsigned long long m = __ballot(g == 0 && key < thr);
+            while (m) {  // rare once the list has warmed up
+                const int src = __ffsll((long long)m) - 1;
+                m &= m - 1;
+                const uint64_t x = shfl_u64(key, src);
+                if (x < thr) {
+                    const uint64_t prev = shfl_up_u64(L, 1);
+                    if (L > x) L = (lane == 0 || prev <= x) ? x : prev;
+                    thr = shfl_u64(L, (int)k - 1);
+                }
+            }
+        };
+        for (uint32_t r0 = (blockIdx.x * NWAVE + wave) * 16; r0 < a.n; r0 += rows_per_pass) {
+            const uint32_t ra = r0 + grp, rb = r0 + 8 + grp;
+            // out-of-range rows re-read the last row (uniform control flow inside exact_score) and are dropped afterwards
+            const uint32_t ca = ra < a.n ? ra : a.n - 1, cb = rb < a.n ? rb : a.n - 1;
+            const float sa = exact_score(a.metric, a.ip_form, qs, a.V + (size_t)ca * a.ld, a.D, g);
+            const float sb = exact_score(a.metric, a.ip_form, qs, a.V + (size_t)cb * a.ld, a.D, g);
+            offer(ra < a.n ? make_key(sa, ra, asc) : KEY_SENTINEL);
+            offer(rb < a.n ? make_key(sb, rb, asc) : KEY_SENTINEL);
+        }
+        wl[wave * 64 + lane] = lane < (int)k ? L : KEY_SENTINEL;
+        __syncthreads();
+        {   // merge the waves by rank: one key per thread, keys are unique apart from the sentinel
+            const uint64_t mine = wl[tid];
+            uint32_t rank = 0;
+            if (mine != KEY_SENTINEL) {  // (only lanes < k of every wave hold keys: NWAVE x k comparisons)
+                for (int w = 0; w < NWAVE; ++w)
+                    for (uint32_t j = 0; j < k; ++j) rank += (wl[w * 64 + j] < mine) ? 1u : 0u;
+                if (rank < k) a.part[((size_t)blockIdx.x * a.nq + q) * k + rank] = mine;
+            }
+            // slots past the number of real keys hold the sentinel
+            uint32_t real = 0;
+            if (tid < (int)k) {
+                for (int w = 0; w < NWAVE; ++w)
+                    for (uint32_t j = 0; j < k; ++j) real += wl[w * 64 + j] != KEY_SENTINEL ? 1u : 0u;
+                if ((uint32_t)tid >= real) a.part[((size_t)blockIdx.x * a.nq + q) * k + tid] = KEY_SENTINEL;
+            }
+        }
+    }
+    // ---- the last workgroup to arrive merges the per-workgroup lists: plain stores -> barrier -> ONE agent-scope release
+    // -> ticket; the last arriver: ONE agent-scope acquire -> barrier -> loads (cdna_hip_programming.md, Guideline 16)
+    __syncthreads();
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the write-back must not be overtaken by the ticket
+        const uint32_t t = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = (t == gridDim.x - 1) ? 1u : 0u;
+        if (s_last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+    if (!s_last) return;
+    const uint32_t nlist = gridDim.x;
+    const uint32_t kout = k < a.n ? k : a.n;
+    uint64_t* lists = wl;  // [nlist][k] staged in LDS (the launch sizes the dynamic LDS for it)
+    for (uint32_t q = 0; q < a.nq; ++q) {
+        __syncthreads();
+        for (uint32_t i = tid; i < nlist * k; i += SMALL_NT) {
+            const uint32_t wg = i / k, j = i % k;
+            lists[i] = a.part[((size_t)wg * a.nq + q) * k + j];
+        }
+        __syncthreads();
+        // thread t < nlist owns list t: k rounds of a block-wide minimum over the list heads
+        uint32_t head = 0;
+        const bool owner = tid < (int)nlist;
+        uint64_t cur = owner ? lists[(size_t)tid * k] : KEY_SENTINEL;
+        for (uint32_t round = 0; round < kout; ++round) {
+            uint64_t v = cur;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { const uint64_t w = shfl_xor_u64(v, o); v = w < v ? w : v; }
+            __syncthreads();
+            if (lane == 0) s_red[wave] = v;
+            __syncthreads();
+            uint64_t best = s_red[0];
+#pragma unroll
+            for (int w = 1; w < NWAVE; ++w) best = s_red[w] < best ? s_red[w] : best;
+            if (owner && cur == best && best != KEY_SENTINEL) {  // keys are unique: exactly one owner advances
+                ++head;
+                cur = head < k ? lists[(size_t)tid * k + head] : KEY_SENTINEL;
+            }
+            if (tid == 0) {
+                a.out_rows[(size_t)q * a.out_k + round] = (uint64_t)key_row(best) * a.row_stride + a.row_offset;
+                a.out_dists[(size_t)q * a.out_k + round] = key_score(best, asc);
+            }
+        }
+        if (tid == 0) { a.out_counts[q] = kout; a.overflow[q] = 0u; }
+    }
+    if (tid == 0) __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 struct FinalArgs {
     const uint64_t* cand;
     const uint32_t* count;

@@ -10,7 +10,9 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <condition_variable>
 #include <mutex>
+#include <shared_mutex>
 #include <string>
 #include <type_traits>
 #include <vector>
@@ -159,12 +161,14 @@ struct Workspace {
     uint32_t* h_hdr = nullptr;       // pinned host mirror of that pair
     uint8_t* h_out = nullptr;        // pinned staging for small host-API results (rows then dists), H_OUT_BYTES
     unsigned long long* pool_total = nullptr;
+    uint64_t* small_part = nullptr;   // k_small_search: [workgroups][SMALL_MAX_Q][SMALL_MAX_K] keys
+    uint32_t* small_ticket = nullptr;
     void release() {
         if (h_hdr) (void)hipHostFree(h_hdr);
         if (h_out) (void)hipHostFree(h_out);
         for (void* p : {(void*)cand, (void*)candB, (void*)segcnt, (void*)count, (void*)thr, (void*)qinv, (void*)qn2,
                         (void*)qrinv, (void*)marg2, (void*)Q16, (void*)Qf, (void*)QW, (void*)QWp, (void*)out_rows,
-                        (void*)out_dists, (void*)out_counts, (void*)pool_total})
+                        (void*)out_dists, (void*)out_counts, (void*)pool_total, (void*)small_part, (void*)small_ticket})
             if (p) (void)hipFree(p);
         *this = Workspace();
     }
@@ -174,8 +178,24 @@ struct lynse_hip_flat {
     uint32_t dim = 0, ld = 0, words = 0;
     int device = 0;
     int num_cu = 256;
-    hipStream_t stream = nullptr;
-    std::mutex mu;
+    // Reader / writer discipline (VectorIndex: Send + Sync, Arc<RwLock<Collection>> with inner.read() on the search path,
+    // src/python/mod.rs:950, :1187): unfiltered searches hold `rw` SHARED and run concurrently, each on its own search
+    // context (workspace + stream + event pool) taken from `ctx`; append / finalize / lazy builds / the subset-filtered
+    // paths (they borrow per-handle scratch) hold it EXCLUSIVE and use context 0.  The context of the calling thread is
+    // selected by a thread-local slot (cur()), so the helpers below keep reading h->ws / cur(h).stream through it.
+    std::shared_mutex rw;
+    struct Ctx {
+        hipStream_t stream = nullptr;
+        Workspace ws;
+        std::vector<hipEvent_t> ev_pool;
+    };
+    static constexpr int MAX_CTX = 8;
+    Ctx ctx[MAX_CTX];
+    int n_ctx = 4;                       // LYNSE_HIP_CONTEXTS (1..8): searches in flight per handle
+    std::mutex ctx_mu;
+    std::condition_variable ctx_cv;
+    uint32_t ctx_busy = 0;               // bit s: context s is taken
+    std::mutex prof_mu;                  // profile counters are shared by the contexts
 
     uint64_t n = 0, capacity = 0;
     float* rows = nullptr;       // capacity x ld f32, row-major (pad columns zero)
@@ -197,10 +217,10 @@ struct lynse_hip_flat {
 
     uint64_t row_stride = 1, row_offset = 0;
     int ip_form = LYNSE_IPFORM_AUTO;
+    int no_fused = 0;            // lynse_hip_flat_set_fused_search(h, 0): always the staged pipeline (tests, A/B)
     int dtype = LYNSE_DTYPE_F32;  // F16: rows hold f16-representable values, distances use the f16 kernels' sequential sums
     uint32_t stage0_rows = 4096, growth = 8, cap = 16384;
 
-    Workspace ws;
     // filtered search: row bitmask of the current subset + staging for the subset ids
     uint32_t* d_mask = nullptr;
     uint64_t mask_words = 0;
@@ -226,7 +246,47 @@ struct lynse_hip_flat {
 
     bool profiling = false;
     lynse_hip_profile prof{};
-    std::vector<hipEvent_t> ev_pool;
+};
+
+static thread_local int tl_ctx_slot = 0;   // the search context of the calling thread (0 outside a concurrent search)
+static inline lynse_hip_flat::Ctx& cur(lynse_hip_flat* h) { return h->ctx[tl_ctx_slot]; }
+static inline const lynse_hip_flat::Ctx& cur(const lynse_hip_flat* h) { return h->ctx[tl_ctx_slot]; }
+
+// Takes a free search context for the calling thread (blocks while all n_ctx are busy); context 0's stream is created with
+// the handle, the others on first use.
+struct CtxLease {
+    lynse_hip_flat* h = nullptr;
+    int slot = 0, prev = 0;
+    int acquire(lynse_hip_flat* hh) {
+        h = hh;
+        {
+            std::unique_lock<std::mutex> lk(h->ctx_mu);
+            for (;;) {
+                int s = 0;
+                while (s < h->n_ctx && ((h->ctx_busy >> s) & 1u)) ++s;
+                if (s < h->n_ctx) { slot = s; h->ctx_busy |= 1u << s; break; }
+                h->ctx_cv.wait(lk);
+            }
+        }
+        prev = tl_ctx_slot;
+        tl_ctx_slot = slot;
+        if (!h->ctx[slot].stream && hipStreamCreateWithFlags(&h->ctx[slot].stream, hipStreamNonBlocking) != hipSuccess) {
+            release();
+            return set_error(LYNSE_ERR_DEVICE, "hipStreamCreate failed");
+        }
+        return LYNSE_OK;
+    }
+    void release() {
+        if (!h) return;
+        tl_ctx_slot = prev;
+        {
+            std::lock_guard<std::mutex> lk(h->ctx_mu);
+            h->ctx_busy &= ~(1u << slot);
+        }
+        h->ctx_cv.notify_one();
+        h = nullptr;
+    }
+    ~CtxLease() { release(); }
 };
 
 static int use_device(const lynse_hip_flat* h) {
@@ -255,14 +315,15 @@ extern "C" int lynse_hip_flat_create(uint32_t dim, int device, lynse_hip_flat** 
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
         h->num_cu = prop.multiProcessorCount;
-    hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+    if (const char* ce = getenv("LYNSE_HIP_CONTEXTS")) h->n_ctx = std::max(1, std::min((int)lynse_hip_flat::MAX_CTX, atoi(ce)));
+    hipError_t e = hipStreamCreateWithFlags(&h->ctx[0].stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
         delete h;
         return set_error(LYNSE_ERR_DEVICE, std::string("hipStreamCreate: ") + hipGetErrorString(e));
     }
     e = hipMalloc(&h->d_stats, 4 * sizeof(uint32_t));
     if (e != hipSuccess) {
-        (void)hipStreamDestroy(h->stream);
+        (void)hipStreamDestroy(cur(h).stream);
         delete h;
         return set_error(LYNSE_ERR_OUT_OF_MEMORY, "hipMalloc(stats)");
     }
@@ -275,14 +336,17 @@ extern "C" int lynse_hip_flat_create(uint32_t dim, int device, lynse_hip_flat** 
 extern "C" int lynse_hip_flat_destroy(lynse_hip_flat* h) {
     if (!h) return LYNSE_OK;
     (void)hipSetDevice(h->device);
-    if (h->stream) (void)hipStreamSynchronize(h->stream);
-    h->ws.release();
-    for (auto e : h->ev_pool) (void)hipEventDestroy(e);
+    for (auto& c : h->ctx) {
+        if (c.stream) (void)hipStreamSynchronize(c.stream);
+        c.ws.release();
+        for (auto e : c.ev_pool) (void)hipEventDestroy(e);
+    }
     for (void* p : {(void*)h->rows, (void*)h->rows16, (void*)h->packed, (void*)h->vn2, (void*)h->vrinv, (void*)h->d_stats,
                     (void*)h->d_mask, (void*)h->d_subset, (void*)h->g_rows16, (void*)h->g_vn2, (void*)h->g_vrinv, (void*)h->g_ids32,
                     (void*)h->sq8, (void*)h->sq8_mins, (void*)h->sq8_scales, (void*)h->sq8_sum, (void*)h->sq8_sum2, (void*)h->sq8_mm, (void*)h->sq8_stats})
         if (p) (void)hipFree(p);
-    if (h->stream) (void)hipStreamDestroy(h->stream);
+    for (auto& c : h->ctx)
+        if (c.stream) (void)hipStreamDestroy(c.stream);
     delete h;
     return LYNSE_OK;
 }
@@ -294,8 +358,8 @@ static int grow_rows(lynse_hip_flat* h, uint64_t need) {
     float* nr = nullptr;
     LY_HIP(hipMalloc(&nr, (size_t)cap * h->ld * sizeof(float)));
     if (h->rows && h->n)
-        LY_HIP(hipMemcpyAsync(nr, h->rows, (size_t)h->n * h->ld * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
-    LY_HIP(hipStreamSynchronize(h->stream));
+        LY_HIP(hipMemcpyAsync(nr, h->rows, (size_t)h->n * h->ld * sizeof(float), hipMemcpyDeviceToDevice, cur(h).stream));
+    LY_HIP(hipStreamSynchronize(cur(h).stream));
     if (h->rows) (void)hipFree(h->rows);
     h->rows = nr;
     h->capacity = cap;
@@ -309,8 +373,8 @@ static int grow_packed(lynse_hip_flat* h, uint64_t need) {
     uint64_t* np = nullptr;
     LY_HIP(hipMalloc(&np, (size_t)cap * h->words * sizeof(uint64_t)));
     if (h->packed && h->n_packed)
-        LY_HIP(hipMemcpyAsync(np, h->packed, (size_t)h->n_packed * h->words * 8, hipMemcpyDeviceToDevice, h->stream));
-    LY_HIP(hipStreamSynchronize(h->stream));
+        LY_HIP(hipMemcpyAsync(np, h->packed, (size_t)h->n_packed * h->words * 8, hipMemcpyDeviceToDevice, cur(h).stream));
+    LY_HIP(hipStreamSynchronize(cur(h).stream));
     if (h->packed) (void)hipFree(h->packed);
     h->packed = np;
     h->packed_capacity = cap;
@@ -319,7 +383,7 @@ static int grow_packed(lynse_hip_flat* h, uint64_t need) {
 
 extern "C" int lynse_hip_flat_reserve(lynse_hip_flat* h, uint64_t rows) {
     if (!h) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "handle is NULL");
-    std::lock_guard<std::mutex> lk(h->mu);
+    std::unique_lock<std::shared_mutex> lk(h->rw);
     LY_TRY(use_device(h));
     if (rows > 0xfffffff0ull) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "row count exceeds the u32 id capacity of one shard");
     if (h->packed_only) return grow_packed(h, rows);
@@ -328,8 +392,8 @@ extern "C" int lynse_hip_flat_reserve(lynse_hip_flat* h, uint64_t rows) {
         float* nr = nullptr;
         LY_HIP(hipMalloc(&nr, (size_t)rows * h->ld * sizeof(float)));
         if (h->rows && h->n)
-            LY_HIP(hipMemcpyAsync(nr, h->rows, (size_t)h->n * h->ld * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
-        LY_HIP(hipStreamSynchronize(h->stream));
+            LY_HIP(hipMemcpyAsync(nr, h->rows, (size_t)h->n * h->ld * sizeof(float), hipMemcpyDeviceToDevice, cur(h).stream));
+        LY_HIP(hipStreamSynchronize(cur(h).stream));
         if (h->rows) (void)hipFree(h->rows);
         h->rows = nr;
         h->capacity = rows;
@@ -341,7 +405,7 @@ static int copy_rows_kernel(lynse_hip_flat* h, float* dst, uint32_t dp, const fl
                             uint64_t n, int zero_pad) {
     const uint64_t total = n * (zero_pad ? dp : width);
     const uint32_t blocks = (uint32_t)std::min<uint64_t>((total + 255) / 256, (uint64_t)h->num_cu * 32);
-    hipLaunchKernelGGL(k_copy_rows, dim3(std::max<uint32_t>(blocks, 1)), dim3(256), 0, h->stream, dst, dp, src, sp, width, n, zero_pad);
+    hipLaunchKernelGGL(k_copy_rows, dim3(std::max<uint32_t>(blocks, 1)), dim3(256), 0, cur(h).stream, dst, dp, src, sp, width, n, zero_pad);
     LY_HIP(hipGetLastError());
     return LYNSE_OK;
 }
@@ -352,14 +416,14 @@ static int append_f32_impl(lynse_hip_flat* h, const float* src, uint64_t n, hipM
     if (!h) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "handle is NULL");
     if (n == 0) return LYNSE_OK;
     if (!src) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "rows is NULL");
-    std::lock_guard<std::mutex> lk(h->mu);
+    std::unique_lock<std::shared_mutex> lk(h->rw);
     LY_TRY(use_device(h));
     if (h->packed_only) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "store holds packed rows; cannot append f32 rows");
     if (h->n + n > 0xfffffff0ull) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "row count exceeds the u32 id capacity of one shard");
     LY_TRY(grow_rows(h, h->n + n));
     float* dst = h->rows + (size_t)h->n * h->ld;
     if (h->ld == h->dim) {
-        LY_HIP(hipMemcpyAsync(dst, src, (size_t)n * h->dim * sizeof(float), kind, h->stream));
+        LY_HIP(hipMemcpyAsync(dst, src, (size_t)n * h->dim * sizeof(float), kind, cur(h).stream));
     } else if (kind == hipMemcpyDeviceToDevice) {
         LY_TRY(copy_rows_kernel(h, dst, h->ld, src, h->dim, h->dim, n, 1));
     } else {
@@ -368,10 +432,10 @@ static int append_f32_impl(lynse_hip_flat* h, const float* src, uint64_t n, hipM
         LY_HIP(hipMalloc(&stage, (size_t)std::min<uint64_t>(chunk, n) * h->dim * 4));
         for (uint64_t r = 0; r < n; r += chunk) {
             const uint64_t nr = std::min<uint64_t>(chunk, n - r);
-            hipError_t e = hipMemcpyAsync(stage, src + r * h->dim, (size_t)nr * h->dim * 4, kind, h->stream);
+            hipError_t e = hipMemcpyAsync(stage, src + r * h->dim, (size_t)nr * h->dim * 4, kind, cur(h).stream);
             int rc = e == hipSuccess ? copy_rows_kernel(h, dst + r * h->ld, h->ld, stage, h->dim, h->dim, nr, 1)
                                      : set_error(LYNSE_ERR_DEVICE, hipGetErrorString(e));
-            if (rc == LYNSE_OK && hipStreamSynchronize(h->stream) != hipSuccess) rc = set_error(LYNSE_ERR_DEVICE, "stream sync failed");
+            if (rc == LYNSE_OK && hipStreamSynchronize(cur(h).stream) != hipSuccess) rc = set_error(LYNSE_ERR_DEVICE, "stream sync failed");
             if (rc != LYNSE_OK) { (void)hipFree(stage); return rc; }
         }
         (void)hipFree(stage);
@@ -379,17 +443,17 @@ static int append_f32_impl(lynse_hip_flat* h, const float* src, uint64_t n, hipM
     if (h->dtype == LYNSE_DTYPE_F16) {  // what the F16 segment file keeps of these rows
         const uint64_t total = n * h->dim;
         hipLaunchKernelGGL(k_round_rows_f16, dim3((uint32_t)std::min<uint64_t>((total + 255) / 256, (uint64_t)h->num_cu * 32)), dim3(256), 0,
-                           h->stream, h->rows, h->ld, h->dim, h->n, h->n + n);
+                           cur(h).stream, h->rows, h->ld, h->dim, h->n, h->n + n);
         LY_HIP(hipGetLastError());
     }
-    LY_HIP(hipStreamSynchronize(h->stream));
+    LY_HIP(hipStreamSynchronize(cur(h).stream));
     h->n += n;
     return LYNSE_OK;
 }
 
 extern "C" int lynse_hip_flat_set_dtype(lynse_hip_flat* h, int dtype) {
     if (!h || (dtype != LYNSE_DTYPE_F32 && dtype != LYNSE_DTYPE_F16)) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "bad dtype");
-    std::lock_guard<std::mutex> lk(h->mu);
+    std::unique_lock<std::shared_mutex> lk(h->rw);
     if (h->n || h->packed_only) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "the dtype is fixed once rows are stored");
     h->dtype = dtype;
     return LYNSE_OK;
@@ -423,14 +487,14 @@ static int append_packed_impl(lynse_hip_flat* h, const uint64_t* src, uint64_t n
     if (!h) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "handle is NULL");
     if (n == 0) return LYNSE_OK;
     if (!src) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "words is NULL");
-    std::lock_guard<std::mutex> lk(h->mu);
+    std::unique_lock<std::shared_mutex> lk(h->rw);
     LY_TRY(use_device(h));
     if (h->n > 0 && !h->packed_only) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "store holds f32 rows; cannot append packed rows");
     if (h->n + n > 0xfffffff0ull) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "row count exceeds the u32 id capacity of one shard");
     h->packed_only = true;
     LY_TRY(grow_packed(h, h->n + n));
-    LY_HIP(hipMemcpyAsync(h->packed + (size_t)h->n * h->words, src, (size_t)n * h->words * 8, kind, h->stream));
-    LY_HIP(hipStreamSynchronize(h->stream));
+    LY_HIP(hipMemcpyAsync(h->packed + (size_t)h->n * h->words, src, (size_t)n * h->words * 8, kind, cur(h).stream));
+    LY_HIP(hipStreamSynchronize(cur(h).stream));
     h->n += n;
     h->n_packed = h->n;
     return LYNSE_OK;
@@ -455,12 +519,12 @@ static int finalize_locked(lynse_hip_flat* h) {
         // +256: the scan kernel's per-tile norm DMA reads a whole 256-row window
         LY_HIP(hipMalloc(&a, ((size_t)cap + 256) * sizeof(float)));
         LY_HIP(hipMalloc(&b, ((size_t)cap + 256) * sizeof(float)));
-        LY_HIP(hipMemsetAsync(a, 0, ((size_t)cap + 256) * sizeof(float), h->stream));
-        LY_HIP(hipMemsetAsync(b, 0, ((size_t)cap + 256) * sizeof(float), h->stream));
+        LY_HIP(hipMemsetAsync(a, 0, ((size_t)cap + 256) * sizeof(float), cur(h).stream));
+        LY_HIP(hipMemsetAsync(b, 0, ((size_t)cap + 256) * sizeof(float), cur(h).stream));
         if (h->n_stats) {
-            LY_HIP(hipMemcpyAsync(a, h->vn2, (size_t)h->n_stats * 4, hipMemcpyDeviceToDevice, h->stream));
-            LY_HIP(hipMemcpyAsync(b, h->vrinv, (size_t)h->n_stats * 4, hipMemcpyDeviceToDevice, h->stream));
-            LY_HIP(hipStreamSynchronize(h->stream));
+            LY_HIP(hipMemcpyAsync(a, h->vn2, (size_t)h->n_stats * 4, hipMemcpyDeviceToDevice, cur(h).stream));
+            LY_HIP(hipMemcpyAsync(b, h->vrinv, (size_t)h->n_stats * 4, hipMemcpyDeviceToDevice, cur(h).stream));
+            LY_HIP(hipStreamSynchronize(cur(h).stream));
         }
         if (h->vn2) (void)hipFree(h->vn2);
         if (h->vrinv) (void)hipFree(h->vrinv);
@@ -470,12 +534,12 @@ static int finalize_locked(lynse_hip_flat* h) {
     }
     const uint64_t nnew = h->n - h->n_stats;
     const uint32_t blocks = (uint32_t)std::min<uint64_t>((nnew + 3) / 4, (uint64_t)h->num_cu * 16);
-    hipLaunchKernelGGL(k_row_stats, dim3(blocks), dim3(256), 0, h->stream, h->rows, h->ld, h->dim,
+    hipLaunchKernelGGL(k_row_stats, dim3(blocks), dim3(256), 0, cur(h).stream, h->rows, h->ld, h->dim,
                        (uint32_t)h->n_stats, (uint32_t)h->n, h->vn2, h->vrinv, h->d_stats);
     LY_HIP(hipGetLastError());
     uint32_t st[4];
-    LY_HIP(hipMemcpyAsync(st, h->d_stats, sizeof st, hipMemcpyDeviceToHost, h->stream));
-    LY_HIP(hipStreamSynchronize(h->stream));
+    LY_HIP(hipMemcpyAsync(st, h->d_stats, sizeof st, hipMemcpyDeviceToHost, cur(h).stream));
+    LY_HIP(hipStreamSynchronize(cur(h).stream));
     float f[3];
     memcpy(f, st, sizeof f);
     h->amax = f[0];
@@ -494,7 +558,7 @@ static int finalize_locked(lynse_hip_flat* h) {
 
 extern "C" int lynse_hip_flat_finalize(lynse_hip_flat* h) {
     if (!h) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "handle is NULL");
-    std::lock_guard<std::mutex> lk(h->mu);
+    std::unique_lock<std::shared_mutex> lk(h->rw);
     LY_TRY(use_device(h));
     return finalize_locked(h);
 }
@@ -505,18 +569,18 @@ static int ensure_packed_locked(lynse_hip_flat* h) {
     LY_TRY(grow_packed(h, std::max<uint64_t>(h->n, h->capacity)));
     const uint64_t nnew = h->n - h->n_packed;
     const uint32_t blocks = (uint32_t)std::min<uint64_t>((nnew + 3) / 4, (uint64_t)h->num_cu * 16);
-    hipLaunchKernelGGL(k_pack_bits, dim3(blocks), dim3(256), 0, h->stream,
+    hipLaunchKernelGGL(k_pack_bits, dim3(blocks), dim3(256), 0, cur(h).stream,
                        h->rows + (size_t)h->n_packed * h->ld, h->ld, h->dim, (uint32_t)nnew,
                        h->packed + (size_t)h->n_packed * h->words, h->words);
     LY_HIP(hipGetLastError());
-    LY_HIP(hipStreamSynchronize(h->stream));
+    LY_HIP(hipStreamSynchronize(cur(h).stream));
     h->n_packed = h->n;
     return LYNSE_OK;
 }
 
 extern "C" int lynse_hip_flat_set_row_map(lynse_hip_flat* h, uint64_t stride, uint64_t offset) {
     if (!h || stride == 0) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "bad row map");
-    std::lock_guard<std::mutex> lk(h->mu);
+    std::unique_lock<std::shared_mutex> lk(h->rw);
     h->row_stride = stride;
     h->row_offset = offset;
     return LYNSE_OK;
@@ -524,8 +588,15 @@ extern "C" int lynse_hip_flat_set_row_map(lynse_hip_flat* h, uint64_t stride, ui
 
 extern "C" int lynse_hip_flat_set_ip_form(lynse_hip_flat* h, int f) {
     if (!h || f < LYNSE_IPFORM_AUTO || f > LYNSE_IPFORM_BATCH8) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "bad ip form");
-    std::lock_guard<std::mutex> lk(h->mu);
+    std::unique_lock<std::shared_mutex> lk(h->rw);
     h->ip_form = f;
+    return LYNSE_OK;
+}
+
+extern "C" int lynse_hip_flat_set_fused_search(lynse_hip_flat* h, int on) {
+    if (!h) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "handle is NULL");
+    std::unique_lock<std::shared_mutex> lk(h->rw);
+    h->no_fused = on ? 0 : 1;
     return LYNSE_OK;
 }
 
@@ -533,9 +604,10 @@ extern "C" int lynse_hip_flat_set_plan(lynse_hip_flat* h, uint32_t stage0_rows, 
     if (!h) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "handle is NULL");
     if (cap < 256 || cap > 16384 || (cap & (cap - 1))) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "cap must be a power of two in [256,16384]");
     if (stage0_rows == 0 || stage0_rows > cap || growth < 2) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "bad stage plan");
-    std::lock_guard<std::mutex> lk(h->mu);
+    std::unique_lock<std::shared_mutex> lk(h->rw);
     (void)hipSetDevice(h->device);
-    if (cap != h->cap) h->ws.release();
+    if (cap != h->cap)
+        for (auto& c : h->ctx) c.ws.release();
     h->stage0_rows = stage0_rows;
     h->growth = growth;
     h->cap = cap;
@@ -549,14 +621,14 @@ extern "C" int lynse_hip_flat_device(const lynse_hip_flat* h) { return h ? h->de
 extern "C" int lynse_hip_flat_read_rows(const lynse_hip_flat* hc, uint64_t first, uint64_t n, float* out) {
     auto* h = const_cast<lynse_hip_flat*>(hc);
     if (!h || (!out && n)) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "NULL argument");
-    std::lock_guard<std::mutex> lk(h->mu);
+    std::unique_lock<std::shared_mutex> lk(h->rw);
     LY_TRY(use_device(h));
     if (h->packed_only) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "store holds packed rows only");
     if (first + n > h->n) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "row range out of bounds");
     if (n == 0) return LYNSE_OK;
     if (h->ld == h->dim) {
-        LY_HIP(hipMemcpyAsync(out, h->rows + (size_t)first * h->ld, (size_t)n * h->dim * 4, hipMemcpyDeviceToHost, h->stream));
-        LY_HIP(hipStreamSynchronize(h->stream));
+        LY_HIP(hipMemcpyAsync(out, h->rows + (size_t)first * h->ld, (size_t)n * h->dim * 4, hipMemcpyDeviceToHost, cur(h).stream));
+        LY_HIP(hipStreamSynchronize(cur(h).stream));
         return LYNSE_OK;
     }
     const uint64_t chunk = std::max<uint64_t>(1, STAGE_BYTES / ((uint64_t)h->dim * 4));
@@ -565,9 +637,9 @@ extern "C" int lynse_hip_flat_read_rows(const lynse_hip_flat* hc, uint64_t first
     for (uint64_t r = 0; r < n; r += chunk) {
         const uint64_t nr = std::min<uint64_t>(chunk, n - r);
         int rc = copy_rows_kernel(h, stage, h->dim, h->rows + (size_t)(first + r) * h->ld, h->ld, h->dim, nr, 0);
-        if (rc == LYNSE_OK && hipMemcpyAsync(out + r * h->dim, stage, (size_t)nr * h->dim * 4, hipMemcpyDeviceToHost, h->stream) != hipSuccess)
+        if (rc == LYNSE_OK && hipMemcpyAsync(out + r * h->dim, stage, (size_t)nr * h->dim * 4, hipMemcpyDeviceToHost, cur(h).stream) != hipSuccess)
             rc = set_error(LYNSE_ERR_DEVICE, "device-to-host copy failed");
-        if (rc == LYNSE_OK && hipStreamSynchronize(h->stream) != hipSuccess) rc = set_error(LYNSE_ERR_DEVICE, "stream sync failed");
+        if (rc == LYNSE_OK && hipStreamSynchronize(cur(h).stream) != hipSuccess) rc = set_error(LYNSE_ERR_DEVICE, "stream sync failed");
         if (rc != LYNSE_OK) { (void)hipFree(stage); return rc; }
     }
     (void)hipFree(stage);
@@ -577,50 +649,53 @@ extern "C" int lynse_hip_flat_read_rows(const lynse_hip_flat* hc, uint64_t first
 extern "C" int lynse_hip_flat_copy_rows_device(const lynse_hip_flat* hc, uint64_t first, uint64_t n, float* d_out) {
     auto* h = const_cast<lynse_hip_flat*>(hc);
     if (!h || (!d_out && n)) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "NULL argument");
-    std::lock_guard<std::mutex> lk(h->mu);
+    std::unique_lock<std::shared_mutex> lk(h->rw);
     LY_TRY(use_device(h));
     if (h->packed_only) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "store holds packed rows only");
     if (first + n > h->n) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "row range out of bounds");
     if (n == 0) return LYNSE_OK;
     if (h->ld == h->dim)
-        LY_HIP(hipMemcpyAsync(d_out, h->rows + (size_t)first * h->ld, (size_t)n * h->dim * 4, hipMemcpyDeviceToDevice, h->stream));
+        LY_HIP(hipMemcpyAsync(d_out, h->rows + (size_t)first * h->ld, (size_t)n * h->dim * 4, hipMemcpyDeviceToDevice, cur(h).stream));
     else
         LY_TRY(copy_rows_kernel(h, d_out, h->dim, h->rows + (size_t)first * h->ld, h->ld, h->dim, n, 0));
-    LY_HIP(hipStreamSynchronize(h->stream));
+    LY_HIP(hipStreamSynchronize(cur(h).stream));
     return LYNSE_OK;
 }
 
 extern "C" int lynse_hip_flat_read_packed(lynse_hip_flat* h, uint64_t first, uint64_t n, uint64_t* out) {
     if (!h || (!out && n)) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "NULL argument");
-    std::lock_guard<std::mutex> lk(h->mu);
+    std::unique_lock<std::shared_mutex> lk(h->rw);
     LY_TRY(use_device(h));
     if (first + n > h->n) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "row range out of bounds");
     LY_TRY(ensure_packed_locked(h));
     if (n == 0) return LYNSE_OK;
-    LY_HIP(hipMemcpyAsync(out, h->packed + (size_t)first * h->words, (size_t)n * h->words * 8, hipMemcpyDeviceToHost, h->stream));
-    LY_HIP(hipStreamSynchronize(h->stream));
+    LY_HIP(hipMemcpyAsync(out, h->packed + (size_t)first * h->words, (size_t)n * h->words * 8, hipMemcpyDeviceToHost, cur(h).stream));
+    LY_HIP(hipStreamSynchronize(cur(h).stream));
     return LYNSE_OK;
 }
 
 // ---------------------------------------------------------------------------------- profiling ----
 extern "C" int lynse_hip_flat_profile_enable(lynse_hip_flat* h, int on) {
     if (!h) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "handle is NULL");
-    std::lock_guard<std::mutex> lk(h->mu);
+    std::unique_lock<std::shared_mutex> lk(h->rw);
     h->profiling = on != 0;
     return LYNSE_OK;
 }
 
 extern "C" int lynse_hip_flat_profile_get(lynse_hip_flat* h, lynse_hip_profile* out, int reset) {
     if (!h || !out) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "NULL argument");
-    std::lock_guard<std::mutex> lk(h->mu);
+    std::unique_lock<std::shared_mutex> lk(h->rw);
     LY_TRY(use_device(h));
-    if (h->ws.pool_total) {
+    unsigned long long pool_sum = 0;
+    for (auto& c : h->ctx) {  // every search context counts its own rescored candidates
+        if (!c.ws.pool_total) continue;
         unsigned long long pool = 0;
-        LY_HIP(hipStreamSynchronize(h->stream));
-        LY_HIP(hipMemcpy(&pool, h->ws.pool_total, 8, hipMemcpyDeviceToHost));
-        h->prof.pool_entries = pool;
-        if (reset) LY_HIP(hipMemset(h->ws.pool_total, 0, 8));
+        LY_HIP(hipStreamSynchronize(c.stream));
+        LY_HIP(hipMemcpy(&pool, c.ws.pool_total, 8, hipMemcpyDeviceToHost));
+        pool_sum += pool;
+        if (reset) LY_HIP(hipMemset(c.ws.pool_total, 0, 8));
     }
+    h->prof.pool_entries = pool_sum;
     *out = h->prof;
     if (reset) h->prof = lynse_hip_profile{};
     return LYNSE_OK;
@@ -650,7 +725,7 @@ static int set_max_lds(K kernel, size_t bytes) {
 }
 
 static int ensure_workspace(lynse_hip_flat* h, uint32_t k /* caller's k = output stride */) {
-    Workspace& w = h->ws;
+    Workspace& w = cur(h).ws;
     const uint32_t nslab = (h->dim + SCAN_BK - 1) / SCAN_BK;
     if (w.cand && w.cap == h->cap && w.D == h->dim && w.kcap >= k) return LYNSE_OK;
     w.release();
@@ -686,6 +761,9 @@ static int ensure_workspace(lynse_hip_flat* h, uint32_t k /* caller's k = output
     LY_HIP(hipHostMalloc(&w.h_out, H_OUT_BYTES, hipHostMallocDefault));
     LY_HIP(hipMalloc(&w.pool_total, 8));
     LY_HIP(hipMemset(w.pool_total, 0, 8));
+    LY_HIP(hipMalloc(&w.small_part, (size_t)SMALL_NT * SMALL_MAX_Q * SMALL_MAX_K * 8));
+    LY_HIP(hipMalloc(&w.small_ticket, 4));
+    LY_HIP(hipMemset(w.small_ticket, 0, 4));
     return LYNSE_OK;
 }
 
@@ -999,8 +1077,8 @@ static int ensure_shadow_locked(lynse_hip_flat* h) {
         _Float16* nr = nullptr;
         LY_HIP(hipMalloc(&nr, (size_t)cap * h->ld16 * sizeof(_Float16) + 256));
         if (h->rows16 && h->n16 && h->sv16 == h->sv)
-            LY_HIP(hipMemcpyAsync(nr, h->rows16, (size_t)h->n16 * h->ld16 * sizeof(_Float16), hipMemcpyDeviceToDevice, h->stream));
-        LY_HIP(hipStreamSynchronize(h->stream));
+            LY_HIP(hipMemcpyAsync(nr, h->rows16, (size_t)h->n16 * h->ld16 * sizeof(_Float16), hipMemcpyDeviceToDevice, cur(h).stream));
+        LY_HIP(hipStreamSynchronize(cur(h).stream));
         if (h->rows16) (void)hipFree(h->rows16);
         h->rows16 = nr;
         h->cap16 = cap;
@@ -1009,10 +1087,10 @@ static int ensure_shadow_locked(lynse_hip_flat* h) {
     if (h->n16 < h->n) {
         const uint64_t chunks = (h->n - h->n16) * (h->ld16 / 8);
         const uint32_t blocks = (uint32_t)std::min<uint64_t>((chunks + 255) / 256, (uint64_t)h->num_cu * 32);
-        hipLaunchKernelGGL(k_rows_to_f16, dim3(std::max<uint32_t>(blocks, 1)), dim3(256), 0, h->stream, h->rows, h->ld, h->dim,
+        hipLaunchKernelGGL(k_rows_to_f16, dim3(std::max<uint32_t>(blocks, 1)), dim3(256), 0, cur(h).stream, h->rows, h->ld, h->dim,
                            h->n16, h->n, h->sv, h->rows16, h->ld16);
         LY_HIP(hipGetLastError());
-        LY_HIP(hipStreamSynchronize(h->stream));
+        LY_HIP(hipStreamSynchronize(cur(h).stream));
     }
     h->n16 = h->n;
     h->sv16 = h->sv;
@@ -1072,12 +1150,12 @@ static int launch_scan_binary_rows(const BinArgs& a, int metric, uint32_t grid, 
 }
 
 static int get_event(lynse_hip_flat* h, size_t idx, hipEvent_t* out) {
-    while (h->ev_pool.size() <= idx) {
+    while (cur(h).ev_pool.size() <= idx) {
         hipEvent_t e;
         LY_HIP(hipEventCreate(&e));
-        h->ev_pool.push_back(e);
+        cur(h).ev_pool.push_back(e);
     }
-    *out = h->ev_pool[idx];
+    *out = cur(h).ev_pool[idx];
     return LYNSE_OK;
 }
 
@@ -1088,7 +1166,7 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
                      const uint32_t* mask = nullptr, const uint32_t* row_ids = nullptr, bool i8c = false) {
     // i8c: the coarse pass streams the SQ8 codes (1 B / element) against the symmetric int8 query image with a certified
     // error bound (k_i8c_prep_queries) instead of the f16 shadow — FLAT-IP batches of 33..256 queries
-    Workspace& w = h->ws;
+    Workspace& w = cur(h).ws;
     const bool binary = metric >= M_HAMMING;
     const bool asc = metric_ascending(metric);
     const bool h16 = scan_variant() == 3;
@@ -1338,6 +1416,52 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
     return LYNSE_OK;
 }
 
+// The fused single-launch search (k_small_search): a few queries over a shard small enough that the eight dependent
+// launches of the staged pipeline, not the bytes, are the cost.  Exact scores straight from the f32 rows.
+static bool small_path_ok(const lynse_hip_flat* h, uint64_t nq, uint32_t kk, int metric, bool filtered) {
+    static const int env = []() { const char* e = getenv("LYNSE_HIP_FUSED"); return e ? atoi(e) : 1; }();
+    static const uint64_t max_bytes = []() { const char* e = getenv("LYNSE_HIP_FUSED_MAX_MB"); return (uint64_t)(e ? atoi(e) : 64) << 20; }();
+    return env && !h->no_fused && metric <= M_COS && !filtered && h->dtype == LYNSE_DTYPE_F32 && !h->packed_only && nq <= (uint64_t)SMALL_MAX_Q &&
+           kk <= (uint32_t)SMALL_MAX_K && (uint64_t)h->n * h->ld * 4 * nq <= max_bytes &&
+           (size_t)((h->dim + 3) / 4 * 4) * 4 + (size_t)128 * 1024 + 64 <= 150u * 1024u;
+}
+
+static int run_small(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k, int metric, hipStream_t st, size_t* ev_used,
+                     std::vector<std::pair<size_t, uint64_t>>* scan_events, uint64_t* r_dst, float* d_dst, uint32_t* c_dst, uint32_t* o_dst,
+                     const float* d_q) {
+    // r_dst / d_dst / c_dst / o_dst: where the last workgroup writes rows, distances, counts and overflow flags — the
+    // caller's device buffers, or pinned host memory (device-visible): no copy kernels behind the search
+    Workspace& w = cur(h).ws;
+    SmallArgs a{};
+    a.V = h->rows; a.ld = h->ld; a.D = h->dim; a.n = (uint32_t)h->n; a.Qf = d_q; a.nq = nq; a.k = k; a.out_k = out_k; a.metric = metric;
+    int ip_form = h->ip_form;
+    if (ip_form == LYNSE_IPFORM_AUTO) ip_form = h->n < 4096 ? LYNSE_IPFORM_SINGLE : LYNSE_IPFORM_BATCH8;  // flat_mmap.rs:4852-4854
+    a.ip_form = ip_form;
+    a.row_stride = h->row_stride; a.row_offset = h->row_offset;
+    a.part = w.small_part; a.ticket = w.small_ticket;
+    a.out_rows = r_dst; a.out_dists = d_dst; a.out_counts = c_dst; a.overflow = o_dst;
+    // two workgroups per CU (16 waves: the scan is a chain of dependent load batches per wave), one merge list per workgroup:
+    // at most SMALL_NT lists and 128 KB of them in LDS
+    const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint64_t>((uint64_t)std::min(2 * h->num_cu, SMALL_NT), 16384u / std::max<uint32_t>(k, 1)), (h->n + 127) / 128));
+    const size_t lds = (size_t)((h->dim + 3) / 4 * 4) * 4 + std::max<size_t>((size_t)SMALL_NT * 8, (size_t)grid * k * 8) + 64;  // wave lists, then the merge lists
+    static bool small_attr = false;
+    if (!small_attr) { LY_TRY(set_max_lds(k_small_search, 160 * 1024 - 256)); small_attr = true; }
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (h->profiling) {
+        LY_TRY(get_event(h, (*ev_used)++, &e0));
+        LY_TRY(get_event(h, (*ev_used)++, &e1));
+        LY_HIP(hipEventRecord(e0, st));
+    }
+    hipLaunchKernelGGL(k_small_search, dim3(grid), dim3(SMALL_NT), lds, st, a);
+    LY_HIP(hipGetLastError());
+    if (h->profiling) {
+        LY_HIP(hipEventRecord(e1, st));
+        scan_events->push_back({*ev_used - 2, (uint64_t)h->n * nq});
+        h->prof.last_plan = 32u | (1u << 8);  // bit 5: fused single-launch search
+    }
+    return LYNSE_OK;
+}
+
 // ------------------------------------------------------------------------------ SQ8 two-pass ----
 // ensure_sq8 (flat_mmap.rs:375-386) + SQ8Data::from_f32_parallel (:5685-5737): (re)built over ALL rows whenever rows were
 // appended since the last build (min / max are collection-wide).
@@ -1351,8 +1475,8 @@ static int ensure_sq8_locked(lynse_hip_flat* h) {
         LY_HIP(hipMalloc(&h->sq8, (size_t)cap * h->ld8 + 256));
         LY_HIP(hipMalloc(&h->sq8_sum, ((size_t)cap + 256) * 4));
         LY_HIP(hipMalloc(&h->sq8_sum2, ((size_t)cap + 256) * 4));
-        LY_HIP(hipMemsetAsync(h->sq8_sum, 0, ((size_t)cap + 256) * 4, h->stream));
-        LY_HIP(hipMemsetAsync(h->sq8_sum2, 0, ((size_t)cap + 256) * 4, h->stream));
+        LY_HIP(hipMemsetAsync(h->sq8_sum, 0, ((size_t)cap + 256) * 4, cur(h).stream));
+        LY_HIP(hipMemsetAsync(h->sq8_sum2, 0, ((size_t)cap + 256) * 4, cur(h).stream));
         h->sq8_cap = cap;
     }
     if (!h->sq8_mins) {
@@ -1361,20 +1485,20 @@ static int ensure_sq8_locked(lynse_hip_flat* h) {
         LY_HIP(hipMalloc(&h->sq8_mm, (size_t)h->dim * 8));
         LY_HIP(hipMalloc(&h->sq8_stats, 8));
     }
-    LY_HIP(hipMemsetAsync(h->sq8_stats, 0, 8, h->stream));
+    LY_HIP(hipMemsetAsync(h->sq8_stats, 0, 8, cur(h).stream));
     std::vector<uint32_t> init((size_t)h->dim * 2);
     for (uint32_t d = 0; d < h->dim; ++d) { init[d] = f32_to_ord(INFINITY); init[h->dim + d] = f32_to_ord(-INFINITY); }
-    LY_HIP(hipMemcpyAsync(h->sq8_mm, init.data(), init.size() * 4, hipMemcpyHostToDevice, h->stream));
+    LY_HIP(hipMemcpyAsync(h->sq8_mm, init.data(), init.size() * 4, hipMemcpyHostToDevice, cur(h).stream));
     const uint32_t gx = (h->dim + 255) / 256;
     const uint32_t gy = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(h->n / 256, 1), (uint64_t)h->num_cu * 8);
-    hipLaunchKernelGGL(k_sq8_minmax, dim3(gx, gy), dim3(256), 0, h->stream, h->rows, h->ld, h->dim, h->n, h->sq8_mm, h->sq8_mm + h->dim);
-    hipLaunchKernelGGL(k_sq8_scales, dim3(gx), dim3(256), 0, h->stream, h->sq8_mm, h->sq8_mm + h->dim, h->dim, h->sq8_mins, h->sq8_scales);
-    hipLaunchKernelGGL(k_sq8_quantize, dim3((uint32_t)std::min<uint64_t>((h->n + 3) / 4, (uint64_t)h->num_cu * 16)), dim3(256), 0, h->stream,
+    hipLaunchKernelGGL(k_sq8_minmax, dim3(gx, gy), dim3(256), 0, cur(h).stream, h->rows, h->ld, h->dim, h->n, h->sq8_mm, h->sq8_mm + h->dim);
+    hipLaunchKernelGGL(k_sq8_scales, dim3(gx), dim3(256), 0, cur(h).stream, h->sq8_mm, h->sq8_mm + h->dim, h->dim, h->sq8_mins, h->sq8_scales);
+    hipLaunchKernelGGL(k_sq8_quantize, dim3((uint32_t)std::min<uint64_t>((h->n + 3) / 4, (uint64_t)h->num_cu * 16)), dim3(256), 0, cur(h).stream,
                        h->rows, h->ld, h->dim, h->n, h->sq8_mins, h->sq8_scales, h->sq8, h->ld8, h->sq8_sum, h->sq8_sum2, h->sq8_stats);
     LY_HIP(hipGetLastError());
     uint32_t qst[2] = {0, 0};
-    LY_HIP(hipMemcpyAsync(qst, h->sq8_stats, 8, hipMemcpyDeviceToHost, h->stream));
-    LY_HIP(hipStreamSynchronize(h->stream));  // `init` is a temporary
+    LY_HIP(hipMemcpyAsync(qst, h->sq8_stats, 8, hipMemcpyDeviceToHost, cur(h).stream));
+    LY_HIP(hipStreamSynchronize(cur(h).stream));  // `init` is a temporary
     h->sq8_a1 = qst[0];
     h->sq8_finite = qst[1] == 0;
     h->n_sq8 = h->n;
@@ -1383,7 +1507,7 @@ static int ensure_sq8_locked(lynse_hip_flat* h) {
 
 extern "C" int lynse_hip_flat_sq8_params(lynse_hip_flat* h, float* mins, float* scales) {
     if (!h) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "handle is NULL");
-    std::lock_guard<std::mutex> lk(h->mu);
+    std::unique_lock<std::shared_mutex> lk(h->rw);
     LY_TRY(use_device(h));
     if (h->packed_only || h->n == 0) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "no f32 rows");
     LY_TRY(finalize_locked(h));
@@ -1397,7 +1521,7 @@ extern "C" int lynse_hip_flat_sq8_params(lynse_hip_flat* h, float* mins, float* 
 // scores of the u8 codes on the i8 MFMA, exact top-n_cand in (score, row) order with the staged strict thresholds of the
 // packed-binary path; pass 2 = exact f32 rescoring of the n_cand rows, (distance, row) order, top k.
 static int run_chunk_sq8(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k, uint32_t n_cand, int metric, int level, hipStream_t st) {
-    Workspace& w = h->ws;
+    Workspace& w = cur(h).ws;
     const bool ip = metric == M_IP;
     const int m1 = ip ? M_IP : M_L2;  // cosine ranks the codes by squared L2 too (:5887-5890)
     const uint32_t nslab = (h->dim + 127) / 128, qpad = SCAN_BQ_LARGE;
@@ -1471,7 +1595,7 @@ extern "C" int lynse_hip_flat_search_sq8_f32(lynse_hip_flat* h, const float* que
     if (metric > M_COS) return lynse_hip_flat_search_f32(h, queries, nq, k, metric, out_rows, out_dists, out_counts);
     if (nq == 0) return LYNSE_OK;
     if (!queries || !out_counts || (k && (!out_rows || !out_dists))) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "NULL argument");
-    std::lock_guard<std::mutex> lk(h->mu);
+    std::unique_lock<std::shared_mutex> lk(h->rw);
     LY_TRY(use_device(h));
     if (h->packed_only) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "store holds packed rows; float metrics unavailable");
     if (h->dtype != LYNSE_DTYPE_F32) return set_error(LYNSE_ERR_UNSUPPORTED, "SQ8 mode on an F16 shard is not supported");
@@ -1484,8 +1608,8 @@ extern "C" int lynse_hip_flat_search_sq8_f32(lynse_hip_flat* h, const float* que
     if (h->n > h->cap && n_cand > h->cap / 4)
         return set_error(LYNSE_ERR_UNSUPPORTED, "SQ8 candidate count (k * 20, cosine k * 100) exceeds cap/4");
     LY_TRY(ensure_sq8_locked(h));
-    Workspace& w = h->ws;
-    hipStream_t st = h->stream;
+    Workspace& w = cur(h).ws;
+    hipStream_t st = cur(h).stream;
     for (uint64_t q0 = 0; q0 < nq; q0 += QCHUNK) {
         const uint32_t nqc = (uint32_t)std::min<uint64_t>(QCHUNK, nq - q0);
         LY_HIP(hipMemcpyAsync(w.Qf, queries + q0 * h->dim, (size_t)nqc * h->dim * 4, hipMemcpyHostToDevice, st));
@@ -1505,6 +1629,17 @@ extern "C" int lynse_hip_flat_search_sq8_f32(lynse_hip_flat* h, const float* que
     return LYNSE_OK;
 }
 
+// certified int8 coarse pass: FLAT-IP batches of 33..256 queries over an f32 shard (auto: shards of >= 64K rows;
+// LYNSE_HIP_COARSE=i8 / f16 forces / disables it); strikes: overflows so far (3 turn it off), -1 = data not finite
+static int coarse_env() {
+    static const int v = []() { const char* e = getenv("LYNSE_HIP_COARSE"); return !e ? 0 : (!strcmp(e, "i8") ? 2 : (!strcmp(e, "f16") ? 1 : 0)); }();
+    return v;
+}
+static bool i8c_eligible(const lynse_hip_flat* h, int metric, bool filtered, uint64_t nqc) {
+    return metric == M_IP && !filtered && nqc > SCAN_BQ_SMALL && h->dtype == LYNSE_DTYPE_F32 && scan_variant() == 3 && coarse_env() != 1 &&
+           h->i8c_strikes >= 0 && h->i8c_strikes < 3 && (coarse_env() == 2 || h->n >= 65536);
+}
+
 // Shared driver: q_src is nq x dim f32 (float metrics / f32 binary queries) or nq x words u64
 // (pre-packed).  Sources and destinations are host or device pointers according to `on_device`.
 static int search_impl(lynse_hip_flat* h, const void* q_src, bool packed_queries, uint64_t nq, uint32_t k,
@@ -1517,10 +1652,30 @@ static int search_impl(lynse_hip_flat* h, const void* q_src, bool packed_queries
     if (!metric_valid(metric)) return set_error(LYNSE_ERR_UNKNOWN_METRIC, "Unknown metric id");
     if (nq == 0) return LYNSE_OK;
     if (!q_src || !out_counts || (k && (!out_rows || !out_dists))) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "NULL argument");
-    std::lock_guard<std::mutex> lk(h->mu);
     LY_TRY(use_device(h));
     const bool binary = metric >= M_HAMMING;
-    hipStream_t st = user_stream ? user_stream : h->stream;
+    // Locking: an unfiltered search over a shard whose derived data (row statistics, f16 shadow, packed words, SQ8 codes of
+    // the int8 coarse pass) is up to date runs under the SHARED lock on a search context of its own; anything that has to
+    // build or borrows per-handle scratch (lazy builds, subset filters) runs EXCLUSIVE on context 0.
+    std::shared_lock<std::shared_mutex> rlk(h->rw, std::defer_lock);
+    std::unique_lock<std::shared_mutex> xlk(h->rw, std::defer_lock);
+    CtxLease lease;
+    auto derived_ready = [&]() {
+        if (binary) return h->packed_only || (h->packed != nullptr && h->n_packed == h->n);
+        if (h->packed_only) return true;  // (rejected below)
+        if (h->n_stats != h->n || (scan_variant() == 3 && (h->n16 != h->n || h->sv16 != h->sv))) return false;
+        return !i8c_eligible(h, metric, filtered, nq) || (h->sq8 && h->n_sq8 == h->n);
+    };
+    if (!filtered && !user_stream) {
+        rlk.lock();
+        if (derived_ready()) {
+            LY_TRY(lease.acquire(h));
+        } else {
+            rlk.unlock();
+        }
+    }
+    if (!rlk.owns_lock()) xlk.lock();
+    hipStream_t st = user_stream ? user_stream : cur(h).stream;
     const hipMemcpyKind in_kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
     const hipMemcpyKind out_kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
 
@@ -1549,8 +1704,8 @@ static int search_impl(lynse_hip_flat* h, const void* q_src, bool packed_queries
     if (binary) LY_TRY(ensure_packed_locked(h));
     else LY_TRY(finalize_locked(h));
     LY_TRY(ensure_workspace(h, k));
-    Workspace& w = h->ws;
-    hipStream_t st0 = user_stream ? user_stream : h->stream;
+    Workspace& w = cur(h).ws;
+    hipStream_t st0 = user_stream ? user_stream : cur(h).stream;
     bool direct = false;
     std::vector<uint64_t> sorted_subset;
     if (filtered) {
@@ -1687,18 +1842,33 @@ static int search_impl(lynse_hip_flat* h, const void* q_src, bool packed_queries
                 hipLaunchKernelGGL(k_pack_bits, dim3((nqc + 3) / 4), dim3(256), 0, st, w.Qf, h->dim, h->dim, nqc, w.QW, h->words);
                 LY_HIP(hipGetLastError());
             }
-        } else {
+        } else if (!(on_device && small_path_ok(h, nqc, kk, metric, filtered))) {  // (the fused search reads device queries in place)
             LY_HIP(hipMemcpyAsync(w.Qf, (const float*)q_src + q0 * h->dim, (size_t)nqc * h->dim * 4, in_kind, st));
         }
         // certified int8 coarse pass: FLAT-IP batches of 33..256 queries over an f32 shard with finite values (auto: shards
         // of >= 64K rows; LYNSE_HIP_COARSE=i8 / f16 forces / disables it).  An overflow first retries the f16 coarse pass;
         // three such strikes turn the int8 pass off for this handle (margins too wide for this data).
-        static const int coarse_env = []() { const char* e = getenv("LYNSE_HIP_COARSE"); return !e ? 0 : (!strcmp(e, "i8") ? 2 : (!strcmp(e, "f16") ? 1 : 0)); }();
-        bool i8c = metric == M_IP && !filtered && nqc > SCAN_BQ_SMALL && h->dtype == LYNSE_DTYPE_F32 && scan_variant() == 3 &&
-                   coarse_env != 1 && h->i8c_strikes >= 0 && h->i8c_strikes < 3 && (coarse_env == 2 || h->n >= 65536);
+        bool i8c = i8c_eligible(h, metric, filtered, nqc);
         if (i8c) {
             LY_TRY(ensure_sq8_locked(h));
             if (!h->sq8_finite) { h->i8c_strikes = -1; i8c = false; }
+        }
+        if (small_path_ok(h, nqc, kk, metric, filtered)) {
+            // fused single-launch search: the last workgroup writes straight into the caller's device buffers, or into
+            // pinned host memory (no copy kernels, one synchronisation); it cannot overflow
+            const size_t rows_b = (size_t)nqc * k * 8, dists_b = (size_t)nqc * k * 4;
+            uint64_t* r_dst = on_device ? out_rows + q0 * k : reinterpret_cast<uint64_t*>(w.h_out);
+            float* d_dst = on_device ? out_dists + q0 * k : reinterpret_cast<float*>(w.h_out + rows_b);
+            uint32_t* c_dst = on_device ? out_counts + q0 : w.h_hdr;
+            LY_TRY(run_small(h, nqc, kk, k, metric, st, &ev_used, &scan_events, r_dst, d_dst, c_dst, w.h_hdr + QCHUNK,
+                             on_device ? (const float*)q_src + q0 * h->dim : w.Qf));  // device queries are read in place
+            LY_HIP(hipStreamSynchronize(st));
+            if (!on_device) {
+                memcpy(out_rows + q0 * k, w.h_out, rows_b);
+                memcpy(out_dists + q0 * k, w.h_out + rows_b, dists_b);
+                memcpy(out_counts + q0, w.h_hdr, nqc * 4);
+            }
+            continue;
         }
         for (int level = 0; level < 3; ++level) {  // sampled plan -> contiguous plan -> exhaustive plan (make_plan)
             bool sampled = false;
@@ -1736,11 +1906,12 @@ static int search_impl(lynse_hip_flat* h, const void* q_src, bool packed_queries
         LY_HIP(hipEventSynchronize(ev_end));
         float ms = 0.f;
         LY_HIP(hipEventElapsedTime(&ms, ev_begin, ev_end));
+        std::lock_guard<std::mutex> plk(h->prof_mu);
         h->prof.total_us += (double)ms * 1000.0;
         const uint64_t row_bytes = binary ? (uint64_t)h->words * 8 : (uint64_t)h->dim * 4;
         for (auto& se : scan_events) {
             float sms = 0.f;
-            LY_HIP(hipEventElapsedTime(&sms, h->ev_pool[se.first], h->ev_pool[se.first + 1]));
+            LY_HIP(hipEventElapsedTime(&sms, cur(h).ev_pool[se.first], cur(h).ev_pool[se.first + 1]));
             h->prof.scan_us += (double)sms * 1000.0;
             h->prof.scan_launches += 1;
             h->prof.scan_rows += se.second;

@@ -33,6 +33,16 @@ def make_index(L, data):
 
 
 def check_batch(L, oracle, idx, data, queries, k, metric, ip_form=O.IPFORM_AUTO, exact_dist=True):
+    if queries.shape[0] <= 4 and k <= 64:  # small batches take the fused single-launch search: check the staged pipeline as well
+        idx.set_fused_search(False)
+        try:
+            _check_batch(L, oracle, idx, data, queries, k, metric, ip_form, exact_dist)
+        finally:
+            idx.set_fused_search(True)
+    _check_batch(L, oracle, idx, data, queries, k, metric, ip_form, exact_dist)
+
+
+def _check_batch(L, oracle, idx, data, queries, k, metric, ip_form=O.IPFORM_AUTO, exact_dist=True):
     rows, dists, counts = idx.search_batch_arrays(queries, k, NAME[metric])
     for qi in range(queries.shape[0]):
         e_ids, e_d = oracle.canonical_topk(queries[qi], data, k, metric, ip_form)
@@ -185,7 +195,7 @@ def test_float_parity_adversarial_monotone(L, oracle):
     q[1, 1] = 0.25
     idx = make_index(L, data)
     idx.profile_enable(True)
-    check_batch(L, oracle, idx, data, q, 10, IP)
+    check_batch(L, oracle, idx, data, q, 10, IP)   # (the staged pipeline is one of the two passes of check_batch)
     assert idx.profile_get()["fallback_queries"] > 0
 
 
