@@ -1642,10 +1642,14 @@ static bool i8c_eligible(const lynse_hip_flat* h, int metric, bool filtered, uin
 
 // Shared driver: q_src is nq x dim f32 (float metrics / f32 binary queries) or nq x words u64
 // (pre-packed).  Sources and destinations are host or device pointers according to `on_device`.
+static int search_large_k(lynse_hip_flat* h, const void* q_src, bool packed_queries, uint64_t nq, uint32_t k, int metric,
+                          uint64_t* out_rows, float* out_dists, uint32_t* out_counts, bool on_device, hipStream_t user_stream);
+
 static int search_impl(lynse_hip_flat* h, const void* q_src, bool packed_queries, uint64_t nq, uint32_t k,
                        int metric, uint64_t* out_rows, float* out_dists, uint32_t* out_counts,
                        bool on_device, hipStream_t user_stream, const uint64_t* subset = nullptr, uint64_t n_subset = 0,
-                       bool filtered = false, const uint64_t* bitset_words = nullptr, uint64_t n_words = 0) {
+                       bool filtered = false, const uint64_t* bitset_words = nullptr, uint64_t n_words = 0,
+                       bool caller_holds_exclusive = false) {
     // filtered: the subset is either a list of row ids (`subset`, n_subset) or BitSet words (`bitset_words`; n_subset =
     // number of set bits below len, counted by the caller)
     if (!h) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "handle is NULL");
@@ -1666,7 +1670,11 @@ static int search_impl(lynse_hip_flat* h, const void* q_src, bool packed_queries
         if (h->n_stats != h->n || (scan_variant() == 3 && (h->n16 != h->n || h->sv16 != h->sv))) return false;
         return !i8c_eligible(h, metric, filtered, nq) || (h->sq8 && h->n_sq8 == h->n);
     };
-    if (!filtered && !user_stream) {
+    // k beyond the candidate capacity of one pass (k > cap / 4 over more than cap rows; the reference accepts any k, and its
+    // server caps at MAX_TOP_K = 10,000, src/server/mod.rs:46): row ranges of `cap` rows, each answered exactly, merged
+    if (!caller_holds_exclusive && !filtered && h->n > h->cap && std::min<uint64_t>(k, h->n) > h->cap / 4)
+        return search_large_k(h, q_src, packed_queries, nq, k, metric, out_rows, out_dists, out_counts, on_device, user_stream);
+    if (!filtered && !user_stream && !caller_holds_exclusive) {
         rlk.lock();
         if (derived_ready()) {
             LY_TRY(lease.acquire(h));
@@ -1674,7 +1682,7 @@ static int search_impl(lynse_hip_flat* h, const void* q_src, bool packed_queries
             rlk.unlock();
         }
     }
-    if (!rlk.owns_lock()) xlk.lock();
+    if (!rlk.owns_lock() && !caller_holds_exclusive) xlk.lock();
     hipStream_t st = user_stream ? user_stream : cur(h).stream;
     const hipMemcpyKind in_kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
     const hipMemcpyKind out_kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
@@ -1695,7 +1703,7 @@ static int search_impl(lynse_hip_flat* h, const void* q_src, bool packed_queries
     uint32_t kk = (uint32_t)std::min<uint64_t>(k, h->n);  // k.min(n), flat_mmap.rs:836
     if (filtered) kk = (uint32_t)std::min<uint64_t>(kk, n_subset);  // k.min(subset.len()), flat_mmap.rs:501
     if (h->n > h->cap && kk > h->cap / 4)
-        return set_error(LYNSE_ERR_UNSUPPORTED, "k > cap/4 with more rows than the candidate capacity is not supported yet");
+        return set_error(LYNSE_ERR_UNSUPPORTED, "k > cap/4 over more than cap rows is not supported together with a subset filter");
     if (binary && h->words > 16u * BIN_MAX_CHUNKS)
         return set_error(LYNSE_ERR_UNSUPPORTED, "packed-binary rows wider than 4096 bits are not supported yet");
     if (binary && (size_t)QCHUNK * h->words * 8 + QCHUNK * 4 > 150 * 1024)
@@ -1919,6 +1927,100 @@ static int search_impl(lynse_hip_flat* h, const void* q_src, bool packed_queries
         }
         h->prof.searches += 1;
         h->prof.fallback_queries += fallback_queries;
+    }
+    return LYNSE_OK;
+}
+
+// Large k: the shard is cut into row ranges of `cap` rows (any k <= range size is exact there: emit-all + select), every
+// range is searched through a temporary VIEW of the handle (pointers advanced to the range, row map offset), and the sorted
+// per-range lists are merged on the host in the canonical (distance, row) order (VectorStore::merge_results semantics,
+// vector_store.rs:953-970 — the reference's own segments are merged the same way).  Exclusive: the view borrows the handle.
+static int search_large_k(lynse_hip_flat* h, const void* q_src, bool packed_queries, uint64_t nq, uint32_t k, int metric,
+                          uint64_t* out_rows, float* out_dists, uint32_t* out_counts, bool on_device, hipStream_t user_stream) {
+    std::unique_lock<std::shared_mutex> xlk(h->rw);
+    LY_TRY(use_device(h));
+    const bool binary = metric >= M_HAMMING;
+    if (packed_queries && !binary) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "packed queries need a binary metric");
+    if (!binary && h->packed_only) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "store holds packed rows; float metrics unavailable");
+    if (binary) LY_TRY(ensure_packed_locked(h));
+    else LY_TRY(finalize_locked(h));
+    const uint64_t n = h->n, R = h->cap;
+    const uint32_t kk = (uint32_t)std::min<uint64_t>(k, n);
+    const uint64_t n_ranges = (n + R - 1) / R;
+    const size_t q_elems = packed_queries ? h->words : h->dim, q_bytes = q_elems * (packed_queries ? 8 : 4);
+    // queries on the host (the per-range searches go through the host-array path)
+    std::vector<uint8_t> q_host;
+    const uint8_t* qh = reinterpret_cast<const uint8_t*>(q_src);
+    if (on_device) {
+        q_host.resize((size_t)nq * q_bytes);
+        LY_HIP(hipMemcpy(q_host.data(), q_src, q_host.size(), hipMemcpyDeviceToHost));
+        qh = q_host.data();
+    }
+    struct View {  // the scan-side fields of the handle, advanced to one row range for the duration of a call
+        lynse_hip_flat* h;
+        float* rows; _Float16* rows16; float *vn2, *vrinv; uint64_t* packed;
+        uint64_t n, n_stats, n16, n_packed, row_offset;
+        explicit View(lynse_hip_flat* hh) : h(hh), rows(hh->rows), rows16(hh->rows16), vn2(hh->vn2), vrinv(hh->vrinv), packed(hh->packed),
+                                            n(hh->n), n_stats(hh->n_stats), n16(hh->n16), n_packed(hh->n_packed), row_offset(hh->row_offset) {}
+        void set(uint64_t r0, uint64_t r1) {
+            h->rows = rows ? rows + r0 * h->ld : nullptr;
+            h->rows16 = rows16 ? rows16 + r0 * h->ld16 : nullptr;
+            h->vn2 = vn2 ? vn2 + r0 : nullptr;
+            h->vrinv = vrinv ? vrinv + r0 : nullptr;
+            h->packed = packed ? packed + r0 * h->words : nullptr;
+            h->n = r1 - r0;
+            h->n_stats = h->n; h->n16 = rows16 ? h->n : 0; h->n_packed = packed ? h->n : 0;
+            h->row_offset = row_offset + r0 * h->row_stride;
+        }
+        ~View() {
+            h->rows = rows; h->rows16 = rows16; h->vn2 = vn2; h->vrinv = vrinv; h->packed = packed;
+            h->n = n; h->n_stats = n_stats; h->n16 = n16; h->n_packed = n_packed; h->row_offset = row_offset;
+        }
+    } view(h);
+    // the IP accumulation form follows the size of the WHOLE shard (flat_mmap.rs:4852-4854), not of a range
+    struct FormGuard { lynse_hip_flat* h; int f; ~FormGuard() { h->ip_form = f; } } form_guard{h, h->ip_form};
+    if (h->ip_form == LYNSE_IPFORM_AUTO) h->ip_form = n < 4096 ? LYNSE_IPFORM_SINGLE : LYNSE_IPFORM_BATCH8;
+    const uint64_t qb = std::max<uint64_t>(1, std::min<uint64_t>(QCHUNK, (64ull << 20) / std::max<uint64_t>(1, n_ranges * kk * 12)));  // queries per pass (<= 64 MB of lists)
+    std::vector<uint64_t> l_rows((size_t)qb * n_ranges * kk), m_rows(kk);
+    std::vector<float> l_dists((size_t)qb * n_ranges * kk), m_dists(kk);
+    std::vector<uint32_t> l_counts((size_t)qb * n_ranges), r_counts(qb);
+    std::vector<uint64_t> t_rows((size_t)qb * kk);
+    std::vector<float> t_dists((size_t)qb * kk);
+    std::vector<uint64_t> o_rows(on_device ? (size_t)nq * k : 0);
+    std::vector<float> o_dists(on_device ? (size_t)nq * k : 0);
+    std::vector<uint32_t> o_counts(on_device ? nq : 0);
+    uint64_t* res_rows = on_device ? o_rows.data() : out_rows;
+    float* res_dists = on_device ? o_dists.data() : out_dists;
+    uint32_t* res_counts = on_device ? o_counts.data() : out_counts;
+    for (uint64_t q0 = 0; q0 < nq; q0 += qb) {
+        const uint64_t nb = std::min<uint64_t>(qb, nq - q0);
+        for (uint64_t ri = 0; ri < n_ranges; ++ri) {
+            const uint64_t r0 = ri * R, r1 = std::min<uint64_t>(n, r0 + R);
+            const uint32_t kr = (uint32_t)std::min<uint64_t>(kk, r1 - r0);
+            view.set(r0, r1);
+            const int rc = search_impl(h, qh + q0 * q_bytes, packed_queries, nb, kr, metric, t_rows.data(), t_dists.data(), r_counts.data(),
+                                       false, user_stream, nullptr, 0, false, nullptr, 0, true);
+            if (rc != LYNSE_OK) return rc;
+            for (uint64_t q = 0; q < nb; ++q) {  // [query][range][kk] lists for the merge
+                const uint32_t c = r_counts[q];
+                l_counts[q * n_ranges + ri] = c;
+                memcpy(&l_rows[(q * n_ranges + ri) * kk], &t_rows[q * kr], (size_t)c * 8);
+                memcpy(&l_dists[(q * n_ranges + ri) * kk], &t_dists[q * kr], (size_t)c * 4);
+            }
+        }
+        for (uint64_t q = 0; q < nb; ++q) {
+            uint32_t cnt = 0;
+            LY_TRY(lynse_hip_merge_topk(&l_rows[q * n_ranges * kk], &l_dists[q * n_ranges * kk], &l_counts[q * n_ranges], (uint32_t)n_ranges, kk, kk,
+                                        metric, m_rows.data(), m_dists.data(), &cnt));
+            memcpy(res_rows + (q0 + q) * k, m_rows.data(), (size_t)cnt * 8);
+            memcpy(res_dists + (q0 + q) * k, m_dists.data(), (size_t)cnt * 4);
+            res_counts[q0 + q] = cnt;
+        }
+    }
+    if (on_device) {
+        LY_HIP(hipMemcpy(out_rows, o_rows.data(), o_rows.size() * 8, hipMemcpyHostToDevice));
+        LY_HIP(hipMemcpy(out_dists, o_dists.data(), o_dists.size() * 4, hipMemcpyHostToDevice));
+        LY_HIP(hipMemcpy(out_counts, o_counts.data(), o_counts.size() * 4, hipMemcpyHostToDevice));
     }
     return LYNSE_OK;
 }

@@ -532,3 +532,36 @@ def test_insertion_ordered_shard_needs_no_fallback(L, oracle, metric):
         e_ids, e_d = oracle.canonical_topk(queries[qi], data, k, metric)
         assert np.array_equal(rows[qi].astype(np.uint32), e_ids)
         assert np.array_equal(dists[qi].view(np.uint32), e_d.view(np.uint32))
+
+
+@pytest.mark.parametrize("metric", [IP, L2, HAM])
+def test_large_k_up_to_the_server_cap(L, oracle, metric):
+    """k beyond the candidate capacity of one pass (k > cap / 4 over more than cap rows): the reference accepts any k
+    (k.min(n), flat_mmap.rs:836; the server caps requests at MAX_TOP_K = 10,000, src/server/mod.rs:46)."""
+    rng = np.random.default_rng(21 + metric)
+    n, dim = 50_000, 24
+    data = rng.standard_normal((n, dim)).astype(f32) if metric != HAM else (rng.random((n, 64)) < 0.5).astype(f32)
+    queries = data[rng.integers(0, n, 3)] + (0.05 if metric != HAM else 0.0)
+    queries = np.ascontiguousarray(queries, f32)
+    idx = make_index(L, data)
+    for k in (10_000, 5000):
+        rows, dists, counts = idx.search_batch_arrays(queries, k, NAME[metric])
+        for qi in range(queries.shape[0]):
+            e_ids, e_d = oracle.canonical_topk(queries[qi], data, k, metric)
+            assert int(counts[qi]) == k == len(e_ids)
+            assert np.array_equal(dists[qi].view(np.uint32), e_d.view(np.uint32)), (metric, k, qi)
+            assert np.array_equal(rows[qi].astype(np.uint32), e_ids), (metric, k, qi)
+    # device API + k > n
+    import torch
+
+    dev = torch.device("cuda", 0)
+    k = 60_000
+    dq = torch.as_tensor(queries[:1], device=dev)
+    r = torch.zeros((1, k), dtype=torch.int64, device=dev)
+    d = torch.zeros((1, k), dtype=torch.float32, device=dev)
+    c = torch.zeros(1, dtype=torch.int32, device=dev)
+    idx.search_device(dq, k, NAME[metric], r, d, c)
+    torch.cuda.synchronize()
+    assert int(c[0]) == n
+    e_ids, e_d = oracle.canonical_topk(queries[0], data, n, metric)
+    assert np.array_equal(r[0, :n].cpu().numpy().astype(np.uint32), e_ids) and np.array_equal(d[0, :n].cpu().numpy().view(np.uint32), e_d.view(np.uint32))
