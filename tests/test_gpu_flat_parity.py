@@ -565,3 +565,37 @@ def test_large_k_up_to_the_server_cap(L, oracle, metric):
     assert int(c[0]) == n
     e_ids, e_d = oracle.canonical_topk(queries[0], data, n, metric)
     assert np.array_equal(r[0, :n].cpu().numpy().astype(np.uint32), e_ids) and np.array_equal(d[0, :n].cpu().numpy().view(np.uint32), e_d.view(np.uint32))
+
+
+def test_sharded_search_entry_point_with_a_one_rank_communicator(L, oracle):
+    """The C-ABI exchange path (lynse_hip_comm_* + lynse_hip_flat_search_sharded_f32_device) on the one GPU a test box has:
+    RCCL is loaded at run time, a 1-rank communicator is created from its own unique id, the self-check sees 1 rank, and
+    the sharded entry point returns the answers of the plain search (global rows through the row map)."""
+    import torch
+
+    from lynsedb_amd.sharded import NativeComm, ShardedFlat
+
+    rng = np.random.default_rng(17)
+    n, dim, nq, k = 30_000, 64, 40, 10
+    data = rng.standard_normal((n, dim)).astype(f32)
+    queries = (data[rng.integers(0, n, nq)] + 0.05).astype(f32)
+    sh = ShardedFlat(dim, rank=0, world=1, device=0, group=None)
+    sh.index.write(data)
+    sh.index.finalize()
+    sh.comm = NativeComm(None, 0, 1, 0)
+    assert sh.comm.ranks_seen() == 1
+    dev = torch.device("cuda", 0)
+    out = sh.alloc_outputs(nq, k)
+    dq = torch.as_tensor(queries, device=dev)
+    for name, metric in (("ip", IP), ("l2", L2)):
+        m = L.metric_from_str(name)
+        import ctypes as C
+        L._lib.check(L._lib.lib.lynse_hip_flat_search_sharded_f32_device(
+            sh.index.handle, sh.comm.handle, C.c_void_p(dq.data_ptr()), nq, k, m, C.c_void_p(out.rows.data_ptr()),
+            C.c_void_p(out.dists.data_ptr()), C.c_void_p(out.counts.data_ptr())))
+        torch.cuda.synchronize()
+        rows = out.rows.cpu().numpy().view(np.uint64)
+        dists = out.dists.cpu().numpy()
+        for qi in (0, 7, nq - 1):
+            e_ids, e_d = oracle.canonical_topk(queries[qi], data, k, metric)
+            assert np.array_equal(rows[qi].astype(np.uint32), e_ids) and np.array_equal(dists[qi].view(np.uint32), e_d.view(np.uint32))
