@@ -70,6 +70,11 @@ def gen_block(block: int, rows_in_block: int, dim: int, seed: int, device) -> to
 
 def main():
     args = parse_args()
+    # ONE JSON line on stdout: everything else that writes to fd 1 during the run (RCCL prints a version / host banner when
+    # its first communicator is created) goes to stderr instead; the result line is written to the saved descriptor.
+    sys.stdout.flush()
+    result_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -250,7 +255,8 @@ def main():
             result["verify"] = verify
         if not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(args, N, D, K, metric)
-        print(json.dumps(result), flush=True)
+        result_out.write(json.dumps(result) + "\n")
+        result_out.flush()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
