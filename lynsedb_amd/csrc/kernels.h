@@ -2286,6 +2286,7 @@ struct SelectArgs {
     int keep_ties;   // IVF: rows are not scanned in id order -> the cut must let ties of the k-th score through
     int drop_sentinels;  // filtered search: the emit-all stage wrote KEY_SENTINEL for rows outside the subset
     int threshold_only;  // lane-max sample stage: derive the threshold, keep NO candidate (the rows are scanned again)
+    int tighten;         // float coarse passes: threshold from the exact rescoring of the >= k best coarse rows (tau_x -/+ E)
     // segmented emission of the scan stage that ran before this select (ScanArgs::candB / segcnt): nseg segments of
     // `seg` slots per query, segcnt[q][s] keys in segment s.  nseg == 0: none.
     const uint64_t* candB;
@@ -2440,6 +2441,48 @@ __global__ void __launch_bounds__(NT) k_select(SelectArgs a) {
     const uint64_t kth = a.exact ? s_prefix : (s_prefix | 0xffffffffull);  // float: every row of the k-th score counts as <= kth
     const float tau = key_score(kth, asc);
 
+    // ---- exact-rescored threshold (float coarse passes).  The cut tau -/+ 2E brackets the exact k-th best through the
+    // COARSE k-th score tau: one E for the rows that realise tau, one for the row being tested.  Rescoring the >= k best
+    // coarse rows exactly (a few dozen f32 rows per query) gives tau_x = the k-th best EXACT score among them — a valid lower
+    // bound of the shard's exact k-th best whatever rows were picked — and every row that can still matter has a coarse
+    // score within ONE E of it.  tau_x -/+ E is never looser than tau -/+ 2E (the k best coarse rows have exact scores
+    // >= tau - E) and typically one E tighter: with the wide int8 margins that is ~5x fewer keys emitted, kept and
+    // rescored in every later stage.
+    float cut_exact = asc ? LY_INF : -LY_INF;   // tau_x -/+ E; unused when not tightened
+    bool tightened = false;
+    if (!a.exact && a.tighten && a.k <= 128u) {
+        __shared__ uint64_t xs[256];
+        __shared__ uint32_t s_x;
+        const uint32_t mx = a.k * 2u < 256u ? a.k * 2u : 256u;
+        if (tid == 0) s_x = 0;
+        __syncthreads();
+        for (uint32_t i = tid; i < n; i += NT) {
+            const uint64_t key = keys[i];
+            if (key <= kth) {
+                const uint32_t slot = atomicAdd(&s_x, 1u);
+                if (slot < mx) xs[slot] = key;
+            }
+        }
+        __syncthreads();
+        const uint32_t m = s_x < mx ? s_x : mx;   // >= k: at least k keys are <= the k-th smallest
+        if (m >= a.k) {
+            rescore_keys<NT>(xs, m, a.metric, a.ip_form, a.Qf + (size_t)q * a.D, a.V, a.ld, a.D, asc, tid);
+            for (uint32_t i = m + tid; i < 256u; i += NT) xs[i] = KEY_SENTINEL;
+            bitonic_sort_lds<NT>(xs, 256u, tid);
+            __syncthreads();
+            const float tau_x = key_score(xs[a.k - 1], asc);
+            const float e1 = 0.5f * a.marg2[q];
+            cut_exact = asc ? tau_x + e1 : tau_x - e1;
+            tightened = tau_x == tau_x;  // (NaN scores: keep the coarse rule)
+        }
+        __syncthreads();
+    }
+    auto cut_of = [&](float t, float m2) -> float {   // the tighter of the coarse rule and the exact-rescored rule
+        const float c = asc ? t + m2 : t - m2;
+        if (!tightened) return c;
+        return asc ? (cut_exact < c ? cut_exact : c) : (cut_exact > c ? cut_exact : c);
+    };
+
     float thr_new;
     uint32_t keep;
     bool sorted_path = false;
@@ -2447,7 +2490,7 @@ __global__ void __launch_bounds__(NT) k_select(SelectArgs a) {
         if (tid == 0) {
             a.count[q] = 0u;
             const float m2 = a.exact ? 0.0f : a.marg2[q];
-            a.thr[q] = asc ? tau + m2 : tau - m2;
+            a.thr[q] = cut_of(tau, m2);
         }
         return;
     }
@@ -2459,7 +2502,7 @@ __global__ void __launch_bounds__(NT) k_select(SelectArgs a) {
         keep = a.k;
     } else {
         const float m2 = a.marg2[q];
-        thr_new = asc ? tau + m2 : tau - m2;
+        thr_new = cut_of(tau, m2);
         uint32_t local = 0;
         for (uint32_t i = tid; i < n; i += NT) {
             const float sc = key_score(keys[i], asc);

@@ -1382,6 +1382,9 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
         sa.cand = w.cand; sa.count = w.count; sa.overflow = w.overflow; sa.thr = w.thr; sa.marg2 = w.marg2;
         sa.k = k; sa.cap = w.cap; sa.keep_max = w.cap / 2; sa.metric = metric; sa.ip_form = ip_form;
         sa.exact = binary ? 1 : 0;
+        static const int tighten_env = []() { const char* e = getenv("LYNSE_HIP_TIGHTEN"); return e ? atoi(e) : 1; }();
+        // (worth its ~k exact rescorings per query and stage where the margin is wide — the int8 pass — or k is small)
+        sa.tighten = (!binary && tighten_env && (i8c || k <= 32)) ? 1 : 0;
         sa.drop_sentinels = (mask && emit_all) ? 1 : 0;
         sa.emit_all_n = emit_all ? (s.sample_tiles ? (int)(s.sample_tiles * plan_tile) : (int)(s.r1 - s.r0)) : -1;
         if (!binary && emit_all && sample_threshold_only) {
