@@ -2747,6 +2747,8 @@ struct FinalArgs {
     uint64_t* out_rows;
     float* out_dists;
     uint32_t* out_counts;
+    uint32_t* out_counts2;   // optional second destination of the counts (the caller's device array; the first one sits next to
+                             // the overflow flags and comes back in the pinned header)
     unsigned long long* pool_total;
 };
 
@@ -2801,6 +2803,7 @@ __global__ void __launch_bounds__(NT) k_final(FinalArgs a) {
     }
     if (tid == 0) {
         a.out_counts[q] = cnt;
+        if (a.out_counts2) a.out_counts2[q] = cnt;
         if (a.pool_total) atomicAdd(a.pool_total, (unsigned long long)n);
     }
 }

@@ -1163,7 +1163,10 @@ static int get_event(lynse_hip_flat* h, size_t idx, hipEvent_t* out) {
 // QW for binary).  Results land in ws.out_*.  `level` selects the stage plan (make_plan).
 static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k, int metric, int level, hipStream_t st,
                      size_t* ev_used, std::vector<std::pair<size_t, uint64_t>>* scan_events, bool* sampled_plan,
-                     const uint32_t* mask = nullptr, const uint32_t* row_ids = nullptr, bool i8c = false) {
+                     const uint32_t* mask = nullptr, const uint32_t* row_ids = nullptr, bool i8c = false,
+                     uint64_t* r_dst = nullptr, float* d_dst = nullptr, uint32_t* c2_dst = nullptr) {
+    // r_dst / d_dst / c2_dst: where k_final writes rows, distances (stride out_k) and a second copy of the counts — the
+    // caller's device arrays or the pinned staging buffer; nullptr = the workspace (copied out by the caller)
     // i8c: the coarse pass streams the SQ8 codes (1 B / element) against the symmetric int8 query image with a certified
     // error bound (k_i8c_prep_queries) instead of the f16 shadow — FLAT-IP batches of 33..256 queries
     Workspace& w = cur(h).ws;
@@ -1406,7 +1409,8 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
     fa.cand = w.cand; fa.count = w.count; fa.k = k; fa.out_k = out_k; fa.cap = w.cap; fa.metric = metric; fa.ip_form = ip_form;
     fa.exact = binary ? 1 : 0; fa.Qf = w.Qf; fa.V = h->rows; fa.ld = h->ld; fa.D = h->dim;
     fa.row_stride = h->row_stride; fa.row_offset = h->row_offset;
-    fa.out_rows = w.out_rows; fa.out_dists = w.out_dists; fa.out_counts = w.out_counts;
+    fa.out_rows = r_dst ? r_dst : w.out_rows; fa.out_dists = d_dst ? d_dst : w.out_dists; fa.out_counts = w.out_counts;
+    fa.out_counts2 = c2_dst;
     fa.pool_total = h->profiling ? w.pool_total : nullptr;
     if (i8c) {  // a few hundred survivors per query inside the int8 margin: spread their exact rescoring over the chip
         hipLaunchKernelGGL(k_rescore_pool<256>, dim3(nq, 4), dim3(256), 0, st, fa);
@@ -1883,14 +1887,20 @@ static int search_impl(lynse_hip_flat* h, const void* q_src, bool packed_queries
         }
         for (int level = 0; level < 3; ++level) {  // sampled plan -> contiguous plan -> exhaustive plan (make_plan)
             bool sampled = false;
-            LY_TRY(run_chunk(h, nqc, kk, k, metric, level, st, &ev_used, &scan_events, &sampled, mask, direct ? h->g_ids32 : nullptr, i8c));
-            // outputs are copied speculatively with the overflow flags — one synchronisation per chunk; a retry on the
-            // next plan level overwrites them in stream order.  Workspace rows are [nqc][kk]; caller layout is [nq][k]
+            // k_final writes the results where they belong — the caller's device arrays, or the pinned (device-visible)
+            // staging buffer for small host-API results: no copy kernels behind the search; only large host results go
+            // through the workspace + two device-to-host copies.  One synchronisation per chunk (counts + overflow flags in
+            // one small pinned readback); a retry on the next plan level overwrites the outputs in stream order.
             const size_t rows_b = (size_t)nqc * k * 8, dists_b = (size_t)nqc * k * 4;
             const bool staged = !on_device && rows_b + dists_b <= H_OUT_BYTES;
-            LY_HIP(hipMemcpyAsync(staged ? (void*)w.h_out : (void*)(out_rows + q0 * k), w.out_rows, rows_b, out_kind, st));
-            LY_HIP(hipMemcpyAsync(staged ? (void*)(w.h_out + rows_b) : (void*)(out_dists + q0 * k), w.out_dists, dists_b, out_kind, st));
-            if (on_device) LY_HIP(hipMemcpyAsync(out_counts + q0, w.out_counts, nqc * 4, out_kind, st));
+            uint64_t* r_dst = on_device ? out_rows + q0 * k : (staged ? reinterpret_cast<uint64_t*>(w.h_out) : nullptr);
+            float* d_dst = on_device ? out_dists + q0 * k : (staged ? reinterpret_cast<float*>(w.h_out + rows_b) : nullptr);
+            LY_TRY(run_chunk(h, nqc, kk, k, metric, level, st, &ev_used, &scan_events, &sampled, mask, direct ? h->g_ids32 : nullptr, i8c,
+                             r_dst, d_dst, on_device ? out_counts + q0 : nullptr));
+            if (!on_device && !staged) {
+                LY_HIP(hipMemcpyAsync(out_rows + q0 * k, w.out_rows, rows_b, out_kind, st));
+                LY_HIP(hipMemcpyAsync(out_dists + q0 * k, w.out_dists, dists_b, out_kind, st));
+            }
             LY_HIP(hipMemcpyAsync(w.h_hdr, w.out_counts, 2 * QCHUNK * 4, hipMemcpyDeviceToHost, st));  // counts + overflow flags
             LY_HIP(hipStreamSynchronize(st));
             uint32_t nov = 0;
