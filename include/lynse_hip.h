@@ -268,6 +268,19 @@ int lynse_hip_ivf_set_routing(lynse_hip_ivf *h, int ivfflat_routing);
 int lynse_hip_ivf_search_f32(lynse_hip_ivf *h, const float *queries, uint64_t nq, uint32_t k,
                              uint32_t nprobe, uint64_t *out_rows, float *out_dists,
                              uint32_t *out_counts);
+/* Device-resident twins (float metrics): rows / queries / outputs already in HBM.  IvfFlatMmap::build reads its rows from an
+ * mmapped store (src/storage/ivf_flat_mmap.rs:56-159); here k-means, the slab reordering (a gather inside HBM) and the
+ * search never stage row data or candidates through host memory — one GPU's share of BASELINE config 4 is 19 GB.
+ * Centroids and assignments (lynse_hip_ivf_load_device) are host arrays, as in lynse_hip_ivf_load. */
+int lynse_hip_ivf_build_device(const float *d_rows, uint64_t n, uint32_t dim, uint32_t nlist,
+                               uint32_t max_iter, int metric, int l2_partitions, int device,
+                               lynse_hip_ivf **out);
+int lynse_hip_ivf_load_device(const float *d_rows, uint64_t n, uint32_t dim, const float *centroids,
+                              uint32_t nlist, const uint32_t *assignments, int metric, int device,
+                              lynse_hip_ivf **out);
+int lynse_hip_ivf_search_f32_device(lynse_hip_ivf *h, const float *d_queries, uint64_t nq, uint32_t k,
+                                    uint32_t nprobe, uint64_t *d_out_rows, float *d_out_dists,
+                                    uint32_t *d_out_counts);
 /* IvfFlatMmap::search(query, k, nprobe, metric) (src/storage/ivf_flat_mmap.rs:225-305; PyIvfFlatIndex.search,
  * src/python/mod.rs:2130-2155): the metric of the CALL drives centroid routing, scoring and the sort direction (the
  * partitions are metric-agnostic).  Float indexes take ip / l2 / cosine; a binary index only its build metric. */

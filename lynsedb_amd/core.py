@@ -345,6 +345,43 @@ class IvfFlatIndex:
         return IvfFlatIndex(h, dim)
 
     @staticmethod
+    def build_device(d_rows, dim: int, n_partitions: int = 256, n_iters: int = 20, metric: str = "ip",
+                     l2_partitions: bool = True) -> "IvfFlatIndex":
+        """`build` over rows already resident in HBM (a contiguous float32 torch tensor on the target device): k-means, slab
+        reordering and the store never stage row data through host memory.  Float metrics."""
+        m = metric if isinstance(metric, int) else metric_from_str(metric)
+        if d_rows.dim() != 2 or d_rows.shape[1] != dim or not d_rows.is_contiguous():
+            raise ValueError("rows must be a contiguous (n, dim) float32 device tensor")
+        _sync_producer(d_rows)
+        h = C.c_void_p()
+        check(lib.lynse_hip_ivf_build_device(C.c_void_p(d_rows.data_ptr()), d_rows.shape[0], dim, n_partitions, n_iters, m,
+                                             1 if l2_partitions else 0, d_rows.device.index or 0, C.byref(h)))
+        return IvfFlatIndex(h, dim)
+
+    @staticmethod
+    def load_device(d_rows, centroids, assignments, metric: str = "ip", ivfflat_routing: bool = False) -> "IvfFlatIndex":
+        """`load` with the rows in HBM; centroids / assignments are host arrays."""
+        m = metric if isinstance(metric, int) else metric_from_str(metric)
+        c = _f32(centroids, 2, "centroids")
+        asg = np.ascontiguousarray(assignments, dtype=np.uint32)
+        _sync_producer(d_rows)
+        h = C.c_void_p()
+        check(lib.lynse_hip_ivf_load_device(C.c_void_p(d_rows.data_ptr()), d_rows.shape[0], d_rows.shape[1], _ptr(c), c.shape[0], _ptr(asg), m,
+                                            d_rows.device.index or 0, C.byref(h)))
+        idx = IvfFlatIndex(h, d_rows.shape[1])
+        if ivfflat_routing:
+            check(lib.lynse_hip_ivf_set_routing(h, 1))
+        return idx
+
+    def search_device(self, d_queries, k: int, nprobe: int, d_rows, d_dists, d_counts) -> None:
+        """Queries and outputs are torch tensors on the index's device (rows i64[nq,k] holding u64 bits, dists f32[nq,k],
+        counts i32[nq])."""
+        _sync_producer(d_queries)
+        check(lib.lynse_hip_ivf_search_f32_device(self._h, C.c_void_p(d_queries.data_ptr()), d_queries.shape[0], int(k), int(nprobe),
+                                                  C.c_void_p(d_rows.data_ptr()), C.c_void_p(d_dists.data_ptr()),
+                                                  C.c_void_p(d_counts.data_ptr())))
+
+    @staticmethod
     def load(data, centroids, assignments, metric: str = "ip", device: Optional[int] = None,
              ivfflat_routing: bool = False, thresholds=None) -> "IvfFlatIndex":
         """Assemble from given centroids + assignments (parity tests feed the oracle's k-means output).

@@ -324,4 +324,21 @@ __global__ void __launch_bounds__(256) k_scan_binary_tiled(BinTileArgs a) {
     }
 }
 
+
+// Rows gathered by index inside HBM (device-resident IVF build / load: slab reordering of IvfFlatMmap::build,
+// ivf_flat_mmap.rs:115-130, and the k-means init sample): dst[i] = src[ids[i]], `width` floats of a row, pad columns zero.
+__global__ void __launch_bounds__(256) k_gather_rows_f32(const float* __restrict__ src, uint32_t src_ld, const uint32_t* __restrict__ ids,
+                                                         uint64_t m, float* __restrict__ dst, uint32_t dst_ld, uint32_t width) {
+    const uint32_t per_row = (dst_ld + 3) / 4;  // float4 pieces of a destination row
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < m * per_row; i += (uint64_t)gridDim.x * 256) {
+        const uint64_t r = i / per_row;
+        const uint32_t c0 = (uint32_t)(i % per_row) * 4;
+        const float* s = src + (size_t)ids[r] * src_ld;
+        float* d = dst + (size_t)r * dst_ld;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (c0 + e < dst_ld) d[c0 + e] = (c0 + e < width) ? s[c0 + e] : 0.0f;
+    }
+}
+
 }  // namespace lynse

@@ -364,6 +364,40 @@ class ShardedIvf:
             check(lib.lynse_hip_ivf_set_routing(self.index._h, 2))
         self.metric = metric
 
+    def load_local_device(self, d_local_rows, centroids: np.ndarray, local_assignments: np.ndarray, metric: str,
+                          ivfflat_routing: bool = False) -> None:
+        """`load_local` with this rank's rows already in HBM (a torch tensor on the rank's device): nothing of the shard is
+        staged through host memory."""
+        from .core import IvfFlatIndex
+
+        self.index = IvfFlatIndex.load_device(d_local_rows, centroids, local_assignments, metric, ivfflat_routing=ivfflat_routing)
+        check(lib.lynse_hip_ivf_set_row_map(self.index._h, self.world, self.rank))
+        if self.world > 1:
+            check(lib.lynse_hip_ivf_set_routing(self.index._h, 2))
+        self.metric = metric
+
+    def search_device(self, d_queries, k: int, nprobe: int, out: "ShardOutputs") -> None:
+        """Whole-collection answer with queries, per-rank blocks and results in HBM: local scan of the probed lists straight
+        into the rank's result block, one all-gather, device k-way merge — no numpy on the data path."""
+        import torch
+
+        from .core import metric_from_str
+
+        nq = d_queries.shape[0]
+        m = metric_from_str(self.metric)
+        if self.world == 1:
+            self.index.search_device(d_queries, k, nprobe, out.rows, out.dists, out.counts)
+            return
+        pr, pd, pc = out.local_ptrs()
+        torch.cuda.current_stream().synchronize()
+        check(lib.lynse_hip_ivf_search_f32_device(self.index._h, C.c_void_p(d_queries.data_ptr()), nq, k, int(nprobe),
+                                                  C.c_void_p(pr), C.c_void_p(pd), C.c_void_p(pc)))
+        self.dist.all_gather_into_tensor(out.gathered, out.local)
+        check(lib.lynse_hip_merge_topk_device(C.c_void_p(out.gathered.data_ptr()), out.block_bytes, out.rows_off, out.dists_off,
+                                              out.counts_off, self.world, nq, k, m, C.c_void_p(out.rows.data_ptr()),
+                                              C.c_void_p(out.dists.data_ptr()), C.c_void_p(out.counts.data_ptr()),
+                                              C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+
     def search_local(self, queries: np.ndarray, k: int, nprobe: int):
         """This rank's candidates: global row ids (local row l -> l * world + rank), canonical order."""
         return self.index.search_batch_arrays(queries, k, nprobe)

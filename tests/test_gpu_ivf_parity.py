@@ -315,3 +315,41 @@ def test_row_sharded_ivf_equals_single_index(L, oracle, metric, world):
         ids, d = L.merge_topk(cand_r, cand_d, cnt, k, metric)
         e_ids, e_d, _ = oracle.ivf_search(queries[qi], data, cen, off, rows, nprobe, k, metric)
         assert np.array_equal(ids, e_ids) and np.array_equal(d.view(np.uint32), e_d.view(np.uint32))
+
+
+def test_device_resident_ivf_build_load_search(L, oracle):
+    """The `_device` twins (rows, queries and outputs in HBM): same centroids / assignments / results as the host-array
+    entry points (IvfFlatMmap::build reads an mmapped store, ivf_flat_mmap.rs:56-159; here device memory)."""
+    import torch
+
+    rng = np.random.default_rng(5)
+    n, dim, nlist, nprobe, k, nq = 20_000, 48, 32, 6, 10, 40
+    centers = rng.standard_normal((16, dim)).astype(f32)
+    data = (centers[rng.integers(0, 16, n)] + 0.3 * rng.standard_normal((n, dim))).astype(f32)
+    queries = (data[rng.integers(0, n, nq)] + 0.05 * rng.standard_normal((nq, dim))).astype(f32)
+    dev = torch.device("cuda", 0)
+    d_rows = torch.as_tensor(data, device=dev)
+    d_q = torch.as_tensor(queries, device=dev)
+    for metric in (IP, L2):
+        host = L.IvfFlatIndex.build(None, data, dim, nlist, 5, NAME[metric], l2_partitions=False)
+        devi = L.IvfFlatIndex.build_device(d_rows, dim, nlist, 5, NAME[metric], l2_partitions=False)
+        h_cen, h_asg, h_off, h_orig = host.export()
+        d_cen, d_asg, d_off, d_orig = devi.export()
+        assert np.array_equal(h_asg, d_asg) and np.array_equal(h_cen.view(np.uint32), d_cen.view(np.uint32))
+        assert np.array_equal(h_off, d_off) and np.array_equal(h_orig, d_orig)
+        loaded = L.IvfFlatIndex.load_device(d_rows, d_cen, d_asg, NAME[metric])
+        off, rows_l = oracle.lists_from_assignments(d_asg, d_cen.shape[0])
+        r = torch.zeros((nq, k), dtype=torch.int64, device=dev)
+        d = torch.zeros((nq, k), dtype=torch.float32, device=dev)
+        c = torch.zeros(nq, dtype=torch.int32, device=dev)
+        for idx in (devi, loaded):
+            idx.search_device(d_q, k, nprobe, r, d, c)
+            torch.cuda.synchronize()
+            g_rows, g_d, g_c = r.cpu().numpy().view(np.uint64), d.cpu().numpy(), c.cpu().numpy()
+            for qi in (0, 7, 33, nq - 1):
+                e_ids, e_d, _ = oracle.ivf_search(queries[qi], data, d_cen, off, rows_l, nprobe, k, metric)
+                cnt = int(g_c[qi])
+                assert cnt == len(e_ids)
+                assert np.array_equal(g_d[qi, :cnt].view(np.uint32), e_d.view(np.uint32)) and np.array_equal(g_rows[qi, :cnt], e_ids)
+    with pytest.raises(NotImplementedError):
+        L.IvfFlatIndex.build_device(d_rows, dim, nlist, 5, "hamming", l2_partitions=False)
