@@ -2090,15 +2090,33 @@ extern "C" int lynse_hip_top_k_search(const float* query, const float* candidate
     if (dim == 0) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "dimension must be greater than zero");
     if (n == 0 || k == 0) return LYNSE_OK;
     if (!query || !candidates || !out_idx || !out_dist) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "NULL argument");
-    lynse_hip_flat* h = nullptr;
-    LY_TRY(lynse_hip_flat_create(dim, device, &h));
+    // A scratch shard per calling thread and (device, dim), emptied and refilled per call: py_top_k_search / py_compute_distance /
+    // Collection::pending_search call this in loops, and a handle (stream, stats buffers, workspace) is not free to create.
+    struct Scratch {
+        lynse_hip_flat* h = nullptr; int device = -1; uint32_t dim = 0;
+        ~Scratch() { if (h) lynse_hip_flat_destroy(h); }
+    };
+    static thread_local Scratch sc;
+    if (!sc.h || sc.device != device || sc.dim != dim) {
+        if (sc.h) { lynse_hip_flat_destroy(sc.h); sc.h = nullptr; }
+        LY_TRY(lynse_hip_flat_create(dim, device, &sc.h));
+        sc.device = device; sc.dim = dim;
+        LY_TRY(lynse_hip_flat_set_ip_form(sc.h, LYNSE_IPFORM_SINGLE));
+    }
+    lynse_hip_flat* h = sc.h;
+    {   // empty the shard (capacity and buffers stay)
+        std::unique_lock<std::shared_mutex> lk(h->rw);
+        h->n = 0; h->n_stats = 0; h->n16 = 0; h->n_packed = 0; h->n_sq8 = 0; h->i8c_strikes = 0;
+        h->amax = h->vmax = h->vmin = 0.f; h->sv = 1.f; h->cos_degenerate = 0;
+        const uint32_t init[4] = {0u, 0u, 0x7f800000u, 0u};
+        LY_TRY(use_device(h));
+        LY_HIP(hipMemcpy(h->d_stats, init, sizeof init, hipMemcpyHostToDevice));
+    }
     int rc = lynse_hip_flat_append_f32(h, candidates, n);
-    if (rc == LYNSE_OK) rc = lynse_hip_flat_set_ip_form(h, LYNSE_IPFORM_SINGLE);
     const uint32_t kk = (uint32_t)std::min<uint64_t>(k, n);
     std::vector<uint64_t> rows(kk);
     uint32_t cnt = 0;
     if (rc == LYNSE_OK) rc = lynse_hip_flat_search_f32(h, query, 1, kk, metric, rows.data(), out_dist, &cnt);
-    lynse_hip_flat_destroy(h);
     if (rc != LYNSE_OK) return rc;
     for (uint32_t i = 0; i < cnt; ++i) out_idx[i] = (uint32_t)rows[i];
     *out_count = cnt;
