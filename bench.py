@@ -259,6 +259,12 @@ def main():
         result_out.flush()
     if dist is not None:
         dist.barrier()
+        if sh.comm is not None:   # the library's communicator goes first, while every rank is still alive
+            try:
+                sh.comm.close()
+            except Exception:  # noqa: BLE001
+                pass
+            sh.comm = None
         dist.destroy_process_group()
 
 

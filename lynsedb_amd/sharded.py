@@ -60,16 +60,34 @@ class NativeComm:
 
         self._c = C.c_void_p()
         rccl = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")  # ONE RCCL per process: torch's copy
-        check(lib.lynse_hip_comm_load_rccl(rccl.encode() if os.path.exists(rccl) else None))
-        uid = np.zeros(128, np.uint8)
-        if rank == 0:
-            check(lib.lynse_hip_comm_unique_id(uid.ctypes.data_as(C.c_void_p)))
+        # step 1 (local, may fail): load RCCL; rank 0 draws the unique id.  step 2 (collective, always runs): broadcast
+        # [ok flag | 128-byte id] so that a failure on rank 0 cannot leave the other ranks waiting.  step 3: every rank creates
+        # its communicator (ncclCommInitRank is itself a collective).
+        msg = np.zeros(129, np.uint8)
+        err = None
+        try:
+            check(lib.lynse_hip_comm_load_rccl(rccl.encode() if os.path.exists(rccl) else None))
+            if rank == 0:
+                check(lib.lynse_hip_comm_unique_id(msg[1:].ctypes.data_as(C.c_void_p)))
+            msg[0] = 1
+        except Exception as e:  # noqa: BLE001
+            err = e
         if world > 1:
             backend = dist.get_backend()
-            t = torch.from_numpy(uid)
+            t = torch.from_numpy(msg.copy())
             t = t.to(torch.device("cuda", device)) if backend == "nccl" else t
-            dist.broadcast(t, src=0)
-            uid = t.cpu().numpy()
+            dist.broadcast(t, src=0)                      # rank 0's flag + id
+            got = t.cpu().numpy()
+            ok = torch.tensor([1 if (err is None and int(got[0]) == 1) else 0], dtype=torch.int32)
+            ok = ok.to(torch.device("cuda", device)) if backend == "nccl" else ok
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)     # every rank loaded RCCL and rank 0 has an id
+            if int(ok.item()) == 0:
+                raise RuntimeError(f"RCCL bootstrap failed on some rank ({err!r})")
+            uid = np.ascontiguousarray(got[1:])
+        else:
+            if err is not None:
+                raise err
+            uid = np.ascontiguousarray(msg[1:])
         check(lib.lynse_hip_comm_create(uid.ctypes.data_as(C.c_void_p), rank, world, device, C.byref(self._c)))
         self.rank, self.world, self.device = rank, world, device
 
@@ -82,10 +100,13 @@ class NativeComm:
     def handle(self):
         return self._c
 
-    def __del__(self):
+    def close(self) -> None:
         c, self._c = getattr(self, "_c", None), None
         if c:
             lib.lynse_hip_comm_destroy(c)
+
+    def __del__(self):
+        self.close()
 
 
 def block_layout(nq: int, k: int):
