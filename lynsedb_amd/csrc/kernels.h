@@ -2672,26 +2672,26 @@ __global__ void __launch_bounds__(SMALL_NT) k_small_search(SmallArgs a) {
             if (mine != KEY_SENTINEL) {  // (only lanes < k of every wave hold keys: NWAVE x k comparisons)
                 for (int w = 0; w < NWAVE; ++w)
                     for (uint32_t j = 0; j < k; ++j) rank += (wl[w * 64 + j] < mine) ? 1u : 0u;
-                if (rank < k) a.part[((size_t)blockIdx.x * a.nq + q) * k + rank] = mine;
+                // 8-byte agent-scope atomics on both sides of the hand-off (write-through stores, L2-served loads): no cache
+                // write-back / invalidate fences around the ticket (cdna_hip_programming.md G16, 'valid forms')
+                if (rank < k) __hip_atomic_store(&a.part[((size_t)blockIdx.x * a.nq + q) * k + rank], mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             // slots past the number of real keys hold the sentinel
             uint32_t real = 0;
             if (tid < (int)k) {
                 for (int w = 0; w < NWAVE; ++w)
                     for (uint32_t j = 0; j < k; ++j) real += wl[w * 64 + j] != KEY_SENTINEL ? 1u : 0u;
-                if ((uint32_t)tid >= real) a.part[((size_t)blockIdx.x * a.nq + q) * k + tid] = KEY_SENTINEL;
+                if ((uint32_t)tid >= real) __hip_atomic_store(&a.part[((size_t)blockIdx.x * a.nq + q) * k + tid], KEY_SENTINEL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
     }
-    // ---- the last workgroup to arrive merges the per-workgroup lists: plain stores -> barrier -> ONE agent-scope release
-    // -> ticket; the last arriver: ONE agent-scope acquire -> barrier -> loads (cdna_hip_programming.md, Guideline 16)
+    // ---- the last workgroup to arrive merges the per-workgroup lists: agent-scope atomic stores of the keys -> every wave
+    // drains its stores -> barrier -> ticket; the last arriver reads the lists with agent-scope atomic loads
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the write-back must not be overtaken by the ticket
         const uint32_t t = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         s_last = (t == gridDim.x - 1) ? 1u : 0u;
-        if (s_last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
     __syncthreads();
     if (!s_last) return;
@@ -2702,7 +2702,7 @@ __global__ void __launch_bounds__(SMALL_NT) k_small_search(SmallArgs a) {
         __syncthreads();
         for (uint32_t i = tid; i < nlist * k; i += SMALL_NT) {
             const uint32_t wg = i / k, j = i % k;
-            lists[i] = a.part[((size_t)wg * a.nq + q) * k + j];
+            lists[i] = __hip_atomic_load(&a.part[((size_t)wg * a.nq + q) * k + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         __syncthreads();
         // thread t < nlist owns list t: k rounds of a block-wide minimum over the list heads
