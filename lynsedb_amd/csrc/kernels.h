@@ -1017,7 +1017,7 @@ constexpr int HK = 64;  // K elements per slab
 // cost registers the unfiltered kernel does not have to spare (56 B/lane of scratch and 13 % of its speed when they
 // were runtime branches).
 template <int WQ, int WR, int TQ, int TR, int METRIC, int NSV, int NSQ, int NT_HINT, bool TILED = false, bool RAG = true, int DBG = 0, bool FILT = false,
-          int I8Q = 0, int EMIT = -1, int PLACE = 0, bool DENSE = false>
+          int I8Q = 0, int EMIT = -1, int PLACE = 0, bool DENSE = false, bool PRIO = false, bool QCREG = true>
 __global__ void __launch_bounds__(WQ * WR * 64, (TQ * TR >= 16) ? 1 : ((WQ * WR >= 8) ? (WQ * WR / 4) : 2)) k_scan_h16(ScanArgs a) {
     // Two LDS rings: NSV stages of row slabs (HBM latency: deeper) and NSQ <= NSV stages of query-image
     // slabs (L2 latency) — 3 + 2 stages of 32 KiB fill the 160 KiB of a CU for the 256 x 256 tile.
@@ -1087,6 +1087,27 @@ __global__ void __launch_bounds__(WQ * WR * 64, (TQ * TR >= 16) ? 1 : ((WQ * WR 
     uint32_t qs_qslab = a.qpad * LINE;
     constexpr bool NORMS_LDS = !TILED && !I8C && (METRIC != M_IP || I8) && (NORM_RING + (NSV + 1) * 1024 <= 160 * 1024);
     constexpr int NORM_SLOTS = NSV + 1;
+    // Per-query constants of the epilogue (1/scale, the additive term, the threshold): constant for the whole launch, so each
+    // wave keeps the TQ*32 queries of its column in QCN registers per constant (query q of the column lives in lane q % 64 of
+    // register q / 64) and the epilogue fetches its lane's value with ds_bpermute.  Loading them from global memory in the
+    // epilogue put every tile's epilogue behind the LDS-DMA still in flight (VM operations retire in order: the load of a
+    // 4-byte constant waited for the next slab's 64 KiB) and behind one L2 round trip per column block.
+    constexpr bool QC_REG = QCREG && !TILED && !(RAG && I8C);  // (the ragged int8 body has no registers to spare: 8 B of scratch with them)
+    constexpr int QCN = (TQ * 32 + 63) / 64;
+    float qc_inv[QCN], qc_extra[QCN], qc_thr[QCN];
+    if (QC_REG) {
+#pragma unroll
+        for (int t = 0; t < QCN; ++t) {
+            const uint32_t nl = t * 64 + lane;
+            const uint32_t n = wq * (TQ * 32) + nl;
+            const bool ok = nl < TQ * 32 && n < a.nq;
+            qc_inv[t] = ok ? a.qinv[n] : 0.0f;
+            qc_extra[t] = 0.0f;
+            if (METRIC == M_L2 || I8) qc_extra[t] = ok ? a.qn2[n] : 0.0f;
+            if (METRIC == M_COS && !I8) qc_extra[t] = ok ? a.qrinv[n] : 0.0f;
+            qc_thr[t] = ok ? a.thr[n] : 0.0f;
+        }
+    }
     const float* norm_src = (METRIC == M_L2 || I8) ? a.vn2 : a.vrinv;  // I8: a.vn2 carries the per-row int sums
 
     auto v_enter_tile = [&]() {
@@ -1243,6 +1264,10 @@ __global__ void __launch_bounds__(WQ * WR * 64, (TQ * TR >= 16) ? 1 : ((WQ * WR 
         v_advance();
     }
 
+    // static priority for the second-dispatched half of an 8-wave workgroup (MI355X_MICROARCH.md, "Two waves per SIMD", item 4):
+    // it is the arbitration loser on every slab step (s_memtime: 3500-3900 cycles per step against 2600-3500 for waves 0-3,
+    // which then wait at the barrier)
+    if (PRIO && NW == 8 && wave >= NW / 2) __builtin_amdgcn_s_setprio(1);
     uint32_t s_in_tile = 0, tile = blockIdx.x, cv_stage = 0, cq_stage = 0, c_tileseq = 0;
 #ifdef LYNSE_EXPERIMENTS
     const bool timing = (a.debug_flags & 64) && a.dbg;
@@ -1375,11 +1400,18 @@ __global__ void __launch_bounds__(WQ * WR * 64, (TQ * TR >= 16) ? 1 : ((WQ * WR 
                 } else {
                     c_ok[j] = n < ea->nq;
                 }
-                c_qinv[j] = c_ok[j] ? ea->qinv[n] : 0.0f;
-                c_extra[j] = 0.0f;
-                if (METRIC == M_L2 || I8) c_extra[j] = c_ok[j] ? ea->qn2[n] : 0.0f;  // SQ8: the per-query integer constant, as bits; I8C: B_q
-                if (METRIC == M_COS && !I8) c_extra[j] = c_ok[j] ? ea->qrinv[n] : 0.0f;
-                c_thr[j] = c_ok[j] ? ea->thr[n] : 0.0f;
+                if (QC_REG) {
+                    const int src = ((j & 1) * 32 + l32) * 4;  // lane holding query j*32+l32 of the wave's column
+                    c_qinv[j] = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(qc_inv[j / 2])));
+                    c_extra[j] = (METRIC != M_IP || I8) ? __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(qc_extra[j / 2]))) : 0.0f;
+                    c_thr[j] = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(qc_thr[j / 2])));
+                } else {
+                    c_qinv[j] = c_ok[j] ? ea->qinv[n] : 0.0f;
+                    c_extra[j] = 0.0f;
+                    if (METRIC == M_L2 || I8) c_extra[j] = c_ok[j] ? ea->qn2[n] : 0.0f;  // SQ8: the per-query integer constant, as bits; I8C: B_q
+                    if (METRIC == M_COS && !I8) c_extra[j] = c_ok[j] ? ea->qrinv[n] : 0.0f;
+                    c_thr[j] = c_ok[j] ? ea->thr[n] : 0.0f;
+                }
 #ifdef LYNSE_EXPERIMENTS
                 if (ea->debug_flags & 2) c_thr[j] = ASC ? -LY_INF : LY_INF;
 #endif

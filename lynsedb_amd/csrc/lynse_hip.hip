@@ -1056,6 +1056,9 @@ static int launch_scan_i8c(const ScanArgs& a, uint32_t grid, hipStream_t st) {
     }
 #endif
     if (a.ld16 % 128 == 0) {
+        static const int prio = []() { const char* e = getenv("LYNSE_HIP_PRIO"); return e ? atoi(e) : 0; }();
+        static bool prattr = false;
+        if (a.emit_all == 0 && prio) { auto k = k_scan_h16<2, 4, 4, 2, M_IP, 3, 2, 2, false, false, 0, false, 2, 0, 0, false, true>; if (!prattr) { LY_TRY(set_max_lds(k, lds)); prattr = true; } hipLaunchKernelGGL(k, dim3(grid), dim3(512), lds, st, a); LY_HIP(hipGetLastError()); return LYNSE_OK; }
         static const int place = []() { const char* e = getenv("LYNSE_HIP_PLACE"); return e ? atoi(e) : 0; }();
         static bool pattr[2] = {false, false};
         if (a.emit_all == 0 && place == 1) { auto k = k_scan_h16<2, 4, 4, 2, M_IP, 3, 2, 2, false, false, 0, false, 2, 0, 1>; if (!pattr[0]) { LY_TRY(set_max_lds(k, lds)); pattr[0] = true; } hipLaunchKernelGGL(k, dim3(grid), dim3(512), lds, st, a); LY_HIP(hipGetLastError()); return LYNSE_OK; }
