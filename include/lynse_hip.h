@@ -263,6 +263,11 @@ int lynse_hip_ivf_set_row_map(lynse_hip_ivf *h, uint64_t stride, uint64_t offset
  * when the probed lists are empty: one ROW SHARD of a larger index must not answer from rows outside the probed lists
  * just because its own part of them is empty. */
 int lynse_hip_ivf_set_routing(lynse_hip_ivf *h, int ivfflat_routing);
+/* One to four queries (k <= 64, nprobe <= 64 < nlist, float metrics, exact centroid ranking, no subset) are answered by TWO
+ * fused launches with no host round trip in between: k_small_search ranks the centroids, then scans the probed lists
+ * straight from that ranking in device memory, every row scored exactly from the f32 slab — the reference's usual IVF
+ * call is one query at a time (ivf.rs:181-348).  Same results as the staged path; on = 0 forces the staged path. */
+int lynse_hip_ivf_set_fused_search(lynse_hip_ivf *h, int on);
 /* IVFIndex::search (ivf.rs:181-348): rank all centroids with the routing metric, scan the nprobe
  * nearest lists, exact top-k of the probed rows.  nprobe == 0 -> 1 (ivf.rs:192-196). */
 int lynse_hip_ivf_search_f32(lynse_hip_ivf *h, const float *queries, uint64_t nq, uint32_t k,

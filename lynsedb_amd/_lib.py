@@ -92,6 +92,7 @@ SIGNATURES = {
     "lynse_hip_ivf_export": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
     "lynse_hip_ivf_set_row_map": (C.c_int, [_vp, C.c_uint64, C.c_uint64]),
     "lynse_hip_ivf_set_routing": (C.c_int, [_vp, C.c_int]),
+    "lynse_hip_ivf_set_fused_search": (C.c_int, [_vp, C.c_int]),
     "lynse_hip_ivf_search_f32": (C.c_int, [_vp, _vp, C.c_uint64, C.c_uint32, C.c_uint32, _vp, _vp, _vp]),
     "lynse_hip_ivf_build_device": (C.c_int, [_vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_int, C.POINTER(_vp)]),
     "lynse_hip_ivf_load_device": (C.c_int, [_vp, C.c_uint64, C.c_uint32, _vp, C.c_uint32, _vp, C.c_int, C.c_int, C.POINTER(_vp)]),

@@ -373,6 +373,10 @@ class IvfFlatIndex:
             check(lib.lynse_hip_ivf_set_routing(h, 1))
         return idx
 
+    def set_fused_search(self, on: bool = True) -> None:
+        """on=False forces the staged pipeline for few-query searches too (tests, A/B); results are identical."""
+        check(lib.lynse_hip_ivf_set_fused_search(self._h, 1 if on else 0))
+
     def search_device(self, d_queries, k: int, nprobe: int, d_rows, d_dists, d_counts) -> None:
         """Queries and outputs are torch tensors on the index's device (rows i64[nq,k] holding u64 bits, dists f32[nq,k],
         counts i32[nq])."""

@@ -2636,12 +2636,21 @@ struct SmallArgs {
     uint32_t nq, k, out_k;
     int metric, ip_form;
     uint64_t row_stride, row_offset;
-    uint64_t* part;          // [gridDim.x][nq][k] sorted keys of every workgroup
+    uint64_t* part;          // [nq][gridDim.x][k] sorted keys of every workgroup
     uint32_t* ticket;        // arrival counter (left at zero)
     uint64_t* out_rows;
     float* out_dists;
     uint32_t* out_counts;
     uint32_t* overflow;      // cleared: this path cannot overflow
+    // IVF mode (probes != nullptr): query q scans the rows of its nprobe probed lists instead of rows [0, n) — slab
+    // positions list_off[c] .. list_off[c+1] of every probed list c < nlist, keys carry orig[position] (the canonical
+    // order and the output use the original row, like k_final).  flag_empty: overflow[q] = 1 when the probed lists hold
+    // no row at all (IVFIndex then falls back to every row, ivf.rs:258-265: the host reruns the general path).
+    const uint64_t* probes;  // [nq][nprobe] list ids (the fused centroid ranking's out_rows)
+    uint32_t nprobe, nlist;
+    const uint64_t* list_off;
+    const uint32_t* orig;
+    int flag_empty;
 };
 
 __device__ __forceinline__ uint64_t shfl_up_u64(uint64_t v, int d) {
@@ -2657,21 +2666,76 @@ __device__ __forceinline__ uint64_t shfl_xor_u64(uint64_t v, int m) {
     return ((uint64_t)hi << 32) | lo;
 }
 
+// Cross-lane helpers of the fused search that stay off the LDS crossbar (ds_bpermute round trips were ~1 us per output
+// rank): a uniform source lane is a v_readlane, the neighbour lane is a DPP wave shift, a wave-wide minimum is four DPP
+// row rotations plus one v_readlane per row of 16 lanes.
+__device__ __forceinline__ uint64_t readlane_u64(uint64_t v, int src_uniform) {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, src_uniform);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), src_uniform);
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint64_t wave_shr1_u64(uint64_t v) {  // lane i <- lane i-1 (lane 0 keeps its own value)
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)v, (int)(uint32_t)v, 0x138, 0xf, 0xf, false);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)(v >> 32), (int)(uint32_t)(v >> 32), 0x138, 0xf, 0xf, false);
+    return ((uint64_t)hi << 32) | lo;
+}
+template <int CTRL>
+__device__ __forceinline__ uint64_t dpp_u64(uint64_t v) {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)v, (int)(uint32_t)v, CTRL, 0xf, 0xf, false);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)(v >> 32), (int)(uint32_t)(v >> 32), CTRL, 0xf, 0xf, false);
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint64_t wave_min_u64(uint64_t v) {  // the minimum over the 64 lanes, in every lane
+    uint64_t w;
+    w = dpp_u64<0x128>(v); v = w < v ? w : v;  // row_ror:8
+    w = dpp_u64<0x124>(v); v = w < v ? w : v;  // row_ror:4
+    w = dpp_u64<0x122>(v); v = w < v ? w : v;  // row_ror:2
+    w = dpp_u64<0x121>(v); v = w < v ? w : v;  // row_ror:1 -> every lane holds its row's minimum
+    const uint64_t r0 = readlane_u64(v, 0), r1 = readlane_u64(v, 16), r2 = readlane_u64(v, 32), r3 = readlane_u64(v, 48);
+    const uint64_t a = r0 < r1 ? r0 : r1, b = r2 < r3 ? r2 : r3;
+    return a < b ? a : b;
+}
+
 __global__ void __launch_bounds__(SMALL_NT) k_small_search(SmallArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* qs = reinterpret_cast<float*>(smem);                                   // D floats: the query being scanned
     uint64_t* wl = reinterpret_cast<uint64_t*>(smem + (size_t)((a.D + 3) / 4 * 4) * 4);  // [8 waves][64] keys; later the merge lists
     __shared__ uint32_t s_last;
-    __shared__ uint64_t s_red[SMALL_NT / 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane & 7, grp = lane >> 3;
     const bool asc = a.metric != M_IP;
     const uint32_t k = a.k;
     constexpr int NWAVE = SMALL_NT / 64;
     const uint32_t rows_per_pass = gridDim.x * NWAVE * 16;   // a group of 8 lanes scores TWO rows per pass (two load streams in flight)
+    // IVF mode: the probed lists of the query laid end to end — s_pre[i] = rows before list i, s_start[i] = its slab position
+    __shared__ uint32_t s_pre[SMALL_MAX_K + 1], s_start[SMALL_MAX_K];
+    const bool ivf = a.probes != nullptr;
+    auto enter_lists = [&](uint32_t q) -> uint32_t {  // (called by every thread; ends with the arrays visible to all)
+        __syncthreads();
+        if (wave == 0) {
+            uint32_t len = 0, start = 0;
+            if ((uint32_t)lane < a.nprobe) {
+                const uint64_t c = a.probes[(size_t)q * a.nprobe + lane];
+                if (c < a.nlist) { start = (uint32_t)a.list_off[c]; len = (uint32_t)(a.list_off[c + 1] - a.list_off[c]); }
+            }
+            uint32_t inc = len;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)inc, o, 64); if (lane >= o) inc += t; }
+            if (lane < SMALL_MAX_K) { s_pre[lane + 1] = inc; s_start[lane] = start; }
+            if (lane == 0) s_pre[0] = 0;
+        }
+        __syncthreads();
+        return s_pre[a.nprobe < (uint32_t)SMALL_MAX_K ? a.nprobe : (uint32_t)SMALL_MAX_K];
+    };
+    auto slab_pos = [&](uint32_t v) -> uint32_t {  // v-th row of the concatenated lists -> slab position (v < total)
+        uint32_t lo = 0, hi = a.nprobe;  // last i with s_pre[i] <= v
+        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (s_pre[mid] <= v) lo = mid; else hi = mid; }
+        return s_start[lo] + (v - s_pre[lo]);
+    };
     for (uint32_t q = 0; q < a.nq; ++q) {
         __syncthreads();
         for (uint32_t i = tid; i < a.D; i += SMALL_NT) qs[i] = a.Qf[(size_t)q * a.D + i];
         __syncthreads();
+        const uint32_t n_rows = ivf ? enter_lists(q) : a.n;
         uint64_t L = KEY_SENTINEL;  // lane j holds the wave's j-th best key (ascending = best first)
         uint64_t thr = KEY_SENTINEL;
         auto offer = [&](uint64_t key) {
@@ -2679,41 +2743,57 @@ __global__ void __launch_bounds__(SMALL_NT) k_small_search(SmallArgs a) {
             while (m) {  // rare once the list has warmed up
                 const int src = __ffsll((long long)m) - 1;
                 m &= m - 1;
-                const uint64_t x = shfl_u64(key, src);
+                const uint64_t x = readlane_u64(key, src);
                 if (x < thr) {
-                    const uint64_t prev = shfl_up_u64(L, 1);
+                    const uint64_t prev = wave_shr1_u64(L);
                     if (L > x) L = (lane == 0 || prev <= x) ? x : prev;
-                    thr = shfl_u64(L, (int)k - 1);
+                    thr = readlane_u64(L, (int)k - 1);
                 }
             }
         };
-        for (uint32_t r0 = (blockIdx.x * NWAVE + wave) * 16; r0 < a.n; r0 += rows_per_pass) {
+        for (uint32_t r0 = (blockIdx.x * NWAVE + wave) * 16; r0 < n_rows; r0 += rows_per_pass) {
             const uint32_t ra = r0 + grp, rb = r0 + 8 + grp;
             // out-of-range rows re-read the last row (uniform control flow inside exact_score) and are dropped afterwards
-            const uint32_t ca = ra < a.n ? ra : a.n - 1, cb = rb < a.n ? rb : a.n - 1;
+            uint32_t ca = ra < n_rows ? ra : n_rows - 1, cb = rb < n_rows ? rb : n_rows - 1;
+            if (ivf) { ca = slab_pos(ca); cb = slab_pos(cb); }
             const float sa = exact_score(a.metric, a.ip_form, qs, a.V + (size_t)ca * a.ld, a.D, g);
             const float sb = exact_score(a.metric, a.ip_form, qs, a.V + (size_t)cb * a.ld, a.D, g);
-            offer(ra < a.n ? make_key(sa, ra, asc) : KEY_SENTINEL);
-            offer(rb < a.n ? make_key(sb, rb, asc) : KEY_SENTINEL);
+            if (ivf && a.orig) { ca = a.orig[ca]; cb = a.orig[cb]; }
+            else if (!ivf) { ca = ra; cb = rb; }
+            offer(ra < n_rows ? make_key(sa, ca, asc) : KEY_SENTINEL);
+            offer(rb < n_rows ? make_key(sb, cb, asc) : KEY_SENTINEL);
         }
         wl[wave * 64 + lane] = lane < (int)k ? L : KEY_SENTINEL;
         __syncthreads();
-        {   // merge the waves by rank: one key per thread, keys are unique apart from the sentinel
+        {   // merge the waves by rank: one key per thread, keys are unique apart from the sentinel.  Every wave list is sorted
+            // (slots >= k hold the sentinel), so the rank of a key is the sum of eight branch-free binary searches — seven
+            // dependent LDS reads with the eight lists interleaved, instead of 8 k sequential reads per thread.
+            auto rank_of = [&](uint64_t x) -> uint32_t {
+                uint32_t pos[NWAVE];
+#pragma unroll
+                for (int w = 0; w < NWAVE; ++w) pos[w] = 0;
+#pragma unroll
+                for (int step = 32; step >= 1; step >>= 1) {
+#pragma unroll
+                    for (int w = 0; w < NWAVE; ++w) pos[w] += (wl[w * 64 + pos[w] + step - 1] < x) ? (uint32_t)step : 0u;
+                }
+                uint32_t r = 0;
+#pragma unroll
+                for (int w = 0; w < NWAVE; ++w) r += pos[w] + ((wl[w * 64 + pos[w]] < x) ? 1u : 0u);  // pos <= 63
+                return r;
+            };
             const uint64_t mine = wl[tid];
-            uint32_t rank = 0;
-            if (mine != KEY_SENTINEL) {  // (only lanes < k of every wave hold keys: NWAVE x k comparisons)
-                for (int w = 0; w < NWAVE; ++w)
-                    for (uint32_t j = 0; j < k; ++j) rank += (wl[w * 64 + j] < mine) ? 1u : 0u;
-                // 8-byte agent-scope atomics on both sides of the hand-off (write-through stores, L2-served loads): no cache
-                // write-back / invalidate fences around the ticket (cdna_hip_programming.md G16, 'valid forms')
-                if (rank < k) __hip_atomic_store(&a.part[((size_t)blockIdx.x * a.nq + q) * k + rank], mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            uint64_t* dst = a.part + ((size_t)q * gridDim.x + blockIdx.x) * k;  // [nq][workgroups][k]: a query's lists are contiguous
+            // 8-byte agent-scope atomics on both sides of the hand-off (write-through stores, L2-served loads): no cache
+            // write-back / invalidate fences around the ticket (cdna_hip_programming.md G16, 'valid forms')
+            if (mine != KEY_SENTINEL) {
+                const uint32_t rank = rank_of(mine);
+                if (rank < k) __hip_atomic_store(&dst[rank], mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             // slots past the number of real keys hold the sentinel
-            uint32_t real = 0;
             if (tid < (int)k) {
-                for (int w = 0; w < NWAVE; ++w)
-                    for (uint32_t j = 0; j < k; ++j) real += wl[w * 64 + j] != KEY_SENTINEL ? 1u : 0u;
-                if ((uint32_t)tid >= real) __hip_atomic_store(&a.part[((size_t)blockIdx.x * a.nq + q) * k + tid], KEY_SENTINEL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t real = rank_of(KEY_SENTINEL);
+                if ((uint32_t)tid >= real) __hip_atomic_store(&dst[tid], KEY_SENTINEL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
     }
@@ -2728,39 +2808,64 @@ __global__ void __launch_bounds__(SMALL_NT) k_small_search(SmallArgs a) {
     __syncthreads();
     if (!s_last) return;
     const uint32_t nlist = gridDim.x;
-    const uint32_t kout = k < a.n ? k : a.n;
     uint64_t* lists = wl;  // [nlist][k] staged in LDS (the launch sizes the dynamic LDS for it)
     for (uint32_t q = 0; q < a.nq; ++q) {
+        const uint32_t n_rows = ivf ? enter_lists(q) : a.n;
+        const uint32_t kout = k < n_rows ? k : n_rows;
         __syncthreads();
-        for (uint32_t i = tid; i < nlist * k; i += SMALL_NT) {
-            const uint32_t wg = i / k, j = i % k;
-            lists[i] = __hip_atomic_load(&a.part[((size_t)wg * a.nq + q) * k + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        __syncthreads();
-        // thread t < nlist owns list t: k rounds of a block-wide minimum over the list heads
-        uint32_t head = 0;
-        const bool owner = tid < (int)nlist;
-        uint64_t cur = owner ? lists[(size_t)tid * k] : KEY_SENTINEL;
-        for (uint32_t round = 0; round < kout; ++round) {
-            uint64_t v = cur;
+        {   // the query's lists are contiguous: eight independent loads in flight per thread (one load per trip waited a full L2
+            // round trip per key: 26 us for 512 lists of 32 keys)
+            const uint64_t* src = a.part + (size_t)q * nlist * k;
+            const uint32_t total = nlist * k;
+            for (uint32_t base = tid; base < total; base += SMALL_NT * 8) {
+                uint64_t v[8];
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) { const uint64_t w = shfl_xor_u64(v, o); v = w < v ? w : v; }
-            __syncthreads();
-            if (lane == 0) s_red[wave] = v;
-            __syncthreads();
-            uint64_t best = s_red[0];
+                for (int u = 0; u < 8; ++u) {
+                    const uint32_t i = base + u * SMALL_NT;
+                    v[u] = i < total ? __hip_atomic_load(&src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : KEY_SENTINEL;
+                }
 #pragma unroll
-            for (int w = 1; w < NWAVE; ++w) best = s_red[w] < best ? s_red[w] : best;
-            if (owner && cur == best && best != KEY_SENTINEL) {  // keys are unique: exactly one owner advances
-                ++head;
-                cur = head < k ? lists[(size_t)tid * k + head] : KEY_SENTINEL;
-            }
-            if (tid == 0) {
-                a.out_rows[(size_t)q * a.out_k + round] = (uint64_t)key_row(best) * a.row_stride + a.row_offset;
-                a.out_dists[(size_t)q * a.out_k + round] = key_score(best, asc);
+                for (int u = 0; u < 8; ++u) {
+                    const uint32_t i = base + u * SMALL_NT;
+                    if (i < total) lists[i] = v[u];
+                }
             }
         }
-        if (tid == 0) { a.out_counts[q] = kout; a.overflow[q] = 0u; }
+        __syncthreads();
+        // two barrier-free tournaments: every wave merges the (at most 64) lists its lanes own into its kout best keys, then
+        // wave 0 merges the eight wave results and writes the outputs — one wave-wide minimum per rank and level
+        uint64_t* wres = lists + (size_t)nlist * k;  // [NWAVE][k]
+        {
+            const uint32_t li = wave * 64 + lane;
+            const bool owner = li < nlist;
+            uint32_t head = 0;
+            uint64_t cur = owner ? lists[(size_t)li * k] : KEY_SENTINEL;
+            for (uint32_t round = 0; round < kout; ++round) {
+                const uint64_t best = wave_min_u64(cur);
+                if (lane == 0) wres[wave * k + round] = best;
+                if (owner && cur == best && best != KEY_SENTINEL) {  // keys are unique: exactly one owner advances
+                    ++head;
+                    cur = head < k ? lists[(size_t)li * k + head] : KEY_SENTINEL;
+                }
+            }
+        }
+        __syncthreads();
+        if (wave == 0) {
+            uint32_t head = 0;
+            uint64_t cur = (lane < NWAVE && kout) ? wres[lane * k] : KEY_SENTINEL;
+            for (uint32_t round = 0; round < kout; ++round) {
+                const uint64_t best = wave_min_u64(cur);
+                if (lane < NWAVE && cur == best && best != KEY_SENTINEL) {
+                    ++head;
+                    cur = head < kout ? wres[lane * k + head] : KEY_SENTINEL;
+                }
+                if (lane == 0) {
+                    a.out_rows[(size_t)q * a.out_k + round] = (uint64_t)key_row(best) * a.row_stride + a.row_offset;
+                    a.out_dists[(size_t)q * a.out_k + round] = key_score(best, asc);
+                }
+            }
+        }
+        if (tid == 0) { a.out_counts[q] = kout; a.overflow[q] = (ivf && a.flag_empty && n_rows == 0) ? 1u : 0u; }
     }
     if (tid == 0) __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }

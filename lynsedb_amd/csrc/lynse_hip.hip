@@ -1436,9 +1436,14 @@ static bool small_path_ok(const lynse_hip_flat* h, uint64_t nq, uint32_t kk, int
            (size_t)((h->dim + 3) / 4 * 4) * 4 + (size_t)128 * 1024 + 64 <= 150u * 1024u;
 }
 
+// SmallRows: the row matrix a fused search scans when it is not the handle's own (IVF: the centroid matrix, the slab with
+// its row map); SmallIvf: the probed-lists mode of k_small_search.
+struct SmallRows { const float* V; uint32_t ld; uint64_t n; int ip_form; uint64_t row_stride, row_offset; };
+struct SmallIvf { const uint64_t* probes; uint32_t nprobe, nlist; const uint64_t* list_off; const uint32_t* orig; int flag_empty; };
+
 static int run_small(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k, int metric, hipStream_t st, size_t* ev_used,
                      std::vector<std::pair<size_t, uint64_t>>* scan_events, uint64_t* r_dst, float* d_dst, uint32_t* c_dst, uint32_t* o_dst,
-                     const float* d_q) {
+                     const float* d_q, const SmallRows* rows = nullptr, const SmallIvf* ivf = nullptr) {
     // r_dst / d_dst / c_dst / o_dst: where the last workgroup writes rows, distances, counts and overflow flags — the
     // caller's device buffers, or pinned host memory (device-visible): no copy kernels behind the search
     Workspace& w = cur(h).ws;
@@ -1448,23 +1453,27 @@ static int run_small(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
     if (ip_form == LYNSE_IPFORM_AUTO) ip_form = h->n < 4096 ? LYNSE_IPFORM_SINGLE : LYNSE_IPFORM_BATCH8;  // flat_mmap.rs:4852-4854
     a.ip_form = ip_form;
     a.row_stride = h->row_stride; a.row_offset = h->row_offset;
+    uint64_t n_scan = h->n;  // rows one query scans (IVF mode: an upper bound, for the grid size only)
+    if (rows) { a.V = rows->V; a.ld = rows->ld; a.n = (uint32_t)rows->n; a.ip_form = rows->ip_form; a.row_stride = rows->row_stride; a.row_offset = rows->row_offset; n_scan = rows->n; }
+    if (ivf) { a.probes = ivf->probes; a.nprobe = ivf->nprobe; a.nlist = ivf->nlist; a.list_off = ivf->list_off; a.orig = ivf->orig; a.flag_empty = ivf->flag_empty; }
     a.part = w.small_part; a.ticket = w.small_ticket;
     a.out_rows = r_dst; a.out_dists = d_dst; a.out_counts = c_dst; a.overflow = o_dst;
     // two workgroups per CU (16 waves: the scan is a chain of dependent load batches per wave), one merge list per workgroup:
     // at most SMALL_NT lists and 128 KB of them in LDS
-    const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint64_t>((uint64_t)std::min(2 * h->num_cu, SMALL_NT), 16384u / std::max<uint32_t>(k, 1)), (h->n + 127) / 128));
-    const size_t lds = (size_t)((h->dim + 3) / 4 * 4) * 4 + std::max<size_t>((size_t)SMALL_NT * 8, (size_t)grid * k * 8) + 64;  // wave lists, then the merge lists
+    const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint64_t>((uint64_t)std::min(2 * h->num_cu, SMALL_NT), 16384u / std::max<uint32_t>(k, 1)), (n_scan + 127) / 128));
+    const size_t lds = (size_t)((h->dim + 3) / 4 * 4) * 4 + std::max<size_t>((size_t)SMALL_NT * 8, (size_t)grid * k * 8) + (size_t)(SMALL_NT / 64) * k * 8 + 64;  // wave lists, then the merge lists + the per-wave tournament results
     static bool small_attr = false;
-    if (!small_attr) { LY_TRY(set_max_lds(k_small_search, 160 * 1024 - 256)); small_attr = true; }
+    if (!small_attr) { LY_TRY(set_max_lds(k_small_search, 160 * 1024 - 1024)); small_attr = true; }
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (h->profiling) {
+    const bool timed = h->profiling && ev_used && scan_events;
+    if (timed) {
         LY_TRY(get_event(h, (*ev_used)++, &e0));
         LY_TRY(get_event(h, (*ev_used)++, &e1));
         LY_HIP(hipEventRecord(e0, st));
     }
     hipLaunchKernelGGL(k_small_search, dim3(grid), dim3(SMALL_NT), lds, st, a);
     LY_HIP(hipGetLastError());
-    if (h->profiling) {
+    if (timed) {
         LY_HIP(hipEventRecord(e1, st));
         scan_events->push_back({*ev_used - 2, (uint64_t)h->n * nq});
         h->prof.last_plan = 32u | (1u << 8);  // bit 5: fused single-launch search

@@ -353,3 +353,57 @@ def test_device_resident_ivf_build_load_search(L, oracle):
                 assert np.array_equal(g_d[qi, :cnt].view(np.uint32), e_d.view(np.uint32)) and np.array_equal(g_rows[qi, :cnt], e_ids)
     with pytest.raises(NotImplementedError):
         L.IvfFlatIndex.build_device(d_rows, dim, nlist, 5, "hamming", l2_partitions=False)
+
+
+@pytest.mark.parametrize("metric", [IP, L2, COS])
+def test_ivf_few_queries_fused_path_equals_staged_and_oracle(L, oracle, metric):
+    """One to four queries take the two-launch fused path (centroid ranking + probed-list scan in k_small_search, no host
+    round trip); more queries and `set_fused_search(False)` take the staged path.  Both must return the oracle's rows and
+    distance bits — including k larger than the probed lists hold, duplicate rows (ties broken by the original row id),
+    lists left empty by the clustering, and the all-probed-lists-empty fallback of IVFIndex (ivf.rs:258-265)."""
+    rng = np.random.default_rng(90 + metric)
+    n, dim, nlist = 9000, 72, 96
+    centers = rng.standard_normal((40, dim)).astype(f32)
+    data = (centers[rng.integers(0, 40, n)] + 0.25 * rng.standard_normal((n, dim))).astype(f32)
+    data[100:140] = data[7]                                   # 40 copies of one row: ties on (distance) -> original row order
+    cen, asg, off, rows = oracle_ivf(oracle, data, nlist, metric)
+    idx = L.IvfFlatIndex.load(data, cen, asg, NAME[metric])
+    queries = (data[rng.integers(0, n, 4)] + 0.05 * rng.standard_normal((4, dim))).astype(f32)
+    queries[1] = data[7]
+    for nq in (1, 2, 4):
+        for nprobe, k in ((1, 10), (6, 10), (32, 64), (64, 50), (3, 1)):
+            got = {}
+            for fused in (True, False):
+                idx.set_fused_search(fused)
+                got[fused] = idx.search_batch_arrays(queries[:nq], k, nprobe)
+            idx.set_fused_search(True)
+            for qi in range(nq):
+                e_ids, e_d, _ = oracle.ivf_search(queries[qi], data, cen, off, rows, nprobe, k, metric)
+                for fused in (True, False):
+                    g_rows, g_d, g_c = got[fused]
+                    c = int(g_c[qi])
+                    assert c == len(e_ids), (fused, nq, nprobe, k, qi, c, len(e_ids))
+                    assert np.array_equal(g_d[qi, :c].view(np.uint32), e_d.view(np.uint32)), (fused, nq, nprobe, k, qi)
+                    assert np.array_equal(g_rows[qi, :c], e_ids), (fused, nq, nprobe, k, qi, g_rows[qi, :c], e_ids)
+    # every probed list empty: centroids far from the data own no row; a query next to one probes only empty lists.
+    # IVFIndex then searches every row (the fused path flags it and the staged path answers).
+    cen2 = np.concatenate([cen, (100.0 + np.arange(4 * dim, dtype=f32)).reshape(4, dim)])
+    idx2 = L.IvfFlatIndex.load(data, cen2, asg, NAME[metric])
+    off2, rows2 = oracle.lists_from_assignments(asg, cen2.shape[0])
+    q_far = cen2[-1:].copy() if metric != COS else cen2[-2:-1].copy()
+    g_rows, g_d, g_c = idx2.search_batch_arrays(q_far, 5, 1)
+    e_ids, e_d, _ = oracle.ivf_search(q_far[0], data, cen2, off2, rows2, 1, 5, metric)
+    probes = oracle.ivf_search(q_far[0], data, cen2, off2, rows2, 1, 5, metric)[2]
+    c = int(g_c[0])
+    assert c == len(e_ids) and np.array_equal(g_rows[0, :c], e_ids) and np.array_equal(g_d[0, :c].view(np.uint32), e_d.view(np.uint32)), (probes, g_rows[0], e_ids)
+    # device-resident twin through the fused path
+    import torch
+    dev = torch.device("cuda", 0)
+    dq = torch.as_tensor(queries[:3], device=dev)
+    r = torch.zeros((3, 10), dtype=torch.int64, device=dev); d = torch.zeros((3, 10), dtype=torch.float32, device=dev)
+    cc = torch.zeros(3, dtype=torch.int32, device=dev)
+    idx.search_device(dq, 10, 6, r, d, cc)
+    for qi in range(3):
+        e_ids, e_d, _ = oracle.ivf_search(queries[qi], data, cen, off, rows, 6, 10, metric)
+        assert np.array_equal(r[qi].cpu().numpy().astype(np.uint64)[:len(e_ids)], e_ids.astype(np.uint64))
+        assert np.array_equal(d[qi].cpu().numpy()[:len(e_ids)].view(np.uint32), e_d.view(np.uint32))
