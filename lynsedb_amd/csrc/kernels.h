@@ -1061,6 +1061,9 @@ __global__ void __launch_bounds__(WQ * WR * 64, (TQ * TR >= 16) ? 1 : ((WQ * WR 
     const int wq = wave % WQ, wr = wave / WQ;
 
     if (blockIdx.x >= a.ntiles) return;
+    // blockIdx.y: which chunk of BQ queries this workgroup scores (one launch scores a.qpad / BQ chunks against the same rows:
+    // the k-means assignment step searches thousands of rows against a few thousand centroids); 0 for ordinary searches
+    const uint32_t qchunk = (TILED || I8 || FILT) ? 0u : blockIdx.y * (uint32_t)BQ;  // (the int8 passes always run one chunk)
     const uint32_t my_tiles = (a.ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x;
     const uint32_t G = my_tiles * a.nslab;
     const uint32_t tstride = a.tile_stride ? a.tile_stride : (uint32_t)BR;
@@ -1092,14 +1095,14 @@ __global__ void __launch_bounds__(WQ * WR * 64, (TQ * TR >= 16) ? 1 : ((WQ * WR 
     // register q / 64) and the epilogue fetches its lane's value with ds_bpermute.  Loading them from global memory in the
     // epilogue put every tile's epilogue behind the LDS-DMA still in flight (VM operations retire in order: the load of a
     // 4-byte constant waited for the next slab's 64 KiB) and behind one L2 round trip per column block.
-    constexpr bool QC_REG = QCREG && !TILED && !(RAG && I8C);  // (the ragged int8 body has no registers to spare: 8 B of scratch with them)
+    constexpr bool QC_REG = QCREG && !TILED && !FILT && !(RAG && WR >= 4);  // (the ragged <2,4,4,2> bodies have no registers to spare: 8 B of scratch with them)
     constexpr int QCN = (TQ * 32 + 63) / 64;
     float qc_inv[QCN], qc_extra[QCN], qc_thr[QCN];
     if (QC_REG) {
 #pragma unroll
         for (int t = 0; t < QCN; ++t) {
             const uint32_t nl = t * 64 + lane;
-            const uint32_t n = wq * (TQ * 32) + nl;
+            const uint32_t n = qchunk + wq * (TQ * 32) + nl;
             const bool ok = nl < TQ * 32 && n < a.nq;
             qc_inv[t] = ok ? a.qinv[n] : 0.0f;
             qc_extra[t] = 0.0f;
@@ -1136,7 +1139,7 @@ __global__ void __launch_bounds__(WQ * WR * 64, (TQ * TR >= 16) ? 1 : ((WQ * WR 
         }
     };
     auto q_enter_tile = [&]() {
-        q_base = reinterpret_cast<const char*>(a.Q16);
+        q_base = reinterpret_cast<const char*>(a.Q16) + (size_t)qchunk * LINE;  // (chunk's first query; the slab stride is a.qpad lines)
         if (TILED) {
             const IvfTile td = a.tiles[qs_tile];
             q_base += (size_t)td.qimg_off * 2;
@@ -1393,7 +1396,7 @@ __global__ void __launch_bounds__(WQ * WR * 64, (TQ * TR >= 16) ? 1 : ((WQ * WR 
             for (int j = 0; j < TQ; ++j) {
                 uint32_t rb = __builtin_amdgcn_readfirstlane(rbase);  // (uniform) opaque per column block: keeps the row-index terms of the TR x 16 rows from being hoisted out of
                 asm volatile("" : "+s"(rb));  // the unrolled column loop (all live at once: hundreds of bytes of scratch per lane)
-                uint32_t n = wq * (TQ * 32) + j * 32 + l32;  // this lane's query of column block j (TILED: through the group's pair list)
+                uint32_t n = qchunk + wq * (TQ * 32) + j * 32 + l32;  // this lane's query of column block j (TILED: through the group's pair list)
                 if (TILED) {
                     c_ok[j] = n < td.nq;
                     n = c_ok[j] ? ea->pair_q[td.pair0 + n] : 0u;
@@ -1663,7 +1666,7 @@ __global__ void __launch_bounds__(WQ * WR * 64, (TQ * TR >= 16) ? 1 : ((WQ * WR 
         if (ea->seg && (hi == 0 || DENSE)) {  // DENSE: one segment per wave half (the lane's own), else one per row-wave
 #pragma unroll
             for (int j = 0; j < TQ; ++j) {
-                const uint32_t n = wq * (TQ * 32) + j * 32 + l32;
+                const uint32_t n = qchunk + wq * (TQ * 32) + j * 32 + l32;
                 const uint32_t sgm = DENSE ? (blockIdx.x * WR + wr) * 2 + hi : blockIdx.x * WR + wr;
                 if (n < ea->nq) ea->segcnt[(size_t)n * ea->nseg + sgm] = (uint8_t)((segpk >> (8 * j)) & 0xffu);
             }

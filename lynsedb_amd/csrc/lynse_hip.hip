@@ -218,6 +218,8 @@ struct lynse_hip_flat {
     uint64_t row_stride = 1, row_offset = 0;
     int ip_form = LYNSE_IPFORM_AUTO;
     int no_fused = 0;            // lynse_hip_flat_set_fused_search(h, 0): always the staged pipeline (tests, A/B)
+    uint32_t qchunk = 256;       // queries per pipeline pass (QCHUNK); the k-means assignment step widens it on its centroid store:
+                                 // thousands of rows per launch against <= cap centroids (k_scan_h16's blockIdx.y)
     int dtype = LYNSE_DTYPE_F32;  // F16: rows hold f16-representable values, distances use the f16 kernels' sequential sums
     uint32_t stage0_rows = 4096, growth = 8, cap = 16384;
 
@@ -727,37 +729,38 @@ static int set_max_lds(K kernel, size_t bytes) {
 static int ensure_workspace(lynse_hip_flat* h, uint32_t k /* caller's k = output stride */) {
     Workspace& w = cur(h).ws;
     const uint32_t nslab = (h->dim + SCAN_BK - 1) / SCAN_BK;
-    if (w.cand && w.cap == h->cap && w.D == h->dim && w.kcap >= k) return LYNSE_OK;
+    const uint32_t QC = std::max<uint32_t>(h->qchunk, QCHUNK);
+    if (w.cand && w.cap == h->cap && w.D == h->dim && w.kcap >= k && w.qcap == QC) return LYNSE_OK;
     w.release();
-    w.qcap = QCHUNK;
+    w.qcap = QC;
     w.cap = h->cap;
     w.D = h->dim;
     w.W = h->words;
     w.kcap = std::max<uint32_t>(k, 128);
-    LY_HIP(hipMalloc(&w.cand, (size_t)QCHUNK * w.cap * 8));
+    LY_HIP(hipMalloc(&w.cand, (size_t)QC * w.cap * 8));
     LY_HIP(hipMalloc(&w.candB, (size_t)QCHUNK * SEG_KEYS * 8));
     LY_HIP(hipMalloc(&w.segcnt, (size_t)QCHUNK * SEG_MAX));
-    LY_HIP(hipMalloc(&w.count, QCHUNK * 4));
-    LY_HIP(hipMalloc(&w.thr, QCHUNK * 4));
-    LY_HIP(hipMalloc(&w.qinv, QCHUNK * 4));
-    LY_HIP(hipMalloc(&w.qn2, QCHUNK * 4));
-    LY_HIP(hipMalloc(&w.qrinv, QCHUNK * 4));
-    LY_HIP(hipMalloc(&w.marg2, QCHUNK * 4));
-    w.q16_halves = (size_t)nslab * QCHUNK * SCAN_LDK;
+    LY_HIP(hipMalloc(&w.count, (size_t)QC * 4));
+    LY_HIP(hipMalloc(&w.thr, (size_t)QC * 4));
+    LY_HIP(hipMalloc(&w.qinv, (size_t)QC * 4));
+    LY_HIP(hipMalloc(&w.qn2, (size_t)QC * 4));
+    LY_HIP(hipMalloc(&w.qrinv, (size_t)QC * 4));
+    LY_HIP(hipMalloc(&w.marg2, (size_t)QC * 4));
+    w.q16_halves = (size_t)nslab * QC * SCAN_LDK;
     LY_HIP(hipMalloc(&w.Q16, w.q16_halves * sizeof(_Float16)));
     LY_HIP(hipMemset(w.Q16, 0, w.q16_halves * sizeof(_Float16)));
-    LY_HIP(hipMalloc(&w.Qf, (size_t)QCHUNK * h->dim * 4));
+    LY_HIP(hipMalloc(&w.Qf, (size_t)QC * h->dim * 4));
     LY_HIP(hipMalloc(&w.QW, (size_t)QCHUNK * h->words * 8));
     {
         uint32_t wcap = 1;
         while (wcap < h->words) wcap <<= 1;
         LY_HIP(hipMalloc(&w.QWp, (size_t)QCHUNK * wcap * 8));
     }
-    LY_HIP(hipMalloc(&w.out_rows, (size_t)QCHUNK * w.kcap * 8));
-    LY_HIP(hipMalloc(&w.out_dists, (size_t)QCHUNK * w.kcap * 4));
-    LY_HIP(hipMalloc(&w.out_counts, 2 * QCHUNK * 4));
-    w.overflow = w.out_counts + QCHUNK;
-    LY_HIP(hipHostMalloc(&w.h_hdr, 2 * QCHUNK * 4, hipHostMallocDefault));
+    LY_HIP(hipMalloc(&w.out_rows, (size_t)QC * w.kcap * 8));
+    LY_HIP(hipMalloc(&w.out_dists, (size_t)QC * w.kcap * 4));
+    LY_HIP(hipMalloc(&w.out_counts, (size_t)2 * QC * 4));
+    w.overflow = w.out_counts + QC;
+    LY_HIP(hipHostMalloc(&w.h_hdr, (size_t)2 * QC * 4, hipHostMallocDefault));
     LY_HIP(hipHostMalloc(&w.h_out, H_OUT_BYTES, hipHostMallocDefault));
     LY_HIP(hipMalloc(&w.pool_total, 8));
     LY_HIP(hipMemset(w.pool_total, 0, 8));
@@ -915,14 +918,14 @@ static int scan_variant() {
 // the product path uses: <2,4,4,2> for unfiltered IP, <4,2,2,4> for L2 / cosine and every subset-filtered scan.
 // The <= 32-query kernel and the IVF work-list kernel (<1,4,1,1>) keep the runtime emission switch (no spills there).
 template <int WQ, int WR, int TQ, int TR, int NSV, int NSQ, bool TILED>
-static int launch_scan_h16(const ScanArgs& a, int metric, uint32_t grid, hipStream_t st) {
+static int launch_scan_h16(const ScanArgs& a, int metric, uint32_t grid, hipStream_t st, uint32_t grid_y = 1) {
     constexpr int BQ = WQ * TQ * 32, BR = WR * TR * 32;
     constexpr size_t rings = (size_t)(NSV * BR + NSQ * BQ) * (HK * 2);
     const size_t lds = (rings + (NSV + 1) * 1024 <= 160 * 1024) ? rings + (NSV + 1) * 1024 : rings;
     static bool attr_done[64] = {false};
     auto go = [&](auto kern, int slot) -> int {
         if (!attr_done[slot]) { LY_TRY(set_max_lds(kern, lds)); attr_done[slot] = true; }
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(WQ * WR * 64), lds, st, a);
+        hipLaunchKernelGGL(kern, dim3(grid, grid_y), dim3(WQ * WR * 64), lds, st, a);
         LY_HIP(hipGetLastError());
         return LYNSE_OK;
     };
@@ -1179,7 +1182,10 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
     const bool glds = scan_variant() == 0;
     const uint32_t nslab = i8c ? (h->dim + 127) / 128 : glds ? (h->dim + GL_BK - 1) / GL_BK : (h->dim + SCAN_BK - 1) / SCAN_BK;  // h16: HK == SCAN_BK == 64
     const bool small = nq <= SCAN_BQ_SMALL;
-    const uint32_t qpad = small ? SCAN_BQ_SMALL : SCAN_BQ_LARGE;
+    const uint32_t qpad = small ? SCAN_BQ_SMALL : round_up(nq, SCAN_BQ_LARGE);  // > 256 queries: a widened handle, qpad / 256 chunks per launch
+    const uint32_t qchunks = small ? 1u : qpad / SCAN_BQ_LARGE;
+    if (qchunks > 1 && (binary || i8c || mask || row_ids || !h16 || h->n > w.cap || nq > w.qcap))
+        return set_error(LYNSE_ERR_INTERNAL, "more than 256 queries per pass need the widened float pipeline over <= cap rows");
     int ip_form = h->ip_form;
     if (ip_form == LYNSE_IPFORM_AUTO) ip_form = h->n < 4096 ? LYNSE_IPFORM_SINGLE : LYNSE_IPFORM_BATCH8;
     if (mask || row_ids) ip_form = LYNSE_IPFORM_SINGLE;
@@ -1341,8 +1347,10 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
                     if (waves16 == 2) LY_TRY((launch_scan_h16<2, 4, 4, 2, 2, 2, false>(a, metric, grid, st)));
                     else
 #endif
-                    if (waves16 == 3 || waves16 == 2) LY_TRY((launch_scan_h16<2, 4, 4, 2, 3, 2, false>(a, metric, grid, st)));
-                    else LY_TRY((launch_scan_h16<4, 2, 2, 4, 2, 2, false>(a, metric, grid, st)));
+                    if (qchunks > 1 && !(plan.size() == 1 && a.emit_all == 1))
+                        return set_error(LYNSE_ERR_INTERNAL, "the widened pipeline runs single-stage emit-all plans only");
+                    if (waves16 == 3 || waves16 == 2) LY_TRY((launch_scan_h16<2, 4, 4, 2, 3, 2, false>(a, metric, grid, st, qchunks)));
+                    else LY_TRY((launch_scan_h16<4, 2, 2, 4, 2, 2, false>(a, metric, grid, st, qchunks)));
                 }
             }
 #ifdef LYNSE_EXPERIMENTS
@@ -1858,8 +1866,12 @@ static int search_impl(lynse_hip_flat* h, const void* q_src, bool packed_queries
     }
     uint64_t fallback_queries = 0;
 
-    for (uint64_t q0 = 0; q0 < nq; q0 += QCHUNK) {
-        const uint32_t nqc = (uint32_t)std::min<uint64_t>(QCHUNK, nq - q0);
+    // queries per pipeline pass: QCHUNK; a widened handle (the k-means assignment's centroid store: unfiltered float search of
+    // a shard of <= cap rows) takes h->qchunk queries per pass, one k_scan_h16 launch scoring qchunk / 256 chunks (blockIdx.y)
+    const bool wide = h->qchunk > QCHUNK && !binary && !filtered && scan_variant() == 3 && h->n <= h->cap;
+    const uint32_t QC = wide ? w.qcap : QCHUNK;
+    for (uint64_t q0 = 0; q0 < nq; q0 += QC) {
+        const uint32_t nqc = (uint32_t)std::min<uint64_t>(QC, nq - q0);
         // stage the chunk's queries in the workspace
         if (binary) {
             if (packed_queries) {
@@ -1887,7 +1899,7 @@ static int search_impl(lynse_hip_flat* h, const void* q_src, bool packed_queries
             uint64_t* r_dst = on_device ? out_rows + q0 * k : reinterpret_cast<uint64_t*>(w.h_out);
             float* d_dst = on_device ? out_dists + q0 * k : reinterpret_cast<float*>(w.h_out + rows_b);
             uint32_t* c_dst = on_device ? out_counts + q0 : w.h_hdr;
-            LY_TRY(run_small(h, nqc, kk, k, metric, st, &ev_used, &scan_events, r_dst, d_dst, c_dst, w.h_hdr + QCHUNK,
+            LY_TRY(run_small(h, nqc, kk, k, metric, st, &ev_used, &scan_events, r_dst, d_dst, c_dst, w.h_hdr + w.qcap,
                              on_device ? (const float*)q_src + q0 * h->dim : w.Qf));  // device queries are read in place
             LY_HIP(hipStreamSynchronize(st));
             if (!on_device) {
@@ -1913,10 +1925,10 @@ static int search_impl(lynse_hip_flat* h, const void* q_src, bool packed_queries
                 LY_HIP(hipMemcpyAsync(out_rows + q0 * k, w.out_rows, rows_b, out_kind, st));
                 LY_HIP(hipMemcpyAsync(out_dists + q0 * k, w.out_dists, dists_b, out_kind, st));
             }
-            LY_HIP(hipMemcpyAsync(w.h_hdr, w.out_counts, 2 * QCHUNK * 4, hipMemcpyDeviceToHost, st));  // counts + overflow flags
+            LY_HIP(hipMemcpyAsync(w.h_hdr, w.out_counts, (size_t)2 * w.qcap * 4, hipMemcpyDeviceToHost, st));  // counts + overflow flags
             LY_HIP(hipStreamSynchronize(st));
             uint32_t nov = 0;
-            for (uint32_t i = 0; i < nqc; ++i) nov += w.h_hdr[QCHUNK + i] ? 1 : 0;
+            for (uint32_t i = 0; i < nqc; ++i) nov += w.h_hdr[w.qcap + i] ? 1 : 0;
             if (nov == 0) {
                 if (staged) { memcpy(out_rows + q0 * k, w.h_out, rows_b); memcpy(out_dists + q0 * k, w.h_out + rows_b, dists_b); }
                 break;
