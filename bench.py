@@ -58,6 +58,10 @@ def parse_args():
     p.add_argument("--verify-queries", type=int, default=16)
     p.add_argument("--stage0", type=int, default=0, help="override the stage-0 row count of the scan plan")
     p.add_argument("--growth", type=int, default=0, help="override the stage growth factor of the scan plan")
+    p.add_argument("--in-flight", type=int, default=int(os.environ.get("LYNSE_BENCH_IN_FLIGHT", "0")),
+                   help="batches in flight (lynse_hip_flat_search_submit_* / _wait): step i+1 is enqueued before step i is waited "
+                        "for; 1 = the blocking entry points (one host round trip per step); 0 = default: 1 on one GPU (the "
+                        "kernel durations of the roofline stay undisturbed; in flight gains 1 %% there), 3 on a sharded collection")
     return p.parse_args()
 
 
@@ -138,28 +142,50 @@ def main():
     g.manual_seed(args.seed + 11)
     queries = (q_src + 0.03 * torch.randn((B, D), generator=g, device=dev, dtype=torch.float32)).contiguous()
 
-    out = sh.alloc_outputs(B, K)
+    # Batches in flight: the reference answers concurrent readers (Arc<RwLock<Collection>>, src/python/mod.rs:950, :1187);
+    # here step i+1 is ENQUEUED (scan -> selects -> rescoring [-> all-gather -> merge]) before step i is waited for, each on
+    # its own search context and output buffers.  Every one of the K steps is complete — overflow flags checked, results
+    # final — inside the timed region.
+    in_flight = max(1, min(args.in_flight, 4)) if args.in_flight > 0 else (1 if world == 1 else 3)
+    outs = [sh.alloc_outputs(B, K) for _ in range(in_flight)]
+    out = outs[0]
 
-    def step():
-        sh.search_device(queries, K, metric, out)
+    def run_steps(n):
+        if in_flight == 1:
+            for _ in range(n):
+                sh.search_device(queries, K, metric, out)
+            return
+        pending = []
+        for i in range(n):
+            pending.append(sh.search_submit(queries, K, metric, outs[i % in_flight]))
+            if len(pending) >= in_flight:
+                pending.pop(0).wait()
+        for t in pending:
+            t.wait()
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    run_steps(args.warmup)
     sh.index.profile_enable(True)
     sh.index.profile_get(reset=True)
     barrier()
     t_start = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    run_steps(args.steps)
     barrier()
     elapsed = time.perf_counter() - t_start
     prof = sh.index.profile_get(reset=True)
     sh.index.profile_enable(False)
+    # (outside the timed region) latency of ONE blocking batch: the same step through the blocking entry points
+    lat_steps = max(1, min(args.steps, 10))
+    barrier()
+    t_lat = time.perf_counter()
+    for _ in range(lat_steps):
+        sh.search_device(queries, K, metric, out)
+    barrier()
+    lat_ms = (time.perf_counter() - t_lat) / lat_steps * 1000.0
     if dist is not None:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -245,8 +271,10 @@ def main():
                        "exchange": ("rccl all_gather of %d B/rank, %s" % (B * K * 12 + B * 4, "inside the library (C-ABI), one stream" if native
                                     else "through torch.distributed (%s)" % (sh.comm_error or os.environ.get("LYNSE_BENCH_BACKEND", "nccl")))) if world > 1 else "none",
                        "rccl_ranks_seen": (sh.ranks_seen if native else None),
+                       "batches_in_flight": in_flight,
                        "build_s": round(build_s, 1)},
             "roofline": roofline,
+            "blocking_ms_per_batch": round(lat_ms, 4),
             "pipeline_us_per_step": round(prof["total_us"] / max(prof["searches"], 1), 1),
             "rescored_per_query": round(prof["pool_entries"] / max(prof["searches"] * B, 1), 1),
             "fallback_queries": int(prof["fallback_queries"]),

@@ -331,6 +331,29 @@ int lynse_hip_flat_search_sharded_packed_u64_device(lynse_hip_flat *h, lynse_hip
                                                     int metric, uint64_t *d_out_rows, float *d_out_dists,
                                                     uint32_t *d_out_counts);
 
+/* ---- searches in flight: submit / wait ----
+ *
+ * The reference serves concurrent readers (Arc<RwLock<Collection>> with inner.read() on the search path,
+ * src/python/mod.rs:950, :1187; RPC / HTTP workers call search concurrently, src/rpc.rs:588-590): a batch does not wait
+ * for the previous one to be answered.  submit enqueues a whole batch of <= 256 queries on one of the handle's search
+ * contexts (stream + workspace; LYNSE_HIP_CONTEXTS of them) — the staged pipeline and, with a communicator, the
+ * ncclAllGather of the result blocks and the device merge — and returns a ticket; wait blocks until that batch is final in
+ * the caller's DEVICE arrays (identical to the blocking entry points: an overflowed plan is re-run on the next plan level
+ * inside wait, on every rank of a sharded collection) and frees the ticket.  `c` = NULL: this shard only.  Queries and
+ * outputs must stay valid until wait returns.  Tickets are waited for by the thread that submitted them, in any order;
+ * append / finalize and the filtered searches need every ticket waited for first.  With a communicator submit is a
+ * COLLECTIVE: every rank submits and waits for the same sequence.  A search that cannot be pipelined (more than 256
+ * queries, k beyond one pass, the fused few-query search, derived data still to build) is answered inside submit. */
+typedef struct lynse_hip_ticket lynse_hip_ticket;
+int lynse_hip_flat_search_submit_f32_device(lynse_hip_flat *h, lynse_hip_comm *c, const float *d_queries, uint64_t nq,
+                                            uint32_t k, int metric, uint64_t *d_out_rows, float *d_out_dists,
+                                            uint32_t *d_out_counts, lynse_hip_ticket **out);
+int lynse_hip_flat_search_submit_packed_u64_device(lynse_hip_flat *h, lynse_hip_comm *c,
+                                                   const uint64_t *d_query_words, uint64_t nq, uint32_t k, int metric,
+                                                   uint64_t *d_out_rows, float *d_out_dists, uint32_t *d_out_counts,
+                                                   lynse_hip_ticket **out);
+int lynse_hip_flat_search_wait(lynse_hip_ticket *t);
+
 /* ---- shard-node glue around a search (host only, no device work) ---- */
 
 /* Collection::filter_tombstoned_limit (src/engine.rs:3286-3308): drop the tombstoned ids, keep the order, at most

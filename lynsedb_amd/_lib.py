@@ -115,6 +115,9 @@ SIGNATURES = {
     "lynse_hip_comm_ranks_seen": (C.c_int, [_vp, C.POINTER(C.c_int)]),
     "lynse_hip_flat_search_sharded_f32_device": (C.c_int, [_vp, _vp, _vp, C.c_uint64, C.c_uint32, C.c_int, _vp, _vp, _vp]),
     "lynse_hip_flat_search_sharded_packed_u64_device": (C.c_int, [_vp, _vp, _vp, C.c_uint64, C.c_uint32, C.c_int, _vp, _vp, _vp]),
+    "lynse_hip_flat_search_submit_f32_device": (C.c_int, [_vp, _vp, _vp, C.c_uint64, C.c_uint32, C.c_int, _vp, _vp, _vp, C.POINTER(_vp)]),
+    "lynse_hip_flat_search_submit_packed_u64_device": (C.c_int, [_vp, _vp, _vp, C.c_uint64, C.c_uint32, C.c_int, _vp, _vp, _vp, C.POINTER(_vp)]),
+    "lynse_hip_flat_search_wait": (C.c_int, [_vp]),
 }
 
 if not LIB_PATH.exists():

@@ -302,6 +302,19 @@ class FlatIndex:
             C.c_void_p(d_dists.data_ptr()), C.c_void_p(d_counts.data_ptr()),
             C.c_void_p(stream) if stream else None))
 
+    # -- searches in flight (lynse_hip_flat_search_submit_* / _wait) --------------------------------
+    def search_submit(self, d_queries, k: int, metric, d_rows, d_dists, d_counts, comm=None) -> "SearchTicket":
+        """Enqueue one batch (<= 256 queries, torch tensors on this device) on a search context of the index and return a
+        ticket; `wait()` makes the results final in d_rows / d_dists / d_counts.  Up to LYNSE_HIP_CONTEXTS batches overlap on
+        the device.  `comm`: the communicator handle of a row-sharded collection (a collective then)."""
+        m = metric if isinstance(metric, int) else metric_from_str(metric)
+        _sync_producer(d_queries)
+        t = C.c_void_p()
+        fn = lib.lynse_hip_flat_search_submit_packed_u64_device if m >= 3 else lib.lynse_hip_flat_search_submit_f32_device
+        check(fn(self._h, comm, C.c_void_p(d_queries.data_ptr()), d_queries.shape[0], int(k), m, C.c_void_p(d_rows.data_ptr()),
+                 C.c_void_p(d_dists.data_ptr()), C.c_void_p(d_counts.data_ptr()), C.byref(t)))
+        return SearchTicket(t, (d_queries, d_rows, d_dists, d_counts))
+
     # -- profiling ----------------------------------------------------------------------------
     def profile_enable(self, on: bool = True) -> None:
         check(lib.lynse_hip_flat_profile_enable(self._h, 1 if on else 0))
@@ -310,6 +323,27 @@ class FlatIndex:
         p = _lib.Profile()
         check(lib.lynse_hip_flat_profile_get(self._h, C.byref(p), 1 if reset else 0))
         return {f: getattr(p, f) for f, _ in _lib.Profile._fields_}
+
+
+class SearchTicket:
+    """A batch in flight (FlatIndex.search_submit).  Keeps the tensors of the batch alive until it is waited for."""
+
+    def __init__(self, handle, keep):
+        self._t, self._keep = handle, keep
+
+    def wait(self) -> None:
+        t, self._t = self._t, None
+        if t is not None:
+            try:
+                check(lib.lynse_hip_flat_search_wait(t))
+            finally:
+                self._keep = None
+
+    def __del__(self):  # a ticket must not die with its batch in flight: it holds a search context and the reader lock
+        try:
+            self.wait()
+        except Exception:  # noqa: BLE001
+            pass
 
 
 class IvfFlatIndex:

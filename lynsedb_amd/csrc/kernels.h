@@ -2890,6 +2890,10 @@ struct FinalArgs {
     uint32_t* out_counts2;   // optional second destination of the counts (the caller's device array; the first one sits next to
                              // the overflow flags and comes back in the pinned header)
     unsigned long long* pool_total;
+    // searches in flight (lynse_hip_flat_search_submit_*): the per-query overflow flags of k_select are OR-ed into ONE status
+    // word that travels with the result block (the host looks at it when the ticket is waited for); NULL otherwise
+    const uint32_t* overflow;
+    uint32_t* any_overflow;
 };
 
 // k_rescore_pool: the exact rescoring of k_final spread over gridDim.y blocks per query (IVF on tightly clustered
@@ -2945,6 +2949,7 @@ __global__ void __launch_bounds__(NT) k_final(FinalArgs a) {
         a.out_counts[q] = cnt;
         if (a.out_counts2) a.out_counts2[q] = cnt;
         if (a.pool_total) atomicAdd(a.pool_total, (unsigned long long)n);
+        if (a.any_overflow && a.overflow[q]) atomicOr(a.any_overflow, 1u);
     }
 }
 
@@ -2962,6 +2967,10 @@ struct MergeArgs {
     uint64_t* out_rows;
     float* out_dists;
     uint32_t* out_counts;
+    // searches in flight: every block carries a status word at status_off (bit 0: a query of that shard overflowed its
+    // candidate buffers); their OR goes to out_status (pinned host memory, read when the ticket is waited for)
+    uint64_t status_off;
+    uint32_t* out_status;
 };
 
 template <int NT>
@@ -3021,6 +3030,11 @@ __global__ void __launch_bounds__(NT) k_merge(MergeArgs a) {
         }
     }
     if (tid == 0) a.out_counts[q] = cnt;
+    if (q == 0 && tid == 0 && a.out_status) {
+        uint32_t st = 0;
+        for (uint32_t l = 0; l < a.n_lists; ++l) st |= *reinterpret_cast<const uint32_t*>(a.blocks + (size_t)l * a.block_bytes + a.status_off);
+        *a.out_status = st;
+    }
 }
 
 }  // namespace lynse

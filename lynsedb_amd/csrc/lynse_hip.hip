@@ -7,10 +7,12 @@
 //     -> VectorStore::search (vector_store.rs:972-1004) -> FlatMmap::search (flat_mmap.rs:824-923)
 //     -> exact_flat_search / packed_binary_search (:1173-1230, :1345-1409) -> simd kernels.
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <condition_variable>
+#include <memory>
 #include <mutex>
 #include <shared_mutex>
 #include <string>
@@ -196,6 +198,7 @@ struct lynse_hip_flat {
     std::condition_variable ctx_cv;
     uint32_t ctx_busy = 0;               // bit s: context s is taken
     std::mutex prof_mu;                  // profile counters are shared by the contexts
+    std::atomic<int> inflight{0};        // tickets of lynse_hip_flat_search_submit_* not yet waited for (async_host.inc)
 
     uint64_t n = 0, capacity = 0;
     float* rows = nullptr;       // capacity x ld f32, row-major (pad columns zero)
@@ -1170,7 +1173,8 @@ static int get_event(lynse_hip_flat* h, size_t idx, hipEvent_t* out) {
 static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k, int metric, int level, hipStream_t st,
                      size_t* ev_used, std::vector<std::pair<size_t, uint64_t>>* scan_events, bool* sampled_plan,
                      const uint32_t* mask = nullptr, const uint32_t* row_ids = nullptr, bool i8c = false,
-                     uint64_t* r_dst = nullptr, float* d_dst = nullptr, uint32_t* c2_dst = nullptr) {
+                     uint64_t* r_dst = nullptr, float* d_dst = nullptr, uint32_t* c2_dst = nullptr, uint32_t* any_ovf = nullptr) {
+    // any_ovf: device status word k_final ORs the overflow flags into (searches in flight), or nullptr
     // r_dst / d_dst / c2_dst: where k_final writes rows, distances (stride out_k) and a second copy of the counts — the
     // caller's device arrays or the pinned staging buffer; nullptr = the workspace (copied out by the caller)
     // i8c: the coarse pass streams the SQ8 codes (1 B / element) against the symmetric int8 query image with a certified
@@ -1423,6 +1427,7 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
     fa.out_rows = r_dst ? r_dst : w.out_rows; fa.out_dists = d_dst ? d_dst : w.out_dists; fa.out_counts = w.out_counts;
     fa.out_counts2 = c2_dst;
     fa.pool_total = h->profiling ? w.pool_total : nullptr;
+    fa.overflow = w.overflow; fa.any_overflow = any_ovf;
     if (i8c) {  // a few hundred survivors per query inside the int8 margin: spread their exact rescoring over the chip
         hipLaunchKernelGGL(k_rescore_pool<256>, dim3(nq, 4), dim3(256), 0, st, fa);
         LY_HIP(hipGetLastError());
@@ -1671,6 +1676,29 @@ static bool i8c_eligible(const lynse_hip_flat* h, int metric, bool filtered, uin
 // (pre-packed).  Sources and destinations are host or device pointers according to `on_device`.
 static int search_large_k(lynse_hip_flat* h, const void* q_src, bool packed_queries, uint64_t nq, uint32_t k, int metric,
                           uint64_t* out_rows, float* out_dists, uint32_t* out_counts, bool on_device, hipStream_t user_stream);
+
+// Adds one finished search to the handle's profile: the pipeline time between its two events and the HIP-event duration of
+// every scan launch (events of the search context `cx`).
+static int prof_accumulate(lynse_hip_flat* h, lynse_hip_flat::Ctx& cx, hipEvent_t ev_begin, hipEvent_t ev_end,
+                           const std::vector<std::pair<size_t, uint64_t>>& scan_events, bool binary, uint64_t fallback_queries) {
+    LY_HIP(hipEventSynchronize(ev_end));
+    float ms = 0.f;
+    LY_HIP(hipEventElapsedTime(&ms, ev_begin, ev_end));
+    std::lock_guard<std::mutex> plk(h->prof_mu);
+    h->prof.total_us += (double)ms * 1000.0;
+    const uint64_t row_bytes = binary ? (uint64_t)h->words * 8 : (uint64_t)h->dim * 4;
+    for (auto& se : scan_events) {
+        float sms = 0.f;
+        LY_HIP(hipEventElapsedTime(&sms, cx.ev_pool[se.first], cx.ev_pool[se.first + 1]));
+        h->prof.scan_us += (double)sms * 1000.0;
+        h->prof.scan_launches += 1;
+        h->prof.scan_rows += se.second;
+        h->prof.scan_bytes += se.second * row_bytes;
+    }
+    h->prof.searches += 1;
+    h->prof.fallback_queries += fallback_queries;
+    return LYNSE_OK;
+}
 
 static int search_impl(lynse_hip_flat* h, const void* q_src, bool packed_queries, uint64_t nq, uint32_t k,
                        int metric, uint64_t* out_rows, float* out_dists, uint32_t* out_counts,
@@ -1948,22 +1976,7 @@ static int search_impl(lynse_hip_flat* h, const void* q_src, bool packed_queries
 
     if (h->profiling) {
         LY_HIP(hipEventRecord(ev_end, st));
-        LY_HIP(hipEventSynchronize(ev_end));
-        float ms = 0.f;
-        LY_HIP(hipEventElapsedTime(&ms, ev_begin, ev_end));
-        std::lock_guard<std::mutex> plk(h->prof_mu);
-        h->prof.total_us += (double)ms * 1000.0;
-        const uint64_t row_bytes = binary ? (uint64_t)h->words * 8 : (uint64_t)h->dim * 4;
-        for (auto& se : scan_events) {
-            float sms = 0.f;
-            LY_HIP(hipEventElapsedTime(&sms, cur(h).ev_pool[se.first], cur(h).ev_pool[se.first + 1]));
-            h->prof.scan_us += (double)sms * 1000.0;
-            h->prof.scan_launches += 1;
-            h->prof.scan_rows += se.second;
-            h->prof.scan_bytes += se.second * row_bytes;
-        }
-        h->prof.searches += 1;
-        h->prof.fallback_queries += fallback_queries;
+        LY_TRY(prof_accumulate(h, cur(h), ev_begin, ev_end, scan_events, binary, fallback_queries));
     }
     return LYNSE_OK;
 }
@@ -2197,10 +2210,10 @@ extern "C" int lynse_hip_merge_topk(const uint64_t* ids, const float* dists, con
     return LYNSE_OK;
 }
 
-extern "C" int lynse_hip_merge_topk_device(const void* d_blocks, uint64_t block_bytes, uint64_t rows_off,
-                                           uint64_t dists_off, uint64_t counts_off, uint32_t n_lists, uint64_t nq,
-                                           uint32_t k, int metric, uint64_t* d_out_rows, float* d_out_dists,
-                                           uint32_t* d_out_counts, void* stream) {
+static int merge_topk_device_impl(const void* d_blocks, uint64_t block_bytes, uint64_t rows_off,
+                                  uint64_t dists_off, uint64_t counts_off, uint32_t n_lists, uint64_t nq,
+                                  uint32_t k, int metric, uint64_t* d_out_rows, float* d_out_dists,
+                                  uint32_t* d_out_counts, void* stream, uint64_t status_off, uint32_t* out_status) {
     if (!metric_valid(metric)) return set_error(LYNSE_ERR_UNKNOWN_METRIC, "Unknown metric id");
     if (nq == 0) return LYNSE_OK;
     if (!d_blocks || !d_out_counts || (k && (!d_out_rows || !d_out_dists))) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "NULL argument");
@@ -2222,11 +2235,21 @@ extern "C" int lynse_hip_merge_topk_device(const void* d_blocks, uint64_t block_
     a.blocks = (const char*)d_blocks; a.block_bytes = block_bytes; a.rows_off = rows_off; a.dists_off = dists_off;
     a.counts_off = counts_off; a.n_lists = n_lists; a.k = k; a.metric = metric;
     a.out_rows = d_out_rows; a.out_dists = d_out_dists; a.out_counts = d_out_counts;
+    a.status_off = status_off; a.out_status = out_status;
     hipLaunchKernelGGL(k_merge<256>, dim3((uint32_t)nq), dim3(256), (size_t)np2 * 12, (hipStream_t)stream, a);
     LY_HIP(hipGetLastError());
     return LYNSE_OK;
 }
 
+extern "C" int lynse_hip_merge_topk_device(const void* d_blocks, uint64_t block_bytes, uint64_t rows_off,
+                                           uint64_t dists_off, uint64_t counts_off, uint32_t n_lists, uint64_t nq,
+                                           uint32_t k, int metric, uint64_t* d_out_rows, float* d_out_dists,
+                                           uint32_t* d_out_counts, void* stream) {
+    return merge_topk_device_impl(d_blocks, block_bytes, rows_off, dists_off, counts_off, n_lists, nq, k, metric, d_out_rows,
+                                  d_out_dists, d_out_counts, stream, 0, nullptr);
+}
+
 #include "ivf_host.inc"
 #include "shard_host.inc"
 #include "comm_host.inc"
+#include "async_host.inc"

@@ -225,6 +225,21 @@ class ShardedFlat:
                                               C.c_void_p(out.rows.data_ptr()), C.c_void_p(out.dists.data_ptr()),
                                               C.c_void_p(out.counts.data_ptr()), C.c_void_p(stream)))
 
+    def search_submit(self, d_queries, k: int, metric: int, out: ShardOutputs):
+        """One batch IN FLIGHT (lynse_hip_flat_search_submit_*): scan -> ncclAllGather -> merge enqueued on a search context of
+        the shard; returns a ticket whose wait() makes out.rows / dists / counts final.  A collective with world > 1 (every
+        rank submits and waits for the same sequence).  Needs the native communicator (or world == 1); without it the
+        batch is answered here and the ticket is already complete."""
+        if self.world == 1 or self.comm is not None:
+            return self.index.search_submit(d_queries, k, metric, out.rows, out.dists, out.counts,
+                                            comm=self.comm.handle if (self.world > 1 and self.comm is not None) else None)
+        self.search_device(d_queries, k, metric, out)
+
+        class _Done:
+            def wait(self):
+                return None
+        return _Done()
+
     def search(self, queries: np.ndarray, k: int, metric: int):
         """Host-array convenience wrapper around search_device."""
         import torch
