@@ -1109,6 +1109,23 @@ __global__ void __launch_bounds__(WQ * WR * 64, (TQ * TR >= 16) ? 1 : ((WQ * WR 
             if (METRIC == M_L2 || I8) qc_extra[t] = ok ? a.qn2[n] : 0.0f;
             if (METRIC == M_COS && !I8) qc_extra[t] = ok ? a.qrinv[n] : 0.0f;
             qc_thr[t] = ok ? a.thr[n] : 0.0f;
+            if constexpr (I8C) {
+                // INTEGER image of the threshold: the coarse score B_q + s_q * (float)dot is monotone non-decreasing in the
+                // integer dot product (s_q >= 0; conversion, product and sum round monotonically), so "score >= thr" is
+                // EXACTLY "dot >= T" with T = the smallest dot whose score passes — found once per launch by bisection over
+                // |dot| <= 2^29 (128 * 127 * D).  The epilogue then compares accumulators as integers: no cvt / mul / add per
+                // element.  T = 2^29 + 1: nothing passes (thr = NaN / +inf, or a query slot past nq).
+                const float s_q = qc_inv[t], b_q = qc_extra[t], th = qc_thr[t];
+                int lo = -(1 << 29), hi_ = 1 << 29;
+#pragma unroll 1
+                for (int it = 0; it < 31; ++it) {
+                    const int mid = lo + ((hi_ - lo) >> 1);
+                    const bool ge = (b_q + s_q * (float)mid) >= th;
+                    hi_ = ge ? mid : hi_;
+                    lo = ge ? lo : mid + 1;
+                }
+                qc_thr[t] = __int_as_float(ok ? lo : 0x7fffffff);
+            }
         }
     }
     const float* norm_src = (METRIC == M_L2 || I8) ? a.vn2 : a.vrinv;  // I8: a.vn2 carries the per-row int sums
@@ -1416,7 +1433,7 @@ __global__ void __launch_bounds__(WQ * WR * 64, (TQ * TR >= 16) ? 1 : ((WQ * WR 
                     c_thr[j] = c_ok[j] ? ea->thr[n] : 0.0f;
                 }
 #ifdef LYNSE_EXPERIMENTS
-                if (ea->debug_flags & 2) c_thr[j] = ASC ? -LY_INF : LY_INF;
+                if (ea->debug_flags & 2) c_thr[j] = (I8C && QC_REG) ? __int_as_float(0x7fffffff) : (ASC ? -LY_INF : LY_INF);
 #endif
                 set_pre(j, c_thr[j], e_vmax2);
                 if ((WR >= 4 || EMIT == 2) && !FILT && e_emit_all == 2 && !TILED) {  // (runtime-EMIT bodies of the <4,2,2,4> tiling and the subset-filter variants leave it out: it would spill there)
@@ -1474,6 +1491,37 @@ __global__ void __launch_bounds__(WQ * WR * 64, (TQ * TR >= 16) ? 1 : ((WQ * WR 
                                     ((mw >> bit) & 1u) ? make_key(sc, (FILT && !TILED && ea->row_ids) ? ea->row_ids[m] : m, ASC) : KEY_SENTINEL;
                         }
                     }
+                } else if (DENSE && I8C && QC_REG && !TILED && !FILT) {
+                    // ---- DENSE threshold stage of the certified int8 pass: while the threshold is loose (the first stage behind
+                    // the sample: the int8 margin keeps ~5x the rows an exact threshold would) most 32-query x 64-row blocks
+                    // hold a survivor and the two-level filter pays level 2 on top of level 1 almost always.  One pass instead:
+                    // one integer compare per accumulator against T and a wave-level branch; only elements some lane passes
+                    // build the key.  Lane-private segments as below.
+                    const uint32_t e_seg = ea->seg;
+                    uint32_t cnt = (segpk >> (8 * j)) & 0xffu;
+                    uint64_t* segdst = ea->candB + ((size_t)n * ea->nseg + ((blockIdx.x * WR + wr) * 2 + hi)) * e_seg;
+                    const int T = __float_as_int(c_thr[j]);
+#pragma unroll
+                    for (int i = 0; i < TR; ++i) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int v = __float_as_int(acc[i][j][r]);
+                            if (v >= T) {
+                                const uint32_t m = rb + wr * (TR * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                                if (m < row_end) {
+                                    const uint64_t key = make_key(c_extra[j] + c_qinv[j] * (float)v, m, ASC);
+                                    if (cnt < e_seg) {
+                                        segdst[cnt] = key;
+                                        ++cnt;
+                                    } else {
+                                        const uint32_t slot = atomicAdd(&ea->count[n], 1u);
+                                        if (slot < ea->cap) ea->cand[(size_t)n * ea->cap + slot] = key;
+                                    }
+                                }
+                            }
+                        }
+                    }
+                    segpk = (segpk & ~(0xffu << (8 * j))) | (cnt << (8 * j));
                 } else if (DENSE && !I8 && !TILED && !FILT) {
                     // ---- DENSE threshold stage (many survivors per block: large k over few rows seen so far, e.g. k = 100 on 1M
                     // rows).  The two-level filter degenerates there — nearly every 32-query x TR*32-row block holds a survivor,
@@ -1545,8 +1593,10 @@ __global__ void __launch_bounds__(WQ * WR * 64, (TQ * TR >= 16) ? 1 : ((WQ * WR 
                                 const int v = __float_as_int(acc[i][j][r]);
                                 bi = bi > v ? bi : v;
                             }
-                        // the exact score expression on the column maximum (monotone: s_q >= 0)
-                        best = c_extra[j] + c_qinv[j] * (float)bi;
+                        // the exact score expression on the column maximum (monotone: s_q >= 0) — or, with the integer image of
+                        // the threshold, the column maximum itself
+                        if constexpr (QC_REG) best = (bi >= __float_as_int(c_thr[j])) ? LY_INF : -LY_INF;
+                        else best = c_extra[j] + c_qinv[j] * (float)bi;
                     }
                     if constexpr (!I8) {
 #pragma unroll
@@ -1578,7 +1628,7 @@ __global__ void __launch_bounds__(WQ * WR * 64, (TQ * TR >= 16) ? 1 : ((WQ * WR 
                         }
                     }
                     if constexpr (!I8 && METRIC == M_IP) best = best * c_qinv[j];  // the exact expression on the column maximum (qinv > 0)
-                    const bool hit = c_ok[j] && ((I8C || (!I8 && METRIC == M_IP)) ? best >= c_thr[j] : (I8 || best >= c_pre[j]));
+                    const bool hit = c_ok[j] && ((I8C && QC_REG) ? best > 0.0f : ((I8C || (!I8 && METRIC == M_IP)) ? best >= c_thr[j] : (I8 || best >= c_pre[j])));
                     if (__ballot(hit) != 0ull) {
                     // ---- level 2: the exact expression against the exact threshold; pass masks of the block's TR x 16 rows
                     const float e_thr = c_thr[j];
@@ -1592,8 +1642,13 @@ __global__ void __launch_bounds__(WQ * WR * 64, (TQ * TR >= 16) ? 1 : ((WQ * WR 
                             const uint32_t bit = (r & 3) + 8 * (r >> 2) + 4 * hi;
                             const uint32_t m = rb + wr * (TR * 32) + i * 32 + bit;
                             const bool rok = m < row_end && ((mw >> bit) & 1u);
-                            const float sc = score(i, j, r, m, rok);
-                            bool pass = ASC ? (sc <= e_thr) : (sc >= e_thr);
+                            bool pass;
+                            if constexpr (I8C && QC_REG) {
+                                pass = __float_as_int(acc[i][j][r]) >= __float_as_int(e_thr);  // integer image of the threshold
+                            } else {
+                                const float sc = score(i, j, r, m, rok);
+                                pass = ASC ? (sc <= e_thr) : (sc >= e_thr);
+                            }
                             if (FILT && TILED && ea->mask && c_ok[j] && rok && pass)  // IVF subset filter: mask by slab position, looked up
                                 pass = (ea->mask[m >> 5] >> (m & 31)) & 1u;     // only for rows that beat the threshold
                             if (c_ok[j] && rok && pass) msk |= 1u << r;

@@ -1031,7 +1031,7 @@ static int launch_scan_h16(const ScanArgs& a, int metric, uint32_t grid, hipStre
 // (ragged last slab, emission mode)
 static int launch_scan_i8c(const ScanArgs& a, uint32_t grid, hipStream_t st) {
     constexpr size_t lds = (size_t)(3 * 256 + 2 * 256) * 128;
-    static bool attr_done[6] = {false};
+    static bool attr_done[7] = {false};
     auto go = [&](auto kern, int slot) -> int {
         if (!attr_done[slot]) { LY_TRY(set_max_lds(kern, lds)); attr_done[slot] = true; }
         hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, a);
@@ -1069,6 +1069,7 @@ static int launch_scan_i8c(const ScanArgs& a, uint32_t grid, hipStream_t st) {
         static bool pattr[2] = {false, false};
         if (a.emit_all == 0 && place == 1) { auto k = k_scan_h16<2, 4, 4, 2, M_IP, 3, 2, 2, false, false, 0, false, 2, 0, 1>; if (!pattr[0]) { LY_TRY(set_max_lds(k, lds)); pattr[0] = true; } hipLaunchKernelGGL(k, dim3(grid), dim3(512), lds, st, a); LY_HIP(hipGetLastError()); return LYNSE_OK; }
         if (a.emit_all == 0 && place == 2) { auto k = k_scan_h16<2, 4, 4, 2, M_IP, 3, 2, 2, false, false, 0, false, 2, 0, 2>; if (!pattr[1]) { LY_TRY(set_max_lds(k, lds)); pattr[1] = true; } hipLaunchKernelGGL(k, dim3(grid), dim3(512), lds, st, a); LY_HIP(hipGetLastError()); return LYNSE_OK; }
+        if (a.emit_all == 0 && a.dense) return go(k_scan_h16<2, 4, 4, 2, M_IP, 3, 2, 2, false, false, 0, false, 2, 0, 0, true>, 6);
         if (a.emit_all == 0) return go(k_scan_h16<2, 4, 4, 2, M_IP, 3, 2, 2, false, false, 0, false, 2, 0>, 0);
         if (a.emit_all == 1) return go(k_scan_h16<2, 4, 4, 2, M_IP, 3, 2, 2, false, false, 0, false, 2, 1>, 1);
         return go(k_scan_h16<2, 4, 4, 2, M_IP, 3, 2, 2, false, false, 0, false, 2, 2>, 2);
@@ -1329,7 +1330,14 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
             if (i8c) {
                 a.candB = w.candB; a.segcnt = w.segcnt;
                 const uint32_t grid = std::min<uint32_t>(a.ntiles, (uint32_t)h->num_cu);
-                if (!a.emit_all) seg_geometry(grid, 4, &a.nseg, &a.seg);
+                // DENSE epilogue while the threshold is loose (kernels.h): the int8 margin keeps ~5x the rows an exact threshold
+                // would, so a 32-query x 64-row block holds a survivor with probability ~ 2048 * 5 k / rows-seen-before; above
+                // ~0.2 one integer compare per accumulator beats level 1 + (mostly) level 2.  Segments are per wave half then.
+                static const int dense_env = []() { const char* e = getenv("LYNSE_HIP_DENSE"); return e ? atoi(e) : -1; }();
+                const uint64_t seen_before = s.sample_tiles ? 0 : (sample.sample_tiles ? std::max<uint64_t>((uint64_t)sample.sample_tiles * plan_tile, s.r0) : s.r0);
+                a.dense = (!a.emit_all && a.ld16 % 128 == 0 && seen_before &&
+                           (dense_env >= 0 ? dense_env != 0 : (uint64_t)k * 50000ull > seen_before)) ? 1 : 0;
+                if (!a.emit_all) seg_geometry(grid, a.dense ? 8 : 4, &a.nseg, &a.seg);
                 LY_TRY(launch_scan_i8c(a, grid, st));
             } else if (h16) {
                 a.candB = w.candB; a.segcnt = w.segcnt;
