@@ -58,10 +58,11 @@ def parse_args():
     p.add_argument("--verify-queries", type=int, default=16)
     p.add_argument("--stage0", type=int, default=0, help="override the stage-0 row count of the scan plan")
     p.add_argument("--growth", type=int, default=0, help="override the stage growth factor of the scan plan")
+    p.add_argument("--profile-every", type=int, default=4, help="HIP-event timing of the scan launches on every n-th step of the timed region")
     p.add_argument("--in-flight", type=int, default=int(os.environ.get("LYNSE_BENCH_IN_FLIGHT", "0")),
                    help="batches in flight (lynse_hip_flat_search_submit_* / _wait): step i+1 is enqueued before step i is waited "
                         "for; 1 = the blocking entry points (one host round trip per step); 0 = default: 1 on one GPU (the "
-                        "kernel durations of the roofline stay undisturbed; in flight gains 1 %% there), 3 on a sharded collection")
+                        "kernel durations of the roofline stay undisturbed; in flight gains < 1 %% there), 2 on a sharded collection")
     return p.parse_args()
 
 
@@ -146,7 +147,7 @@ def main():
     # here step i+1 is ENQUEUED (scan -> selects -> rescoring [-> all-gather -> merge]) before step i is waited for, each on
     # its own search context and output buffers.  Every one of the K steps is complete — overflow flags checked, results
     # final — inside the timed region.
-    in_flight = max(1, min(args.in_flight, 4)) if args.in_flight > 0 else (1 if world == 1 else 3)
+    in_flight = max(1, min(args.in_flight, 4)) if args.in_flight > 0 else (1 if world == 1 else 2)
     outs = [sh.alloc_outputs(B, K) for _ in range(in_flight)]
     out = outs[0]
 
@@ -169,7 +170,9 @@ def main():
         torch.cuda.synchronize()
 
     run_steps(args.warmup)
-    sh.index.profile_enable(True)
+    # HIP events around the scan launches of every 4th step inside the timed region (each recorded event costs the stream a
+    # few microseconds: timing every step added 30-40 us to each)
+    sh.index.profile_enable(args.profile_every)
     sh.index.profile_get(reset=True)
     barrier()
     t_start = time.perf_counter()
@@ -205,7 +208,8 @@ def main():
         # one pass over the shard serves the whole batch -> algorithmic bytes per step = rows x row bytes.
         # (The launches of a step also re-scan the 65536 sample rows of the first stage: time counted, bytes not.)
         row_bytes = D * 4 if metric < 3 else ((D + 63) // 64) * 8
-        alg_bytes = float(n_local) * row_bytes * args.steps
+        timed_steps = max(int(prof["searches"]), 1)   # the steps whose launches carry HIP events (every --profile-every-th)
+        alg_bytes = float(n_local) * row_bytes * timed_steps
         alg_gbps = (alg_bytes / scan_s / 1e9) if scan_s > 0 else 0.0
         prof["scan_bytes"] = int(alg_bytes)
         plan = int(prof.get("last_plan", 0))
@@ -217,10 +221,10 @@ def main():
             kernel_bytes = alg_bytes
         elif i8c:
             kernel, elem_bytes, mfma_peak, mfma_unit = "k_scan_h16<2,4,4,2,IP,i8c>", 1, MFMA_I8_PEAK_TOPS, "TOP/s"
-            kernel_bytes = float(n_local) * (-(-D // 16) * 16) * args.steps
+            kernel_bytes = float(n_local) * (-(-D // 16) * 16) * timed_steps
         else:
             kernel, elem_bytes, mfma_peak, mfma_unit = "k_scan_h16<f16>", 2, MFMA_F16_PEAK_TFLOPS, "TFLOP/s"
-            kernel_bytes = float(n_local) * (-(-D // 8) * 8) * 2 * args.steps
+            kernel_bytes = float(n_local) * (-(-D // 8) * 8) * 2 * timed_steps
         hbm_gbps = (kernel_bytes / scan_s / 1e9) if scan_s > 0 else 0.0
         # matrix work of the launches (sample rows included: they are really multiplied)
         ops = 2.0 * B * prof["scan_rows"] * D if metric < 3 else 0.0
@@ -251,10 +255,10 @@ def main():
             "algorithmic": {"achieved": round(alg_gbps, 1), "unit": "GB/s", "frac_of_hbm_peak": round(alg_gbps / HBM_PEAK_GBPS, 4),
                             "bytes_per_launch": int(alg_bytes // launches)},
             "launches": launches, "avg_launch_us": round(prof["scan_us"] / launches, 2),
-            "launches_per_step": round(launches / max(args.steps, 1), 2),
+            "launches_per_step": round(launches / timed_steps, 2), "timed_steps": timed_steps,
             "plan": {"sampled": bool(plan & 1), "threshold_only_sample": bool(plan & 2), "int8_coarse_pass": i8c,
                      "segmented_emission": bool(plan & 8), "stages": (plan >> 8) & 0xff, "tiling": hex((plan >> 16) & 0xff)},
-            "note": "rank-0 shard; time = sum of HIP-event durations of the scan launches on the launch stream inside the timed region",
+            "note": "rank-0 shard; time = sum of HIP-event durations of the scan launches on the launch stream, every %d-th step of the timed region" % max(args.profile_every, 1),
         }
         result = {
             "metric": "queries/sec, FLAT-%s %dx%d float32, batch=%d, k=%d" % (args.metric.upper(), N, D, B, K),

@@ -185,7 +185,8 @@ int lynse_hip_flat_search_packed_u64_device(lynse_hip_flat *h, const uint64_t *d
                                             uint64_t *d_out_rows, float *d_out_dists,
                                             uint32_t *d_out_counts, void *stream);
 
-/* Profiling: when enabled, searches bracket the scan kernel with HIP events on its stream. */
+/* Profiling: when enabled, searches bracket the scan kernel with HIP events on its stream.  on = n > 1 times every n-th
+ * search only (an event recorded between two kernels costs a few microseconds of the stream's time). */
 int lynse_hip_flat_profile_enable(lynse_hip_flat *h, int on);
 int lynse_hip_flat_profile_get(lynse_hip_flat *h, lynse_hip_profile *out, int reset);
 /* Tuning knobs (defaults are fine): first-stage rows and growth factor of the contiguous stage plan (the fallback of the

@@ -316,8 +316,9 @@ class FlatIndex:
         return SearchTicket(t, (d_queries, d_rows, d_dists, d_counts))
 
     # -- profiling ----------------------------------------------------------------------------
-    def profile_enable(self, on: bool = True) -> None:
-        check(lib.lynse_hip_flat_profile_enable(self._h, 1 if on else 0))
+    def profile_enable(self, on=True) -> None:
+        """True / 1: time every search; n > 1: every n-th search (HIP events between the kernels cost microseconds); False: off."""
+        check(lib.lynse_hip_flat_profile_enable(self._h, int(on)))
 
     def profile_get(self, reset: bool = True) -> dict:
         p = _lib.Profile()

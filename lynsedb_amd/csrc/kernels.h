@@ -2949,6 +2949,10 @@ struct FinalArgs {
     // word that travels with the result block (the host looks at it when the ticket is waited for); NULL otherwise
     const uint32_t* overflow;
     uint32_t* any_overflow;
+    // pinned host header of the search context: counts in [0, hdr_q), overflow flags in [hdr_q, 2 hdr_q) — written here instead
+    // of being copied back by a copy kernel behind the search; NULL = not wanted
+    uint32_t* h_hdr;
+    uint32_t hdr_q;
 };
 
 // k_rescore_pool: the exact rescoring of k_final spread over gridDim.y blocks per query (IVF on tightly clustered
@@ -3005,6 +3009,7 @@ __global__ void __launch_bounds__(NT) k_final(FinalArgs a) {
         if (a.out_counts2) a.out_counts2[q] = cnt;
         if (a.pool_total) atomicAdd(a.pool_total, (unsigned long long)n);
         if (a.any_overflow && a.overflow[q]) atomicOr(a.any_overflow, 1u);
+        if (a.h_hdr) { a.h_hdr[q] = cnt; a.h_hdr[a.hdr_q + q] = a.overflow[q]; }
     }
 }
 

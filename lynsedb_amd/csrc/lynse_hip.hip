@@ -250,9 +250,12 @@ struct lynse_hip_flat {
     uint64_t g_cap = 0;
 
     bool profiling = false;
+    uint32_t prof_rate = 1;              // every prof_rate-th search records its events (lynse_hip_flat_profile_enable(h, n))
+    std::atomic<uint32_t> prof_seq{0};
     lynse_hip_profile prof{};
 };
 
+static thread_local bool tl_prof = false;   // the search running on this thread records profile events (profile_begin_search)
 static thread_local int tl_ctx_slot = 0;   // the search context of the calling thread (0 outside a concurrent search)
 static inline lynse_hip_flat::Ctx& cur(lynse_hip_flat* h) { return h->ctx[tl_ctx_slot]; }
 static inline const lynse_hip_flat::Ctx& cur(const lynse_hip_flat* h) { return h->ctx[tl_ctx_slot]; }
@@ -293,6 +296,12 @@ struct CtxLease {
     }
     ~CtxLease() { release(); }
 };
+
+// decides whether the search starting on this thread is a timed one (profiling on, and its turn at the sampling rate)
+static bool profile_begin_search(lynse_hip_flat* h) {
+    tl_prof = h->profiling && (h->prof_rate <= 1 || h->prof_seq.fetch_add(1) % h->prof_rate == 0);
+    return tl_prof;
+}
 
 static int use_device(const lynse_hip_flat* h) {
     LY_HIP(hipSetDevice(h->device));
@@ -684,6 +693,8 @@ extern "C" int lynse_hip_flat_profile_enable(lynse_hip_flat* h, int on) {
     if (!h) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "handle is NULL");
     std::unique_lock<std::shared_mutex> lk(h->rw);
     h->profiling = on != 0;
+    h->prof_rate = on > 1 ? (uint32_t)on : 1u;   // on = n > 1: every n-th search is timed (HIP events between the kernels cost a few us each)
+    h->prof_seq.store(0);
     return LYNSE_OK;
 }
 
@@ -1174,13 +1185,18 @@ static int get_event(lynse_hip_flat* h, size_t idx, hipEvent_t* out) {
 static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k, int metric, int level, hipStream_t st,
                      size_t* ev_used, std::vector<std::pair<size_t, uint64_t>>* scan_events, bool* sampled_plan,
                      const uint32_t* mask = nullptr, const uint32_t* row_ids = nullptr, bool i8c = false,
-                     uint64_t* r_dst = nullptr, float* d_dst = nullptr, uint32_t* c2_dst = nullptr, uint32_t* any_ovf = nullptr) {
+                     uint64_t* r_dst = nullptr, float* d_dst = nullptr, uint32_t* c2_dst = nullptr, uint32_t* any_ovf = nullptr,
+                     const float* qsrc = nullptr, bool hdr_direct = false) {
+    // qsrc: the float queries of the chunk when they already live in device memory that stays valid for the whole search (no
+    // staging copy into the workspace); nullptr = w.Qf.  hdr_direct: k_final writes counts + overflow flags straight into the
+    // pinned header of the context (no copy kernel behind the search)
     // any_ovf: device status word k_final ORs the overflow flags into (searches in flight), or nullptr
     // r_dst / d_dst / c2_dst: where k_final writes rows, distances (stride out_k) and a second copy of the counts — the
     // caller's device arrays or the pinned staging buffer; nullptr = the workspace (copied out by the caller)
     // i8c: the coarse pass streams the SQ8 codes (1 B / element) against the symmetric int8 query image with a certified
     // error bound (k_i8c_prep_queries) instead of the f16 shadow — FLAT-IP batches of 33..256 queries
     Workspace& w = cur(h).ws;
+    const float* Qf = qsrc ? qsrc : w.Qf;
     const bool binary = metric >= M_HAMMING;
     const bool asc = metric_ascending(metric);
     const bool h16 = scan_variant() == 3;
@@ -1210,9 +1226,10 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
         LY_HIP(hipMemsetAsync(w.overflow, 0, nq * 4, st));
         LY_HIP(hipStreamSynchronize(st));  // thr0 is a stack/heap temporary
     } else if (i8c) {
-        LY_HIP(hipMemsetAsync(w.Q16, 0, (size_t)nslab * qpad * 128, st));
+        if (nq != qpad || h->dim % 128 != 0)  // (a full chunk of whole slabs overwrites every byte of the image)
+            LY_HIP(hipMemsetAsync(w.Q16, 0, (size_t)nslab * qpad * 128, st));
         I8cPrepArgs p{};
-        p.Q = w.Qf; p.D = h->dim; p.qpad = qpad; p.nslab = nslab; p.mins = h->sq8_mins; p.scales = h->sq8_scales;
+        p.Q = Qf; p.D = h->dim; p.qpad = qpad; p.nslab = nslab; p.mins = h->sq8_mins; p.scales = h->sq8_scales;
         p.a1 = h->sq8_a1; p.vmax = h->vmax; p.img = reinterpret_cast<int8_t*>(w.Q16);
         p.sq = w.qinv; p.bq = w.qn2; p.marg2 = w.marg2; p.thr = w.thr; p.count = w.count; p.overflow = w.overflow;
         hipLaunchKernelGGL(k_i8c_prep_queries, dim3(nq), dim3(256), 0, st, p);
@@ -1221,7 +1238,7 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
         // queries with index >= nq inside the padded tile must be finite: zero the image
         LY_HIP(hipMemsetAsync(w.Q16, 0, (size_t)nslab * qpad * (glds ? GL_BK : (h16 ? HK : SCAN_LDK)) * sizeof(_Float16), st));
         PrepArgs p{};
-        p.Q = w.Qf; p.D = h->dim; p.nq = nq; p.qpad = qpad; p.nslab = nslab; p.metric = metric; p.layout = glds ? 1 : (h16 ? 2 : 0);
+        p.Q = Qf; p.D = h->dim; p.nq = nq; p.qpad = qpad; p.nslab = nslab; p.metric = metric; p.layout = glds ? 1 : (h16 ? 2 : 0);
         p.sv = h->sv; p.vmax = h->vmax; p.vmin = h->vmin; p.cos_degenerate = h->cos_degenerate;
         p.Q16 = w.Q16; p.qinv = w.qinv; p.qn2 = w.qn2; p.qrinv = w.qrinv; p.marg2 = w.marg2; p.thr = w.thr;
         p.count = w.count; p.overflow = w.overflow;
@@ -1263,7 +1280,7 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
         const Stage s = plan[si];
         const bool emit_all = si == 0;
         hipEvent_t e0 = nullptr, e1 = nullptr;
-        if (h->profiling) {
+        if (tl_prof) {
             LY_TRY(get_event(h, (*ev_used)++, &e0));
             LY_TRY(get_event(h, (*ev_used)++, &e1));
             LY_HIP(hipEventRecord(e0, st));
@@ -1400,7 +1417,7 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
             st_nseg = a.seg ? a.nseg : 0; st_seg = a.seg;
             plan_used_segments = plan_used_segments || a.seg != 0;
         }
-        if (h->profiling) {
+        if (tl_prof) {
             LY_HIP(hipEventRecord(e1, st));
             scan_events->push_back({*ev_used - 2, s.sample_tiles ? (uint64_t)s.sample_tiles * plan_tile : (uint64_t)(s.r1 - s.r0)});
         }
@@ -1418,24 +1435,25 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
             sa.drop_sentinels = 1;  // a lane whose rows are all masked / out of range wrote the sentinel
             sa.emit_all_n = (int)(s.sample_tiles * sample_keys_per_tile);
         }
-        sa.Qf = w.Qf; sa.V = h->rows; sa.ld = h->ld; sa.D = h->dim;
+        sa.Qf = Qf; sa.V = h->rows; sa.ld = h->ld; sa.D = h->dim;
         sa.candB = w.candB; sa.segcnt = w.segcnt; sa.seg = st_seg; sa.nseg = st_nseg;
         hipLaunchKernelGGL(k_select<SEL_NT>, dim3(nq), dim3(SEL_NT), (size_t)w.cap * 8, st, sa);
         LY_HIP(hipGetLastError());
     }
-    if (h->profiling && !binary) {
+    if (tl_prof && !binary) {
         const uint64_t tiling = small ? 0x14u : ((waves16 == 3 || waves16 == 2) ? 0x24u : 0x42u);
         h->prof.last_plan = (sample.sample_tiles ? 1u : 0u) | ((sample.sample_tiles && sample_threshold_only) ? 2u : 0u) | (i8c ? 4u : 0u) |
                             (plan_used_segments ? 8u : 0u) | (small ? 16u : 0u) | ((uint64_t)(plan.size() & 0xff) << 8) | (tiling << 16);
     }
     FinalArgs fa{};
     fa.cand = w.cand; fa.count = w.count; fa.k = k; fa.out_k = out_k; fa.cap = w.cap; fa.metric = metric; fa.ip_form = ip_form;
-    fa.exact = binary ? 1 : 0; fa.Qf = w.Qf; fa.V = h->rows; fa.ld = h->ld; fa.D = h->dim;
+    fa.exact = binary ? 1 : 0; fa.Qf = Qf; fa.V = h->rows; fa.ld = h->ld; fa.D = h->dim;
     fa.row_stride = h->row_stride; fa.row_offset = h->row_offset;
     fa.out_rows = r_dst ? r_dst : w.out_rows; fa.out_dists = d_dst ? d_dst : w.out_dists; fa.out_counts = w.out_counts;
     fa.out_counts2 = c2_dst;
-    fa.pool_total = h->profiling ? w.pool_total : nullptr;
+    fa.pool_total = tl_prof ? w.pool_total : nullptr;
     fa.overflow = w.overflow; fa.any_overflow = any_ovf;
+    if (hdr_direct) { fa.h_hdr = w.h_hdr; fa.hdr_q = w.qcap; }
     if (i8c) {  // a few hundred survivors per query inside the int8 margin: spread their exact rescoring over the chip
         hipLaunchKernelGGL(k_rescore_pool<256>, dim3(nq, 4), dim3(256), 0, st, fa);
         LY_HIP(hipGetLastError());
@@ -1486,7 +1504,7 @@ static int run_small(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
     static bool small_attr = false;
     if (!small_attr) { LY_TRY(set_max_lds(k_small_search, 160 * 1024 - 1024)); small_attr = true; }
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    const bool timed = h->profiling && ev_used && scan_events;
+    const bool timed = tl_prof && ev_used && scan_events;
     if (timed) {
         LY_TRY(get_event(h, (*ev_used)++, &e0));
         LY_TRY(get_event(h, (*ev_used)++, &e1));
@@ -1720,6 +1738,7 @@ static int search_impl(lynse_hip_flat* h, const void* q_src, bool packed_queries
     if (nq == 0) return LYNSE_OK;
     if (!q_src || !out_counts || (k && (!out_rows || !out_dists))) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "NULL argument");
     LY_TRY(use_device(h));
+    profile_begin_search(h);
     const bool binary = metric >= M_HAMMING;
     // Locking: an unfiltered search over a shard whose derived data (row statistics, f16 shadow, packed words, SQ8 codes of
     // the int8 coarse pass) is up to date runs under the SHARED lock on a search context of its own; anything that has to
@@ -1895,7 +1914,7 @@ static int search_impl(lynse_hip_flat* h, const void* q_src, bool packed_queries
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     size_t ev_used = 0;
     std::vector<std::pair<size_t, uint64_t>> scan_events;
-    if (h->profiling) {
+    if (tl_prof) {
         LY_TRY(get_event(h, ev_used++, &ev_begin));
         LY_TRY(get_event(h, ev_used++, &ev_end));
         LY_HIP(hipEventRecord(ev_begin, st));
@@ -1917,9 +1936,10 @@ static int search_impl(lynse_hip_flat* h, const void* q_src, bool packed_queries
                 hipLaunchKernelGGL(k_pack_bits, dim3((nqc + 3) / 4), dim3(256), 0, st, w.Qf, h->dim, h->dim, nqc, w.QW, h->words);
                 LY_HIP(hipGetLastError());
             }
-        } else if (!(on_device && small_path_ok(h, nqc, kk, metric, filtered))) {  // (the fused search reads device queries in place)
+        } else if (!on_device) {  // (device queries are read in place: they stay valid for the whole call)
             LY_HIP(hipMemcpyAsync(w.Qf, (const float*)q_src + q0 * h->dim, (size_t)nqc * h->dim * 4, in_kind, st));
         }
+        const float* qsrc = (on_device && !binary) ? (const float*)q_src + q0 * h->dim : nullptr;
         // certified int8 coarse pass: FLAT-IP batches of 33..256 queries over an f32 shard with finite values (auto: shards
         // of >= 64K rows; LYNSE_HIP_COARSE=i8 / f16 forces / disables it).  An overflow first retries the f16 coarse pass;
         // three such strikes turn the int8 pass off for this handle (margins too wide for this data).
@@ -1956,13 +1976,12 @@ static int search_impl(lynse_hip_flat* h, const void* q_src, bool packed_queries
             uint64_t* r_dst = on_device ? out_rows + q0 * k : (staged ? reinterpret_cast<uint64_t*>(w.h_out) : nullptr);
             float* d_dst = on_device ? out_dists + q0 * k : (staged ? reinterpret_cast<float*>(w.h_out + rows_b) : nullptr);
             LY_TRY(run_chunk(h, nqc, kk, k, metric, level, st, &ev_used, &scan_events, &sampled, mask, direct ? h->g_ids32 : nullptr, i8c,
-                             r_dst, d_dst, on_device ? out_counts + q0 : nullptr));
+                             r_dst, d_dst, on_device ? out_counts + q0 : nullptr, nullptr, qsrc, true));
             if (!on_device && !staged) {
                 LY_HIP(hipMemcpyAsync(out_rows + q0 * k, w.out_rows, rows_b, out_kind, st));
                 LY_HIP(hipMemcpyAsync(out_dists + q0 * k, w.out_dists, dists_b, out_kind, st));
             }
-            LY_HIP(hipMemcpyAsync(w.h_hdr, w.out_counts, (size_t)2 * w.qcap * 4, hipMemcpyDeviceToHost, st));  // counts + overflow flags
-            LY_HIP(hipStreamSynchronize(st));
+            LY_HIP(hipStreamSynchronize(st));  // (counts + overflow flags: written into the pinned header by k_final)
             uint32_t nov = 0;
             for (uint32_t i = 0; i < nqc; ++i) nov += w.h_hdr[w.qcap + i] ? 1 : 0;
             if (nov == 0) {
@@ -1982,7 +2001,7 @@ static int search_impl(lynse_hip_flat* h, const void* q_src, bool packed_queries
         if (!on_device) memcpy(out_counts + q0, w.h_hdr, nqc * 4);
     }
 
-    if (h->profiling) {
+    if (tl_prof) {
         LY_HIP(hipEventRecord(ev_end, st));
         LY_TRY(prof_accumulate(h, cur(h), ev_begin, ev_end, scan_events, binary, fallback_queries));
     }
