@@ -62,7 +62,7 @@ def parse_args():
     p.add_argument("--in-flight", type=int, default=int(os.environ.get("LYNSE_BENCH_IN_FLIGHT", "0")),
                    help="batches in flight (lynse_hip_flat_search_submit_* / _wait): step i+1 is enqueued before step i is waited "
                         "for; 1 = the blocking entry points (one host round trip per step); 0 = default: 1 on one GPU (the "
-                        "kernel durations of the roofline stay undisturbed; in flight gains < 1 %% there), 2 on a sharded collection")
+                        "kernel durations of the roofline stay undisturbed; in flight gains < 1 %% there), 3 on a sharded collection")
     return p.parse_args()
 
 
@@ -147,7 +147,7 @@ def main():
     # here step i+1 is ENQUEUED (scan -> selects -> rescoring [-> all-gather -> merge]) before step i is waited for, each on
     # its own search context and output buffers.  Every one of the K steps is complete — overflow flags checked, results
     # final — inside the timed region.
-    in_flight = max(1, min(args.in_flight, 4)) if args.in_flight > 0 else (1 if world == 1 else 2)
+    in_flight = max(1, min(args.in_flight, 4)) if args.in_flight > 0 else (1 if world == 1 else 3)
     outs = [sh.alloc_outputs(B, K) for _ in range(in_flight)]
     out = outs[0]
 
