@@ -148,6 +148,8 @@ def main():
     # its own search context and output buffers.  Every one of the K steps is complete — overflow flags checked, results
     # final — inside the timed region.
     in_flight = max(1, min(args.in_flight, 4)) if args.in_flight > 0 else (1 if world == 1 else 3)
+    if world > 1 and not native:
+        in_flight = 1   # (the torch.distributed fallback of the exchange is a blocking collective)
     outs = [sh.alloc_outputs(B, K) for _ in range(in_flight)]
     out = outs[0]
 
