@@ -2028,6 +2028,61 @@ __global__ void __launch_bounds__(256) k_scan_binary(BinArgs a) {
     }
 }
 
+// k_scan_binary_wide: packed rows WIDER than 4096 bits (the register-resident kernels hold at most 64 words per row; the
+// reference has no width limit: BinaryData rows are ceil(D/64) words, flat_mmap.rs:145-160).  Eight lanes own one row and
+// walk its words with stride 8 for every query — row words come back through L1 / L2 once per query, query words and
+// thresholds are read from global memory.  A correctness path for rare shapes, not a tuned one.
+template <int KIND>  // 0 hamming, 1 jaccard/tanimoto, 2 dice
+__global__ void __launch_bounds__(256) k_scan_binary_wide(BinArgs a) {
+    const int tid = threadIdx.x, g = tid & 7;
+    for (uint32_t rb = a.row0 + blockIdx.x * 32; rb < a.row1; rb += gridDim.x * 32) {
+        const uint32_t row = rb + (tid >> 3);
+        const bool valid = row < a.row1 && (!a.mask || ((a.mask[row >> 5] >> (row & 31)) & 1u));
+        const uint64_t* rp = a.P + (size_t)(row < a.row1 ? row : a.row0) * a.W;
+        uint32_t popr = 0;
+        if (KIND == 2)
+            for (uint32_t w = g; w < a.W; w += 8) popr += __popcll(rp[w]);
+        for (uint32_t q = 0; q < a.nq; ++q) {
+            const uint64_t* qp = a.QW + (size_t)q * a.W;
+            uint32_t c0 = 0, c1 = 0;
+            for (uint32_t w = g; w < a.W; w += 8) {
+                const uint64_t x = qp[w], r = rp[w];
+                if (KIND == 0) {
+                    c0 += __popcll(x ^ r);
+                } else if (KIND == 1) {
+                    c0 += __popcll(x & r);
+                    c1 += __popcll(x | r);
+                } else {
+                    c0 += __popcll(x & r);
+                    c1 += __popcll(x);
+                }
+            }
+            if (KIND == 2) c1 += popr;
+            c0 += __shfl_xor(c0, 1, 8);
+            c0 += __shfl_xor(c0, 2, 8);
+            c0 += __shfl_xor(c0, 4, 8);
+            if (KIND != 0) {
+                c1 += __shfl_xor(c1, 1, 8);
+                c1 += __shfl_xor(c1, 2, 8);
+                c1 += __shfl_xor(c1, 4, 8);
+            }
+            if (g == 0 && row < a.row1) {
+                float dist;
+                if (KIND == 0) dist = (float)c0;
+                else if (KIND == 1) dist = c1 == 0 ? 0.0f : __fsub_rn(1.0f, __fdiv_rn((float)c0, (float)c1));
+                else dist = c1 == 0 ? 0.0f : __fsub_rn(1.0f, __fdiv_rn((float)(2u * c0), (float)c1));
+                if (a.emit_all) {
+                    const uint32_t slot = row - a.row0;
+                    if (slot < a.cap) a.cand[(size_t)q * a.cap + slot] = valid ? make_key(dist, row, true) : KEY_SENTINEL;
+                } else if (valid && dist <= a.thr[q]) {
+                    const uint32_t slot = atomicAdd(&a.count[q], 1u);
+                    if (slot < a.cap) a.cand[(size_t)q * a.cap + slot] = make_key(dist, row, true);
+                }
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // k_scan_binary_rows: the BATCHED packed-binary scan (nq >= a few).  With many queries the 8-lanes-per-
 // row kernel above is bound by its cross-lane reductions and LDS query reads, not by HBM; here ONE LANE

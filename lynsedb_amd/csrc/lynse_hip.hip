@@ -1136,6 +1136,17 @@ static int launch_scan_binary(const BinArgs& a, int metric, uint32_t grid, size_
     }
 }
 
+// rows wider than 4096 bits (k_scan_binary_wide): no LDS, no register-resident words
+static int launch_scan_binary_wide(const BinArgs& a, int metric, uint32_t grid, hipStream_t st) {
+    switch (metric) {
+    case M_HAMMING: hipLaunchKernelGGL(k_scan_binary_wide<0>, dim3(grid), dim3(256), 0, st, a); break;
+    case M_DICE: hipLaunchKernelGGL(k_scan_binary_wide<2>, dim3(grid), dim3(256), 0, st, a); break;
+    default: hipLaunchKernelGGL(k_scan_binary_wide<1>, dim3(grid), dim3(256), 0, st, a); break;
+    }
+    LY_HIP(hipGetLastError());
+    return LYNSE_OK;
+}
+
 // lane-per-row batched kernel: WCAP = the power of two >= words
 template <int KIND>
 static int launch_scan_binary_rows_k(const BinArgs& a, uint32_t grid, hipStream_t st) {
@@ -1292,7 +1303,11 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
             b.thr = w.thr; b.cand = w.cand; b.count = w.count; b.cap = w.cap; b.emit_all = emit_all ? 1 : 0;
             b.mask = mask;
             static const int rows_minq = []() { const char* e = getenv("LYNSE_HIP_BIN_ROWS_MINQ"); return e ? atoi(e) : 1; }();
-            if ((int)nq >= rows_minq || mask) {  // batched: lane-per-row, scalar query words
+            if (h->words > 16u * BIN_MAX_CHUNKS) {  // wider than 4096 bits: the generic strided kernel
+                const uint32_t groups = (s.r1 - s.r0 + 31) / 32;
+                const uint32_t grid = std::max<uint32_t>(1, std::min<uint32_t>(groups, (uint32_t)h->num_cu * 8));
+                LY_TRY(launch_scan_binary_wide(b, metric, grid, st));
+            } else if ((int)nq >= rows_minq || mask) {  // batched: lane-per-row, scalar query words
                 uint32_t wcap = 1;
                 while (wcap < h->words) wcap <<= 1;
                 if (wcap != h->words) {
@@ -1701,7 +1716,9 @@ static bool i8c_eligible(const lynse_hip_flat* h, int metric, bool filtered, uin
 // Shared driver: q_src is nq x dim f32 (float metrics / f32 binary queries) or nq x words u64
 // (pre-packed).  Sources and destinations are host or device pointers according to `on_device`.
 static int search_large_k(lynse_hip_flat* h, const void* q_src, bool packed_queries, uint64_t nq, uint32_t k, int metric,
-                          uint64_t* out_rows, float* out_dists, uint32_t* out_counts, bool on_device, hipStream_t user_stream);
+                          uint64_t* out_rows, float* out_dists, uint32_t* out_counts, bool on_device, hipStream_t user_stream,
+                          const uint64_t* subset = nullptr, uint64_t n_subset = 0, bool filtered = false,
+                          const uint64_t* bitset_words = nullptr, uint64_t n_words = 0);
 
 // Adds one finished search to the handle's profile: the pipeline time between its two events and the HIP-event duration of
 // every scan launch (events of the search context `cx`).
@@ -1756,6 +1773,9 @@ static int search_impl(lynse_hip_flat* h, const void* q_src, bool packed_queries
     // server caps at MAX_TOP_K = 10,000, src/server/mod.rs:46): row ranges of `cap` rows, each answered exactly, merged
     if (!caller_holds_exclusive && !filtered && h->n > h->cap && std::min<uint64_t>(k, h->n) > h->cap / 4)
         return search_large_k(h, q_src, packed_queries, nq, k, metric, out_rows, out_dists, out_counts, on_device, user_stream);
+    if (!caller_holds_exclusive && filtered && h->n > h->cap && std::min<uint64_t>(std::min<uint64_t>(k, h->n), n_subset) > h->cap / 4)
+        return search_large_k(h, q_src, packed_queries, nq, k, metric, out_rows, out_dists, out_counts, on_device, user_stream,
+                              subset, n_subset, true, bitset_words, n_words);
     if (!filtered && !user_stream && !caller_holds_exclusive) {
         rlk.lock();
         if (derived_ready()) {
@@ -1786,10 +1806,7 @@ static int search_impl(lynse_hip_flat* h, const void* q_src, bool packed_queries
     if (filtered) kk = (uint32_t)std::min<uint64_t>(kk, n_subset);  // k.min(subset.len()), flat_mmap.rs:501
     if (h->n > h->cap && kk > h->cap / 4)
         return set_error(LYNSE_ERR_UNSUPPORTED, "k > cap/4 over more than cap rows is not supported together with a subset filter");
-    if (binary && h->words > 16u * BIN_MAX_CHUNKS)
-        return set_error(LYNSE_ERR_UNSUPPORTED, "packed-binary rows wider than 4096 bits are not supported yet");
-    if (binary && (size_t)QCHUNK * h->words * 8 + QCHUNK * 4 > 150 * 1024)
-        return set_error(LYNSE_ERR_UNSUPPORTED, "packed query tile exceeds LDS");
+    // (rows wider than 4096 bits run on k_scan_binary_wide: no LDS tile, no register-resident words)
 
     if (binary) LY_TRY(ensure_packed_locked(h));
     else LY_TRY(finalize_locked(h));
@@ -2012,8 +2029,11 @@ static int search_impl(lynse_hip_flat* h, const void* q_src, bool packed_queries
 // range is searched through a temporary VIEW of the handle (pointers advanced to the range, row map offset), and the sorted
 // per-range lists are merged on the host in the canonical (distance, row) order (VectorStore::merge_results semantics,
 // vector_store.rs:953-970 — the reference's own segments are merged the same way).  Exclusive: the view borrows the handle.
+// With a subset filter (search_filtered, flat_mmap.rs:498-560: k.min(subset.len())) every range is searched with the ids of
+// the subset that fall into it.
 static int search_large_k(lynse_hip_flat* h, const void* q_src, bool packed_queries, uint64_t nq, uint32_t k, int metric,
-                          uint64_t* out_rows, float* out_dists, uint32_t* out_counts, bool on_device, hipStream_t user_stream) {
+                          uint64_t* out_rows, float* out_dists, uint32_t* out_counts, bool on_device, hipStream_t user_stream,
+                          const uint64_t* subset, uint64_t n_subset, bool filtered, const uint64_t* bitset_words, uint64_t n_words) {
     std::unique_lock<std::shared_mutex> xlk(h->rw);
     LY_TRY(use_device(h));
     const bool binary = metric >= M_HAMMING;
@@ -2022,9 +2042,31 @@ static int search_large_k(lynse_hip_flat* h, const void* q_src, bool packed_quer
     if (binary) LY_TRY(ensure_packed_locked(h));
     else LY_TRY(finalize_locked(h));
     const uint64_t n = h->n, R = h->cap;
-    const uint32_t kk = (uint32_t)std::min<uint64_t>(k, n);
+    // the subset as a sorted set of valid row ids (a BitSet's to_vec; ids >= n are skipped, duplicates count once)
+    std::vector<uint64_t> ids;
+    if (filtered) {
+        if (bitset_words) {
+            const uint64_t nw = std::min<uint64_t>(n_words, (n + 63) / 64);
+            for (uint64_t w = 0; w < nw; ++w)
+                for (uint64_t bits = bitset_words[w]; bits; bits &= bits - 1) {
+                    const uint64_t r = w * 64 + (uint64_t)__builtin_ctzll(bits);
+                    if (r < n) ids.push_back(r);
+                }
+        } else {
+            ids.assign(subset, subset + n_subset);
+            std::sort(ids.begin(), ids.end());
+            ids.erase(std::unique(ids.begin(), ids.end()), ids.end());
+            while (!ids.empty() && ids.back() >= n) ids.pop_back();
+        }
+    }
+    const uint32_t kk = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(k, n), filtered ? ids.size() : n);
     const uint64_t n_ranges = (n + R - 1) / R;
     const size_t q_elems = packed_queries ? h->words : h->dim, q_bytes = q_elems * (packed_queries ? 8 : 4);
+    if (kk == 0) {  // an empty subset: empty results
+        if (on_device) LY_HIP(hipMemset(out_counts, 0, nq * 4));
+        else memset(out_counts, 0, nq * 4);
+        return LYNSE_OK;
+    }
     // queries on the host (the per-range searches go through the host-array path)
     std::vector<uint8_t> q_host;
     const uint8_t* qh = reinterpret_cast<const uint8_t*>(q_src);
@@ -2073,10 +2115,21 @@ static int search_large_k(lynse_hip_flat* h, const void* q_src, bool packed_quer
         const uint64_t nb = std::min<uint64_t>(qb, nq - q0);
         for (uint64_t ri = 0; ri < n_ranges; ++ri) {
             const uint64_t r0 = ri * R, r1 = std::min<uint64_t>(n, r0 + R);
-            const uint32_t kr = (uint32_t)std::min<uint64_t>(kk, r1 - r0);
+            uint32_t kr = (uint32_t)std::min<uint64_t>(kk, r1 - r0);
+            std::vector<uint64_t> local;   // the subset ids of this range, range-local
+            if (filtered) {
+                const auto lo = std::lower_bound(ids.begin(), ids.end(), r0), hi = std::lower_bound(ids.begin(), ids.end(), r1);
+                local.assign(lo, hi);
+                for (uint64_t& v : local) v -= r0;
+                kr = (uint32_t)std::min<uint64_t>(kr, local.size());
+                if (local.empty()) {
+                    for (uint64_t q = 0; q < nb; ++q) l_counts[q * n_ranges + ri] = 0;
+                    continue;
+                }
+            }
             view.set(r0, r1);
             const int rc = search_impl(h, qh + q0 * q_bytes, packed_queries, nb, kr, metric, t_rows.data(), t_dists.data(), r_counts.data(),
-                                       false, user_stream, nullptr, 0, false, nullptr, 0, true);
+                                       false, user_stream, filtered ? local.data() : nullptr, local.size(), filtered, nullptr, 0, true);
             if (rc != LYNSE_OK) return rc;
             for (uint64_t q = 0; q < nb; ++q) {  // [query][range][kk] lists for the merge
                 const uint32_t c = r_counts[q];

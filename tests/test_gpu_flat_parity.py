@@ -243,7 +243,9 @@ def test_ip_forms(L, oracle):
 
 @pytest.mark.parametrize("metric", [HAM, JAC, DICE, TANI])
 @pytest.mark.parametrize("n,bits,nq,k,p", [(50, 64, 3, 10, 0.5), (4000, 130, 5, 50, 0.5), (100000, 1024, 4, 50, 0.5),
-                                           (60000, 1024, 2, 50, 0.05), (30000, 2048, 33, 10, 0.3), (20000, 100, 260, 5, 0.5)])
+                                           (60000, 1024, 2, 50, 0.05), (30000, 2048, 33, 10, 0.3), (20000, 100, 260, 5, 0.5),
+                                           # wider than 4096 bits (no width limit in BinaryData, flat_mmap.rs:145-160)
+                                           (3000, 8192, 5, 20, 0.5), (2500, 5000, 3, 10, 0.3)])
 def test_binary_parity_packed(L, oracle, metric, n, bits, nq, k, p):
     rng = np.random.default_rng(n + bits)
     W = (bits + 63) // 64
@@ -565,6 +567,37 @@ def test_large_k_up_to_the_server_cap(L, oracle, metric):
     assert int(c[0]) == n
     e_ids, e_d = oracle.canonical_topk(queries[0], data, n, metric)
     assert np.array_equal(r[0, :n].cpu().numpy().astype(np.uint32), e_ids) and np.array_equal(d[0, :n].cpu().numpy().view(np.uint32), e_d.view(np.uint32))
+
+
+@pytest.mark.parametrize("metric", [IP, L2])
+def test_large_k_with_a_subset_filter(L, oracle, metric):
+    """k beyond one pass's candidate capacity together with a subset (search_filtered: k.min(subset.len()),
+    flat_mmap.rs:498-501): row-range views, each searched with the subset ids that fall into it."""
+    rng = np.random.default_rng(33 + metric)
+    n, dim = 45_000, 16
+    data = rng.standard_normal((n, dim)).astype(f32)
+    queries = np.ascontiguousarray(data[rng.integers(0, n, 2)] + 0.05, f32)
+    idx = make_index(L, data)
+    subset = np.sort(rng.choice(n, 30_000, replace=False)).astype(np.uint64)
+    for k in (6000, 40_000):          # > cap / 4 = 4096; the second is clamped to the subset length
+        rows, dists, counts = idx.search_filtered_batch_arrays(queries, k, NAME[metric], subset)
+        for qi in range(queries.shape[0]):
+            e_ids, e_d = oracle.canonical_topk_filtered(queries[qi], data, k, metric, subset)
+            c = int(counts[qi])
+            assert c == len(e_ids) == min(k, subset.size)
+            assert np.array_equal(dists[qi, :c].view(np.uint32), e_d.view(np.uint32)), (metric, k, qi)
+            assert np.array_equal(rows[qi, :c].astype(np.uint32), e_ids), (metric, k, qi)
+    # BitSet words, a subset confined to two row ranges, duplicates / out-of-range ids in the list form
+    words = np.zeros((n + 63) // 64, np.uint64)
+    some = np.concatenate([np.arange(100, 9000), np.arange(20_000, 26_000)]).astype(np.uint64)
+    np.bitwise_or.at(words, (some // 64).astype(np.int64), np.uint64(1) << (some % 64))
+    rows, dists, counts = idx.search_filtered_bitset_batch_arrays(queries, 5000, NAME[metric], words)
+    rows2, dists2, counts2 = idx.search_filtered_batch_arrays(queries, 5000, NAME[metric], np.concatenate([some, some[:50], [n + 5]]).astype(np.uint64))
+    for qi in range(queries.shape[0]):
+        e_ids, e_d = oracle.canonical_topk_filtered(queries[qi], data, 5000, metric, some)
+        for r, d, c in ((rows, dists, counts), (rows2, dists2, counts2)):
+            assert int(c[qi]) == 5000
+            assert np.array_equal(r[qi].astype(np.uint32), e_ids) and np.array_equal(d[qi].view(np.uint32), e_d.view(np.uint32))
 
 
 def test_sharded_search_entry_point_with_a_one_rank_communicator(L, oracle):
