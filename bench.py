@@ -115,6 +115,13 @@ def main():
     native = False
     if world > 1 and os.environ.get("LYNSE_BENCH_EXCHANGE", "native") == "native" and (dist is None or dist.get_backend() == "nccl"):
         native = sh.enable_native_comm()   # RCCL inside the library; falls back to torch.distributed's all-gather
+    if world == 1 and os.environ.get("LYNSE_BENCH_FORCE_COMM") == "1":
+        # one GPU, but the batches in flight go through a 1-rank RCCL communicator: the exchange half of a sharded step
+        # (status word in the result block, event hand-over to the exchange stream, merge kernel) without the all-gather
+        from lynsedb_amd.sharded import NativeComm
+
+        sh.comm = NativeComm(None, 0, 1, local_rank)
+        native = True
     n_local = (N - rank + world - 1) // world if N > rank else 0
     sh.index.reserve(max(n_local, 1))
     if args.stage0 or args.growth:
@@ -275,7 +282,8 @@ def main():
                                    % (args.metric.upper(), N, D, B, K),
                        "rows_per_gpu": n_local, "sharding": "row %% %d" % world,
                        "exchange": ("rccl all_gather of %d B/rank, %s" % (B * K * 12 + B * 4, "inside the library (C-ABI), one stream" if native
-                                    else "through torch.distributed (%s)" % (sh.comm_error or os.environ.get("LYNSE_BENCH_BACKEND", "nccl")))) if world > 1 else "none",
+                                    else "through torch.distributed (%s)" % (sh.comm_error or os.environ.get("LYNSE_BENCH_BACKEND", "nccl")))) if world > 1
+                                   else ("1-rank communicator: merge without all-gather" if sh.comm is not None else "none"),
                        "rccl_ranks_seen": (sh.ranks_seen if native else None),
                        "batches_in_flight": in_flight,
                        "build_s": round(build_s, 1)},

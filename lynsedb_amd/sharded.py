@@ -230,9 +230,9 @@ class ShardedFlat:
         the shard; returns a ticket whose wait() makes out.rows / dists / counts final.  A collective with world > 1 (every
         rank submits and waits for the same sequence).  Needs the native communicator (or world == 1); without it the
         batch is answered here and the ticket is already complete."""
-        if self.world == 1 or self.comm is not None:
+        if self.world == 1 or self.comm is not None:  # (a 1-rank communicator still runs the exchange half: status word, merge)
             return self.index.search_submit(d_queries, k, metric, out.rows, out.dists, out.counts,
-                                            comm=self.comm.handle if (self.world > 1 and self.comm is not None) else None)
+                                            comm=self.comm.handle if self.comm is not None else None)
         self.search_device(d_queries, k, metric, out)
 
         class _Done:
