@@ -1593,7 +1593,10 @@ extern "C" int lynse_hip_flat_sq8_params(lynse_hip_flat* h, float* mins, float* 
 // sq8_two_pass_search (flat_mmap.rs:5868-5926) for one chunk of <= 256 queries (queries in ws.Qf): pass 1 = exact integer
 // scores of the u8 codes on the i8 MFMA, exact top-n_cand in (score, row) order with the staged strict thresholds of the
 // packed-binary path; pass 2 = exact f32 rescoring of the n_cand rows, (distance, row) order, top k.
-static int run_chunk_sq8(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k, uint32_t n_cand, int metric, int level, hipStream_t st) {
+static int run_chunk_sq8(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k, uint32_t n_cand, int metric, int level, hipStream_t st,
+                         bool pass1_only = false) {
+    // pass1_only: stop after pass 1 — the outputs are the top-k rows by the integer score of the codes, in (score, row) order,
+    // with that score as the distance (the large-n_cand path merges such lists over row ranges; tests look at the ranking)
     Workspace& w = cur(h).ws;
     const bool ip = metric == M_IP;
     const int m1 = ip ? M_IP : M_L2;  // cosine ranks the codes by squared L2 too (:5887-5890)
@@ -1648,7 +1651,7 @@ static int run_chunk_sq8(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t ou
     fa.row_stride = h->row_stride; fa.row_offset = h->row_offset;
     fa.out_rows = w.out_rows; fa.out_dists = w.out_dists; fa.out_counts = w.out_counts; fa.pool_total = nullptr;
     const char* dbg = getenv("LYNSE_HIP_SQ8_PASS1");  // tests: return the pass-1 ranking (integer scores) instead of rescoring
-    if (dbg && atoi(dbg)) {
+    if (pass1_only || (dbg && atoi(dbg))) {
         fa.metric = m1;
     } else {
         hipLaunchKernelGGL(k_rescore_pool<256>, dim3(nq, nq >= 64 ? 4 : 32), dim3(256), 0, st, fa);
@@ -1659,6 +1662,9 @@ static int run_chunk_sq8(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t ou
     LY_HIP(hipGetLastError());
     return LYNSE_OK;
 }
+
+static int search_sq8_large(lynse_hip_flat* h, std::unique_lock<std::shared_mutex>& lk, const float* queries, uint64_t nq, uint32_t k, uint32_t kk,
+                            uint32_t n_cand, int metric, uint64_t* out_rows, float* out_dists, uint32_t* out_counts);
 
 extern "C" int lynse_hip_flat_search_sq8_f32(lynse_hip_flat* h, const float* queries, uint64_t nq, uint32_t k, int metric,
                                              uint64_t* out_rows, float* out_dists, uint32_t* out_counts) {
@@ -1678,9 +1684,9 @@ extern "C" int lynse_hip_flat_search_sq8_f32(lynse_hip_flat* h, const float* que
     n_cand = std::min<uint64_t>(n_cand, h->n);
     LY_TRY(finalize_locked(h));
     LY_TRY(ensure_workspace(h, k));
-    if (h->n > h->cap && n_cand > h->cap / 4)
-        return set_error(LYNSE_ERR_UNSUPPORTED, "SQ8 candidate count (k * 20, cosine k * 100) exceeds cap/4");
     LY_TRY(ensure_sq8_locked(h));
+    if (h->n > h->cap && n_cand > h->cap / 4)  // more candidates than one pass holds: row ranges + host merge (search_sq8_large)
+        return search_sq8_large(h, lk, queries, nq, k, kk, (uint32_t)n_cand, metric, out_rows, out_dists, out_counts);
     Workspace& w = cur(h).ws;
     hipStream_t st = cur(h).stream;
     for (uint64_t q0 = 0; q0 < nq; q0 += QCHUNK) {
@@ -2151,6 +2157,82 @@ static int search_large_k(lynse_hip_flat* h, const void* q_src, bool packed_quer
         LY_HIP(hipMemcpy(out_rows, o_rows.data(), o_rows.size() * 8, hipMemcpyHostToDevice));
         LY_HIP(hipMemcpy(out_dists, o_dists.data(), o_dists.size() * 4, hipMemcpyHostToDevice));
         LY_HIP(hipMemcpy(out_counts, o_counts.data(), o_counts.size() * 4, hipMemcpyHostToDevice));
+    }
+    return LYNSE_OK;
+}
+
+// FLAT-*-SQ8 with more pass-1 candidates than one pass holds (n_cand = 20 k, cosine 100 k, flat_mmap.rs:5883-5893; above
+// cap / 4 over more than cap rows): pass 1 runs per row range of `cap` rows (exact top-n_cand of the integer code scores
+// there), the per-range lists are merged on the host in the (score, row) order, and pass 2 — the exact f32 scores of the
+// n_cand rows, (distance, row) order, top k — is the subset-filtered exact search over those rows (single-row kernels, as
+// flat_mmap.rs:5899-5906).  One query at a time: a rare shape, not a tuned one.  Called with the writer lock held.
+static int search_sq8_large(lynse_hip_flat* h, std::unique_lock<std::shared_mutex>& lk, const float* queries, uint64_t nq, uint32_t k, uint32_t kk,
+                            uint32_t n_cand, int metric, uint64_t* out_rows, float* out_dists, uint32_t* out_counts) {
+    const uint64_t n = h->n, R = h->cap, n_ranges = (n + R - 1) / R;
+    const int m1 = metric == M_IP ? M_IP : M_L2;
+    LY_TRY(ensure_workspace(h, (uint32_t)std::min<uint64_t>(n_cand, R)));
+    Workspace& w = cur(h).ws;
+    hipStream_t st = cur(h).stream;
+    struct Sq8View {  // the pass-1 side of the handle advanced to one row range; rows come back as RAW shard rows
+        lynse_hip_flat* h;
+        float* rows; int8_t* sq8; int *sum, *sum2; uint64_t n, n_sq8, stride, offset;
+        explicit Sq8View(lynse_hip_flat* hh) : h(hh), rows(hh->rows), sq8(hh->sq8), sum(hh->sq8_sum), sum2(hh->sq8_sum2), n(hh->n), n_sq8(hh->n_sq8),
+                                               stride(hh->row_stride), offset(hh->row_offset) {}
+        void set(uint64_t r0, uint64_t r1) {
+            h->rows = rows + r0 * h->ld; h->sq8 = sq8 + r0 * h->ld8; h->sq8_sum = sum + r0; h->sq8_sum2 = sum2 + r0;
+            h->n = r1 - r0; h->n_sq8 = h->n; h->row_stride = 1; h->row_offset = r0;
+        }
+        void restore() { h->rows = rows; h->sq8 = sq8; h->sq8_sum = sum; h->sq8_sum2 = sum2; h->n = n; h->n_sq8 = n_sq8; h->row_stride = stride; h->row_offset = offset; }
+        ~Sq8View() { restore(); }
+    };
+    std::vector<std::vector<uint64_t>> cand(nq);   // per query: the top-n_cand rows of pass 1
+    {
+        Sq8View view(h);
+        const uint64_t qb = std::max<uint64_t>(1, std::min<uint64_t>(QCHUNK, (64ull << 20) / std::max<uint64_t>(1, n_ranges * n_cand * 12)));
+        std::vector<uint64_t> l_rows((size_t)qb * n_ranges * n_cand), m_rows(n_cand), t_rows;
+        std::vector<float> l_dists((size_t)qb * n_ranges * n_cand), m_dists(n_cand), t_dists;
+        std::vector<uint32_t> l_counts((size_t)qb * n_ranges);
+        for (uint64_t q0 = 0; q0 < nq; q0 += qb) {
+            const uint32_t nb = (uint32_t)std::min<uint64_t>(qb, nq - q0);
+            LY_HIP(hipMemcpyAsync(w.Qf, queries + q0 * h->dim, (size_t)nb * h->dim * 4, hipMemcpyHostToDevice, st));
+            for (uint64_t ri = 0; ri < n_ranges; ++ri) {
+                const uint64_t r0 = ri * R, r1 = std::min<uint64_t>(n, r0 + R);
+                const uint32_t kr = (uint32_t)std::min<uint64_t>(n_cand, r1 - r0);
+                view.set(r0, r1);
+                for (int level = 1; level < 3; ++level) {
+                    LY_TRY(run_chunk_sq8(h, nb, kr, kr, kr, metric, level, st, true));
+                    LY_HIP(hipMemcpyAsync(w.h_hdr, w.out_counts, (size_t)2 * w.qcap * 4, hipMemcpyDeviceToHost, st));
+                    LY_HIP(hipStreamSynchronize(st));
+                    uint32_t nov = 0;
+                    for (uint32_t i = 0; i < nb; ++i) nov += w.h_hdr[w.qcap + i] ? 1 : 0;
+                    if (nov == 0) break;
+                    if (level == 2) return set_error(LYNSE_ERR_INTERNAL, "candidate overflow on the exhaustive plan");
+                }
+                t_rows.resize((size_t)nb * kr);
+                t_dists.resize((size_t)nb * kr);
+                LY_HIP(hipMemcpy(t_rows.data(), w.out_rows, t_rows.size() * 8, hipMemcpyDeviceToHost));
+                LY_HIP(hipMemcpy(t_dists.data(), w.out_dists, t_dists.size() * 4, hipMemcpyDeviceToHost));
+                for (uint32_t q = 0; q < nb; ++q) {
+                    const uint32_t c = w.h_hdr[q];
+                    l_counts[q * n_ranges + ri] = c;
+                    memcpy(&l_rows[(q * n_ranges + ri) * n_cand], &t_rows[(size_t)q * kr], (size_t)c * 8);
+                    memcpy(&l_dists[(q * n_ranges + ri) * n_cand], &t_dists[(size_t)q * kr], (size_t)c * 4);
+                }
+            }
+            for (uint32_t q = 0; q < nb; ++q) {
+                uint32_t cnt = 0;
+                LY_TRY(lynse_hip_merge_topk(&l_rows[(size_t)q * n_ranges * n_cand], &l_dists[(size_t)q * n_ranges * n_cand], &l_counts[(size_t)q * n_ranges],
+                                            (uint32_t)n_ranges, n_cand, n_cand, m1, m_rows.data(), m_dists.data(), &cnt));
+                cand[q0 + q].assign(m_rows.begin(), m_rows.begin() + cnt);
+            }
+        }
+    }
+    // pass 2 through the public filtered path (it takes the locks itself; large k there goes through the row-range views)
+    lk.unlock();
+    for (uint64_t q = 0; q < nq; ++q) {
+        LY_TRY(search_impl(h, queries + q * h->dim, false, 1, k, metric, out_rows + q * k, out_dists + q * k, out_counts + q, false, nullptr,
+                           cand[q].data(), cand[q].size(), true));
+        (void)kk;
     }
     return LYNSE_OK;
 }

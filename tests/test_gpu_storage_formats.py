@@ -139,6 +139,25 @@ def test_open_f16_collection(L, oracle, tmp_path):
         L.FlatIndex(None, 4, 0, dtype="int8")
 
 
+@pytest.mark.parametrize("metric,name,k", [(O.IP, "ip", 300), (O.L2, "l2", 250), (O.COS, "cosine", 60)])
+def test_sq8_more_candidates_than_one_pass_holds(L, oracle, metric, name, k):
+    """n_cand = 20 k (cosine 100 k, flat_mmap.rs:5883-5893) beyond cap / 4 over more than cap rows: pass 1 per row range, host
+    merge in (code score, row) order, pass 2 as the subset-filtered exact search."""
+    rng = np.random.default_rng(77 + metric)
+    n, dim, nq = 40_000, 24, 3
+    data = rng.standard_normal((n, dim)).astype(f32)
+    queries = (data[rng.integers(0, n, nq)] + 0.05 * rng.standard_normal((nq, dim))).astype(f32)
+    idx = L.FlatIndex(None, dim, 0)
+    idx.write(data)
+    mins, scales, codes = oracle.sq8_fit(data)
+    rows, dists, counts = idx.search_sq8_batch_arrays(queries, k, name)
+    for qi in range(nq):
+        e_ids, e_d = oracle.sq8_search(queries[qi], data, mins, scales, codes, k, metric)
+        assert int(counts[qi]) == k == len(e_ids)
+        assert np.array_equal(rows[qi].astype(np.uint32), e_ids), (qi, rows[qi][:8], e_ids[:8])
+        assert np.array_equal(dists[qi].view(np.uint32), e_d.view(np.uint32))
+
+
 # ------------------------------------------------------------------ FLAT-*-SQ8 two-pass mode (SURVEY §8 f3)
 @pytest.mark.parametrize("metric,name", [(O.IP, "ip"), (O.L2, "l2"), (O.COS, "cosine")])
 @pytest.mark.parametrize("n,dim,nq,k,kind", [(3000, 32, 6, 10, "normal"), (40000, 96, 33, 5, "normal"), (70000, 40, 4, 10, "positive"),
