@@ -267,7 +267,9 @@ def main():
             "launches_per_step": round(launches / timed_steps, 2), "timed_steps": timed_steps,
             "plan": {"sampled": bool(plan & 1), "threshold_only_sample": bool(plan & 2), "int8_coarse_pass": i8c,
                      "segmented_emission": bool(plan & 8), "stages": (plan >> 8) & 0xff, "tiling": hex((plan >> 16) & 0xff)},
-            "note": "rank-0 shard; time = sum of HIP-event durations of the scan launches on the launch stream, every %d-th step of the timed region" % max(args.profile_every, 1),
+            "note": ("rank-0 shard; time = sum of HIP-event durations of the scan launches on the launch stream, every %d-th step of the timed region" % max(args.profile_every, 1))
+                    + ("; with %d batches in flight the event brackets of a launch also hold the time it waits for CUs behind other batches' kernels "
+                       "(kernel durations proper: the one-GPU line / profiles/)" % in_flight if in_flight > 1 else ""),
         }
         result = {
             "metric": "queries/sec, FLAT-%s %dx%d float32, batch=%d, k=%d" % (args.metric.upper(), N, D, B, K),
