@@ -1013,7 +1013,7 @@ __global__ void __launch_bounds__(256) k_rows_to_f16(const float* __restrict__ V
 constexpr int HK = 64;  // K elements per slab
 
 // DBG (compile-time experiments, never launched by the product path): 1 no MFMA, 2 no LDS fragment reads,
-// 4 no query-image DMA, 8 no row DMA.  FILT compiles the subset-filter paths in (mask / row_ids of ScanArgs): they
+// 4 no query-image DMA, 8 no row DMA, 16 no epilogue.  FILT compiles the subset-filter paths in (mask / row_ids of ScanArgs): they
 // cost registers the unfiltered kernel does not have to spare (56 B/lane of scratch and 13 % of its speed when they
 // were runtime branches).
 template <int WQ, int WR, int TQ, int TR, int METRIC, int NSV, int NSQ, int NT_HINT, bool TILED = false, bool RAG = true, int DBG = 0, bool FILT = false,
@@ -1365,7 +1365,23 @@ __global__ void __launch_bounds__(WQ * WR * 64, (TQ * TR >= 16) ? 1 : ((WQ * WR 
         q_advance();
         v_advance();
 
-        if (++s_in_tile == a.nslab) {
+        const bool tile_done = ++s_in_tile == a.nslab;
+        if constexpr ((DBG & 16) != 0) {  // (experiments) no epilogue at all: keep the accumulators alive, restart the tile
+          if (tile_done) {
+#pragma unroll
+            for (int i = 0; i < TR; ++i)
+#pragma unroll
+                for (int j = 0; j < TQ; ++j) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        asm volatile("" ::"v"(acc[i][j][r]));   // (a 16-wide vector operand is not a valid "v" operand in the host pass)
+                        acc[i][j][r] = 0.0f;
+                    }
+                }
+            s_in_tile = 0;
+            tile += gridDim.x;
+          }
+        } else if (tile_done) {
             const EpiArgsPtr ea = epi_args();
             uint32_t rbase = ea->row0 + tile * tstride;
             uint32_t row_end = ea->row1;
@@ -1409,6 +1425,10 @@ __global__ void __launch_bounds__(WQ * WR * 64, (TQ * TR >= 16) ? 1 : ((WQ * WR 
                 }
                 return sc;
             };
+            // DENSE float epilogue: the column loop below only prepares the per-query constants; the accumulators of ALL query
+            // columns are scored afterwards, one norm load per group of four rows shared by the columns and issued one group ahead
+            constexpr bool DENSEF = DENSE && !I8 && !TILED && !FILT;
+            uint32_t n_j[TQ];
 #pragma unroll
             for (int j = 0; j < TQ; ++j) {
                 uint32_t rb = __builtin_amdgcn_readfirstlane(rbase);  // (uniform) opaque per column block: keeps the row-index terms of the TR x 16 rows from being hoisted out of
@@ -1436,6 +1456,8 @@ __global__ void __launch_bounds__(WQ * WR * 64, (TQ * TR >= 16) ? 1 : ((WQ * WR 
                 if (ea->debug_flags & 2) c_thr[j] = (I8C && QC_REG) ? __int_as_float(0x7fffffff) : (ASC ? -LY_INF : LY_INF);
 #endif
                 set_pre(j, c_thr[j], e_vmax2);
+                n_j[j] = n;
+                if (DENSEF && !e_emit_all) continue;   // scored after this loop (all columns per norm load)
                 if ((WR >= 4 || EMIT == 2) && !FILT && e_emit_all == 2 && !TILED) {  // (runtime-EMIT bodies of the <4,2,2,4> tiling and the subset-filter variants leave it out: it would spill there)
                     // threshold-only sample stage: each lane keeps the best LM of its TR*16 rows for this query column
                     // (4 WR keys per tile and query) and writes only those.  k_select turns the k-th best of them into a
@@ -1504,76 +1526,28 @@ __global__ void __launch_bounds__(WQ * WR * 64, (TQ * TR >= 16) ? 1 : ((WQ * WR 
 #pragma unroll
                     for (int i = 0; i < TR; ++i) {
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const int v = __float_as_int(acc[i][j][r]);
-                            if (v >= T) {
-                                const uint32_t m = rb + wr * (TR * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                                if (m < row_end) {
-                                    const uint64_t key = make_key(c_extra[j] + c_qinv[j] * (float)v, m, ASC);
-                                    if (cnt < e_seg) {
-                                        segdst[cnt] = key;
-                                        ++cnt;
-                                    } else {
-                                        const uint32_t slot = atomicAdd(&ea->count[n], 1u);
-                                        if (slot < ea->cap) ea->cand[(size_t)n * ea->cap + slot] = key;
-                                    }
-                                }
-                            }
-                        }
-                    }
-                    segpk = (segpk & ~(0xffu << (8 * j))) | (cnt << (8 * j));
-                } else if (DENSE && !I8 && !TILED && !FILT) {
-                    // ---- DENSE threshold stage (many survivors per block: large k over few rows seen so far, e.g. k = 100 on 1M
-                    // rows).  The two-level filter degenerates there — nearly every 32-query x TR*32-row block holds a survivor,
-                    // so level 2 (exact expression + pass masks for all TR x 16 values) runs on top of level 1 almost always.
-                    // One pass instead: per accumulator the level-1 value against the LOOSENED threshold (2 VALU + a wave-level
-                    // branch); only elements some lane passes run the exact expression, the exact threshold and the store.
-                    // Slots: every lane owns one private segment of `seg` slots (segments are per (workgroup, row-wave, wave half):
-                    // no counts to agree on between the two half-waves of a query column); a full segment falls back to the shared
-                    // region (returning atomic).
-                    const uint32_t e_seg = ea->seg;
-                    uint32_t cnt = (segpk >> (8 * j)) & 0xffu;
-                    uint64_t* segdst = ea->candB + ((size_t)n * ea->nseg + ((blockIdx.x * WR + wr) * 2 + hi)) * e_seg;
-                    const float thr_e = c_thr[j], pre_e = c_ok[j] ? (METRIC == M_IP ? c_thr[j] : c_pre[j]) : LY_INF;  // (IP: the level-1 value is the score itself)
-#pragma unroll
-                    for (int i = 0; i < TR; ++i) {
-#pragma unroll
                         for (int g4 = 0; g4 < 4; ++g4) {
-                            float nv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-                            const uint32_t off = wr * (TR * 32) + i * 32 + 8 * g4 + 4 * hi;  // rows off .. off+3 <-> r = 4 g4 .. 4 g4 + 3
-                            if constexpr (METRIC != M_IP) {
-                                if (NORMS_LDS) {
-                                    const f32x4 t4 = *reinterpret_cast<const f32x4*>(nrm + off);
-                                    nv[0] = t4[0]; nv[1] = t4[1]; nv[2] = t4[2]; nv[3] = t4[3];
-                                } else {
+                            // one wave-level branch per FOUR accumulators (their maximum against T): a taken branch per element
+                            // cost more than the compare it guards
+                            const int v0 = __float_as_int(acc[i][j][4 * g4]), v1 = __float_as_int(acc[i][j][4 * g4 + 1]);
+                            const int v2 = __float_as_int(acc[i][j][4 * g4 + 2]), v3 = __float_as_int(acc[i][j][4 * g4 + 3]);
+                            const int m01 = v0 > v1 ? v0 : v1, m23 = v2 > v3 ? v2 : v3;
+                            if ((m01 > m23 ? m01 : m23) >= T) {
 #pragma unroll
-                                    for (int e = 0; e < 4; ++e) {
-                                        const uint32_t m = rb + off + e;
-                                        nv[e] = m < row_end ? (METRIC == M_L2 ? ea->vn2[m] : ea->vrinv[m]) : 0.0f;
-                                    }
-                                }
-                            }
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                const int r = 4 * g4 + e;
-                                float pv = acc[i][j][r];
-                                if (METRIC == M_L2) pv = __fmaf_rn(pv, 2.0f * c_qinv[j], -nv[e]);
-                                if (METRIC == M_COS) pv = pv * nv[e];
-                                if (METRIC == M_IP) pv = pv * c_qinv[j];
-                                if (pv >= pre_e) {
-                                    const uint32_t m = rb + off + e;
-                                    float sc = acc[i][j][r] * c_qinv[j];
-                                    if (METRIC == M_L2) sc = nv[e] - 2.0f * sc + c_extra[j];
-                                    if (METRIC == M_COS) sc = 1.0f - sc * nv[e] * c_extra[j];
-                                    const bool pass = m < row_end && (ASC ? (sc <= thr_e) : (sc >= thr_e));
-                                    if (pass) {
-                                        const uint64_t key = make_key(sc, m, ASC);
-                                        if (cnt < e_seg) {
-                                            segdst[cnt] = key;
-                                            ++cnt;
-                                        } else {
-                                            const uint32_t slot = atomicAdd(&ea->count[n], 1u);
-                                            if (slot < ea->cap) ea->cand[(size_t)n * ea->cap + slot] = key;
+                                for (int e = 0; e < 4; ++e) {
+                                    const int r = 4 * g4 + e;
+                                    const int v = __float_as_int(acc[i][j][r]);
+                                    if (v >= T) {
+                                        const uint32_t m = rb + wr * (TR * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                                        if (m < row_end) {
+                                            const uint64_t key = make_key(c_extra[j] + c_qinv[j] * (float)v, m, ASC);
+                                            if (cnt < e_seg) {
+                                                segdst[cnt] = key;
+                                                ++cnt;
+                                            } else {
+                                                const uint32_t slot = atomicAdd(&ea->count[n], 1u);
+                                                if (slot < ea->cap) ea->cand[(size_t)n * ea->cap + slot] = key;
+                                            }
                                         }
                                     }
                                 }
@@ -1701,6 +1675,100 @@ __global__ void __launch_bounds__(WQ * WR * 64, (TQ * TR >= 16) ? 1 : ((WQ * WR 
                 for (int i = 0; i < TR; ++i)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+            }
+            if constexpr (DENSEF) {
+                if (!e_emit_all) {
+                    // ---- DENSE threshold stage (many survivors per block: large k over few rows seen so far, e.g. k = 100 on 1M
+                    // rows).  The two-level filter degenerates there — nearly every 32-query x TR*32-row block holds a survivor,
+                    // so level 2 (exact expression + pass masks for all TR x 16 values) runs on top of level 1 almost always.
+                    // One pass instead: per group of FOUR accumulators the maximum of the level-1 values against the LOOSENED
+                    // threshold and ONE wave-level branch (a taken branch per element cost several times the fma + compare it
+                    // guarded; NaN values drop out of the maximum as they fail the compare); only groups some lane passes run the
+                    // exact expression, the exact threshold and the store.  The row norms of a group (one ds_read_b128 from the
+                    // norm ring) serve every query column and are fetched one group ahead — loaded where they were used, each of
+                    // the 64 groups of a tile waited out an LDS round trip (with the branches: 60 % of the C3 scan).
+                    // Slots: every lane owns one private segment of `seg` slots (segments are per (workgroup, row-wave, wave half):
+                    // no counts to agree on between the two half-waves of a query column); a full segment falls back to the shared
+                    // region (returning atomic).
+                    uint32_t rb = __builtin_amdgcn_readfirstlane(rbase);
+                    asm volatile("" : "+s"(rb));
+                    const uint32_t e_seg = ea->seg;
+                    uint32_t cnt[TQ];
+                    uint64_t* segdst[TQ];
+                    float pre_e[TQ];
+#pragma unroll
+                    for (int j = 0; j < TQ; ++j) {
+                        cnt[j] = (segpk >> (8 * j)) & 0xffu;
+                        segdst[j] = ea->candB + ((size_t)n_j[j] * ea->nseg + ((blockIdx.x * WR + wr) * 2 + hi)) * e_seg;
+                        pre_e[j] = c_ok[j] ? (METRIC == M_IP ? c_thr[j] : c_pre[j]) : LY_INF;  // (IP: the level-1 value is the score itself)
+                    }
+                    auto load_nv = [&](int grp) -> f32x4 {  // norms of rows off .. off+3 of group grp = (i, g4)
+                        f32x4 t4 = {0.0f, 0.0f, 0.0f, 0.0f};
+                        if constexpr (METRIC != M_IP) {
+                            const uint32_t off = wr * (TR * 32) + (grp >> 2) * 32 + 8 * (grp & 3) + 4 * hi;
+                            if (NORMS_LDS) {
+                                t4 = *reinterpret_cast<const f32x4*>(nrm + off);
+                            } else {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) {
+                                    const uint32_t m = rb + off + e;
+                                    t4[e] = m < row_end ? (METRIC == M_L2 ? ea->vn2[m] : ea->vrinv[m]) : 0.0f;
+                                }
+                            }
+                        }
+                        return t4;
+                    };
+                    f32x4 nxt = load_nv(0);
+#pragma unroll
+                    for (int grp = 0; grp < TR * 4; ++grp) {
+                        const int i = grp >> 2, g4 = grp & 3;
+                        const f32x4 nv = nxt;
+                        if (grp + 1 < TR * 4) nxt = load_nv(grp + 1);
+                        const uint32_t off = wr * (TR * 32) + i * 32 + 8 * g4 + 4 * hi;  // rows off .. off+3 <-> r = 4 g4 .. 4 g4 + 3
+#pragma unroll
+                        for (int j = 0; j < TQ; ++j) {
+                            float pvs[4];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                float pv = acc[i][j][4 * g4 + e];
+                                if (METRIC == M_L2) pv = __fmaf_rn(pv, 2.0f * c_qinv[j], -nv[e]);
+                                if (METRIC == M_COS) pv = pv * nv[e];
+                                if (METRIC == M_IP) pv = pv * c_qinv[j];
+                                pvs[e] = pv;
+                            }
+                            if (fmaxf(fmaxf(fmaxf(pvs[0], pvs[1]), pvs[2]), pvs[3]) >= pre_e[j]) {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) {
+                                    if (pvs[e] >= pre_e[j]) {
+                                        const uint32_t m = rb + off + e;
+                                        float sc = acc[i][j][4 * g4 + e] * c_qinv[j];
+                                        if (METRIC == M_L2) sc = nv[e] - 2.0f * sc + c_extra[j];
+                                        if (METRIC == M_COS) sc = 1.0f - sc * nv[e] * c_extra[j];
+                                        const bool pass = m < row_end && (ASC ? (sc <= c_thr[j]) : (sc >= c_thr[j]));
+                                        if (pass) {
+                                            const uint64_t key = make_key(sc, m, ASC);
+                                            if (cnt[j] < e_seg) {
+                                                segdst[j][cnt[j]] = key;
+                                                ++cnt[j];
+                                            } else {
+                                                const uint32_t slot = atomicAdd(&ea->count[n_j[j]], 1u);
+                                                if (slot < ea->cap) ea->cand[(size_t)n_j[j] * ea->cap + slot] = key;
+                                            }
+                                        }
+                                    }
+                                }
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < TQ; ++j) segpk = (segpk & ~(0xffu << (8 * j))) | (cnt[j] << (8 * j));
+#pragma unroll
+                    for (int i = 0; i < TR; ++i)
+#pragma unroll
+                        for (int j = 0; j < TQ; ++j)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+                }
             }
             s_in_tile = 0;
             tile += gridDim.x;

@@ -814,7 +814,7 @@ static std::vector<Stage> make_plan(const lynse_hip_flat* h, uint32_t k, int lev
         if (threshold_only_sample) {
             static const uint32_t big_env = []() { const char* e = getenv("LYNSE_HIP_SAMPLE_ROWS_TO"); return e ? (uint32_t)atoi(e) : 0u; }();
             const uint64_t want = big_env ? big_env : (uint64_t)h->num_cu * tile_rows;
-            S = (uint32_t)std::max<uint64_t>(S, std::min<uint64_t>(std::min<uint64_t>(want, n / 16), (uint64_t)h->cap / 16 * tile_rows));
+            S = (uint32_t)std::max<uint64_t>(S, std::min<uint64_t>(std::min<uint64_t>(want, big_env ? n / 4 : n / 16), (uint64_t)h->cap / 16 * tile_rows));
             S = S / tile_rows * tile_rows;
         }
         const uint32_t nt = S / tile_rows;
@@ -969,6 +969,31 @@ static int launch_scan_h16(const ScanArgs& a, int metric, uint32_t grid, hipStre
             }
             LY_HIP(hipGetLastError());
             return LYNSE_OK;
+        }
+    }
+#endif
+#ifdef LYNSE_EXPERIMENTS
+    if constexpr (WQ == 4 && WR == 2 && TR == 4 && !TILED) {  // decomposition of the low-D L2 scan (C3): LYNSE_HIP_DEBUG_FLAGS bits 8..12 = DBG << 8
+        const int dbg = (a.debug_flags >> 8) & 31;
+        if (metric == M_L2 && !filt && !ragged && dbg && a.emit_all == 0) {
+            auto ex = [&](auto kern) -> int {
+                LY_TRY(set_max_lds(kern, lds));
+                hipLaunchKernelGGL(kern, dim3(grid), dim3(WQ * WR * 64), lds, st, a);
+                LY_HIP(hipGetLastError());
+                return LYNSE_OK;
+            };
+            switch (dbg) {
+            case 16: return ex(k_scan_h16<WQ, WR, TQ, TR, M_L2, NSV, NSQ, 2, false, false, 16, false, 0, 0, 0, true>);   // no epilogue
+            case 17: return ex(k_scan_h16<WQ, WR, TQ, TR, M_L2, NSV, NSQ, 2, false, false, 17, false, 0, 0, 0, true>);   // + no MFMA (DMA + LDS reads)
+            case 19: return ex(k_scan_h16<WQ, WR, TQ, TR, M_L2, NSV, NSQ, 2, false, false, 19, false, 0, 0, 0, true>);   // DMA only
+            case 20: return ex(k_scan_h16<WQ, WR, TQ, TR, M_L2, NSV, NSQ, 2, false, false, 20, false, 0, 0, 0, true>);   // no epilogue, no query DMA
+            case 24: return ex(k_scan_h16<WQ, WR, TQ, TR, M_L2, NSV, NSQ, 2, false, false, 24, false, 0, 0, 0, true>);   // no epilogue, no row DMA
+            case 28: return ex(k_scan_h16<WQ, WR, TQ, TR, M_L2, NSV, NSQ, 2, false, false, 28, false, 0, 0, 0, true>);   // MFMA + LDS reads only
+            case 30: return ex(k_scan_h16<WQ, WR, TQ, TR, M_L2, NSV, NSQ, 2, false, false, 30, false, 0, 0, 0, true>);   // MFMA only
+            case 12: return ex(k_scan_h16<WQ, WR, TQ, TR, M_L2, NSV, NSQ, 2, false, false, 12, false, 0, 0, 0, true>);   // MFMA + LDS reads + epilogue (no DMA)
+            case 4: return ex(k_scan_h16<WQ, WR, TQ, TR, M_L2, NSV, NSQ, 2, false, false, 4, false, 0, 0, 0, true>);     // everything but the query DMA
+            default: return set_error(LYNSE_ERR_INVALID_ARGUMENT, "unknown experiment");
+            }
         }
     }
 #endif
@@ -1379,13 +1404,12 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
                     LY_TRY((launch_scan_h16<1, 4, 1, 1, 3, 3, false>(a, metric, grid, st)));
                 } else {
                     const uint32_t grid = std::min<uint32_t>(a.ntiles, (uint32_t)h->num_cu);
-                    // DENSE epilogue (<4,2,2,4>, L2 / cosine, unfiltered): the expected share of passing (row, query) pairs of this
-                    // stage is k / rows-seen-before; above ~5e-5 nearly every 32 x 128 block holds a survivor and the two-level
-                    // filter only adds work (C3: k = 100 after 8K / 139K rows).  Its segments are per wave half.
+                    // DENSE epilogue (<4,2,2,4>, L2 / cosine, unfiltered; kernels.h).  Its segments are per wave half.
                     static const int dense_env = []() { const char* e = getenv("LYNSE_HIP_DENSE"); return e ? atoi(e) : -1; }();
                     const uint64_t seen_before = s.sample_tiles ? 0 : (sample.sample_tiles ? std::max<uint64_t>((uint64_t)sample.sample_tiles * plan_tile, s.r0) : s.r0);
-                    a.dense = (!a.emit_all && waves16 == 0 && metric != M_IP && !filt && seen_before &&
-                               (dense_env >= 0 ? dense_env != 0 : (uint64_t)k * 20000ull > seen_before)) ? 1 : 0;
+                    // (since the grouped branches + shared, prefetched norm loads of the DENSE epilogue it beats the two-level filter
+                    // at every threshold tightness measured: 1M x 128 and 4M x 128 / 768, k = 10 and 100)
+                    a.dense = (!a.emit_all && waves16 == 0 && metric != M_IP && !filt && seen_before && (dense_env >= 0 ? dense_env != 0 : true)) ? 1 : 0;
                     if (!a.emit_all) seg_geometry(grid, a.dense ? 4 : ((waves16 == 3 || waves16 == 2) ? 4 : 2), &a.nseg, &a.seg);
 #ifdef LYNSE_EXPERIMENTS
                     if (waves16 == 2) LY_TRY((launch_scan_h16<2, 4, 4, 2, 2, 2, false>(a, metric, grid, st)));
