@@ -1532,7 +1532,7 @@ __global__ void __launch_bounds__(WQ * WR * 64, (TQ * TR >= 16) ? 1 : ((WQ * WR 
                             const int v0 = __float_as_int(acc[i][j][4 * g4]), v1 = __float_as_int(acc[i][j][4 * g4 + 1]);
                             const int v2 = __float_as_int(acc[i][j][4 * g4 + 2]), v3 = __float_as_int(acc[i][j][4 * g4 + 3]);
                             const int m01 = v0 > v1 ? v0 : v1, m23 = v2 > v3 ? v2 : v3;
-                            if ((m01 > m23 ? m01 : m23) >= T) {
+                            if (__builtin_expect((m01 > m23 ? m01 : m23) >= T, 0)) {   // (unlikely: the skip falls through)
 #pragma unroll
                                 for (int e = 0; e < 4; ++e) {
                                     const int r = 4 * g4 + e;
@@ -1736,7 +1736,7 @@ __global__ void __launch_bounds__(WQ * WR * 64, (TQ * TR >= 16) ? 1 : ((WQ * WR 
                                 if (METRIC == M_IP) pv = pv * c_qinv[j];
                                 pvs[e] = pv;
                             }
-                            if (fmaxf(fmaxf(fmaxf(pvs[0], pvs[1]), pvs[2]), pvs[3]) >= pre_e[j]) {
+                            if (__builtin_expect(fmaxf(fmaxf(fmaxf(pvs[0], pvs[1]), pvs[2]), pvs[3]) >= pre_e[j], 0)) {   // (unlikely: the skip falls through)
 #pragma unroll
                                 for (int e = 0; e < 4; ++e) {
                                     if (pvs[e] >= pre_e[j]) {
