@@ -1075,14 +1075,14 @@ static int launch_scan_i8c(const ScanArgs& a, uint32_t grid, hipStream_t st) {
         return LYNSE_OK;
     };
 #ifdef LYNSE_EXPERIMENTS
-    if (a.ld16 % 128 == 0 && a.emit_all == 0 && ((a.debug_flags >> 8) & 15)) {  // timing experiments: DBG variants of the int8 kernel
+    if (a.ld16 % 128 == 0 && a.emit_all == 0 && ((a.debug_flags >> 8) & 31)) {  // timing experiments: DBG variants of the int8 kernel
         auto ex = [&](auto kern) -> int {
             LY_TRY(set_max_lds(kern, lds));
             hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, a);
             LY_HIP(hipGetLastError());
             return LYNSE_OK;
         };
-        switch ((a.debug_flags >> 8) & 15) {
+        switch ((a.debug_flags >> 8) & 31) {
         case 3: return ex(k_scan_h16<2, 4, 4, 2, M_IP, 3, 2, 2, false, false, 3, false, 2, 0>);    // DMA only
         case 4: return ex(k_scan_h16<2, 4, 4, 2, M_IP, 3, 2, 2, false, false, 4, false, 2, 0>);    // no query-image DMA
         case 8: return ex(k_scan_h16<2, 4, 4, 2, M_IP, 3, 2, 2, false, false, 8, false, 2, 0>);    // no row DMA
@@ -1093,6 +1093,7 @@ static int launch_scan_i8c(const ScanArgs& a, uint32_t grid, hipStream_t st) {
         case 13: return ex(k_scan_h16<2, 4, 4, 2, M_IP, 3, 2, 2, false, false, 13, false, 2, 0>);  // LDS reads only
         case 14: return ex(k_scan_h16<2, 4, 4, 2, M_IP, 3, 2, 2, false, false, 14, false, 2, 0>);  // MFMA only
         case 2: return ex(k_scan_h16<2, 4, 4, 2, M_IP, 3, 2, 2, false, false, 2, false, 2, 0>);    // no LDS reads (DMA + MFMA)
+        case 16: return ex(k_scan_h16<2, 4, 4, 2, M_IP, 3, 2, 2, false, false, 16, false, 2, 0>);  // no epilogue
         default: return set_error(LYNSE_ERR_INVALID_ARGUMENT, "unknown experiment");
         }
     }
