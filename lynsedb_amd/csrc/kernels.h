@@ -2433,14 +2433,20 @@ __device__ __forceinline__ void rescore_keys(uint64_t* keys, uint32_t n, int met
     const int g = tid & 7;
     const uint32_t grp = tid >> 3;
     const uint32_t rounds = (n + NT / 8 - 1) / (NT / 8);
-    for (uint32_t r = 0; r < rounds; ++r) {
-        const uint32_t i = r * (NT / 8) + grp;
-        const bool ok = i < n;
-        const uint32_t row = ok ? key_row(keys[i]) : 0u;
-        float s = 0.0f;
-        // all 8 lanes of a group take the same branch, shuffles stay inside the group
-        if (ok) s = exact_score(metric, ip_form, qv, V + (size_t)row * ld, D, g);
-        if (ok && g == 0) keys[i] = make_key(s, row, asc);
+    // two rows per lane group and trip: the loads of the second row are in flight while the first is reduced (a trip waits out
+    // one global round trip either way; 163 survivors at k = 100 were three dependent trips)
+    for (uint32_t r = 0; r < rounds; r += 2) {
+        const uint32_t i0 = r * (NT / 8) + grp, i1 = i0 + NT / 8;
+        const bool ok0 = i0 < n, ok1 = i1 < n;
+        // rows past the end re-score row 0 of the list (uniform control flow inside exact_score) and are dropped
+        const uint32_t row0 = key_row(keys[ok0 ? i0 : 0u]), row1 = key_row(keys[ok1 ? i1 : 0u]);
+        float s0 = 0.0f, s1 = 0.0f;
+        if (n) {
+            s0 = exact_score(metric, ip_form, qv, V + (size_t)row0 * ld, D, g);
+            s1 = exact_score(metric, ip_form, qv, V + (size_t)row1 * ld, D, g);
+        }
+        if (ok0 && g == 0) keys[i0] = make_key(s0, row0, asc);
+        if (ok1 && g == 0) keys[i1] = make_key(s1, row1, asc);
     }
     __syncthreads();
 }
@@ -2680,10 +2686,18 @@ __global__ void __launch_bounds__(NT) k_select(SelectArgs a) {
         const uint32_t m = s_x < mx ? s_x : mx;   // >= k: at least k keys are <= the k-th smallest
         if (m >= a.k) {
             rescore_keys<NT>(xs, m, a.metric, a.ip_form, a.Qf + (size_t)q * a.D, a.V, a.ld, a.D, asc, tid);
-            for (uint32_t i = m + tid; i < 256u; i += NT) xs[i] = KEY_SENTINEL;
-            bitonic_sort_lds<NT>(xs, 256u, tid);
+            // the k-th best of the m <= 256 rescored keys by RANK (keys are unique: the row is part of the key): one thread per key
+            // counts the smaller ones — m broadcast LDS reads instead of the 36 barrier-separated steps of a 256-key bitonic sort
+            __shared__ float s_taux;
             __syncthreads();
-            const float tau_x = key_score(xs[a.k - 1], asc);
+            if ((uint32_t)tid < m) {
+                const uint64_t mine = xs[tid];
+                uint32_t rank = 0;
+                for (uint32_t i = 0; i < m; ++i) rank += xs[i] < mine ? 1u : 0u;
+                if (rank == a.k - 1) s_taux = key_score(mine, asc);
+            }
+            __syncthreads();
+            const float tau_x = s_taux;
             const float e1 = 0.5f * a.marg2[q];
             cut_exact = asc ? tau_x + e1 : tau_x - e1;
             tightened = tau_x == tau_x;  // (NaN scores: keep the coarse rule)
