@@ -1,4 +1,4 @@
-"""GPU: short runs of the randomised parity sweeps (`scripts/stress_parity.py`, `scripts/stress_ivf.py`) with seeds that
+"""GPU: short runs of the randomised parity sweeps (`scripts/stress_parity.py`, `scripts/stress_ivf.py`, `scripts/stress_inflight.py`) with seeds that
 differ from the documented long runs: random shapes / metrics / modes through the C-ABI against the oracle, 0 mismatches."""
 import re
 import subprocess
@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 ROOT = Path(__file__).resolve().parent.parent
 
 
-@pytest.mark.parametrize("script,cases,seed", [("stress_parity.py", 60, 101), ("stress_ivf.py", 60, 202)])
+@pytest.mark.parametrize("script,cases,seed", [("stress_parity.py", 60, 101), ("stress_ivf.py", 60, 202), ("stress_inflight.py", 30, 303)])
 def test_random_sweep_has_no_mismatch(script, cases, seed):
     # case-count-bounded ("c<N>"), not time-bounded: the case list depends on the seed only, not on the machine's speed
     r = subprocess.run([sys.executable, str(ROOT / "scripts" / script), "c%d" % cases, str(seed)], capture_output=True,
