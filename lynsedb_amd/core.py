@@ -308,6 +308,13 @@ class FlatIndex:
         ticket; `wait()` makes the results final in d_rows / d_dists / d_counts.  Up to LYNSE_HIP_CONTEXTS batches overlap on
         the device.  `comm`: the communicator handle of a row-sharded collection (a collective then)."""
         m = metric if isinstance(metric, int) else metric_from_str(metric)
+        if m >= 3 and d_queries.is_floating_point():
+            # float queries of a binary metric are packed by the blocking entry point (pack_binary_query); batches in flight
+            # take packed words: answer this one now (only without a communicator: the sharded entry points are packed-only too)
+            if comm is not None:
+                raise ValueError("sharded searches of a binary metric take packed u64 query words")
+            self.search_device(d_queries, k, m, d_rows, d_dists, d_counts)
+            return SearchTicket(None, None)
         _sync_producer(d_queries)
         t = C.c_void_p()
         fn = lib.lynse_hip_flat_search_submit_packed_u64_device if m >= 3 else lib.lynse_hip_flat_search_submit_f32_device

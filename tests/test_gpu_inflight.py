@@ -103,6 +103,24 @@ def test_packed_hamming_in_flight(L, oracle):
             assert int(c[qi]) == k and np.array_equal(r[qi].astype(np.uint32), e_ids) and np.array_equal(d[qi], e_d), (i, qi)
 
 
+def test_float_queries_of_a_binary_metric_are_answered_by_the_blocking_path(L, oracle):
+    import torch
+
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(12)
+    n, bits, nq, k = 50_000, 256, 40, 10
+    data = (rng.random((n, bits)) < 0.5).astype(f32)
+    idx = L.FlatIndex(None, bits)
+    idx.write(data)
+    q = data[rng.integers(0, n, nq)].copy()
+    q[:, :7] = 1.0 - q[:, :7]
+    o = _tensors(torch, nq, k, dev)
+    idx.search_submit(torch.as_tensor(q, device=dev), k, "hamming", *o).wait()   # packed by pack_binary_query inside the blocking call
+    r, d, c = _host(o)
+    for qi in (0, nq - 1):
+        _assert_oracle(oracle, q[qi], data, k, HAMMING, r[qi], d[qi], c[qi], qi)
+
+
 def test_shapes_that_cannot_be_pipelined_are_answered_inside_submit(L, oracle):
     import torch
 
