@@ -230,14 +230,17 @@ class ShardedFlat:
         the shard; returns a ticket whose wait() makes out.rows / dists / counts final.  A collective with world > 1 (every
         rank submits and waits for the same sequence).  Needs the native communicator (or world == 1); without it the
         batch is answered here and the ticket is already complete."""
+        class _Done:
+            def wait(self):
+                return None
+
+        if metric >= _lib.METRIC_HAMMING and d_queries.is_floating_point():
+            self.search_device(d_queries, k, metric, out)   # float queries of a binary metric: packed inside the blocking call
+            return _Done()
         if self.world == 1 or self.comm is not None:  # (a 1-rank communicator still runs the exchange half: status word, merge)
             return self.index.search_submit(d_queries, k, metric, out.rows, out.dists, out.counts,
                                             comm=self.comm.handle if self.comm is not None else None)
         self.search_device(d_queries, k, metric, out)
-
-        class _Done:
-            def wait(self):
-                return None
         return _Done()
 
     def search(self, queries: np.ndarray, k: int, metric: int):
