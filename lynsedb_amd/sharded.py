@@ -102,7 +102,7 @@ class NativeComm:
 
     def close(self) -> None:
         c, self._c = getattr(self, "_c", None), None
-        if c:
+        if c and lib is not None:  # (at interpreter shutdown the module globals may already be gone: the process exit frees the rest)
             lib.lynse_hip_comm_destroy(c)
 
     def __del__(self):

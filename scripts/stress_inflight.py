@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Randomised sweep of the searches in flight (GPU): lynse_hip_flat_search_submit_* / _wait with random shapes, metrics and
 numbers of batches in flight against the blocking entry points (bit-equal rows, distances, counts) and, for a few queries
-of every case, against the oracle.  Usage: python scripts/stress_inflight.py [seconds | c<N>] [seed]."""
+of every case, against the oracle.  Usage: python scripts/stress_inflight.py [seconds | c<N>] [seed].
+STRESS_COMM=1 sends every batch through a 1-rank RCCL communicator (the exchange half of a sharded ticket: status word in the
+result block, hand-over to the exchange stream, merge kernel)."""
 import sys, time
 from pathlib import Path
 import numpy as np, torch
@@ -16,6 +18,11 @@ budget = float("inf") if max_cases is not None else float(_a1)
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 NAME = {O.IP: "ip", O.L2: "l2", O.COS: "cosine", O.HAMMING: "hamming"}
 dev = torch.device("cuda", 0)
+COMM = None
+import os  # noqa: E402
+if os.environ.get("STRESS_COMM") == "1":
+    from lynsedb_amd.sharded import NativeComm  # noqa: E402
+    COMM = NativeComm(None, 0, 1, 0)
 t0, cases, bad = time.time(), 0, []
 
 
@@ -66,7 +73,7 @@ while time.time() - t0 < budget and (max_cases is None or cases < max_cases):
     got = [outs(nq, k) for _ in dq]
     pending = []
     for i, q in enumerate(dq):
-        pending.append(idx.search_submit(q, k, NAME[metric], *got[i]))
+        pending.append(idx.search_submit(q, k, NAME[metric], *got[i], comm=COMM.handle if COMM is not None else None))
         if len(pending) >= depth:
             pending.pop(0).wait()
     for t in pending:
@@ -92,4 +99,6 @@ while time.time() - t0 < budget and (max_cases is None or cases < max_cases):
         print("MISMATCH", bad[-1], flush=True)
     del idx
 print("cases", cases, "mismatches", len(bad), bad[:10])
+if COMM is not None:
+    COMM.close()
 sys.exit(1 if bad else 0)
