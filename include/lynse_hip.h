@@ -82,7 +82,9 @@ typedef struct lynse_hip_profile {
     uint64_t pool_entries;    /* candidates rescored exactly (sum over queries) */
     uint64_t last_plan;       /* plan of the last profiled float chunk: bit 0 sampled stage plan, bit 1 threshold-only
                                  (lane-max) sample stage, bit 2 certified int8 coarse pass, bit 3 segmented emission,
-                                 bit 4 <= 32-query kernel, bit 5 fused single-launch search (k_small_search), bits 8..15 number of scan stages, bits 16..23 wave tiling
+                                 bit 4 <= 32-query kernel, bit 5 fused single-launch search (k_small_search), bit 6 the search STARTED
+                                 on the certified int8 pass (bit 2 tells what the LAST run used: an overflow retries on the f16
+                                 pass), bits 8..15 number of scan stages, bits 16..23 wave tiling
                                  (0x24 = <2,4,4,2>, 0x42 = <4,2,2,4>, 0x14 = <1,4,1,1>) — lets a test pin the kernel
                                  instantiation a benchmark configuration runs */
 } lynse_hip_profile;
@@ -189,6 +191,11 @@ int lynse_hip_flat_search_packed_u64_device(lynse_hip_flat *h, const uint64_t *d
  * search only (an event recorded between two kernels costs a few microseconds of the stream's time). */
 int lynse_hip_flat_profile_enable(lynse_hip_flat *h, int on);
 int lynse_hip_flat_profile_get(lynse_hip_flat *h, lynse_hip_profile *out, int reset);
+/* Coarse-pass state of a shard (no reference counterpart: the reference has one exact kernel, flat_mmap.rs:4845-4982;
+ * here a certified low-precision pass runs in front of the exact rescoring and can be switched off by the data):
+ * strikes = candidate overflows of the certified int8 pass so far (3 switch it off for the handle; -1 = off because the
+ * rows are not finite), sq8_rows = rows covered by the SQ8 codes currently built (0 = none). */
+int lynse_hip_flat_coarse_state(lynse_hip_flat *h, int *out_strikes, uint64_t *out_sq8_rows);
 /* Tuning knobs (defaults are fine): first-stage rows and growth factor of the contiguous stage plan (the fallback of the
  * default sampled plan), candidate capacity per query (power of two in [256, 16384], default 16384; k <= cap / 4 when the
  * shard holds more than cap rows). */

@@ -332,6 +332,13 @@ class FlatIndex:
         check(lib.lynse_hip_flat_profile_get(self._h, C.byref(p), 1 if reset else 0))
         return {f: getattr(p, f) for f, _ in _lib.Profile._fields_}
 
+    def coarse_state(self) -> dict:
+        """State of the coarse-pass selection: overflow strikes of the certified int8 pass (3 = switched off, -1 = off because the
+        rows are not finite) and the rows covered by the SQ8 codes built so far."""
+        strikes, rows = C.c_int(0), C.c_uint64(0)
+        check(lib.lynse_hip_flat_coarse_state(self._h, C.byref(strikes), C.byref(rows)))
+        return {"i8c_strikes": strikes.value, "sq8_rows": rows.value}
+
 
 class SearchTicket:
     """A batch in flight (FlatIndex.search_submit).  Keeps the tensors of the batch alive until it is waited for."""

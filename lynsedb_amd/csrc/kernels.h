@@ -1294,7 +1294,7 @@ __global__ void __launch_bounds__(WQ * WR * 64, (TQ * TR >= 16) ? 1 : ((WQ * WR 
 #else
     constexpr bool timing = false;  // (phase timing lives in the EXPERIMENTS build: its flag and counters cost SGPRs in the hot loop)
 #endif
-    unsigned long long t_wait = 0, t_bar = 0, t_comp = 0, t_iq = 0, t_iv = 0, tp = timing ? __builtin_amdgcn_s_memtime() : 0;
+    [[maybe_unused]] unsigned long long t_wait = 0, t_bar = 0, t_comp = 0, t_iq = 0, t_iv = 0, tp = timing ? __builtin_amdgcn_s_memtime() : 0;  // (EXPERIMENTS build only)
     for (uint32_t g = 0; g < G; ++g) {
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAIT_OPS) : "memory");
         if (timing) { const unsigned long long t = __builtin_amdgcn_s_memtime(); t_wait += t - tp; tp = t; }

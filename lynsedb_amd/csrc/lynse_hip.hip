@@ -242,7 +242,7 @@ struct lynse_hip_flat {
     uint32_t sq8_a1 = 0;
     bool sq8_finite = false;
     // certified int8 coarse pass (FLAT-IP batches of 33..256 queries): -1 = off (env / strikes), else overflow strikes so far
-    int i8c_strikes = 0;
+    std::atomic<int> i8c_strikes{0};     // (searches under the SHARED lock bump it)
     // gathered ("few matches") filtered path: compact copy of the listed shadow rows, their norms and 32-bit ids
     _Float16* g_rows16 = nullptr;
     float *g_vn2 = nullptr, *g_vrinv = nullptr;
@@ -273,6 +273,11 @@ struct CtxLease {
                 int s = 0;
                 while (s < h->n_ctx && ((h->ctx_busy >> s) & 1u)) ++s;
                 if (s < h->n_ctx) { slot = s; h->ctx_busy |= 1u << s; break; }
+                // every context leased by a TICKET (only a wait() of the caller frees those): an error, not a deadlock
+                if (h->inflight.load(std::memory_order_acquire) >= h->n_ctx) {
+                    h = nullptr;
+                    return set_error(LYNSE_ERR_INVALID_ARGUMENT, "every search context of the handle is held by a ticket: wait for one first (LYNSE_HIP_CONTEXTS)");
+                }
                 h->ctx_cv.wait(lk);
             }
         }
@@ -296,6 +301,21 @@ struct CtxLease {
     }
     ~CtxLease() { release(); }
 };
+
+
+// Writers — append / finalize / lazy builds / setters / the subset-filtered and large-k searches — hold `rw` EXCLUSIVE and
+// refuse to start while tickets of lynse_hip_flat_search_submit_* are outstanding: a ticket does not keep the reader lock
+// (it may be waited for by another thread, and one thread may hold several), it is counted in `inflight` under the
+// shared lock, so a writer that owns the lock sees every ticket submitted before it.
+static int writer_lock(lynse_hip_flat* h, std::unique_lock<std::shared_mutex>& lk) {
+    lk = std::unique_lock<std::shared_mutex>(h->rw);
+    if (h->inflight.load(std::memory_order_acquire) != 0) {
+        lk.unlock();
+        return set_error(LYNSE_ERR_INVALID_ARGUMENT, "searches are in flight on this handle: wait for the outstanding tickets first");
+    }
+    return LYNSE_OK;
+}
+#define LY_WRITER(h, lk) std::unique_lock<std::shared_mutex> lk; LY_TRY(writer_lock((h), lk))
 
 // decides whether the search starting on this thread is a timed one (profiling on, and its turn at the sampling rate)
 static bool profile_begin_search(lynse_hip_flat* h) {
@@ -397,7 +417,7 @@ static int grow_packed(lynse_hip_flat* h, uint64_t need) {
 
 extern "C" int lynse_hip_flat_reserve(lynse_hip_flat* h, uint64_t rows) {
     if (!h) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "handle is NULL");
-    std::unique_lock<std::shared_mutex> lk(h->rw);
+    LY_WRITER(h, lk);
     LY_TRY(use_device(h));
     if (rows > 0xfffffff0ull) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "row count exceeds the u32 id capacity of one shard");
     if (h->packed_only) return grow_packed(h, rows);
@@ -430,7 +450,7 @@ static int append_f32_impl(lynse_hip_flat* h, const float* src, uint64_t n, hipM
     if (!h) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "handle is NULL");
     if (n == 0) return LYNSE_OK;
     if (!src) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "rows is NULL");
-    std::unique_lock<std::shared_mutex> lk(h->rw);
+    LY_WRITER(h, lk);
     LY_TRY(use_device(h));
     if (h->packed_only) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "store holds packed rows; cannot append f32 rows");
     if (h->n + n > 0xfffffff0ull) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "row count exceeds the u32 id capacity of one shard");
@@ -467,7 +487,7 @@ static int append_f32_impl(lynse_hip_flat* h, const float* src, uint64_t n, hipM
 
 extern "C" int lynse_hip_flat_set_dtype(lynse_hip_flat* h, int dtype) {
     if (!h || (dtype != LYNSE_DTYPE_F32 && dtype != LYNSE_DTYPE_F16)) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "bad dtype");
-    std::unique_lock<std::shared_mutex> lk(h->rw);
+    LY_WRITER(h, lk);
     if (h->n || h->packed_only) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "the dtype is fixed once rows are stored");
     h->dtype = dtype;
     return LYNSE_OK;
@@ -501,7 +521,7 @@ static int append_packed_impl(lynse_hip_flat* h, const uint64_t* src, uint64_t n
     if (!h) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "handle is NULL");
     if (n == 0) return LYNSE_OK;
     if (!src) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "words is NULL");
-    std::unique_lock<std::shared_mutex> lk(h->rw);
+    LY_WRITER(h, lk);
     LY_TRY(use_device(h));
     if (h->n > 0 && !h->packed_only) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "store holds f32 rows; cannot append packed rows");
     if (h->n + n > 0xfffffff0ull) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "row count exceeds the u32 id capacity of one shard");
@@ -572,7 +592,7 @@ static int finalize_locked(lynse_hip_flat* h) {
 
 extern "C" int lynse_hip_flat_finalize(lynse_hip_flat* h) {
     if (!h) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "handle is NULL");
-    std::unique_lock<std::shared_mutex> lk(h->rw);
+    LY_WRITER(h, lk);
     LY_TRY(use_device(h));
     return finalize_locked(h);
 }
@@ -594,7 +614,7 @@ static int ensure_packed_locked(lynse_hip_flat* h) {
 
 extern "C" int lynse_hip_flat_set_row_map(lynse_hip_flat* h, uint64_t stride, uint64_t offset) {
     if (!h || stride == 0) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "bad row map");
-    std::unique_lock<std::shared_mutex> lk(h->rw);
+    LY_WRITER(h, lk);
     h->row_stride = stride;
     h->row_offset = offset;
     return LYNSE_OK;
@@ -602,14 +622,14 @@ extern "C" int lynse_hip_flat_set_row_map(lynse_hip_flat* h, uint64_t stride, ui
 
 extern "C" int lynse_hip_flat_set_ip_form(lynse_hip_flat* h, int f) {
     if (!h || f < LYNSE_IPFORM_AUTO || f > LYNSE_IPFORM_BATCH8) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "bad ip form");
-    std::unique_lock<std::shared_mutex> lk(h->rw);
+    LY_WRITER(h, lk);
     h->ip_form = f;
     return LYNSE_OK;
 }
 
 extern "C" int lynse_hip_flat_set_fused_search(lynse_hip_flat* h, int on) {
     if (!h) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "handle is NULL");
-    std::unique_lock<std::shared_mutex> lk(h->rw);
+    LY_WRITER(h, lk);
     h->no_fused = on ? 0 : 1;
     return LYNSE_OK;
 }
@@ -618,7 +638,7 @@ extern "C" int lynse_hip_flat_set_plan(lynse_hip_flat* h, uint32_t stage0_rows, 
     if (!h) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "handle is NULL");
     if (cap < 256 || cap > 16384 || (cap & (cap - 1))) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "cap must be a power of two in [256,16384]");
     if (stage0_rows == 0 || stage0_rows > cap || growth < 2) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "bad stage plan");
-    std::unique_lock<std::shared_mutex> lk(h->rw);
+    LY_WRITER(h, lk);
     (void)hipSetDevice(h->device);
     if (cap != h->cap)
         for (auto& c : h->ctx) c.ws.release();
@@ -678,7 +698,7 @@ extern "C" int lynse_hip_flat_copy_rows_device(const lynse_hip_flat* hc, uint64_
 
 extern "C" int lynse_hip_flat_read_packed(lynse_hip_flat* h, uint64_t first, uint64_t n, uint64_t* out) {
     if (!h || (!out && n)) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "NULL argument");
-    std::unique_lock<std::shared_mutex> lk(h->rw);
+    LY_WRITER(h, lk);
     LY_TRY(use_device(h));
     if (first + n > h->n) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "row range out of bounds");
     LY_TRY(ensure_packed_locked(h));
@@ -1412,14 +1432,14 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
                     // at every threshold tightness measured: 1M x 128 and 4M x 128 / 768, k = 10 and 100)
                     a.dense = (!a.emit_all && waves16 == 0 && metric != M_IP && !filt && seen_before && (dense_env >= 0 ? dense_env != 0 : true)) ? 1 : 0;
                     if (!a.emit_all) seg_geometry(grid, a.dense ? 4 : ((waves16 == 3 || waves16 == 2) ? 4 : 2), &a.nseg, &a.seg);
-#ifdef LYNSE_EXPERIMENTS
-                    if (waves16 == 2) LY_TRY((launch_scan_h16<2, 4, 4, 2, 2, 2, false>(a, metric, grid, st)));
-                    else
-#endif
                     if (qchunks > 1 && !(plan.size() == 1 && a.emit_all == 1))
                         return set_error(LYNSE_ERR_INTERNAL, "the widened pipeline runs single-stage emit-all plans only");
-                    if (waves16 == 3 || waves16 == 2) LY_TRY((launch_scan_h16<2, 4, 4, 2, 3, 2, false>(a, metric, grid, st, qchunks)));
-                    else LY_TRY((launch_scan_h16<4, 2, 2, 4, 2, 2, false>(a, metric, grid, st, qchunks)));
+#ifdef LYNSE_EXPERIMENTS
+                    if (waves16 == 2) { LY_TRY((launch_scan_h16<2, 4, 4, 2, 2, 2, false>(a, metric, grid, st))); }
+                    else
+#endif
+                    if (waves16 == 3) { LY_TRY((launch_scan_h16<2, 4, 4, 2, 3, 2, false>(a, metric, grid, st, qchunks))); }
+                    else { LY_TRY((launch_scan_h16<4, 2, 2, 4, 2, 2, false>(a, metric, grid, st, qchunks))); }
                 }
             }
 #ifdef LYNSE_EXPERIMENTS
@@ -1482,6 +1502,7 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
     }
     if (tl_prof && !binary) {
         const uint64_t tiling = small ? 0x14u : ((waves16 == 3 || waves16 == 2) ? 0x24u : 0x42u);
+        std::lock_guard<std::mutex> plk(h->prof_mu);
         h->prof.last_plan = (sample.sample_tiles ? 1u : 0u) | ((sample.sample_tiles && sample_threshold_only) ? 2u : 0u) | (i8c ? 4u : 0u) |
                             (plan_used_segments ? 8u : 0u) | (small ? 16u : 0u) | ((uint64_t)(plan.size() & 0xff) << 8) | (tiling << 16);
     }
@@ -1555,6 +1576,7 @@ static int run_small(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
     if (timed) {
         LY_HIP(hipEventRecord(e1, st));
         scan_events->push_back({*ev_used - 2, (uint64_t)h->n * nq});
+        std::lock_guard<std::mutex> plk(h->prof_mu);
         h->prof.last_plan = 32u | (1u << 8);  // bit 5: fused single-launch search
     }
     return LYNSE_OK;
@@ -1605,7 +1627,7 @@ static int ensure_sq8_locked(lynse_hip_flat* h) {
 
 extern "C" int lynse_hip_flat_sq8_params(lynse_hip_flat* h, float* mins, float* scales) {
     if (!h) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "handle is NULL");
-    std::unique_lock<std::shared_mutex> lk(h->rw);
+    LY_WRITER(h, lk);
     LY_TRY(use_device(h));
     if (h->packed_only || h->n == 0) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "no f32 rows");
     LY_TRY(finalize_locked(h));
@@ -1699,7 +1721,7 @@ extern "C" int lynse_hip_flat_search_sq8_f32(lynse_hip_flat* h, const float* que
     if (metric > M_COS) return lynse_hip_flat_search_f32(h, queries, nq, k, metric, out_rows, out_dists, out_counts);
     if (nq == 0) return LYNSE_OK;
     if (!queries || !out_counts || (k && (!out_rows || !out_dists))) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "NULL argument");
-    std::unique_lock<std::shared_mutex> lk(h->rw);
+    LY_WRITER(h, lk);
     LY_TRY(use_device(h));
     if (h->packed_only) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "store holds packed rows; float metrics unavailable");
     if (h->dtype != LYNSE_DTYPE_F32) return set_error(LYNSE_ERR_UNSUPPORTED, "SQ8 mode on an F16 shard is not supported");
@@ -1739,9 +1761,10 @@ static int coarse_env() {
     static const int v = []() { const char* e = getenv("LYNSE_HIP_COARSE"); return !e ? 0 : (!strcmp(e, "i8") ? 2 : (!strcmp(e, "f16") ? 1 : 0)); }();
     return v;
 }
-static bool i8c_eligible(const lynse_hip_flat* h, int metric, bool filtered, uint64_t nqc) {
-    return metric == M_IP && !filtered && nqc > SCAN_BQ_SMALL && h->dtype == LYNSE_DTYPE_F32 && scan_variant() == 3 && coarse_env() != 1 &&
-           h->i8c_strikes >= 0 && h->i8c_strikes < 3 && (coarse_env() == 2 || h->n >= 65536);
+static bool i8c_eligible(const lynse_hip_flat* h, int metric, bool filtered, uint64_t nqc, bool view = false) {
+    // view: a row-range view of search_large_k (h->n is the range): the SQ8 codes belong to the whole shard
+    return metric == M_IP && !filtered && !view && nqc > SCAN_BQ_SMALL && h->dtype == LYNSE_DTYPE_F32 && scan_variant() == 3 && coarse_env() != 1 &&
+           h->i8c_strikes.load() >= 0 && h->i8c_strikes.load() < 3 && (coarse_env() == 2 || h->n >= 65536);
 }
 
 // Shared driver: q_src is nq x dim f32 (float metrics / f32 binary queries) or nq x words u64
@@ -1798,24 +1821,33 @@ static int search_impl(lynse_hip_flat* h, const void* q_src, bool packed_queries
         if (binary) return h->packed_only || (h->packed != nullptr && h->n_packed == h->n);
         if (h->packed_only) return true;  // (rejected below)
         if (h->n_stats != h->n || (scan_variant() == 3 && (h->n16 != h->n || h->sv16 != h->sv))) return false;
-        return !i8c_eligible(h, metric, filtered, nq) || (h->sq8 && h->n_sq8 == h->n);
+        return !i8c_eligible(h, metric, filtered, std::min<uint64_t>(nq, QCHUNK), caller_holds_exclusive) || (h->sq8 && h->n_sq8 == h->n);
     };
     // k beyond the candidate capacity of one pass (k > cap / 4 over more than cap rows; the reference accepts any k, and its
-    // server caps at MAX_TOP_K = 10,000, src/server/mod.rs:46): row ranges of `cap` rows, each answered exactly, merged
-    if (!caller_holds_exclusive && !filtered && h->n > h->cap && std::min<uint64_t>(k, h->n) > h->cap / 4)
-        return search_large_k(h, q_src, packed_queries, nq, k, metric, out_rows, out_dists, out_counts, on_device, user_stream);
-    if (!caller_holds_exclusive && filtered && h->n > h->cap && std::min<uint64_t>(std::min<uint64_t>(k, h->n), n_subset) > h->cap / 4)
-        return search_large_k(h, q_src, packed_queries, nq, k, metric, out_rows, out_dists, out_counts, on_device, user_stream,
-                              subset, n_subset, true, bitset_words, n_words);
-    if (!filtered && !user_stream && !caller_holds_exclusive) {
+    // server caps at MAX_TOP_K = 10,000, src/server/mod.rs:46): row ranges of `cap` rows, each answered exactly, merged.
+    // (n and cap are read under the lock the search then runs under: an append between the decision and the search
+    // cannot turn an ordinary search into an unsupported one.)
+    auto needs_large_k = [&]() {
+        if (h->n <= h->cap) return false;
+        const uint64_t kk0 = std::min<uint64_t>(k, h->n);
+        return (filtered ? std::min<uint64_t>(kk0, n_subset) : kk0) > h->cap / 4;
+    };
+    auto go_large_k = [&]() {
+        return filtered ? search_large_k(h, q_src, packed_queries, nq, k, metric, out_rows, out_dists, out_counts, on_device, user_stream,
+                                         subset, n_subset, true, bitset_words, n_words)
+                        : search_large_k(h, q_src, packed_queries, nq, k, metric, out_rows, out_dists, out_counts, on_device, user_stream);
+    };
+    if (!caller_holds_exclusive) {
         rlk.lock();
-        if (derived_ready()) {
+        if (needs_large_k()) { rlk.unlock(); return go_large_k(); }
+        if (!filtered && !user_stream && derived_ready()) {
             LY_TRY(lease.acquire(h));
         } else {
             rlk.unlock();
+            LY_TRY(writer_lock(h, xlk));  // (builds, subset filters, a caller's stream: exclusive, and no tickets outstanding)
+            if (needs_large_k()) { xlk.unlock(); return go_large_k(); }
         }
     }
-    if (!rlk.owns_lock() && !caller_holds_exclusive) xlk.lock();
     hipStream_t st = user_stream ? user_stream : cur(h).stream;
     const hipMemcpyKind in_kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
     const hipMemcpyKind out_kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
@@ -1968,6 +2000,7 @@ static int search_impl(lynse_hip_flat* h, const void* q_src, bool packed_queries
         LY_HIP(hipEventRecord(ev_begin, st));
     }
     uint64_t fallback_queries = 0;
+    bool i8c_attempted = false;
 
     // queries per pipeline pass: QCHUNK; a widened handle (the k-means assignment's centroid store: unfiltered float search of
     // a shard of <= cap rows) takes h->qchunk queries per pass, one k_scan_h16 launch scoring qchunk / 256 chunks (blockIdx.y)
@@ -1991,11 +2024,13 @@ static int search_impl(lynse_hip_flat* h, const void* q_src, bool packed_queries
         // certified int8 coarse pass: FLAT-IP batches of 33..256 queries over an f32 shard with finite values (auto: shards
         // of >= 64K rows; LYNSE_HIP_COARSE=i8 / f16 forces / disables it).  An overflow first retries the f16 coarse pass;
         // three such strikes turn the int8 pass off for this handle (margins too wide for this data).
-        bool i8c = i8c_eligible(h, metric, filtered, nqc);
+        bool i8c = i8c_eligible(h, metric, filtered, nqc, caller_holds_exclusive);
         if (i8c) {
-            LY_TRY(ensure_sq8_locked(h));
-            if (!h->sq8_finite) { h->i8c_strikes = -1; i8c = false; }
+            if (xlk.owns_lock()) LY_TRY(ensure_sq8_locked(h));          // lazy build: exclusive path only
+            else if (!(h->sq8 && h->n_sq8 == h->n)) i8c = false;         // (shared path: derived_ready() saw them built)
+            if (i8c && !h->sq8_finite) { h->i8c_strikes.store(-1); i8c = false; }
         }
+        i8c_attempted = i8c_attempted || i8c;
         if (small_path_ok(h, nqc, kk, metric, filtered)) {
             // fused single-launch search: the last workgroup writes straight into the caller's device buffers, or into
             // pinned host memory (no copy kernels, one synchronisation); it cannot overflow
@@ -2040,7 +2075,7 @@ static int search_impl(lynse_hip_flat* h, const void* q_src, bool packed_queries
             fallback_queries += nov;
             if (i8c) {  // same plan level again with the f16 coarse pass
                 i8c = false;
-                h->i8c_strikes += 1;
+                if (h->i8c_strikes.load() >= 0) h->i8c_strikes.fetch_add(1);
                 --level;
                 continue;
             }
@@ -2052,7 +2087,22 @@ static int search_impl(lynse_hip_flat* h, const void* q_src, bool packed_queries
     if (tl_prof) {
         LY_HIP(hipEventRecord(ev_end, st));
         LY_TRY(prof_accumulate(h, cur(h), ev_begin, ev_end, scan_events, binary, fallback_queries));
+        if (i8c_attempted) {  // bit 6: the search STARTED on the certified int8 pass (an overflow may have sent it to the f16 pass)
+            std::lock_guard<std::mutex> plk(h->prof_mu);
+            h->prof.last_plan |= 64u;
+        }
     }
+    return LYNSE_OK;
+}
+
+// State of the coarse-pass selection of a shard (tests, diagnostics): strikes = overflows of the certified int8 pass so
+// far (3 switch it off for the handle, -1 = switched off because the data is not finite), sq8_rows = rows covered by the
+// SQ8 codes currently built.
+extern "C" int lynse_hip_flat_coarse_state(lynse_hip_flat* h, int* out_strikes, uint64_t* out_sq8_rows) {
+    if (!h) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "handle is NULL");
+    std::shared_lock<std::shared_mutex> lk(h->rw);
+    if (out_strikes) *out_strikes = h->i8c_strikes.load();
+    if (out_sq8_rows) *out_sq8_rows = h->sq8 ? h->n_sq8 : 0;
     return LYNSE_OK;
 }
 
@@ -2065,7 +2115,7 @@ static int search_impl(lynse_hip_flat* h, const void* q_src, bool packed_queries
 static int search_large_k(lynse_hip_flat* h, const void* q_src, bool packed_queries, uint64_t nq, uint32_t k, int metric,
                           uint64_t* out_rows, float* out_dists, uint32_t* out_counts, bool on_device, hipStream_t user_stream,
                           const uint64_t* subset, uint64_t n_subset, bool filtered, const uint64_t* bitset_words, uint64_t n_words) {
-    std::unique_lock<std::shared_mutex> xlk(h->rw);
+    LY_WRITER(h, xlk);
     LY_TRY(use_device(h));
     const bool binary = metric >= M_HAMMING;
     if (packed_queries && !binary) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "packed queries need a binary metric");
@@ -2330,7 +2380,7 @@ extern "C" int lynse_hip_top_k_search(const float* query, const float* candidate
     lynse_hip_flat* h = sc.h;
     {   // empty the shard (capacity and buffers stay)
         std::unique_lock<std::shared_mutex> lk(h->rw);
-        h->n = 0; h->n_stats = 0; h->n16 = 0; h->n_packed = 0; h->n_sq8 = 0; h->i8c_strikes = 0;
+        h->n = 0; h->n_stats = 0; h->n16 = 0; h->n_packed = 0; h->n_sq8 = 0; h->i8c_strikes.store(0);
         h->amax = h->vmax = h->vmin = 0.f; h->sv = 1.f; h->cos_degenerate = 0;
         const uint32_t init[4] = {0u, 0u, 0x7f800000u, 0u};
         LY_TRY(use_device(h));

@@ -1,0 +1,170 @@
+"""Deterministic `-m gpu` oracle tests that REACH the certified int8 coarse pass (FLAT-IP, 33..256 queries over >= 64K
+rows) on data that is hostile to per-dimension min / scale SQ8 — the bound E of DESIGN.md §3b is a hand derivation, and
+uniform[0,1) data (the benchmark's) is the friendliest input it can meet (VERDICT r2 "weak" #1 / "next" #3).
+
+Every case goes through the C-ABI, asserts from `profile_get()["last_plan"]` that the search STARTED on the int8 pass
+(bit 6; bit 2 = the last run still used it, i.e. no overflow retry), and compares ids and f32 distance bits with the CPU
+oracle (`oracle.canonical_topk`, the restatement of exact_flat_search, flat_mmap.rs:4845-4982 + the batch-8 IP kernel
+simd.rs:1452-1525).  Results never depend on the coarse pass — what these cases pin is that the certified margin keeps
+every true neighbour on such data, and that the safety net (f16 retry, three strikes) engages where the margin explodes.
+"""
+import numpy as np
+import pytest
+
+import oracle as O
+
+pytestmark = pytest.mark.gpu
+f32 = np.float32
+
+PLAN_I8C, PLAN_I8C_STARTED = 4, 64
+CHECK = (0, 1, 31, 32, 33, 63, 64, 100, 127, 128, 129, 199, 254, 255)
+
+
+@pytest.fixture(scope="module")
+def L():
+    import lynsedb_amd as L_
+
+    assert L_._lib.device_count() >= 1
+    return L_
+
+
+def run_case(L, oracle, data, queries, k, tag, expect_i8c_kept=True, check=CHECK):
+    n, dim = data.shape
+    idx = L.FlatIndex(None, dim)
+    idx.reserve(n)
+    for b in range(0, n, 200_000):
+        idx.write(data[b:b + 200_000])
+    idx.finalize()
+    idx.profile_enable(True)
+    idx.profile_get(reset=True)
+    rows, dists, counts = idx.search_batch_arrays(queries, k, "ip")
+    p = idx.profile_get(reset=True)
+    flags = int(p["last_plan"]) & 0xff
+    assert flags & PLAN_I8C_STARTED, (tag, "the search did not start on the certified int8 pass", bin(flags))
+    if expect_i8c_kept:
+        assert flags & PLAN_I8C and p["fallback_queries"] == 0, (tag, p)
+    for qi in check:
+        if qi >= len(queries):
+            continue
+        e_ids, e_d = oracle.canonical_topk(queries[qi], data, k, O.IP)
+        c = int(counts[qi])
+        assert c == len(e_ids), (tag, qi, c)
+        assert np.array_equal(rows[qi, :c].astype(np.uint64), e_ids.astype(np.uint64)), (tag, qi, rows[qi, :c], e_ids)
+        assert np.array_equal(dists[qi, :c].view(np.uint32), e_d.view(np.uint32)), (tag, qi, dists[qi, :c], e_d)
+    return idx, p, (rows, dists, counts)
+
+
+def unit_rows(rng, n, dim):
+    x = np.empty((n, dim), f32)
+    for b in range(0, n, 100_000):
+        e = min(n, b + 100_000)
+        blk = rng.standard_normal((e - b, dim)).astype(f32)
+        blk /= np.linalg.norm(blk, axis=1, keepdims=True)
+        x[b:e] = blk
+    return x
+
+
+def test_unit_gaussian_1m_x_768_mixed_sign_queries(L, oracle):
+    """N(0,1) rows L2-normalised (SURVEY §8(d) C2's second distribution), mixed-sign queries: scores are N(0, 1/768), the
+    top-10 sits ~4.7 sigma out and the int8 margin is a sizeable fraction of that."""
+    rng = np.random.default_rng(1001)
+    n, dim, nq, k = 1_000_000, 768, 256, 10
+    data = unit_rows(rng, n, dim)
+    queries = unit_rows(rng, nq, dim)
+    queries[::2] = (data[rng.integers(0, n, nq // 2)] + 0.02 * rng.standard_normal((nq // 2, dim)).astype(f32)).astype(f32)
+    idx, p, _ = run_case(L, oracle, data, queries, k, "unit_gaussian")
+    assert p["pool_entries"] / nq < 4000, p   # the margin is data dependent: on record, and bounded
+
+
+def test_constant_and_tiny_range_dimensions(L, oracle):
+    """10 % of the dimensions constant (scale = 0: the bound must treat them as exact), 5 % with a range of 1e-6 around
+    a large offset (codes use all 256 levels of a meaningless range), negative queries."""
+    rng = np.random.default_rng(1002)
+    n, dim, nq, k = 300_000, 256, 200, 10
+    data = rng.standard_normal((n, dim)).astype(f32)
+    const = rng.choice(dim, dim // 10, replace=False)
+    data[:, const] = rng.standard_normal(len(const)).astype(f32) * 3.0
+    tiny = rng.choice(np.setdiff1d(np.arange(dim), const), dim // 20, replace=False)
+    data[:, tiny] = (5.0 + 1e-6 * rng.random((n, len(tiny)))).astype(f32)
+    queries = -np.abs(rng.standard_normal((nq, dim))).astype(f32)
+    queries[:50] = rng.standard_normal((50, dim)).astype(f32)
+    run_case(L, oracle, data, queries, k, "constant_dims")
+
+
+def test_lognormal_row_scales(L, oracle):
+    """Row norms spread over three orders of magnitude: the per-dimension range is set by the few largest rows, most rows
+    quantise to a handful of codes around the middle."""
+    rng = np.random.default_rng(1003)
+    n, dim, nq, k = 400_000, 384, 256, 10
+    data = rng.standard_normal((n, dim)).astype(f32)
+    data *= np.exp(1.5 * rng.standard_normal((n, 1))).astype(f32)
+    queries = rng.standard_normal((nq, dim)).astype(f32)
+    run_case(L, oracle, data, queries, k, "lognormal", expect_i8c_kept=False)
+
+
+def test_offset_data_far_from_zero(L, oracle):
+    """Every dimension lives in [1000, 1001]: B_q dominates the score, the f32 roundings of B_q + s_q * dot are the
+    delicate term of the bound."""
+    rng = np.random.default_rng(1004)
+    n, dim, nq, k = 200_000, 128, 64, 10
+    data = (1000.0 + rng.random((n, dim))).astype(f32)
+    queries = rng.standard_normal((nq, dim)).astype(f32)
+    run_case(L, oracle, data, queries, k, "offset", expect_i8c_kept=False)
+
+
+def test_outlier_dimension_overflows_retries_and_strikes_out(L, oracle):
+    """One row carries 1e4 in one dimension: that dimension's scale collapses, its quantisation error times |q_d| dwarfs
+    every score gap, the int8 margin lets (nearly) every row through -> candidate overflow -> the SAME plan level is
+    re-run on the f16 coarse pass (and further down the ladder if that overflows too); results stay exact, every such
+    batch is a strike, and the third strike switches the int8 pass off for the handle."""
+    rng = np.random.default_rng(1005)
+    n, dim, nq, k = 150_000, 128, 64, 10
+    data = rng.standard_normal((n, dim)).astype(f32)
+    data[12345, 7] = 1.0e4
+    queries = rng.standard_normal((nq, dim)).astype(f32)
+    idx, p, first = run_case(L, oracle, data, queries, k, "outlier", expect_i8c_kept=False, check=(0, 1, 33, 63))
+    assert p["fallback_queries"] > 0, p                       # the overflow ladder ran
+    assert not (int(p["last_plan"]) & PLAN_I8C), p            # ... and the run that answered was not the int8 pass
+    st = idx.coarse_state()
+    assert st["i8c_strikes"] == 1 and st["sq8_rows"] == n, st
+    for expected in (2, 3):
+        r, d, c = idx.search_batch_arrays(queries, k, "ip")
+        assert np.array_equal(r, first[0]) and np.array_equal(d.view(np.uint32), first[1].view(np.uint32))
+        assert idx.coarse_state()["i8c_strikes"] == expected
+    idx.profile_get(reset=True)
+    r, d, c = idx.search_batch_arrays(queries, k, "ip")       # struck out: starts on the f16 pass
+    p4 = idx.profile_get(reset=True)
+    assert not (int(p4["last_plan"]) & PLAN_I8C_STARTED), p4
+    assert idx.coarse_state()["i8c_strikes"] == 3
+    assert np.array_equal(r, first[0]) and np.array_equal(d.view(np.uint32), first[1].view(np.uint32))
+
+
+def test_non_finite_rows_switch_the_int8_pass_off(L, oracle):
+    rng = np.random.default_rng(1006)
+    n, dim, nq, k = 100_000, 64, 40, 5
+    data = rng.standard_normal((n, dim)).astype(f32)
+    data[777, 3] = np.inf
+    queries = np.abs(rng.standard_normal((nq, dim))).astype(f32)
+    idx = L.FlatIndex(None, dim)
+    idx.write(data)
+    idx.finalize()
+    rows, dists, counts = idx.search_batch_arrays(queries, k, "ip")
+    assert idx.coarse_state()["i8c_strikes"] == -1
+    for qi in (0, 39):
+        e_ids, e_d = oracle.canonical_topk(queries[qi], data, k, O.IP)
+        assert np.array_equal(rows[qi].astype(np.uint64), e_ids.astype(np.uint64)), (qi, rows[qi], e_ids)
+        assert np.array_equal(dists[qi].view(np.uint32), e_d.view(np.uint32))
+        assert rows[qi, 0] == 777 and np.isinf(dists[qi, 0])   # +inf * positive query component wins
+
+
+def test_many_queries_tie_for_the_same_rows(L, oracle):
+    """All 256 queries are the SAME vector and 40 rows are exact duplicates of the best row: every query column must
+    resolve the ties by row id, and the level-1 / DENSE epilogues see identical accumulators in every column."""
+    rng = np.random.default_rng(1007)
+    n, dim, nq, k = 131_072, 192, 256, 10
+    data = rng.random((n, dim), dtype=f32)
+    dup = np.sort(rng.choice(n, 40, replace=False))
+    data[dup] = data[dup[0]] * 1.5
+    queries = np.repeat(rng.random((1, dim), dtype=f32), nq, axis=0)
+    idx, p, (rows, dists, counts) = run_case(L, oracle, data, queries, k, "same_query")
+    assert np.all(rows == rows[0]) and np.array_equal(rows[0], dup[:k].astype(np.uint64))
