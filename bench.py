@@ -266,7 +266,8 @@ def main():
             "launches": launches, "avg_launch_us": round(prof["scan_us"] / launches, 2),
             "launches_per_step": round(launches / timed_steps, 2), "timed_steps": timed_steps,
             "plan": {"sampled": bool(plan & 1), "threshold_only_sample": bool(plan & 2), "int8_coarse_pass": i8c,
-                     "segmented_emission": bool(plan & 8), "stages": (plan >> 8) & 0xff, "tiling": hex((plan >> 16) & 0xff)},
+                     "segmented_emission": bool(plan & 8), "fused_sample_stage": bool(plan & 128), "stages": (plan >> 8) & 0xff,
+                     "tiling": hex((plan >> 16) & 0xff)},
             "note": ("rank-0 shard; time = sum of HIP-event durations of the scan launches on the launch stream, every %d-th step of the timed region" % max(args.profile_every, 1))
                     + ("; with %d batches in flight the event brackets of a launch also hold the time it waits for CUs behind other batches' kernels "
                        "(kernel durations proper: the one-GPU line / profiles/)" % in_flight if in_flight > 1 else ""),

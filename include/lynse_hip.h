@@ -84,7 +84,8 @@ typedef struct lynse_hip_profile {
                                  (lane-max) sample stage, bit 2 certified int8 coarse pass, bit 3 segmented emission,
                                  bit 4 <= 32-query kernel, bit 5 fused single-launch search (k_small_search), bit 6 the search STARTED
                                  on the certified int8 pass (bit 2 tells what the LAST run used: an overflow retries on the f16
-                                 pass), bits 8..15 number of scan stages, bits 16..23 wave tiling
+                                 pass), bit 7 the sample stage ran INSIDE the launch of the first threshold stage (one scan launch less than
+                                 stages), bits 8..15 number of scan stages, bits 16..23 wave tiling
                                  (0x24 = <2,4,4,2>, 0x42 = <4,2,2,4>, 0x14 = <1,4,1,1>) — lets a test pin the kernel
                                  instantiation a benchmark configuration runs */
 } lynse_hip_profile;

@@ -74,6 +74,11 @@ __device__ __forceinline__ float exact_score_f16seq(int metric, const float* __r
     return __shfl(r, 0, 8);
 }
 
+// UB: 8-element steps whose loads are issued together (the FMA chain keeps the reference's order either way).  One candidate
+// is a chain of D / 8 dependent FMAs per lane; with the loads of 8 steps in flight a 768-d row is 12 dependent global round
+// trips (~1 us each: the exact rescoring of a handful of rows was half of k_select's 26 us) — the latency-bound callers
+// (rescore_keys, k_rescore_pool) ask for 32.
+template <int UB = 8>
 __device__ __forceinline__ float exact_score(int metric, int ip_form, const float* __restrict__ q,
                                              const float* __restrict__ v, uint32_t D, int g) {
     if (ip_form == LYNSE_IPFORM_F16SEQ) return exact_score_f16seq(metric, q, v, D, g);
@@ -83,12 +88,21 @@ __device__ __forceinline__ float exact_score(int metric, int ip_form, const floa
         // of D/8 dependent FMAs, and waiting out a global-load round trip per step made k_final latency-bound
         float acc = 0.0f;
         uint32_t i = 0;
-        for (; i + 8 <= chunks; i += 8) {
-            float a[8], b[8];
+        for (; i + UB <= chunks; i += UB) {
+            float a[UB], b[UB];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) { a[u] = q[(i + u) * 8 + g]; b[u] = v[(i + u) * 8 + g]; }
+            for (int u = 0; u < UB; ++u) { a[u] = q[(i + u) * 8 + g]; b[u] = v[(i + u) * 8 + g]; }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) acc = __fmaf_rn(a[u], b[u], acc);
+            for (int u = 0; u < UB; ++u) acc = __fmaf_rn(a[u], b[u], acc);
+        }
+        if constexpr (UB > 8) {
+            for (; i + 8 <= chunks; i += 8) {
+                float a[8], b[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { a[u] = q[(i + u) * 8 + g]; b[u] = v[(i + u) * 8 + g]; }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc = __fmaf_rn(a[u], b[u], acc);
+            }
         }
         for (; i < chunks; ++i) acc = __fmaf_rn(q[i * 8 + g], v[i * 8 + g], acc);
         float sum = hsum8(acc);
@@ -100,12 +114,12 @@ __device__ __forceinline__ float exact_score(int metric, int ip_form, const floa
         const uint32_t dbl = chunks / 2, single = chunks % 2;
         float acc0 = 0.0f, acc1 = 0.0f;
         uint32_t i = 0;
-        for (; i + 4 <= dbl; i += 4) {
-            float a[8], b[8];
+        for (; i + UB / 2 <= dbl; i += UB / 2) {
+            float a[UB], b[UB];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) { a[u] = q[i * 16 + u * 8 + g]; b[u] = v[i * 16 + u * 8 + g]; }
+            for (int u = 0; u < UB; ++u) { a[u] = q[i * 16 + u * 8 + g]; b[u] = v[i * 16 + u * 8 + g]; }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < UB / 2; ++u) {
                 if (l2) {
                     const float d0 = __fsub_rn(a[2 * u], b[2 * u]), d1 = __fsub_rn(a[2 * u + 1], b[2 * u + 1]);
                     acc0 = __fmaf_rn(d0, d0, acc0);
@@ -113,6 +127,24 @@ __device__ __forceinline__ float exact_score(int metric, int ip_form, const floa
                 } else {
                     acc0 = __fmaf_rn(a[2 * u], b[2 * u], acc0);
                     acc1 = __fmaf_rn(a[2 * u + 1], b[2 * u + 1], acc1);
+                }
+            }
+        }
+        if constexpr (UB > 8) {
+            for (; i + 4 <= dbl; i += 4) {
+                float a[8], b[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { a[u] = q[i * 16 + u * 8 + g]; b[u] = v[i * 16 + u * 8 + g]; }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (l2) {
+                        const float d0 = __fsub_rn(a[2 * u], b[2 * u]), d1 = __fsub_rn(a[2 * u + 1], b[2 * u + 1]);
+                        acc0 = __fmaf_rn(d0, d0, acc0);
+                        acc1 = __fmaf_rn(d1, d1, acc1);
+                    } else {
+                        acc0 = __fmaf_rn(a[2 * u], b[2 * u], acc0);
+                        acc1 = __fmaf_rn(a[2 * u + 1], b[2 * u + 1], acc1);
+                    }
                 }
             }
         }
@@ -151,15 +183,28 @@ __device__ __forceinline__ float exact_score(int metric, int ip_form, const floa
     // cosine distance
     float d = 0.0f, x = 0.0f, y = 0.0f;
     uint32_t i = 0;
-    for (; i + 8 <= chunks; i += 8) {
-        float a8[8], b8[8];
+    for (; i + UB <= chunks; i += UB) {
+        float a8[UB], b8[UB];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) { a8[u] = q[(i + u) * 8 + g]; b8[u] = v[(i + u) * 8 + g]; }
+        for (int u = 0; u < UB; ++u) { a8[u] = q[(i + u) * 8 + g]; b8[u] = v[(i + u) * 8 + g]; }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < UB; ++u) {
             d = __fmaf_rn(a8[u], b8[u], d);
             x = __fmaf_rn(a8[u], a8[u], x);
             y = __fmaf_rn(b8[u], b8[u], y);
+        }
+    }
+    if constexpr (UB > 8) {
+        for (; i + 8 <= chunks; i += 8) {
+            float a8[8], b8[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { a8[u] = q[(i + u) * 8 + g]; b8[u] = v[(i + u) * 8 + g]; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                d = __fmaf_rn(a8[u], b8[u], d);
+                x = __fmaf_rn(a8[u], a8[u], x);
+                y = __fmaf_rn(b8[u], b8[u], y);
+            }
         }
     }
     for (; i < chunks; ++i) {
@@ -425,6 +470,17 @@ struct ScanArgs {
     const struct IvfTile* tiles;
     const uint32_t* pair_q;
     unsigned long long* dbg;  // debug_flags & 64: per-block phase cycle sums [block][wave][4]: wait, barrier, issue, compute
+    // Fused sample stage (k_scan_h16<..., FS = 1>): workgroup b first scores sample tile b (rows [b * fs_stride, +BR) of the
+    // WHOLE shard, fs_rows rows), publishes its lane-max keys, and the grid agrees on the first thresholds inside the
+    // launch (two grid-wide hand-overs around a per-query select by workgroup q) before the ordinary tiles of the stage run
+    // under them — the sample launch and its k_select are gone (fused_sample_threshold, below).
+    uint32_t fs_stride, fs_rows;
+    uint32_t* gsync;          // [0] arrivals 1, [1] arrivals 2, [2] abort (zeroed by the prep kernel of the batch)
+    const float* Qf;          // f32 queries (exact rescoring of the k best sample rows)
+    const float* marg2;
+    float* thr_out;           // = thr (written by the select of the fused sample)
+    uint32_t k;
+    int ip_form, metric;
 };
 
 struct IvfTile {
@@ -1010,6 +1066,157 @@ __global__ void __launch_bounds__(256) k_rows_to_f16(const float* __restrict__ V
 // address for rows, pre-applied in the image for queries).  A and B fragments are single
 // ds_read_b128s.  Ring protocol as k_scan_glds, NS >= 2 stages.
 // ------------------------------------------------------------------------------------------------
+
+// ---- fused sample stage of k_scan_h16 (FS = 1) ----------------------------------------------------
+__device__ __forceinline__ uint64_t fs_readlane_u64(uint64_t v, int src_uniform) {
+    const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)v, src_uniform), hi = __builtin_amdgcn_readlane((uint32_t)(v >> 32), src_uniform);
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint64_t fs_shfl_u64(uint64_t v, int src) {
+    const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)v, src, 64), hi = (uint32_t)__shfl((int)(uint32_t)(v >> 32), src, 64);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+// Grid-wide hand-over of the fused sample stage: every workgroup is resident (grid <= CUs, one workgroup per CU by LDS),
+// thread 0 arrives on a counter the prep kernel zeroed (agent-scope release in front: MI355X_MICROARCH.md, Guideline 16)
+// and polls it relaxed; `flag` is a word of the LDS ring stage this workgroup has just consumed (free until the next slab
+// step issues into it).  A launch that cannot get all its workgroups resident (another fully occupying launch holding
+// CUs) never completes the count: the poll gives up after ~0.1 s, raises the abort word, and every workgroup leaves — the
+// select behind the launch turns the abort into the overflow flag of every query and the host re-runs the batch on the
+// ordinary plan.  Returns false on abort.
+__device__ __forceinline__ bool fs_grid_sync(uint32_t* ctr, uint32_t* abort_word, uint32_t target, volatile uint32_t* flag, int tid) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's stores (and its LDS-DMA prefetch) have completed
+    __syncthreads();
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+        uint32_t ok = 1;
+        while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            if (__hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { ok = 0; break; }
+            if (__builtin_amdgcn_s_memtime() - t0 > (1ull << 28)) {
+                __hip_atomic_store(abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ok = 0;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(4);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        *flag = ok;
+    }
+    __syncthreads();
+    const uint32_t ok = *flag;
+    __syncthreads();
+    return ok != 0;
+}
+
+// The workgroup (NT threads) derives the first threshold of query q from the nkeys lane-max keys the sample tiles left in
+// keys_g (best-first u64 keys, KEY_SENTINEL = no row).  k_select's threshold-only rule with two changes that keep it valid:
+// the k "best" rows are the k smallest of a two-level "two smallest per lane" reduction (the k-th of them is >= the true k-th
+// smallest, so >= k rows are at least as good as it: a valid tau, looser only when three of the true best k share a lane's
+// stripe), and tau_x is the WORST exact score of exactly those k rows (k rows with an exact score >= tau_x exist).  cut =
+// the tighter of tau -/+ 2E and tau_x -/+ E, as k_select's cut_of.  Fewer than k real keys: the threshold stays open.
+// scr_a / scr_b: two free 32 KiB ring stages of the caller's LDS.  Every step is one memory round trip for the whole
+// workgroup: the keys (one batch of loads per wave), then the k rows, staged in LDS with coalesced loads so that the
+// reference-order FMA chains of exact_score run out of LDS (a chain straight from HBM is D / 64 dependent round trips —
+// 70-100 us per query in the first version of this function).
+template <int NT>
+__device__ __forceinline__ void fused_sample_threshold(const uint64_t* __restrict__ keys_g, uint32_t nkeys, uint32_t k, float marg2, int metric,
+                                                       int ip_form, const float* __restrict__ qv, const float* __restrict__ V, uint32_t ld,
+                                                       uint32_t D, float* __restrict__ thr_q, char* scr_a, char* scr_b, int tid) {
+    constexpr int NWV = NT / 64;
+    const int lane = tid & 63, wave = tid >> 6;
+    const bool asc = metric_ascending(metric);
+    uint64_t* cand2 = reinterpret_cast<uint64_t*>(scr_b);                 // [NWV][128] per-wave candidates
+    uint32_t* sel_rows = reinterpret_cast<uint32_t*>(scr_b + 8192);       // [k] rows to rescore
+    float* sel_score = reinterpret_cast<float*>(scr_b + 8192 + 256);      // [k] their exact scores
+    volatile float* s_tau = reinterpret_cast<volatile float*>(scr_b + 8192 + 512);  // [0] tau, [1] 1.0 = k keys found
+    float* q_lds = reinterpret_cast<float*>(scr_b + 9216);                // [D] the query (<= 22 KiB)
+    float* rows_lds = reinterpret_cast<float*>(scr_a);                    // [chunk][D] rows being rescored
+    auto top2 = [&](uint64_t key, uint64_t& b0, uint64_t& b1) {
+        const bool lt0 = key < b0, lt1 = key < b1;
+        b1 = lt0 ? b0 : (lt1 ? key : b1);
+        b0 = lt0 ? key : b0;
+    };
+    // ---- level 1: every wave reduces its share of the keys to two per lane
+    {
+        uint64_t b0 = KEY_SENTINEL, b1 = KEY_SENTINEL;
+        const uint32_t per_wave = (nkeys + NWV - 1) / NWV, w0 = wave * per_wave, w1 = (w0 + per_wave < nkeys) ? w0 + per_wave : nkeys;
+        for (uint32_t i0 = w0; i0 < w1; i0 += 64 * 8) {
+            uint64_t kv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const uint32_t i = i0 + u * 64 + lane;
+                kv[u] = i < w1 ? keys_g[i] : KEY_SENTINEL;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) top2(kv[u], b0, b1);
+        }
+        cand2[wave * 128 + lane] = b0;
+        cand2[wave * 128 + 64 + lane] = b1;
+    }
+    const bool q_in_lds = D * 4u <= 22528u;
+    if (q_in_lds)
+        for (uint32_t i = tid; i < D; i += NT) q_lds[i] = qv[i];
+    if (tid == 0) { s_tau[0] = 0.0f; s_tau[1] = 0.0f; }
+    __syncthreads();
+    // ---- level 2 (one wave): two per lane again, ranks, the k smallest
+    if (wave == 0) {
+        uint64_t b0 = KEY_SENTINEL, b1 = KEY_SENTINEL;
+#pragma unroll
+        for (int u = 0; u < 2 * NWV; ++u) top2(cand2[u * 64 + lane], b0, b1);
+        uint32_t r0 = 0, r1 = 0;  // ranks among the 128 candidates (real keys are unique: the row is part of the key)
+        for (int l = 0; l < 64; ++l) {
+            const uint64_t o0 = fs_readlane_u64(b0, l), o1 = fs_readlane_u64(b1, l);
+            r0 += (o0 < b0 ? 1u : 0u) + (o1 < b0 ? 1u : 0u);
+            r1 += (o0 < b1 ? 1u : 0u) + (o1 < b1 ? 1u : 0u);
+        }
+        const bool in0 = b0 != KEY_SENTINEL && r0 < k, in1 = b1 != KEY_SENTINEL && r1 < k;
+        if (in0) sel_rows[r0] = key_row(b0);
+        if (in1) sel_rows[r1] = key_row(b1);
+        const uint64_t mk = __ballot((in0 && r0 == k - 1) || (in1 && r1 == k - 1));
+        if (mk) {   // the key of rank k - 1 exists <=> at least k real keys
+            const int src = __builtin_ctzll(mk);
+            const uint64_t kk0 = fs_readlane_u64(b0, src), kk1 = fs_readlane_u64(b1, src);
+            const uint32_t rr0 = __builtin_amdgcn_readlane(r0, src);
+            if (lane == 0) { s_tau[0] = key_score(rr0 == k - 1 ? kk0 : kk1, asc); s_tau[1] = 1.0f; }
+        }
+    }
+    __syncthreads();
+    if (s_tau[1] == 0.0f) return;   // fewer than k sample keys: the threshold stays open (uniform: every thread reads the same word)
+    // ---- exact scores of the k rows, in chunks that fit the row stage
+    const uint32_t chunk_rows = (32768u / (D * 4u)) < 1u ? 1u : (32768u / (D * 4u));
+    const int g = lane & 7;
+    for (uint32_t c0 = 0; c0 < k; c0 += chunk_rows) {
+        const uint32_t cn = (k - c0 < chunk_rows) ? k - c0 : chunk_rows;
+        if (D * 4u <= 32768u) {
+            const uint32_t total = cn * D;
+            for (uint32_t i = tid; i < total; i += NT) {
+                const uint32_t r = i / D, d = i - r * D;
+                rows_lds[i] = V[(size_t)sel_rows[c0 + r] * ld + d];
+            }
+        }
+        __syncthreads();
+        for (uint32_t r = tid >> 3; r < cn; r += NT / 8) {   // (the 8 lanes of a group share r: uniform control flow inside exact_score)
+            const float* vrow = (D * 4u <= 32768u) ? rows_lds + (size_t)r * D : V + (size_t)sel_rows[c0 + r] * ld;
+            float sc = exact_score(metric, ip_form, q_in_lds ? q_lds : qv, vrow, D, g);
+            if (sc != sc) sc = asc ? LY_INF : -LY_INF;   // NaN sorts last (make_key)
+            if (g == 0) sel_score[c0 + r] = sc;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        float worst = asc ? -LY_INF : LY_INF;
+        for (uint32_t i = 0; i < k; ++i) worst = asc ? fmaxf(worst, sel_score[i]) : fminf(worst, sel_score[i]);
+        const float tau = s_tau[0];
+        const float c = asc ? tau + marg2 : tau - marg2;
+        const float cx = asc ? worst + 0.5f * marg2 : worst - 0.5f * marg2;
+        *thr_q = asc ? (cx < c ? cx : c) : (cx > c ? cx : c);
+    }
+    __syncthreads();
+}
+
 constexpr int HK = 64;  // K elements per slab
 
 // DBG (compile-time experiments, never launched by the product path): 1 no MFMA, 2 no LDS fragment reads,
@@ -1017,7 +1224,7 @@ constexpr int HK = 64;  // K elements per slab
 // cost registers the unfiltered kernel does not have to spare (56 B/lane of scratch and 13 % of its speed when they
 // were runtime branches).
 template <int WQ, int WR, int TQ, int TR, int METRIC, int NSV, int NSQ, int NT_HINT, bool TILED = false, bool RAG = true, int DBG = 0, bool FILT = false,
-          int I8Q = 0, int EMIT = -1, int PLACE = 0, bool DENSE = false, bool PRIO = false, bool QCREG = true>
+          int I8Q = 0, int EMIT = -1, int PLACE = 0, bool DENSE = false, bool PRIO = false, bool QCREG = true, int FS = 0>
 __global__ void __launch_bounds__(WQ * WR * 64, (TQ * TR >= 16) ? 1 : ((WQ * WR >= 8) ? (WQ * WR / 4) : 2)) k_scan_h16(ScanArgs a) {
     // Two LDS rings: NSV stages of row slabs (HBM latency: deeper) and NSQ <= NSV stages of query-image
     // slabs (L2 latency) — 3 + 2 stages of 32 KiB fill the 160 KiB of a CU for the 256 x 256 tile.
@@ -1061,10 +1268,15 @@ __global__ void __launch_bounds__(WQ * WR * 64, (TQ * TR >= 16) ? 1 : ((WQ * WR 
     const int wq = wave % WQ, wr = wave / WQ;
 
     if (blockIdx.x >= a.ntiles) return;
+    [[maybe_unused]] const unsigned long long t_kernel0 = FS ? __builtin_amdgcn_s_memtime() : 0ull;
     // blockIdx.y: which chunk of BQ queries this workgroup scores (one launch scores a.qpad / BQ chunks against the same rows:
     // the k-means assignment step searches thousands of rows against a few thousand centroids); 0 for ordinary searches
     const uint32_t qchunk = (TILED || I8 || FILT) ? 0u : blockIdx.y * (uint32_t)BQ;  // (the int8 passes always run one chunk)
-    const uint32_t my_tiles = (a.ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x;
+    // FS (fused sample stage): the workgroup's FIRST tile is its sample tile (rows [blockIdx.x * fs_stride, +BR) of the whole
+    // shard), then its ordinary tiles blockIdx.x, blockIdx.x + grid, ... of [row0, row1) — the tile counters start one grid
+    // stride below blockIdx.x (modulo 2^32) so that the ordinary advance lands on blockIdx.x
+    static_assert(!FS || (!TILED && !FILT && EMIT == 0), "fused sample stage: unfiltered threshold stages of the FLAT scan");
+    const uint32_t my_tiles = (a.ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x + (FS ? 1u : 0u);
     const uint32_t G = my_tiles * a.nslab;
     const uint32_t tstride = a.tile_stride ? a.tile_stride : (uint32_t)BR;
     const bool ragged_k = RAG && (a.ld16 % KS) != 0;  // last slab reaches past ld16: clamp columns (they meet zeros in the query image)
@@ -1084,7 +1296,7 @@ __global__ void __launch_bounds__(WQ * WR * 64, (TQ * TR >= 16) ? 1 : ((WQ * WR 
         return ((lane & 7) ^ ((r >> 1) & 7)) * EPS;
     };
     // row stream position
-    uint32_t vs_tile = blockIdx.x, vs_slab = 0, vs_stage = 0, vs_count = 0, vs_tileseq = 0;
+    uint32_t vs_tile = FS ? blockIdx.x - gridDim.x : blockIdx.x, vs_slab = 0, vs_stage = 0, vs_count = 0, vs_tileseq = 0;
     // query stream position
     uint32_t qs_tile = blockIdx.x, qs_slab = 0, qs_stage = 0, qs_count = 0;
     uint32_t qs_qslab = a.qpad * LINE;
@@ -1097,18 +1309,16 @@ __global__ void __launch_bounds__(WQ * WR * 64, (TQ * TR >= 16) ? 1 : ((WQ * WR 
     // 4-byte constant waited for the next slab's 64 KiB) and behind one L2 round trip per column block.
     constexpr bool QC_REG = QCREG && !TILED && !FILT && !(RAG && WR >= 4);  // (the ragged <2,4,4,2> bodies have no registers to spare: 8 B of scratch with them)
     constexpr int QCN = (TQ * 32 + 63) / 64;
+    static_assert(!FS || (QC_REG && I8C), "fused sample stage: the certified int8 pass with register-resident query constants");
     float qc_inv[QCN], qc_extra[QCN], qc_thr[QCN];
-    if (QC_REG) {
+    // (re)loads the thresholds of the wave's query column; FS: called again once the grid has agreed on them
+    auto load_qc_thr = [&](const float* thr_src, uint32_t nq_) {
 #pragma unroll
         for (int t = 0; t < QCN; ++t) {
             const uint32_t nl = t * 64 + lane;
             const uint32_t n = qchunk + wq * (TQ * 32) + nl;
-            const bool ok = nl < TQ * 32 && n < a.nq;
-            qc_inv[t] = ok ? a.qinv[n] : 0.0f;
-            qc_extra[t] = 0.0f;
-            if (METRIC == M_L2 || I8) qc_extra[t] = ok ? a.qn2[n] : 0.0f;
-            if (METRIC == M_COS && !I8) qc_extra[t] = ok ? a.qrinv[n] : 0.0f;
-            qc_thr[t] = ok ? a.thr[n] : 0.0f;
+            const bool ok = nl < TQ * 32 && n < nq_;
+            qc_thr[t] = ok ? thr_src[n] : 0.0f;
             if constexpr (I8C) {
                 // INTEGER image of the threshold: the coarse score B_q + s_q * (float)dot is monotone non-decreasing in the
                 // integer dot product (s_q >= 0; conversion, product and sum round monotonically), so "score >= thr" is
@@ -1127,6 +1337,20 @@ __global__ void __launch_bounds__(WQ * WR * 64, (TQ * TR >= 16) ? 1 : ((WQ * WR 
                 qc_thr[t] = __int_as_float(ok ? lo : 0x7fffffff);
             }
         }
+    };
+    if (QC_REG) {
+#pragma unroll
+        for (int t = 0; t < QCN; ++t) {
+            const uint32_t nl = t * 64 + lane;
+            const uint32_t n = qchunk + wq * (TQ * 32) + nl;
+            const bool ok = nl < TQ * 32 && n < a.nq;
+            qc_inv[t] = ok ? a.qinv[n] : 0.0f;
+            qc_extra[t] = 0.0f;
+            if (METRIC == M_L2 || I8) qc_extra[t] = ok ? a.qn2[n] : 0.0f;
+            if (METRIC == M_COS && !I8) qc_extra[t] = ok ? a.qrinv[n] : 0.0f;
+            qc_thr[t] = 0.0f;
+        }
+        if (!FS) load_qc_thr(a.thr, a.nq);   // (FS: the thresholds do not exist yet; the sample tile's epilogue needs none)
     }
     const float* norm_src = (METRIC == M_L2 || I8) ? a.vn2 : a.vrinv;  // I8: a.vn2 carries the per-row int sums
 
@@ -1270,7 +1494,20 @@ __global__ void __launch_bounds__(WQ * WR * 64, (TQ * TR >= 16) ? 1 : ((WQ * WR 
     };
 
     // Prologue: the issue order of the steady state (per step: queries(s+NSQ-1), then rows(s+NSV-1))
-    v_enter_tile();
+    if constexpr (FS != 0) {   // the sample tile of this workgroup (its arguments through the laundered pointer: no SGPRs live in the loop)
+        static_assert(!FS || !NORMS_LDS, "fused sample stage: no norm ring");
+        const EpiArgsPtr ea = epi_args();
+        const uint32_t rbase = blockIdx.x * ea->fs_stride, span = ea->fs_rows - 1 - rbase;
+        v_base = reinterpret_cast<const char*>(a.V16) + (size_t)rbase * a.ld16 * ES;
+#pragma unroll
+        for (int j = 0; j < VPW; ++j) {
+            uint32_t r = (wave * VPW + j) * 8 + (lane >> 3);
+            r = r < span ? r : span;
+            v_off[j] = (r * a.ld16 + v_swz_col(j)) * ES;
+        }
+    } else {
+        v_enter_tile();
+    }
     q_enter_tile();
 #pragma unroll
     for (int s0 = -(NSV - 1); s0 < 0; ++s0) {
@@ -1288,7 +1525,8 @@ __global__ void __launch_bounds__(WQ * WR * 64, (TQ * TR >= 16) ? 1 : ((WQ * WR 
     // it is the arbitration loser on every slab step (s_memtime: 3500-3900 cycles per step against 2600-3500 for waves 0-3,
     // which then wait at the barrier)
     if (PRIO && NW == 8 && wave >= NW / 2) __builtin_amdgcn_s_setprio(1);
-    uint32_t s_in_tile = 0, tile = blockIdx.x, cv_stage = 0, cq_stage = 0, c_tileseq = 0;
+    uint32_t s_in_tile = 0, tile = FS ? blockIdx.x - gridDim.x : blockIdx.x, cv_stage = 0, cq_stage = 0, c_tileseq = 0;
+    bool c_first = FS != 0;   // FS: the tile being computed is the workgroup's sample tile
 #ifdef LYNSE_EXPERIMENTS
     const bool timing = (a.debug_flags & 64) && a.dbg;
 #else
@@ -1385,6 +1623,7 @@ __global__ void __launch_bounds__(WQ * WR * 64, (TQ * TR >= 16) ? 1 : ((WQ * WR 
             const EpiArgsPtr ea = epi_args();
             uint32_t rbase = ea->row0 + tile * tstride;
             uint32_t row_end = ea->row1;
+            if (FS && c_first) { rbase = blockIdx.x * ea->fs_stride; row_end = ea->fs_rows; }
             IvfTile td{};
             if (TILED) {
                 td = ea->tiles[tile];
@@ -1402,7 +1641,7 @@ __global__ void __launch_bounds__(WQ * WR * 64, (TQ * TR >= 16) ? 1 : ((WQ * WR 
             // EMIT >= 0: the emission mode is a compile-time constant (0 threshold stages, 1 emit-all, 2 lane-max sample) — the
             // 256 x 256 tilings compile ONE epilogue per kernel: with all three in one body the row-index terms of the
             // emit-all / lane-max branches are hoisted across the unrolled column loop and spill (600 B / lane).
-            const int e_emit_all = TILED ? 0 : (EMIT >= 0 ? EMIT : ea->emit_all);
+            const int e_emit_all = TILED ? 0 : (FS ? (c_first ? 2 : 0) : (EMIT >= 0 ? EMIT : ea->emit_all));
             auto score = [&](int i, int j, int r, uint32_t m, bool rok) -> float {
                 if constexpr (I8C) {
                     return c_extra[j] + c_qinv[j] * (float)__float_as_int(acc[i][j][r]);  // B_q + s_q * dot (separate mul / add)
@@ -1458,7 +1697,7 @@ __global__ void __launch_bounds__(WQ * WR * 64, (TQ * TR >= 16) ? 1 : ((WQ * WR 
                 set_pre(j, c_thr[j], e_vmax2);
                 n_j[j] = n;
                 if (DENSEF && !e_emit_all) continue;   // scored after this loop (all columns per norm load)
-                if ((WR >= 4 || EMIT == 2) && !FILT && e_emit_all == 2 && !TILED) {  // (runtime-EMIT bodies of the <4,2,2,4> tiling and the subset-filter variants leave it out: it would spill there)
+                if ((WR >= 4 || EMIT == 2) && (FS || EMIT != 0) && !FILT && e_emit_all == 2 && !TILED) {  // (runtime-EMIT bodies of the <4,2,2,4> tiling and the subset-filter variants leave it out: it would spill there)
                     // threshold-only sample stage: each lane keeps the best LM of its TR*16 rows for this query column
                     // (4 WR keys per tile and query) and writes only those.  k_select turns the k-th best of them into a
                     // valid threshold and keeps no candidate: the sample tiles are scanned again by the ordinary stages.
@@ -1494,10 +1733,10 @@ __global__ void __launch_bounds__(WQ * WR * 64, (TQ * TR >= 16) ? 1 : ((WQ * WR 
 #pragma unroll
                     for (int t = 0; t < LM; ++t) {
                         const uint64_t key = bm[t] == 0xffffffffu ? KEY_SENTINEL : make_key(bs[t], (FILT && ea->row_ids) ? ea->row_ids[bm[t]] : bm[t], ASC);
-                        const uint32_t slot = (tile * (2 * WR) + 2 * wr + hi) * LM + t;
+                        const uint32_t slot = ((FS ? blockIdx.x : tile) * (2 * WR) + 2 * wr + hi) * LM + t;
                         if (c_ok[j] && slot < ea->cap) ea->cand[(size_t)n * ea->cap + slot] = key;
                     }
-                } else if (e_emit_all && !TILED) {
+                } else if (!FS && e_emit_all && !TILED) {
 #pragma unroll
                     for (int i = 0; i < TR; ++i) {
                         const uint32_t mw = mw_t[i];
@@ -1770,6 +2009,32 @@ __global__ void __launch_bounds__(WQ * WR * 64, (TQ * TR >= 16) ? 1 : ((WQ * WR 
                             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
                 }
             }
+            if constexpr (FS != 0) {
+                if (c_first) {
+                    // ---- the grid agrees on the first thresholds: every workgroup has published the lane-max keys of its sample
+                    // tile; workgroup q derives the threshold of query q (one wave); everybody picks the thresholds up
+                    c_first = false;
+                    uint32_t* gs = ea->gsync;
+                    // (debug_flags & 128: s_memtime stamps of this phase, [block][8] u64 behind the first 64 words of gsync)
+                    unsigned long long* stamp = (ea->debug_flags & 128) ? reinterpret_cast<unsigned long long*>(gs + 64) + (size_t)blockIdx.x * 8 : nullptr;
+                    if (stamp && tid == 0) { stamp[0] = t_kernel0; stamp[1] = __builtin_amdgcn_s_memtime(); }
+                    volatile uint32_t* flag = reinterpret_cast<volatile uint32_t*>(const_cast<char*>(stv));  // ring stage just consumed: free
+                    bool ok = fs_grid_sync(gs, gs + 2, gridDim.x, flag, tid);
+                    if (stamp && tid == 0) stamp[2] = __builtin_amdgcn_s_memtime();
+                    if (ok) {
+                        for (uint32_t q = blockIdx.x; q < ea->nq; q += gridDim.x)   // (uniform per workgroup)
+                            fused_sample_threshold<NW * 64>(ea->cand + (size_t)q * ea->cap, gridDim.x * (2 * WR * 2), ea->k, ea->marg2[q], METRIC, ea->ip_form,
+                                                            ea->Qf + (size_t)q * ea->D, ea->V, ea->ld, ea->D, ea->thr_out + q, const_cast<char*>(stv),
+                                                            const_cast<char*>(stq), tid);
+                        if (stamp && tid == 0) stamp[3] = __builtin_amdgcn_s_memtime();
+                        ok = fs_grid_sync(gs + 1, gs + 2, gridDim.x, flag, tid);
+                        if (stamp && tid == 0) stamp[4] = __builtin_amdgcn_s_memtime();
+                    }
+                    if (!ok) return;   // aborted (fs_grid_sync): nothing of this launch is used; every DMA has landed
+                    load_qc_thr(ea->thr, ea->nq);
+                    if (stamp && tid == 0) stamp[5] = __builtin_amdgcn_s_memtime();
+                }
+            }
             s_in_tile = 0;
             tile += gridDim.x;
         }
@@ -1786,6 +2051,7 @@ __global__ void __launch_bounds__(WQ * WR * 64, (TQ * TR >= 16) ? 1 : ((WQ * WR 
 #endif
     if (!TILED) {
         const EpiArgsPtr ea = epi_args();
+        if (FS && (ea->debug_flags & 128) && tid == 0) reinterpret_cast<unsigned long long*>(ea->gsync + 64)[(size_t)blockIdx.x * 8 + 6] = __builtin_amdgcn_s_memtime();
         if (ea->seg && (hi == 0 || DENSE)) {  // DENSE: one segment per wave half (the lane's own), else one per row-wave
 #pragma unroll
             for (int j = 0; j < TQ; ++j) {
@@ -1932,6 +2198,7 @@ struct I8cPrepArgs {
     int8_t* img;
     float *sq, *bq, *marg2, *thr;  // s_q -> ScanArgs::qinv, B_q -> ScanArgs::qn2
     uint32_t *count, *overflow;
+    uint32_t* gsync;     // hand-over words of the fused sample stage (ScanArgs::gsync): zeroed here, once per batch
 };
 
 __global__ void __launch_bounds__(256) k_i8c_prep_queries(I8cPrepArgs a) {
@@ -1987,6 +2254,7 @@ __global__ void __launch_bounds__(256) k_i8c_prep_queries(I8cPrepArgs a) {
         a.thr[q] = -LY_INF;
         a.count[q] = 0u;
         a.overflow[q] = 0u;
+        if (q == 0 && a.gsync) { a.gsync[0] = 0u; a.gsync[1] = 0u; a.gsync[2] = 0u; }
     }
     __syncthreads();
     const double inv = 1.0 / (double)s_sq;
@@ -2399,6 +2667,50 @@ __global__ void __launch_bounds__(256) k_scan_binary_rows(BinArgs a) {
     }
 }
 
+// ---- cross-lane helpers (k_select's small-k path, k_small_search) ----
+__device__ __forceinline__ uint64_t shfl_up_u64(uint64_t v, int d) {
+    const uint32_t lo = (uint32_t)__shfl_up((int)(uint32_t)v, d, 64), hi = (uint32_t)__shfl_up((int)(uint32_t)(v >> 32), d, 64);
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint64_t shfl_u64(uint64_t v, int src) {
+    const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)v, src, 64), hi = (uint32_t)__shfl((int)(uint32_t)(v >> 32), src, 64);
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint64_t shfl_xor_u64(uint64_t v, int m) {
+    const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, m, 64), hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), m, 64);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+// Cross-lane helpers of the fused search that stay off the LDS crossbar (ds_bpermute round trips were ~1 us per output
+// rank): a uniform source lane is a v_readlane, the neighbour lane is a DPP wave shift, a wave-wide minimum is four DPP
+// row rotations plus one v_readlane per row of 16 lanes.
+__device__ __forceinline__ uint64_t readlane_u64(uint64_t v, int src_uniform) {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, src_uniform);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), src_uniform);
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint64_t wave_shr1_u64(uint64_t v) {  // lane i <- lane i-1 (lane 0 keeps its own value)
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)v, (int)(uint32_t)v, 0x138, 0xf, 0xf, false);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)(v >> 32), (int)(uint32_t)(v >> 32), 0x138, 0xf, 0xf, false);
+    return ((uint64_t)hi << 32) | lo;
+}
+template <int CTRL>
+__device__ __forceinline__ uint64_t dpp_u64(uint64_t v) {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)v, (int)(uint32_t)v, CTRL, 0xf, 0xf, false);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)(v >> 32), (int)(uint32_t)(v >> 32), CTRL, 0xf, 0xf, false);
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint64_t wave_min_u64(uint64_t v) {  // the minimum over the 64 lanes, in every lane
+    uint64_t w;
+    w = dpp_u64<0x128>(v); v = w < v ? w : v;  // row_ror:8
+    w = dpp_u64<0x124>(v); v = w < v ? w : v;  // row_ror:4
+    w = dpp_u64<0x122>(v); v = w < v ? w : v;  // row_ror:2
+    w = dpp_u64<0x121>(v); v = w < v ? w : v;  // row_ror:1 -> every lane holds its row's minimum
+    const uint64_t r0 = readlane_u64(v, 0), r1 = readlane_u64(v, 16), r2 = readlane_u64(v, 32), r3 = readlane_u64(v, 48);
+    const uint64_t a = r0 < r1 ? r0 : r1, b = r2 < r3 ? r2 : r3;
+    return a < b ? a : b;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Block-wide bitonic sort of npow2 u64 keys in LDS (ascending).
 // ------------------------------------------------------------------------------------------------
@@ -2442,8 +2754,8 @@ __device__ __forceinline__ void rescore_keys(uint64_t* keys, uint32_t n, int met
         const uint32_t row0 = key_row(keys[ok0 ? i0 : 0u]), row1 = key_row(keys[ok1 ? i1 : 0u]);
         float s0 = 0.0f, s1 = 0.0f;
         if (n) {
-            s0 = exact_score(metric, ip_form, qv, V + (size_t)row0 * ld, D, g);
-            s1 = exact_score(metric, ip_form, qv, V + (size_t)row1 * ld, D, g);
+            s0 = exact_score<32>(metric, ip_form, qv, V + (size_t)row0 * ld, D, g);
+            s1 = exact_score<32>(metric, ip_form, qv, V + (size_t)row1 * ld, D, g);
         }
         if (ok0 && g == 0) keys[i0] = make_key(s0, row0, asc);
         if (ok1 && g == 0) keys[i1] = make_key(s1, row1, asc);
@@ -2514,6 +2826,8 @@ struct SelectArgs {
     const float* Qf;
     const float* V;
     uint32_t ld, D;
+    const uint32_t* abort_word;  // fused sample stage (ScanArgs::gsync + 2): != 0 -> the scan launch gave up, nothing it wrote is valid
+    unsigned long long* stamps;  // debugging: [query][8] s_memtime stamps of the phases (nullptr = off)
 };
 
 // k_select finds the k-th best key with an 8-pass MSB radix select over the keys in LDS (256-bin
@@ -2521,16 +2835,24 @@ struct SelectArgs {
 // only have to be FOUND, k_final orders them once at the end.  (A full bitonic sort of 8192 keys cost
 // 97 us per stage; the radix select is ~10x cheaper.)  The rare compaction path (more than keep_max
 // survivors: rescore exactly, cut to the exact top-k) still sorts.
+// select_body: the whole of k_select for query q with the keys staged in `keys` (LDS, cap slots).  Returns the number of
+// survivors it left in cand[q][0 .. ) (count[q] holds the same); *rescored = those keys already carry EXACT scores (the
+// compaction path).  k_select is this and nothing else; k_select_final goes on to the exact rescoring + final order in the
+// same launch.
 template <int NT>
-__global__ void __launch_bounds__(NT) k_select(SelectArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    uint64_t* keys = reinterpret_cast<uint64_t*>(smem);
+__device__ __forceinline__ uint32_t select_body(const SelectArgs& a, uint64_t* keys, const uint32_t q, bool* rescored) {
     __shared__ uint32_t hist[256];
     __shared__ uint32_t s_keep, s_rank;
     __shared__ uint64_t s_prefix;
-    const uint32_t q = blockIdx.x;
+    *rescored = false;
     const int tid = threadIdx.x, lane = tid & 63;
     const bool asc = metric_ascending(a.metric);
+    auto stamp = [&](int i) { if (a.stamps && tid == 0) a.stamps[(size_t)q * 8 + i] = __builtin_amdgcn_s_memtime(); };
+    stamp(0);
+    if (a.abort_word && *a.abort_word) {  // the scan gave up: no candidates, the overflow flag sends the batch down the plan ladder
+        if (tid == 0) { a.overflow[q] = 1u; a.count[q] = 0u; }
+        return 0u;
+    }
     uint32_t n = a.emit_all_n >= 0 ? (uint32_t)a.emit_all_n : a.count[q];
     if (n > a.cap) {
         if (tid == 0) a.overflow[q] = 1u;
@@ -2541,17 +2863,27 @@ __global__ void __launch_bounds__(NT) k_select(SelectArgs a) {
     if (a.drop_sentinels) {  // load + drop the slots of rows outside the subset
         if (tid == 0) s_keep = 0;
         __syncthreads();
-        for (uint32_t i0 = 0; i0 < n; i0 += NT) {
-            const uint32_t i = i0 + tid;
-            const uint64_t key = i < n ? gkeys[i] : KEY_SENTINEL;
-            const bool real = key != KEY_SENTINEL;
-            const uint64_t m = __ballot(real);
-            if (m) {
-                uint32_t base = 0;
-                const int leader = __builtin_ctzll(m);
-                if (lane == leader) base = atomicAdd(&s_keep, (uint32_t)__popcll(m));
-                base = __shfl(base, leader, 64);
-                if (real) keys[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = key;
+        // (eight loads in flight per thread: with one load per trip of the compaction the 4096 sample keys were eight
+        // dependent global round trips, a third of this kernel's time)
+        for (uint32_t i0 = 0; i0 < n; i0 += NT * 8) {
+            uint64_t kv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const uint32_t i = i0 + u * NT + tid;
+                kv[u] = i < n ? gkeys[i] : KEY_SENTINEL;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const uint64_t key = kv[u];
+                const bool real = key != KEY_SENTINEL;
+                const uint64_t m = __ballot(real);
+                if (m) {
+                    uint32_t base = 0;
+                    const int leader = __builtin_ctzll(m);
+                    if (lane == leader) base = atomicAdd(&s_keep, (uint32_t)__popcll(m));
+                    base = __shfl(base, leader, 64);
+                    if (real) keys[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = key;
+                }
             }
         }
         __syncthreads();
@@ -2568,7 +2900,21 @@ __global__ void __launch_bounds__(NT) k_select(SelectArgs a) {
         const uint32_t s1 = s0 + per < a.nseg ? s0 + per : a.nseg;
         const uint8_t* sc = a.segcnt + (size_t)q * a.nseg;
         uint32_t mine = 0;
-        for (uint32_t sgm = s0; sgm < s1; ++sgm) mine += sc[sgm];
+        // up to 8 segments per thread with their counts and FIRST keys loaded together (most segments hold 0 or 1 key): two
+        // global round trips for the whole gather instead of one per segment and key
+        uint32_t cnt8[8];
+        uint64_t first8[8];
+        const bool fast = per <= 8;
+        if (fast) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) cnt8[u] = (s0 + u < s1) ? (uint32_t)sc[s0 + u] : 0u;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) first8[u] = cnt8[u] ? a.candB[((size_t)q * a.nseg + s0 + u) * a.seg] : 0ull;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) mine += cnt8[u];
+        } else {
+            for (uint32_t sgm = s0; sgm < s1; ++sgm) mine += sc[sgm];
+        }
         uint32_t incl = mine;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
@@ -2585,11 +2931,25 @@ __global__ void __launch_bounds__(NT) k_select(SelectArgs a) {
             total += ws;
         }
         uint32_t off = n + wbase + incl - mine;
-        for (uint32_t sgm = s0; sgm < s1; ++sgm) {
-            const uint32_t c = sc[sgm];
-            const uint64_t* src = a.candB + ((size_t)q * a.nseg + sgm) * a.seg;
-            for (uint32_t i = 0; i < c; ++i, ++off)
-                if (off < a.cap) keys[off] = src[i];
+        if (fast) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const uint32_t c = cnt8[u];
+                if (c) {
+                    if (off < a.cap) keys[off] = first8[u];
+                    ++off;
+                    const uint64_t* src = a.candB + ((size_t)q * a.nseg + s0 + u) * a.seg;
+                    for (uint32_t i = 1; i < c; ++i, ++off)
+                        if (off < a.cap) keys[off] = src[i];
+                }
+            }
+        } else {
+            for (uint32_t sgm = s0; sgm < s1; ++sgm) {
+                const uint32_t c = sc[sgm];
+                const uint64_t* src = a.candB + ((size_t)q * a.nseg + sgm) * a.seg;
+                for (uint32_t i = 0; i < c; ++i, ++off)
+                    if (off < a.cap) keys[off] = src[i];
+            }
         }
         if (n + total > a.cap) {
             if (tid == 0) a.overflow[q] = 1u;
@@ -2600,109 +2960,118 @@ __global__ void __launch_bounds__(NT) k_select(SelectArgs a) {
         compacted = true;  // the keys live in LDS only: every exit below writes them back
         __syncthreads();
     }
+    stamp(1);
     if (n < a.k || a.k == 0) {  // fewer than k candidates so far: keep all, the threshold stays open
         if (compacted && !a.threshold_only)
             for (uint32_t i = tid; i < n; i += NT) gkeys[i] = keys[i];
         // the threshold is left as it is: open (set by the prep kernel) until a select has seen k keys — or already valid
         // for the whole shard when the threshold-only sample stage set it
         if (tid == 0) a.count[q] = a.threshold_only ? 0u : n;
-        return;
+        return a.threshold_only ? 0u : n;
     }
     if (!compacted)
         for (uint32_t i = tid; i < n; i += NT) keys[i] = gkeys[i];
     if (tid == 0) { s_keep = 0; s_prefix = 0; s_rank = a.k - 1; }
     __syncthreads();
 
-    // ---- k-th smallest key (keys are unique: the low word is the row).  Float metrics only need the k-th SCORE (every
-    // tie of it survives the margin cut anyway): four passes over the score word instead of eight over the whole key.
-    const int last_shift = a.exact ? 0 : 32;
-    for (int shift = 56; shift >= last_shift; shift -= 8) {
-        if (tid < 256) hist[tid] = 0;
-        __syncthreads();
-        const uint64_t prefix = s_prefix;
-        const uint64_t himask = shift == 56 ? 0ull : (~0ull << (shift + 8));
-        for (uint32_t i0 = 0; i0 < n; i0 += NT) {
-            const uint32_t i = i0 + tid;
-            const bool on = i < n && (keys[i] & himask) == prefix;
-            const uint32_t bin = on ? (uint32_t)(keys[i] >> shift) & 255u : 0u;
-            // the high bytes of the scores are (nearly) the same for every key: one atomic per wave for the
-            // first lane's bin, plain atomics for the lanes that differ
-            const uint64_t act = __ballot(on);
-            if (act) {
-                const int leader = __builtin_ctzll(act);
-                const uint32_t first = __shfl(bin, leader, 64);
-                const uint64_t same = __ballot(on && bin == first);
-                if (lane == leader) atomicAdd(&hist[first], (uint32_t)__popcll(same));
-                if (on && bin != first) atomicAdd(&hist[bin], 1u);
-            }
-        }
-        __syncthreads();
-        if (tid < 64) {  // one wave: 4 bins per lane, inclusive scan over lanes, the bucket holding the rank
-            const uint32_t rank = s_rank;
-            const uint32_t h0 = hist[4 * lane], h1 = hist[4 * lane + 1], h2 = hist[4 * lane + 2], h3 = hist[4 * lane + 3];
-            const uint32_t sum = h0 + h1 + h2 + h3;
-            uint32_t incl = sum;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const uint32_t up = __shfl_up(incl, o, 64);
-                if (lane >= o) incl += up;
-            }
-            const uint32_t excl = incl - sum;
-            if (excl <= rank && rank < incl) {
-                uint32_t r = rank - excl, b = 4 * lane;
-                if (r >= h0) { r -= h0; ++b; if (r >= h1) { r -= h1; ++b; if (r >= h2) { r -= h2; ++b; } } }
-                s_rank = r;
-                s_prefix = prefix | ((uint64_t)b << shift);
-            }
-        }
-        __syncthreads();
-    }
-    const uint64_t kth = a.exact ? s_prefix : (s_prefix | 0xffffffffull);  // float: every row of the k-th score counts as <= kth
-    const float tau = key_score(kth, asc);
-
-    // ---- exact-rescored threshold (float coarse passes).  The cut tau -/+ 2E brackets the exact k-th best through the
-    // COARSE k-th score tau: one E for the rows that realise tau, one for the row being tested.  Rescoring the >= k best
-    // coarse rows exactly (a few dozen f32 rows per query) gives tau_x = the k-th best EXACT score among them — a valid lower
-    // bound of the shard's exact k-th best whatever rows were picked — and every row that can still matter has a coarse
-    // score within ONE E of it.  tau_x -/+ E is never looser than tau -/+ 2E (the k best coarse rows have exact scores
-    // >= tau - E) and typically one E tighter: with the wide int8 margins that is ~5x fewer keys emitted, kept and
-    // rescored in every later stage.
+    // (A small-k variant — per-wave insertion lists in registers, one key per lane, merged by wave 0 — was measured SLOWER than
+    // the radix select on MI355X: ~150 cycles per serial insertion (readlane / DPP / scalar ping-pong), 4096 keys, k = 10:
+    // 36k ticks against 28k; removed.)
+    uint64_t kth = 0;
+    float tau = 0.0f;
     float cut_exact = asc ? LY_INF : -LY_INF;   // tau_x -/+ E; unused when not tightened
     bool tightened = false;
-    if (!a.exact && a.tighten && a.k <= 128u) {
-        __shared__ uint64_t xs[256];
-        __shared__ uint32_t s_x;
-        const uint32_t mx = a.k * 2u < 256u ? a.k * 2u : 256u;
-        if (tid == 0) s_x = 0;
-        __syncthreads();
-        for (uint32_t i = tid; i < n; i += NT) {
-            const uint64_t key = keys[i];
-            if (key <= kth) {
-                const uint32_t slot = atomicAdd(&s_x, 1u);
-                if (slot < mx) xs[slot] = key;
-            }
-        }
-        __syncthreads();
-        const uint32_t m = s_x < mx ? s_x : mx;   // >= k: at least k keys are <= the k-th smallest
-        if (m >= a.k) {
-            rescore_keys<NT>(xs, m, a.metric, a.ip_form, a.Qf + (size_t)q * a.D, a.V, a.ld, a.D, asc, tid);
-            // the k-th best of the m <= 256 rescored keys by RANK (keys are unique: the row is part of the key): one thread per key
-            // counts the smaller ones — m broadcast LDS reads instead of the 36 barrier-separated steps of a 256-key bitonic sort
-            __shared__ float s_taux;
+    {
+        // ---- k-th smallest key (keys are unique: the low word is the row).  Float metrics only need the k-th SCORE (every
+        // tie of it survives the margin cut anyway): four passes over the score word instead of eight over the whole key.
+        const int last_shift = a.exact ? 0 : 32;
+        for (int shift = 56; shift >= last_shift; shift -= 8) {
+            if (tid < 256) hist[tid] = 0;
             __syncthreads();
-            if ((uint32_t)tid < m) {
-                const uint64_t mine = xs[tid];
-                uint32_t rank = 0;
-                for (uint32_t i = 0; i < m; ++i) rank += xs[i] < mine ? 1u : 0u;
-                if (rank == a.k - 1) s_taux = key_score(mine, asc);
+            const uint64_t prefix = s_prefix;
+            const uint64_t himask = shift == 56 ? 0ull : (~0ull << (shift + 8));
+            for (uint32_t i0 = 0; i0 < n; i0 += NT) {
+                const uint32_t i = i0 + tid;
+                const bool on = i < n && (keys[i] & himask) == prefix;
+                const uint32_t bin = on ? (uint32_t)(keys[i] >> shift) & 255u : 0u;
+                // the high bytes of the scores are (nearly) the same for every key: one atomic per wave for the
+                // first lane's bin, plain atomics for the lanes that differ
+                const uint64_t act = __ballot(on);
+                if (act) {
+                    const int leader = __builtin_ctzll(act);
+                    const uint32_t first = __shfl(bin, leader, 64);
+                    const uint64_t same = __ballot(on && bin == first);
+                    if (lane == leader) atomicAdd(&hist[first], (uint32_t)__popcll(same));
+                    if (on && bin != first) atomicAdd(&hist[bin], 1u);
+                }
             }
             __syncthreads();
-            const float tau_x = s_taux;
-            const float e1 = 0.5f * a.marg2[q];
-            cut_exact = asc ? tau_x + e1 : tau_x - e1;
-            tightened = tau_x == tau_x;  // (NaN scores: keep the coarse rule)
+            if (tid < 64) {  // one wave: 4 bins per lane, inclusive scan over lanes, the bucket holding the rank
+                const uint32_t rank = s_rank;
+                const uint32_t h0 = hist[4 * lane], h1 = hist[4 * lane + 1], h2 = hist[4 * lane + 2], h3 = hist[4 * lane + 3];
+                const uint32_t sum = h0 + h1 + h2 + h3;
+                uint32_t incl = sum;
+    #pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const uint32_t up = __shfl_up(incl, o, 64);
+                    if (lane >= o) incl += up;
+                }
+                const uint32_t excl = incl - sum;
+                if (excl <= rank && rank < incl) {
+                    uint32_t r = rank - excl, b = 4 * lane;
+                    if (r >= h0) { r -= h0; ++b; if (r >= h1) { r -= h1; ++b; if (r >= h2) { r -= h2; ++b; } } }
+                    s_rank = r;
+                    s_prefix = prefix | ((uint64_t)b << shift);
+                }
+            }
+            __syncthreads();
         }
-        __syncthreads();
+        stamp(2);
+        kth = a.exact ? s_prefix : (s_prefix | 0xffffffffull);  // float: every row of the k-th score counts as <= kth
+        tau = key_score(kth, asc);
+
+        // ---- exact-rescored threshold (float coarse passes).  The cut tau -/+ 2E brackets the exact k-th best through the
+        // COARSE k-th score tau: one E for the rows that realise tau, one for the row being tested.  Rescoring the >= k best
+        // coarse rows exactly (a few dozen f32 rows per query) gives tau_x = the k-th best EXACT score among them — a valid lower
+        // bound of the shard's exact k-th best whatever rows were picked — and every row that can still matter has a coarse
+        // score within ONE E of it.  tau_x -/+ E is never looser than tau -/+ 2E (the k best coarse rows have exact scores
+        // >= tau - E) and typically one E tighter: with the wide int8 margins that is ~5x fewer keys emitted, kept and
+        // rescored in every later stage.
+        if (!a.exact && a.tighten && a.k <= 128u) {
+            __shared__ uint64_t xs[256];
+            __shared__ uint32_t s_x;
+            const uint32_t mx = a.k * 2u < 256u ? a.k * 2u : 256u;
+            if (tid == 0) s_x = 0;
+            __syncthreads();
+            for (uint32_t i = tid; i < n; i += NT) {
+                const uint64_t key = keys[i];
+                if (key <= kth) {
+                    const uint32_t slot = atomicAdd(&s_x, 1u);
+                    if (slot < mx) xs[slot] = key;
+                }
+            }
+            __syncthreads();
+            const uint32_t m = s_x < mx ? s_x : mx;   // >= k: at least k keys are <= the k-th smallest
+            if (m >= a.k) {
+                rescore_keys<NT>(xs, m, a.metric, a.ip_form, a.Qf + (size_t)q * a.D, a.V, a.ld, a.D, asc, tid);
+                // the k-th best of the m <= 256 rescored keys by RANK (keys are unique: the row is part of the key): one thread per key
+                // counts the smaller ones — m broadcast LDS reads instead of the 36 barrier-separated steps of a 256-key bitonic sort
+                __shared__ float s_taux;
+                __syncthreads();
+                if ((uint32_t)tid < m) {
+                    const uint64_t mine = xs[tid];
+                    uint32_t rank = 0;
+                    for (uint32_t i = 0; i < m; ++i) rank += xs[i] < mine ? 1u : 0u;
+                    if (rank == a.k - 1) s_taux = key_score(mine, asc);
+                }
+                __syncthreads();
+                const float tau_x = s_taux;
+                const float e1 = 0.5f * a.marg2[q];
+                cut_exact = asc ? tau_x + e1 : tau_x - e1;
+                tightened = tau_x == tau_x;  // (NaN scores: keep the coarse rule)
+            }
+            __syncthreads();
+        }
     }
     auto cut_of = [&](float t, float m2) -> float {   // the tighter of the coarse rule and the exact-rescored rule
         const float c = asc ? t + m2 : t - m2;
@@ -2710,6 +3079,7 @@ __global__ void __launch_bounds__(NT) k_select(SelectArgs a) {
         return asc ? (cut_exact < c ? cut_exact : c) : (cut_exact > c ? cut_exact : c);
     };
 
+    stamp(3);
     float thr_new;
     uint32_t keep;
     bool sorted_path = false;
@@ -2719,7 +3089,7 @@ __global__ void __launch_bounds__(NT) k_select(SelectArgs a) {
             const float m2 = a.exact ? 0.0f : a.marg2[q];
             a.thr[q] = cut_of(tau, m2);
         }
-        return;
+        return 0u;
     }
     if (a.exact) {
         // FLAT scans rows in ascending id order, so a later tie of the k-th score can never win: strict
@@ -2769,9 +3139,11 @@ __global__ void __launch_bounds__(NT) k_select(SelectArgs a) {
             a.count[q] = kept;
             a.thr[q] = asc ? xk + m2 : xk - m2;
         }
-        return;
+        *rescored = true;
+        return kept;
     }
 
+    stamp(4);
     // ---- write the survivors back, compacted (order is irrelevant: one atomic per wave reserves the slots)
     __syncthreads();
     if (tid == 0) s_keep = 0;
@@ -2802,6 +3174,15 @@ __global__ void __launch_bounds__(NT) k_select(SelectArgs a) {
         a.count[q] = keep;
         a.thr[q] = thr_new;
     }
+    stamp(5);
+    return keep;
+}
+
+template <int NT>
+__global__ void __launch_bounds__(NT) k_select(SelectArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bool rescored;
+    (void)select_body<NT>(a, reinterpret_cast<uint64_t*>(smem), blockIdx.x, &rescored);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2847,49 +3228,6 @@ struct SmallArgs {
     const uint32_t* orig;
     int flag_empty;
 };
-
-__device__ __forceinline__ uint64_t shfl_up_u64(uint64_t v, int d) {
-    const uint32_t lo = (uint32_t)__shfl_up((int)(uint32_t)v, d, 64), hi = (uint32_t)__shfl_up((int)(uint32_t)(v >> 32), d, 64);
-    return ((uint64_t)hi << 32) | lo;
-}
-__device__ __forceinline__ uint64_t shfl_u64(uint64_t v, int src) {
-    const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)v, src, 64), hi = (uint32_t)__shfl((int)(uint32_t)(v >> 32), src, 64);
-    return ((uint64_t)hi << 32) | lo;
-}
-__device__ __forceinline__ uint64_t shfl_xor_u64(uint64_t v, int m) {
-    const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, m, 64), hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), m, 64);
-    return ((uint64_t)hi << 32) | lo;
-}
-
-// Cross-lane helpers of the fused search that stay off the LDS crossbar (ds_bpermute round trips were ~1 us per output
-// rank): a uniform source lane is a v_readlane, the neighbour lane is a DPP wave shift, a wave-wide minimum is four DPP
-// row rotations plus one v_readlane per row of 16 lanes.
-__device__ __forceinline__ uint64_t readlane_u64(uint64_t v, int src_uniform) {
-    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, src_uniform);
-    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), src_uniform);
-    return ((uint64_t)hi << 32) | lo;
-}
-__device__ __forceinline__ uint64_t wave_shr1_u64(uint64_t v) {  // lane i <- lane i-1 (lane 0 keeps its own value)
-    const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)v, (int)(uint32_t)v, 0x138, 0xf, 0xf, false);
-    const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)(v >> 32), (int)(uint32_t)(v >> 32), 0x138, 0xf, 0xf, false);
-    return ((uint64_t)hi << 32) | lo;
-}
-template <int CTRL>
-__device__ __forceinline__ uint64_t dpp_u64(uint64_t v) {
-    const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)v, (int)(uint32_t)v, CTRL, 0xf, 0xf, false);
-    const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)(v >> 32), (int)(uint32_t)(v >> 32), CTRL, 0xf, 0xf, false);
-    return ((uint64_t)hi << 32) | lo;
-}
-__device__ __forceinline__ uint64_t wave_min_u64(uint64_t v) {  // the minimum over the 64 lanes, in every lane
-    uint64_t w;
-    w = dpp_u64<0x128>(v); v = w < v ? w : v;  // row_ror:8
-    w = dpp_u64<0x124>(v); v = w < v ? w : v;  // row_ror:4
-    w = dpp_u64<0x122>(v); v = w < v ? w : v;  // row_ror:2
-    w = dpp_u64<0x121>(v); v = w < v ? w : v;  // row_ror:1 -> every lane holds its row's minimum
-    const uint64_t r0 = readlane_u64(v, 0), r1 = readlane_u64(v, 16), r2 = readlane_u64(v, 32), r3 = readlane_u64(v, 48);
-    const uint64_t a = r0 < r1 ? r0 : r1, b = r2 < r3 ? r2 : r3;
-    return a < b ? a : b;
-}
 
 __global__ void __launch_bounds__(SMALL_NT) k_small_search(SmallArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -3106,31 +3444,46 @@ __global__ void __launch_bounds__(NT) k_rescore_pool(FinalArgs a) {
     const float* qv = a.Qf + (size_t)q * a.D;
     for (uint32_t i = blockIdx.y * (NT / 8) + (tid >> 3); i < n; i += gridDim.y * (NT / 8)) {
         const uint32_t row = key_row(keys[i]);
-        const float s = exact_score(a.metric, a.ip_form, qv, a.V + (size_t)row * a.ld, a.D, g);
+        const float s = exact_score<32>(a.metric, a.ip_form, qv, a.V + (size_t)row * a.ld, a.D, g);
         if (g == 0) keys[i] = make_key(s, row, asc);
     }
 }
 
+// final_body: k_final for query q — n survivors in cand[q][0 .. n), `keys` = cap slots of LDS.
 template <int NT>
-__global__ void __launch_bounds__(NT) k_final(FinalArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    uint64_t* keys = reinterpret_cast<uint64_t*>(smem);
-    const uint32_t q = blockIdx.x;
+__device__ __forceinline__ void final_body(const FinalArgs& a, uint64_t* keys, const uint32_t q, uint32_t n, const bool exact, const bool same_launch = false) {
     const int tid = threadIdx.x;
     const bool asc = metric_ascending(a.metric);
-    uint32_t n = a.count[q];
     if (n > a.cap) n = a.cap;
     const uint32_t np2 = next_pow2(n < 2 ? 2 : n);
     const uint64_t* src = a.cand + (size_t)q * a.cap;
-    for (uint32_t i = tid; i < np2; i += NT) keys[i] = i < n ? src[i] : KEY_SENTINEL;
+    // same_launch: the keys were stored by THIS workgroup a barrier ago — read them past the vector L1 (sc1: L2-served)
+    for (uint32_t i = tid; i < np2; i += NT)
+        keys[i] = i < n ? (same_launch ? __hip_atomic_load(&src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : src[i]) : KEY_SENTINEL;
     __syncthreads();
-    if (!a.exact)
+    if (!exact)
         rescore_keys<NT>(keys, n, a.metric, a.ip_form, a.Qf + (size_t)q * a.D, a.V, a.ld, a.D, asc, tid);
     if (a.orig_ids) {  // canonical order is (distance, ORIGINAL row): swap the row word before the final sort
         for (uint32_t i = tid; i < n; i += NT) keys[i] = (keys[i] & 0xffffffff00000000ull) | a.orig_ids[key_row(keys[i])];
         __syncthreads();
     }
-    bitonic_sort_lds<NT>(keys, np2, tid);
+    // a few dozen survivors (the usual pool): rank sort — every thread counts the keys below its own (n broadcast LDS reads,
+    // keys are unique) — instead of the 28 barrier-separated steps of a 128-key bitonic network
+    if (n <= 256u && a.cap >= 512u) {
+        uint64_t* sorted = keys + 256;
+        uint64_t mine = KEY_SENTINEL;
+        uint32_t rank = 0;
+        if ((uint32_t)tid < n) {
+            mine = keys[tid];
+            for (uint32_t i = 0; i < n; ++i) rank += (keys[i] < mine || (keys[i] == mine && i < (uint32_t)tid)) ? 1u : 0u;   // (a permutation whatever the keys)
+        }
+        __syncthreads();
+        if ((uint32_t)tid < n) sorted[rank] = mine;
+        __syncthreads();
+        keys = sorted;
+    } else {
+        bitonic_sort_lds<NT>(keys, np2, tid);
+    }
     const uint32_t cnt = n < a.k ? n : a.k;
     for (uint32_t i = tid; i < a.out_k; i += NT) {
         if (i < cnt) {
@@ -3148,6 +3501,34 @@ __global__ void __launch_bounds__(NT) k_final(FinalArgs a) {
         if (a.any_overflow && a.overflow[q]) atomicOr(a.any_overflow, 1u);
         if (a.h_hdr) { a.h_hdr[q] = cnt; a.h_hdr[a.hdr_q + q] = a.overflow[q]; }
     }
+}
+
+template <int NT>
+__global__ void __launch_bounds__(NT) k_final(FinalArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    final_body<NT>(a, reinterpret_cast<uint64_t*>(smem), blockIdx.x, a.count[blockIdx.x], a.exact != 0);
+}
+
+// k_select_final: the select behind the LAST scan stage, the exact rescoring of its survivors and the final order in ONE
+// launch per batch (they were three: k_select, k_rescore_pool / the rescoring half of k_final, k_final — 40 us of a 345 us
+// step on a 1.25M-row shard, two kernel boundaries and two trips of the survivors through HBM).  The survivors go to
+// cand[q] as before (same workgroup: visible behind the barrier) and come back into LDS for the rescoring and the sort.
+struct TailArgs {
+    SelectArgs s;
+    FinalArgs f;
+};
+
+template <int NT>
+__global__ void __launch_bounds__(NT) k_select_final(TailArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint64_t* keys = reinterpret_cast<uint64_t*>(smem);
+    const uint32_t q = blockIdx.x;
+    bool rescored;
+    const uint32_t n = select_body<NT>(a.s, keys, q, &rescored);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's survivor stores have reached L2 (they are read back sc1)
+    __syncthreads();
+    final_body<NT>(a.f, keys, q, n, a.f.exact != 0 || rescored, true);
+    if (a.s.stamps && threadIdx.x == 0) a.s.stamps[(size_t)q * 8 + 6] = __builtin_amdgcn_s_memtime();
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -163,6 +163,7 @@ struct Workspace {
     uint32_t* h_hdr = nullptr;       // pinned host mirror of that pair
     uint8_t* h_out = nullptr;        // pinned staging for small host-API results (rows then dists), H_OUT_BYTES
     unsigned long long* pool_total = nullptr;
+    uint32_t* gsync = nullptr;        // hand-over words of the fused sample stage (ScanArgs::gsync)
     uint64_t* small_part = nullptr;   // k_small_search: [workgroups][SMALL_MAX_Q][SMALL_MAX_K] keys
     uint32_t* small_ticket = nullptr;
     void release() {
@@ -170,7 +171,7 @@ struct Workspace {
         if (h_out) (void)hipHostFree(h_out);
         for (void* p : {(void*)cand, (void*)candB, (void*)segcnt, (void*)count, (void*)thr, (void*)qinv, (void*)qn2,
                         (void*)qrinv, (void*)marg2, (void*)Q16, (void*)Qf, (void*)QW, (void*)QWp, (void*)out_rows,
-                        (void*)out_dists, (void*)out_counts, (void*)pool_total, (void*)small_part, (void*)small_ticket})
+                        (void*)out_dists, (void*)out_counts, (void*)pool_total, (void*)small_part, (void*)small_ticket, (void*)gsync})
             if (p) (void)hipFree(p);
         *this = Workspace();
     }
@@ -798,6 +799,8 @@ static int ensure_workspace(lynse_hip_flat* h, uint32_t k /* caller's k = output
     LY_HIP(hipHostMalloc(&w.h_out, H_OUT_BYTES, hipHostMallocDefault));
     LY_HIP(hipMalloc(&w.pool_total, 8));
     LY_HIP(hipMemset(w.pool_total, 0, 8));
+    LY_HIP(hipMalloc(&w.gsync, 256 + 1024 * 64));   // hand-over words + (debugging) 8 time stamps per workgroup / per (stage, query)
+    LY_HIP(hipMemset(w.gsync, 0, 256 + 1024 * 64));
     LY_HIP(hipMalloc(&w.small_part, (size_t)SMALL_NT * SMALL_MAX_Q * SMALL_MAX_K * 8));
     LY_HIP(hipMalloc(&w.small_ticket, 4));
     LY_HIP(hipMemset(w.small_ticket, 0, 4));
@@ -928,6 +931,32 @@ static int launch_scan_glds(const ScanArgs& a, int metric, bool scale, uint32_t 
 }
 
 #endif  // LYNSE_EXPERIMENTS
+
+// debugging only (not in the header): per-query thresholds / shared-region counts / overflow flags and the hand-over words of
+// context 0's workspace
+extern "C" int lynse_hip_debug_workspace(lynse_hip_flat* h, float* thr, uint32_t* count, uint32_t* overflow, uint32_t* gsync, uint32_t nq) {
+    if (!h || !h->ctx[0].ws.thr) return 1;
+    Workspace& w = h->ctx[0].ws;
+    (void)hipSetDevice(h->device);
+    (void)hipStreamSynchronize(h->ctx[0].stream);
+    if (thr && hipMemcpy(thr, w.thr, nq * 4, hipMemcpyDeviceToHost) != hipSuccess) return 2;
+    if (count && hipMemcpy(count, w.count, nq * 4, hipMemcpyDeviceToHost) != hipSuccess) return 2;
+    if (overflow && hipMemcpy(overflow, w.overflow, nq * 4, hipMemcpyDeviceToHost) != hipSuccess) return 2;
+    if (gsync && hipMemcpy(gsync, w.gsync, 16, hipMemcpyDeviceToHost) != hipSuccess) return 2;
+    return 0;
+}
+extern "C" int lynse_hip_debug_fs_stamps(lynse_hip_flat* h, unsigned long long* out /* [512][8] */) {
+    if (!h || !h->ctx[0].ws.gsync) return 1;
+    (void)hipSetDevice(h->device);
+    (void)hipStreamSynchronize(h->ctx[0].stream);
+    return hipMemcpy(out, h->ctx[0].ws.gsync + 64, 512 * 64, hipMemcpyDeviceToHost) == hipSuccess ? 0 : 2;
+}
+extern "C" int lynse_hip_debug_sel_stamps(lynse_hip_flat* h, unsigned long long* out /* [4][256][8] */) {
+    if (!h || !h->ctx[0].ws.gsync) return 1;
+    (void)hipSetDevice(h->device);
+    (void)hipStreamSynchronize(h->ctx[0].stream);
+    return hipMemcpy(out, h->ctx[0].ws.gsync + 64, 1024 * 64, hipMemcpyDeviceToHost) == hipSuccess ? 0 : 2;
+}
 
 static unsigned long long* g_dbg_ptr = nullptr;
 extern "C" int lynse_hip_debug_phase_cycles(unsigned long long* out, int n) {  // experiments only (not in the header)
@@ -1085,9 +1114,9 @@ static int launch_scan_h16(const ScanArgs& a, int metric, uint32_t grid, hipStre
 
 // certified int8 coarse pass: the 256 x 256 IP tiling with 3 + 2-stage rings over 128-element slabs, one kernel per
 // (ragged last slab, emission mode)
-static int launch_scan_i8c(const ScanArgs& a, uint32_t grid, hipStream_t st) {
+static int launch_scan_i8c(const ScanArgs& a, uint32_t grid, hipStream_t st, bool fs = false) {
     constexpr size_t lds = (size_t)(3 * 256 + 2 * 256) * 128;
-    static bool attr_done[7] = {false};
+    static bool attr_done[9] = {false};
     auto go = [&](auto kern, int slot) -> int {
         if (!attr_done[slot]) { LY_TRY(set_max_lds(kern, lds)); attr_done[slot] = true; }
         hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, a);
@@ -1126,6 +1155,11 @@ static int launch_scan_i8c(const ScanArgs& a, uint32_t grid, hipStream_t st) {
         static bool pattr[2] = {false, false};
         if (a.emit_all == 0 && place == 1) { auto k = k_scan_h16<2, 4, 4, 2, M_IP, 3, 2, 2, false, false, 0, false, 2, 0, 1>; if (!pattr[0]) { LY_TRY(set_max_lds(k, lds)); pattr[0] = true; } hipLaunchKernelGGL(k, dim3(grid), dim3(512), lds, st, a); LY_HIP(hipGetLastError()); return LYNSE_OK; }
         if (a.emit_all == 0 && place == 2) { auto k = k_scan_h16<2, 4, 4, 2, M_IP, 3, 2, 2, false, false, 0, false, 2, 0, 2>; if (!pattr[1]) { LY_TRY(set_max_lds(k, lds)); pattr[1] = true; } hipLaunchKernelGGL(k, dim3(grid), dim3(512), lds, st, a); LY_HIP(hipGetLastError()); return LYNSE_OK; }
+        if (fs) {  // fused sample stage: sample tile + in-launch thresholds + the first threshold stage (kernels.h, FS)
+            if (a.emit_all != 0) return set_error(LYNSE_ERR_INTERNAL, "the fused sample stage is a threshold stage");
+            if (!a.dense) return set_error(LYNSE_ERR_INTERNAL, "the fused sample stage is compiled with the DENSE epilogue");  // (the two-level body spills 12 B with it)
+            return go(k_scan_h16<2, 4, 4, 2, M_IP, 3, 2, 2, false, false, 0, false, 2, 0, 0, true, false, true, 1>, 7);
+        }
         if (a.emit_all == 0 && a.dense) return go(k_scan_h16<2, 4, 4, 2, M_IP, 3, 2, 2, false, false, 0, false, 2, 0, 0, true>, 6);
         if (a.emit_all == 0) return go(k_scan_h16<2, 4, 4, 2, M_IP, 3, 2, 2, false, false, 0, false, 2, 0>, 0);
         if (a.emit_all == 1) return go(k_scan_h16<2, 4, 4, 2, M_IP, 3, 2, 2, false, false, 0, false, 2, 1>, 1);
@@ -1273,6 +1307,7 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
     if (!sel_attr) {
         LY_TRY(set_max_lds(k_select<SEL_NT>, 16384 * 8));
         LY_TRY(set_max_lds(k_final<SEL_NT>, 16384 * 8));
+        LY_TRY(set_max_lds(k_select_final<SEL_NT>, 16384 * 8));
         sel_attr = true;
     }
 
@@ -1289,6 +1324,7 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
         p.Q = Qf; p.D = h->dim; p.qpad = qpad; p.nslab = nslab; p.mins = h->sq8_mins; p.scales = h->sq8_scales;
         p.a1 = h->sq8_a1; p.vmax = h->vmax; p.img = reinterpret_cast<int8_t*>(w.Q16);
         p.sq = w.qinv; p.bq = w.qn2; p.marg2 = w.marg2; p.thr = w.thr; p.count = w.count; p.overflow = w.overflow;
+        p.gsync = w.gsync;
         hipLaunchKernelGGL(k_i8c_prep_queries, dim3(nq), dim3(256), 0, st, p);
         LY_HIP(hipGetLastError());
     } else {
@@ -1332,10 +1368,30 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
     // k <= keys per tile: the best sample tile alone supplies k keys (a shard sorted by score still gets a tight threshold)
     const bool sample_threshold_only = h16 && !binary && !filt && sample.sample_tiles && !no_lane_max && sample_keys_per_tile &&
                                        (k <= sample_keys_per_tile || (uint64_t)sample.sample_tiles * sample_keys_per_tile >= 8ull * k);
+    // Fused sample stage (k_scan_h16<.., FS>, LYNSE_HIP_FUSED_SAMPLE=1; OFF by default): the sample tiles are scored by the
+    // workgroups of the FIRST threshold stage (one each) and the grid agrees on the thresholds inside that launch — no
+    // sample launch, no k_select between.  Needs one sample tile per workgroup, every workgroup resident (grid = CUs) and
+    // the register-resident query constants of the certified int8 pass.  Bit-identical results (tests), but MEASURED SLOWER
+    // than the two launches it replaces (MI355X, 1.25M x 768 x 256: 366 us against 33 + 26 + 261 us; s_memtime stamps,
+    // scripts/dbg_fs_stamps.py: first tile 32 us, hand-over 1 27 us, select 15 us, hand-over 2 17 us, restart): a grid-wide
+    // hand-over drains the LDS-DMA ring of every CU and idles the chip twice, which costs more than a kernel boundary.
+    const int fs_env = []() { const char* e = getenv("LYNSE_HIP_FUSED_SAMPLE"); return e ? atoi(e) : 0; }();   // (read per call: tests flip it)
+    static const int dbg_env = []() { const char* e = getenv("LYNSE_HIP_DEBUG_FLAGS"); return e ? atoi(e) : 0; }();
+    const bool fs = fs_env != 0 && !dbg_env && i8c && h->ld8 % 128 == 0 && sample_threshold_only && plan.size() >= 2 && k <= 32 &&
+                    sample.sample_tiles == (uint32_t)h->num_cu && (plan[1].r1 - plan[1].r0 + 255) / 256 >= (uint32_t)h->num_cu &&
+                    (uint64_t)k * 50000ull > (uint64_t)sample.sample_tiles * plan_tile &&   // (the stage behind the sample runs the DENSE epilogue)
+                    []() { const char* e = getenv("LYNSE_HIP_DENSE"); return !e || atoi(e) != 0; }();
     bool plan_used_segments = false;
+    // the select behind the last stage + exact rescoring + final order in one launch (k_select_final); LYNSE_HIP_FUSED_TAIL=0:
+    // the three separate kernels (A/B)
+    const int fused_tail_env = []() { const char* e = getenv("LYNSE_HIP_FUSED_TAIL"); return e ? atoi(e) : 1; }();   // (read per call: tests flip it)
+    const bool fused_tail = fused_tail_env != 0 && !plan.empty();
+    SelectArgs sa_last{};
     for (size_t si = 0; si < plan.size(); ++si) {
         const Stage s = plan[si];
         const bool emit_all = si == 0;
+        if (fs && si == 0) continue;   // scored inside the launch of stage 1
+        const bool fs_stage = fs && si == 1;
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (tl_prof) {
             LY_TRY(get_event(h, (*ev_used)++, &e0));
@@ -1416,7 +1472,12 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
                 a.dense = (!a.emit_all && a.ld16 % 128 == 0 && seen_before &&
                            (dense_env >= 0 ? dense_env != 0 : (uint64_t)k * 50000ull > seen_before)) ? 1 : 0;
                 if (!a.emit_all) seg_geometry(grid, a.dense ? 8 : 4, &a.nseg, &a.seg);
-                LY_TRY(launch_scan_i8c(a, grid, st));
+                if (fs_stage) {
+                    a.fs_stride = sample.sample_stride; a.fs_rows = (uint32_t)h->n; a.gsync = w.gsync; a.Qf = Qf; a.marg2 = w.marg2;
+                    a.thr_out = w.thr; a.k = k; a.ip_form = ip_form; a.metric = metric;
+                    if (getenv("LYNSE_HIP_FS_STAMPS")) a.debug_flags |= 128;
+                }
+                LY_TRY(launch_scan_i8c(a, grid, st, fs_stage));
             } else if (h16) {
                 a.candB = w.candB; a.segcnt = w.segcnt;
                 if (small) {
@@ -1479,7 +1540,8 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
         }
         if (tl_prof) {
             LY_HIP(hipEventRecord(e1, st));
-            scan_events->push_back({*ev_used - 2, s.sample_tiles ? (uint64_t)s.sample_tiles * plan_tile : (uint64_t)(s.r1 - s.r0)});
+            scan_events->push_back({*ev_used - 2, s.sample_tiles ? (uint64_t)s.sample_tiles * plan_tile
+                                                                  : (uint64_t)(s.r1 - s.r0) + (fs_stage ? (uint64_t)sample.sample_tiles * plan_tile : 0ull)});
         }
         SelectArgs sa{};
         sa.cand = w.cand; sa.count = w.count; sa.overflow = w.overflow; sa.thr = w.thr; sa.marg2 = w.marg2;
@@ -1497,6 +1559,11 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
         }
         sa.Qf = Qf; sa.V = h->rows; sa.ld = h->ld; sa.D = h->dim;
         sa.candB = w.candB; sa.segcnt = w.segcnt; sa.seg = st_seg; sa.nseg = st_nseg;
+        sa.abort_word = fs_stage ? w.gsync + 2 : nullptr;
+        if (getenv("LYNSE_HIP_SEL_STAMPS"))   // debugging: phase stamps of the select behind stage si ([stage][query][8] behind the fs stamps)
+            sa.stamps = reinterpret_cast<unsigned long long*>(w.gsync + 64) + (size_t)si * 256 * 8;
+        if (fs_stage && getenv("LYNSE_HIP_DEBUG_FS")) return LYNSE_OK;   // debugging: stop behind the fused stage (lynse_hip_debug_workspace)
+        if (fused_tail && si + 1 == plan.size()) { sa_last = sa; continue; }  // the last select runs inside k_select_final
         hipLaunchKernelGGL(k_select<SEL_NT>, dim3(nq), dim3(SEL_NT), (size_t)w.cap * 8, st, sa);
         LY_HIP(hipGetLastError());
     }
@@ -1504,7 +1571,7 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
         const uint64_t tiling = small ? 0x14u : ((waves16 == 3 || waves16 == 2) ? 0x24u : 0x42u);
         std::lock_guard<std::mutex> plk(h->prof_mu);
         h->prof.last_plan = (sample.sample_tiles ? 1u : 0u) | ((sample.sample_tiles && sample_threshold_only) ? 2u : 0u) | (i8c ? 4u : 0u) |
-                            (plan_used_segments ? 8u : 0u) | (small ? 16u : 0u) | ((uint64_t)(plan.size() & 0xff) << 8) | (tiling << 16);
+                            (plan_used_segments ? 8u : 0u) | (small ? 16u : 0u) | (fs ? 128u : 0u) | ((uint64_t)(plan.size() & 0xff) << 8) | (tiling << 16);
     }
     FinalArgs fa{};
     fa.cand = w.cand; fa.count = w.count; fa.k = k; fa.out_k = out_k; fa.cap = w.cap; fa.metric = metric; fa.ip_form = ip_form;
@@ -1515,6 +1582,13 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
     fa.pool_total = tl_prof ? w.pool_total : nullptr;
     fa.overflow = w.overflow; fa.any_overflow = any_ovf;
     if (hdr_direct) { fa.h_hdr = w.h_hdr; fa.hdr_q = w.qcap; }
+    if (fused_tail) {
+        TailArgs ta{sa_last, fa};
+        hipLaunchKernelGGL(k_select_final<SEL_NT>, dim3(nq), dim3(SEL_NT), (size_t)w.cap * 8, st, ta);
+        LY_HIP(hipGetLastError());
+        (void)asc;
+        return LYNSE_OK;
+    }
     if (i8c) {  // a few hundred survivors per query inside the int8 margin: spread their exact rescoring over the chip
         hipLaunchKernelGGL(k_rescore_pool<256>, dim3(nq, 4), dim3(256), 0, st, fa);
         LY_HIP(hipGetLastError());

@@ -19,7 +19,7 @@ import oracle as O
 pytestmark = pytest.mark.gpu
 f32 = np.float32
 
-PLAN_SAMPLED, PLAN_THRESHOLD_ONLY, PLAN_I8C, PLAN_SEGMENTS, PLAN_SMALL = 1, 2, 4, 8, 16
+PLAN_SAMPLED, PLAN_THRESHOLD_ONLY, PLAN_I8C, PLAN_SEGMENTS, PLAN_SMALL, PLAN_FUSED_SAMPLE = 1, 2, 4, 8, 16, 128
 
 
 def plan_fields(p):
@@ -66,10 +66,21 @@ def test_c2_flat_ip_768_batch256_runs_the_benchmarked_kernels(L, oracle):
     assert p["scan_launches"] == 3 and stages == 3, p
     assert tiling == 0x24, hex(tiling)
     assert flags & PLAN_SAMPLED and flags & PLAN_THRESHOLD_ONLY and flags & PLAN_I8C and flags & PLAN_SEGMENTS, bin(flags)
-    check = [0, 1, 2, 31, 32, 100, 128, 200, 254, 255]  # both wave columns, every 32-query column block of the tile
-    for qi in check:
-        assert_rows_equal(oracle.canonical_topk(queries[qi], data, k, O.IP), rows[qi], dists[qi], counts[qi], ("c2", qi))
-        assert rows[qi, 0] == q_rows[qi]                   # the perturbed source row wins
+    assert not (flags & PLAN_FUSED_SAMPLE), bin(flags)
+    # the same batch (a) with the sample stage INSIDE the launch of the first threshold stage (k_scan_h16<.., FS>: grid-wide
+    # threshold hand-over; off by default — measured slower than the two launches) and (b) on the three separate tail kernels
+    # instead of k_select_final: identical bits
+    import os
+    for env, launches, fused in (({"LYNSE_HIP_FUSED_SAMPLE": "1"}, 2, True), ({"LYNSE_HIP_FUSED_TAIL": "0"}, 3, False)):
+        os.environ.update(env)
+        try:
+            r_u, d_u, c_u = idx.search_batch_arrays(queries, k, "ip")
+            p_u = idx.profile_get(reset=True)
+        finally:
+            for name in env:
+                del os.environ[name]
+        assert p_u["scan_launches"] == launches and bool(plan_fields(p_u)[0] & PLAN_FUSED_SAMPLE) == fused and p_u["fallback_queries"] == 0, p_u
+        assert np.array_equal(r_u, rows) and np.array_equal(d_u.view(np.uint32), dists.view(np.uint32)) and np.array_equal(c_u, counts)
     # other batch sizes give the same answers: 40 queries (same kernels, mostly empty query columns) and 8 queries
     # (the <= 32-query kernel over the f16 shadow)
     r40, d40, c40 = idx.search_batch_arrays(queries[:40], k, "ip")
