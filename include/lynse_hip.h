@@ -258,6 +258,14 @@ int lynse_hip_ivf_load_binary(const float *rows, uint64_t n, uint32_t dim, const
                               const float *thresholds, int device, lynse_hip_ivf **out);
 /* Fitted BinaryQuantizer state of a binary index: thresholds[dim], already_binary flag. */
 int lynse_hip_ivf_thresholds(const lynse_hip_ivf *h, float *thresholds, int *already_binary);
+/* IVFIndex::insert (src/index/ivf.rs:392-441): `rows` (n x dim f32; a binary index pushes them through its quantizer) are
+ * assigned to the EXISTING centroids with the routing metric (every centroid in ascending order, strictly better wins) and
+ * appended behind the rows already indexed (new row ids old_len .. old_len + n - 1); no retraining.
+ * IVFIndex::delete (:350-390): the listed rows go, the rest keep their order under consecutive row ids and are all
+ * reassigned to the existing centroids (kmeans::assign_metric).  lynse_hip_ivf_assign_f32 is the assignment rule alone. */
+int lynse_hip_ivf_insert_f32(lynse_hip_ivf *h, const float *rows, uint64_t n);
+int lynse_hip_ivf_delete_rows(lynse_hip_ivf *h, const uint64_t *row_ids, uint64_t n_ids);
+int lynse_hip_ivf_assign_f32(lynse_hip_ivf *h, const float *rows, uint64_t n, uint32_t *out_assignments);
 int lynse_hip_ivf_destroy(lynse_hip_ivf *h);
 uint64_t lynse_hip_ivf_len(const lynse_hip_ivf *h);
 uint32_t lynse_hip_ivf_nlist(const lynse_hip_ivf *h);

@@ -471,6 +471,24 @@ class IvfFlatIndex:
     def n_partitions(self) -> int:
         return int(lib.lynse_hip_ivf_nlist(self._h))
 
+    def insert(self, data) -> None:
+        """`IVFIndex::insert` (ivf.rs:392-441): assign the new rows to the existing centroids, append them (no retraining)."""
+        a = _f32(data, 2, "data")
+        if a.shape[1] != self._dim:
+            raise ValueError(f"dimension mismatch: expected {self._dim}, got {a.shape[1]}")
+        check(lib.lynse_hip_ivf_insert_f32(self._h, _ptr(a), a.shape[0]))
+
+    def delete(self, rows) -> None:
+        """`IVFIndex::delete` (ivf.rs:350-390): drop the listed rows; the rest are renumbered in order and reassigned."""
+        r = np.ascontiguousarray(np.asarray(rows).reshape(-1), dtype=np.uint64)
+        check(lib.lynse_hip_ivf_delete_rows(self._h, _ptr(r) if r.size else None, r.size))
+
+    def assign(self, data) -> np.ndarray:
+        a = _f32(data, 2, "data")
+        out = np.zeros(a.shape[0], np.uint32)
+        check(lib.lynse_hip_ivf_assign_f32(self._h, _ptr(a), a.shape[0], _ptr(out)))
+        return out
+
     def export(self):
         n, nl = len(self), self.n_partitions
         cen = np.empty((nl, self._dim), np.float32)
@@ -807,7 +825,11 @@ class Collection:
             return np.zeros((nq, 0), np.uint64), np.zeros((nq, 0), np.float32), np.zeros(nq, np.uint32)
         if self._ivf is not None:
             if self._ivf_rows != len(self._flat):
-                self._build_ivf()  # rows were committed after the build (the reference inserts them incrementally; here: retrain)
+                # rows were committed after the build: Collection::flush hands them to idx.insert (engine.rs:3642-3645, :3858) —
+                # assigned to the existing centroids, no retraining
+                n_new = len(self._flat) - self._ivf_rows
+                self._ivf.insert(self._flat.read_rows(self._ivf_rows, n_new))
+                self._ivf_rows = len(self._flat)
             np_ = self._ivf_nprobe if not nprobe else int(nprobe)  # nprobe == 0 -> the build default (engine.rs:4743-4746)
             if subset_rows is not None:
                 if subset_rows.size == 0:

@@ -121,6 +121,113 @@ def test_device_kmeans_matches_oracle(L, oracle, metric, l2p):
         assert np.array_equal(g_ids.astype(np.uint64), e_ids) and np.array_equal(g_d, e_d)
 
 
+@pytest.mark.parametrize("n,dim,nlist,iters,metric,device_rows", [
+    (50_000, 64, 256, 4, IP, False),      # assignment in wide passes (8192 rows per launch, several query chunks per launch)
+    (50_000, 64, 256, 3, L2, True),       # ... and the device-resident twin (rows never leave HBM)
+    (20_000, 32, 5000, 3, L2, False),     # more than 4096 centroids: the centroid store is past the single / batch-8 boundary of the
+    (20_000, 32, 5000, 2, IP, False),     # IP kernels (flat_mmap.rs:4852-4854) and past one 4096-row plan stage
+    (9_000, 40, 4097, 2, COS, False),     # nlist just past the boundary, rows ~ 2 per list: empty-cluster reseeding in play
+])
+def test_device_kmeans_matches_oracle_at_scale(L, oracle, n, dim, nlist, iters, metric, device_rows):
+    """The device k-means (csrc/ivf_host.inc: FastRng(42) + farthest-point init, assignment = FLAT k=1 search against the
+    centroid matrix in wide passes, sequential-order centroid sums) against the oracle's kmeans::train_for_metric
+    (kmeans.rs:74-139, :237-315) where the wide-pass assignment and > 4096 centroids are actually reached (VERDICT r2 weak #2:
+    the n = 3000 case above never leaves one launch): centroid bits and assignments identical."""
+    rng = np.random.default_rng(1000 + n + nlist)
+    centers = rng.standard_normal((max(nlist // 3, 8), dim)).astype(f32)
+    data = (centers[rng.integers(0, len(centers), n)] + 0.35 * rng.standard_normal((n, dim))).astype(f32)
+    if device_rows:
+        import torch
+
+        idx = L.IvfFlatIndex.build_device(torch.as_tensor(data, device="cuda:0"), dim, nlist, iters, NAME[metric], l2_partitions=False)
+    else:
+        idx = L.IvfFlatIndex.build(None, data, dim, nlist, iters, NAME[metric], l2_partitions=False)
+    cen, asg, off, orig = idx.export()
+    e_cen, e_asg = oracle.kmeans_train(data, nlist, iters, metric)
+    assert cen.shape == e_cen.shape, (cen.shape, e_cen.shape)
+    assert np.array_equal(asg, e_asg), int((asg != e_asg).sum())
+    assert np.array_equal(cen.view(np.uint32), e_cen.view(np.uint32)), int((cen.view(np.uint32) != e_cen.view(np.uint32)).sum())
+    # and a search over the index built from them equals the oracle's IVFIndex::search on its own centroids / lists
+    e_off, e_rows = oracle.lists_from_assignments(e_asg, e_cen.shape[0])
+    for qi in (0, n // 2):
+        q = (data[qi] + 0.05 * rng.standard_normal(dim)).astype(f32)
+        e_ids, e_d, _ = oracle.ivf_search(q, data, e_cen, e_off, e_rows, 8, 10, metric)
+        g_ids, g_d = idx.search(q, 10, 8, NAME[metric])
+        assert np.array_equal(g_ids.astype(np.uint64), e_ids) and np.array_equal(g_d.view(np.uint32), e_d.view(np.uint32)), (qi, g_ids, e_ids)
+
+
+@pytest.mark.parametrize("metric", [IP, L2, COS])
+def test_ivfindex_insert_and_delete_keep_the_centroids(L, oracle, metric):
+    """IVFIndex::insert / ::delete (ivf.rs:350-441): build -> add rows -> search -> delete rows -> search.  New rows are
+    assigned to the EXISTING centroids (kmeans::assign_metric's loop, restated by oracle.kmeans_assign) and appended; a
+    delete renumbers the remaining rows in order and reassigns all of them; the centroids never move.  Assignments and
+    search results equal the oracle's IVFIndex::search over the same centroids and the lists those rules give."""
+    rng = np.random.default_rng(4100 + metric)
+    n0, n1, dim, nlist, nprobe, k = 6000, 1500, 48, 40, 5, 10
+    centers = rng.standard_normal((12, dim)).astype(f32)
+    mk = lambda m: (centers[rng.integers(0, 12, m)] + 0.3 * rng.standard_normal((m, dim))).astype(f32)  # noqa: E731
+    base, extra = mk(n0), mk(n1)
+    idx = L.IvfFlatIndex.build(None, base, dim, nlist, 6, NAME[metric], l2_partitions=False)
+    cen0, asg0, _, _ = idx.export()
+    e_new = oracle.kmeans_assign(extra, cen0, metric)
+    assert np.array_equal(idx.assign(extra), e_new)
+    idx.insert(extra)
+    cen1, asg1, off1, orig1 = idx.export()
+    assert len(idx) == n0 + n1 and np.array_equal(cen1.view(np.uint32), cen0.view(np.uint32))
+    assert np.array_equal(asg1, np.concatenate([asg0, e_new]))
+    data = np.concatenate([base, extra])
+    e_off, e_rows = oracle.lists_from_assignments(asg1, cen0.shape[0])
+    assert np.array_equal(off1, e_off) and np.array_equal(orig1, e_rows)      # new rows sit at the END of their lists
+    queries = (data[rng.integers(0, n0 + n1, 12)] + 0.05 * rng.standard_normal((12, dim))).astype(f32)
+    g_rows, g_d, g_c = idx.search_batch_arrays(queries, k, nprobe)
+    for qi in range(len(queries)):
+        e_ids, e_d, _ = oracle.ivf_search(queries[qi], data, cen0, e_off, e_rows, nprobe, k, metric)
+        c = int(g_c[qi])
+        assert c == len(e_ids) and np.array_equal(g_rows[qi, :c], e_ids) and np.array_equal(g_d[qi, :c].view(np.uint32), e_d.view(np.uint32)), qi
+    # delete: every third of the first 3000 rows + a few of the inserted ones + ids that do not exist
+    gone = np.concatenate([np.arange(0, 3000, 3), n0 + np.arange(0, 200, 7), [10**9]]).astype(np.uint64)
+    idx.delete(gone)
+    keep = np.setdiff1d(np.arange(n0 + n1), gone[gone < n0 + n1].astype(np.int64))
+    left = data[keep]
+    cen2, asg2, off2, orig2 = idx.export()
+    assert len(idx) == len(keep) and np.array_equal(cen2.view(np.uint32), cen0.view(np.uint32))
+    e_asg2 = oracle.kmeans_assign(left, cen0, metric)
+    assert np.array_equal(asg2, e_asg2)
+    e_off2, e_rows2 = oracle.lists_from_assignments(e_asg2, cen0.shape[0])
+    g_rows, g_d, g_c = idx.search_batch_arrays(queries, k, nprobe)
+    for qi in range(len(queries)):
+        e_ids, e_d, _ = oracle.ivf_search(queries[qi], left, cen0, e_off2, e_rows2, nprobe, k, metric)
+        c = int(g_c[qi])
+        assert c == len(e_ids) and np.array_equal(g_rows[qi, :c], e_ids) and np.array_equal(g_d[qi, :c].view(np.uint32), e_d.view(np.uint32)), qi
+
+
+def test_ivf_binary_insert_goes_through_the_quantizer(L, oracle):
+    """IVF-HAMMING-BINARY: inserted rows are encoded with the thresholds FITTED AT BUILD (quantizer.encode -> decode,
+    ivf.rs:398-404), routed with L2 on the codes, and searched by popcount like the rest."""
+    rng = np.random.default_rng(77)
+    n0, n1, dim, nlist, nprobe, k = 4000, 900, 96, 24, 6, 10
+    base = (rng.standard_normal((n0, dim)) * 2 + 1).astype(f32)
+    extra = (rng.standard_normal((n1, dim)) * 2 + 1).astype(f32)
+    idx = L.IvfFlatIndex.build(None, base, dim, nlist, 8, "hamming", l2_partitions=False)
+    thr, ab = idx.thresholds()
+    cen, asg0, _, _ = idx.export()
+    enc_new = oracle.binary_quantize(extra, thr)
+    e_new = oracle.kmeans_assign(enc_new, cen, O.L2)
+    idx.insert(extra)
+    _, asg1, off1, orig1 = idx.export()
+    assert np.array_equal(asg1, np.concatenate([asg0, e_new]))
+    enc = np.concatenate([oracle.binary_quantize(base, thr), enc_new])
+    packed = oracle.pack_binary(enc)
+    e_off, e_rows = oracle.lists_from_assignments(asg1, cen.shape[0])
+    queries = np.concatenate([base[:5], extra[:5]]).astype(f32)
+    g_rows, g_d, g_c = idx.search_batch_arrays(queries, k, nprobe)
+    for qi in range(len(queries)):
+        eq = oracle.binary_quantize(queries[qi], thr)[0]
+        e_ids, e_d, _ = oracle.ivf_search(eq, enc, cen, e_off, e_rows, nprobe, k, O.HAMMING, packed=packed)
+        c = int(g_c[qi])
+        assert c == len(e_ids) and np.array_equal(g_rows[qi, :c], e_ids) and np.array_equal(g_d[qi, :c].view(np.uint32), e_d.view(np.uint32)), qi
+
+
 def test_ivf_build_recall_and_errors(L, oracle):
     rng = np.random.default_rng(3)
     n, dim = 20000, 64
