@@ -208,6 +208,8 @@ def main():
     verify = None
     if not args.no_verify:
         verify = sh.verify_against_torch(queries, K, metric, out, nverify=min(args.verify_queries, B))
+        if world == 1 and metric == 0 and rank == 0:
+            verify.update(oracle_distance_bits(sh.index, queries, out, B, K))
 
     result = None
     if rank == 0:
@@ -323,6 +325,32 @@ def main():
                 pass
             sh.comm = None
         dist.destroy_process_group()
+
+
+def oracle_distance_bits(index, queries, out, B, K):
+    """Every (row, distance) pair the timed batch returned against the ORACLE's bit pattern: the rows come back from the
+    index (HBM copy), the oracle scores them with the reference's batch-8 IP kernel (simd.rs:1452-1525, the form every row of
+    a >= 4096-row store is scored with) and the f32 bits must be equal; ids: the recall figures above (torch fp32 top-k).
+    The full ranking against the oracle's exact_flat_search is tests/test_gpu_baseline_configs.py::test_c2_* (2.4M rows)."""
+    import oracle as O
+
+    orc = O.get()
+    rows = out.rows[:B].cpu().numpy().astype(np.int64)
+    dists = out.dists[:B].cpu().numpy()
+    qh = queries[:B].cpu().numpy()
+    uniq = np.unique(rows.ravel())
+    uniq = uniq[uniq >= 0]
+    order = np.argsort(uniq)
+    fetched = {}
+    # contiguous runs would be nice, the result rows are scattered: one read per distinct row (a few thousand)
+    for r in uniq[order]:
+        fetched[int(r)] = index.read_rows(int(r), 1)[0]
+    bad = 0
+    for qi in range(B):
+        for j in range(K):
+            e = orc.ip_batch8_row(qh[qi], fetched[int(rows[qi, j])])
+            bad += int(np.float32(e).view(np.uint32) != dists[qi, j].view(np.uint32))
+    return {"oracle_distance_bits_checked": int(B * K), "oracle_distance_bits_equal": bad == 0, "oracle_distance_bits_mismatches": bad}
 
 
 def _time_calls(fn, warm, reps):

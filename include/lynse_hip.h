@@ -347,6 +347,14 @@ int lynse_hip_flat_search_sharded_packed_u64_device(lynse_hip_flat *h, lynse_hip
                                                     const uint64_t *d_query_words, uint64_t nq, uint32_t k,
                                                     int metric, uint64_t *d_out_rows, float *d_out_dists,
                                                     uint32_t *d_out_counts);
+/* Row-sharded IVF search (BASELINE config 4): the local part of the probed lists -> ncclAllGather of the result blocks ->
+ * device merge in the canonical (distance, global row) order, on the shard's stream.  Every rank holds its rows of every
+ * list under the same centroids (lynse_hip_ivf_load_device with the shared centroids, lynse_hip_ivf_set_row_map for global
+ * row ids, lynse_hip_ivf_set_routing(h, 2): no all-lists-empty fallback on a shard).  Stands where the reference fans an
+ * index search out to its shard nodes and merges (src/cluster.rs:101-123, :173-217, :327-393).  A collective. */
+int lynse_hip_ivf_search_sharded_f32_device(lynse_hip_ivf *h, lynse_hip_comm *c, const float *d_queries, uint64_t nq,
+                                            uint32_t k, uint32_t nprobe, uint64_t *d_out_rows, float *d_out_dists,
+                                            uint32_t *d_out_counts);
 
 /* ---- searches in flight: submit / wait ----
  *

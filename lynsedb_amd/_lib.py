@@ -108,6 +108,7 @@ SIGNATURES = {
                                                 C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]),
     "lynse_hip_ivf_profile_get": (C.c_int, [_vp, C.POINTER(Profile), C.c_int]),
     "lynse_hip_ivf_insert_f32": (C.c_int, [_vp, _vp, C.c_uint64]),
+    "lynse_hip_ivf_search_sharded_f32_device": (C.c_int, [_vp, _vp, _vp, C.c_uint64, C.c_uint32, C.c_uint32, _vp, _vp, _vp]),
     "lynse_hip_ivf_delete_rows": (C.c_int, [_vp, _vp, C.c_uint64]),
     "lynse_hip_ivf_assign_f32": (C.c_int, [_vp, _vp, C.c_uint64, _vp]),
     "lynse_hip_comm_load_rccl": (C.c_int, [C.c_char_p]),

@@ -341,4 +341,33 @@ __global__ void __launch_bounds__(256) k_gather_rows_f32(const float* __restrict
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// k_ivf_score_positions — the exact scores of a list of slab positions against ONE query, as (score, ORIGINAL row) keys.
+// IVF search with k beyond the candidate capacity of the staged pipeline (k > cap / 4: IVFIndex::search accepts any k,
+// ivf.rs:304-310, the server caps at MAX_TOP_K = 10,000): every row of the probed lists is scored with the single-row
+// kernels (compute_distance_f32, ivf.rs:294-298) and the host takes the top k of the keys.
+// ------------------------------------------------------------------------------------------------
+struct IvfScoreArgs {
+    const float* V;
+    uint32_t ld, D;
+    const float* q;
+    const uint32_t* pos;
+    const uint32_t* orig;
+    uint32_t n;
+    int metric;
+    uint64_t* keys;
+};
+
+__global__ void __launch_bounds__(256) k_ivf_score_positions(IvfScoreArgs a) {
+    const int g = threadIdx.x & 7;
+    const bool asc = metric_ascending(a.metric);
+    const uint32_t bound = (a.n + 31u) / 32u * 32u;   // whole waves run the same trip count (exact_score shuffles inside its 8 lanes)
+    for (uint32_t i = blockIdx.x * 32u + (threadIdx.x >> 3); i < bound; i += gridDim.x * 32u) {
+        const uint32_t p = a.pos[i < a.n ? i : a.n - 1];
+        const float s = exact_score<32>(a.metric, LYNSE_IPFORM_SINGLE, a.q, a.V + (size_t)p * a.ld, a.D, g);
+        if (g == 0 && i < a.n) a.keys[i] = make_key(s, a.orig[p], asc);
+    }
+}
+
 }  // namespace lynse

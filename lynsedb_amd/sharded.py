@@ -370,6 +370,17 @@ class ShardedIvf:
         self.dim, self.rank, self.world, self.device = dim, rank, world, device
         self.dist = group
         self.index = None
+        self.comm: Optional[NativeComm] = None   # RCCL behind the C-ABI (enable_native_comm); None = torch.distributed's all-gather
+
+    def enable_native_comm(self) -> bool:
+        """The exchange inside the library (lynse_hip_ivf_search_sharded_f32_device: local scan -> ncclAllGather -> k_merge on
+        one stream).  Collective; False (and the torch.distributed path stays) if RCCL cannot be set up on some rank."""
+        try:
+            self.comm = NativeComm(self.dist, self.rank, self.world, self.device if self.device is not None else 0)
+            return True
+        except Exception:  # noqa: BLE001
+            self.comm = None
+            return False
 
     @staticmethod
     def assign(rows: np.ndarray, centroids: np.ndarray, metric: str, device: Optional[int] = None) -> np.ndarray:
@@ -424,6 +435,12 @@ class ShardedIvf:
 
         nq = d_queries.shape[0]
         m = metric_from_str(self.metric)
+        if self.comm is not None:   # scan -> ncclAllGather -> k_merge behind the C-ABI, no host round trip in between
+            torch.cuda.current_stream().synchronize()
+            check(lib.lynse_hip_ivf_search_sharded_f32_device(self.index._h, self.comm.handle, C.c_void_p(d_queries.data_ptr()), nq, int(k),
+                                                              int(nprobe), C.c_void_p(out.rows.data_ptr()), C.c_void_p(out.dists.data_ptr()),
+                                                              C.c_void_p(out.counts.data_ptr())))
+            return
         if self.world == 1:
             self.index.search_device(d_queries, k, nprobe, out.rows, out.dists, out.counts)
             return

@@ -514,3 +514,57 @@ def test_ivf_few_queries_fused_path_equals_staged_and_oracle(L, oracle, metric):
         e_ids, e_d, _ = oracle.ivf_search(queries[qi], data, cen, off, rows, 6, 10, metric)
         assert np.array_equal(r[qi].cpu().numpy().astype(np.uint64)[:len(e_ids)], e_ids.astype(np.uint64))
         assert np.array_equal(d[qi].cpu().numpy()[:len(e_ids)].view(np.uint32), e_d.view(np.uint32))
+
+
+def test_sharded_ivf_entry_point_with_a_one_rank_communicator(L, oracle):
+    """lynse_hip_ivf_search_sharded_f32_device (local part of the probed lists -> RCCL exchange -> device merge behind the
+    C-ABI) on the one GPU a test box has: a 1-rank RCCL communicator, global rows through the row map, results equal to
+    the oracle's IVFIndex::search over the same centroids / lists — and to the torch.distributed-free device path."""
+    import torch
+
+    from lynsedb_amd.sharded import NativeComm, ShardedIvf, ShardOutputs
+
+    rng = np.random.default_rng(91)
+    n, dim, nlist, nprobe, nq, k = 30_000, 64, 64, 6, 40, 10
+    centers = rng.standard_normal((20, dim)).astype(f32)
+    data = (centers[rng.integers(0, 20, n)] + 0.3 * rng.standard_normal((n, dim))).astype(f32)
+    cen, asg, off, rows = oracle_ivf(oracle, data, nlist, IP, iters=5)
+    sh = ShardedIvf(dim, rank=0, world=1, device=0, group=None)
+    sh.load_local(data, cen, asg, "ip")
+    queries = (data[rng.integers(0, n, nq)] + 0.05 * rng.standard_normal((nq, dim))).astype(f32)
+    dq = torch.as_tensor(queries, device="cuda:0")
+    plain = ShardOutputs(nq, k, 1, dq.device)
+    sh.search_device(dq, k, nprobe, plain)
+    torch.cuda.synchronize()
+    sh.comm = NativeComm(None, 0, 1, 0)
+    out = ShardOutputs(nq, k, 1, dq.device)
+    sh.search_device(dq, k, nprobe, out)
+    torch.cuda.synchronize()
+    assert torch.equal(out.rows, plain.rows) and torch.equal(out.dists, plain.dists) and torch.equal(out.counts, plain.counts)
+    r, d, c = out.rows.cpu().numpy().view(np.uint64), out.dists.cpu().numpy(), out.counts.cpu().numpy()
+    for qi in range(nq):
+        e_ids, e_d, _ = oracle.ivf_search(queries[qi], data, cen, off, rows, nprobe, k, IP)
+        cc = int(c[qi])
+        assert cc == len(e_ids) and np.array_equal(r[qi, :cc], e_ids) and np.array_equal(d[qi, :cc].view(np.uint32), e_d.view(np.uint32)), qi
+
+
+@pytest.mark.parametrize("metric", [IP, L2])
+def test_ivf_any_k_up_to_max_top_k(L, oracle, metric):
+    """IVFIndex::search takes any k (ivf.rs:304-310; the server caps at MAX_TOP_K = 10,000, src/server/mod.rs:46): beyond the
+    candidate capacity of the staged pipeline (k > 4096) every row of the probed lists is scored exactly and the host keeps
+    the k best keys — ids and distance bits equal the oracle's, also when the probed lists hold fewer than k rows and for
+    the all-lists-empty fallback."""
+    rng = np.random.default_rng(300 + metric)
+    n, dim, nlist, nprobe = 60_000, 32, 16, 8
+    centers = rng.standard_normal((16, dim)).astype(f32)
+    data = (centers[rng.integers(0, 16, n)] + 0.4 * rng.standard_normal((n, dim))).astype(f32)
+    cen, asg, off, rows = oracle_ivf(oracle, data, nlist, metric, iters=4)
+    idx = L.IvfFlatIndex.load(data, cen, asg, NAME[metric])
+    queries = (data[rng.integers(0, n, 3)] + 0.05 * rng.standard_normal((3, dim))).astype(f32)
+    for k, npr in ((10_000, nprobe), (5_000, 1), (4_097, 3)):
+        g_rows, g_d, g_c = idx.search_batch_arrays(queries, k, npr)
+        for qi in range(len(queries)):
+            e_ids, e_d, _ = oracle.ivf_search(queries[qi], data, cen, off, rows, npr, k, metric)
+            c = int(g_c[qi])
+            assert c == len(e_ids), (k, npr, qi, c, len(e_ids))
+            assert np.array_equal(g_rows[qi, :c], e_ids) and np.array_equal(g_d[qi, :c].view(np.uint32), e_d.view(np.uint32)), (k, npr, qi)
