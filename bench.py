@@ -245,11 +245,11 @@ def main():
         frac_mfma = (mfma_rate / mfma_peak) if mfma_peak else 0.0
         traffic, traffic_note = None, "no PMC summary under profiles/ for this kernel"
         try:  # HBM bytes per launch from the committed PMC pass (bench.py itself cannot run rocprofv3 --pmc)
-            pm = json.loads((ROOT / "profiles" / "r02_pmc_traffic.json").read_text())
+            pm = json.loads((ROOT / "profiles" / "r03_pmc_traffic.json").read_text())
             pm = pm["i8c" if i8c else ("binary" if metric >= 3 else "f16")]
             traffic = int(kernel_bytes / launches * pm["ratio_hbm_over_kernel_bytes"])
             traffic_note = "kernel stream bytes x %.4f (FETCH_SIZE, gfx950-corrected x2; %s)" % (
-                pm["ratio_hbm_over_kernel_bytes"], "profiles/r02_pmc_traffic.json")
+                pm["ratio_hbm_over_kernel_bytes"], "profiles/r03_pmc_traffic.json")
         except Exception:
             pass
         hbm_bound = frac_hbm >= frac_mfma
