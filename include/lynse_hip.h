@@ -197,6 +197,9 @@ int lynse_hip_flat_profile_get(lynse_hip_flat *h, lynse_hip_profile *out, int re
  * strikes = candidate overflows of the certified int8 pass so far (3 switch it off for the handle; -1 = off because the
  * rows are not finite), sq8_rows = rows covered by the SQ8 codes currently built (0 = none). */
 int lynse_hip_flat_coarse_state(lynse_hip_flat *h, int *out_strikes, uint64_t *out_sq8_rows);
+/* Rows covered by the +-1 byte copy of the packed rows that feeds batched Hamming searches (>= 96 queries) to the int8 MFMA
+ * (packed_binary_search for a batch, flat_mmap.rs:1345-1409); 0 = not built (diagnostics / tests). */
+uint64_t lynse_hip_flat_bpm_rows(const lynse_hip_flat *h);
 /* Tuning knobs (defaults are fine): first-stage rows and growth factor of the contiguous stage plan (the fallback of the
  * default sampled plan), candidate capacity per query (power of two in [256, 16384], default 16384; k <= cap / 4 when the
  * shard holds more than cap rows). */

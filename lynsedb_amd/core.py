@@ -337,7 +337,7 @@ class FlatIndex:
         rows are not finite) and the rows covered by the SQ8 codes built so far."""
         strikes, rows = C.c_int(0), C.c_uint64(0)
         check(lib.lynse_hip_flat_coarse_state(self._h, C.byref(strikes), C.byref(rows)))
-        return {"i8c_strikes": strikes.value, "sq8_rows": rows.value}
+        return {"i8c_strikes": strikes.value, "sq8_rows": rows.value, "bpm_rows": int(lib.lynse_hip_flat_bpm_rows(self._h))}
 
 
 class SearchTicket:

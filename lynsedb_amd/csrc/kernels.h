@@ -2274,6 +2274,71 @@ __global__ void __launch_bounds__(256) k_i8c_prep_queries(I8cPrepArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Batched Hamming on the matrix pipe (packed_binary_search, flat_mmap.rs:1345-1409, for batches of queries).
+// popcount(x ^ q) = (D - sum_d s_x[d] s_q[d]) / 2 with s = +1 for a set bit, -1 for a clear one (0 in the pad columns of
+// both sides): a batch of queries against the rows is an int8 GEMM with EXACT integer results, and "smaller distance" is
+// "larger dot product" — the certified-int8 IP scan (k_scan_h16<2,4,4,2,IP,I8Q=2>) runs it unchanged with s_q = 1, B_q = 0
+// and a zero margin; k_select takes the strict cut of the binary metrics, k_final turns the dot product back into the
+// distance (FinalArgs::ham_dim).  The lane-per-row popcount kernel (k_scan_binary_rows) needs 2 VALU operations per 32 bits
+// and (row, query) pair and is VALU-bound from ~16 queries on (36.8k queries/s at 12.5M x 1024 bits x 256 queries).
+//   k_bits_to_pm1      : packed words -> one signed byte per bit (+1 / -1), pitch ld8 (multiple of 16), pad columns 0;
+//                        a resident copy like the f16 shadow / the SQ8 codes, built on the first batched Hamming search
+//   k_bpm_prep_queries : packed query words -> the +-1 query image in the scan kernel's slab layout, open thresholds
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_bits_to_pm1(const uint64_t* __restrict__ P, uint32_t W, uint32_t D, uint64_t r0, uint64_t r1,
+                                                     int8_t* __restrict__ out, uint32_t ld8) {
+    const uint32_t cpr = ld8 / 16;   // 16-byte pieces per row
+    const uint64_t total = (r1 - r0) * cpr;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t r = r0 + i / cpr;
+        const uint32_t c0 = (uint32_t)(i % cpr) * 16;
+        const uint32_t w = c0 >> 6;
+        const uint32_t bits = w < W ? (uint32_t)(P[r * W + w] >> (c0 & 63)) & 0xffffu : 0u;
+        u32x4 v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            uint32_t word = 0;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const uint32_t col = c0 + j * 4 + b;
+                const uint32_t byte = col < D ? (((bits >> (j * 4 + b)) & 1u) ? 0x01u : 0xffu) : 0u;
+                word |= byte << (8 * b);
+            }
+            v[j] = word;
+        }
+        *reinterpret_cast<u32x4*>(out + r * ld8 + c0) = v;
+    }
+}
+
+struct BpmPrepArgs {
+    const uint64_t* QW;   // nq x W packed query words
+    uint32_t W, D, qpad, nslab;
+    int8_t* img;
+    float *sq, *bq, *marg2, *thr;
+    uint32_t *count, *overflow;
+};
+
+__global__ void __launch_bounds__(256) k_bpm_prep_queries(BpmPrepArgs a) {
+    const uint32_t q = blockIdx.x;
+    const int tid = threadIdx.x;
+    const uint32_t total = a.nslab * 128;
+    for (uint32_t i = tid; i < total; i += 256) {
+        int u = 0;
+        if (i < a.D) u = ((a.QW[(size_t)q * a.W + (i >> 6)] >> (i & 63)) & 1ull) ? 1 : -1;
+        const uint32_t s = i / 128, k = i % 128, l = k >> 4, e = k & 15, p = l ^ ((q >> 1) & 7);
+        a.img[(((size_t)s * a.qpad + q) * 8 + p) * 16 + e] = (int8_t)u;
+    }
+    if (tid == 0) {
+        a.sq[q] = 1.0f;          // score = B_q + s_q * dot = the dot product itself (exact)
+        a.bq[q] = 0.0f;
+        a.marg2[q] = 0.0f;
+        a.thr[q] = -LY_INF;
+        a.count[q] = 0u;
+        a.overflow[q] = 0u;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // k_scan_binary: packed one-bit rows (ceil(D/64) u64 words per row).  Eight lanes own one row
 // (16 B per lane per chunk -> a row's words are read as contiguous 128-B pieces), row words stay
 // in registers across the query loop, packed queries + thresholds sit in LDS.  Distances follow
@@ -3428,6 +3493,9 @@ struct FinalArgs {
     // of being copied back by a copy kernel behind the search; NULL = not wanted
     uint32_t* h_hdr;
     uint32_t hdr_q;
+    // batched Hamming on the matrix pipe: the keys carry the +-1 dot product (best-first as an IP score); the distance
+    // written out is (ham_dim - dot) / 2 — exact (integers below 2^24).  0 = off
+    uint32_t ham_dim;
 };
 
 // k_rescore_pool: the exact rescoring of k_final spread over gridDim.y blocks per query (IVF on tightly clustered
@@ -3488,10 +3556,11 @@ __device__ __forceinline__ void final_body(const FinalArgs& a, uint64_t* keys, c
     for (uint32_t i = tid; i < a.out_k; i += NT) {
         if (i < cnt) {
             a.out_rows[(size_t)q * a.out_k + i] = (uint64_t)key_row(keys[i]) * a.row_stride + a.row_offset;
-            a.out_dists[(size_t)q * a.out_k + i] = key_score(keys[i], asc);
+            const float sc = key_score(keys[i], asc);
+            a.out_dists[(size_t)q * a.out_k + i] = a.ham_dim ? ((float)a.ham_dim - sc) * 0.5f : sc;
         } else {
             a.out_rows[(size_t)q * a.out_k + i] = ~0ull;
-            a.out_dists[(size_t)q * a.out_k + i] = asc ? LY_INF : -LY_INF;
+            a.out_dists[(size_t)q * a.out_k + i] = (a.ham_dim || asc) ? LY_INF : -LY_INF;
         }
     }
     if (tid == 0) {

@@ -244,6 +244,11 @@ struct lynse_hip_flat {
     bool sq8_finite = false;
     // certified int8 coarse pass (FLAT-IP batches of 33..256 queries): -1 = off (env / strikes), else overflow strikes so far
     std::atomic<int> i8c_strikes{0};     // (searches under the SHARED lock bump it)
+    // batched Hamming on the matrix pipe: one signed byte per bit (+1 / -1) of the packed rows, pitch ld8; built lazily on the
+    // first Hamming batch of >= bin_mfma_minq() queries (8x the packed words: the price of feeding the int8 MFMA from HBM)
+    int8_t* bpm = nullptr;
+    uint64_t n_bpm = 0, bpm_cap = 0;
+    bool bpm_failed = false;             // the copy did not fit: the popcount kernels answer
     // gathered ("few matches") filtered path: compact copy of the listed shadow rows, their norms and 32-bit ids
     _Float16* g_rows16 = nullptr;
     float *g_vn2 = nullptr, *g_vrinv = nullptr;
@@ -378,7 +383,7 @@ extern "C" int lynse_hip_flat_destroy(lynse_hip_flat* h) {
     }
     for (void* p : {(void*)h->rows, (void*)h->rows16, (void*)h->packed, (void*)h->vn2, (void*)h->vrinv, (void*)h->d_stats,
                     (void*)h->d_mask, (void*)h->d_subset, (void*)h->g_rows16, (void*)h->g_vn2, (void*)h->g_vrinv, (void*)h->g_ids32,
-                    (void*)h->sq8, (void*)h->sq8_mins, (void*)h->sq8_scales, (void*)h->sq8_sum, (void*)h->sq8_sum2, (void*)h->sq8_mm, (void*)h->sq8_stats})
+                    (void*)h->bpm, (void*)h->sq8, (void*)h->sq8_mins, (void*)h->sq8_scales, (void*)h->sq8_sum, (void*)h->sq8_sum2, (void*)h->sq8_mm, (void*)h->sq8_stats})
         if (p) (void)hipFree(p);
     for (auto& c : h->ctx)
         if (c.stream) (void)hipStreamDestroy(c.stream);
@@ -610,6 +615,43 @@ static int ensure_packed_locked(lynse_hip_flat* h) {
     LY_HIP(hipGetLastError());
     LY_HIP(hipStreamSynchronize(cur(h).stream));
     h->n_packed = h->n;
+    return LYNSE_OK;
+}
+
+// Batched Hamming on the int8 MFMA (kernels.h, k_bits_to_pm1): batches of at least LYNSE_HIP_BIN_MFMA_MINQ (default 16)
+// queries, unfiltered, Hamming only (Jaccard / Dice need the row popcounts in the score: the popcount kernels keep them).
+static uint32_t bin_mfma_minq() {
+    static const uint32_t v = []() { const char* e = getenv("LYNSE_HIP_BIN_MFMA_MINQ"); return e ? (uint32_t)atoi(e) : 96u; }();
+    return v;   // (the MFMA pass costs the same for 33 or 256 queries, the popcount kernel scales with the batch: they cross near 100)
+}
+static bool bin_mfma_eligible(const lynse_hip_flat* h, int metric, bool filtered, uint64_t nq) {
+    return metric == M_HAMMING && !filtered && bin_mfma_minq() > 0 && nq >= bin_mfma_minq() && nq > SCAN_BQ_SMALL && !h->bpm_failed &&
+           h->n >= 65536 && scan_variant() == 3;
+}
+static int ensure_bpm_locked(lynse_hip_flat* h) {
+    if (h->bpm_failed || (h->bpm && h->n_bpm == h->n)) return LYNSE_OK;
+    LY_TRY(ensure_packed_locked(h));
+    if (h->bpm_cap < h->n) {
+        const uint64_t cap = std::max<uint64_t>(h->n, std::max<uint64_t>(h->capacity, h->packed_capacity));
+        int8_t* nb = nullptr;
+        if (hipMalloc(&nb, (size_t)cap * h->ld8 + 256) != hipSuccess) {  // no room for the 8x copy: not an error
+            (void)hipGetLastError();
+            h->bpm_failed = true;
+            return LYNSE_OK;
+        }
+        if (h->bpm && h->n_bpm)
+            LY_HIP(hipMemcpyAsync(nb, h->bpm, (size_t)h->n_bpm * h->ld8, hipMemcpyDeviceToDevice, cur(h).stream));
+        LY_HIP(hipStreamSynchronize(cur(h).stream));
+        if (h->bpm) (void)hipFree(h->bpm);
+        h->bpm = nb;
+        h->bpm_cap = cap;
+    }
+    const uint64_t pieces = (h->n - h->n_bpm) * (h->ld8 / 16);
+    hipLaunchKernelGGL(k_bits_to_pm1, dim3((uint32_t)std::min<uint64_t>((pieces + 255) / 256, (uint64_t)h->num_cu * 32)), dim3(256), 0, cur(h).stream,
+                       h->packed, h->words, h->dim, h->n_bpm, h->n, h->bpm, h->ld8);
+    LY_HIP(hipGetLastError());
+    LY_HIP(hipStreamSynchronize(cur(h).stream));
+    h->n_bpm = h->n;
     return LYNSE_OK;
 }
 
@@ -1292,6 +1334,9 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
     const bool asc = metric_ascending(metric);
     const bool h16 = scan_variant() == 3;
     const bool glds = scan_variant() == 0;
+    // batched Hamming on the int8 MFMA: the +-1 copy of the rows is there and the batch is large enough (search_impl builds it)
+    const bool bin_mfma = h16 && bin_mfma_eligible(h, metric, mask != nullptr || row_ids != nullptr, nq) && h->bpm && h->n_bpm == h->n;
+    if (bin_mfma) i8c = true;   // the scan side IS the certified-int8 IP scan (exact here: margin 0)
     const uint32_t nslab = i8c ? (h->dim + 127) / 128 : glds ? (h->dim + GL_BK - 1) / GL_BK : (h->dim + SCAN_BK - 1) / SCAN_BK;  // h16: HK == SCAN_BK == 64
     const bool small = nq <= SCAN_BQ_SMALL;
     const uint32_t qpad = small ? SCAN_BQ_SMALL : round_up(nq, SCAN_BQ_LARGE);  // > 256 queries: a widened handle, qpad / 256 chunks per launch
@@ -1311,7 +1356,14 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
         sel_attr = true;
     }
 
-    if (binary) {
+    if (bin_mfma) {
+        if (nq != qpad || h->dim % 128 != 0) LY_HIP(hipMemsetAsync(w.Q16, 0, (size_t)nslab * qpad * 128, st));
+        BpmPrepArgs p{};
+        p.QW = w.QW; p.W = h->words; p.D = h->dim; p.qpad = qpad; p.nslab = nslab; p.img = reinterpret_cast<int8_t*>(w.Q16);
+        p.sq = w.qinv; p.bq = w.qn2; p.marg2 = w.marg2; p.thr = w.thr; p.count = w.count; p.overflow = w.overflow;
+        hipLaunchKernelGGL(k_bpm_prep_queries, dim3(nq), dim3(256), 0, st, p);
+        LY_HIP(hipGetLastError());
+    } else if (binary) {
         std::vector<float> thr0(nq, INFINITY);
         LY_HIP(hipMemcpyAsync(w.thr, thr0.data(), nq * 4, hipMemcpyHostToDevice, st));
         LY_HIP(hipMemsetAsync(w.count, 0, nq * 4, st));
@@ -1399,7 +1451,7 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
             LY_HIP(hipEventRecord(e0, st));
         }
         uint32_t st_nseg = 0, st_seg = 0;  // segmented emission of this stage (k_select gathers)
-        if (binary) {
+        if (binary && !bin_mfma) {
             BinArgs b{};
             b.P = h->packed; b.W = h->words; b.row0 = s.r0; b.row1 = s.r1; b.QW = w.QW; b.nq = nq;
             b.thr = w.thr; b.cand = w.cand; b.count = w.count; b.cap = w.cap; b.emit_all = emit_all ? 1 : 0;
@@ -1439,7 +1491,7 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
             uint32_t tile_rows = (glds && !small && big_rows == 256) ? 256u : (uint32_t)SCAN_BR;
             if (h16) tile_rows = small ? 128u : 256u;
             a.V16 = h->rows16; a.ld16 = h->ld16;
-            if (i8c) { a.V16 = reinterpret_cast<const _Float16*>(h->sq8); a.ld16 = h->ld8; }
+            if (i8c) { a.V16 = reinterpret_cast<const _Float16*>(bin_mfma ? h->bpm : h->sq8); a.ld16 = h->ld8; }
             if (glds && !small && big_rows == 192 && metric == M_IP) tile_rows = 192u;
             a.qpad = qpad; a.nq = nq; a.nslab = nslab; a.ntiles = (s.r1 - s.r0 + tile_rows - 1) / tile_rows;
             if (s.sample_tiles) a.ntiles = s.sample_tiles;
@@ -1545,7 +1597,7 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
         }
         SelectArgs sa{};
         sa.cand = w.cand; sa.count = w.count; sa.overflow = w.overflow; sa.thr = w.thr; sa.marg2 = w.marg2;
-        sa.k = k; sa.cap = w.cap; sa.keep_max = w.cap / 2; sa.metric = metric; sa.ip_form = ip_form;
+        sa.k = k; sa.cap = w.cap; sa.keep_max = w.cap / 2; sa.metric = bin_mfma ? (int)M_IP : metric; sa.ip_form = ip_form;   // (bin_mfma: the keys are best-first +-1 dot products)
         sa.exact = binary ? 1 : 0;
         static const int tighten_env = []() { const char* e = getenv("LYNSE_HIP_TIGHTEN"); return e ? atoi(e) : 1; }();
         // (worth its ~k exact rescorings per query and stage where the margin is wide — the int8 pass — or k is small)
@@ -1574,7 +1626,8 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
                             (plan_used_segments ? 8u : 0u) | (small ? 16u : 0u) | (fs ? 128u : 0u) | ((uint64_t)(plan.size() & 0xff) << 8) | (tiling << 16);
     }
     FinalArgs fa{};
-    fa.cand = w.cand; fa.count = w.count; fa.k = k; fa.out_k = out_k; fa.cap = w.cap; fa.metric = metric; fa.ip_form = ip_form;
+    fa.cand = w.cand; fa.count = w.count; fa.k = k; fa.out_k = out_k; fa.cap = w.cap; fa.metric = bin_mfma ? (int)M_IP : metric; fa.ip_form = ip_form;
+    fa.ham_dim = bin_mfma ? h->dim : 0u;
     fa.exact = binary ? 1 : 0; fa.Qf = Qf; fa.V = h->rows; fa.ld = h->ld; fa.D = h->dim;
     fa.row_stride = h->row_stride; fa.row_offset = h->row_offset;
     fa.out_rows = r_dst ? r_dst : w.out_rows; fa.out_dists = d_dst ? d_dst : w.out_dists; fa.out_counts = w.out_counts;
@@ -1589,7 +1642,7 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
         (void)asc;
         return LYNSE_OK;
     }
-    if (i8c) {  // a few hundred survivors per query inside the int8 margin: spread their exact rescoring over the chip
+    if (i8c && !bin_mfma) {  // a few hundred survivors per query inside the int8 margin: spread their exact rescoring over the chip
         hipLaunchKernelGGL(k_rescore_pool<256>, dim3(nq, 4), dim3(256), 0, st, fa);
         LY_HIP(hipGetLastError());
         fa.exact = 1;
@@ -1892,7 +1945,10 @@ static int search_impl(lynse_hip_flat* h, const void* q_src, bool packed_queries
     std::unique_lock<std::shared_mutex> xlk(h->rw, std::defer_lock);
     CtxLease lease;
     auto derived_ready = [&]() {
-        if (binary) return h->packed_only || (h->packed != nullptr && h->n_packed == h->n);
+        if (binary) {
+            if (!(h->packed_only || (h->packed != nullptr && h->n_packed == h->n))) return false;
+            return !bin_mfma_eligible(h, metric, filtered, std::min<uint64_t>(nq, QCHUNK)) || (h->bpm && h->n_bpm == h->n);   // (the +-1 copy is a lazy build too)
+        }
         if (h->packed_only) return true;  // (rejected below)
         if (h->n_stats != h->n || (scan_variant() == 3 && (h->n16 != h->n || h->sv16 != h->sv))) return false;
         return !i8c_eligible(h, metric, filtered, std::min<uint64_t>(nq, QCHUNK), caller_holds_exclusive) || (h->sq8 && h->n_sq8 == h->n);
@@ -1945,8 +2001,12 @@ static int search_impl(lynse_hip_flat* h, const void* q_src, bool packed_queries
         return set_error(LYNSE_ERR_UNSUPPORTED, "k > cap/4 over more than cap rows is not supported together with a subset filter");
     // (rows wider than 4096 bits run on k_scan_binary_wide: no LDS tile, no register-resident words)
 
-    if (binary) LY_TRY(ensure_packed_locked(h));
-    else LY_TRY(finalize_locked(h));
+    if (binary) {
+        LY_TRY(ensure_packed_locked(h));
+        if (xlk.owns_lock() && bin_mfma_eligible(h, metric, filtered, std::min<uint64_t>(nq, QCHUNK))) LY_TRY(ensure_bpm_locked(h));
+    } else {
+        LY_TRY(finalize_locked(h));
+    }
     LY_TRY(ensure_workspace(h, k));
     Workspace& w = cur(h).ws;
     hipStream_t st0 = user_stream ? user_stream : cur(h).stream;
@@ -2179,6 +2239,8 @@ extern "C" int lynse_hip_flat_coarse_state(lynse_hip_flat* h, int* out_strikes, 
     if (out_sq8_rows) *out_sq8_rows = h->sq8 ? h->n_sq8 : 0;
     return LYNSE_OK;
 }
+
+extern "C" uint64_t lynse_hip_flat_bpm_rows(const lynse_hip_flat* h) { return (h && h->bpm) ? h->n_bpm : 0; }
 
 // Large k: the shard is cut into row ranges of `cap` rows (any k <= range size is exact there: emit-all + select), every
 // range is searched through a temporary VIEW of the handle (pointers advanced to the range, row map offset), and the sorted
@@ -2454,7 +2516,7 @@ extern "C" int lynse_hip_top_k_search(const float* query, const float* candidate
     lynse_hip_flat* h = sc.h;
     {   // empty the shard (capacity and buffers stay)
         std::unique_lock<std::shared_mutex> lk(h->rw);
-        h->n = 0; h->n_stats = 0; h->n16 = 0; h->n_packed = 0; h->n_sq8 = 0; h->i8c_strikes.store(0);
+        h->n = 0; h->n_stats = 0; h->n16 = 0; h->n_packed = 0; h->n_sq8 = 0; h->n_bpm = 0; h->i8c_strikes.store(0);
         h->amax = h->vmax = h->vmin = 0.f; h->sv = 1.f; h->cos_degenerate = 0;
         const uint32_t init[4] = {0u, 0u, 0x7f800000u, 0u};
         LY_TRY(use_device(h));

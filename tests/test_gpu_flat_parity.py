@@ -632,3 +632,32 @@ def test_sharded_search_entry_point_with_a_one_rank_communicator(L, oracle):
         for qi in (0, 7, nq - 1):
             e_ids, e_d = oracle.canonical_topk(queries[qi], data, k, metric)
             assert np.array_equal(rows[qi].astype(np.uint32), e_ids) and np.array_equal(dists[qi].view(np.uint32), e_d.view(np.uint32))
+
+
+@pytest.mark.parametrize("n,bits,nq,k,p_one", [(200_000, 1024, 256, 50, 0.5), (150_000, 200, 130, 10, 0.3), (70_000, 64, 100, 64, 0.5),
+                                              (300_000, 1152, 97, 5, 0.1)])
+def test_batched_hamming_on_the_matrix_pipe_equals_the_popcount_kernels(L, oracle, n, bits, nq, k, p_one):
+    """Hamming batches of >= 96 queries run as an exact +-1 int8 GEMM on the MFMA (popcount(x ^ q) = (D - dot) / 2, strict
+    cut, no rescoring; packed_binary_search, flat_mmap.rs:1345-1409).  Same ids and distances as the oracle and as the
+    popcount kernels a small batch takes — widths that are no multiple of 128 (ragged last slab), narrow rows with huge tie
+    groups at the k-th distance, sparse rows."""
+    from lynsedb_amd.datasets import packed_bernoulli
+
+    words = packed_bernoulli(n, bits, p_one, 100 + bits)
+    if bits % 64:
+        words[:, -1] &= np.uint64((1 << (bits % 64)) - 1)
+    idx = L.FlatIndex(None, bits)
+    idx.write_packed(words)
+    idx.finalize()
+    rng = np.random.default_rng(bits)
+    qw = words[rng.integers(0, n, nq)].copy()
+    qw[:, 0] ^= np.uint64(0x5A5A)
+    rows, dists, counts = idx.search_packed_arrays(qw, k, "hamming")          # MFMA path
+    r_small = [idx.search_packed_arrays(qw[i:i + 32], k, "hamming") for i in range(0, nq, 32)]   # <= 32 queries: popcount kernels
+    rs = np.concatenate([r[0] for r in r_small]); ds = np.concatenate([r[1] for r in r_small]); cs = np.concatenate([r[2] for r in r_small])
+    assert np.array_equal(rows, rs) and np.array_equal(dists.view(np.uint32), ds.view(np.uint32)) and np.array_equal(counts, cs)
+    for qi in sorted({0, nq // 2, nq - 1}):
+        e_ids, e_d = oracle.canonical_topk_packed(qw[qi], words, k, O.HAMMING)
+        c = int(counts[qi])
+        assert c == len(e_ids) and np.array_equal(rows[qi, :c].astype(np.uint32), e_ids) and np.array_equal(dists[qi, :c], e_d), qi
+    assert idx.coarse_state()["bpm_rows"] == n                                 # the +-1 copy was built: the MFMA path ran
