@@ -194,3 +194,26 @@ def test_sq8_two_pass_parity(L, oracle, metric, name, n, dim, nq, k, kind):
     for qi in range(2):
         e_ids, e_d = oracle.sq8_search(queries[qi], both, mins2, scales2, codes2, k, metric)
         assert np.array_equal(rows[qi, :len(e_ids)].astype(np.uint32), e_ids) and np.array_equal(dists[qi, :len(e_ids)].view(np.uint32), e_d.view(np.uint32))
+
+
+def test_hand_assembled_reference_layout_opens_and_searches(L, oracle, tmp_path, golden_dir):
+    """The hand-assembled directory of tests/golden/reference_layout_fixture.json (see tests/test_storage_formats.py) opened
+    into an HBM shard: searches equal the oracle's over the rows the fixture's closed form defines; ids go through id_map.bin."""
+    from test_storage_formats import _materialise_reference_layout
+
+    fx = _materialise_reference_layout(tmp_path, golden_dir)
+    dim, n = fx["dim"], fx["rows"]
+    idx, id_map, m = S.open_flat_collection(tmp_path, dim)
+    assert len(idx) == n and len(m.segments) == 3
+    want = np.array([[((r * 37 + d * 11) % 101 - 50) * 0.125 for d in range(dim)] for r in range(n)], f32)
+    rng = np.random.default_rng(8)
+    for name, metric in (("ip", O.IP), ("l2", O.L2), ("cosine", O.COS)):
+        for _ in range(3):
+            q = rng.standard_normal(dim).astype(f32)
+            ids, d = idx.search(q, 7, name)
+            e_ids, e_d = oracle.canonical_topk(q, want, 7, metric)
+            assert np.array_equal(ids, e_ids) and np.array_equal(d.view(np.uint32), e_d.view(np.uint32))
+    ids, _ = idx.search(want[59], 2, "l2")
+    assert ids[0] == 59 and S.rows_to_user_ids(ids[:1], id_map).tolist() == [10_000_000_177]
+    ids, _ = idx.search(want[92], 1, "l2")
+    assert S.rows_to_user_ids(ids, id_map).tolist() == [92]              # past the end of the map: the row itself

@@ -123,3 +123,38 @@ def test_open_ivf_flat_reports_a_short_data_file(tmp_path):  # ivf_flat_mmap.rs:
     data.write_bytes(np.zeros(4 * 3, "<f4").tobytes())   # 4 rows instead of 5
     with pytest.raises(IOError, match="shorter than its metadata"):
         S.open_ivf_flat(data)
+
+
+def _materialise_reference_layout(tmp_path, golden_dir):
+    import json
+
+    fx = json.loads((golden_dir / "reference_layout_fixture.json").read_text())
+    for rel, hx in fx["files"].items():
+        f = tmp_path / rel
+        f.parent.mkdir(parents=True, exist_ok=True)
+        f.write_bytes(bytes.fromhex(hx))
+    return fx
+
+
+def test_hand_assembled_reference_layout_is_read_byte_for_byte(tmp_path, golden_dir):
+    """A collection directory assembled BY HAND from the reference's struct definitions and serde_json's pretty format
+    (tests/golden/make_reference_layout_fixture.py: vector_store.rs:24-66, :294-298, :370-445; engine.rs:2588-2617) — not by this
+    package's writer: manifest field order / segment naming after three appends / raw LE f32 rows / a torn trailing append /
+    a short id map with stray bytes."""
+    fx = _materialise_reference_layout(tmp_path, golden_dir)
+    dim, n = fx["dim"], fx["rows"]
+    m = S.load_manifest(tmp_path, dim)
+    assert (m.version, m.generation, m.id_map_file) == (1, 3, "id_map.bin")
+    assert [s.file for s in m.segments] == ["vectors.bin", "vector_segments/seg-00000000000000000002-000001.bin",
+                                            "vector_segments/seg-00000000000000000003-000002.bin"]
+    assert [s.rows for s in m.segments] == fx["segment_rows"]            # the 7 torn bytes of the last segment are ignored
+    got = np.concatenate([rows for _, rows in S.read_segments(tmp_path, dim)])
+    want = np.array([[((r * 37 + d * 11) % 101 - 50) * 0.125 for d in range(dim)] for r in range(n)], np.float32)
+    assert got.shape == (n, dim) and np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    ids = S.load_id_map(tmp_path / m.id_map_file)
+    assert ids.dtype == np.uint64 and ids.tolist() == fx["mapped_ids"]   # 3 stray bytes ignored
+    assert S.rows_to_user_ids(np.array([0, 59, 60, 92]), ids).tolist() == [10_000_000_000, 10_000_000_177, 60, 92]
+    # and this package's own writer, continuing the SAME directory, names the next segment as the reference would
+    S.write_flat_collection(tmp_path, [np.zeros((50, dim), np.float32)], segment_target_bytes=1024)
+    m2 = S.load_manifest(tmp_path, dim)
+    assert m2.generation == 4 and m2.segments[-1].file == "vector_segments/seg-00000000000000000004-000003.bin"
