@@ -200,6 +200,12 @@ int lynse_hip_flat_coarse_state(lynse_hip_flat *h, int *out_strikes, uint64_t *o
 /* Rows covered by the +-1 byte copy of the packed rows that feeds batched Hamming searches (>= 96 queries) to the int8 MFMA
  * (packed_binary_search for a batch, flat_mmap.rs:1345-1409); 0 = not built (diagnostics / tests). */
 uint64_t lynse_hip_flat_bpm_rows(const lynse_hip_flat *h);
+/* Builds the derived copies a batch of nq queries of `metric` will read NOW instead of inside the first such search
+ * (the reference's ensure_binary / ensure_sq8 are lazy as well, flat_mmap.rs:375-401): statistics + f16 shadow, SQ8 codes of
+ * the certified int8 pass, packed words, the +-1 byte copy of batched Hamming.  lynse_hip_flat_hbm_bytes: HBM held by the
+ * shard, source rows + derived copies. */
+int lynse_hip_flat_prepare(lynse_hip_flat *h, int metric, uint64_t nq);
+uint64_t lynse_hip_flat_hbm_bytes(const lynse_hip_flat *h);
 /* Tuning knobs (defaults are fine): first-stage rows and growth factor of the contiguous stage plan (the fallback of the
  * default sampled plan), candidate capacity per query (power of two in [256, 16384], default 16384; k <= cap / 4 when the
  * shard holds more than cap rows). */

@@ -76,6 +76,8 @@ SIGNATURES = {
     "lynse_hip_flat_profile_get": (C.c_int, [_vp, C.POINTER(Profile), C.c_int]),
     "lynse_hip_flat_coarse_state": (C.c_int, [_vp, C.POINTER(C.c_int), _u64p]),
     "lynse_hip_flat_bpm_rows": (C.c_uint64, [_vp]),
+    "lynse_hip_flat_prepare": (C.c_int, [_vp, C.c_int, C.c_uint64]),
+    "lynse_hip_flat_hbm_bytes": (C.c_uint64, [_vp]),
     "lynse_hip_flat_set_fused_search": (C.c_int, [_vp, C.c_int]),
     "lynse_hip_flat_set_plan": (C.c_int, [_vp, C.c_uint32, C.c_uint32, C.c_uint32]),
     "lynse_hip_compute_distance": (C.c_int, [_vp, _vp, C.c_uint32, C.c_int, C.c_int, _f32p]),

@@ -332,6 +332,14 @@ class FlatIndex:
         check(lib.lynse_hip_flat_profile_get(self._h, C.byref(p), 1 if reset else 0))
         return {f: getattr(p, f) for f, _ in _lib.Profile._fields_}
 
+    def prepare(self, metric, nq: int = 256) -> None:
+        """Build the derived copies a batch of `nq` queries of `metric` reads now (SQ8 codes, +-1 bytes, packed words, shadow)."""
+        m = metric if isinstance(metric, int) else metric_from_str(metric)
+        check(lib.lynse_hip_flat_prepare(self._h, m, int(nq)))
+
+    def hbm_bytes(self) -> int:
+        return int(lib.lynse_hip_flat_hbm_bytes(self._h))
+
     def coarse_state(self) -> dict:
         """State of the coarse-pass selection: overflow strikes of the certified int8 pass (3 = switched off, -1 = off because the
         rows are not finite) and the rows covered by the SQ8 codes built so far."""

@@ -2242,6 +2242,45 @@ extern "C" int lynse_hip_flat_coarse_state(lynse_hip_flat* h, int* out_strikes, 
 
 extern "C" uint64_t lynse_hip_flat_bpm_rows(const lynse_hip_flat* h) { return (h && h->bpm) ? h->n_bpm : 0; }
 
+// Builds — now, not inside the first search that needs it — every derived copy a batch of `nq` queries of `metric` will read:
+// row statistics + f16 shadow (float metrics), the SQ8 codes of the certified int8 pass (IP batches of 33..256 queries over
+// >= 64K rows), the packed words (binary metrics from f32 rows) and the +-1 byte copy of batched Hamming (>= 96 queries).
+// The reference builds its own derived data lazily too (ensure_binary / ensure_sq8, flat_mmap.rs:375-401); a server calls
+// this after a bulk load so that the first query does not pay for it under the writer lock.
+extern "C" int lynse_hip_flat_prepare(lynse_hip_flat* h, int metric, uint64_t nq) {
+    if (!h) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "handle is NULL");
+    if (!metric_valid(metric)) return set_error(LYNSE_ERR_UNKNOWN_METRIC, "Unknown metric id");
+    LY_WRITER(h, lk);
+    LY_TRY(use_device(h));
+    if (h->n == 0) return LYNSE_OK;
+    const uint64_t nqc = std::min<uint64_t>(std::max<uint64_t>(nq, 1), QCHUNK);
+    if (metric >= M_HAMMING) {
+        LY_TRY(ensure_packed_locked(h));
+        if (bin_mfma_eligible(h, metric, false, nqc)) LY_TRY(ensure_bpm_locked(h));
+        return LYNSE_OK;
+    }
+    if (h->packed_only) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "store holds packed rows; float metrics unavailable");
+    LY_TRY(finalize_locked(h));
+    if (i8c_eligible(h, metric, false, nqc)) {
+        LY_TRY(ensure_sq8_locked(h));
+        if (!h->sq8_finite) h->i8c_strikes.store(-1);
+    }
+    return LYNSE_OK;
+}
+
+// Bytes of HBM the shard holds: source rows + every derived copy built so far (search workspaces not included).
+extern "C" uint64_t lynse_hip_flat_hbm_bytes(const lynse_hip_flat* h) {
+    if (!h) return 0;
+    uint64_t b = 0;
+    if (h->rows) b += h->capacity * h->ld * 4ull;
+    if (h->rows16) b += h->cap16 * h->ld16 * 2ull;
+    if (h->vn2) b += 2ull * (h->stats_capacity + 256) * 4;
+    if (h->packed) b += h->packed_capacity * h->words * 8ull;
+    if (h->sq8) b += h->sq8_cap * h->ld8 + 2ull * (h->sq8_cap + 256) * 4;
+    if (h->bpm) b += h->bpm_cap * h->ld8;
+    return b;
+}
+
 // Large k: the shard is cut into row ranges of `cap` rows (any k <= range size is exact there: emit-all + select), every
 // range is searched through a temporary VIEW of the handle (pointers advanced to the range, row map offset), and the sorted
 // per-range lists are merged on the host in the canonical (distance, row) order (VectorStore::merge_results semantics,
