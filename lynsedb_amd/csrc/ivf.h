@@ -370,4 +370,49 @@ __global__ void __launch_bounds__(256) k_ivf_score_positions(IvfScoreArgs a) {
     }
 }
 
+
+// Packed-binary twin of k_ivf_score_positions: the distance of every listed slab position to ONE packed query (Hamming /
+// Jaccard = Tanimoto / Dice, as k_scan_binary_wide), 8 lanes per row striding over the words — any width.
+struct IvfScorePackedArgs {
+    const uint64_t* P;
+    uint32_t W;
+    const uint64_t* qw;
+    const uint32_t* pos;
+    const uint32_t* orig;
+    uint32_t n;
+    int kind;   // 0 hamming, 1 jaccard / tanimoto, 2 dice
+    uint64_t* keys;
+};
+
+__global__ void __launch_bounds__(256) k_ivf_score_positions_packed(IvfScorePackedArgs a) {
+    const int g = threadIdx.x & 7;
+    const uint32_t bound = (a.n + 31u) / 32u * 32u;
+    for (uint32_t i = blockIdx.x * 32u + (threadIdx.x >> 3); i < bound; i += gridDim.x * 32u) {
+        const uint32_t p = a.pos[i < a.n ? i : a.n - 1];
+        const uint64_t* rp = a.P + (size_t)p * a.W;
+        uint32_t c0 = 0, c1 = 0;
+        for (uint32_t w = g; w < a.W; w += 8) {
+            const uint64_t x = a.qw[w], r = rp[w];
+            if (a.kind == 0) {
+                c0 += __popcll(x ^ r);
+            } else if (a.kind == 1) {
+                c0 += __popcll(x & r);
+                c1 += __popcll(x | r);
+            } else {
+                c0 += __popcll(x & r);
+                c1 += __popcll(x) + __popcll(r);
+            }
+        }
+        c0 += __shfl_xor(c0, 1, 8); c0 += __shfl_xor(c0, 2, 8); c0 += __shfl_xor(c0, 4, 8);
+        c1 += __shfl_xor(c1, 1, 8); c1 += __shfl_xor(c1, 2, 8); c1 += __shfl_xor(c1, 4, 8);
+        if (g == 0 && i < a.n) {
+            float dist;
+            if (a.kind == 0) dist = (float)c0;
+            else if (a.kind == 1) dist = c1 == 0 ? 0.0f : __fsub_rn(1.0f, __fdiv_rn((float)c0, (float)c1));
+            else dist = c1 == 0 ? 0.0f : __fsub_rn(1.0f, __fdiv_rn((float)(2u * c0), (float)c1));
+            a.keys[i] = make_key(dist, a.orig[p], true);
+        }
+    }
+}
+
 }  // namespace lynse

@@ -568,3 +568,37 @@ def test_ivf_any_k_up_to_max_top_k(L, oracle, metric):
             c = int(g_c[qi])
             assert c == len(e_ids), (k, npr, qi, c, len(e_ids))
             assert np.array_equal(g_rows[qi, :c], e_ids) and np.array_equal(g_d[qi, :c].view(np.uint32), e_d.view(np.uint32)), (k, npr, qi)
+
+
+def test_ivf_any_k_with_a_subset_and_wide_binary_rows(L, oracle):
+    """The exact-scoring IVF path (k beyond the staged pipeline's capacity, or packed rows wider than 4096 bits) with
+    SearchParams.subset (ivf.rs:251-265) and for the IVF-HAMMING-BINARY mode (quantizer -> L2 routing on the codes -> popcount)."""
+    rng = np.random.default_rng(808)
+    # float index, k = 6000 within a 40 % subset
+    n, dim, nlist, nprobe, k = 40_000, 24, 12, 6, 6_000
+    data = rng.standard_normal((n, dim)).astype(f32)
+    cen, asg, off, rows = oracle_ivf(oracle, data, nlist, L2, iters=3)
+    idx = L.IvfFlatIndex.load(data, cen, asg, "l2")
+    subset = np.sort(rng.choice(n, n * 2 // 5, replace=False)).astype(np.uint64)
+    q = rng.standard_normal((2, dim)).astype(f32)
+    g_rows, g_d, g_c = idx.search_filtered_batch_arrays(q, k, nprobe, subset)
+    for qi in range(2):
+        e_ids, e_d = oracle.ivf_search_filtered(q[qi], data, cen, off, rows, nprobe, k, L2, subset)
+        c = int(g_c[qi])
+        assert c == len(e_ids) and np.array_equal(g_rows[qi, :c], e_ids) and np.array_equal(g_d[qi, :c].view(np.uint32), e_d.view(np.uint32)), qi
+    # binary index over 4160-bit codes (wider than the tiled popcount kernel's 4096) and k = 5000 on a narrow one
+    for n, dim, nlist, nprobe, k in ((3_000, 4160, 8, 3, 10), (30_000, 64, 8, 6, 5_000)):
+        data = (rng.standard_normal((n, dim)) + 0.3).astype(f32)
+        ab, thr = oracle.binary_fit(data)
+        enc = oracle.binary_quantize(data, thr)
+        packed = oracle.pack_binary(enc)
+        cen, asg = oracle.kmeans_train(enc, nlist, 4, O.L2)
+        off, rows = oracle.lists_from_assignments(asg, cen.shape[0])
+        idx = L.IvfFlatIndex.load(data, cen, asg, "hamming", thresholds=thr)
+        queries = data[rng.integers(0, n, 3)].copy()
+        g_rows, g_d, g_c = idx.search_batch_arrays(queries, k, nprobe)
+        for qi in range(3):
+            eq = oracle.binary_quantize(queries[qi], thr)[0]
+            e_ids, e_d, _ = oracle.ivf_search(eq, enc, cen, off, rows, nprobe, k, O.HAMMING, packed=packed)
+            c = int(g_c[qi])
+            assert c == len(e_ids) and np.array_equal(g_rows[qi, :c], e_ids) and np.array_equal(g_d[qi, :c].view(np.uint32), e_d.view(np.uint32)), (dim, qi)
