@@ -44,25 +44,28 @@ __device__ __forceinline__ float hsum8(float a) {
 // f16 storage (VectorDtype::F16): simd::inner_product_f16 / l2_squared_f16 / cosine_distance_f16 (simd.rs:805-846) are
 // plain sequential f32 sums over the decoded row, separate multiply and add.  One lane does the chain, the 8-lane
 // group gets the result.
-__device__ __forceinline__ float exact_score_f16seq(int metric, const float* __restrict__ q, const float* __restrict__ v,
+// An F16 shard keeps its rows as f16 bits only (no f32 decode in HBM): `v` points at the row's HALVES (callers hand the f16
+// row matrix in as float* with a pitch of ld16 / 2 floats — LYNSE_IPFORM_F16SEQ implies it); the decode f16 -> f32 is exact.
+__device__ __forceinline__ float exact_score_f16seq(int metric, const float* __restrict__ q, const float* __restrict__ v_as_f32,
                                                     uint32_t D, int g) {
+    const _Float16* __restrict__ v = reinterpret_cast<const _Float16*>(v_as_f32);
     float r = 0.0f;
     if (g == 0) {
         if (metric == M_IP) {
             float sum = 0.0f;
-            for (uint32_t i = 0; i < D; ++i) sum = __fadd_rn(sum, __fmul_rn(q[i], v[i]));
+            for (uint32_t i = 0; i < D; ++i) sum = __fadd_rn(sum, __fmul_rn(q[i], (float)v[i]));
             r = sum;
         } else if (metric == M_L2) {
             float sum = 0.0f;
             for (uint32_t i = 0; i < D; ++i) {
-                const float d = __fsub_rn(q[i], v[i]);
+                const float d = __fsub_rn(q[i], (float)v[i]);
                 sum = __fadd_rn(sum, __fmul_rn(d, d));
             }
             r = sum;
         } else {
             float dot = 0.0f, nq = 0.0f, nc = 0.0f;
             for (uint32_t i = 0; i < D; ++i) {
-                const float a = q[i], c = v[i];
+                const float a = q[i], c = (float)v[i];
                 dot = __fadd_rn(dot, __fmul_rn(a, c));
                 nq = __fadd_rn(nq, __fmul_rn(a, a));
                 nc = __fadd_rn(nc, __fmul_rn(c, c));
@@ -231,7 +234,8 @@ __device__ __forceinline__ float exact_score(int metric, int ip_form, const floa
 // parameterise the certified f16 error margin.  One wave per row.
 // stats[0]=bits(max|v|) stats[1]=bits(max n2) stats[2]=bits(min nonzero n2) stats[3]=#rows with 0<n2<1e-30
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_row_stats(const float* __restrict__ V, uint32_t ld, uint32_t D,
+template <typename T>  // float rows, or the f16 bits of an F16 shard
+__global__ void __launch_bounds__(256) k_row_stats(const T* __restrict__ V, uint32_t ld, uint32_t D,
                                                    uint32_t row0, uint32_t row1, float* __restrict__ vn2,
                                                    float* __restrict__ vrinv, uint32_t* __restrict__ stats) {
     const int lane = threadIdx.x & 63;
@@ -240,10 +244,10 @@ __global__ void __launch_bounds__(256) k_row_stats(const float* __restrict__ V, 
     float amax = 0.0f, n2max = 0.0f, n2min = LY_INF;
     uint32_t ndegen = 0;
     for (uint32_t row = row0 + wave; row < row1; row += nwaves) {
-        const float* v = V + (size_t)row * ld;
+        const T* v = V + (size_t)row * ld;
         float s = 0.0f;
         for (uint32_t i = lane; i < D; i += 64) {
-            float x = v[i];
+            float x = (float)v[i];
             s = __fmaf_rn(x, x, s);
             amax = fmaxf(amax, fabsf(x));
         }
@@ -286,16 +290,17 @@ __global__ void __launch_bounds__(256) k_copy_rows(float* __restrict__ dst, uint
 // k_pack_bits: bit i of word i/64 = (value > 0.5), LSB first — pack_binary_row_f32
 // (flat_mmap.rs:1284-1290, simd.rs:750-757).  One wave per row; wave64 __ballot IS one u64 word.
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_pack_bits(const float* __restrict__ V, uint32_t ld, uint32_t D,
+template <typename T>
+__global__ void __launch_bounds__(256) k_pack_bits(const T* __restrict__ V, uint32_t ld, uint32_t D,
                                                    uint32_t nrows, uint64_t* __restrict__ out, uint32_t W) {
     const int lane = threadIdx.x & 63;
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
     for (uint32_t row = wave; row < nrows; row += nwaves) {
-        const float* v = V + (size_t)row * ld;
+        const T* v = V + (size_t)row * ld;
         for (uint32_t w = 0; w < W; ++w) {
             uint32_t i = w * 64 + lane;
-            bool bit = (i < D) && (v[i] > 0.5f);
+            bool bit = (i < D) && ((float)v[i] > 0.5f);
             uint64_t m = __ballot(bit);
             if (lane == 0) out[(size_t)row * W + w] = m;
         }
@@ -1026,6 +1031,27 @@ __global__ void __launch_bounds__(WQ * WR * 64, (WQ * WR >= 8) ? (WQ * WR / 4) :
 #endif  // LYNSE_EXPERIMENTS
 
 // f16 storage: rows [r0,r1) <- f16::to_f32(f16::from_f32(row)) in place (encode_f32_slice_as_le_bytes F16, RNE)
+// F16 shards: f32 rows in -> f16 bits (RNE, what an F16 segment file keeps: src/storage/dtype.rs, flat_mmap.rs:187-221),
+// pitch ld16 halves with zero pad columns; and the exact decode back for the row readers.
+__global__ void __launch_bounds__(256) k_f32_to_f16_rows(_Float16* __restrict__ dst, uint32_t ld16, const float* __restrict__ src,
+                                                         uint32_t src_pitch, uint32_t width, uint64_t nrows) {
+    const uint64_t total = nrows * ld16;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t r = i / ld16;
+        const uint32_t c = (uint32_t)(i % ld16);
+        dst[i] = c < width ? (_Float16)src[r * src_pitch + c] : (_Float16)0.0f;
+    }
+}
+__global__ void __launch_bounds__(256) k_f16_to_f32_rows(float* __restrict__ dst, uint32_t dst_pitch, const _Float16* __restrict__ src,
+                                                         uint32_t ld16, uint32_t width, uint64_t nrows) {
+    const uint64_t total = nrows * width;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t r = i / width;
+        const uint32_t c = (uint32_t)(i % width);
+        dst[r * dst_pitch + c] = (float)src[r * ld16 + c];
+    }
+}
+
 __global__ void __launch_bounds__(256) k_round_rows_f16(float* __restrict__ V, uint32_t ld, uint32_t D, uint64_t r0, uint64_t r1) {
     const uint64_t total = (r1 - r0) * D;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
@@ -1039,17 +1065,18 @@ __global__ void __launch_bounds__(256) k_round_rows_f16(float* __restrict__ V, u
 // RNE — bit for bit the conversion k_scan_glds does in flight, done once per appended row at finalize.
 // One thread per 8 output halves (16 B); columns [D, ld16) are zero.
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_rows_to_f16(const float* __restrict__ V, uint32_t ld, uint32_t D, uint64_t r0,
+template <typename T>
+__global__ void __launch_bounds__(256) k_rows_to_f16(const T* __restrict__ V, uint32_t ld, uint32_t D, uint64_t r0,
                                                      uint64_t r1, float sv, _Float16* __restrict__ out, uint32_t ld16) {
     const uint32_t cpr = ld16 / 8;  // 16-B chunks per row
     const uint64_t total = (r1 - r0) * cpr;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
         const uint64_t r = r0 + i / cpr;
         const uint32_t c0 = (uint32_t)(i % cpr) * 8;
-        const float* src = V + r * ld + c0;
+        const T* src = V + r * ld + c0;
         half8 h;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) h[e] = (c0 + e < D) ? (_Float16)(src[e] * sv) : (_Float16)0.0f;
+        for (int e = 0; e < 8; ++e) h[e] = (c0 + e < D) ? (_Float16)((float)src[e] * sv) : (_Float16)0.0f;
         *reinterpret_cast<half8*>(out + r * ld16 + c0) = h;
     }
 }

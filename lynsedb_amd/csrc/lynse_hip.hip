@@ -202,7 +202,12 @@ struct lynse_hip_flat {
     std::atomic<int> inflight{0};        // tickets of lynse_hip_flat_search_submit_* not yet waited for (async_host.inc)
 
     uint64_t n = 0, capacity = 0;
-    float* rows = nullptr;       // capacity x ld f32, row-major (pad columns zero)
+    float* rows = nullptr;       // capacity x ld f32, row-major (pad columns zero); nullptr for an F16 shard
+    // VectorDtype::F16 shards (src/storage/dtype.rs, flat_mmap.rs:187-221) keep their rows as f16 bits ONLY: capacity x ld16
+    // halves, pad columns zero — the bytes of an F16 segment file, the source of every exact score (sequential f32 sums over
+    // the exactly decoded halves, simd.rs:805-846).  With sv == 1 the coarse-pass shadow rows16 is this very buffer.
+    _Float16* rows_h = nullptr;
+    bool shadow_alias = false;   // rows16 == rows_h (not separately owned)
     // f16 shadow of the rows for the coarse scan (k_scan_h16): (half)(v * sv16), pitch ld16 halves, built at finalize
     _Float16* rows16 = nullptr;
     uint32_t ld16 = 0;
@@ -260,6 +265,12 @@ struct lynse_hip_flat {
     std::atomic<uint32_t> prof_seq{0};
     lynse_hip_profile prof{};
 };
+
+static inline bool is_f16(const lynse_hip_flat* h) { return h->dtype == LYNSE_DTYPE_F16; }
+// the row matrix the exact-scoring kernels read: f32 rows, or the f16 bits of an F16 shard handed in as float* with a pitch
+// of ld16 / 2 floats (exact_score_f16seq turns the pointer back; LYNSE_IPFORM_F16SEQ goes with it)
+static inline const float* score_rows(const lynse_hip_flat* h) { return is_f16(h) ? reinterpret_cast<const float*>(h->rows_h) : h->rows; }
+static inline uint32_t score_ld(const lynse_hip_flat* h) { return is_f16(h) ? h->ld16 / 2 : h->ld; }
 
 static thread_local bool tl_prof = false;   // the search running on this thread records profile events (profile_begin_search)
 static thread_local int tl_ctx_slot = 0;   // the search context of the calling thread (0 outside a concurrent search)
@@ -381,7 +392,8 @@ extern "C" int lynse_hip_flat_destroy(lynse_hip_flat* h) {
         c.ws.release();
         for (auto e : c.ev_pool) (void)hipEventDestroy(e);
     }
-    for (void* p : {(void*)h->rows, (void*)h->rows16, (void*)h->packed, (void*)h->vn2, (void*)h->vrinv, (void*)h->d_stats,
+    if (h->shadow_alias) h->rows16 = nullptr;
+    for (void* p : {(void*)h->rows, (void*)h->rows_h, (void*)h->rows16, (void*)h->packed, (void*)h->vn2, (void*)h->vrinv, (void*)h->d_stats,
                     (void*)h->d_mask, (void*)h->d_subset, (void*)h->g_rows16, (void*)h->g_vn2, (void*)h->g_vrinv, (void*)h->g_ids32,
                     (void*)h->bpm, (void*)h->sq8, (void*)h->sq8_mins, (void*)h->sq8_scales, (void*)h->sq8_sum, (void*)h->sq8_sum2, (void*)h->sq8_mm, (void*)h->sq8_stats})
         if (p) (void)hipFree(p);
@@ -391,10 +403,24 @@ extern "C" int lynse_hip_flat_destroy(lynse_hip_flat* h) {
     return LYNSE_OK;
 }
 
+static int realloc_rows_h(lynse_hip_flat* h, uint64_t cap) {   // F16 shard: capacity of the f16 row matrix
+    _Float16* nr = nullptr;
+    LY_HIP(hipMalloc(&nr, (size_t)cap * h->ld16 * sizeof(_Float16) + 256));
+    if (h->rows_h && h->n)
+        LY_HIP(hipMemcpyAsync(nr, h->rows_h, (size_t)h->n * h->ld16 * sizeof(_Float16), hipMemcpyDeviceToDevice, cur(h).stream));
+    LY_HIP(hipStreamSynchronize(cur(h).stream));
+    if (h->rows_h) (void)hipFree(h->rows_h);
+    h->rows_h = nr;
+    h->capacity = cap;
+    if (h->shadow_alias) { h->rows16 = h->rows_h; h->cap16 = cap; }
+    return LYNSE_OK;
+}
+
 static int grow_rows(lynse_hip_flat* h, uint64_t need) {
     if (need <= h->capacity) return LYNSE_OK;
     uint64_t cap = std::max<uint64_t>(need, h->capacity + h->capacity / 2);
     cap = std::max<uint64_t>(cap, 1024);
+    if (is_f16(h)) return realloc_rows_h(h, cap);
     float* nr = nullptr;
     LY_HIP(hipMalloc(&nr, (size_t)cap * h->ld * sizeof(float)));
     if (h->rows && h->n)
@@ -427,6 +453,7 @@ extern "C" int lynse_hip_flat_reserve(lynse_hip_flat* h, uint64_t rows) {
     LY_TRY(use_device(h));
     if (rows > 0xfffffff0ull) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "row count exceeds the u32 id capacity of one shard");
     if (h->packed_only) return grow_packed(h, rows);
+    if (rows > h->capacity && is_f16(h)) return realloc_rows_h(h, rows);
     if (rows > h->capacity) {
         // exact reservation (no 1.5x slack): callers reserve to size a shard to its HBM budget
         float* nr = nullptr;
@@ -450,6 +477,15 @@ static int copy_rows_kernel(lynse_hip_flat* h, float* dst, uint32_t dp, const fl
     return LYNSE_OK;
 }
 
+// F16 shard: rows [first, first + n) decoded to f32 (exact) into dst (pitch dp floats)
+static int decode_rows_kernel(lynse_hip_flat* h, float* dst, uint32_t dp, uint64_t first, uint64_t n) {
+    const uint64_t total = n * h->dim;
+    hipLaunchKernelGGL(k_f16_to_f32_rows, dim3((uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((total + 255) / 256, (uint64_t)h->num_cu * 32))), dim3(256), 0,
+                       cur(h).stream, dst, dp, h->rows_h + (size_t)first * h->ld16, h->ld16, h->dim, n);
+    LY_HIP(hipGetLastError());
+    return LYNSE_OK;
+}
+
 constexpr uint64_t STAGE_BYTES = 64ull << 20;  // dense staging buffer for padded-layout host transfers
 
 static int append_f32_impl(lynse_hip_flat* h, const float* src, uint64_t n, hipMemcpyKind kind) {
@@ -461,6 +497,35 @@ static int append_f32_impl(lynse_hip_flat* h, const float* src, uint64_t n, hipM
     if (h->packed_only) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "store holds packed rows; cannot append f32 rows");
     if (h->n + n > 0xfffffff0ull) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "row count exceeds the u32 id capacity of one shard");
     LY_TRY(grow_rows(h, h->n + n));
+    if (is_f16(h)) {
+        // f32 in (host or device) -> f16 bits (RNE): device rows are converted in place, host rows through a staging buffer
+        _Float16* dsth = h->rows_h + (size_t)h->n * h->ld16;
+        auto convert = [&](const float* d_src, uint64_t nr, uint64_t r) -> int {
+            const uint64_t total = nr * h->ld16;
+            hipLaunchKernelGGL(k_f32_to_f16_rows, dim3((uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((total + 255) / 256, (uint64_t)h->num_cu * 32))), dim3(256), 0,
+                               cur(h).stream, dsth + r * h->ld16, h->ld16, d_src, h->dim, h->dim, nr);
+            LY_HIP(hipGetLastError());
+            return LYNSE_OK;
+        };
+        if (kind == hipMemcpyDeviceToDevice) {
+            LY_TRY(convert(src, n, 0));
+        } else {
+            const uint64_t chunk = std::max<uint64_t>(1, STAGE_BYTES / ((uint64_t)h->dim * 4));
+            float* stage = nullptr;
+            LY_HIP(hipMalloc(&stage, (size_t)std::min<uint64_t>(chunk, n) * h->dim * 4));
+            for (uint64_t r = 0; r < n; r += chunk) {
+                const uint64_t nr = std::min<uint64_t>(chunk, n - r);
+                int rc = hipMemcpyAsync(stage, src + r * h->dim, (size_t)nr * h->dim * 4, kind, cur(h).stream) == hipSuccess ? convert(stage, nr, r)
+                                                                                                                       : set_error(LYNSE_ERR_DEVICE, "host-to-device copy failed");
+                if (rc == LYNSE_OK && hipStreamSynchronize(cur(h).stream) != hipSuccess) rc = set_error(LYNSE_ERR_DEVICE, "stream sync failed");
+                if (rc != LYNSE_OK) { (void)hipFree(stage); return rc; }
+            }
+            (void)hipFree(stage);
+        }
+        LY_HIP(hipStreamSynchronize(cur(h).stream));
+        h->n += n;
+        return LYNSE_OK;
+    }
     float* dst = h->rows + (size_t)h->n * h->ld;
     if (h->ld == h->dim) {
         LY_HIP(hipMemcpyAsync(dst, src, (size_t)n * h->dim * sizeof(float), kind, cur(h).stream));
@@ -574,8 +639,12 @@ static int finalize_locked(lynse_hip_flat* h) {
     }
     const uint64_t nnew = h->n - h->n_stats;
     const uint32_t blocks = (uint32_t)std::min<uint64_t>((nnew + 3) / 4, (uint64_t)h->num_cu * 16);
-    hipLaunchKernelGGL(k_row_stats, dim3(blocks), dim3(256), 0, cur(h).stream, h->rows, h->ld, h->dim,
-                       (uint32_t)h->n_stats, (uint32_t)h->n, h->vn2, h->vrinv, h->d_stats);
+    if (is_f16(h))
+        hipLaunchKernelGGL(k_row_stats<_Float16>, dim3(blocks), dim3(256), 0, cur(h).stream, h->rows_h, h->ld16, h->dim,
+                           (uint32_t)h->n_stats, (uint32_t)h->n, h->vn2, h->vrinv, h->d_stats);
+    else
+        hipLaunchKernelGGL(k_row_stats<float>, dim3(blocks), dim3(256), 0, cur(h).stream, h->rows, h->ld, h->dim,
+                           (uint32_t)h->n_stats, (uint32_t)h->n, h->vn2, h->vrinv, h->d_stats);
     LY_HIP(hipGetLastError());
     uint32_t st[4];
     LY_HIP(hipMemcpyAsync(st, h->d_stats, sizeof st, hipMemcpyDeviceToHost, cur(h).stream));
@@ -609,9 +678,14 @@ static int ensure_packed_locked(lynse_hip_flat* h) {
     LY_TRY(grow_packed(h, std::max<uint64_t>(h->n, h->capacity)));
     const uint64_t nnew = h->n - h->n_packed;
     const uint32_t blocks = (uint32_t)std::min<uint64_t>((nnew + 3) / 4, (uint64_t)h->num_cu * 16);
-    hipLaunchKernelGGL(k_pack_bits, dim3(blocks), dim3(256), 0, cur(h).stream,
-                       h->rows + (size_t)h->n_packed * h->ld, h->ld, h->dim, (uint32_t)nnew,
-                       h->packed + (size_t)h->n_packed * h->words, h->words);
+    if (is_f16(h))
+        hipLaunchKernelGGL(k_pack_bits<_Float16>, dim3(blocks), dim3(256), 0, cur(h).stream,
+                           h->rows_h + (size_t)h->n_packed * h->ld16, h->ld16, h->dim, (uint32_t)nnew,
+                           h->packed + (size_t)h->n_packed * h->words, h->words);
+    else
+        hipLaunchKernelGGL(k_pack_bits<float>, dim3(blocks), dim3(256), 0, cur(h).stream,
+                           h->rows + (size_t)h->n_packed * h->ld, h->ld, h->dim, (uint32_t)nnew,
+                           h->packed + (size_t)h->n_packed * h->words, h->words);
     LY_HIP(hipGetLastError());
     LY_HIP(hipStreamSynchronize(cur(h).stream));
     h->n_packed = h->n;
@@ -703,7 +777,7 @@ extern "C" int lynse_hip_flat_read_rows(const lynse_hip_flat* hc, uint64_t first
     if (h->packed_only) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "store holds packed rows only");
     if (first + n > h->n) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "row range out of bounds");
     if (n == 0) return LYNSE_OK;
-    if (h->ld == h->dim) {
+    if (!is_f16(h) && h->ld == h->dim) {
         LY_HIP(hipMemcpyAsync(out, h->rows + (size_t)first * h->ld, (size_t)n * h->dim * 4, hipMemcpyDeviceToHost, cur(h).stream));
         LY_HIP(hipStreamSynchronize(cur(h).stream));
         return LYNSE_OK;
@@ -713,7 +787,8 @@ extern "C" int lynse_hip_flat_read_rows(const lynse_hip_flat* hc, uint64_t first
     LY_HIP(hipMalloc(&stage, (size_t)std::min<uint64_t>(chunk, n) * h->dim * 4));
     for (uint64_t r = 0; r < n; r += chunk) {
         const uint64_t nr = std::min<uint64_t>(chunk, n - r);
-        int rc = copy_rows_kernel(h, stage, h->dim, h->rows + (size_t)(first + r) * h->ld, h->ld, h->dim, nr, 0);
+        int rc = is_f16(h) ? decode_rows_kernel(h, stage, h->dim, first + r, nr)
+                           : copy_rows_kernel(h, stage, h->dim, h->rows + (size_t)(first + r) * h->ld, h->ld, h->dim, nr, 0);
         if (rc == LYNSE_OK && hipMemcpyAsync(out + r * h->dim, stage, (size_t)nr * h->dim * 4, hipMemcpyDeviceToHost, cur(h).stream) != hipSuccess)
             rc = set_error(LYNSE_ERR_DEVICE, "device-to-host copy failed");
         if (rc == LYNSE_OK && hipStreamSynchronize(cur(h).stream) != hipSuccess) rc = set_error(LYNSE_ERR_DEVICE, "stream sync failed");
@@ -731,7 +806,9 @@ extern "C" int lynse_hip_flat_copy_rows_device(const lynse_hip_flat* hc, uint64_
     if (h->packed_only) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "store holds packed rows only");
     if (first + n > h->n) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "row range out of bounds");
     if (n == 0) return LYNSE_OK;
-    if (h->ld == h->dim)
+    if (is_f16(h))
+        LY_TRY(decode_rows_kernel(h, d_out, h->dim, first, n));
+    else if (h->ld == h->dim)
         LY_HIP(hipMemcpyAsync(d_out, h->rows + (size_t)first * h->ld, (size_t)n * h->dim * 4, hipMemcpyDeviceToDevice, cur(h).stream));
     else
         LY_TRY(copy_rows_kernel(h, d_out, h->dim, h->rows + (size_t)first * h->ld, h->ld, h->dim, n, 0));
@@ -1215,6 +1292,21 @@ static int launch_scan_i8c(const ScanArgs& a, uint32_t grid, hipStream_t st, boo
 // f16 shadow rows [n16, n) (all rows again when the scale changed)
 static int ensure_shadow_locked(lynse_hip_flat* h) {
     if (h->packed_only || h->n == 0) return LYNSE_OK;
+    if (is_f16(h) && h->sv == 1.0f) {   // the f16 bits ARE the shadow (no scaling): one copy of the rows in HBM
+        if (!h->shadow_alias && h->rows16) (void)hipFree(h->rows16);
+        h->shadow_alias = true;
+        h->rows16 = h->rows_h;
+        h->cap16 = h->capacity;
+        h->n16 = h->n;
+        h->sv16 = h->sv;
+        return LYNSE_OK;
+    }
+    if (h->shadow_alias) {              // the scale moved away from 1: the shadow becomes a buffer of its own
+        h->shadow_alias = false;
+        h->rows16 = nullptr;
+        h->cap16 = 0;
+        h->n16 = 0;
+    }
     if (h->cap16 < h->n) {
         const uint64_t cap = std::max<uint64_t>(h->capacity, h->n);
         _Float16* nr = nullptr;
@@ -1230,8 +1322,12 @@ static int ensure_shadow_locked(lynse_hip_flat* h) {
     if (h->n16 < h->n) {
         const uint64_t chunks = (h->n - h->n16) * (h->ld16 / 8);
         const uint32_t blocks = (uint32_t)std::min<uint64_t>((chunks + 255) / 256, (uint64_t)h->num_cu * 32);
-        hipLaunchKernelGGL(k_rows_to_f16, dim3(std::max<uint32_t>(blocks, 1)), dim3(256), 0, cur(h).stream, h->rows, h->ld, h->dim,
-                           h->n16, h->n, h->sv, h->rows16, h->ld16);
+        if (is_f16(h))
+            hipLaunchKernelGGL(k_rows_to_f16<_Float16>, dim3(std::max<uint32_t>(blocks, 1)), dim3(256), 0, cur(h).stream, h->rows_h, h->ld16, h->dim,
+                               h->n16, h->n, h->sv, h->rows16, h->ld16);
+        else
+            hipLaunchKernelGGL(k_rows_to_f16<float>, dim3(std::max<uint32_t>(blocks, 1)), dim3(256), 0, cur(h).stream, h->rows, h->ld, h->dim,
+                               h->n16, h->n, h->sv, h->rows16, h->ld16);
         LY_HIP(hipGetLastError());
         LY_HIP(hipStreamSynchronize(cur(h).stream));
     }
@@ -1482,7 +1578,7 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
             }
         } else {
             ScanArgs a{};
-            a.V = h->rows; a.ld = h->ld; a.D = h->dim; a.row0 = s.r0; a.row1 = s.r1; a.Q16 = w.Q16;
+            a.V = score_rows(h); a.ld = score_ld(h); a.D = h->dim; a.row0 = s.r0; a.row1 = s.r1; a.Q16 = w.Q16;
             a.mask = mask;
             a.row_ids = row_ids;
             a.tile_stride = s.sample_stride;  // 0 = contiguous
@@ -1609,7 +1705,7 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
             sa.drop_sentinels = 1;  // a lane whose rows are all masked / out of range wrote the sentinel
             sa.emit_all_n = (int)(s.sample_tiles * sample_keys_per_tile);
         }
-        sa.Qf = Qf; sa.V = h->rows; sa.ld = h->ld; sa.D = h->dim;
+        sa.Qf = Qf; sa.V = score_rows(h); sa.ld = score_ld(h); sa.D = h->dim;
         sa.candB = w.candB; sa.segcnt = w.segcnt; sa.seg = st_seg; sa.nseg = st_nseg;
         sa.abort_word = fs_stage ? w.gsync + 2 : nullptr;
         if (getenv("LYNSE_HIP_SEL_STAMPS"))   // debugging: phase stamps of the select behind stage si ([stage][query][8] behind the fs stamps)
@@ -1628,7 +1724,7 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
     FinalArgs fa{};
     fa.cand = w.cand; fa.count = w.count; fa.k = k; fa.out_k = out_k; fa.cap = w.cap; fa.metric = bin_mfma ? (int)M_IP : metric; fa.ip_form = ip_form;
     fa.ham_dim = bin_mfma ? h->dim : 0u;
-    fa.exact = binary ? 1 : 0; fa.Qf = Qf; fa.V = h->rows; fa.ld = h->ld; fa.D = h->dim;
+    fa.exact = binary ? 1 : 0; fa.Qf = Qf; fa.V = score_rows(h); fa.ld = score_ld(h); fa.D = h->dim;
     fa.row_stride = h->row_stride; fa.row_offset = h->row_offset;
     fa.out_rows = r_dst ? r_dst : w.out_rows; fa.out_dists = d_dst ? d_dst : w.out_dists; fa.out_counts = w.out_counts;
     fa.out_counts2 = c2_dst;
@@ -2148,7 +2244,7 @@ static int search_impl(lynse_hip_flat* h, const void* q_src, bool packed_queries
                 LY_HIP(hipMemcpyAsync(w.QW, (const uint64_t*)q_src + q0 * h->words, (size_t)nqc * h->words * 8, in_kind, st));
             } else {  // pack_binary_query (flat_mmap.rs:1292-1296)
                 LY_HIP(hipMemcpyAsync(w.Qf, (const float*)q_src + q0 * h->dim, (size_t)nqc * h->dim * 4, in_kind, st));
-                hipLaunchKernelGGL(k_pack_bits, dim3((nqc + 3) / 4), dim3(256), 0, st, w.Qf, h->dim, h->dim, nqc, w.QW, h->words);
+                hipLaunchKernelGGL(k_pack_bits<float>, dim3((nqc + 3) / 4), dim3(256), 0, st, w.Qf, h->dim, h->dim, nqc, w.QW, h->words);
                 LY_HIP(hipGetLastError());
             }
         } else if (!on_device) {  // (device queries are read in place: they stay valid for the whole call)
@@ -2273,7 +2369,8 @@ extern "C" uint64_t lynse_hip_flat_hbm_bytes(const lynse_hip_flat* h) {
     if (!h) return 0;
     uint64_t b = 0;
     if (h->rows) b += h->capacity * h->ld * 4ull;
-    if (h->rows16) b += h->cap16 * h->ld16 * 2ull;
+    if (h->rows_h) b += h->capacity * h->ld16 * 2ull;
+    if (h->rows16 && !h->shadow_alias) b += h->cap16 * h->ld16 * 2ull;
     if (h->vn2) b += 2ull * (h->stats_capacity + 256) * 4;
     if (h->packed) b += h->packed_capacity * h->words * 8ull;
     if (h->sq8) b += h->sq8_cap * h->ld8 + 2ull * (h->sq8_cap + 256) * 4;
@@ -2333,12 +2430,13 @@ static int search_large_k(lynse_hip_flat* h, const void* q_src, bool packed_quer
     }
     struct View {  // the scan-side fields of the handle, advanced to one row range for the duration of a call
         lynse_hip_flat* h;
-        float* rows; _Float16* rows16; float *vn2, *vrinv; uint64_t* packed;
+        float* rows; _Float16 *rows16, *rows_h; float *vn2, *vrinv; uint64_t* packed;
         uint64_t n, n_stats, n16, n_packed, row_offset;
-        explicit View(lynse_hip_flat* hh) : h(hh), rows(hh->rows), rows16(hh->rows16), vn2(hh->vn2), vrinv(hh->vrinv), packed(hh->packed),
+        explicit View(lynse_hip_flat* hh) : h(hh), rows(hh->rows), rows16(hh->rows16), rows_h(hh->rows_h), vn2(hh->vn2), vrinv(hh->vrinv), packed(hh->packed),
                                             n(hh->n), n_stats(hh->n_stats), n16(hh->n16), n_packed(hh->n_packed), row_offset(hh->row_offset) {}
         void set(uint64_t r0, uint64_t r1) {
             h->rows = rows ? rows + r0 * h->ld : nullptr;
+            h->rows_h = rows_h ? rows_h + r0 * h->ld16 : nullptr;
             h->rows16 = rows16 ? rows16 + r0 * h->ld16 : nullptr;
             h->vn2 = vn2 ? vn2 + r0 : nullptr;
             h->vrinv = vrinv ? vrinv + r0 : nullptr;
@@ -2348,7 +2446,7 @@ static int search_large_k(lynse_hip_flat* h, const void* q_src, bool packed_quer
             h->row_offset = row_offset + r0 * h->row_stride;
         }
         ~View() {
-            h->rows = rows; h->rows16 = rows16; h->vn2 = vn2; h->vrinv = vrinv; h->packed = packed;
+            h->rows = rows; h->rows_h = rows_h; h->rows16 = rows16; h->vn2 = vn2; h->vrinv = vrinv; h->packed = packed;
             h->n = n; h->n_stats = n_stats; h->n16 = n16; h->n_packed = n_packed; h->row_offset = row_offset;
         }
     } view(h);

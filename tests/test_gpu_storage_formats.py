@@ -217,3 +217,39 @@ def test_hand_assembled_reference_layout_opens_and_searches(L, oracle, tmp_path,
     assert ids[0] == 59 and S.rows_to_user_ids(ids[:1], id_map).tolist() == [10_000_000_177]
     ids, _ = idx.search(want[92], 1, "l2")
     assert S.rows_to_user_ids(ids, id_map).tolist() == [92]              # past the end of the map: the row itself
+
+
+def test_f16_shard_holds_one_copy_of_its_rows(L, oracle):
+    """VectorDtype::F16 (src/storage/dtype.rs, flat_mmap.rs:187-221): the shard keeps the f16 bits and nothing else of the rows —
+    no f32 decode, and (values within the unscaled f16 range) the coarse-pass shadow IS that buffer: 2 B per element + the
+    per-row norms, against 4 + 2 B for an f32 shard.  Rows read back decode exactly; appends after a search keep working."""
+    rng = np.random.default_rng(12)
+    n, dim = 50_000, 96
+    data = oracle.round_f16(rng.standard_normal((n, dim)).astype(f32)).reshape(n, dim)
+    idx = L.FlatIndex(None, dim, dtype="f16")
+    idx.write(data[:30_000])
+    idx.finalize()
+    q = rng.standard_normal((5, dim)).astype(f32)
+    idx.search_batch_arrays(q, 10, "ip")
+    idx.write(data[30_000:])
+    idx.finalize()
+    assert idx.hbm_bytes() <= n * dim * 2 * 1.6 + (1 << 20), idx.hbm_bytes()     # one f16 copy (+ growth slack, norms)
+    f32_idx = L.FlatIndex(None, dim)
+    f32_idx.write(data)
+    f32_idx.finalize()
+    assert f32_idx.hbm_bytes() >= n * dim * 6
+    assert np.array_equal(idx.read_rows(0, n).view(np.uint32), data.view(np.uint32))
+    for name, metric in (("ip", O.IP), ("l2", O.L2), ("cosine", O.COS)):
+        rows, dists, counts = idx.search_batch_arrays(q, 10, name)
+        for i in range(5):
+            e_ids, e_d = oracle.canonical_topk_f16(q[i], data, 10, metric)
+            assert np.array_equal(rows[i].astype(np.uint32), e_ids) and np.array_equal(dists[i].view(np.uint32), e_d.view(np.uint32)), (name, i)
+    # values beyond 2^15: the shadow is a scaled copy of its own, the results do not change
+    big = oracle.round_f16((rng.standard_normal((20_000, dim)) * 9000.0).astype(f32)).reshape(20_000, dim)
+    idx2 = L.FlatIndex(None, dim, dtype="f16")
+    idx2.write(big)
+    idx2.finalize()
+    rows, dists, counts = idx2.search_batch_arrays(q, 10, "l2")
+    for i in range(5):
+        e_ids, e_d = oracle.canonical_topk_f16(q[i], big, 10, O.L2)
+        assert np.array_equal(rows[i].astype(np.uint32), e_ids) and np.array_equal(dists[i].view(np.uint32), e_d.view(np.uint32)), i
