@@ -2097,7 +2097,10 @@ __global__ void __launch_bounds__(WQ * WR * 64, (TQ * TR >= 16) ? 1 : ((WQ * WR 
 // signed codes and of their squares, and the same for the queries.
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_sq8_minmax(const float* __restrict__ V, uint32_t ld, uint32_t D, uint64_t n,
-                                                    uint32_t* __restrict__ omin, uint32_t* __restrict__ omax) {
+                                                    uint32_t* __restrict__ omin, uint32_t* __restrict__ omax,
+                                                    const float* __restrict__ row_scale = nullptr) {
+    // row_scale: the coded value of element (r, d) is V[r][d] * row_scale[r] (one f32 multiply) — the unit-norm rows of the
+    // cosine form of the certified int8 pass
     // thread = one dimension (coalesced across the row), block = a strip of rows; `<` / `>` updates like the reference
     // (NaN never replaces), merged with atomics on the order-preserving image
     const uint64_t rows_per_block = (n + gridDim.y - 1) / gridDim.y;
@@ -2106,7 +2109,7 @@ __global__ void __launch_bounds__(256) k_sq8_minmax(const float* __restrict__ V,
     if (d >= D) return;
     float mn = LY_INF, mx = -LY_INF;
     for (uint64_t r = r0; r < r1; ++r) {
-        const float v = V[r * ld + d];
+        const float v = row_scale ? __fmul_rn(V[r * ld + d], row_scale[r]) : V[r * ld + d];
         if (v < mn) mn = v;
         if (v > mx) mx = v;
     }
@@ -2124,6 +2127,20 @@ __global__ void __launch_bounds__(256) k_sq8_scales(const uint32_t* __restrict__
     scales[d] = range > 1e-30f ? __fdiv_rn(255.0f, range) : 0.0f;
 }
 
+// min / max of one column held as a vector (the squared row norms: column D of the augmented rows), same update rule
+__global__ void __launch_bounds__(256) k_vec_minmax(const float* __restrict__ x, uint64_t n, uint32_t* __restrict__ omin, uint32_t* __restrict__ omax,
+                                                    uint32_t ncopies) {
+    float mn = LY_INF, mx = -LY_INF;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const float v = x[i];
+        if (v < mn) mn = v;
+        if (v > mx) mx = v;
+    }
+    for (int o = 32; o > 0; o >>= 1) { mn = fminf(mn, __shfl_xor(mn, o, 64)); mx = fmaxf(mx, __shfl_xor(mx, o, 64)); }
+    if ((threadIdx.x & 63) == 0)
+        for (uint32_t j = 0; j < ncopies; ++j) { atomicMin(omin + j, f32_to_ord(mn)); atomicMax(omax + j, f32_to_ord(mx)); }
+}
+
 __device__ __forceinline__ int sq8_code(float v, float mn, float sc) {
     float q = roundf(__fmul_rn(__fsub_rn(v, mn), sc));  // f32::round: half away from zero
     if (!(q == q)) return 0;
@@ -2135,7 +2152,12 @@ __device__ __forceinline__ int sq8_code(float v, float mn, float sc) {
 __global__ void __launch_bounds__(256) k_sq8_quantize(const float* __restrict__ V, uint32_t ld, uint32_t D, uint64_t n,
                                                       const float* __restrict__ mins, const float* __restrict__ scales,
                                                       int8_t* __restrict__ out, uint32_t ld8, int* __restrict__ sums,
-                                                      int* __restrict__ sums2, uint32_t* __restrict__ stats) {
+                                                      int* __restrict__ sums2, uint32_t* __restrict__ stats,
+                                                      const float* __restrict__ extra_col = nullptr, uint32_t n_extra = 0,
+                                                      const float* __restrict__ row_scale = nullptr) {
+    // extra_col != nullptr: columns D .. D + n_extra - 1 of the coded row all hold extra_col[row] (mins / scales have D + n_extra
+    // entries) — the squared row norm of the L2 form of the certified int8 pass (k_i8c_prep_queries, aug); sums / sums2 may be
+    // NULL then
     // stats[0] = max over rows of sum |code - 128| (the query-quantisation term of the certified int8 bound),
     // stats[1] = number of non-finite elements (the certified int8 coarse pass is only valid without them)
     const int lane = threadIdx.x & 63;
@@ -2146,8 +2168,8 @@ __global__ void __launch_bounds__(256) k_sq8_quantize(const float* __restrict__ 
         int s1 = 0, s2 = 0, l1 = 0;
         for (uint32_t d = lane; d < ld8; d += 64) {
             int c = 0;
-            if (d < D) {
-                const float v = V[row * ld + d];
+            if (d < D || (extra_col && d < D + n_extra)) {
+                const float v = d < D ? (row_scale ? __fmul_rn(V[row * ld + d], row_scale[row]) : V[row * ld + d]) : extra_col[row];
                 if (!(fabsf(v) < LY_INF)) nonfinite += 1;
                 c = sq8_code(v, mins[d], scales[d]) - 128;
                 s1 += c;
@@ -2157,7 +2179,7 @@ __global__ void __launch_bounds__(256) k_sq8_quantize(const float* __restrict__ 
             out[row * ld8 + d] = (int8_t)c;
         }
         for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); l1 += __shfl_xor(l1, o, 64); }
-        if (lane == 0) { sums[row] = s1; sums2[row] = s2; }
+        if (lane == 0 && sums) { sums[row] = s1; sums2[row] = s2; }
         a1max = a1max > (uint32_t)l1 ? a1max : (uint32_t)l1;
     }
     for (int o = 32; o > 0; o >>= 1) nonfinite += __shfl_xor(nonfinite, o, 64);
@@ -2226,6 +2248,22 @@ struct I8cPrepArgs {
     float *sq, *bq, *marg2, *thr;  // s_q -> ScanArgs::qinv, B_q -> ScanArgs::qn2
     uint32_t *count, *overflow;
     uint32_t* gsync;     // hand-over words of the fused sample stage (ScanArgs::gsync): zeroed here, once per batch
+    // aug = m > 0: squared L2 as an inner product of AUGMENTED vectors.  -|q - v|^2 = q'.v' - |q|^2 with q' = [2 q, -1/m x m]
+    // and v' = [v, |v|^2 x m]: the rows are coded with their f32 squared norm in columns D .. D + m - 1 (m a power of two: the
+    // m query entries -1/m sum to -1 exactly; ONE column would carry a weight w = -1/scale that dwarfs the data columns'
+    // and with it the resolution s_q = max |w| / 127 of the whole query image — uniform 100-d data: margin 2.7 against
+    // neighbour distances of ~10; spread over m columns the weight shrinks m-fold).  mins / scales: D + m entries, a1 over
+    // D + m columns; the coarse score B' + s_q dot, B' = B(q', mins) - |q|^2, brackets the NEGATED reference-order distance —
+    // "smaller distance" is "larger score", the IP scan / select run unchanged, the exact rescoring negates the true L2
+    // (SelectArgs / FinalArgs::neg_metric1) and k_final negates it back.  E = the IP bound over (q', v') + the f32 error of
+    // the stored norm and of the reference's own difference-form sum: 8 (D + 8) 2^-24 (|q|^2 + max |v|^2).
+    int aug;
+    // cosine = 1: cosine distance as an inner product of UNIT vectors.  The rows are coded as fl(v_d * rinv[row]) (rinv = the
+    // stored reciprocal f32 norm; a zero row codes as zeros and scores distance 1 like the reference's denom < 1e-30 rule), the
+    // query enters as q / |q|; coarse score q^.v^ - 1 = -(coarse distance), exact scores are the NEGATED reference cosine
+    // distances (neg_metric1).  E = the IP bound over the unit vectors + 9 (D + 8) 2^-24 for the f32 normalisation of the rows
+    // and the reference's own dot / norm sums.
+    int cosine;
 };
 
 __global__ void __launch_bounds__(256) k_i8c_prep_queries(I8cPrepArgs a) {
@@ -2234,16 +2272,34 @@ __global__ void __launch_bounds__(256) k_i8c_prep_queries(I8cPrepArgs a) {
     const uint32_t q = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* qv = a.Q + (size_t)q * a.D;
+    const uint32_t DA = a.D + (uint32_t)a.aug;     // dimensions of the coded vectors
+    double qrn = 1.0;                               // cosine: 1 / |q| (0 for a zero query: every coarse score is -1 = distance 1)
+    if (a.cosine) {
+        __shared__ double rs[4];
+        double t = 0.0;
+        for (uint32_t i = tid; i < a.D; i += 256) { const double o = (double)qv[i]; t += o * o; }
+        for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+        if (lane == 0) rs[wave] = t;
+        __syncthreads();
+        t = (rs[0] + rs[1]) + (rs[2] + rs[3]);
+        qrn = t > 0.0 ? 1.0 / sqrt(t) : 0.0;
+        __syncthreads();
+    }
+    auto qel = [&](uint32_t i) -> double {          // element i of the (augmented / normalised) query
+        if (a.cosine) return (double)qv[i] * qrn;
+        if (!a.aug) return (double)qv[i];
+        return i < a.D ? 2.0 * (double)qv[i] : -1.0 / (double)a.aug;
+    };
     double wmax = 0.0, sw = 0.0, swabs = 0.0, sqm = 0.0, s2 = 0.0;
-    for (uint32_t i = tid; i < a.D; i += 256) {
-        const double x = (double)qv[i];
+    for (uint32_t i = tid; i < DA; i += 256) {
+        const double x = qel(i);
         const float sc = a.scales[i];
         const double w = sc > 0.0f ? x / (double)sc : 0.0;
         wmax = fmax(wmax, fabs(w));
         sw += w;
         swabs += fabs(w);
         sqm += x * (double)a.mins[i];
-        s2 += x * x;
+        if (i < a.D) { const double o = (double)qv[i]; s2 += o * o; }   // |q|^2 of the ORIGINAL query
     }
     for (int o = 32; o > 0; o >>= 1) {
         wmax = fmax(wmax, __shfl_xor(wmax, o, 64));
@@ -2267,12 +2323,14 @@ __global__ void __launch_bounds__(256) k_i8c_prep_queries(I8cPrepArgs a) {
             if (!(sq > 0.0f)) sq = 1.1754944e-38f;
         }
         s_sq = sq;
-        const double bq = sqm + 128.0 * sw;
+        const double bq = sqm + 128.0 * sw - (a.aug ? s2 : 0.0) - (a.cosine ? 1.0 : 0.0);
         const float bqf = (float)bq;
         const double a1 = (double)a.a1;
         const double gam = 10.0 * (double)a.D * 5.9604645e-8;  // reference f32 accumulation order vs the real dot product
-        double E = 0.5001 * swabs + 0.5001 * (double)sq * a1 + 2.5e-7 * (fabs(bq) + 127.0 * (double)sq * a1) +
-                   gam * sqrt(s2) * (double)a.vmax;
+        const double ref_term = a.cosine ? 9.0 * ((double)a.D + 8.0) * 5.9604645e-8
+                                : a.aug  ? 8.0 * ((double)a.D + 8.0) * 5.9604645e-8 * (s2 + (double)a.vmax * (double)a.vmax)
+                                         : gam * sqrt(s2) * (double)a.vmax;
+        double E = 0.5001 * swabs + 0.5001 * (double)sq * a1 + 2.5e-7 * (fabs(bq) + (a.cosine ? 1.0 : fabs(s2)) + 127.0 * (double)sq * a1) + ref_term;
         E *= 1.02;
         if (!(wmax < 1.0e30) || !(E == E) || E > 3.0e38) E = 3.0e38;
         a.sq[q] = sq;
@@ -2288,9 +2346,9 @@ __global__ void __launch_bounds__(256) k_i8c_prep_queries(I8cPrepArgs a) {
     const uint32_t total = a.nslab * 128;
     for (uint32_t i = tid; i < total; i += 256) {
         int u = 0;
-        if (i < a.D) {
+        if (i < DA) {
             const float sc = a.scales[i];
-            const double w = sc > 0.0f ? (double)qv[i] / (double)sc : 0.0;
+            const double w = sc > 0.0f ? qel(i) / (double)sc : 0.0;
             double r = rint(w * inv);
             r = r < -127.0 ? -127.0 : (r > 127.0 ? 127.0 : r);
             u = (r == r) ? (int)r : 0;
@@ -2833,7 +2891,8 @@ __device__ __forceinline__ uint32_t next_pow2(uint32_t n) {
 template <int NT>
 __device__ __forceinline__ void rescore_keys(uint64_t* keys, uint32_t n, int metric, int ip_form,
                                              const float* qv, const float* V, uint32_t ld, uint32_t D,
-                                             bool asc, int tid) {
+                                             bool asc, int tid, bool neg = false) {
+    // neg: the keys live in the NEGATED score space of an ascending metric run as a best-first scan (SelectArgs::neg_metric1)
     const int g = tid & 7;
     const uint32_t grp = tid >> 3;
     const uint32_t rounds = (n + NT / 8 - 1) / (NT / 8);
@@ -2849,6 +2908,7 @@ __device__ __forceinline__ void rescore_keys(uint64_t* keys, uint32_t n, int met
             s0 = exact_score<32>(metric, ip_form, qv, V + (size_t)row0 * ld, D, g);
             s1 = exact_score<32>(metric, ip_form, qv, V + (size_t)row1 * ld, D, g);
         }
+        if (neg) { s0 = -s0; s1 = -s1; }
         if (ok0 && g == 0) keys[i0] = make_key(s0, row0, asc);
         if (ok1 && g == 0) keys[i1] = make_key(s1, row1, asc);
     }
@@ -2920,6 +2980,9 @@ struct SelectArgs {
     uint32_t ld, D;
     const uint32_t* abort_word;  // fused sample stage (ScanArgs::gsync + 2): != 0 -> the scan launch gave up, nothing it wrote is valid
     unsigned long long* stamps;  // debugging: [query][8] s_memtime stamps of the phases (nullptr = off)
+    // != 0: `metric` only gives the KEY ORDER (M_IP: best-first); exact scores are those of metric neg_metric1 - 1, NEGATED —
+    // the certified int8 pass of an ascending metric (squared L2 as an augmented inner product, k_i8c_prep_queries aug = 1)
+    int neg_metric1;
 };
 
 // k_select finds the k-th best key with an 8-pass MSB radix select over the keys in LDS (256-bin
@@ -3145,7 +3208,7 @@ __device__ __forceinline__ uint32_t select_body(const SelectArgs& a, uint64_t* k
             __syncthreads();
             const uint32_t m = s_x < mx ? s_x : mx;   // >= k: at least k keys are <= the k-th smallest
             if (m >= a.k) {
-                rescore_keys<NT>(xs, m, a.metric, a.ip_form, a.Qf + (size_t)q * a.D, a.V, a.ld, a.D, asc, tid);
+                rescore_keys<NT>(xs, m, a.neg_metric1 ? a.neg_metric1 - 1 : a.metric, a.ip_form, a.Qf + (size_t)q * a.D, a.V, a.ld, a.D, asc, tid, a.neg_metric1 != 0);
                 // the k-th best of the m <= 256 rescored keys by RANK (keys are unique: the row is part of the key): one thread per key
                 // counts the smaller ones — m broadcast LDS reads instead of the 36 barrier-separated steps of a 256-key bitonic sort
                 __shared__ float s_taux;
@@ -3212,7 +3275,7 @@ __device__ __forceinline__ uint32_t select_body(const SelectArgs& a, uint64_t* k
         __syncthreads();
         for (uint32_t i = n + tid; i < np2; i += NT) keys[i] = KEY_SENTINEL;
         bitonic_sort_lds<NT>(keys, np2, tid);  // survivors are a prefix of the sorted keys
-        rescore_keys<NT>(keys, keep, a.metric, a.ip_form, a.Qf + (size_t)q * a.D, a.V, a.ld, a.D, asc, tid);
+        rescore_keys<NT>(keys, keep, a.neg_metric1 ? a.neg_metric1 - 1 : a.metric, a.ip_form, a.Qf + (size_t)q * a.D, a.V, a.ld, a.D, asc, tid, a.neg_metric1 != 0);
         for (uint32_t i = keep + tid; i < np2; i += NT) keys[i] = KEY_SENTINEL;
         bitonic_sort_lds<NT>(keys, np2, tid);
         const float xk = key_score(keys[a.k - 1], asc);
@@ -3523,6 +3586,7 @@ struct FinalArgs {
     // batched Hamming on the matrix pipe: the keys carry the +-1 dot product (best-first as an IP score); the distance
     // written out is (ham_dim - dot) / 2 — exact (integers below 2^24).  0 = off
     uint32_t ham_dim;
+    int neg_metric1;   // as SelectArgs::neg_metric1: rescoring with metric neg_metric1 - 1, negated; the distances written out are negated back
 };
 
 // k_rescore_pool: the exact rescoring of k_final spread over gridDim.y blocks per query (IVF on tightly clustered
@@ -3539,7 +3603,8 @@ __global__ void __launch_bounds__(NT) k_rescore_pool(FinalArgs a) {
     const float* qv = a.Qf + (size_t)q * a.D;
     for (uint32_t i = blockIdx.y * (NT / 8) + (tid >> 3); i < n; i += gridDim.y * (NT / 8)) {
         const uint32_t row = key_row(keys[i]);
-        const float s = exact_score<32>(a.metric, a.ip_form, qv, a.V + (size_t)row * a.ld, a.D, g);
+        float s = exact_score<32>(a.neg_metric1 ? a.neg_metric1 - 1 : a.metric, a.ip_form, qv, a.V + (size_t)row * a.ld, a.D, g);
+        if (a.neg_metric1) s = -s;
         if (g == 0) keys[i] = make_key(s, row, asc);
     }
 }
@@ -3557,7 +3622,7 @@ __device__ __forceinline__ void final_body(const FinalArgs& a, uint64_t* keys, c
         keys[i] = i < n ? (same_launch ? __hip_atomic_load(&src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : src[i]) : KEY_SENTINEL;
     __syncthreads();
     if (!exact)
-        rescore_keys<NT>(keys, n, a.metric, a.ip_form, a.Qf + (size_t)q * a.D, a.V, a.ld, a.D, asc, tid);
+        rescore_keys<NT>(keys, n, a.neg_metric1 ? a.neg_metric1 - 1 : a.metric, a.ip_form, a.Qf + (size_t)q * a.D, a.V, a.ld, a.D, asc, tid, a.neg_metric1 != 0);
     if (a.orig_ids) {  // canonical order is (distance, ORIGINAL row): swap the row word before the final sort
         for (uint32_t i = tid; i < n; i += NT) keys[i] = (keys[i] & 0xffffffff00000000ull) | a.orig_ids[key_row(keys[i])];
         __syncthreads();
@@ -3584,10 +3649,10 @@ __device__ __forceinline__ void final_body(const FinalArgs& a, uint64_t* keys, c
         if (i < cnt) {
             a.out_rows[(size_t)q * a.out_k + i] = (uint64_t)key_row(keys[i]) * a.row_stride + a.row_offset;
             const float sc = key_score(keys[i], asc);
-            a.out_dists[(size_t)q * a.out_k + i] = a.ham_dim ? ((float)a.ham_dim - sc) * 0.5f : sc;
+            a.out_dists[(size_t)q * a.out_k + i] = a.ham_dim ? ((float)a.ham_dim - sc) * 0.5f : (a.neg_metric1 ? 0.0f - sc : sc);   // (0 - (+0) = +0: a zero distance keeps its sign)
         } else {
             a.out_rows[(size_t)q * a.out_k + i] = ~0ull;
-            a.out_dists[(size_t)q * a.out_k + i] = (a.ham_dim || asc) ? LY_INF : -LY_INF;
+            a.out_dists[(size_t)q * a.out_k + i] = (a.ham_dim || a.neg_metric1 || asc) ? LY_INF : -LY_INF;
         }
     }
     if (tid == 0) {

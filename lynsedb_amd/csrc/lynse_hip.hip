@@ -247,6 +247,26 @@ struct lynse_hip_flat {
     uint32_t* sq8_stats = nullptr;  // [0] max row L1 of the signed codes, [1] non-finite elements (k_sq8_quantize)
     uint32_t sq8_a1 = 0;
     bool sq8_finite = false;
+    // the L2 form of the certified int8 pass: SQ8 codes of the AUGMENTED rows [v, |v|^2] (k_i8c_prep_queries, aug = 1), pitch
+    // ld8a = round_up(dim + 1, 128) (whole 128-column slabs: the non-ragged scan kernels), built lazily on the first L2 batch
+    // of 33..256 queries
+    int8_t* sq8a = nullptr;
+    uint32_t ld8a = 0, aug_cols = 1;     // aug_cols: columns carrying |v|^2 (a power of two <= 32 that fits the slab padding)
+    uint64_t n_sq8a = 0, sq8a_cap = 0;
+    float *sq8a_mins = nullptr, *sq8a_scales = nullptr;
+    uint32_t *sq8a_mm = nullptr, *sq8a_stats = nullptr;
+    uint32_t sq8a_a1 = 0;
+    bool sq8a_finite = false;
+    std::atomic<int> i8c_strikes_l2{0};
+    // the cosine form: SQ8 codes of the UNIT rows fl(v_d * rinv[row]) (pitch ld8), built lazily on the first cosine batch of
+    // 33..256 queries
+    int8_t* sq8c = nullptr;
+    uint64_t n_sq8c = 0, sq8c_cap = 0;
+    float *sq8c_mins = nullptr, *sq8c_scales = nullptr;
+    uint32_t *sq8c_mm = nullptr, *sq8c_stats = nullptr;
+    uint32_t sq8c_a1 = 0;
+    bool sq8c_finite = false;
+    std::atomic<int> i8c_strikes_cos{0};
     // certified int8 coarse pass (FLAT-IP batches of 33..256 queries): -1 = off (env / strikes), else overflow strikes so far
     std::atomic<int> i8c_strikes{0};     // (searches under the SHARED lock bump it)
     // batched Hamming on the matrix pipe: one signed byte per bit (+1 / -1) of the packed rows, pitch ld8; built lazily on the
@@ -361,6 +381,8 @@ extern "C" int lynse_hip_flat_create(uint32_t dim, int device, lynse_hip_flat** 
     h->ld = round_up(dim, 4);
     h->ld16 = round_up(dim, 8);
     h->ld8 = round_up(dim, 16);
+    h->ld8a = round_up(dim + 1, 128);
+    while (h->aug_cols * 2 <= 32 && dim + h->aug_cols * 2 <= h->ld8a) h->aug_cols *= 2;
     h->words = (dim + 63) / 64;
     h->device = device;
     hipDeviceProp_t prop;
@@ -395,7 +417,8 @@ extern "C" int lynse_hip_flat_destroy(lynse_hip_flat* h) {
     if (h->shadow_alias) h->rows16 = nullptr;
     for (void* p : {(void*)h->rows, (void*)h->rows_h, (void*)h->rows16, (void*)h->packed, (void*)h->vn2, (void*)h->vrinv, (void*)h->d_stats,
                     (void*)h->d_mask, (void*)h->d_subset, (void*)h->g_rows16, (void*)h->g_vn2, (void*)h->g_vrinv, (void*)h->g_ids32,
-                    (void*)h->bpm, (void*)h->sq8, (void*)h->sq8_mins, (void*)h->sq8_scales, (void*)h->sq8_sum, (void*)h->sq8_sum2, (void*)h->sq8_mm, (void*)h->sq8_stats})
+                    (void*)h->bpm, (void*)h->sq8c, (void*)h->sq8c_mins, (void*)h->sq8c_scales, (void*)h->sq8c_mm, (void*)h->sq8c_stats, (void*)h->sq8a, (void*)h->sq8a_mins, (void*)h->sq8a_scales, (void*)h->sq8a_mm, (void*)h->sq8a_stats,
+                    (void*)h->sq8, (void*)h->sq8_mins, (void*)h->sq8_scales, (void*)h->sq8_sum, (void*)h->sq8_sum2, (void*)h->sq8_mm, (void*)h->sq8_stats})
         if (p) (void)hipFree(p);
     for (auto& c : h->ctx)
         if (c.stream) (void)hipStreamDestroy(c.stream);
@@ -1433,7 +1456,12 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
     // batched Hamming on the int8 MFMA: the +-1 copy of the rows is there and the batch is large enough (search_impl builds it)
     const bool bin_mfma = h16 && bin_mfma_eligible(h, metric, mask != nullptr || row_ids != nullptr, nq) && h->bpm && h->n_bpm == h->n;
     if (bin_mfma) i8c = true;   // the scan side IS the certified-int8 IP scan (exact here: margin 0)
-    const uint32_t nslab = i8c ? (h->dim + 127) / 128 : glds ? (h->dim + GL_BK - 1) / GL_BK : (h->dim + SCAN_BK - 1) / SCAN_BK;  // h16: HK == SCAN_BK == 64
+    // squared L2 on the certified int8 pass: an inner product of augmented vectors in the negated score space (kernels.h,
+    // I8cPrepArgs::aug): scan, thresholds and selects run as a best-first IP search, exact scores are -|q - v|^2
+    const bool aug = i8c && !bin_mfma && metric == M_L2;
+    const bool cosq = i8c && !bin_mfma && metric == M_COS;   // cosine distance: unit vectors, negated score space (I8cPrepArgs::cosine)
+    const int key_metric = (bin_mfma || aug || cosq) ? (int)M_IP : metric;   // the order of the candidate keys
+    const uint32_t nslab = i8c ? ((aug ? h->dim + h->aug_cols : h->dim) + 127) / 128 : glds ? (h->dim + GL_BK - 1) / GL_BK : (h->dim + SCAN_BK - 1) / SCAN_BK;  // h16: HK == SCAN_BK == 64
     const bool small = nq <= SCAN_BQ_SMALL;
     const uint32_t qpad = small ? SCAN_BQ_SMALL : round_up(nq, SCAN_BQ_LARGE);  // > 256 queries: a widened handle, qpad / 256 chunks per launch
     const uint32_t qchunks = small ? 1u : qpad / SCAN_BQ_LARGE;
@@ -1466,11 +1494,12 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
         LY_HIP(hipMemsetAsync(w.overflow, 0, nq * 4, st));
         LY_HIP(hipStreamSynchronize(st));  // thr0 is a stack/heap temporary
     } else if (i8c) {
-        if (nq != qpad || h->dim % 128 != 0)  // (a full chunk of whole slabs overwrites every byte of the image)
+        if (nq != qpad || (aug ? h->dim + h->aug_cols : h->dim) % 128 != 0)  // (a full chunk of whole slabs overwrites every byte of the image)
             LY_HIP(hipMemsetAsync(w.Q16, 0, (size_t)nslab * qpad * 128, st));
         I8cPrepArgs p{};
-        p.Q = Qf; p.D = h->dim; p.qpad = qpad; p.nslab = nslab; p.mins = h->sq8_mins; p.scales = h->sq8_scales;
-        p.a1 = h->sq8_a1; p.vmax = h->vmax; p.img = reinterpret_cast<int8_t*>(w.Q16);
+        p.Q = Qf; p.D = h->dim; p.qpad = qpad; p.nslab = nslab; p.mins = aug ? h->sq8a_mins : (cosq ? h->sq8c_mins : h->sq8_mins);
+        p.scales = aug ? h->sq8a_scales : (cosq ? h->sq8c_scales : h->sq8_scales);
+        p.a1 = aug ? h->sq8a_a1 : (cosq ? h->sq8c_a1 : h->sq8_a1); p.vmax = h->vmax; p.cosine = cosq ? 1 : 0; p.img = reinterpret_cast<int8_t*>(w.Q16); p.aug = aug ? (int)h->aug_cols : 0;
         p.sq = w.qinv; p.bq = w.qn2; p.marg2 = w.marg2; p.thr = w.thr; p.count = w.count; p.overflow = w.overflow;
         p.gsync = w.gsync;
         hipLaunchKernelGGL(k_i8c_prep_queries, dim3(nq), dim3(256), 0, st, p);
@@ -1525,7 +1554,7 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
     // hand-over drains the LDS-DMA ring of every CU and idles the chip twice, which costs more than a kernel boundary.
     const int fs_env = []() { const char* e = getenv("LYNSE_HIP_FUSED_SAMPLE"); return e ? atoi(e) : 0; }();   // (read per call: tests flip it)
     static const int dbg_env = []() { const char* e = getenv("LYNSE_HIP_DEBUG_FLAGS"); return e ? atoi(e) : 0; }();
-    const bool fs = fs_env != 0 && !dbg_env && i8c && h->ld8 % 128 == 0 && sample_threshold_only && plan.size() >= 2 && k <= 32 &&
+    const bool fs = fs_env != 0 && !dbg_env && i8c && !aug && !cosq && !bin_mfma && h->ld8 % 128 == 0 && sample_threshold_only && plan.size() >= 2 && k <= 32 &&
                     sample.sample_tiles == (uint32_t)h->num_cu && (plan[1].r1 - plan[1].r0 + 255) / 256 >= (uint32_t)h->num_cu &&
                     (uint64_t)k * 50000ull > (uint64_t)sample.sample_tiles * plan_tile &&   // (the stage behind the sample runs the DENSE epilogue)
                     []() { const char* e = getenv("LYNSE_HIP_DENSE"); return !e || atoi(e) != 0; }();
@@ -1587,7 +1616,7 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
             uint32_t tile_rows = (glds && !small && big_rows == 256) ? 256u : (uint32_t)SCAN_BR;
             if (h16) tile_rows = small ? 128u : 256u;
             a.V16 = h->rows16; a.ld16 = h->ld16;
-            if (i8c) { a.V16 = reinterpret_cast<const _Float16*>(bin_mfma ? h->bpm : h->sq8); a.ld16 = h->ld8; }
+            if (i8c) { a.V16 = reinterpret_cast<const _Float16*>(bin_mfma ? h->bpm : (aug ? h->sq8a : (cosq ? h->sq8c : h->sq8))); a.ld16 = aug ? h->ld8a : h->ld8; }
             if (glds && !small && big_rows == 192 && metric == M_IP) tile_rows = 192u;
             a.qpad = qpad; a.nq = nq; a.nslab = nslab; a.ntiles = (s.r1 - s.r0 + tile_rows - 1) / tile_rows;
             if (s.sample_tiles) a.ntiles = s.sample_tiles;
@@ -1693,7 +1722,8 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
         }
         SelectArgs sa{};
         sa.cand = w.cand; sa.count = w.count; sa.overflow = w.overflow; sa.thr = w.thr; sa.marg2 = w.marg2;
-        sa.k = k; sa.cap = w.cap; sa.keep_max = w.cap / 2; sa.metric = bin_mfma ? (int)M_IP : metric; sa.ip_form = ip_form;   // (bin_mfma: the keys are best-first +-1 dot products)
+        sa.k = k; sa.cap = w.cap; sa.keep_max = w.cap / 2; sa.metric = key_metric; sa.ip_form = ip_form;   // (bin_mfma: best-first +-1 dot products; aug: negated squared L2)
+        sa.neg_metric1 = (aug || cosq) ? metric + 1 : 0;
         sa.exact = binary ? 1 : 0;
         static const int tighten_env = []() { const char* e = getenv("LYNSE_HIP_TIGHTEN"); return e ? atoi(e) : 1; }();
         // (worth its ~k exact rescorings per query and stage where the margin is wide — the int8 pass — or k is small)
@@ -1722,8 +1752,9 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
                             (plan_used_segments ? 8u : 0u) | (small ? 16u : 0u) | (fs ? 128u : 0u) | ((uint64_t)(plan.size() & 0xff) << 8) | (tiling << 16);
     }
     FinalArgs fa{};
-    fa.cand = w.cand; fa.count = w.count; fa.k = k; fa.out_k = out_k; fa.cap = w.cap; fa.metric = bin_mfma ? (int)M_IP : metric; fa.ip_form = ip_form;
+    fa.cand = w.cand; fa.count = w.count; fa.k = k; fa.out_k = out_k; fa.cap = w.cap; fa.metric = key_metric; fa.ip_form = ip_form;
     fa.ham_dim = bin_mfma ? h->dim : 0u;
+    fa.neg_metric1 = (aug || cosq) ? metric + 1 : 0;
     fa.exact = binary ? 1 : 0; fa.Qf = Qf; fa.V = score_rows(h); fa.ld = score_ld(h); fa.D = h->dim;
     fa.row_stride = h->row_stride; fa.row_offset = h->row_offset;
     fa.out_rows = r_dst ? r_dst : w.out_rows; fa.out_dists = d_dst ? d_dst : w.out_dists; fa.out_counts = w.out_counts;
@@ -1845,6 +1876,83 @@ static int ensure_sq8_locked(lynse_hip_flat* h) {
     h->sq8_a1 = qst[0];
     h->sq8_finite = qst[1] == 0;
     h->n_sq8 = h->n;
+    return LYNSE_OK;
+}
+
+// The augmented code set of the L2 form (rows [v, |v|^2]): rebuilt over all rows when rows were appended, like the SQ8 set.
+static int ensure_sq8a_locked(lynse_hip_flat* h) {
+    if (h->n_sq8a == h->n && h->sq8a) return LYNSE_OK;
+    const uint32_t DA = h->dim + h->aug_cols;
+    if (h->sq8a_cap < h->n) {
+        if (h->sq8a) (void)hipFree(h->sq8a);
+        h->sq8a = nullptr;
+        const uint64_t cap = std::max<uint64_t>(h->capacity, h->n);
+        LY_HIP(hipMalloc(&h->sq8a, (size_t)cap * h->ld8a + 256));
+        h->sq8a_cap = cap;
+    }
+    if (!h->sq8a_mins) {
+        LY_HIP(hipMalloc(&h->sq8a_mins, (size_t)DA * 4));
+        LY_HIP(hipMalloc(&h->sq8a_scales, (size_t)DA * 4));
+        LY_HIP(hipMalloc(&h->sq8a_mm, (size_t)DA * 8));
+        LY_HIP(hipMalloc(&h->sq8a_stats, 8));
+    }
+    LY_HIP(hipMemsetAsync(h->sq8a_stats, 0, 8, cur(h).stream));
+    std::vector<uint32_t> init((size_t)DA * 2);
+    for (uint32_t d = 0; d < DA; ++d) { init[d] = f32_to_ord(INFINITY); init[DA + d] = f32_to_ord(-INFINITY); }
+    LY_HIP(hipMemcpyAsync(h->sq8a_mm, init.data(), init.size() * 4, hipMemcpyHostToDevice, cur(h).stream));
+    const uint32_t gx = (h->dim + 255) / 256;
+    const uint32_t gy = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(h->n / 256, 1), (uint64_t)h->num_cu * 8);
+    hipLaunchKernelGGL(k_sq8_minmax, dim3(gx, gy), dim3(256), 0, cur(h).stream, h->rows, h->ld, h->dim, h->n, h->sq8a_mm, h->sq8a_mm + DA);
+    hipLaunchKernelGGL(k_vec_minmax, dim3((uint32_t)std::min<uint64_t>((h->n + 255) / 256, (uint64_t)h->num_cu * 8)), dim3(256), 0, cur(h).stream,
+                       h->vn2, h->n, h->sq8a_mm + h->dim, h->sq8a_mm + DA + h->dim, h->aug_cols);
+    hipLaunchKernelGGL(k_sq8_scales, dim3((DA + 255) / 256), dim3(256), 0, cur(h).stream, h->sq8a_mm, h->sq8a_mm + DA, DA, h->sq8a_mins, h->sq8a_scales);
+    hipLaunchKernelGGL(k_sq8_quantize, dim3((uint32_t)std::min<uint64_t>((h->n + 3) / 4, (uint64_t)h->num_cu * 16)), dim3(256), 0, cur(h).stream,
+                       h->rows, h->ld, h->dim, h->n, h->sq8a_mins, h->sq8a_scales, h->sq8a, h->ld8a, (int*)nullptr, (int*)nullptr, h->sq8a_stats, h->vn2, h->aug_cols);
+    LY_HIP(hipGetLastError());
+    uint32_t qst[2] = {0, 0};
+    LY_HIP(hipMemcpyAsync(qst, h->sq8a_stats, 8, hipMemcpyDeviceToHost, cur(h).stream));
+    LY_HIP(hipStreamSynchronize(cur(h).stream));  // `init` is a temporary
+    h->sq8a_a1 = qst[0];
+    h->sq8a_finite = qst[1] == 0;
+    h->n_sq8a = h->n;
+    return LYNSE_OK;
+}
+
+// The code set of the cosine form: SQ8 codes of the rows scaled to unit norm with the stored reciprocal norm.
+static int ensure_sq8c_locked(lynse_hip_flat* h) {
+    if (h->n_sq8c == h->n && h->sq8c) return LYNSE_OK;
+    const uint32_t D = h->dim;
+    if (h->sq8c_cap < h->n) {
+        if (h->sq8c) (void)hipFree(h->sq8c);
+        h->sq8c = nullptr;
+        const uint64_t cap = std::max<uint64_t>(h->capacity, h->n);
+        LY_HIP(hipMalloc(&h->sq8c, (size_t)cap * h->ld8 + 256));
+        h->sq8c_cap = cap;
+    }
+    if (!h->sq8c_mins) {
+        LY_HIP(hipMalloc(&h->sq8c_mins, (size_t)D * 4));
+        LY_HIP(hipMalloc(&h->sq8c_scales, (size_t)D * 4));
+        LY_HIP(hipMalloc(&h->sq8c_mm, (size_t)D * 8));
+        LY_HIP(hipMalloc(&h->sq8c_stats, 8));
+    }
+    LY_HIP(hipMemsetAsync(h->sq8c_stats, 0, 8, cur(h).stream));
+    std::vector<uint32_t> init((size_t)D * 2);
+    for (uint32_t d = 0; d < D; ++d) { init[d] = f32_to_ord(INFINITY); init[D + d] = f32_to_ord(-INFINITY); }
+    LY_HIP(hipMemcpyAsync(h->sq8c_mm, init.data(), init.size() * 4, hipMemcpyHostToDevice, cur(h).stream));
+    const uint32_t gx = (D + 255) / 256;
+    const uint32_t gy = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(h->n / 256, 1), (uint64_t)h->num_cu * 8);
+    hipLaunchKernelGGL(k_sq8_minmax, dim3(gx, gy), dim3(256), 0, cur(h).stream, h->rows, h->ld, D, h->n, h->sq8c_mm, h->sq8c_mm + D, h->vrinv);
+    hipLaunchKernelGGL(k_sq8_scales, dim3(gx), dim3(256), 0, cur(h).stream, h->sq8c_mm, h->sq8c_mm + D, D, h->sq8c_mins, h->sq8c_scales);
+    hipLaunchKernelGGL(k_sq8_quantize, dim3((uint32_t)std::min<uint64_t>((h->n + 3) / 4, (uint64_t)h->num_cu * 16)), dim3(256), 0, cur(h).stream,
+                       h->rows, h->ld, D, h->n, h->sq8c_mins, h->sq8c_scales, h->sq8c, h->ld8, (int*)nullptr, (int*)nullptr, h->sq8c_stats,
+                       (const float*)nullptr, 0u, h->vrinv);
+    LY_HIP(hipGetLastError());
+    uint32_t qst[2] = {0, 0};
+    LY_HIP(hipMemcpyAsync(qst, h->sq8c_stats, 8, hipMemcpyDeviceToHost, cur(h).stream));
+    LY_HIP(hipStreamSynchronize(cur(h).stream));  // `init` is a temporary
+    h->sq8c_a1 = qst[0];
+    h->sq8c_finite = qst[1] == 0;
+    h->n_sq8c = h->n;
     return LYNSE_OK;
 }
 
@@ -1984,10 +2092,36 @@ static int coarse_env() {
     static const int v = []() { const char* e = getenv("LYNSE_HIP_COARSE"); return !e ? 0 : (!strcmp(e, "i8") ? 2 : (!strcmp(e, "f16") ? 1 : 0)); }();
     return v;
 }
+// per-metric state of the certified int8 pass: IP reads the SQ8 codes of the rows, squared L2 the codes of the augmented rows
+static std::atomic<int>& i8c_strike_counter(lynse_hip_flat* h, int metric) {
+    return metric == M_L2 ? h->i8c_strikes_l2 : (metric == M_COS ? h->i8c_strikes_cos : h->i8c_strikes);
+}
+static bool i8c_codes_ready(const lynse_hip_flat* h, int metric) {
+    if (metric == M_L2) return h->sq8a && h->n_sq8a == h->n;
+    if (metric == M_COS) return h->sq8c && h->n_sq8c == h->n;
+    return h->sq8 && h->n_sq8 == h->n;
+}
+static bool i8c_codes_finite(const lynse_hip_flat* h, int metric) { return metric == M_L2 ? h->sq8a_finite : (metric == M_COS ? h->sq8c_finite : h->sq8_finite); }
+static int ensure_i8c_codes_locked(lynse_hip_flat* h, int metric) {
+    return metric == M_L2 ? ensure_sq8a_locked(h) : (metric == M_COS ? ensure_sq8c_locked(h) : ensure_sq8_locked(h));
+}
+static void i8c_add_strike(lynse_hip_flat* h, int metric) {
+    std::atomic<int>& c = i8c_strike_counter(h, metric);
+    if (c.load() >= 0) c.fetch_add(1);
+}
 static bool i8c_eligible(const lynse_hip_flat* h, int metric, bool filtered, uint64_t nqc, bool view = false) {
     // view: a row-range view of search_large_k (h->n is the range): the SQ8 codes belong to the whole shard
-    return metric == M_IP && !filtered && !view && nqc > SCAN_BQ_SMALL && h->dtype == LYNSE_DTYPE_F32 && scan_variant() == 3 && coarse_env() != 1 &&
-           h->i8c_strikes.load() >= 0 && h->i8c_strikes.load() < 3 && (coarse_env() == 2 || h->n >= 65536);
+    const int strikes = (metric == M_L2 ? h->i8c_strikes_l2 : (metric == M_COS ? h->i8c_strikes_cos : h->i8c_strikes)).load();
+    static const int l2_off = []() { const char* e = getenv("LYNSE_HIP_COARSE_L2"); return e && !strcmp(e, "f16") ? 1 : 0; }();
+    // squared L2 streams round_up(dim + 1, 128) bytes of augmented codes per row against 2 round_up(dim, 8) of the f16 shadow and
+    // rescoring pools ~10x wider: it pays from ~256 dimensions on (MI355X: 10M x 768 x 256 3.97 -> 2.81 ms; 1M x 128, k = 100
+    // 0.24 -> 0.34 ms: stays on the f16 pass)
+    const bool l2_ok = metric == M_L2 && !l2_off && h->dim >= 256 && (uint64_t)h->ld8a * 4 <= (uint64_t)h->ld16 * 2 * 3;
+    // cosine streams the codes of the unit rows (1 B per element, like IP); tiny-norm rows make the f16 pass go exhaustive and
+    // are left to it
+    const bool cos_ok = metric == M_COS && !l2_off && h->dim >= 256 && !h->cos_degenerate;
+    return (metric == M_IP || l2_ok || cos_ok) && !filtered && !view && nqc > SCAN_BQ_SMALL && h->dtype == LYNSE_DTYPE_F32 &&
+           scan_variant() == 3 && coarse_env() != 1 && strikes >= 0 && strikes < 3 && (coarse_env() == 2 || h->n >= 65536);
 }
 
 // Shared driver: q_src is nq x dim f32 (float metrics / f32 binary queries) or nq x words u64
@@ -2047,7 +2181,7 @@ static int search_impl(lynse_hip_flat* h, const void* q_src, bool packed_queries
         }
         if (h->packed_only) return true;  // (rejected below)
         if (h->n_stats != h->n || (scan_variant() == 3 && (h->n16 != h->n || h->sv16 != h->sv))) return false;
-        return !i8c_eligible(h, metric, filtered, std::min<uint64_t>(nq, QCHUNK), caller_holds_exclusive) || (h->sq8 && h->n_sq8 == h->n);
+        return !i8c_eligible(h, metric, filtered, std::min<uint64_t>(nq, QCHUNK), caller_holds_exclusive) || i8c_codes_ready(h, metric);
     };
     // k beyond the candidate capacity of one pass (k > cap / 4 over more than cap rows; the reference accepts any k, and its
     // server caps at MAX_TOP_K = 10,000, src/server/mod.rs:46): row ranges of `cap` rows, each answered exactly, merged.
@@ -2256,9 +2390,9 @@ static int search_impl(lynse_hip_flat* h, const void* q_src, bool packed_queries
         // three such strikes turn the int8 pass off for this handle (margins too wide for this data).
         bool i8c = i8c_eligible(h, metric, filtered, nqc, caller_holds_exclusive);
         if (i8c) {
-            if (xlk.owns_lock()) LY_TRY(ensure_sq8_locked(h));          // lazy build: exclusive path only
-            else if (!(h->sq8 && h->n_sq8 == h->n)) i8c = false;         // (shared path: derived_ready() saw them built)
-            if (i8c && !h->sq8_finite) { h->i8c_strikes.store(-1); i8c = false; }
+            if (xlk.owns_lock()) LY_TRY(ensure_i8c_codes_locked(h, metric));   // lazy build: exclusive path only
+            else if (!i8c_codes_ready(h, metric)) i8c = false;                    // (shared path: derived_ready() saw them built)
+            if (i8c && !i8c_codes_finite(h, metric)) { i8c_strike_counter(h, metric).store(-1); i8c = false; }
         }
         i8c_attempted = i8c_attempted || i8c;
         if (small_path_ok(h, nqc, kk, metric, filtered)) {
@@ -2305,7 +2439,7 @@ static int search_impl(lynse_hip_flat* h, const void* q_src, bool packed_queries
             fallback_queries += nov;
             if (i8c) {  // same plan level again with the f16 coarse pass
                 i8c = false;
-                if (h->i8c_strikes.load() >= 0) h->i8c_strikes.fetch_add(1);
+                i8c_add_strike(h, metric);
                 --level;
                 continue;
             }
@@ -2358,8 +2492,8 @@ extern "C" int lynse_hip_flat_prepare(lynse_hip_flat* h, int metric, uint64_t nq
     if (h->packed_only) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "store holds packed rows; float metrics unavailable");
     LY_TRY(finalize_locked(h));
     if (i8c_eligible(h, metric, false, nqc)) {
-        LY_TRY(ensure_sq8_locked(h));
-        if (!h->sq8_finite) h->i8c_strikes.store(-1);
+        LY_TRY(ensure_i8c_codes_locked(h, metric));
+        if (!i8c_codes_finite(h, metric)) i8c_strike_counter(h, metric).store(-1);
     }
     return LYNSE_OK;
 }
@@ -2374,6 +2508,8 @@ extern "C" uint64_t lynse_hip_flat_hbm_bytes(const lynse_hip_flat* h) {
     if (h->vn2) b += 2ull * (h->stats_capacity + 256) * 4;
     if (h->packed) b += h->packed_capacity * h->words * 8ull;
     if (h->sq8) b += h->sq8_cap * h->ld8 + 2ull * (h->sq8_cap + 256) * 4;
+    if (h->sq8a) b += h->sq8a_cap * h->ld8a;
+    if (h->sq8c) b += h->sq8c_cap * h->ld8;
     if (h->bpm) b += h->bpm_cap * h->ld8;
     return b;
 }
@@ -2653,7 +2789,7 @@ extern "C" int lynse_hip_top_k_search(const float* query, const float* candidate
     lynse_hip_flat* h = sc.h;
     {   // empty the shard (capacity and buffers stay)
         std::unique_lock<std::shared_mutex> lk(h->rw);
-        h->n = 0; h->n_stats = 0; h->n16 = 0; h->n_packed = 0; h->n_sq8 = 0; h->n_bpm = 0; h->i8c_strikes.store(0);
+        h->n = 0; h->n_stats = 0; h->n16 = 0; h->n_packed = 0; h->n_sq8 = 0; h->n_sq8a = 0; h->n_sq8c = 0; h->n_bpm = 0; h->i8c_strikes.store(0); h->i8c_strikes_l2.store(0); h->i8c_strikes_cos.store(0);
         h->amax = h->vmax = h->vmin = 0.f; h->sv = 1.f; h->cos_degenerate = 0;
         const uint32_t init[4] = {0u, 0u, 0x7f800000u, 0u};
         LY_TRY(use_device(h));

@@ -91,6 +91,36 @@ def test_c2_flat_ip_768_batch256_runs_the_benchmarked_kernels(L, oracle):
     assert np.array_equal(r8, rows[:8]) and np.array_equal(d8.view(np.uint32), dists[:8].view(np.uint32))
 
 
+def test_l2_768_batch256_runs_the_certified_int8_pass(L, oracle):
+    """FLAT-L2 2.4M x 768, 256 queries, k=10 (north_star: "batched cosine/IP/L2"): the certified int8 pass in its L2 form
+    (augmented inner product, negated score space) on the kernels of config 2 — plan pinned, ids and distance bits equal the
+    oracle's exact_flat_search with the difference-form L2 kernel (simd.rs:1529-1581)."""
+    n, dim, nq, k = 2_400_000, 768, 256, 10
+    rng = np.random.default_rng(43)
+    idx = L.FlatIndex(None, dim)
+    idx.reserve(n)
+    data = np.empty((n, dim), f32)
+    for b in range(0, n, 200_000):
+        e = min(n, b + 200_000)
+        rng.random(out=data[b:e], dtype=f32)
+        idx.write(data[b:e])
+    q_rows = np.sort(rng.integers(0, n, nq))
+    queries = (data[q_rows] + 0.03 * rng.standard_normal((nq, dim)).astype(f32)).astype(f32)
+    idx.finalize()
+    idx.prepare("l2", nq)
+    idx.profile_enable(True)
+    idx.profile_get(reset=True)
+    rows, dists, counts = idx.search_batch_arrays(queries, k, "l2")
+    p = idx.profile_get(reset=True)
+    flags, stages, tiling = plan_fields(p)
+    assert p["fallback_queries"] == 0 and tiling == 0x24 and flags & PLAN_I8C and flags & PLAN_SAMPLED and flags & PLAN_THRESHOLD_ONLY, (p, bin(flags))
+    for qi in (0, 1, 31, 32, 100, 128, 200, 255):
+        assert_rows_equal(oracle.canonical_topk(queries[qi], data, k, O.L2), rows[qi], dists[qi], counts[qi], ("l2", qi))
+        assert rows[qi, 0] == q_rows[qi]
+    r8, d8, c8 = idx.search_batch_arrays(queries[:8], k, "l2")      # the <= 32-query kernel over the f16 shadow: same answers
+    assert np.array_equal(r8, rows[:8]) and np.array_equal(d8.view(np.uint32), dists[:8].view(np.uint32))
+
+
 def test_c3_flat_l2_sift_like_1m_k100(L, oracle):
     from lynsedb_amd.datasets import sift_like
 

@@ -28,7 +28,7 @@ def L():
     return L_
 
 
-def run_case(L, oracle, data, queries, k, tag, expect_i8c_kept=True, check=CHECK):
+def run_case(L, oracle, data, queries, k, tag, expect_i8c_kept=True, check=CHECK, metric="ip"):
     n, dim = data.shape
     idx = L.FlatIndex(None, dim)
     idx.reserve(n)
@@ -37,7 +37,7 @@ def run_case(L, oracle, data, queries, k, tag, expect_i8c_kept=True, check=CHECK
     idx.finalize()
     idx.profile_enable(True)
     idx.profile_get(reset=True)
-    rows, dists, counts = idx.search_batch_arrays(queries, k, "ip")
+    rows, dists, counts = idx.search_batch_arrays(queries, k, metric)
     p = idx.profile_get(reset=True)
     flags = int(p["last_plan"]) & 0xff
     assert flags & PLAN_I8C_STARTED, (tag, "the search did not start on the certified int8 pass", bin(flags))
@@ -46,7 +46,7 @@ def run_case(L, oracle, data, queries, k, tag, expect_i8c_kept=True, check=CHECK
     for qi in check:
         if qi >= len(queries):
             continue
-        e_ids, e_d = oracle.canonical_topk(queries[qi], data, k, O.IP)
+        e_ids, e_d = oracle.canonical_topk(queries[qi], data, k, {"ip": O.IP, "l2": O.L2, "cosine": O.COS}[metric])
         c = int(counts[qi])
         assert c == len(e_ids), (tag, qi, c)
         assert np.array_equal(rows[qi, :c].astype(np.uint64), e_ids.astype(np.uint64)), (tag, qi, rows[qi, :c], e_ids)
@@ -168,3 +168,69 @@ def test_many_queries_tie_for_the_same_rows(L, oracle):
     queries = np.repeat(rng.random((1, dim), dtype=f32), nq, axis=0)
     idx, p, (rows, dists, counts) = run_case(L, oracle, data, queries, k, "same_query")
     assert np.all(rows == rows[0]) and np.array_equal(rows[0], dup[:k].astype(np.uint64))
+
+
+# ---- squared L2 on the certified int8 pass: an inner product of augmented vectors q' = [2q, -1], v' = [v, |v|^2] in the negated
+# score space (kernels.h, I8cPrepArgs::aug; l2_squared, simd.rs:1529-1581)
+def test_l2_unit_gaussian_768(L, oracle):
+    rng = np.random.default_rng(2001)
+    n, dim, nq, k = 500_000, 768, 256, 10
+    data = unit_rows(rng, n, dim)
+    queries = unit_rows(rng, nq, dim)
+    queries[::2] = (data[rng.integers(0, n, nq // 2)] + 0.02 * rng.standard_normal((nq // 2, dim)).astype(f32)).astype(f32)
+    run_case(L, oracle, data, queries, k, "l2_unit_gaussian", metric="l2")
+
+
+def test_l2_uniform_and_integer_ties(L, oracle):
+    """uniform[0,1) rows (the benchmark's distribution) and small-integer rows whose squared distances are exact integers with
+    huge tie groups: the canonical (distance, row) order must come out of the negated score space unchanged, +0.0 included."""
+    rng = np.random.default_rng(2002)
+    n, dim, nq, k = 300_000, 300, 200, 10            # 300 + 32 augmented columns: three 128-column slabs, the last one ragged in use
+    data = rng.random((n, dim), dtype=f32)
+    queries = (data[rng.integers(0, n, nq)] + 0.03 * rng.standard_normal((nq, dim))).astype(f32)
+    queries[:3] = data[[5, 6, 7]]                     # exact hits: distance +0.0
+    idx, p, (rows, dists, counts) = run_case(L, oracle, data, queries, k, "l2_uniform", metric="l2")
+    assert np.all(dists[:3, 0].view(np.uint32) == 0) and rows[0, 0] == 5
+    ints = rng.integers(0, 4, (200_000, 256)).astype(f32)
+    qi = ints[rng.integers(0, len(ints), 64)].copy()
+    run_case(L, oracle, ints, qi, 20, "l2_integer_ties", metric="l2", check=(0, 1, 33, 63))
+
+
+def test_l2_rows_of_very_different_norms_and_offset_data(L, oracle):
+    """The 8-bit code of |v|^2 is the weak spot of the augmented form: norms spread over orders of magnitude (margin grows, the
+    f16 retry may take over — results stay exact), data far from the origin."""
+    rng = np.random.default_rng(2003)
+    n, dim, nq, k = 250_000, 256, 128, 10
+    data = rng.standard_normal((n, dim)).astype(f32)
+    data *= np.exp(1.0 * rng.standard_normal((n, 1))).astype(f32)
+    queries = (data[rng.integers(0, n, nq)] * (1 + 0.05 * rng.standard_normal((nq, dim)))).astype(f32)
+    run_case(L, oracle, data, queries, k, "l2_lognormal", expect_i8c_kept=False, metric="l2", check=(0, 1, 33, 64, 127))
+    off = (100.0 + rng.random((200_000, 256))).astype(f32)
+    qo = (off[rng.integers(0, len(off), 64)] + 0.05 * rng.standard_normal((64, 256))).astype(f32)
+    run_case(L, oracle, off, qo, k, "l2_offset", expect_i8c_kept=False, metric="l2", check=(0, 1, 33, 63))
+
+
+# ---- cosine distance on the certified int8 pass: inner product of unit vectors (rows coded as fl(v * 1/|v|)), negated score space
+# (kernels.h, I8cPrepArgs::cosine; cosine_distance, simd.rs:1585-1636)
+def test_cosine_768_rows_of_any_length(L, oracle):
+    rng = np.random.default_rng(3001)
+    n, dim, nq, k = 400_000, 768, 256, 10
+    data = rng.standard_normal((n, dim)).astype(f32) * np.exp(rng.standard_normal((n, 1))).astype(f32)   # norms over 2 orders of magnitude
+    data[1000] = 0.0                                     # a zero row: distance 1 by the reference's denom < 1e-30 rule
+    queries = (data[rng.integers(0, n, nq)] * 0.7 + 0.1 * rng.standard_normal((nq, dim))).astype(f32)
+    queries[7] = 0.0                                     # a zero query: every distance is 1, ties by row
+    # (the zero query ties with every row: its candidates overflow and that batch goes down the ladder — results stay exact)
+    run_case(L, oracle, data, queries, k, "cos_768", expect_i8c_kept=False, metric="cosine", check=(0, 1, 7, 31, 32, 100, 128, 255))
+    idx, p, _ = run_case(L, oracle, data, np.delete(queries, 7, axis=0), k, "cos_768_no_zero_query", metric="cosine", check=(0, 1, 100, 254))
+    assert p["fallback_queries"] == 0
+
+
+def test_cosine_uniform_and_offset_data(L, oracle):
+    rng = np.random.default_rng(3002)
+    n, dim, nq, k = 300_000, 256, 100, 10
+    data = rng.random((n, dim), dtype=f32)               # all-positive: cosine similarities crowd near 0.75
+    queries = (data[rng.integers(0, n, nq)] + 0.03 * rng.standard_normal((nq, dim))).astype(f32)
+    run_case(L, oracle, data, queries, k, "cos_uniform", expect_i8c_kept=False, metric="cosine", check=(0, 1, 33, 64, 99))
+    off = (50.0 + rng.standard_normal((150_000, 384))).astype(f32)   # far from the origin: similarities within 1e-3 of 1
+    qo = (off[rng.integers(0, len(off), 64)] + 0.1 * rng.standard_normal((64, 384))).astype(f32)
+    run_case(L, oracle, off, qo, k, "cos_offset", expect_i8c_kept=False, metric="cosine", check=(0, 1, 33, 63))
