@@ -1334,7 +1334,9 @@ __global__ void __launch_bounds__(WQ * WR * 64, (TQ * TR >= 16) ? 1 : ((WQ * WR 
     // register q / 64) and the epilogue fetches its lane's value with ds_bpermute.  Loading them from global memory in the
     // epilogue put every tile's epilogue behind the LDS-DMA still in flight (VM operations retire in order: the load of a
     // 4-byte constant waited for the next slab's 64 KiB) and behind one L2 round trip per column block.
-    constexpr bool QC_REG = QCREG && !TILED && !FILT && !(RAG && WR >= 4);  // (the ragged <2,4,4,2> bodies have no registers to spare: 8 B of scratch with them)
+    // (FILT && I8C: the masked certified-int8 scan — only the DENSE threshold epilogue and the emit-all sample are instantiated
+    // for it, both with registers to spare)
+    constexpr bool QC_REG = QCREG && !TILED && (!FILT || I8C) && !(RAG && WR >= 4);  // (the ragged <2,4,4,2> bodies have no registers to spare: 8 B of scratch with them)
     constexpr int QCN = (TQ * 32 + 63) / 64;
     static_assert(!FS || (QC_REG && I8C), "fused sample stage: the certified int8 pass with register-resident query constants");
     float qc_inv[QCN], qc_extra[QCN], qc_thr[QCN];
@@ -1779,7 +1781,7 @@ __global__ void __launch_bounds__(WQ * WR * 64, (TQ * TR >= 16) ? 1 : ((WQ * WR 
                                     ((mw >> bit) & 1u) ? make_key(sc, (FILT && !TILED && ea->row_ids) ? ea->row_ids[m] : m, ASC) : KEY_SENTINEL;
                         }
                     }
-                } else if (DENSE && I8C && QC_REG && !TILED && !FILT) {
+                } else if (DENSE && I8C && QC_REG && !TILED) {
                     // ---- DENSE threshold stage of the certified int8 pass: while the threshold is loose (the first stage behind
                     // the sample: the int8 margin keeps ~5x the rows an exact threshold would) most 32-query x 64-row blocks
                     // hold a survivor and the two-level filter pays level 2 on top of level 1 almost always.  One pass instead:
@@ -1804,8 +1806,9 @@ __global__ void __launch_bounds__(WQ * WR * 64, (TQ * TR >= 16) ? 1 : ((WQ * WR 
                                     const int r = 4 * g4 + e;
                                     const int v = __float_as_int(acc[i][j][r]);
                                     if (v >= T) {
-                                        const uint32_t m = rb + wr * (TR * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                                        if (m < row_end) {
+                                        const uint32_t bit = (r & 3) + 8 * (r >> 2) + 4 * hi;
+                                        const uint32_t m = rb + wr * (TR * 32) + i * 32 + bit;
+                                        if (m < row_end && (!FILT || ((mw_t[i] >> bit) & 1u))) {   // (FILT: rows outside the subset never become candidates)
                                             const uint64_t key = make_key(c_extra[j] + c_qinv[j] * (float)v, m, ASC);
                                             if (cnt < e_seg) {
                                                 segdst[cnt] = key;

@@ -1256,9 +1256,9 @@ static int launch_scan_h16(const ScanArgs& a, int metric, uint32_t grid, hipStre
 
 // certified int8 coarse pass: the 256 x 256 IP tiling with 3 + 2-stage rings over 128-element slabs, one kernel per
 // (ragged last slab, emission mode)
-static int launch_scan_i8c(const ScanArgs& a, uint32_t grid, hipStream_t st, bool fs = false) {
+static int launch_scan_i8c(const ScanArgs& a, uint32_t grid, hipStream_t st, bool fs = false, bool filt = false) {
     constexpr size_t lds = (size_t)(3 * 256 + 2 * 256) * 128;
-    static bool attr_done[9] = {false};
+    static bool attr_done[11] = {false};
     auto go = [&](auto kern, int slot) -> int {
         if (!attr_done[slot]) { LY_TRY(set_max_lds(kern, lds)); attr_done[slot] = true; }
         hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, a);
@@ -1289,6 +1289,12 @@ static int launch_scan_i8c(const ScanArgs& a, uint32_t grid, hipStream_t st, boo
         }
     }
 #endif
+    if (filt) {  // masked scan (subset as a row bitmask): emit-all sample with sentinels, DENSE threshold stages (kernels.h, FILT && I8C)
+        if (a.ld16 % 128 != 0 || a.row_ids) return set_error(LYNSE_ERR_INTERNAL, "the masked int8 scan needs whole 128-column slabs and a row bitmask");
+        if (a.emit_all == 1) return go(k_scan_h16<2, 4, 4, 2, M_IP, 3, 2, 2, false, false, 0, true, 2, 1>, 9);
+        if (a.emit_all != 0 || !a.dense) return set_error(LYNSE_ERR_INTERNAL, "the masked int8 scan runs emit-all and DENSE threshold stages");
+        return go(k_scan_h16<2, 4, 4, 2, M_IP, 3, 2, 2, false, false, 0, true, 2, 0, 0, true>, 10);
+    }
     if (a.ld16 % 128 == 0) {
         static const int prio = []() { const char* e = getenv("LYNSE_HIP_PRIO"); return e ? atoi(e) : 0; }();
         static bool prattr = false;
@@ -1647,14 +1653,14 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
                 static const int dense_env = []() { const char* e = getenv("LYNSE_HIP_DENSE"); return e ? atoi(e) : -1; }();
                 const uint64_t seen_before = s.sample_tiles ? 0 : (sample.sample_tiles ? std::max<uint64_t>((uint64_t)sample.sample_tiles * plan_tile, s.r0) : s.r0);
                 a.dense = (!a.emit_all && a.ld16 % 128 == 0 && seen_before &&
-                           (dense_env >= 0 ? dense_env != 0 : (uint64_t)k * 50000ull > seen_before)) ? 1 : 0;
+                           (filt || (dense_env >= 0 ? dense_env != 0 : (uint64_t)k * 50000ull > seen_before))) ? 1 : 0;   // (masked: DENSE is the one epilogue compiled with the mask)
                 if (!a.emit_all) seg_geometry(grid, a.dense ? 8 : 4, &a.nseg, &a.seg);
                 if (fs_stage) {
                     a.fs_stride = sample.sample_stride; a.fs_rows = (uint32_t)h->n; a.gsync = w.gsync; a.Qf = Qf; a.marg2 = w.marg2;
                     a.thr_out = w.thr; a.k = k; a.ip_form = ip_form; a.metric = metric;
                     if (getenv("LYNSE_HIP_FS_STAMPS")) a.debug_flags |= 128;
                 }
-                LY_TRY(launch_scan_i8c(a, grid, st, fs_stage));
+                LY_TRY(launch_scan_i8c(a, grid, st, fs_stage, filt));
             } else if (h16) {
                 a.candB = w.candB; a.segcnt = w.segcnt;
                 if (small) {
@@ -2109,7 +2115,9 @@ static void i8c_add_strike(lynse_hip_flat* h, int metric) {
     std::atomic<int>& c = i8c_strike_counter(h, metric);
     if (c.load() >= 0) c.fetch_add(1);
 }
-static bool i8c_eligible(const lynse_hip_flat* h, int metric, bool filtered, uint64_t nqc, bool view = false) {
+static bool i8c_eligible(const lynse_hip_flat* h, int metric, bool filtered, uint64_t nqc, bool view = false, bool masked = false) {
+    // filtered: a subset filter on the gathered-rows strategy (never int8); masked: a subset filter as a row bitmask — the
+    // masked int8 scan (whole 128-column slabs only)
     // view: a row-range view of search_large_k (h->n is the range): the SQ8 codes belong to the whole shard
     const int strikes = (metric == M_L2 ? h->i8c_strikes_l2 : (metric == M_COS ? h->i8c_strikes_cos : h->i8c_strikes)).load();
     static const int l2_off = []() { const char* e = getenv("LYNSE_HIP_COARSE_L2"); return e && !strcmp(e, "f16") ? 1 : 0; }();
@@ -2120,6 +2128,7 @@ static bool i8c_eligible(const lynse_hip_flat* h, int metric, bool filtered, uin
     // cosine streams the codes of the unit rows (1 B per element, like IP); tiny-norm rows make the f16 pass go exhaustive and
     // are left to it
     const bool cos_ok = metric == M_COS && !l2_off && h->dim >= 256 && !h->cos_degenerate;
+    if (masked && metric != M_L2 && h->ld8 % 128 != 0) return false;
     return (metric == M_IP || l2_ok || cos_ok) && !filtered && !view && nqc > SCAN_BQ_SMALL && h->dtype == LYNSE_DTYPE_F32 &&
            scan_variant() == 3 && coarse_env() != 1 && strikes >= 0 && strikes < 3 && (coarse_env() == 2 || h->n >= 65536);
 }
@@ -2388,7 +2397,7 @@ static int search_impl(lynse_hip_flat* h, const void* q_src, bool packed_queries
         // certified int8 coarse pass: FLAT-IP batches of 33..256 queries over an f32 shard with finite values (auto: shards
         // of >= 64K rows; LYNSE_HIP_COARSE=i8 / f16 forces / disables it).  An overflow first retries the f16 coarse pass;
         // three such strikes turn the int8 pass off for this handle (margins too wide for this data).
-        bool i8c = i8c_eligible(h, metric, filtered, nqc, caller_holds_exclusive);
+        bool i8c = i8c_eligible(h, metric, filtered && direct, nqc, caller_holds_exclusive, filtered && !direct);
         if (i8c) {
             if (xlk.owns_lock()) LY_TRY(ensure_i8c_codes_locked(h, metric));   // lazy build: exclusive path only
             else if (!i8c_codes_ready(h, metric)) i8c = false;                    // (shared path: derived_ready() saw them built)

@@ -234,3 +234,62 @@ def test_cosine_uniform_and_offset_data(L, oracle):
     off = (50.0 + rng.standard_normal((150_000, 384))).astype(f32)   # far from the origin: similarities within 1e-3 of 1
     qo = (off[rng.integers(0, len(off), 64)] + 0.1 * rng.standard_normal((64, 384))).astype(f32)
     run_case(L, oracle, off, qo, k, "cos_offset", expect_i8c_kept=False, metric="cosine", check=(0, 1, 33, 63))
+
+
+# ---- subset filter as a row bitmask on the certified int8 pass (k_scan_h16<.., FILT, I8C>: emit-all sample with sentinels for
+# the rows outside the subset, DENSE threshold stages that test the bit next to the integer threshold; search_with_filter,
+# flat_mmap.rs:549-556 / vector_store.rs:1309-1329)
+@pytest.mark.parametrize("metric,dim", [("ip", 768), ("ip", 256), ("l2", 768), ("l2", 300), ("cosine", 384)])
+@pytest.mark.parametrize("frac", [0.5, 0.02])
+def test_masked_scan_runs_the_certified_int8_pass(L, oracle, metric, dim, frac, monkeypatch):
+    monkeypatch.setenv("LYNSE_HIP_FILTER_STRATEGY", "2")
+    rng = np.random.default_rng(4000 + dim + int(frac * 100))
+    n, nq, k = 300_000, 130, 10
+    data = rng.random((n, dim), dtype=f32) if metric != "cosine" else rng.standard_normal((n, dim)).astype(f32)
+    queries = (data[rng.integers(0, n, nq)] + 0.05 * rng.standard_normal((nq, dim))).astype(f32)
+    member = rng.random(n) < frac
+    member[:4096] = False                                   # whole tiles outside the subset
+    member[-300:] = True                                    # ... and the ragged last tile inside it
+    ids = np.nonzero(member)[0].astype(np.uint64)
+    words = np.zeros((n + 63) // 64, np.uint64)
+    np.bitwise_or.at(words, (ids // 64).astype(np.int64), np.uint64(1) << (ids % np.uint64(64)))
+    idx = L.FlatIndex(None, dim)
+    idx.write(data)
+    idx.finalize()
+    idx.profile_enable(True)
+    idx.profile_get(reset=True)
+    rows, dists, counts = idx.search_filtered_bitset_batch_arrays(queries, k, metric, words)
+    p = idx.profile_get(reset=True)
+    flags = int(p["last_plan"]) & 0xff
+    assert flags & PLAN_I8C_STARTED, ("the masked search did not start on the certified int8 pass", bin(flags))
+    assert flags & PLAN_I8C and p["fallback_queries"] == 0, p
+    m = {"ip": O.IP, "l2": O.L2, "cosine": O.COS}[metric]
+    for qi in (0, 1, 31, 32, 33, 64, 127, 128, 129):
+        e_ids, e_d = oracle.canonical_topk_filtered(queries[qi], data, k, m, ids)
+        assert int(counts[qi]) == k
+        assert np.array_equal(rows[qi].astype(np.uint64), e_ids.astype(np.uint64)), (qi, rows[qi], e_ids)
+        assert np.array_equal(dists[qi].view(np.uint32), e_d.view(np.uint32)), (qi, dists[qi], e_d)
+    # the id-list entry point builds the same bitmask
+    r2, d2, c2 = idx.search_filtered_batch_arrays(queries, k, metric, ids)
+    assert np.array_equal(r2, rows) and np.array_equal(d2.view(np.uint32), dists.view(np.uint32))
+
+
+def test_masked_int8_scan_subset_smaller_than_k_and_empty_tiles(L, oracle, monkeypatch):
+    """Fewer subset rows than k (every one of them is returned, the thresholds never tighten) and a subset living in one corner
+    of the shard (most sample tiles hold no member)."""
+    monkeypatch.setenv("LYNSE_HIP_FILTER_STRATEGY", "2")
+    rng = np.random.default_rng(4100)
+    n, dim, nq, k = 200_000, 256, 70, 10
+    data = rng.random((n, dim), dtype=f32)
+    queries = rng.random((nq, dim), dtype=f32)
+    idx = L.FlatIndex(None, dim)
+    idx.write(data)
+    idx.finalize()
+    for ids in (np.array([5, 70_000, 199_999], np.uint64), np.arange(150_000, 151_000, dtype=np.uint64)):
+        rows, dists, counts = idx.search_filtered_batch_arrays(queries, k, "ip", ids)
+        for qi in (0, 33, 69):
+            e_ids, e_d = oracle.canonical_topk_filtered(queries[qi], data, k, O.IP, ids)
+            c = int(counts[qi])
+            assert c == len(e_ids) == min(k, len(ids))
+            assert np.array_equal(rows[qi, :c].astype(np.uint64), e_ids.astype(np.uint64))
+            assert np.array_equal(dists[qi, :c].view(np.uint32), e_d.view(np.uint32))
