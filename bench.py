@@ -436,7 +436,11 @@ def other_configs(dev):
     orc = O.get()
     out = {}
 
+    only = os.environ.get("LYNSE_BENCH_ONLY_CONFIG")   # (development: one of c1 / c3 / c5_share / c4_share)
+
     def guarded(name, fn):
+        if only and name != only:
+            return
         try:
             out[name] = fn()
         except Exception as e:  # noqa: BLE001

@@ -377,6 +377,15 @@ class IvfFlatIndex:
         self._h = handle
         self._dim = dim
 
+    def profile_enable(self, on=True) -> None:
+        check(lib.lynse_hip_ivf_profile_enable(self._h, int(on)))
+
+    def profile_get(self, reset: bool = True) -> dict:
+        """The slab store's profile; `last_plan` bit 2 / bit 6: the last staged chunk ran / started on the certified int8 pass."""
+        p = _lib.Profile()
+        check(lib.lynse_hip_ivf_profile_get(self._h, C.byref(p), 1 if reset else 0))
+        return {f: getattr(p, f) for f, _ in _lib.Profile._fields_}
+
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
         if h:

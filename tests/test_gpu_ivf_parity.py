@@ -602,3 +602,66 @@ def test_ivf_any_k_with_a_subset_and_wide_binary_rows(L, oracle):
             e_ids, e_d, _ = oracle.ivf_search(eq, enc, cen, off, rows, nprobe, k, O.HAMMING, packed=packed)
             c = int(g_c[qi])
             assert c == len(e_ids) and np.array_equal(g_rows[qi, :c], e_ids) and np.array_equal(g_d[qi, :c].view(np.uint32), e_d.view(np.uint32)), (dim, qi)
+
+
+# ---- the staged path on the certified int8 coarse pass (k_scan_h16<.., TILED, I8C>): IP batches of more than 32 queries over
+# an f32 slab of >= 64K rows and whole 128-column slabs scan the SQ8 codes of the probed lists; survivors are rescored exactly
+# from the f32 slab as always (IVFIndex::search, ivf.rs:181-348)
+@pytest.mark.parametrize("n,dim,nlist,nprobe,nq,k,kind,metric", [
+    (120_000, 128, 256, 8, 100, 10, "clustered", IP), (90_000, 256, 64, 64, 40, 25, "gaussian", IP),
+    (200_000, 384, 1024, 16, 256, 10, "uniform", IP), (70_000, 128, 300, 5, 33, 100, "clustered", IP),
+    (150_000, 256, 512, 12, 130, 10, "uniform", L2), (100_000, 300, 128, 9, 64, 10, "clustered", L2),
+    (150_000, 384, 512, 12, 130, 10, "gaussian", COS), (80_000, 256, 100, 100, 48, 20, "clustered", COS),
+])
+def test_ivf_staged_path_on_the_certified_int8_pass(L, oracle, n, dim, nlist, nprobe, nq, k, kind, metric):
+    rng = np.random.default_rng(n + dim + nlist + nq)
+    if kind == "clustered":
+        centers = rng.standard_normal((nlist // 2, dim)).astype(f32)
+        data = (centers[rng.integers(0, centers.shape[0], n)] + 0.3 * rng.standard_normal((n, dim))).astype(f32)
+    elif kind == "gaussian":
+        data = rng.standard_normal((n, dim)).astype(f32)
+    else:
+        data = rng.random((n, dim), dtype=f32)
+    queries = (data[rng.integers(0, n, nq)] + 0.05 * rng.standard_normal((nq, dim))).astype(f32)
+    # (the partitions only have to be SOME centroids + assignments: a short device k-means, exported and fed to both sides)
+    built = L.IvfFlatIndex.build(None, data, dim, nlist, 2, NAME[metric], l2_partitions=False)
+    cen, asg, _, _ = built.export()
+    del built
+    idx = L.IvfFlatIndex.load(data, cen, asg, NAME[metric])
+    off, rows = oracle.lists_from_assignments(asg, cen.shape[0])
+    idx.profile_enable(True)
+    g_rows, g_d, g_c = idx.search_batch_arrays(queries, k, nprobe)
+    p = idx.profile_get()
+    assert int(p["last_plan"]) & 64, ("the staged IVF search did not start on the int8 pass", p["last_plan"])
+    assert int(p["last_plan"]) & 4, ("the int8 pass overflowed on benign data", p["last_plan"])
+    for qi in sorted({0, 1, 31, 32, nq // 2, nq - 1}):
+        e_ids, e_d, _ = oracle.ivf_search(queries[qi], data, cen, off, rows, nprobe, k, metric)
+        c = int(g_c[qi])
+        assert c == len(e_ids), (qi, c, len(e_ids))
+        assert np.array_equal(g_d[qi, :c].view(np.uint32), e_d.view(np.uint32)), (qi, g_d[qi, :c], e_d)
+        assert np.array_equal(g_rows[qi, :c], e_ids), (qi, g_rows[qi, :c], e_ids)
+    # 32 queries or fewer stay on the f16 shadow: the same answers
+    r2, d2, c2 = idx.search_batch_arrays(queries[:20], k, nprobe)
+    assert not (int(idx.profile_get()["last_plan"]) & 64)
+    assert np.array_equal(r2, g_rows[:20]) and np.array_equal(d2.view(np.uint32), g_d[:20].view(np.uint32))
+
+
+def test_ivf_int8_pass_overflow_goes_back_to_the_f16_shadow(L, oracle):
+    """One row with 1e4 in one dimension collapses that dimension's SQ8 scale: the int8 margin lets every probed row through,
+    the candidate pool overflows, the chunk is answered by the f16 shadow (a strike), results stay exact."""
+    rng = np.random.default_rng(5150)
+    n, dim, nlist, nprobe, nq, k = 100_000, 128, 32, 8, 64, 10
+    data = rng.standard_normal((n, dim)).astype(f32)
+    data[4321, 9] = 1.0e4
+    queries = rng.standard_normal((nq, dim)).astype(f32)
+    cen, asg = oracle.kmeans_train(data[:4000], nlist, 3, IP)
+    asg = np.concatenate([asg, rng.integers(0, cen.shape[0], n - 4000).astype(asg.dtype)])
+    idx = L.IvfFlatIndex.load(data, cen, asg, "ip")
+    off, rows = oracle.lists_from_assignments(asg, cen.shape[0])
+    idx.profile_enable(True)
+    g_rows, g_d, g_c = idx.search_batch_arrays(queries, k, nprobe)
+    plan = int(idx.profile_get()["last_plan"])
+    assert plan & 64
+    for qi in (0, 33, 63):
+        e_ids, e_d, _ = oracle.ivf_search(queries[qi], data, cen, off, rows, nprobe, k, IP)
+        assert np.array_equal(g_rows[qi], e_ids) and np.array_equal(g_d[qi].view(np.uint32), e_d.view(np.uint32))
