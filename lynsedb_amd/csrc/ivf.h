@@ -115,6 +115,172 @@ __global__ void __launch_bounds__(256) k_ivf_gather_q(const _Float16* __restrict
 }
 
 // ------------------------------------------------------------------------------------------------
+// Device-side grouping of a batch's (query, list) pairs (the host loop of ivf_search_chunk_staged, on the device): pairs
+// grouped by list (a counting sort over the lists with LDS atomics: the order of the queries inside a list is whatever the
+// atomics make it — results do not depend on it, every candidate goes through the canonical select), lists cut into groups of
+// at most 32 queries (one 32-query image each), and the tile lists of the three position windows [0, a0), [a0, 16 a0),
+// [16 a0, ..) of every probed list.  Everything the scan launches need stays in device memory: the tile counts are read by
+// k_scan_h16 through ScanArgs::ntiles_dev, the group count by k_ivf_gather_groups / k_ivf_emit_tiles.  One workgroup: at most
+// IVF_GROUP_MAX_PAIRS pairs and IVF_GROUP_MAX_LISTS lists (its LDS); anything larger keeps the host path.
+// ------------------------------------------------------------------------------------------------
+constexpr uint32_t IVF_GROUP_MAX_PAIRS = 8192;
+constexpr uint32_t IVF_GROUP_MAX_LISTS = 8192;
+
+struct IvfGroup {
+    uint32_t list, pair0, nq, qimg_off;   // qimg_off in halves (16-bit units), like IvfTile
+};
+
+struct IvfGroupArgs {
+    const uint64_t* probes64;  // [nq][np]: the centroid ranking as row ids of the centroid store (exact routing) — or NULL
+    const uint32_t* probes32;  // [nq][np]: k_ivf_route's output
+    uint32_t nq, np, nlist;
+    const uint64_t* offsets;   // [nlist + 1] slab offsets of the lists
+    uint32_t gimg_halves;      // halves per group image
+    uint32_t a0, tile_rows;
+    uint32_t win_cap;          // tiles reserved per window in `tiles`
+    uint32_t flag_empty;       // IVFIndex: a query whose probed lists are all empty scans EVERY list (ivf.rs:258-265): flagged, host path
+    uint32_t* pair_q;          // out [pairs]: the query of pair slot i (slots grouped by list)
+    IvfGroup* groups;          // out [groups]
+    uint32_t* tbase;           // out [3][gmax]: first tile of group g in window w
+    uint32_t gmax;
+    IvfTile* tiles;            // out [3][win_cap] (k_ivf_emit_tiles)
+    uint32_t* hdr;             // out: [0] groups, [1..3] tiles of window 0..2, [4] host path needed, [5] pairs
+};
+
+// inclusive scan of v[0, n) in place by one workgroup of NT threads; tot: NT / 64 words of LDS
+template <int NT>
+__device__ inline void ivf_block_scan(uint32_t* v, uint32_t n, uint32_t* tot) {
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t ch = (n + NT - 1) / NT;
+    const uint32_t b = tid * ch < n ? tid * ch : n, e = b + ch < n ? b + ch : n;
+    uint32_t acc = 0;
+    for (uint32_t i = b; i < e; ++i) { acc += v[i]; v[i] = acc; }
+    uint32_t inc = acc;   // wave-level inclusive scan of the thread totals
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t t = (uint32_t)__shfl_up((int)inc, off, 64);
+        if ((int)lane >= off) inc += t;
+    }
+    if (lane == 63) tot[wave] = inc;
+    __syncthreads();
+    uint32_t wpre = 0;
+    for (uint32_t x = 0; x < wave; ++x) wpre += tot[x];
+    const uint32_t pre = wpre + inc - acc;
+    for (uint32_t i = b; i < e; ++i) v[i] += pre;
+    __syncthreads();
+}
+
+template <int NT>
+__global__ void __launch_bounds__(NT) k_ivf_group(IvfGroupArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char ivf_smem[];
+    const uint32_t P = a.nq * a.np, NL = a.nlist;
+    uint32_t* cnt = reinterpret_cast<uint32_t*>(ivf_smem);   // [NL] pairs per list
+    uint32_t* pinc = cnt + NL;                                // [NL] inclusive scan of cnt; later tiles per group (<= P entries)
+    uint32_t* ginc = pinc + (NL > P ? NL : P);                // [NL] inclusive scan of the groups per list
+    uint32_t* prank = ginc + NL;                              // [P]  rank of pair i inside its list, ~0 = no pair
+    uint32_t* tot = prank + P;                                // [NT / 64]
+    uint32_t* qcnt = tot + NT / 64;                           // [256] valid pairs per query
+    __shared__ uint32_t s_flag;
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t c = tid; c < NL; c += NT) cnt[c] = 0;
+    if (tid < 256) qcnt[tid] = 0;
+    if (tid == 0) s_flag = 0;
+    __syncthreads();
+    for (uint32_t i = tid; i < P; i += NT) {
+        const uint64_t c64 = a.probes64 ? a.probes64[i] : (uint64_t)a.probes32[i];
+        uint32_t r = 0xffffffffu;
+        if (c64 < NL && a.offsets[c64 + 1] > a.offsets[c64]) {
+            r = atomicAdd(&cnt[(uint32_t)c64], 1u);
+            atomicAdd(&qcnt[i / a.np], 1u);
+        }
+        prank[i] = r;
+    }
+    __syncthreads();
+    if (a.flag_empty && tid < a.nq && qcnt[tid] == 0) s_flag = 1;
+    for (uint32_t c = tid; c < NL; c += NT) { pinc[c] = cnt[c]; ginc[c] = (cnt[c] + 31) / 32; }
+    __syncthreads();
+    ivf_block_scan<NT>(pinc, NL, tot);
+    ivf_block_scan<NT>(ginc, NL, tot);
+    const uint32_t nv = NL ? pinc[NL - 1] : 0u, G = NL ? ginc[NL - 1] : 0u;
+    for (uint32_t i = tid; i < P; i += NT) {
+        const uint32_t r = prank[i];
+        if (r != 0xffffffffu) {
+            const uint32_t c = (uint32_t)(a.probes64 ? a.probes64[i] : (uint64_t)a.probes32[i]);
+            a.pair_q[pinc[c] - cnt[c] + r] = i / a.np;
+        }
+    }
+    for (uint32_t c = tid; c < NL; c += NT) {
+        const uint32_t m = cnt[c];
+        if (m) {
+            const uint32_t p0 = pinc[c] - m, gb = ginc[c] - (m + 31) / 32;
+            for (uint32_t j = 0; j * 32 < m; ++j)
+                a.groups[gb + j] = {c, p0 + 32 * j, m - 32 * j < 32u ? m - 32 * j : 32u, (gb + j) * a.gimg_halves};
+        }
+    }
+    __syncthreads();
+    // first tile of every group in each of the three position windows (groups in list order inside a window)
+    uint32_t* tcnt = pinc;   // [G <= P]
+    for (int w = 0; w < 3; ++w) {
+        const uint64_t wlo = w == 0 ? 0ull : (w == 1 ? (uint64_t)a.a0 : (uint64_t)a.a0 * 16);
+        const uint64_t whi = w == 0 ? (uint64_t)a.a0 : (w == 1 ? (uint64_t)a.a0 * 16 : ~0ull);
+        for (uint32_t g = tid; g < G; g += NT) {
+            const uint32_t c = a.groups[g].list;
+            const uint64_t len = a.offsets[c + 1] - a.offsets[c];
+            const uint64_t lo = wlo < len ? wlo : len, hi = whi < len ? whi : len;
+            tcnt[g] = (uint32_t)((hi - lo + a.tile_rows - 1) / a.tile_rows);
+        }
+        __syncthreads();
+        ivf_block_scan<NT>(tcnt, G, tot);
+        for (uint32_t g = tid; g < G; g += NT) a.tbase[(size_t)w * a.gmax + g] = g ? tcnt[g - 1] : 0u;
+        if (tid == 0) {
+            const uint32_t total = G ? tcnt[G - 1] : 0u;
+            a.hdr[1 + w] = total < a.win_cap ? total : a.win_cap;
+            if (total > a.win_cap) s_flag = 1;   // (the host's bound makes this unreachable; never scan a truncated list silently)
+        }
+        __syncthreads();
+    }
+    if (tid == 0) { a.hdr[0] = G; a.hdr[4] = s_flag; a.hdr[5] = nv; }
+}
+
+// the tile records of every (window, group): one thread each
+__global__ void __launch_bounds__(256) k_ivf_emit_tiles(IvfGroupArgs a) {
+    const uint32_t G = a.hdr[0];
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (uint64_t)G * 3; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t w = (uint32_t)(i / G), g = (uint32_t)(i % G);
+        const uint64_t wlo = w == 0 ? 0ull : (w == 1 ? (uint64_t)a.a0 : (uint64_t)a.a0 * 16);
+        const uint64_t whi = w == 0 ? (uint64_t)a.a0 : (w == 1 ? (uint64_t)a.a0 * 16 : ~0ull);
+        const IvfGroup gr = a.groups[g];
+        const uint64_t b0 = a.offsets[gr.list], len = a.offsets[gr.list + 1] - b0;
+        const uint64_t lo = wlo < len ? wlo : len, hi = whi < len ? whi : len;
+        uint32_t t = a.tbase[(size_t)w * a.gmax + g];
+        for (uint64_t r = lo; r < hi; r += a.tile_rows, ++t)
+            if (t < a.win_cap)
+                a.tiles[(size_t)w * a.win_cap + t] = {(uint32_t)(b0 + r), (uint32_t)(hi - r < a.tile_rows ? hi - r : a.tile_rows), gr.qimg_off, gr.pair0, gr.nq};
+    }
+}
+
+// The 32-query image of every group from the batch image (both in the 8-slot line layout of k_scan_h16: f16 layout 2 and the
+// int8 image); slots past the group's queries are zeroed (no memset of the group images).  One thread per 16-B slot.
+__global__ void __launch_bounds__(256) k_ivf_gather_groups(const _Float16* __restrict__ base, uint32_t qpad, _Float16* __restrict__ gimg,
+                                                           const IvfGroup* __restrict__ groups, const uint32_t* __restrict__ pair_q,
+                                                           const uint32_t* __restrict__ hdr, uint32_t nslab) {
+    const uint64_t total = (uint64_t)hdr[0] * 32 * nslab * 8;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t l = (uint32_t)(i & 7);
+        const uint32_t s = (uint32_t)((i >> 3) % nslab);
+        const uint32_t n = (uint32_t)(((i >> 3) / nslab) & 31);
+        const uint32_t g = (uint32_t)(((i >> 3) / nslab) >> 5);
+        const IvfGroup gr = groups[g];
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (n < gr.nq) {
+            const uint32_t q = pair_q[gr.pair0 + n];
+            v = *reinterpret_cast<const u32x4*>(base + (((size_t)s * qpad + q) * 8 + (l ^ ((q >> 1) & 7))) * 8);
+        }
+        *reinterpret_cast<u32x4*>(gimg + gr.qimg_off + (((size_t)s * 32 + n) * 8 + (l ^ ((n >> 1) & 7))) * 8) = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // k-means helpers (kmeans.rs).  Assignment is a FLAT k=1 search of the rows against the centroid
 // matrix (same canonical arithmetic and first-smaller-wins tie rule, kmeans.rs:237-264); the update
 // sums each cluster's rows in ascending row order with one thread per dimension — the SEQUENTIAL

@@ -474,6 +474,7 @@ struct ScanArgs {
     // f16 image starts at Q16 + qimg_off halves; local query n of the group is query pair_q[pair0+n]
     const struct IvfTile* tiles;
     const uint32_t* pair_q;
+    const uint32_t* ntiles_dev;   // work-list mode: the number of tiles lives in device memory (k_ivf_group built the list); NULL: ntiles
     unsigned long long* dbg;  // debug_flags & 64: per-block phase cycle sums [block][wave][4]: wait, barrier, issue, compute
     // Fused sample stage (k_scan_h16<..., FS = 1>): workgroup b first scores sample tile b (rows [b * fs_stride, +BR) of the
     // WHOLE shard, fs_rows rows), publishes its lane-max keys, and the grid agrees on the first thresholds inside the
@@ -1294,7 +1295,8 @@ __global__ void __launch_bounds__(WQ * WR * 64, (TQ * TR >= 16) ? 1 : ((WQ * WR 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wq = wave % WQ, wr = wave / WQ;
 
-    if (blockIdx.x >= a.ntiles) return;
+    const uint32_t ntiles_ = (TILED && a.ntiles_dev) ? __builtin_amdgcn_readfirstlane(*a.ntiles_dev) : a.ntiles;
+    if (blockIdx.x >= ntiles_) return;
     [[maybe_unused]] const unsigned long long t_kernel0 = FS ? __builtin_amdgcn_s_memtime() : 0ull;
     // blockIdx.y: which chunk of BQ queries this workgroup scores (one launch scores a.qpad / BQ chunks against the same rows:
     // the k-means assignment step searches thousands of rows against a few thousand centroids); 0 for ordinary searches
@@ -1303,7 +1305,7 @@ __global__ void __launch_bounds__(WQ * WR * 64, (TQ * TR >= 16) ? 1 : ((WQ * WR 
     // shard), then its ordinary tiles blockIdx.x, blockIdx.x + grid, ... of [row0, row1) — the tile counters start one grid
     // stride below blockIdx.x (modulo 2^32) so that the ordinary advance lands on blockIdx.x
     static_assert(!FS || (!TILED && !FILT && EMIT == 0), "fused sample stage: unfiltered threshold stages of the FLAT scan");
-    const uint32_t my_tiles = (a.ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x + (FS ? 1u : 0u);
+    const uint32_t my_tiles = (ntiles_ - blockIdx.x + gridDim.x - 1) / gridDim.x + (FS ? 1u : 0u);
     const uint32_t G = my_tiles * a.nslab;
     const uint32_t tstride = a.tile_stride ? a.tile_stride : (uint32_t)BR;
     const bool ragged_k = RAG && (a.ld16 % KS) != 0;  // last slab reaches past ld16: clamp columns (they meet zeros in the query image)
