@@ -665,3 +665,36 @@ def test_ivf_int8_pass_overflow_goes_back_to_the_f16_shadow(L, oracle):
     for qi in (0, 33, 63):
         e_ids, e_d, _ = oracle.ivf_search(queries[qi], data, cen, off, rows, nprobe, k, IP)
         assert np.array_equal(g_rows[qi], e_ids) and np.array_equal(g_d[qi].view(np.uint32), e_d.view(np.uint32))
+
+
+@pytest.mark.parametrize("metric", [IP, L2, COS])
+def test_ivf_device_side_grouping_equals_the_host_path(L, oracle, metric, monkeypatch):
+    """k_ivf_group / k_ivf_emit_tiles / k_ivf_gather_groups against the host loop they replace (LYNSE_HIP_IVF_DEVICE_GROUPING=0)
+    and the oracle: many queries per list (groups of 32 split), lists left empty, a query that probes ONLY empty lists in the
+    middle of the batch (IVFIndex then scans every list, ivf.rs:258-265: the kernel flags it, the host path answers), lists
+    longer than the second position window."""
+    rng = np.random.default_rng(700 + metric)
+    n, dim, nlist, nq, k = 60_000, 64, 48, 150, 10
+    centers = rng.standard_normal((12, dim)).astype(f32)
+    data = (centers[rng.integers(0, 12, n)] + 0.25 * rng.standard_normal((n, dim))).astype(f32)
+    cen, asg, off, rows = oracle_ivf(oracle, data, nlist, metric, iters=3)
+    far = (200.0 + np.arange(3 * dim, dtype=f32)).reshape(3, dim)      # three centroids that own no row
+    cen = np.concatenate([cen, far])
+    off, rows = oracle.lists_from_assignments(asg, cen.shape[0])
+    idx = L.IvfFlatIndex.load(data, cen, asg, NAME[metric])
+    queries = (data[rng.integers(0, n, nq)] + 0.05 * rng.standard_normal((nq, dim))).astype(f32)
+    for nprobe, with_far in ((6, False), (1, False), (20, False), (2, True)):
+        qs = queries.copy()
+        if with_far:
+            qs[77] = far[2] if metric != COS else far[1]
+        got = {}
+        for dg in ("1", "0"):
+            monkeypatch.setenv("LYNSE_HIP_IVF_DEVICE_GROUPING", dg)
+            got[dg] = idx.search_batch_arrays(qs, k, nprobe)
+        assert np.array_equal(got["1"][0], got["0"][0]) and np.array_equal(got["1"][2], got["0"][2])
+        assert np.array_equal(got["1"][1].view(np.uint32), got["0"][1].view(np.uint32))
+        for qi in (0, 31, 32, 77, 149):
+            e_ids, e_d, _ = oracle.ivf_search(qs[qi], data, cen, off, rows, nprobe, k, metric)
+            c = int(got["1"][2][qi])
+            assert c == len(e_ids) and np.array_equal(got["1"][0][qi, :c], e_ids), (nprobe, with_far, qi, got["1"][0][qi, :c], e_ids)
+            assert np.array_equal(got["1"][1][qi, :c].view(np.uint32), e_d.view(np.uint32))
