@@ -315,6 +315,10 @@ def main():
             # OUTSIDE the headline's timed region: the same workload on a second distribution (the certified int8 margin is
             # data dependent) and the other BASELINE.json configurations at one GPU's share, each with its own time, rate,
             # roofline fraction and an oracle-parity bool.  The headline index is released first.
+            try:
+                result["same_shard_variants"] = same_shard_variants(sh.index, queries, B, K, n_local, D)
+            except Exception as e:  # noqa: BLE001
+                result["same_shard_variants"] = {"error": repr(e)}
             del sh, outs, out
             torch.cuda.empty_cache()
             try:
@@ -386,6 +390,42 @@ def _scan_profile(idx, fn, reps, bytes_per_row):
     us = p["scan_us"] / max(reps, 1)
     gbps = (p["scan_rows"] * bytes_per_row / (p["scan_us"] * 1e-6) / 1e9) if p["scan_us"] else 0.0
     return round(us, 1), round(gbps, 1), p
+
+
+def same_shard_variants(idx, queries, B, K, N, D):
+    """The headline shard and queries under the other float metrics and under a subset filter (outside the timed region): squared
+    L2 and cosine (certified int8 pass over the augmented / unit-row codes), FLAT-IP restricted to a random 50 % subset
+    given as BitSet words (masked int8 scan; host entry point: the 1.25 MB of words are uploaded on every call).
+    Oracle parity of these paths: tests/test_gpu_baseline_configs.py, tests/test_gpu_i8c_hostile.py."""
+    out = {}
+    rows = torch.zeros((B, K), dtype=torch.int64, device=queries.device)
+    dists = torch.zeros((B, K), dtype=torch.float32, device=queries.device)
+    counts = torch.zeros(B, dtype=torch.int32, device=queries.device)
+    for name in ("l2", "cosine"):
+        t0 = time.time()
+        idx.prepare(name, B)
+        torch.cuda.synchronize()
+        build_s = time.time() - t0
+        fn = lambda: idx.search_device(queries, K, name, rows, dists, counts)  # noqa: E731
+        ms = _time_calls(fn, 3, 10) * 1e3
+        us, _, p = _scan_profile(idx, fn, 4, 0)
+        plan = int(p["last_plan"])
+        out[name] = {"ms_per_step": round(ms, 4), "queries_per_s": round(B / ms * 1e3, 1), "scan_us_per_step": us, "derived_build_s": round(build_s, 3),
+                     "int8_coarse_pass": bool(plan & 4), "fallback_queries": int(p["fallback_queries"]),
+                     "rescored_per_query": round(p["pool_entries"] / max(p["searches"] * B, 1), 1)}
+    rng = np.random.default_rng(7)
+    member = rng.random(N) < 0.5
+    ids = np.nonzero(member)[0].astype(np.uint64)
+    words = np.zeros((N + 63) // 64, np.uint64)
+    np.bitwise_or.at(words, (ids // 64).astype(np.int64), np.uint64(1) << (ids % np.uint64(64)))
+    qh = np.ascontiguousarray(queries.cpu().numpy())
+    fn = lambda: idx.search_filtered_bitset_batch_arrays(qh, K, "ip", words)  # noqa: E731
+    ms = _time_calls(fn, 2, 8) * 1e3
+    us, _, p = _scan_profile(idx, fn, 4, 0)
+    out["ip_subset_50pct_bitset"] = {"ms_per_call_host_api": round(ms, 4), "scan_us_per_call": us, "int8_coarse_pass": bool(int(p["last_plan"]) & 4),
+                                     "fallback_queries": int(p["fallback_queries"]), "subset_rows": int(ids.size)}
+    out["hbm_bytes_with_l2_and_cosine_codes"] = int(idx.hbm_bytes())
+    return out
 
 
 def second_distribution(args, dev):

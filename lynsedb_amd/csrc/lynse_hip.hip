@@ -191,6 +191,12 @@ struct lynse_hip_flat {
         hipStream_t stream = nullptr;
         Workspace ws;
         std::vector<hipEvent_t> ev_pool;
+        // filtered search: row bitmask of the subset + staging for the subset ids — per context, so that masked filtered
+        // searches run under the shared lock like unfiltered ones (the gathered-rows strategy swaps handle fields: exclusive)
+        uint32_t* d_mask = nullptr;
+        uint64_t mask_words = 0;
+        uint64_t* d_subset = nullptr;
+        uint64_t subset_cap = 0;
     };
     static constexpr int MAX_CTX = 8;
     Ctx ctx[MAX_CTX];
@@ -232,11 +238,6 @@ struct lynse_hip_flat {
     int dtype = LYNSE_DTYPE_F32;  // F16: rows hold f16-representable values, distances use the f16 kernels' sequential sums
     uint32_t stage0_rows = 4096, growth = 8, cap = 16384;
 
-    // filtered search: row bitmask of the current subset + staging for the subset ids
-    uint32_t* d_mask = nullptr;
-    uint64_t mask_words = 0;
-    uint64_t* d_subset = nullptr;
-    uint64_t subset_cap = 0;
     // SQ8 two-pass mode (FLAT-*-SQ8): signed codes (code - 128), per-dimension min / scale, per-row sums; built lazily
     int8_t* sq8 = nullptr;
     uint32_t ld8 = 0;
@@ -412,11 +413,13 @@ extern "C" int lynse_hip_flat_destroy(lynse_hip_flat* h) {
     for (auto& c : h->ctx) {
         if (c.stream) (void)hipStreamSynchronize(c.stream);
         c.ws.release();
+        if (c.d_mask) (void)hipFree(c.d_mask);
+        if (c.d_subset) (void)hipFree(c.d_subset);
         for (auto e : c.ev_pool) (void)hipEventDestroy(e);
     }
     if (h->shadow_alias) h->rows16 = nullptr;
     for (void* p : {(void*)h->rows, (void*)h->rows_h, (void*)h->rows16, (void*)h->packed, (void*)h->vn2, (void*)h->vrinv, (void*)h->d_stats,
-                    (void*)h->d_mask, (void*)h->d_subset, (void*)h->g_rows16, (void*)h->g_vn2, (void*)h->g_vrinv, (void*)h->g_ids32,
+                    (void*)h->g_rows16, (void*)h->g_vn2, (void*)h->g_vrinv, (void*)h->g_ids32,
                     (void*)h->bpm, (void*)h->sq8c, (void*)h->sq8c_mins, (void*)h->sq8c_scales, (void*)h->sq8c_mm, (void*)h->sq8c_stats, (void*)h->sq8a, (void*)h->sq8a_mins, (void*)h->sq8a_scales, (void*)h->sq8a_mm, (void*)h->sq8a_stats,
                     (void*)h->sq8, (void*)h->sq8_mins, (void*)h->sq8_scales, (void*)h->sq8_sum, (void*)h->sq8_sum2, (void*)h->sq8_mm, (void*)h->sq8_stats})
         if (p) (void)hipFree(p);
@@ -2178,8 +2181,9 @@ static int search_impl(lynse_hip_flat* h, const void* q_src, bool packed_queries
     profile_begin_search(h);
     const bool binary = metric >= M_HAMMING;
     // Locking: an unfiltered search over a shard whose derived data (row statistics, f16 shadow, packed words, SQ8 codes of
-    // the int8 coarse pass) is up to date runs under the SHARED lock on a search context of its own; anything that has to
-    // build or borrows per-handle scratch (lazy builds, subset filters) runs EXCLUSIVE on context 0.
+    // the int8 coarse pass) is up to date runs under the SHARED lock on a search context of its own — subset-filtered searches on
+    // the masked-scan strategy included; anything that has to build or borrows per-handle state (lazy builds, the gathered-rows
+    // strategy of a subset filter) runs EXCLUSIVE on context 0.
     std::shared_lock<std::shared_mutex> rlk(h->rw, std::defer_lock);
     std::unique_lock<std::shared_mutex> xlk(h->rw, std::defer_lock);
     CtxLease lease;
@@ -2190,7 +2194,8 @@ static int search_impl(lynse_hip_flat* h, const void* q_src, bool packed_queries
         }
         if (h->packed_only) return true;  // (rejected below)
         if (h->n_stats != h->n || (scan_variant() == 3 && (h->n16 != h->n || h->sv16 != h->sv))) return false;
-        return !i8c_eligible(h, metric, filtered, std::min<uint64_t>(nq, QCHUNK), caller_holds_exclusive) || i8c_codes_ready(h, metric);
+        // (filtered: what matters is the MASKED int8 scan — a gathered-rows search goes exclusive anyway)
+        return !i8c_eligible(h, metric, false, std::min<uint64_t>(nq, QCHUNK), caller_holds_exclusive, filtered) || i8c_codes_ready(h, metric);
     };
     // k beyond the candidate capacity of one pass (k > cap / 4 over more than cap rows; the reference accepts any k, and its
     // server caps at MAX_TOP_K = 10,000, src/server/mod.rs:46): row ranges of `cap` rows, each answered exactly, merged.
@@ -2206,10 +2211,28 @@ static int search_impl(lynse_hip_flat* h, const void* q_src, bool packed_queries
                                          subset, n_subset, true, bitset_words, n_words)
                         : search_large_k(h, q_src, packed_queries, nq, k, metric, out_rows, out_dists, out_counts, on_device, user_stream);
     };
+    // filtered search, strategy (flat_mmap.rs:549-556 switches at a fixed 50,000 ids): gather the listed shadow rows and scan
+    // only those when that is cheaper than a masked scan of the whole shard — bytes over measured rates on MI355X
+    auto choose_direct = [&]() -> bool {
+        if (!filtered || binary) return false;
+        const double rate = nq <= SCAN_BQ_SMALL ? 6.0e12 : 3.4e12;
+        const double chunks = (double)((nq + QCHUNK - 1) / QCHUNK);
+        const double row_b = (double)h->dim * 2.0;
+        const double c_direct = (double)n_subset * row_b * 2.0 / 2.5e12 + (double)n_subset * row_b / rate * chunks + 120e-6;
+        // (the masked scan of 33..256 queries streams the SQ8 codes when the certified int8 pass is available: 1 B per element
+        // at ~3.6 TB/s, measured 10M x 768 x 256 with a 50 % subset: 2.2 ms)
+        const bool mask_i8 = i8c_eligible(h, metric, false, std::min<uint64_t>(nq, QCHUNK), caller_holds_exclusive, true);
+        const double c_scan = (mask_i8 ? (double)h->n * (double)h->dim / 3.6e12 : (double)h->n * row_b / rate) * chunks + 80e-6;
+        const char* fe = getenv("LYNSE_HIP_FILTER_STRATEGY");  // tests: 1 = gathered rows, 2 = masked scan (read per call)
+        const int force = fe ? atoi(fe) : 0;
+        return (double)n_subset * row_b <= 8e9 && (force == 1 || (force == 0 && c_direct < c_scan));
+    };
     if (!caller_holds_exclusive) {
         rlk.lock();
         if (needs_large_k()) { rlk.unlock(); return go_large_k(); }
-        if (!filtered && !user_stream && derived_ready()) {
+        // (a MASKED filtered search only needs scratch of its own context: shared lock; the gathered-rows strategy points the
+        // handle's scan-side fields at the compact copy for the duration of the call: exclusive)
+        if (!user_stream && derived_ready() && !(filtered && (n_subset == 0 || choose_direct()))) {
             LY_TRY(lease.acquire(h));
         } else {
             rlk.unlock();
@@ -2251,49 +2274,38 @@ static int search_impl(lynse_hip_flat* h, const void* q_src, bool packed_queries
     hipStream_t st0 = user_stream ? user_stream : cur(h).stream;
     bool direct = false;
     std::vector<uint64_t> sorted_subset;
+    auto& fc = cur(h);   // (this search's context: 0 under the exclusive lock, the leased one under the shared lock)
     if (filtered) {
-        // strategy (flat_mmap.rs:549-556 switches at a fixed 50,000 ids): gather the listed shadow rows and scan only
-        // those when that is cheaper than a masked scan of the whole shard — bytes over measured rates on MI355X
-        const double rate = nq <= SCAN_BQ_SMALL ? 6.0e12 : 3.4e12;
-        const double chunks = (double)((nq + QCHUNK - 1) / QCHUNK);
-        const double row_b = (double)h->dim * 2.0;
-        const double c_direct = (double)n_subset * row_b * 2.0 / 2.5e12 + (double)n_subset * row_b / rate * chunks + 120e-6;
-        // (the masked scan of 33..256 queries streams the SQ8 codes when the certified int8 pass is available: 1 B per element
-        // at ~3.6 TB/s, measured 10M x 768 x 256 with a 50 % subset: 2.2 ms)
-        const bool mask_i8 = !binary && i8c_eligible(h, metric, false, std::min<uint64_t>(nq, QCHUNK), caller_holds_exclusive, true);
-        const double c_scan = (mask_i8 ? (double)h->n * (double)h->dim / 3.6e12 : (double)h->n * row_b / rate) * chunks + 80e-6;
-        const char* fe = getenv("LYNSE_HIP_FILTER_STRATEGY");  // tests: 1 = gathered rows, 2 = masked scan (read per call)
-        const int force = fe ? atoi(fe) : 0;
-        direct = !binary && (double)n_subset * row_b <= 8e9 && (force == 1 || (force == 0 && c_direct < c_scan));
-        if (n_subset > h->subset_cap && (direct || !bitset_words)) {
-            if (h->d_subset) (void)hipFree(h->d_subset);
-            h->d_subset = nullptr;
-            LY_HIP(hipMalloc(&h->d_subset, n_subset * 8));
-            h->subset_cap = n_subset;
+        direct = choose_direct();
+        if (n_subset > fc.subset_cap && (direct || !bitset_words)) {
+            if (fc.d_subset) (void)hipFree(fc.d_subset);
+            fc.d_subset = nullptr;
+            LY_HIP(hipMalloc(&fc.d_subset, n_subset * 8));
+            fc.subset_cap = n_subset;
         }
         bool ids_on_device = false;
         if (bitset_words && direct) {  // BitSet::to_vec on the device: upload the words (they double as scratch in d_mask), expand
             const uint64_t nw = std::min<uint64_t>(n_words, (h->n + 63) / 64);
             const uint64_t words32 = (std::max<uint64_t>(h->n, h->capacity) + 511) / 32 + 8;
             const uint32_t nblocks = (uint32_t)((nw + 255) / 256);
-            if (words32 + nblocks + 16 > h->mask_words) {
-                if (h->d_mask) (void)hipFree(h->d_mask);
-                h->d_mask = nullptr;
-                LY_HIP(hipMalloc(&h->d_mask, (words32 + nblocks + 16) * 4));
-                h->mask_words = words32 + nblocks + 16;
+            if (words32 + nblocks + 16 > fc.mask_words) {
+                if (fc.d_mask) (void)hipFree(fc.d_mask);
+                fc.d_mask = nullptr;
+                LY_HIP(hipMalloc(&fc.d_mask, (words32 + nblocks + 16) * 4));
+                fc.mask_words = words32 + nblocks + 16;
             }
-            if (n_subset > h->subset_cap) {
-                if (h->d_subset) (void)hipFree(h->d_subset);
-                h->d_subset = nullptr;
-                LY_HIP(hipMalloc(&h->d_subset, n_subset * 8));
-                h->subset_cap = n_subset;
+            if (n_subset > fc.subset_cap) {
+                if (fc.d_subset) (void)hipFree(fc.d_subset);
+                fc.d_subset = nullptr;
+                LY_HIP(hipMalloc(&fc.d_subset, n_subset * 8));
+                fc.subset_cap = n_subset;
             }
-            uint32_t* d_counts = h->d_mask + words32;
-            LY_HIP(hipMemcpyAsync(h->d_mask, bitset_words, nw * 8, hipMemcpyHostToDevice, st0));
-            const uint64_t* d_words = reinterpret_cast<const uint64_t*>(h->d_mask);
+            uint32_t* d_counts = fc.d_mask + words32;
+            LY_HIP(hipMemcpyAsync(fc.d_mask, bitset_words, nw * 8, hipMemcpyHostToDevice, st0));
+            const uint64_t* d_words = reinterpret_cast<const uint64_t*>(fc.d_mask);
             hipLaunchKernelGGL(k_bits_count, dim3(nblocks), dim3(256), 0, st0, d_words, nw, h->n, d_counts);
             hipLaunchKernelGGL(k_bits_offsets, dim3(1), dim3(1024), 0, st0, d_counts, nblocks);
-            hipLaunchKernelGGL(k_bits_expand, dim3(nblocks), dim3(256), 0, st0, d_words, nw, h->n, d_counts, h->d_subset);
+            hipLaunchKernelGGL(k_bits_expand, dim3(nblocks), dim3(256), 0, st0, d_words, nw, h->n, d_counts, fc.d_subset);
             LY_HIP(hipGetLastError());
             ids_on_device = true;
         }
@@ -2310,22 +2322,22 @@ static int search_impl(lynse_hip_flat* h, const void* q_src, bool packed_queries
                 n_subset = sorted_subset.size();
             }
         }
-        if (src && n_subset && !ids_on_device) LY_HIP(hipMemcpyAsync(h->d_subset, src, n_subset * 8, hipMemcpyHostToDevice, st0));
+        if (src && n_subset && !ids_on_device) LY_HIP(hipMemcpyAsync(fc.d_subset, src, n_subset * 8, hipMemcpyHostToDevice, st0));
         if (!direct) {  // subset ids -> row bitmask on the device (the reference's bitset, flat_mmap.rs:672-679)
             const uint64_t words = (std::max<uint64_t>(h->n, h->capacity) + 511) / 32 + 8;
-            if (words > h->mask_words) {
-                if (h->d_mask) (void)hipFree(h->d_mask);
-                h->d_mask = nullptr;
-                LY_HIP(hipMalloc(&h->d_mask, words * 4));
-                h->mask_words = words;
+            if (words > fc.mask_words) {
+                if (fc.d_mask) (void)hipFree(fc.d_mask);
+                fc.d_mask = nullptr;
+                LY_HIP(hipMalloc(&fc.d_mask, words * 4));
+                fc.mask_words = words;
             }
-            LY_HIP(hipMemsetAsync(h->d_mask, 0, h->mask_words * 4, st0));
+            LY_HIP(hipMemsetAsync(fc.d_mask, 0, fc.mask_words * 4, st0));
             if (bitset_words) {  // the caller's BitSet words ARE the mask (u64 LE = two u32 words); bits >= len never match a row
                 const uint64_t bytes = std::min<uint64_t>(n_words * 8, (h->n + 63) / 64 * 8);
-                LY_HIP(hipMemcpyAsync(h->d_mask, bitset_words, bytes, hipMemcpyHostToDevice, st0));
+                LY_HIP(hipMemcpyAsync(fc.d_mask, bitset_words, bytes, hipMemcpyHostToDevice, st0));
             } else {
                 const uint32_t blocks = (uint32_t)std::min<uint64_t>((n_subset + 255) / 256, (uint64_t)h->num_cu * 8);
-                hipLaunchKernelGGL(k_mask_build, dim3(std::max<uint32_t>(blocks, 1)), dim3(256), 0, st0, h->d_subset, n_subset, h->n, h->d_mask);
+                hipLaunchKernelGGL(k_mask_build, dim3(std::max<uint32_t>(blocks, 1)), dim3(256), 0, st0, fc.d_subset, n_subset, h->n, fc.d_mask);
                 LY_HIP(hipGetLastError());
             }
         }
@@ -2344,10 +2356,10 @@ static int search_impl(lynse_hip_flat* h, const void* q_src, bool packed_queries
             }
             const uint64_t pieces = n_subset * (h->ld16 / 8);
             hipLaunchKernelGGL(k_gather_rows16, dim3((uint32_t)std::min<uint64_t>((pieces + 255) / 256, (uint64_t)h->num_cu * 32)), dim3(256), 0,
-                               st0, h->rows16, h->ld16, h->d_subset, n_subset, h->g_rows16);
+                               st0, h->rows16, h->ld16, fc.d_subset, n_subset, h->g_rows16);
             LY_HIP(hipGetLastError());
             hipLaunchKernelGGL(k_gather_norms, dim3((uint32_t)std::min<uint64_t>((n_subset + 255) / 256, (uint64_t)h->num_cu * 8)), dim3(256), 0,
-                               st0, h->vn2, h->vrinv, h->d_subset, n_subset, h->g_vn2, h->g_vrinv, h->g_ids32);
+                               st0, h->vn2, h->vrinv, fc.d_subset, n_subset, h->g_vn2, h->g_vrinv, h->g_ids32);
             LY_HIP(hipGetLastError());
         }
         LY_HIP(hipStreamSynchronize(st0));  // `subset` / sorted_subset are caller / stack memory
@@ -2358,7 +2370,7 @@ static int search_impl(lynse_hip_flat* h, const void* q_src, bool packed_queries
             return LYNSE_OK;
         }
     }
-    const uint32_t* mask = (filtered && !direct) ? h->d_mask : nullptr;
+    const uint32_t* mask = (filtered && !direct) ? fc.d_mask : nullptr;
     // the gathered path scans the compact store through the ordinary pipeline: point the scan-side fields of the handle
     // at it for the duration of this call (the mutex is held); rescoring keeps using the f32 source rows by original id
     struct ViewGuard {
