@@ -15,6 +15,7 @@
 #pragma once
 
 #include "common.h"
+#include <utility>
 
 namespace lynse {
 
@@ -1245,6 +1246,30 @@ __device__ __forceinline__ void fused_sample_threshold(const uint64_t* __restric
     __syncthreads();
 }
 
+// ---- accumulators in AGPRs (one wave per SIMD: 4 waves x 4 x 4 blocks of 32 x 32, 256 accumulator registers per lane) ----
+// hipcc keeps 4 of the 16 accumulator tuples in a[0:63] and cycles the rest through scratch around every group of four MFMAs
+// when it allocates them itself (1152 B of scratch per lane inside the MFMA loop, ISA inspected); here the MFMAs are inline
+// assembly on FIXED AGPR tuples a[16 t : 16 t + 15], the epilogue reads / clears them with v_accvgpr_read / _write, and the
+// compiler never sees an accumulator value during the MFMA loop.
+template <typename F, int... I>
+__device__ __forceinline__ void ly_static_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, typename F>
+__device__ __forceinline__ void ly_static_for(F&& f) { ly_static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+template <int R>
+__device__ __forceinline__ float ly_agpr_take() {   // read accumulator register R and clear it
+    float x;
+    asm volatile("v_accvgpr_read_b32 %0, a[%1]\n\tv_accvgpr_write_b32 a[%1], 0" : "=v"(x) : "n"(R));
+    return x;
+}
+template <int T, typename V>
+__device__ __forceinline__ void ly_mfma_i8_agpr(V a, V b) {
+    asm volatile("v_mfma_i32_32x32x32_i8 a[%2:%3], %0, %1, a[%2:%3]" ::"v"(a), "v"(b), "n"(T * 16), "n"(T * 16 + 15));
+}
+__device__ __forceinline__ void ly_agpr_clear_all() {   // (the clobber list is what tells the compiler that the kernel uses a0..a255)
+    ly_static_for<256>([&](auto rc) { asm volatile("v_accvgpr_write_b32 a[%0], 0" ::"n"(decltype(rc)::value)); });
+    asm volatile("s_nop 4" ::: "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47", "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63", "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71", "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79", "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87", "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95", "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103", "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111", "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119", "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127", "a128", "a129", "a130", "a131", "a132", "a133", "a134", "a135", "a136", "a137", "a138", "a139", "a140", "a141", "a142", "a143", "a144", "a145", "a146", "a147", "a148", "a149", "a150", "a151", "a152", "a153", "a154", "a155", "a156", "a157", "a158", "a159", "a160", "a161", "a162", "a163", "a164", "a165", "a166", "a167", "a168", "a169", "a170", "a171", "a172", "a173", "a174", "a175", "a176", "a177", "a178", "a179", "a180", "a181", "a182", "a183", "a184", "a185", "a186", "a187", "a188", "a189", "a190", "a191", "a192", "a193", "a194", "a195", "a196", "a197", "a198", "a199", "a200", "a201", "a202", "a203", "a204", "a205", "a206", "a207", "a208", "a209", "a210", "a211", "a212", "a213", "a214", "a215", "a216", "a217", "a218", "a219", "a220", "a221", "a222", "a223", "a224", "a225", "a226", "a227", "a228", "a229", "a230", "a231", "a232", "a233", "a234", "a235", "a236", "a237", "a238", "a239", "a240", "a241", "a242", "a243", "a244", "a245", "a246", "a247", "a248", "a249", "a250", "a251", "a252", "a253", "a254", "a255");
+}
+
 constexpr int HK = 64;  // K elements per slab
 
 // DBG (compile-time experiments, never launched by the product path): 1 no MFMA, 2 no LDS fragment reads,
@@ -1266,6 +1291,21 @@ __global__ void __launch_bounds__(WQ * WR * 64, (TQ * TR >= 16) ? 1 : ((WQ * WR 
     constexpr bool I8 = I8Q != 0;           // int8 operands (SQ8 pass 1 or the certified coarse pass)
     constexpr bool I8C = I8Q == 2;
     static_assert(!I8C || METRIC == M_IP, "certified int8 coarse pass: IP only");
+    constexpr bool AG = I8C && TQ * TR == 16;   // one wave per SIMD: accumulators in fixed AGPR tuples (ly_mfma_i8_agpr)
+#ifndef LYNSE_DEFER
+#define LYNSE_DEFER 1
+#endif
+    // DEFER: the MFMAs of a slab's LAST k-step run at the start of the NEXT slab step, behind the barrier and the first fragment
+    // reads of the new slab — every slab step used to open with all eight waves waiting for their first LDS reads (nothing left
+    // to issue: both waves of a SIMD stand at the same point), now the deferred MFMA group covers that round trip.  The
+    // fragments of the deferred k-step are in registers before the barrier, so "every wave has finished reading slab g" still
+    // holds when the ring stages are refilled.  (256 x 256 int8 tilings; the tile epilogue follows the deferred group.)
+    // Measured (MI355X, 10M x 768 x 256, builds alternated on one box): the 8-wave tilings LOSE 1.7 % with it (2.20 against 2.165
+    // ms: their LDS port is as busy as the matrix pipe — 192 KB of fragment reads + 64 KB of DMA writes per slab step are 2048
+    // cycles at 128 B / cycle, the MFMAs are 2048 too — so there is no idle round trip to cover, only added branches); the
+    // one-wave-per-SIMD tiling (AG: a third fewer fragment reads, nobody else to issue while a wave waits) is what it is for.
+    constexpr bool DEFER = LYNSE_DEFER && AG;
+    static_assert(!AG || (!TILED && !FS && DBG == 0 && EMIT == 0), "AGPR accumulators: threshold stages of the FLAT int8 scan");
     constexpr int ES = I8 ? 1 : 2;          // element size in bytes
     constexpr int KS = 128 / ES;            // elements per slab
     constexpr int EPS = 16 / ES;            // elements per 16-B slot
@@ -1477,6 +1517,7 @@ __global__ void __launch_bounds__(WQ * WR * 64, (TQ * TR >= 16) ? 1 : ((WQ * WR 
         for (int j = 0; j < TQ; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    if constexpr (AG) ly_agpr_clear_all();   // (AG: acc[][] only carries one query column at a time through the epilogue)
 
     const int l32 = lane & 31, hi = lane >> 5;
     const int swz = (l32 >> 1) & 7;   // (line>>1)&7 — tile offsets are multiples of 32
@@ -1564,20 +1605,26 @@ __global__ void __launch_bounds__(WQ * WR * 64, (TQ * TR >= 16) ? 1 : ((WQ * WR 
     constexpr bool timing = false;  // (phase timing lives in the EXPERIMENTS build: its flag and counters cost SGPRs in the hot loop)
 #endif
     [[maybe_unused]] unsigned long long t_wait = 0, t_bar = 0, t_comp = 0, t_iq = 0, t_iv = 0, tp = timing ? __builtin_amdgcn_s_memtime() : 0;  // (EXPERIMENTS build only)
-    for (uint32_t g = 0; g < G; ++g) {
+    half8 af[2][TR], bf[2][TQ];          // (DEFER: buffer 1 carries the last k-step's fragments across the loop edge)
+    const char *stv = smem, *stq = smem;
+    bool pend_done = false;              // DEFER: the deferred MFMA group completes a tile
+    bool tile_done = false;
+    for (uint32_t g = 0; g < G + (DEFER ? 1u : 0u); ++g) {
+        if (!DEFER || g < G) {
+        if constexpr (DEFER) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the deferred k-step's fragments are in registers: this wave is done with the old slab
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAIT_OPS) : "memory");
         if (timing) { const unsigned long long t = __builtin_amdgcn_s_memtime(); t_wait += t - tp; tp = t; }
         __builtin_amdgcn_s_barrier();
         if (timing) { const unsigned long long t = __builtin_amdgcn_s_memtime(); t_bar += t - tp; tp = t; }
 
-        const char* stv = smem + cv_stage * V_BYTES;
-        const char* stq = smem + Q_RING + cq_stage * Q_BYTES;
+        stv = smem + cv_stage * V_BYTES;
+        stq = smem + Q_RING + cq_stage * Q_BYTES;
         cv_stage = cv_stage + 1 == NSV ? 0 : cv_stage + 1;
         cq_stage = cq_stage + 1 == NSQ ? 0 : cq_stage + 1;
+        }
         // Software pipeline over the four 16-wide k-steps: the fragments of step kk+1 are read from LDS
         // while the MFMAs of step kk run (sched_barriers pin the order — left alone, the scheduler sinks
         // every ds_read next to its first use and each MFMA group then waits out an LDS round trip).
-        half8 af[2][TR], bf[2][TQ];
         auto load_frags = [&](int kk, int buf) {
             const int ls = ((kk * 2 + hi) ^ swz) * 16;
 #pragma unroll
@@ -1585,6 +1632,53 @@ __global__ void __launch_bounds__(WQ * WR * 64, (TQ * TR >= 16) ? 1 : ((WQ * WR 
 #pragma unroll
             for (int i = 0; i < TR; ++i) af[buf][i] = *reinterpret_cast<const half8*>(stv + a_base + i * 32 * LINE + ls);
         };
+        [[maybe_unused]] auto mfma_group = [&](int buf, int i) {
+#pragma unroll
+            for (int j = 0; j < TQ; ++j) {
+                typedef int i32x4 __attribute__((ext_vector_type(4)));
+                typedef int i32x16 __attribute__((ext_vector_type(16)));
+                acc[i][j] = __builtin_bit_cast(f32x16, __builtin_amdgcn_mfma_i32_32x32x32_i8(
+                    __builtin_bit_cast(i32x4, af[buf][i]), __builtin_bit_cast(i32x4, bf[buf][j]), __builtin_bit_cast(i32x16, acc[i][j]), 0, 0, 0));
+            }
+        };
+        [[maybe_unused]] auto slot_pieces = [&](int slot) {   // the refill pieces scheduled behind MFMA group `slot` of NSLOT
+#pragma unroll
+            for (int p = 0; p < OPS; ++p)
+                if (p % NSLOT == slot) issue_piece(p);
+        };
+        // (AG: MFMAs on fixed AGPR tuples need compile-time block indices)
+        [[maybe_unused]] auto group_at = [&](auto bufc, auto ic) {
+            constexpr int buf = decltype(bufc)::value, i = decltype(ic)::value;
+            if constexpr (AG) ly_static_for<TQ>([&](auto jc) { ly_mfma_i8_agpr<i * TQ + decltype(jc)::value>(af[buf][i], bf[buf][decltype(jc)::value]); });
+            else mfma_group(buf, i);
+        };
+        if constexpr (DEFER) {
+            // slots of a slab step: 0 .. TR-1 the deferred group (last k-step of the previous slab), then k-steps 0 .. 2 of this slab
+            const bool td_prev = pend_done;
+            if (g < G && !td_prev) load_frags(0, 0);   // (not across a tile epilogue: its registers are spoken for)
+            __builtin_amdgcn_sched_barrier(0);
+            ly_static_for<TR>([&](auto ic) {
+                if (g > 0) group_at(std::integral_constant<int, 1>{}, ic);
+                if (g < G) slot_pieces(decltype(ic)::value);
+            });
+            __builtin_amdgcn_sched_barrier(0);
+            tile_done = td_prev;
+        } else if constexpr (AG) {
+            load_frags(0, 0);
+            ly_static_for<HK / 16>([&](auto kkc) {
+                constexpr int kk = decltype(kkc)::value, cur = kk & 1;
+                if constexpr (kk + 1 < HK / 16) load_frags(kk + 1, cur ^ 1);
+                __builtin_amdgcn_sched_barrier(0);
+                ly_static_for<TR>([&](auto ic) {
+                    constexpr int i = decltype(ic)::value;
+                    ly_static_for<TQ>([&](auto jc) { ly_mfma_i8_agpr<i * TQ + decltype(jc)::value>(af[cur][i], bf[cur][decltype(jc)::value]); });
+                    ly_static_for<OPS>([&](auto pc) {   // refill pieces behind this MFMA group (slot kk*TR+i of NSLOT)
+                        if constexpr (decltype(pc)::value % NSLOT == kk * TR + i) issue_piece(decltype(pc)::value);
+                    });
+                });
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        } else {
         if (!(DBG & 2) || g == 0) load_frags(0, 0);
 #pragma unroll
         for (int kk = 0; kk < HK / 16; ++kk) {
@@ -1631,10 +1725,12 @@ __global__ void __launch_bounds__(WQ * WR * 64, (TQ * TR >= 16) ? 1 : ((WQ * WR 
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        q_advance();
-        v_advance();
-
-        const bool tile_done = ++s_in_tile == a.nslab;
+        }
+        if constexpr (!DEFER) {
+            q_advance();
+            v_advance();
+            tile_done = ++s_in_tile == a.nslab;
+        }
         if constexpr ((DBG & 16) != 0) {  // (experiments) no epilogue at all: keep the accumulators alive, restart the tile
           if (tile_done) {
 #pragma unroll
@@ -1699,8 +1795,25 @@ __global__ void __launch_bounds__(WQ * WR * 64, (TQ * TR >= 16) ? 1 : ((WQ * WR 
             // columns are scored afterwards, one norm load per group of four rows shared by the columns and issued one group ahead
             constexpr bool DENSEF = DENSE && !I8 && !TILED && !FILT;
             uint32_t n_j[TQ];
+            if constexpr (AG) asm volatile("s_nop 15\n\ts_nop 15");   // (the last MFMAs' results before v_accvgpr_read: the hazard recognizer does not see inline assembly)
 #pragma unroll
             for (int j = 0; j < TQ; ++j) {
+                if constexpr (AG) {   // this query column's TR x 16 accumulators out of the AGPRs (cleared as they are read)
+                    auto take = [&](auto jc) {
+                        constexpr int jj = decltype(jc)::value;
+                        ly_static_for<TR>([&](auto ic) {
+                            ly_static_for<16>([&](auto rc) {
+                                acc[decltype(ic)::value][jj][decltype(rc)::value] = ly_agpr_take<(decltype(ic)::value * TQ + jj) * 16 + decltype(rc)::value>();
+                            });
+                        });
+                    };
+                    switch (j) {
+                    case 0: take(std::integral_constant<int, 0>{}); break;
+                    case 1: take(std::integral_constant<int, (TQ > 1 ? 1 : 0)>{}); break;
+                    case 2: take(std::integral_constant<int, (TQ > 2 ? 2 : 0)>{}); break;
+                    default: take(std::integral_constant<int, (TQ > 3 ? 3 : 0)>{}); break;
+                    }
+                }
                 uint32_t rb = __builtin_amdgcn_readfirstlane(rbase);  // (uniform) opaque per column block: keeps the row-index terms of the TR x 16 rows from being hoisted out of
                 asm volatile("" : "+s"(rb));  // the unrolled column loop (all live at once: hundreds of bytes of scratch per lane)
                 uint32_t n = qchunk + wq * (TQ * 32) + j * 32 + l32;  // this lane's query of column block j (TILED: through the group's pair list)
@@ -2067,8 +2180,26 @@ __global__ void __launch_bounds__(WQ * WR * 64, (TQ * TR >= 16) ? 1 : ((WQ * WR 
                     if (stamp && tid == 0) stamp[5] = __builtin_amdgcn_s_memtime();
                 }
             }
-            s_in_tile = 0;
+            if constexpr (!DEFER) s_in_tile = 0;
             tile += gridDim.x;
+        }
+        if constexpr (DEFER) {
+            if (g == G) break;
+            if (tile_done) load_frags(0, 0);
+            ly_static_for<HK / 16 - 1>([&](auto kkc) {
+                constexpr int kk = decltype(kkc)::value, cur = kk & 1;
+                load_frags(kk + 1, cur ^ 1);
+                __builtin_amdgcn_sched_barrier(0);
+                ly_static_for<TR>([&](auto ic) {
+                    group_at(std::integral_constant<int, cur>{}, ic);
+                    slot_pieces(TR + kk * TR + decltype(ic)::value);
+                });
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            q_advance();
+            v_advance();
+            pend_done = ++s_in_tile == a.nslab;
+            if (pend_done) s_in_tile = 0;
         }
         if (timing) {
             asm volatile("" ::"v"(acc[0][0][0]));

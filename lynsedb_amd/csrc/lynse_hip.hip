@@ -1298,6 +1298,20 @@ static int launch_scan_i8c(const ScanArgs& a, uint32_t grid, hipStream_t st, boo
         if (a.emit_all != 0 || !a.dense) return set_error(LYNSE_ERR_INTERNAL, "the masked int8 scan runs emit-all and DENSE threshold stages");
         return go(k_scan_h16<2, 4, 4, 2, M_IP, 3, 2, 2, false, false, 0, true, 2, 0, 0, true>, 10);
     }
+    // One wave per SIMD: 4 waves x (128 queries x 128 rows), accumulators in fixed AGPR tuples (kernels.h, AG) — the threshold
+    // stages over whole 128-column slabs (LYNSE_HIP_AG=1; the sample stages keep the 8-wave kernels)
+    const int ag_env = []() { const char* e = getenv("LYNSE_HIP_AG"); return e ? atoi(e) : 0; }();   // (read per call: A/B, tests)
+    if (ag_env && a.ld16 % 128 == 0 && a.emit_all == 0 && !fs) {
+        static bool ag_attr[2] = {false, false};
+        auto go4 = [&](auto kern, int slot) -> int {
+            if (!ag_attr[slot]) { LY_TRY(set_max_lds(kern, lds)); ag_attr[slot] = true; }
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a);
+            LY_HIP(hipGetLastError());
+            return LYNSE_OK;
+        };
+        if (a.dense) return go4(k_scan_h16<2, 2, 4, 4, M_IP, 3, 2, 2, false, false, 0, false, 2, 0, 0, true>, 0);
+        return go4(k_scan_h16<2, 2, 4, 4, M_IP, 3, 2, 2, false, false, 0, false, 2, 0>, 1);
+    }
     if (a.ld16 % 128 == 0) {
         static const int prio = []() { const char* e = getenv("LYNSE_HIP_PRIO"); return e ? atoi(e) : 0; }();
         static bool prattr = false;
@@ -1657,7 +1671,8 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
                 const uint64_t seen_before = s.sample_tiles ? 0 : (sample.sample_tiles ? std::max<uint64_t>((uint64_t)sample.sample_tiles * plan_tile, s.r0) : s.r0);
                 a.dense = (!a.emit_all && a.ld16 % 128 == 0 && seen_before &&
                            (filt || (dense_env >= 0 ? dense_env != 0 : (uint64_t)k * 50000ull > seen_before))) ? 1 : 0;   // (masked: DENSE is the one epilogue compiled with the mask)
-                if (!a.emit_all) seg_geometry(grid, a.dense ? 8 : 4, &a.nseg, &a.seg);
+                const bool ag = getenv("LYNSE_HIP_AG") && atoi(getenv("LYNSE_HIP_AG")) && a.ld16 % 128 == 0 && !a.emit_all && !fs_stage && !filt;
+                if (!a.emit_all) seg_geometry(grid, (a.dense ? 8 : 4) / (ag ? 2 : 1), &a.nseg, &a.seg);   // (segments per workgroup: WR, or 2 WR wave halves with DENSE)
                 if (fs_stage) {
                     a.fs_stride = sample.sample_stride; a.fs_rows = (uint32_t)h->n; a.gsync = w.gsync; a.Qf = Qf; a.marg2 = w.marg2;
                     a.thr_out = w.thr; a.k = k; a.ip_form = ip_form; a.metric = metric;

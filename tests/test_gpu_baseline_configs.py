@@ -69,9 +69,11 @@ def test_c2_flat_ip_768_batch256_runs_the_benchmarked_kernels(L, oracle):
     assert not (flags & PLAN_FUSED_SAMPLE), bin(flags)
     # the same batch (a) with the sample stage INSIDE the launch of the first threshold stage (k_scan_h16<.., FS>: grid-wide
     # threshold hand-over; off by default — measured slower than the two launches) and (b) on the three separate tail kernels
-    # instead of k_select_final: identical bits
+    # instead of k_select_final, and (c) with the threshold stages on the one-wave-per-SIMD tiling (4 waves x 4 x 4 blocks,
+    # accumulators in fixed AGPR tuples, the last k-step's MFMAs deferred behind the next slab's barrier; off by default —
+    # measured 11 % slower): identical bits
     import os
-    for env, launches, fused in (({"LYNSE_HIP_FUSED_SAMPLE": "1"}, 2, True), ({"LYNSE_HIP_FUSED_TAIL": "0"}, 3, False)):
+    for env, launches, fused in (({"LYNSE_HIP_FUSED_SAMPLE": "1"}, 2, True), ({"LYNSE_HIP_FUSED_TAIL": "0"}, 3, False), ({"LYNSE_HIP_AG": "1"}, 3, False)):
         os.environ.update(env)
         try:
             r_u, d_u, c_u = idx.search_batch_arrays(queries, k, "ip")
