@@ -1270,6 +1270,26 @@ __device__ __forceinline__ void ly_agpr_clear_all() {   // (the clobber list is 
     asm volatile("s_nop 4" ::: "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47", "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63", "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71", "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79", "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87", "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95", "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103", "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111", "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119", "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127", "a128", "a129", "a130", "a131", "a132", "a133", "a134", "a135", "a136", "a137", "a138", "a139", "a140", "a141", "a142", "a143", "a144", "a145", "a146", "a147", "a148", "a149", "a150", "a151", "a152", "a153", "a154", "a155", "a156", "a157", "a158", "a159", "a160", "a161", "a162", "a163", "a164", "a165", "a166", "a167", "a168", "a169", "a170", "a171", "a172", "a173", "a174", "a175", "a176", "a177", "a178", "a179", "a180", "a181", "a182", "a183", "a184", "a185", "a186", "a187", "a188", "a189", "a190", "a191", "a192", "a193", "a194", "a195", "a196", "a197", "a198", "a199", "a200", "a201", "a202", "a203", "a204", "a205", "a206", "a207", "a208", "a209", "a210", "a211", "a212", "a213", "a214", "a215", "a216", "a217", "a218", "a219", "a220", "a221", "a222", "a223", "a224", "a225", "a226", "a227", "a228", "a229", "a230", "a231", "a232", "a233", "a234", "a235", "a236", "a237", "a238", "a239", "a240", "a241", "a242", "a243", "a244", "a245", "a246", "a247", "a248", "a249", "a250", "a251", "a252", "a253", "a254", "a255");
 }
 
+// 32 x 32 x 64 FP4 x FP4 MFMA with unit block scales (E8M0 127 = 2^0): a / b carry 16 B per lane (32 nibbles), the upper half of
+// the 8-dword operands is not read for FP4.  (Which K index a nibble position stands for does not matter here: rows and queries
+// are packed the same way, and a dot product does not depend on the order of its terms.)
+// `unit` = 0x7f7f7f7f in a VGPR the CALLER keeps live across its loop (made opaque there): as an immediate the compiler
+// re-materialises it with a v_mov at the bottom of the loop body and every MFMA of the body sinks below that v_mov — past the
+// sched_barriers, all 32 in one cluster behind all 24 fragment reads (ISA inspected: 236 B of scratch from the fragments alone).
+template <typename V>
+__device__ __forceinline__ f32x16 ly_mfma_fp4(V a, V b, f32x16 c, int unit) {
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    typedef int i32x8 __attribute__((ext_vector_type(8)));
+    const i32x4 a4 = __builtin_bit_cast(i32x4, a), b4 = __builtin_bit_cast(i32x4, b);
+    const i32x8 a8 = {a4[0], a4[1], a4[2], a4[3], 0, 0, 0, 0}, b8 = {b4[0], b4[1], b4[2], b4[3], 0, 0, 0, 0};
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, c, 4, 4, 0, unit, 0, unit);
+#else
+    (void)a8; (void)b8; (void)unit;
+    return c;
+#endif
+}
+
 constexpr int HK = 64;  // K elements per slab
 
 // DBG (compile-time experiments, never launched by the product path): 1 no MFMA, 2 no LDS fragment reads,
@@ -1288,10 +1308,15 @@ __global__ void __launch_bounds__(WQ * WR * 64, (TQ * TR >= 16) ? 1 : ((WQ * WR 
     // image of w = q / scale (k_i8c_prep_queries); coarse score = B_q + s_q * (int dot), with a certified bound on its
     // distance to the reference-order f32 score — half the HBM / LDS-DMA bytes and half the MFMA time of
     // the f16 shadow; survivors are rescored exactly from the f32 rows as always.
-    constexpr bool I8 = I8Q != 0;           // int8 operands (SQ8 pass 1 or the certified coarse pass)
-    constexpr bool I8C = I8Q == 2;
+    // I8Q = 3 (F4): the operands are FP4 (E2M1) nibbles, two per byte — +1.0 / -1.0 / 0 are exact in it — on
+    // v_mfma_scale_f32_32x32x64_f8f6f4 with unit scales: batched Hamming as a +-1 GEMM (k_bits_to_fp4) at twice the int8 MFMA
+    // rate and half the bytes.  A 128-B line holds 256 elements; the K loop, the rings and the epilogue are those of the
+    // certified int8 pass (the f32 accumulators hold exact integers: converted where the integer epilogue reads them).
+    constexpr bool I8 = I8Q != 0;           // byte-addressed operands (SQ8 pass 1, the certified coarse pass, FP4 pairs)
+    constexpr bool F4 = I8Q == 3;
+    constexpr bool I8C = I8Q == 2 || F4;
     static_assert(!I8C || METRIC == M_IP, "certified int8 coarse pass: IP only");
-    constexpr bool AG = I8C && TQ * TR == 16;   // one wave per SIMD: accumulators in fixed AGPR tuples (ly_mfma_i8_agpr)
+    constexpr bool AG = I8Q == 2 && TQ * TR == 16;   // one wave per SIMD: accumulators in fixed AGPR tuples (ly_mfma_i8_agpr)
 #ifndef LYNSE_DEFER
 #define LYNSE_DEFER 1
 #endif
@@ -1510,6 +1535,11 @@ __global__ void __launch_bounds__(WQ * WR * 64, (TQ * TR >= 16) ? 1 : ((WQ * WR 
 
     uint32_t segpk = 0;  // segmented emission: this lane's TQ per-query slot counters, 8 bits each
     static_assert(TQ <= 4, "packed segment counters");
+    // the integer dot product an accumulator holds (I8C epilogues compare integers): the i32 MFMA's bits, or the exact integer
+    // value of the FP4 MFMA's f32 accumulator
+    [[maybe_unused]] auto acc_int = [](float x) -> int { return F4 ? (int)x : __float_as_int(x); };
+    [[maybe_unused]] int f4_unit = 0x7f7f7f7f;   // E8M0 scale bytes 127 = 2^0 (ly_mfma_fp4)
+    if constexpr (F4) asm volatile("" : "+v"(f4_unit));
     f32x16 acc[TR][TQ];
 #pragma unroll
     for (int i = 0; i < TR; ++i)
@@ -1694,7 +1724,15 @@ __global__ void __launch_bounds__(WQ * WR * 64, (TQ * TR >= 16) ? 1 : ((WQ * WR 
                 } else {
 #pragma unroll
                     for (int j = 0; j < TQ; ++j) {
-                        if constexpr (I8) {
+                        if constexpr (F4) {
+                            acc[i][j] = ly_mfma_fp4(af[cur][i], bf[cur][j], acc[i][j], f4_unit);
+#if defined(__HIP_DEVICE_COMPILE__)
+                            // pins the MFMA in front of the next sched_barrier: the scaled MFMA is in none of the instruction
+                            // classes sched_barrier(0) fences, and all 32 of a slab step sank below the last barrier of the
+                            // body — behind all 24 fragment reads, whose registers then went to scratch (ISA inspected)
+                            asm volatile("" : "+v"(acc[i][j]));
+#endif
+                        } else if constexpr (I8) {
                             typedef int i32x4 __attribute__((ext_vector_type(4)));
                             typedef int i32x16 __attribute__((ext_vector_type(16)));
                             acc[i][j] = __builtin_bit_cast(f32x16, __builtin_amdgcn_mfma_i32_32x32x32_i8(
@@ -1771,7 +1809,7 @@ __global__ void __launch_bounds__(WQ * WR * 64, (TQ * TR >= 16) ? 1 : ((WQ * WR 
             const int e_emit_all = TILED ? 0 : (FS ? (c_first ? 2 : 0) : (EMIT >= 0 ? EMIT : ea->emit_all));
             auto score = [&](int i, int j, int r, uint32_t m, bool rok) -> float {
                 if constexpr (I8C) {
-                    return c_extra[j] + c_qinv[j] * (float)__float_as_int(acc[i][j][r]);  // B_q + s_q * dot (separate mul / add)
+                    return c_extra[j] + c_qinv[j] * (float)acc_int(acc[i][j][r]);  // B_q + s_q * dot (separate mul / add)
                 } else if constexpr (I8) {
                     // dot of the u8 codes = i8 dot + 128 (sum q' + sum r') + 16384 D; squared L2 = sum q'^2 + sum r'^2 - 2 dot
                     const float accv = acc[i][j][r];
@@ -1912,14 +1950,14 @@ __global__ void __launch_bounds__(WQ * WR * 64, (TQ * TR >= 16) ? 1 : ((WQ * WR 
                         for (int g4 = 0; g4 < 4; ++g4) {
                             // one wave-level branch per FOUR accumulators (their maximum against T): a taken branch per element
                             // cost more than the compare it guards
-                            const int v0 = __float_as_int(acc[i][j][4 * g4]), v1 = __float_as_int(acc[i][j][4 * g4 + 1]);
-                            const int v2 = __float_as_int(acc[i][j][4 * g4 + 2]), v3 = __float_as_int(acc[i][j][4 * g4 + 3]);
+                            const int v0 = acc_int(acc[i][j][4 * g4]), v1 = acc_int(acc[i][j][4 * g4 + 1]);
+                            const int v2 = acc_int(acc[i][j][4 * g4 + 2]), v3 = acc_int(acc[i][j][4 * g4 + 3]);
                             const int m01 = v0 > v1 ? v0 : v1, m23 = v2 > v3 ? v2 : v3;
                             if (__builtin_expect((m01 > m23 ? m01 : m23) >= T, 0)) {   // (unlikely: the skip falls through)
 #pragma unroll
                                 for (int e = 0; e < 4; ++e) {
                                     const int r = 4 * g4 + e;
-                                    const int v = __float_as_int(acc[i][j][r]);
+                                    const int v = acc_int(acc[i][j][r]);
                                     if (v >= T) {
                                         const uint32_t bit = (r & 3) + 8 * (r >> 2) + 4 * hi;
                                         const uint32_t m = rb + wr * (TR * 32) + i * 32 + bit;
@@ -1948,7 +1986,7 @@ __global__ void __launch_bounds__(WQ * WR * 64, (TQ * TR >= 16) ? 1 : ((WQ * WR 
                         for (int i = 0; i < TR; ++i)
 #pragma unroll
                             for (int r = 0; r < 16; ++r) {
-                                const int v = __float_as_int(acc[i][j][r]);
+                                const int v = acc_int(acc[i][j][r]);
                                 bi = bi > v ? bi : v;
                             }
                         // the exact score expression on the column maximum (monotone: s_q >= 0) — or, with the integer image of
@@ -2002,7 +2040,7 @@ __global__ void __launch_bounds__(WQ * WR * 64, (TQ * TR >= 16) ? 1 : ((WQ * WR 
                             const bool rok = m < row_end && ((mw >> bit) & 1u);
                             bool pass;
                             if constexpr (I8C && QC_REG) {
-                                pass = __float_as_int(acc[i][j][r]) >= __float_as_int(e_thr);  // integer image of the threshold
+                                pass = acc_int(acc[i][j][r]) >= __float_as_int(e_thr);  // integer image of the threshold
                             } else {
                                 const float sc = score(i, j, r, m, rok);
                                 pass = ASC ? (sc <= e_thr) : (sc >= e_thr);
@@ -2502,39 +2540,43 @@ __global__ void __launch_bounds__(256) k_i8c_prep_queries(I8cPrepArgs a) {
 // and a zero margin; k_select takes the strict cut of the binary metrics, k_final turns the dot product back into the
 // distance (FinalArgs::ham_dim).  The lane-per-row popcount kernel (k_scan_binary_rows) needs 2 VALU operations per 32 bits
 // and (row, query) pair and is VALU-bound from ~16 queries on (36.8k queries/s at 12.5M x 1024 bits x 256 queries).
-//   k_bits_to_pm1      : packed words -> one signed byte per bit (+1 / -1), pitch ld8 (multiple of 16), pad columns 0;
+//   k_bits_to_fp4      : packed words -> one FP4 nibble per bit (+1.0 / -1.0), pitch round_up(D, 256) / 2 bytes, pad columns 0;
 //                        a resident copy like the f16 shadow / the SQ8 codes, built on the first batched Hamming search
+//                        (round 3 first fed the int8 MFMA from +-1 BYTES: 8x the packed words and the int8 rate; the FP4
+//                        form is 4x the words at twice the rate: v_mfma_scale_f32_32x32x64_f8f6f4, k_scan_h16<.., I8Q = 3>)
 //   k_bpm_prep_queries : packed query words -> the +-1 query image in the scan kernel's slab layout, open thresholds
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_bits_to_pm1(const uint64_t* __restrict__ P, uint32_t W, uint32_t D, uint64_t r0, uint64_t r1,
-                                                     int8_t* __restrict__ out, uint32_t ld8) {
-    const uint32_t cpr = ld8 / 16;   // 16-byte pieces per row
+__global__ void __launch_bounds__(256) k_bits_to_fp4(const uint64_t* __restrict__ P, uint32_t W, uint32_t D, uint64_t r0, uint64_t r1,
+                                                     uint8_t* __restrict__ out, uint32_t ldb) {
+    // one FP4 (E2M1) nibble per bit: 0x2 = +1.0 for a set bit, 0xA = -1.0 for a clear one, 0x0 = +0.0 in the pad columns;
+    // column c sits in nibble c & 1 of byte c / 2 (pitch ldb bytes = round_up(D, 256) / 2: whole 128-B slabs)
+    const uint32_t cpr = ldb / 16;   // 16-byte pieces (32 columns) per row
     const uint64_t total = (r1 - r0) * cpr;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
         const uint64_t r = r0 + i / cpr;
-        const uint32_t c0 = (uint32_t)(i % cpr) * 16;
+        const uint32_t c0 = (uint32_t)(i % cpr) * 32;
         const uint32_t w = c0 >> 6;
-        const uint32_t bits = w < W ? (uint32_t)(P[r * W + w] >> (c0 & 63)) & 0xffffu : 0u;
+        const uint32_t bits = w < W ? (uint32_t)(P[r * W + w] >> (c0 & 63)) : 0u;
         u32x4 v;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             uint32_t word = 0;
 #pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                const uint32_t col = c0 + j * 4 + b;
-                const uint32_t byte = col < D ? (((bits >> (j * 4 + b)) & 1u) ? 0x01u : 0xffu) : 0u;
-                word |= byte << (8 * b);
+            for (int b = 0; b < 8; ++b) {
+                const uint32_t col = c0 + j * 8 + b;
+                const uint32_t nib = col < D ? (((bits >> (j * 8 + b)) & 1u) ? 0x2u : 0xAu) : 0u;
+                word |= nib << (4 * b);
             }
             v[j] = word;
         }
-        *reinterpret_cast<u32x4*>(out + r * ld8 + c0) = v;
+        *reinterpret_cast<u32x4*>(out + r * ldb + (size_t)(i % cpr) * 16) = v;
     }
 }
 
 struct BpmPrepArgs {
     const uint64_t* QW;   // nq x W packed query words
-    uint32_t W, D, qpad, nslab;
-    int8_t* img;
+    uint32_t W, D, qpad, nslab;   // nslab: 128-B slabs of 256 columns
+    uint8_t* img;
     float *sq, *bq, *marg2, *thr;
     uint32_t *count, *overflow;
 };
@@ -2542,12 +2584,17 @@ struct BpmPrepArgs {
 __global__ void __launch_bounds__(256) k_bpm_prep_queries(BpmPrepArgs a) {
     const uint32_t q = blockIdx.x;
     const int tid = threadIdx.x;
-    const uint32_t total = a.nslab * 128;
+    const uint32_t total = a.nslab * 128;   // bytes of this query's image
     for (uint32_t i = tid; i < total; i += 256) {
-        int u = 0;
-        if (i < a.D) u = ((a.QW[(size_t)q * a.W + (i >> 6)] >> (i & 63)) & 1ull) ? 1 : -1;
+        uint32_t byte = 0;
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const uint32_t col = 2 * i + b;
+            const uint32_t nib = col < a.D ? (((a.QW[(size_t)q * a.W + (col >> 6)] >> (col & 63)) & 1ull) ? 0x2u : 0xAu) : 0u;
+            byte |= nib << (4 * b);
+        }
         const uint32_t s = i / 128, k = i % 128, l = k >> 4, e = k & 15, p = l ^ ((q >> 1) & 7);
-        a.img[(((size_t)s * a.qpad + q) * 8 + p) * 16 + e] = (int8_t)u;
+        a.img[(((size_t)s * a.qpad + q) * 8 + p) * 16 + e] = (uint8_t)byte;
     }
     if (tid == 0) {
         a.sq[q] = 1.0f;          // score = B_q + s_q * dot = the dot product itself (exact)

@@ -271,8 +271,9 @@ struct lynse_hip_flat {
     // certified int8 coarse pass (FLAT-IP batches of 33..256 queries): -1 = off (env / strikes), else overflow strikes so far
     std::atomic<int> i8c_strikes{0};     // (searches under the SHARED lock bump it)
     // batched Hamming on the matrix pipe: one signed byte per bit (+1 / -1) of the packed rows, pitch ld8; built lazily on the
-    // first Hamming batch of >= bin_mfma_minq() queries (8x the packed words: the price of feeding the int8 MFMA from HBM)
-    int8_t* bpm = nullptr;
+    // first Hamming batch of >= bin_mfma_minq() queries (4x the packed words: the price of feeding the matrix pipe from HBM)
+    uint8_t* bpm = nullptr;              // FP4 nibbles (+1.0 / -1.0 per bit), pitch ld_bpm = round_up(dim, 256) / 2 bytes
+    uint32_t ld_bpm = 0;
     uint64_t n_bpm = 0, bpm_cap = 0;
     bool bpm_failed = false;             // the copy did not fit: the popcount kernels answer
     // gathered ("few matches") filtered path: compact copy of the listed shadow rows, their norms and 32-bit ids
@@ -382,6 +383,7 @@ extern "C" int lynse_hip_flat_create(uint32_t dim, int device, lynse_hip_flat** 
     h->ld = round_up(dim, 4);
     h->ld16 = round_up(dim, 8);
     h->ld8 = round_up(dim, 16);
+    h->ld_bpm = round_up(dim, 256) / 2;
     h->ld8a = round_up(dim + 1, 128);
     while (h->aug_cols * 2 <= 32 && dim + h->aug_cols * 2 <= h->ld8a) h->aug_cols *= 2;
     h->words = (dim + 63) / 64;
@@ -733,22 +735,22 @@ static int ensure_bpm_locked(lynse_hip_flat* h) {
     LY_TRY(ensure_packed_locked(h));
     if (h->bpm_cap < h->n) {
         const uint64_t cap = std::max<uint64_t>(h->n, std::max<uint64_t>(h->capacity, h->packed_capacity));
-        int8_t* nb = nullptr;
-        if (hipMalloc(&nb, (size_t)cap * h->ld8 + 256) != hipSuccess) {  // no room for the 8x copy: not an error
+        uint8_t* nb = nullptr;
+        if (hipMalloc(&nb, (size_t)cap * h->ld_bpm + 256) != hipSuccess) {  // no room for the 4x copy: not an error
             (void)hipGetLastError();
             h->bpm_failed = true;
             return LYNSE_OK;
         }
         if (h->bpm && h->n_bpm)
-            LY_HIP(hipMemcpyAsync(nb, h->bpm, (size_t)h->n_bpm * h->ld8, hipMemcpyDeviceToDevice, cur(h).stream));
+            LY_HIP(hipMemcpyAsync(nb, h->bpm, (size_t)h->n_bpm * h->ld_bpm, hipMemcpyDeviceToDevice, cur(h).stream));
         LY_HIP(hipStreamSynchronize(cur(h).stream));
         if (h->bpm) (void)hipFree(h->bpm);
         h->bpm = nb;
         h->bpm_cap = cap;
     }
-    const uint64_t pieces = (h->n - h->n_bpm) * (h->ld8 / 16);
-    hipLaunchKernelGGL(k_bits_to_pm1, dim3((uint32_t)std::min<uint64_t>((pieces + 255) / 256, (uint64_t)h->num_cu * 32)), dim3(256), 0, cur(h).stream,
-                       h->packed, h->words, h->dim, h->n_bpm, h->n, h->bpm, h->ld8);
+    const uint64_t pieces = (h->n - h->n_bpm) * (h->ld_bpm / 16);
+    hipLaunchKernelGGL(k_bits_to_fp4, dim3((uint32_t)std::min<uint64_t>((pieces + 255) / 256, (uint64_t)h->num_cu * 32)), dim3(256), 0, cur(h).stream,
+                       h->packed, h->words, h->dim, h->n_bpm, h->n, h->bpm, h->ld_bpm);
     LY_HIP(hipGetLastError());
     LY_HIP(hipStreamSynchronize(cur(h).stream));
     h->n_bpm = h->n;
@@ -1259,9 +1261,9 @@ static int launch_scan_h16(const ScanArgs& a, int metric, uint32_t grid, hipStre
 
 // certified int8 coarse pass: the 256 x 256 IP tiling with 3 + 2-stage rings over 128-element slabs, one kernel per
 // (ragged last slab, emission mode)
-static int launch_scan_i8c(const ScanArgs& a, uint32_t grid, hipStream_t st, bool fs = false, bool filt = false) {
+static int launch_scan_i8c(const ScanArgs& a, uint32_t grid, hipStream_t st, bool fs = false, bool filt = false, bool f4 = false) {
     constexpr size_t lds = (size_t)(3 * 256 + 2 * 256) * 128;
-    static bool attr_done[11] = {false};
+    static bool attr_done[16] = {false};
     auto go = [&](auto kern, int slot) -> int {
         if (!attr_done[slot]) { LY_TRY(set_max_lds(kern, lds)); attr_done[slot] = true; }
         hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, a);
@@ -1292,6 +1294,13 @@ static int launch_scan_i8c(const ScanArgs& a, uint32_t grid, hipStream_t st, boo
         }
     }
 #endif
+    if (f4) {   // batched Hamming: FP4 +-1 operands (kernels.h, I8Q = 3); whole 128-B slabs by construction, unfiltered
+        if (a.ld16 % 128 != 0 || filt || fs) return set_error(LYNSE_ERR_INTERNAL, "the FP4 Hamming scan runs unfiltered over whole slabs");
+        if (a.emit_all == 1) return go(k_scan_h16<2, 4, 4, 2, M_IP, 3, 2, 2, false, false, 0, false, 3, 1>, 11);
+        if (a.emit_all == 2) return go(k_scan_h16<2, 4, 4, 2, M_IP, 3, 2, 2, false, false, 0, false, 3, 2>, 12);
+        if (a.dense) return go(k_scan_h16<2, 4, 4, 2, M_IP, 3, 2, 2, false, false, 0, false, 3, 0, 0, true>, 13);
+        return go(k_scan_h16<2, 4, 4, 2, M_IP, 3, 2, 2, false, false, 0, false, 3, 0>, 14);
+    }
     if (filt) {  // masked scan (subset as a row bitmask): emit-all sample with sentinels, DENSE threshold stages (kernels.h, FILT && I8C)
         if (a.ld16 % 128 != 0 || a.row_ids) return set_error(LYNSE_ERR_INTERNAL, "the masked int8 scan needs whole 128-column slabs and a row bitmask");
         if (a.emit_all == 1) return go(k_scan_h16<2, 4, 4, 2, M_IP, 3, 2, 2, false, false, 0, true, 2, 1>, 9);
@@ -1484,7 +1493,7 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
     const bool aug = i8c && !bin_mfma && metric == M_L2;
     const bool cosq = i8c && !bin_mfma && metric == M_COS;   // cosine distance: unit vectors, negated score space (I8cPrepArgs::cosine)
     const int key_metric = (bin_mfma || aug || cosq) ? (int)M_IP : metric;   // the order of the candidate keys
-    const uint32_t nslab = i8c ? ((aug ? h->dim + h->aug_cols : h->dim) + 127) / 128 : glds ? (h->dim + GL_BK - 1) / GL_BK : (h->dim + SCAN_BK - 1) / SCAN_BK;  // h16: HK == SCAN_BK == 64
+    const uint32_t nslab = bin_mfma ? h->ld_bpm / 128 : i8c ? ((aug ? h->dim + h->aug_cols : h->dim) + 127) / 128 : glds ? (h->dim + GL_BK - 1) / GL_BK : (h->dim + SCAN_BK - 1) / SCAN_BK;  // h16: HK == SCAN_BK == 64
     const bool small = nq <= SCAN_BQ_SMALL;
     const uint32_t qpad = small ? SCAN_BQ_SMALL : round_up(nq, SCAN_BQ_LARGE);  // > 256 queries: a widened handle, qpad / 256 chunks per launch
     const uint32_t qchunks = small ? 1u : qpad / SCAN_BQ_LARGE;
@@ -1504,9 +1513,9 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
     }
 
     if (bin_mfma) {
-        if (nq != qpad || h->dim % 128 != 0) LY_HIP(hipMemsetAsync(w.Q16, 0, (size_t)nslab * qpad * 128, st));
+        if (nq != qpad) LY_HIP(hipMemsetAsync(w.Q16, 0, (size_t)nslab * qpad * 128, st));   // (the prep kernel writes every byte of its queries' lines, pad columns included)
         BpmPrepArgs p{};
-        p.QW = w.QW; p.W = h->words; p.D = h->dim; p.qpad = qpad; p.nslab = nslab; p.img = reinterpret_cast<int8_t*>(w.Q16);
+        p.QW = w.QW; p.W = h->words; p.D = h->dim; p.qpad = qpad; p.nslab = nslab; p.img = reinterpret_cast<uint8_t*>(w.Q16);
         p.sq = w.qinv; p.bq = w.qn2; p.marg2 = w.marg2; p.thr = w.thr; p.count = w.count; p.overflow = w.overflow;
         hipLaunchKernelGGL(k_bpm_prep_queries, dim3(nq), dim3(256), 0, st, p);
         LY_HIP(hipGetLastError());
@@ -1639,7 +1648,7 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
             uint32_t tile_rows = (glds && !small && big_rows == 256) ? 256u : (uint32_t)SCAN_BR;
             if (h16) tile_rows = small ? 128u : 256u;
             a.V16 = h->rows16; a.ld16 = h->ld16;
-            if (i8c) { a.V16 = reinterpret_cast<const _Float16*>(bin_mfma ? h->bpm : (aug ? h->sq8a : (cosq ? h->sq8c : h->sq8))); a.ld16 = aug ? h->ld8a : h->ld8; }
+            if (i8c) { a.V16 = reinterpret_cast<const _Float16*>(bin_mfma ? (const int8_t*)h->bpm : (aug ? h->sq8a : (cosq ? h->sq8c : h->sq8))); a.ld16 = bin_mfma ? h->ld_bpm : (aug ? h->ld8a : h->ld8); }
             if (glds && !small && big_rows == 192 && metric == M_IP) tile_rows = 192u;
             a.qpad = qpad; a.nq = nq; a.nslab = nslab; a.ntiles = (s.r1 - s.r0 + tile_rows - 1) / tile_rows;
             if (s.sample_tiles) a.ntiles = s.sample_tiles;
@@ -1671,14 +1680,14 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
                 const uint64_t seen_before = s.sample_tiles ? 0 : (sample.sample_tiles ? std::max<uint64_t>((uint64_t)sample.sample_tiles * plan_tile, s.r0) : s.r0);
                 a.dense = (!a.emit_all && a.ld16 % 128 == 0 && seen_before &&
                            (filt || (dense_env >= 0 ? dense_env != 0 : (uint64_t)k * 50000ull > seen_before))) ? 1 : 0;   // (masked: DENSE is the one epilogue compiled with the mask)
-                const bool ag = getenv("LYNSE_HIP_AG") && atoi(getenv("LYNSE_HIP_AG")) && a.ld16 % 128 == 0 && !a.emit_all && !fs_stage && !filt;
+                const bool ag = getenv("LYNSE_HIP_AG") && atoi(getenv("LYNSE_HIP_AG")) && a.ld16 % 128 == 0 && !a.emit_all && !fs_stage && !filt && !bin_mfma;
                 if (!a.emit_all) seg_geometry(grid, (a.dense ? 8 : 4) / (ag ? 2 : 1), &a.nseg, &a.seg);   // (segments per workgroup: WR, or 2 WR wave halves with DENSE)
                 if (fs_stage) {
                     a.fs_stride = sample.sample_stride; a.fs_rows = (uint32_t)h->n; a.gsync = w.gsync; a.Qf = Qf; a.marg2 = w.marg2;
                     a.thr_out = w.thr; a.k = k; a.ip_form = ip_form; a.metric = metric;
                     if (getenv("LYNSE_HIP_FS_STAMPS")) a.debug_flags |= 128;
                 }
-                LY_TRY(launch_scan_i8c(a, grid, st, fs_stage, filt));
+                LY_TRY(launch_scan_i8c(a, grid, st, fs_stage, filt, bin_mfma));
             } else if (h16) {
                 a.candB = w.candB; a.segcnt = w.segcnt;
                 if (small) {
@@ -2549,7 +2558,7 @@ extern "C" uint64_t lynse_hip_flat_hbm_bytes(const lynse_hip_flat* h) {
     if (h->sq8) b += h->sq8_cap * h->ld8 + 2ull * (h->sq8_cap + 256) * 4;
     if (h->sq8a) b += h->sq8a_cap * h->ld8a;
     if (h->sq8c) b += h->sq8c_cap * h->ld8;
-    if (h->bpm) b += h->bpm_cap * h->ld8;
+    if (h->bpm) b += h->bpm_cap * h->ld_bpm;
     return b;
 }
 
