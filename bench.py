@@ -559,8 +559,8 @@ def other_configs(dev):
             for i in sorted({0, nq - 1}):
                 e_ids, e_d = orc.canonical_topk_packed(qw[i], host, 50, O.HAMMING)
                 ok = ok and np.array_equal(r[i].astype(np.uint32), e_ids) and np.array_equal(dd[i], e_d)
-            # >= 96 queries: the +-1 GEMM on the FP4 MFMA streams one NIBBLE per bit (4x the packed words); below: the popcount kernels
-            mfma = nq >= 96
+            # >= 72 queries: the +-1 GEMM on the FP4 MFMA streams one NIBBLE per bit (4x the packed words); below: the popcount kernels
+            mfma = nq >= 72
             kb = gbps * (4.0 if mfma else 1.0)
             res["nq%d" % nq] = {"ms": round(ms, 4), "queries_per_s": round(nq / ms * 1e3, 1), "scan_us": us, "packed_GBps": gbps,
                                 "kernel": "k_scan_h16<2,4,4,2,IP,fp4> (v_mfma_scale_f32_32x32x64_f8f6f4) over the +-1 FP4 copy" if mfma else "k_scan_binary_rows",

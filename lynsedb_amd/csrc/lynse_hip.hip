@@ -720,11 +720,11 @@ static int ensure_packed_locked(lynse_hip_flat* h) {
     return LYNSE_OK;
 }
 
-// Batched Hamming on the int8 MFMA (kernels.h, k_bits_to_pm1): batches of at least LYNSE_HIP_BIN_MFMA_MINQ (default 16)
+// Batched Hamming on the int8 MFMA (kernels.h, k_bits_to_pm1): batches of at least LYNSE_HIP_BIN_MFMA_MINQ (default 72)
 // queries, unfiltered, Hamming only (Jaccard / Dice need the row popcounts in the score: the popcount kernels keep them).
 static uint32_t bin_mfma_minq() {
-    static const uint32_t v = []() { const char* e = getenv("LYNSE_HIP_BIN_MFMA_MINQ"); return e ? (uint32_t)atoi(e) : 96u; }();
-    return v;   // (the MFMA pass costs the same for 33 or 256 queries, the popcount kernel scales with the batch: they cross near 100)
+    static const uint32_t v = []() { const char* e = getenv("LYNSE_HIP_BIN_MFMA_MINQ"); return e ? (uint32_t)atoi(e) : 72u; }();
+    return v;   // (the MFMA pass costs the same for 33 or 256 queries — 1.9 ms at 12.5M x 1024 bits —, the popcount kernel ~27 us per query: they cross near 70)
 }
 static bool bin_mfma_eligible(const lynse_hip_flat* h, int metric, bool filtered, uint64_t nq) {
     return metric == M_HAMMING && !filtered && bin_mfma_minq() > 0 && nq >= bin_mfma_minq() && nq > SCAN_BQ_SMALL && !h->bpm_failed &&

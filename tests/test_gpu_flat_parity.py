@@ -635,12 +635,12 @@ def test_sharded_search_entry_point_with_a_one_rank_communicator(L, oracle):
 
 
 @pytest.mark.parametrize("n,bits,nq,k,p_one", [(200_000, 1024, 256, 50, 0.5), (150_000, 200, 130, 10, 0.3), (70_000, 64, 100, 64, 0.5),
-                                              (300_000, 1152, 97, 5, 0.1)])
+                                              (300_000, 1152, 97, 5, 0.1), (100_000, 4096, 72, 20, 0.5)])
 def test_batched_hamming_on_the_matrix_pipe_equals_the_popcount_kernels(L, oracle, n, bits, nq, k, p_one):
-    """Hamming batches of >= 96 queries run as an exact +-1 int8 GEMM on the MFMA (popcount(x ^ q) = (D - dot) / 2, strict
+    """Hamming batches of >= 72 queries run as an exact +-1 GEMM in FP4 on the MFMA (popcount(x ^ q) = (D - dot) / 2, strict
     cut, no rescoring; packed_binary_search, flat_mmap.rs:1345-1409).  Same ids and distances as the oracle and as the
-    popcount kernels a small batch takes — widths that are no multiple of 128 (ragged last slab), narrow rows with huge tie
-    groups at the k-th distance, sparse rows."""
+    popcount kernels a small batch takes — widths that are no multiple of 256 (zero nibbles in the pad columns), narrow rows
+    with huge tie groups at the k-th distance, sparse rows."""
     from lynsedb_amd.datasets import packed_bernoulli
 
     words = packed_bernoulli(n, bits, p_one, 100 + bits)
