@@ -4,7 +4,7 @@ mkdir -p gpurun_out/r03
 (time timeout 900 python bench.py) > gpurun_out/r03/bench_full.json 2> gpurun_out/r03/bench_full.err
 bash scripts/prof.sh r03_c2 python bench.py --no-cpu-baseline --no-configs --no-verify --steps 15 --warmup 3 > gpurun_out/r03/prof_c2.log 2>&1
 python scripts/summarize_pmc.py gpurun_out/r03_c2 gpurun_out/r03/r03_c2_pmc k_scan_h16 k_select k_select_final k_i8c_prep_queries > gpurun_out/r03/sum.log 2>&1
-python scripts/pmc_traffic.py gpurun_out/r03_c2 gpurun_out/r03/r03_pmc_traffic.json 10000000 768 18 >> gpurun_out/r03/sum.log 2>&1
+python scripts/pmc_traffic.py gpurun_out/r03_c2 gpurun_out/r03/r03_pmc_traffic.json 10000000 768 28 >> gpurun_out/r03/sum.log 2>&1
 f=$(find gpurun_out/r03_c2/stats -name "*kernel_stats.csv" | head -1); cp "$f" gpurun_out/r03/r03_c2_kernel_stats.csv
 S="timeout 300 python bench.py --no-cpu-baseline --no-configs --no-verify --steps 60 --warmup 5 --rows 1250000"
 LYNSE_BENCH_FORCE_COMM=1 $S --in-flight 3 > gpurun_out/r03/shard_1p25m_in_flight_1rank_comm.json 2>/dev/null
