@@ -123,7 +123,7 @@ __global__ void __launch_bounds__(256) k_ivf_gather_q(const _Float16* __restrict
 // k_scan_h16 through ScanArgs::ntiles_dev, the group count by k_ivf_gather_groups / k_ivf_emit_tiles.  One workgroup: at most
 // IVF_GROUP_MAX_PAIRS pairs and IVF_GROUP_MAX_LISTS lists (its LDS); anything larger keeps the host path.
 // ------------------------------------------------------------------------------------------------
-constexpr uint32_t IVF_GROUP_MAX_PAIRS = 8192;
+constexpr uint32_t IVF_GROUP_MAX_PAIRS = 16384;
 constexpr uint32_t IVF_GROUP_MAX_LISTS = 8192;
 
 struct IvfGroup {
@@ -141,6 +141,7 @@ struct IvfGroupArgs {
     uint32_t flag_empty;       // IVFIndex: a query whose probed lists are all empty scans EVERY list (ivf.rs:258-265): flagged, host path
     uint32_t* pair_q;          // out [pairs]: the query of pair slot i (slots grouped by list)
     IvfGroup* groups;          // out [groups]
+    uint32_t* prank;           // scratch [pairs]: rank of pair i inside its list (global memory: the LDS holds the per-list arrays)
     uint32_t* tbase;           // out [3][gmax]: first tile of group g in window w
     uint32_t gmax;
     IvfTile* tiles;            // out [3][win_cap] (k_ivf_emit_tiles)
@@ -177,8 +178,8 @@ __global__ void __launch_bounds__(NT) k_ivf_group(IvfGroupArgs a) {
     uint32_t* cnt = reinterpret_cast<uint32_t*>(ivf_smem);   // [NL] pairs per list
     uint32_t* pinc = cnt + NL;                                // [NL] inclusive scan of cnt; later tiles per group (<= P entries)
     uint32_t* ginc = pinc + (NL > P ? NL : P);                // [NL] inclusive scan of the groups per list
-    uint32_t* prank = ginc + NL;                              // [P]  rank of pair i inside its list, ~0 = no pair
-    uint32_t* tot = prank + P;                                // [NT / 64]
+    uint32_t* prank = a.prank;                                // [P]  rank of pair i inside its list, ~0 = no pair
+    uint32_t* tot = ginc + NL;                                // [NT / 64]
     uint32_t* qcnt = tot + NT / 64;                           // [256] valid pairs per query
     __shared__ uint32_t s_flag;
     const uint32_t tid = threadIdx.x;

@@ -698,3 +698,13 @@ def test_ivf_device_side_grouping_equals_the_host_path(L, oracle, metric, monkey
             c = int(got["1"][2][qi])
             assert c == len(e_ids) and np.array_equal(got["1"][0][qi, :c], e_ids), (nprobe, with_far, qi, got["1"][0][qi, :c], e_ids)
             assert np.array_equal(got["1"][1][qi, :c].view(np.uint32), e_d.view(np.uint32))
+    # more pairs than 8192 (256 queries x 40 probes): the pair ranks live in global memory, the per-list arrays in LDS
+    big = (data[rng.integers(0, n, 256)] + 0.05 * rng.standard_normal((256, dim))).astype(f32)
+    got = {}
+    for dg in ("1", "0"):
+        monkeypatch.setenv("LYNSE_HIP_IVF_DEVICE_GROUPING", dg)
+        got[dg] = idx.search_batch_arrays(big, k, 40)
+    assert np.array_equal(got["1"][0], got["0"][0]) and np.array_equal(got["1"][1].view(np.uint32), got["0"][1].view(np.uint32))
+    for qi in (0, 100, 255):
+        e_ids, e_d, _ = oracle.ivf_search(big[qi], data, cen, off, rows, 40, k, metric)
+        assert np.array_equal(got["1"][0][qi, :len(e_ids)], e_ids) and np.array_equal(got["1"][1][qi, :len(e_ids)].view(np.uint32), e_d.view(np.uint32))
