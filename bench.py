@@ -401,6 +401,9 @@ def same_shard_variants(idx, queries, B, K, N, D):
     rows = torch.zeros((B, K), dtype=torch.int64, device=queries.device)
     dists = torch.zeros((B, K), dtype=torch.float32, device=queries.device)
     counts = torch.zeros(B, dtype=torch.int32, device=queries.device)
+    idx.search_device(queries, K, "ip", rows, dists, counts)
+    torch.cuda.synchronize()
+    rows_ip = rows.clone()
     for name in ("l2", "cosine"):
         t0 = time.time()
         idx.prepare(name, B)
@@ -413,6 +416,20 @@ def same_shard_variants(idx, queries, B, K, N, D):
         out[name] = {"ms_per_step": round(ms, 4), "queries_per_s": round(B / ms * 1e3, 1), "scan_us_per_step": us, "derived_build_s": round(build_s, 3),
                      "int8_coarse_pass": bool(plan & 4), "fallback_queries": int(p["fallback_queries"]),
                      "rescored_per_query": round(p["pool_entries"] / max(p["searches"] * B, 1), 1)}
+    # small batches on the same shard (the 128-row x 32-query tiling; from 256K rows on it streams the SQ8 codes as well): HBM-bound
+    for nq in (1, 32):
+        dq = queries[:nq].contiguous()
+        r1 = torch.zeros((nq, K), dtype=torch.int64, device=queries.device)
+        d1 = torch.zeros((nq, K), dtype=torch.float32, device=queries.device)
+        c1 = torch.zeros(nq, dtype=torch.int32, device=queries.device)
+        fn = lambda: idx.search_device(dq, K, "ip", r1, d1, c1)  # noqa: E731
+        ms = _time_calls(fn, 3, 10) * 1e3
+        us, _, p = _scan_profile(idx, fn, 4, 0)
+        same = bool(torch.equal(r1, rows_ip[:nq])) if rows_ip is not None else None
+        out["ip_nq%d" % nq] = {"ms_per_call": round(ms, 4), "queries_per_s": round(nq / ms * 1e3, 1), "scan_us_per_call": us,
+                               "int8_stream_GBps": round(N * D / (us * 1e-6) / 1e9, 1) if us else None,
+                               "frac_of_hbm_peak": round(N * D / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4) if us else None,
+                               "int8_coarse_pass": bool(int(p["last_plan"]) & 4), "same_rows_as_the_256_query_batch": same}
     rng = np.random.default_rng(7)
     member = rng.random(N) < 0.5
     ids = np.nonzero(member)[0].astype(np.uint64)

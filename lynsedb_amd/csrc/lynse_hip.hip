@@ -1259,6 +1259,21 @@ static int launch_scan_h16(const ScanArgs& a, int metric, uint32_t grid, hipStre
     }
 }
 
+// certified int8 coarse pass for batches of <= 32 queries: the 128-row x 32-query tiling (two workgroups per CU, 3 + 3-stage
+// rings) over the SQ8 codes — HBM-bound like its f16 twin, at half the bytes; emission mode at run time (EMIT = -1)
+static int launch_scan_i8c_small(const ScanArgs& a, uint32_t grid, hipStream_t st) {
+    constexpr size_t lds = (size_t)(3 * 128 + 3 * 32) * 128;
+    static bool attr_done[2] = {false, false};
+    auto go = [&](auto kern, int slot) -> int {
+        if (!attr_done[slot]) { LY_TRY(set_max_lds(kern, lds)); attr_done[slot] = true; }
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a);
+        LY_HIP(hipGetLastError());
+        return LYNSE_OK;
+    };
+    if (a.ld16 % 128 == 0) return go(k_scan_h16<1, 4, 1, 1, M_IP, 3, 3, 2, false, false, 0, false, 2>, 0);
+    return go(k_scan_h16<1, 4, 1, 1, M_IP, 3, 3, 2, false, true, 0, false, 2>, 1);
+}
+
 // certified int8 coarse pass: the 256 x 256 IP tiling with 3 + 2-stage rings over 128-element slabs, one kernel per
 // (ragged last slab, emission mode)
 static int launch_scan_i8c(const ScanArgs& a, uint32_t grid, hipStream_t st, bool fs = false, bool filt = false, bool f4 = false) {
@@ -1670,7 +1685,12 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
                 }
             }
             const int variant = scan_variant();
-            if (i8c) {
+            if (i8c && small) {
+                a.candB = w.candB; a.segcnt = w.segcnt;
+                const uint32_t grid = std::min<uint32_t>(a.ntiles, (uint32_t)h->num_cu * 2);
+                if (!a.emit_all) seg_geometry(grid, 4, &a.nseg, &a.seg);
+                LY_TRY(launch_scan_i8c_small(a, grid, st));
+            } else if (i8c) {
                 a.candB = w.candB; a.segcnt = w.segcnt;
                 const uint32_t grid = std::min<uint32_t>(a.ntiles, (uint32_t)h->num_cu);
                 // DENSE epilogue while the threshold is loose (kernels.h): the int8 margin keeps ~5x the rows an exact threshold
@@ -2156,7 +2176,11 @@ static bool i8c_eligible(const lynse_hip_flat* h, int metric, bool filtered, uin
     // are left to it
     const bool cos_ok = metric == M_COS && !l2_off && h->dim >= 256 && !h->cos_degenerate;
     if (masked && metric != M_L2 && h->ld8 % 128 != 0) return false;
-    return (metric == M_IP || l2_ok || cos_ok) && !filtered && !view && nqc > SCAN_BQ_SMALL && h->dtype == LYNSE_DTYPE_F32 &&
+    // batches of <= 32 queries (the 128 x 32 tiling, HBM-bound: half the bytes = half the time) from 256K rows on — below, the scan
+    // is a few tens of microseconds either way and the exact few-query kernel often answers alone (LYNSE_HIP_COARSE_SMALLQ=0: off)
+    static const int smallq = []() { const char* e = getenv("LYNSE_HIP_COARSE_SMALLQ"); return e ? atoi(e) : 1; }();
+    const bool nq_ok = nqc > SCAN_BQ_SMALL || (smallq && !masked && nqc >= 1 && (coarse_env() == 2 || h->n >= 262144));
+    return (metric == M_IP || l2_ok || cos_ok) && !filtered && !view && nq_ok && h->dtype == LYNSE_DTYPE_F32 &&
            scan_variant() == 3 && coarse_env() != 1 && strikes >= 0 && strikes < 3 && (coarse_env() == 2 || h->n >= 65536);
 }
 

@@ -84,7 +84,7 @@ def test_c2_flat_ip_768_batch256_runs_the_benchmarked_kernels(L, oracle):
         assert p_u["scan_launches"] == launches and bool(plan_fields(p_u)[0] & PLAN_FUSED_SAMPLE) == fused and p_u["fallback_queries"] == 0, p_u
         assert np.array_equal(r_u, rows) and np.array_equal(d_u.view(np.uint32), dists.view(np.uint32)) and np.array_equal(c_u, counts)
     # other batch sizes give the same answers: 40 queries (same kernels, mostly empty query columns) and 8 queries
-    # (the <= 32-query kernel over the f16 shadow)
+    # (the <= 32-query tiling; from 256K rows on it streams the SQ8 codes too)
     r40, d40, c40 = idx.search_batch_arrays(queries[:40], k, "ip")
     assert np.array_equal(r40, rows[:40]) and np.array_equal(d40.view(np.uint32), dists[:40].view(np.uint32))
     r8, d8, c8 = idx.search_batch_arrays(queries[:8], k, "ip")

@@ -293,3 +293,30 @@ def test_masked_int8_scan_subset_smaller_than_k_and_empty_tiles(L, oracle, monke
             assert c == len(e_ids) == min(k, len(ids))
             assert np.array_equal(rows[qi, :c].astype(np.uint64), e_ids.astype(np.uint64))
             assert np.array_equal(dists[qi, :c].view(np.uint32), e_d.view(np.uint32))
+
+
+# ---- batches of <= 32 queries on the certified int8 pass (k_scan_h16<1,4,1,1,IP,..,I8Q=2>: the 128-row x 32-query tiling over
+# the SQ8 codes; shards of >= 256K rows): single queries and small batches are HBM-bound, the codes are half the bytes
+@pytest.mark.parametrize("metric,n,dim", [("ip", 400_000, 768), ("ip", 300_000, 200), ("l2", 300_000, 512), ("cosine", 300_000, 256)])
+def test_small_batches_run_the_certified_int8_pass(L, oracle, metric, n, dim):
+    rng = np.random.default_rng(5000 + dim)
+    data = rng.random((n, dim), dtype=f32) if metric == "ip" else rng.standard_normal((n, dim)).astype(f32)
+    queries = (data[rng.integers(0, n, 32)] + 0.05 * rng.standard_normal((32, dim))).astype(f32)
+    queries[3] = -queries[3]                               # a mixed-sign / far-away query among them
+    idx = L.FlatIndex(None, dim)
+    idx.write(data)
+    idx.finalize()
+    idx.profile_enable(True)
+    m = {"ip": O.IP, "l2": O.L2, "cosine": O.COS}[metric]
+    for nq, k in ((1, 10), (5, 1), (32, 10), (17, 64)):
+        idx.profile_get(reset=True)
+        rows, dists, counts = idx.search_batch_arrays(queries[:nq], k, metric)
+        p = idx.profile_get(reset=True)
+        flags = int(p["last_plan"]) & 0xff
+        assert flags & PLAN_I8C_STARTED and flags & 16, (metric, nq, bin(flags))      # started on int8, on the <= 32-query tiling
+        assert flags & PLAN_I8C and p["fallback_queries"] == 0, (metric, nq, p)
+        for qi in sorted({0, min(3, nq - 1), nq - 1}):
+            e_ids, e_d = oracle.canonical_topk(queries[qi], data, k, m)
+            assert int(counts[qi]) == k
+            assert np.array_equal(rows[qi].astype(np.uint64), e_ids.astype(np.uint64)), (metric, nq, qi, rows[qi], e_ids)
+            assert np.array_equal(dists[qi].view(np.uint32), e_d.view(np.uint32)), (metric, nq, qi)
