@@ -1274,6 +1274,28 @@ static int launch_scan_i8c_small(const ScanArgs& a, uint32_t grid, hipStream_t s
     return go(k_scan_h16<1, 4, 1, 1, M_IP, 3, 3, 2, false, true, 0, false, 2>, 1);
 }
 
+// certified int8 coarse pass for batches of 33..64 queries (128 rows x 64 queries, 4 waves, two workgroups per CU, 3 + 3 stages)
+// and of 65..128 queries (256 rows x 128 queries, 8 waves as 2 x 4, 3 + 2 stages): per row byte they do a quarter / half of the
+// MFMA and fragment-read work of the 256-query tiling, which a batch of 40 or 100 queries would otherwise pay in full
+static int launch_scan_i8c_mid(const ScanArgs& a, uint32_t grid, hipStream_t st, bool wide) {
+    static bool attr_done[4] = {false, false, false, false};
+    const bool rag = a.ld16 % 128 != 0;
+    auto go = [&](auto kern, int slot, size_t lds, uint32_t threads) -> int {
+        if (!attr_done[slot]) { LY_TRY(set_max_lds(kern, lds)); attr_done[slot] = true; }
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, st, a);
+        LY_HIP(hipGetLastError());
+        return LYNSE_OK;
+    };
+    if (!wide) {
+        constexpr size_t lds = (size_t)(3 * 128 + 3 * 64) * 128;
+        if (!rag) return go(k_scan_h16<1, 4, 2, 1, M_IP, 3, 3, 2, false, false, 0, false, 2>, 0, lds, 256);
+        return go(k_scan_h16<1, 4, 2, 1, M_IP, 3, 3, 2, false, true, 0, false, 2>, 1, lds, 256);
+    }
+    constexpr size_t lds = (size_t)(3 * 256 + 2 * 128) * 128;
+    if (!rag) return go(k_scan_h16<2, 4, 2, 2, M_IP, 3, 2, 2, false, false, 0, false, 2>, 2, lds, 512);
+    return go(k_scan_h16<2, 4, 2, 2, M_IP, 3, 2, 2, false, true, 0, false, 2>, 3, lds, 512);
+}
+
 // certified int8 coarse pass: the 256 x 256 IP tiling with 3 + 2-stage rings over 128-element slabs, one kernel per
 // (ragged last slab, emission mode)
 static int launch_scan_i8c(const ScanArgs& a, uint32_t grid, hipStream_t st, bool fs = false, bool filt = false, bool f4 = false) {
@@ -1510,8 +1532,13 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
     const int key_metric = (bin_mfma || aug || cosq) ? (int)M_IP : metric;   // the order of the candidate keys
     const uint32_t nslab = bin_mfma ? h->ld_bpm / 128 : i8c ? ((aug ? h->dim + h->aug_cols : h->dim) + 127) / 128 : glds ? (h->dim + GL_BK - 1) / GL_BK : (h->dim + SCAN_BK - 1) / SCAN_BK;  // h16: HK == SCAN_BK == 64
     const bool small = nq <= SCAN_BQ_SMALL;
-    const uint32_t qpad = small ? SCAN_BQ_SMALL : round_up(nq, SCAN_BQ_LARGE);  // > 256 queries: a widened handle, qpad / 256 chunks per launch
-    const uint32_t qchunks = small ? 1u : qpad / SCAN_BQ_LARGE;
+    // mid-size batches on the int8 codes: 33..64 queries -> the 128 x 64 tiling, 65..128 -> the 256 x 128 tiling (LYNSE_HIP_MID_TILINGS=0: off)
+    const int mid_env = []() { const char* e = getenv("LYNSE_HIP_MID_TILINGS"); return e ? atoi(e) : 1; }();   // (read per call: tests flip it)
+    const bool mid_ok = mid_env && i8c && !bin_mfma && !small && !mask && !row_ids && h16;
+    const bool mid64 = mid_ok && nq <= 64, mid128 = mid_ok && !mid64 && nq <= 128;
+    const bool narrow = small || mid64;   // 128-row tiles
+    const uint32_t qpad = small ? SCAN_BQ_SMALL : mid64 ? 64u : mid128 ? 128u : round_up(nq, SCAN_BQ_LARGE);  // > 256 queries: a widened handle, qpad / 256 chunks per launch
+    const uint32_t qchunks = (small || mid64 || mid128) ? 1u : qpad / SCAN_BQ_LARGE;
     if (qchunks > 1 && (binary || i8c || mask || row_ids || !h16 || h->n > w.cap || nq > w.qcap))
         return set_error(LYNSE_ERR_INTERNAL, "more than 256 queries per pass need the widened float pipeline over <= cap rows");
     int ip_form = h->ip_form;
@@ -1564,7 +1591,7 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
     }
 
     // the sampled plan needs the strided-tile support of k_scan_h16; every other kernel starts at level 1
-    const uint32_t plan_tile = (h16 && !binary) ? (small ? 128u : 256u) : 0u;
+    const uint32_t plan_tile = (h16 && !binary) ? (narrow ? 128u : 256u) : 0u;
     static const int no_sample = []() { const char* e = getenv("LYNSE_HIP_NO_SAMPLE_PLAN"); return e ? atoi(e) : 0; }();
     // wave tiling of the 256 x 256 tile (measured on MI355X, 10M x 768, 256 queries): IP is fastest with <2,4,4,2> and the
     // 3+2-stage split rings, L2 / cosine (norm ring in LDS, more registers in the epilogue) with <4,2,2,4> and 2+2 stages
@@ -1601,7 +1628,7 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
     // hand-over drains the LDS-DMA ring of every CU and idles the chip twice, which costs more than a kernel boundary.
     const int fs_env = []() { const char* e = getenv("LYNSE_HIP_FUSED_SAMPLE"); return e ? atoi(e) : 0; }();   // (read per call: tests flip it)
     static const int dbg_env = []() { const char* e = getenv("LYNSE_HIP_DEBUG_FLAGS"); return e ? atoi(e) : 0; }();
-    const bool fs = fs_env != 0 && !dbg_env && i8c && !aug && !cosq && !bin_mfma && h->ld8 % 128 == 0 && sample_threshold_only && plan.size() >= 2 && k <= 32 &&
+    const bool fs = fs_env != 0 && !dbg_env && i8c && !aug && !cosq && !bin_mfma && !mid64 && !mid128 && h->ld8 % 128 == 0 && sample_threshold_only && plan.size() >= 2 && k <= 32 &&
                     sample.sample_tiles == (uint32_t)h->num_cu && (plan[1].r1 - plan[1].r0 + 255) / 256 >= (uint32_t)h->num_cu &&
                     (uint64_t)k * 50000ull > (uint64_t)sample.sample_tiles * plan_tile &&   // (the stage behind the sample runs the DENSE epilogue)
                     []() { const char* e = getenv("LYNSE_HIP_DENSE"); return !e || atoi(e) != 0; }();
@@ -1661,7 +1688,7 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
             if (!s.sample_tiles && sample.sample_tiles && !sample_threshold_only) { a.skip_stride = sample.sample_stride; a.skip_tiles = sample.sample_tiles; }
             static const int big_rows = []() { const char* e = getenv("LYNSE_HIP_SCAN_BR"); return e ? atoi(e) : 256; }();
             uint32_t tile_rows = (glds && !small && big_rows == 256) ? 256u : (uint32_t)SCAN_BR;
-            if (h16) tile_rows = small ? 128u : 256u;
+            if (h16) tile_rows = narrow ? 128u : 256u;
             a.V16 = h->rows16; a.ld16 = h->ld16;
             if (i8c) { a.V16 = reinterpret_cast<const _Float16*>(bin_mfma ? (const int8_t*)h->bpm : (aug ? h->sq8a : (cosq ? h->sq8c : h->sq8))); a.ld16 = bin_mfma ? h->ld_bpm : (aug ? h->ld8a : h->ld8); }
             if (glds && !small && big_rows == 192 && metric == M_IP) tile_rows = 192u;
@@ -1690,6 +1717,11 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
                 const uint32_t grid = std::min<uint32_t>(a.ntiles, (uint32_t)h->num_cu * 2);
                 if (!a.emit_all) seg_geometry(grid, 4, &a.nseg, &a.seg);
                 LY_TRY(launch_scan_i8c_small(a, grid, st));
+            } else if (mid64 || mid128) {
+                a.candB = w.candB; a.segcnt = w.segcnt;
+                const uint32_t grid = std::min<uint32_t>(a.ntiles, (uint32_t)h->num_cu * (mid64 ? 2u : 1u));
+                if (!a.emit_all) seg_geometry(grid, 4, &a.nseg, &a.seg);
+                LY_TRY(launch_scan_i8c_mid(a, grid, st, mid128));
             } else if (i8c) {
                 a.candB = w.candB; a.segcnt = w.segcnt;
                 const uint32_t grid = std::min<uint32_t>(a.ntiles, (uint32_t)h->num_cu);
@@ -1799,7 +1831,7 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
         LY_HIP(hipGetLastError());
     }
     if (tl_prof && !binary) {
-        const uint64_t tiling = small ? 0x14u : ((waves16 == 3 || waves16 == 2) ? 0x24u : 0x42u);
+        const uint64_t tiling = (small || mid64) ? 0x14u : ((waves16 == 3 || waves16 == 2) ? 0x24u : 0x42u);
         std::lock_guard<std::mutex> plk(h->prof_mu);
         h->prof.last_plan = (sample.sample_tiles ? 1u : 0u) | ((sample.sample_tiles && sample_threshold_only) ? 2u : 0u) | (i8c ? 4u : 0u) |
                             (plan_used_segments ? 8u : 0u) | (small ? 16u : 0u) | (fs ? 128u : 0u) | ((uint64_t)(plan.size() & 0xff) << 8) | (tiling << 16);

@@ -320,3 +320,31 @@ def test_small_batches_run_the_certified_int8_pass(L, oracle, metric, n, dim):
             assert int(counts[qi]) == k
             assert np.array_equal(rows[qi].astype(np.uint64), e_ids.astype(np.uint64)), (metric, nq, qi, rows[qi], e_ids)
             assert np.array_equal(dists[qi].view(np.uint32), e_d.view(np.uint32)), (metric, nq, qi)
+
+
+# ---- mid-size batches: 33..64 queries on the 128-row x 64-query tiling, 65..128 on the 256-row x 128-query tiling (int8 codes)
+@pytest.mark.parametrize("metric,n,dim", [("ip", 300_000, 768), ("ip", 200_000, 200), ("l2", 200_000, 512), ("cosine", 200_000, 256)])
+def test_mid_size_batches_on_their_own_tilings(L, oracle, metric, n, dim, monkeypatch):
+    rng = np.random.default_rng(6000 + dim)
+    data = rng.random((n, dim), dtype=f32) if metric == "ip" else rng.standard_normal((n, dim)).astype(f32)
+    queries = (data[rng.integers(0, n, 128)] + 0.05 * rng.standard_normal((128, dim))).astype(f32)
+    idx = L.FlatIndex(None, dim)
+    idx.write(data)
+    idx.finalize()
+    idx.profile_enable(True)
+    m = {"ip": O.IP, "l2": O.L2, "cosine": O.COS}[metric]
+    monkeypatch.setenv("LYNSE_HIP_MID_TILINGS", "0")
+    ref = idx.search_batch_arrays(queries, 10, metric)          # the 256-query tiling
+    monkeypatch.setenv("LYNSE_HIP_MID_TILINGS", "1")
+    for nq, k in ((33, 10), (64, 10), (65, 10), (100, 25), (128, 10), (48, 1)):
+        idx.profile_get(reset=True)
+        rows, dists, counts = idx.search_batch_arrays(queries[:nq], k, metric)
+        p = idx.profile_get(reset=True)
+        flags = int(p["last_plan"]) & 0xff
+        assert flags & PLAN_I8C_STARTED and flags & PLAN_I8C and p["fallback_queries"] == 0, (metric, nq, bin(flags), p)
+        if k == 10:
+            assert np.array_equal(rows, ref[0][:nq]) and np.array_equal(dists.view(np.uint32), ref[1][:nq].view(np.uint32)), (metric, nq)
+        for qi in sorted({0, 31, 32, nq // 2, nq - 1}):
+            e_ids, e_d = oracle.canonical_topk(queries[qi], data, k, m)
+            assert np.array_equal(rows[qi].astype(np.uint64), e_ids.astype(np.uint64)), (metric, nq, qi, rows[qi], e_ids)
+            assert np.array_equal(dists[qi].view(np.uint32), e_d.view(np.uint32)), (metric, nq, qi)
