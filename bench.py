@@ -59,6 +59,7 @@ def parse_args():
     p.add_argument("--stage0", type=int, default=0, help="override the stage-0 row count of the scan plan")
     p.add_argument("--growth", type=int, default=0, help="override the stage growth factor of the scan plan")
     p.add_argument("--profile-every", type=int, default=4, help="HIP-event timing of the scan launches on every n-th step of the timed region")
+    p.add_argument("--settle-ms", type=float, default=60.0, help="untimed steps before the warm-up until the GPU's clocks have settled (0 = none)")
     p.add_argument("--no-configs", action="store_true", help="skip the extra keys: the other BASELINE configurations and the second data distribution")
     p.add_argument("--in-flight", type=int, default=int(os.environ.get("LYNSE_BENCH_IN_FLIGHT", "0")),
                    help="batches in flight (lynse_hip_flat_search_submit_* / _wait): step i+1 is enqueued before step i is waited "
@@ -186,6 +187,19 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # Clock / power settling, BEFORE the W warm-up steps and outside every timed region: after any idle (the build, even a 50 ms
+    # sleep) this GPU needs ~30 ms of continuous work to reach its steady state under this kernel — per-step times of the blocking
+    # 10M x 768 x 256 search after an idle: 2.08 2.85 2.67 2.50 2.44 2.36 2.28 ... 2.06 from the 15th step on
+    # (scripts/step_times.py, profiles/r03_step_times_after_idle.txt).  W = 5 steps of a 0.36 ms shard step would leave the whole
+    # timed region of an 8-GPU run inside that ramp.  The settle phase runs the same step for --settle-ms (default 60 ms, at
+    # least 3 steps); it is reported in config.settle_steps / settle_ms and is not counted in `warmup`.
+    settle_steps = 0
+    if args.settle_ms > 0:
+        t_settle = time.perf_counter()
+        while settle_steps < 3 or (time.perf_counter() - t_settle) * 1e3 < args.settle_ms:
+            run_steps(max(1, in_flight))
+            torch.cuda.synchronize()
+            settle_steps += max(1, in_flight)
     run_steps(args.warmup)
     # HIP events around the scan launches of every 4th step inside the timed region (each recorded event costs the stream a
     # few microseconds: timing every step added 30-40 us to each)
@@ -298,7 +312,7 @@ def main():
                                     else "through torch.distributed (%s)" % (sh.comm_error or os.environ.get("LYNSE_BENCH_BACKEND", "nccl")))) if world > 1
                                    else ("1-rank communicator: merge without all-gather" if sh.comm is not None else "none"),
                        "rccl_ranks_seen": (sh.ranks_seen if native else None),
-                       "batches_in_flight": in_flight,
+                       "batches_in_flight": in_flight, "settle_steps": settle_steps, "settle_ms": args.settle_ms,
                        "build_s": round(build_s, 1), "derived_build_s": round(prepare_s, 3),
                        "hbm_bytes_per_gpu": int(hbm_bytes), "hbm_bytes_over_f32_rows": round(hbm_bytes / max(n_local * D * 4, 1), 3)},
             "roofline": roofline,
