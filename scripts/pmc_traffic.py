@@ -35,6 +35,8 @@ for (kind, emit), t in tot.items():
         continue  # threshold stages: together they stream every row of the shard exactly once per step
     elem = 1 if kind == "i8c" else 2
     pad = 16 if kind == "i8c" else 8
+    if steps <= 0:   # 0 = derive from the trace: every step of the headline plan launches TWO threshold stages (two-level + DENSE)
+        steps = len(t["dispatches"]) // 2
     stream = rows * (-(-dim // pad) * pad) * elem * steps
     hbm = t["fetch_kib"] * 1024 * 2
     out[kind] = {"kernel": "k_scan_h16<%s, EMIT=0>" % kind, "source": str(f.relative_to(src.parent)) if src.parent in f.parents else str(f),
