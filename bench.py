@@ -175,10 +175,17 @@ def main():
                 sh.search_device(queries, K, metric, out)
             return
         pending = []
+        trace = os.environ.get("LYNSE_BENCH_TRACE_STEPS") == "1"   # (development: completions that come > 1 ms apart, to stderr)
+        last = time.perf_counter()
         for i in range(n):
             pending.append(sh.search_submit(queries, K, metric, outs[i % in_flight]))
             if len(pending) >= in_flight:
                 pending.pop(0).wait()
+                if trace:
+                    now = time.perf_counter()
+                    if now - last > 1e-3:
+                        print("slow completion: step %d of %d, %.2f ms" % (i, n, (now - last) * 1e3), file=sys.stderr)
+                    last = now
         for t in pending:
             t.wait()
 
@@ -193,6 +200,11 @@ def main():
     # (scripts/step_times.py, profiles/r03_step_times_after_idle.txt).  W = 5 steps of a 0.36 ms shard step would leave the whole
     # timed region of an 8-GPU run inside that ramp.  The settle phase runs the same step for --settle-ms (default 60 ms, at
     # least 3 steps); it is reported in config.settle_steps / settle_ms and is not counted in `warmup`.
+    # (Python's cyclic GC is switched off from here to the end of the measurements, as timeit does: a full collection — it came
+    # ~200 tickets into a run with batches in flight — stalls the submitting thread for ~43 ms, 130 shard steps)
+    import gc
+    gc.collect()
+    gc.disable()
     settle_steps = 0
     if args.settle_ms > 0:
         t_settle = time.perf_counter()
@@ -225,6 +237,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    gc.enable()
     # ---- verification (outside the timed region): recall@k and score agreement vs torch fp32
     verify = None
     if not args.no_verify:
