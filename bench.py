@@ -207,11 +207,24 @@ def main():
     gc.disable()
     settle_steps = 0
     if args.settle_ms > 0:
+        # the number of settle steps must be the SAME on every rank (a sharded step is a collective): three steps timed on every
+        # rank, the slowest rank's step time agreed on, then as many steps as fill settle_ms at that rate
+        probe = max(3, in_flight)
+        run_steps(probe)                     # (first calls: workspace / context creation, not a step time)
+        torch.cuda.synchronize()
         t_settle = time.perf_counter()
-        while settle_steps < 3 or (time.perf_counter() - t_settle) * 1e3 < args.settle_ms:
-            run_steps(max(1, in_flight))
+        run_steps(probe)
+        torch.cuda.synchronize()
+        step_ms = (time.perf_counter() - t_settle) * 1e3 / probe
+        if dist is not None:
+            t = torch.tensor([step_ms], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            step_ms = float(t.item())
+        more = min(2000, max(0, int(np.ceil(args.settle_ms / max(step_ms, 1e-3))) - 2 * probe))
+        if more:
+            run_steps(more)
             torch.cuda.synchronize()
-            settle_steps += max(1, in_flight)
+        settle_steps = 2 * probe + more
     run_steps(args.warmup)
     # HIP events around the scan launches of every 4th step inside the timed region (each recorded event costs the stream a
     # few microseconds: timing every step added 30-40 us to each)
