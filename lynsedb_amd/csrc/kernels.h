@@ -1312,7 +1312,14 @@ __global__ void __launch_bounds__(WQ * WR * 64, (TQ * TR >= 16) ? 1 : ((WQ * WR 
     // v_mfma_scale_f32_32x32x64_f8f6f4 with unit scales: batched Hamming as a +-1 GEMM (k_bits_to_fp4) at twice the int8 MFMA
     // rate and half the bytes.  A 128-B line holds 256 elements; the K loop, the rings and the epilogue are those of the
     // certified int8 pass (the f32 accumulators hold exact integers: converted where the integer epilogue reads them).
-    constexpr bool I8 = I8Q != 0;           // byte-addressed operands (SQ8 pass 1, the certified coarse pass, FP4 pairs)
+    // I8Q = 4 (I8L): squared L2 on the PLAIN SQ8 codes — the int8 MFMA of the certified pass feeding the FLOAT L2 epilogue of the
+    // f16 shadow: the accumulators become (float)dot when a tile is done and from there the kernel is the f16 L2 kernel, with
+    // qinv = s_q and qn2 = |q|^2 - 2 B_q, i.e. coarse distance = |v|^2 - 2 s_q dot + (|q|^2 - 2 B_q) with the exact f32 row norm
+    // from the norm ring (k_i8c_prep_queries, l2n).  768 B per row instead of the 896 of the augmented codes, IP-sized margins.
+    constexpr bool I8OPS = I8Q != 0;        // byte-addressed operands (SQ8 pass 1, the certified coarse pass, FP4 pairs, I8L)
+    constexpr bool I8L = I8Q == 4;
+    constexpr bool I8 = I8OPS && !I8L;      // ... with an integer-score epilogue
+    static_assert(!I8L || (METRIC == M_L2 && !TILED), "int8 operands with the float epilogue: squared L2, FLAT");
     constexpr bool F4 = I8Q == 3;
     constexpr bool I8C = I8Q == 2 || F4;
     static_assert(!I8C || METRIC == M_IP, "certified int8 coarse pass: IP only");
@@ -1331,7 +1338,7 @@ __global__ void __launch_bounds__(WQ * WR * 64, (TQ * TR >= 16) ? 1 : ((WQ * WR 
     // one-wave-per-SIMD tiling (AG: a third fewer fragment reads, nobody else to issue while a wave waits) is what it is for.
     constexpr bool DEFER = LYNSE_DEFER && AG;
     static_assert(!AG || (!TILED && !FS && DBG == 0 && EMIT == 0), "AGPR accumulators: threshold stages of the FLAT int8 scan");
-    constexpr int ES = I8 ? 1 : 2;          // element size in bytes
+    constexpr int ES = I8OPS ? 1 : 2;       // element size in bytes
     constexpr int KS = 128 / ES;            // elements per slab
     constexpr int EPS = 16 / ES;            // elements per 16-B slot
     constexpr int NW = WQ * WR;
@@ -1365,7 +1372,7 @@ __global__ void __launch_bounds__(WQ * WR * 64, (TQ * TR >= 16) ? 1 : ((WQ * WR 
     [[maybe_unused]] const unsigned long long t_kernel0 = FS ? __builtin_amdgcn_s_memtime() : 0ull;
     // blockIdx.y: which chunk of BQ queries this workgroup scores (one launch scores a.qpad / BQ chunks against the same rows:
     // the k-means assignment step searches thousands of rows against a few thousand centroids); 0 for ordinary searches
-    const uint32_t qchunk = (TILED || I8 || FILT) ? 0u : blockIdx.y * (uint32_t)BQ;  // (the int8 passes always run one chunk)
+    const uint32_t qchunk = (TILED || I8OPS || FILT) ? 0u : blockIdx.y * (uint32_t)BQ;  // (the int8 passes always run one chunk)
     // FS (fused sample stage): the workgroup's FIRST tile is its sample tile (rows [blockIdx.x * fs_stride, +BR) of the whole
     // shard), then its ordinary tiles blockIdx.x, blockIdx.x + grid, ... of [row0, row1) — the tile counters start one grid
     // stride below blockIdx.x (modulo 2^32) so that the ordinary advance lands on blockIdx.x
@@ -1732,7 +1739,7 @@ __global__ void __launch_bounds__(WQ * WR * 64, (TQ * TR >= 16) ? 1 : ((WQ * WR 
                             // body — behind all 24 fragment reads, whose registers then went to scratch (ISA inspected)
                             asm volatile("" : "+v"(acc[i][j]));
 #endif
-                        } else if constexpr (I8) {
+                        } else if constexpr (I8OPS) {
                             typedef int i32x4 __attribute__((ext_vector_type(4)));
                             typedef int i32x16 __attribute__((ext_vector_type(16)));
                             acc[i][j] = __builtin_bit_cast(f32x16, __builtin_amdgcn_mfma_i32_32x32x32_i8(
@@ -1785,6 +1792,14 @@ __global__ void __launch_bounds__(WQ * WR * 64, (TQ * TR >= 16) ? 1 : ((WQ * WR 
             tile += gridDim.x;
           }
         } else if (tile_done) {
+            if constexpr (I8L) {   // integer dot products -> floats: the float L2 epilogue takes over
+#pragma unroll
+                for (int i = 0; i < TR; ++i)
+#pragma unroll
+                    for (int j = 0; j < TQ; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[i][j][r] = (float)__float_as_int(acc[i][j][r]);
+            }
             const EpiArgsPtr ea = epi_args();
             uint32_t rbase = ea->row0 + tile * tstride;
             uint32_t row_end = ea->row1;
@@ -2432,6 +2447,10 @@ struct I8cPrepArgs {
     // (SelectArgs / FinalArgs::neg_metric1) and k_final negates it back.  E = the IP bound over (q', v') + the f32 error of
     // the stored norm and of the reference's own difference-form sum: 8 (D + 8) 2^-24 (|q|^2 + max |v|^2).
     int aug;
+    // l2n = 1: squared L2 on the PLAIN codes (k_scan_h16<.., I8Q = 4>): the image and s_q are the IP ones; bq receives
+    // |q|^2 - 2 B_q (the kernel's qn2), thr opens at +inf (ascending keys), E = 2 x the IP quantisation terms + the f32 roundings of
+    // |v|^2 - 2 s_q dot + qn2, of the stored row norm and of the reference's own difference-form sum.
+    int l2n;
     // cosine = 1: cosine distance as an inner product of UNIT vectors.  The rows are coded as fl(v_d * rinv[row]) (rinv = the
     // stored reciprocal f32 norm; a zero row codes as zeros and scores distance 1 like the reference's denom < 1e-30 rule), the
     // query enters as q / |q|; coarse score q^.v^ - 1 = -(coarse distance), exact scores are the NEGATED reference cosine
@@ -2505,12 +2524,19 @@ __global__ void __launch_bounds__(256) k_i8c_prep_queries(I8cPrepArgs a) {
                                 : a.aug  ? 8.0 * ((double)a.D + 8.0) * 5.9604645e-8 * (s2 + (double)a.vmax * (double)a.vmax)
                                          : gam * sqrt(s2) * (double)a.vmax;
         double E = 0.5001 * swabs + 0.5001 * (double)sq * a1 + 2.5e-7 * (fabs(bq) + (a.cosine ? 1.0 : fabs(s2)) + 127.0 * (double)sq * a1) + ref_term;
+        float bq_out = bqf;
+        if (a.l2n) {
+            const double vm2 = (double)a.vmax * (double)a.vmax;
+            E = 2.0 * (0.5001 * swabs + 0.5001 * (double)sq * a1) + 5.0e-7 * (2.0 * fabs(bq) + s2 + vm2 + 2.0 * 127.0 * (double)sq * a1) +
+                8.0 * ((double)a.D + 8.0) * 5.9604645e-8 * (s2 + vm2);
+            bq_out = (float)(s2 - 2.0 * bq);
+        }
         E *= 1.02;
         if (!(wmax < 1.0e30) || !(E == E) || E > 3.0e38) E = 3.0e38;
         a.sq[q] = sq;
-        a.bq[q] = bqf;
+        a.bq[q] = bq_out;
         a.marg2[q] = (float)(2.0 * E);
-        a.thr[q] = -LY_INF;
+        a.thr[q] = a.l2n ? LY_INF : -LY_INF;
         a.count[q] = 0u;
         a.overflow[q] = 0u;
         if (q == 0 && a.gsync) { a.gsync[0] = 0u; a.gsync[1] = 0u; a.gsync[2] = 0u; }

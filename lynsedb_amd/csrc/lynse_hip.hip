@@ -1274,6 +1274,24 @@ static int launch_scan_i8c_small(const ScanArgs& a, uint32_t grid, hipStream_t s
     return go(k_scan_h16<1, 4, 1, 1, M_IP, 3, 3, 2, false, true, 0, false, 2>, 1);
 }
 
+// squared L2 on the plain SQ8 codes (kernels.h, I8Q = 4): the <4,2,2,4> L2 tiling with 2 + 2-stage rings and the norm ring, int8
+// operands, float epilogue; whole 128-column slabs
+static int launch_scan_i8l2(const ScanArgs& a, uint32_t grid, hipStream_t st) {
+    constexpr size_t lds = (size_t)(2 * 256 + 2 * 256) * 128 + 3 * 1024;
+    static bool attr_done[4] = {false, false, false, false};
+    auto go = [&](auto kern, int slot) -> int {
+        if (!attr_done[slot]) { LY_TRY(set_max_lds(kern, lds)); attr_done[slot] = true; }
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, a);
+        LY_HIP(hipGetLastError());
+        return LYNSE_OK;
+    };
+    if (a.ld16 % 128 != 0) return set_error(LYNSE_ERR_INTERNAL, "the plain-code L2 scan needs whole 128-column slabs");
+    if (a.emit_all == 1) return go(k_scan_h16<4, 2, 2, 4, M_L2, 2, 2, 2, false, false, 0, false, 4, 1>, 0);
+    if (a.emit_all == 2) return go(k_scan_h16<4, 2, 2, 4, M_L2, 2, 2, 2, false, false, 0, false, 4, 2>, 1);
+    if (a.dense) return go(k_scan_h16<4, 2, 2, 4, M_L2, 2, 2, 2, false, false, 0, false, 4, 0, 0, true>, 2);
+    return go(k_scan_h16<4, 2, 2, 4, M_L2, 2, 2, 2, false, false, 0, false, 4, 0>, 3);
+}
+
 // certified int8 coarse pass for batches of 33..64 queries (128 rows x 64 queries, 4 waves, two workgroups per CU, 3 + 3 stages)
 // and of 65..128 queries (256 rows x 128 queries, 8 waves as 2 x 4, 3 + 2 stages): per row byte they do a quarter / half of the
 // MFMA and fragment-read work of the 256-query tiling, which a batch of 40 or 100 queries would otherwise pay in full
@@ -1501,6 +1519,8 @@ static int get_event(lynse_hip_flat* h, size_t idx, hipEvent_t* out) {
     return LYNSE_OK;
 }
 
+static bool l2_plain(const lynse_hip_flat* h, uint64_t nqc, bool masked = false);   // (defined with the other int8-pass rules)
+
 // One chunk (<= QCHUNK queries) whose inputs are already in the workspace (Qf for float metrics,
 // QW for binary).  Results land in ws.out_*.  `level` selects the stage plan (make_plan).
 static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k, int metric, int level, hipStream_t st,
@@ -1527,7 +1547,9 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
     if (bin_mfma) i8c = true;   // the scan side IS the certified-int8 IP scan (exact here: margin 0)
     // squared L2 on the certified int8 pass: an inner product of augmented vectors in the negated score space (kernels.h,
     // I8cPrepArgs::aug): scan, thresholds and selects run as a best-first IP search, exact scores are -|q - v|^2
-    const bool aug = i8c && !bin_mfma && metric == M_L2;
+    // squared L2 on the plain codes + exact row norms (l2_plain): the <4,2,2,4> L2 tiling with int8 operands and the float epilogue
+    const bool l2n = i8c && !bin_mfma && metric == M_L2 && !row_ids && l2_plain(h, nq, mask != nullptr);
+    const bool aug = i8c && !bin_mfma && metric == M_L2 && !l2n;
     const bool cosq = i8c && !bin_mfma && metric == M_COS;   // cosine distance: unit vectors, negated score space (I8cPrepArgs::cosine)
     const int key_metric = (bin_mfma || aug || cosq) ? (int)M_IP : metric;   // the order of the candidate keys
     const uint32_t nslab = bin_mfma ? h->ld_bpm / 128 : i8c ? ((aug ? h->dim + h->aug_cols : h->dim) + 127) / 128 : glds ? (h->dim + GL_BK - 1) / GL_BK : (h->dim + SCAN_BK - 1) / SCAN_BK;  // h16: HK == SCAN_BK == 64
@@ -1573,7 +1595,7 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
         I8cPrepArgs p{};
         p.Q = Qf; p.D = h->dim; p.qpad = qpad; p.nslab = nslab; p.mins = aug ? h->sq8a_mins : (cosq ? h->sq8c_mins : h->sq8_mins);
         p.scales = aug ? h->sq8a_scales : (cosq ? h->sq8c_scales : h->sq8_scales);
-        p.a1 = aug ? h->sq8a_a1 : (cosq ? h->sq8c_a1 : h->sq8_a1); p.vmax = h->vmax; p.cosine = cosq ? 1 : 0; p.img = reinterpret_cast<int8_t*>(w.Q16); p.aug = aug ? (int)h->aug_cols : 0;
+        p.a1 = aug ? h->sq8a_a1 : (cosq ? h->sq8c_a1 : h->sq8_a1); p.vmax = h->vmax; p.cosine = cosq ? 1 : 0; p.img = reinterpret_cast<int8_t*>(w.Q16); p.aug = aug ? (int)h->aug_cols : 0; p.l2n = l2n ? 1 : 0;
         p.sq = w.qinv; p.bq = w.qn2; p.marg2 = w.marg2; p.thr = w.thr; p.count = w.count; p.overflow = w.overflow;
         p.gsync = w.gsync;
         hipLaunchKernelGGL(k_i8c_prep_queries, dim3(nq), dim3(256), 0, st, p);
@@ -1602,7 +1624,7 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
 #endif
     const bool filt = mask != nullptr || row_ids != nullptr;
     // (the subset-filter variants of <2,4,4,2> spill 96 B into the MFMA loop: masked 10M x 768 scan 7.5 ms vs 4.9 ms with <4,2,2,4>)
-    const int waves16 = i8c ? 3 : (w16env >= 0 ? w16env : ((metric == M_IP && !filt) ? 3 : 0));
+    const int waves16 = l2n ? 0 : i8c ? 3 : (w16env >= 0 ? w16env : ((metric == M_IP && !filt) ? 3 : 0));
     static const int no_lane_max0 = []() { const char* e = getenv("LYNSE_HIP_NO_LANE_MAX"); return e ? atoi(e) : 0; }();
     // the subset-filter kernel variants carry no lane-max code (registers)
     // (k <= 16: the best tile alone supplies k keys, so even a shard sorted by score gets a tight threshold from its best
@@ -1628,7 +1650,7 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
     // hand-over drains the LDS-DMA ring of every CU and idles the chip twice, which costs more than a kernel boundary.
     const int fs_env = []() { const char* e = getenv("LYNSE_HIP_FUSED_SAMPLE"); return e ? atoi(e) : 0; }();   // (read per call: tests flip it)
     static const int dbg_env = []() { const char* e = getenv("LYNSE_HIP_DEBUG_FLAGS"); return e ? atoi(e) : 0; }();
-    const bool fs = fs_env != 0 && !dbg_env && i8c && !aug && !cosq && !bin_mfma && !mid64 && !mid128 && h->ld8 % 128 == 0 && sample_threshold_only && plan.size() >= 2 && k <= 32 &&
+    const bool fs = fs_env != 0 && !dbg_env && i8c && !aug && !cosq && !l2n && !bin_mfma && !mid64 && !mid128 && h->ld8 % 128 == 0 && sample_threshold_only && plan.size() >= 2 && k <= 32 &&
                     sample.sample_tiles == (uint32_t)h->num_cu && (plan[1].r1 - plan[1].r0 + 255) / 256 >= (uint32_t)h->num_cu &&
                     (uint64_t)k * 50000ull > (uint64_t)sample.sample_tiles * plan_tile &&   // (the stage behind the sample runs the DENSE epilogue)
                     []() { const char* e = getenv("LYNSE_HIP_DENSE"); return !e || atoi(e) != 0; }();
@@ -1722,6 +1744,13 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
                 const uint32_t grid = std::min<uint32_t>(a.ntiles, (uint32_t)h->num_cu * (mid64 ? 2u : 1u));
                 if (!a.emit_all) seg_geometry(grid, 4, &a.nseg, &a.seg);
                 LY_TRY(launch_scan_i8c_mid(a, grid, st, mid128));
+            } else if (l2n) {
+                a.candB = w.candB; a.segcnt = w.segcnt;
+                const uint32_t grid = std::min<uint32_t>(a.ntiles, (uint32_t)h->num_cu);
+                const uint64_t seen_before = s.sample_tiles ? 0 : (sample.sample_tiles ? std::max<uint64_t>((uint64_t)sample.sample_tiles * plan_tile, s.r0) : s.r0);
+                a.dense = (!a.emit_all && seen_before) ? 1 : 0;   // (the DENSE float epilogue, like every L2 threshold stage of the f16 shadow)
+                if (!a.emit_all) seg_geometry(grid, a.dense ? 4 : 2, &a.nseg, &a.seg);
+                LY_TRY(launch_scan_i8l2(a, grid, st));
             } else if (i8c) {
                 a.candB = w.candB; a.segcnt = w.segcnt;
                 const uint32_t grid = std::min<uint32_t>(a.ntiles, (uint32_t)h->num_cu);
@@ -2181,14 +2210,24 @@ static int coarse_env() {
 static std::atomic<int>& i8c_strike_counter(lynse_hip_flat* h, int metric) {
     return metric == M_L2 ? h->i8c_strikes_l2 : (metric == M_COS ? h->i8c_strikes_cos : h->i8c_strikes);
 }
-static bool i8c_codes_ready(const lynse_hip_flat* h, int metric) {
-    if (metric == M_L2) return h->sq8a && h->n_sq8a == h->n;
+// Squared L2 has two int8 forms: batches of 129..256 queries over whole 128-column slabs, unfiltered, run on the PLAIN codes with
+// the exact f32 row norms in a float epilogue (k_scan_h16<.., I8Q = 4>: 1 B per element, no second code set, IP-sized margins);
+// everything else (<= 128 queries, masked, IVF) on the codes of the AUGMENTED rows through the IP kernels.  nqc = 0: "not a FLAT
+// batch" (IVF): the augmented form.  LYNSE_HIP_L2_PLAIN=0: always the augmented form.
+static bool l2_plain(const lynse_hip_flat* h, uint64_t nqc, bool masked) {
+    static const int on = []() { const char* e = getenv("LYNSE_HIP_L2_PLAIN"); return e ? atoi(e) : 1; }();
+    return on && !masked && nqc > 128 && nqc <= QCHUNK && h->ld8 % 128 == 0 && h->dim >= 256;   // (1M x 128, k = 100: 0.244 ms on the f16 shadow, 0.277 on the codes)
+}
+static bool i8c_codes_ready(const lynse_hip_flat* h, int metric, uint64_t nqc = 0, bool masked = false) {
+    if (metric == M_L2 && !l2_plain(h, nqc, masked)) return h->sq8a && h->n_sq8a == h->n;
     if (metric == M_COS) return h->sq8c && h->n_sq8c == h->n;
     return h->sq8 && h->n_sq8 == h->n;
 }
-static bool i8c_codes_finite(const lynse_hip_flat* h, int metric) { return metric == M_L2 ? h->sq8a_finite : (metric == M_COS ? h->sq8c_finite : h->sq8_finite); }
-static int ensure_i8c_codes_locked(lynse_hip_flat* h, int metric) {
-    return metric == M_L2 ? ensure_sq8a_locked(h) : (metric == M_COS ? ensure_sq8c_locked(h) : ensure_sq8_locked(h));
+static bool i8c_codes_finite(const lynse_hip_flat* h, int metric, uint64_t nqc = 0, bool masked = false) {
+    return (metric == M_L2 && !l2_plain(h, nqc, masked)) ? h->sq8a_finite : (metric == M_COS ? h->sq8c_finite : h->sq8_finite);
+}
+static int ensure_i8c_codes_locked(lynse_hip_flat* h, int metric, uint64_t nqc = 0, bool masked = false) {
+    return (metric == M_L2 && !l2_plain(h, nqc, masked)) ? ensure_sq8a_locked(h) : (metric == M_COS ? ensure_sq8c_locked(h) : ensure_sq8_locked(h));
 }
 static void i8c_add_strike(lynse_hip_flat* h, int metric) {
     std::atomic<int>& c = i8c_strike_counter(h, metric);
@@ -2203,7 +2242,8 @@ static bool i8c_eligible(const lynse_hip_flat* h, int metric, bool filtered, uin
     // squared L2 streams round_up(dim + 1, 128) bytes of augmented codes per row against 2 round_up(dim, 8) of the f16 shadow and
     // rescoring pools ~10x wider: it pays from ~256 dimensions on (MI355X: 10M x 768 x 256 3.97 -> 2.81 ms; 1M x 128, k = 100
     // 0.24 -> 0.34 ms: stays on the f16 pass)
-    const bool l2_ok = metric == M_L2 && !l2_off && h->dim >= 256 && (uint64_t)h->ld8a * 4 <= (uint64_t)h->ld16 * 2 * 3;
+    const bool l2_ok = metric == M_L2 && !l2_off &&
+                       (l2_plain(h, nqc, masked) || (h->dim >= 256 && (uint64_t)h->ld8a * 4 <= (uint64_t)h->ld16 * 2 * 3));
     // cosine streams the codes of the unit rows (1 B per element, like IP); tiny-norm rows make the f16 pass go exhaustive and
     // are left to it
     const bool cos_ok = metric == M_COS && !l2_off && h->dim >= 256 && !h->cos_degenerate;
@@ -2275,7 +2315,7 @@ static int search_impl(lynse_hip_flat* h, const void* q_src, bool packed_queries
         if (h->packed_only) return true;  // (rejected below)
         if (h->n_stats != h->n || (scan_variant() == 3 && (h->n16 != h->n || h->sv16 != h->sv))) return false;
         // (filtered: what matters is the MASKED int8 scan — a gathered-rows search goes exclusive anyway)
-        return !i8c_eligible(h, metric, false, std::min<uint64_t>(nq, QCHUNK), caller_holds_exclusive, filtered) || i8c_codes_ready(h, metric);
+        return !i8c_eligible(h, metric, false, std::min<uint64_t>(nq, QCHUNK), caller_holds_exclusive, filtered) || i8c_codes_ready(h, metric, std::min<uint64_t>(nq, QCHUNK), filtered);
     };
     // k beyond the candidate capacity of one pass (k > cap / 4 over more than cap rows; the reference accepts any k, and its
     // server caps at MAX_TOP_K = 10,000, src/server/mod.rs:46): row ranges of `cap` rows, each answered exactly, merged.
@@ -2494,9 +2534,10 @@ static int search_impl(lynse_hip_flat* h, const void* q_src, bool packed_queries
         // three such strikes turn the int8 pass off for this handle (margins too wide for this data).
         bool i8c = i8c_eligible(h, metric, filtered && direct, nqc, caller_holds_exclusive, filtered && !direct);
         if (i8c) {
-            if (xlk.owns_lock()) LY_TRY(ensure_i8c_codes_locked(h, metric));   // lazy build: exclusive path only
-            else if (!i8c_codes_ready(h, metric)) i8c = false;                    // (shared path: derived_ready() saw them built)
-            if (i8c && !i8c_codes_finite(h, metric)) { i8c_strike_counter(h, metric).store(-1); i8c = false; }
+            const bool msk = filtered && !direct;
+            if (xlk.owns_lock()) LY_TRY(ensure_i8c_codes_locked(h, metric, nqc, msk));   // lazy build: exclusive path only
+            else if (!i8c_codes_ready(h, metric, nqc, msk)) i8c = false;                    // (shared path: derived_ready() saw them built)
+            if (i8c && !i8c_codes_finite(h, metric, nqc, msk)) { i8c_strike_counter(h, metric).store(-1); i8c = false; }
         }
         i8c_attempted = i8c_attempted || i8c;
         if (small_path_ok(h, nqc, kk, metric, filtered)) {
@@ -2596,8 +2637,8 @@ extern "C" int lynse_hip_flat_prepare(lynse_hip_flat* h, int metric, uint64_t nq
     if (h->packed_only) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "store holds packed rows; float metrics unavailable");
     LY_TRY(finalize_locked(h));
     if (i8c_eligible(h, metric, false, nqc)) {
-        LY_TRY(ensure_i8c_codes_locked(h, metric));
-        if (!i8c_codes_finite(h, metric)) i8c_strike_counter(h, metric).store(-1);
+        LY_TRY(ensure_i8c_codes_locked(h, metric, nqc));
+        if (!i8c_codes_finite(h, metric, nqc)) i8c_strike_counter(h, metric).store(-1);
     }
     return LYNSE_OK;
 }

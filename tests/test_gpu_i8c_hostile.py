@@ -348,3 +348,23 @@ def test_mid_size_batches_on_their_own_tilings(L, oracle, metric, n, dim, monkey
             e_ids, e_d = oracle.canonical_topk(queries[qi], data, k, m)
             assert np.array_equal(rows[qi].astype(np.uint64), e_ids.astype(np.uint64)), (metric, nq, qi, rows[qi], e_ids)
             assert np.array_equal(dists[qi].view(np.uint32), e_d.view(np.uint32)), (metric, nq, qi)
+
+
+# ---- squared L2 on the PLAIN codes with the exact row norms (k_scan_h16<4,2,2,4,L2,..,I8Q=4>; 129..256 queries, whole 128-column
+# slabs, >= 256 dimensions): the quantisation error only touches q.v, the norms enter exactly
+def test_l2_plain_codes_hostile_data(L, oracle):
+    rng = np.random.default_rng(7001)
+    n, dim, nq, k = 300_000, 512, 200, 10
+    data = rng.standard_normal((n, dim)).astype(f32) * np.exp(0.8 * rng.standard_normal((n, 1))).astype(f32)   # norms over two orders of magnitude
+    queries = (data[rng.integers(0, n, nq)] * (1 + 0.03 * rng.standard_normal((nq, dim)))).astype(f32)
+    queries[:3] = data[[11, 12, 13]]                                  # exact hits: distance +0.0
+    idx, p, (rows, dists, counts) = run_case(L, oracle, data, queries, k, "l2_plain_lognormal", expect_i8c_kept=False, metric="l2",
+                                             check=(0, 1, 2, 33, 128, 129, 199))
+    assert (int(p["last_plan"]) >> 16) & 0xff == 0x42                 # the <4,2,2,4> tiling: the plain-code form ran
+    assert np.all(dists[:3, 0].view(np.uint32) == 0) and rows[0, 0] == 11
+    off = (30.0 + rng.random((200_000, 256))).astype(f32)             # far from the origin: |v|^2 ~ 2.4e5, neighbour distances ~ 40
+    qo = (off[rng.integers(0, len(off), 160)] + 0.05 * rng.standard_normal((160, 256))).astype(f32)
+    run_case(L, oracle, off, qo, k, "l2_plain_offset", expect_i8c_kept=False, metric="l2", check=(0, 1, 33, 100, 159))
+    ints = rng.integers(0, 4, (150_000, 256)).astype(f32)            # integer data: exact integer distances, huge tie groups
+    qi = ints[rng.integers(0, len(ints), 140)].copy()
+    run_case(L, oracle, ints, qi, 20, "l2_plain_integer_ties", metric="l2", check=(0, 1, 64, 139))
