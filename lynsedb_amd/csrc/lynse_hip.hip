@@ -1261,9 +1261,17 @@ static int launch_scan_h16(const ScanArgs& a, int metric, uint32_t grid, hipStre
 
 // certified int8 coarse pass for batches of <= 32 queries: the 128-row x 32-query tiling (two workgroups per CU, 3 + 3-stage
 // rings) over the SQ8 codes — HBM-bound like its f16 twin, at half the bytes; emission mode at run time (EMIT = -1)
-static int launch_scan_i8c_small(const ScanArgs& a, uint32_t grid, hipStream_t st) {
+static int launch_scan_i8c_small(const ScanArgs& a, uint32_t grid, hipStream_t st, bool l2n = false) {
     constexpr size_t lds = (size_t)(3 * 128 + 3 * 32) * 128;
-    static bool attr_done[2] = {false, false};
+    static bool attr_done[3] = {false, false, false};
+    if (l2n) {   // plain-code L2 (I8Q = 4): + the norm ring
+        constexpr size_t ldsn = lds + 4 * 1024;
+        auto kern = k_scan_h16<1, 4, 1, 1, M_L2, 3, 3, 2, false, false, 0, false, 4>;
+        if (!attr_done[2]) { LY_TRY(set_max_lds(kern, ldsn)); attr_done[2] = true; }
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), ldsn, st, a);
+        LY_HIP(hipGetLastError());
+        return LYNSE_OK;
+    }
     auto go = [&](auto kern, int slot) -> int {
         if (!attr_done[slot]) { LY_TRY(set_max_lds(kern, lds)); attr_done[slot] = true; }
         hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a);
@@ -1295,9 +1303,19 @@ static int launch_scan_i8l2(const ScanArgs& a, uint32_t grid, hipStream_t st) {
 // certified int8 coarse pass for batches of 33..64 queries (128 rows x 64 queries, 4 waves, two workgroups per CU, 3 + 3 stages)
 // and of 65..128 queries (256 rows x 128 queries, 8 waves as 2 x 4, 3 + 2 stages): per row byte they do a quarter / half of the
 // MFMA and fragment-read work of the 256-query tiling, which a batch of 40 or 100 queries would otherwise pay in full
-static int launch_scan_i8c_mid(const ScanArgs& a, uint32_t grid, hipStream_t st, bool wide) {
-    static bool attr_done[4] = {false, false, false, false};
+static int launch_scan_i8c_mid(const ScanArgs& a, uint32_t grid, hipStream_t st, bool wide, bool l2n = false) {
+    static bool attr_done[6] = {false, false, false, false, false, false};
     const bool rag = a.ld16 % 128 != 0;
+    if (l2n) {   // plain-code L2 (I8Q = 4): whole slabs, + the norm ring
+        auto gol = [&](auto kern, int slot, size_t lds, uint32_t threads) -> int {
+            if (!attr_done[slot]) { LY_TRY(set_max_lds(kern, lds)); attr_done[slot] = true; }
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, st, a);
+            LY_HIP(hipGetLastError());
+            return LYNSE_OK;
+        };
+        if (!wide) return gol(k_scan_h16<1, 4, 2, 1, M_L2, 3, 3, 2, false, false, 0, false, 4>, 4, (size_t)(3 * 128 + 3 * 64) * 128 + 4 * 1024, 256);
+        return gol(k_scan_h16<2, 4, 2, 2, M_L2, 3, 2, 2, false, false, 0, false, 4>, 5, (size_t)(3 * 256 + 2 * 128) * 128 + 4 * 1024, 512);
+    }
     auto go = [&](auto kern, int slot, size_t lds, uint32_t threads) -> int {
         if (!attr_done[slot]) { LY_TRY(set_max_lds(kern, lds)); attr_done[slot] = true; }
         hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, st, a);
@@ -1636,7 +1654,7 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
     *sampled_plan = sample.sample_tiles != 0;
     // sampled plan: the sample stage only has to produce a threshold -> one key per lane (its best row) instead of every
     // score, as long as that leaves comfortably more than k keys per query (2 WR keys per tile and query)
-    const uint32_t sample_keys_per_tile = (small || waves16 != 0) ? 16u : 8u;  // 2 WR lanes per query and tile x their best 2 rows (WR = 4: 16, <4,2,2,4>: 8)
+    const uint32_t sample_keys_per_tile = (small || mid64 || mid128 || waves16 != 0) ? 16u : 8u;  // 2 WR lanes per query and tile x their best 2 rows (WR = 4: 16, <4,2,2,4>: 8)
     static const int no_lane_max = []() { const char* e = getenv("LYNSE_HIP_NO_LANE_MAX"); return e ? atoi(e) : 0; }();
     // k <= keys per tile: the best sample tile alone supplies k keys (a shard sorted by score still gets a tight threshold)
     const bool sample_threshold_only = h16 && !binary && !filt && sample.sample_tiles && !no_lane_max && sample_keys_per_tile &&
@@ -1738,12 +1756,12 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
                 a.candB = w.candB; a.segcnt = w.segcnt;
                 const uint32_t grid = std::min<uint32_t>(a.ntiles, (uint32_t)h->num_cu * 2);
                 if (!a.emit_all) seg_geometry(grid, 4, &a.nseg, &a.seg);
-                LY_TRY(launch_scan_i8c_small(a, grid, st));
+                LY_TRY(launch_scan_i8c_small(a, grid, st, l2n));
             } else if (mid64 || mid128) {
                 a.candB = w.candB; a.segcnt = w.segcnt;
                 const uint32_t grid = std::min<uint32_t>(a.ntiles, (uint32_t)h->num_cu * (mid64 ? 2u : 1u));
                 if (!a.emit_all) seg_geometry(grid, 4, &a.nseg, &a.seg);
-                LY_TRY(launch_scan_i8c_mid(a, grid, st, mid128));
+                LY_TRY(launch_scan_i8c_mid(a, grid, st, mid128, l2n));
             } else if (l2n) {
                 a.candB = w.candB; a.segcnt = w.segcnt;
                 const uint32_t grid = std::min<uint32_t>(a.ntiles, (uint32_t)h->num_cu);
@@ -1860,7 +1878,7 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
         LY_HIP(hipGetLastError());
     }
     if (tl_prof && !binary) {
-        const uint64_t tiling = (small || mid64) ? 0x14u : ((waves16 == 3 || waves16 == 2) ? 0x24u : 0x42u);
+        const uint64_t tiling = (small || mid64) ? 0x14u : ((mid128 || waves16 == 3 || waves16 == 2) ? 0x24u : 0x42u);
         std::lock_guard<std::mutex> plk(h->prof_mu);
         h->prof.last_plan = (sample.sample_tiles ? 1u : 0u) | ((sample.sample_tiles && sample_threshold_only) ? 2u : 0u) | (i8c ? 4u : 0u) |
                             (plan_used_segments ? 8u : 0u) | (small ? 16u : 0u) | (fs ? 128u : 0u) | ((uint64_t)(plan.size() & 0xff) << 8) | (tiling << 16);
@@ -2210,13 +2228,13 @@ static int coarse_env() {
 static std::atomic<int>& i8c_strike_counter(lynse_hip_flat* h, int metric) {
     return metric == M_L2 ? h->i8c_strikes_l2 : (metric == M_COS ? h->i8c_strikes_cos : h->i8c_strikes);
 }
-// Squared L2 has two int8 forms: batches of 129..256 queries over whole 128-column slabs, unfiltered, run on the PLAIN codes with
-// the exact f32 row norms in a float epilogue (k_scan_h16<.., I8Q = 4>: 1 B per element, no second code set, IP-sized margins);
-// everything else (<= 128 queries, masked, IVF) on the codes of the AUGMENTED rows through the IP kernels.  nqc = 0: "not a FLAT
+// Squared L2 has two int8 forms: unfiltered FLAT batches over whole 128-column slabs run on the PLAIN codes with the exact f32
+// row norms in a float epilogue (k_scan_h16<.., I8Q = 4>, every tiling: 1 B per element, no second code set, IP-sized margins);
+// everything else (ragged widths, masked scans, IVF) on the codes of the AUGMENTED rows through the IP kernels.  nqc = 0: "not a FLAT
 // batch" (IVF): the augmented form.  LYNSE_HIP_L2_PLAIN=0: always the augmented form.
 static bool l2_plain(const lynse_hip_flat* h, uint64_t nqc, bool masked) {
     static const int on = []() { const char* e = getenv("LYNSE_HIP_L2_PLAIN"); return e ? atoi(e) : 1; }();
-    return on && !masked && nqc > 128 && nqc <= QCHUNK && h->ld8 % 128 == 0 && h->dim >= 256;   // (1M x 128, k = 100: 0.244 ms on the f16 shadow, 0.277 on the codes)
+    return on && !masked && nqc >= 1 && nqc <= QCHUNK && h->ld8 % 128 == 0 && h->dim >= 256;   // (1M x 128, k = 100: 0.244 ms on the f16 shadow, 0.277 on the codes)
 }
 static bool i8c_codes_ready(const lynse_hip_flat* h, int metric, uint64_t nqc = 0, bool masked = false) {
     if (metric == M_L2 && !l2_plain(h, nqc, masked)) return h->sq8a && h->n_sq8a == h->n;

@@ -95,8 +95,8 @@ def test_c2_flat_ip_768_batch256_runs_the_benchmarked_kernels(L, oracle):
 
 def test_l2_768_batch256_runs_the_certified_int8_pass(L, oracle):
     """FLAT-L2 2.4M x 768, 256 queries, k=10 (north_star: "batched cosine/IP/L2"): the certified int8 pass in its L2 forms — the
-    256-query batch on the PLAIN SQ8 codes with the exact f32 row norms in a float epilogue (k_scan_h16<4,2,2,4,L2,..,I8Q=4>), the
-    100- and 8-query batches on the codes of the augmented rows (inner product, negated score space) — plans pinned, ids and
+    PLAIN SQ8 codes with the exact f32 row norms in a float epilogue (k_scan_h16<..,L2,..,I8Q=4>) on every tiling: 256, 100, 48 and 8
+    queries — plans pinned, ids and
     distance bits equal the oracle's exact_flat_search with the difference-form L2 kernel (simd.rs:1529-1581)."""
     n, dim, nq, k = 2_400_000, 768, 256, 10
     rng = np.random.default_rng(43)
@@ -121,14 +121,17 @@ def test_l2_768_batch256_runs_the_certified_int8_pass(L, oracle):
         assert_rows_equal(oracle.canonical_topk(queries[qi], data, k, O.L2), rows[qi], dists[qi], counts[qi], ("l2", qi))
         assert rows[qi, 0] == q_rows[qi]
     import os
-    os.environ["LYNSE_HIP_MID_TILINGS"] = "0"      # 100 queries on the 256-query IP tiling over the AUGMENTED codes
-    try:
-        r100, d100, c100 = idx.search_batch_arrays(queries[:100], k, "l2")
-        p100 = idx.profile_get(reset=True)
-    finally:
-        del os.environ["LYNSE_HIP_MID_TILINGS"]
-    assert plan_fields(p100)[2] == 0x24 and plan_fields(p100)[0] & PLAN_I8C and p100["fallback_queries"] == 0, p100
-    assert np.array_equal(r100, rows[:100]) and np.array_equal(d100.view(np.uint32), dists[:100].view(np.uint32))
+    # 100 queries: the 256 x 128 tiling of the plain-code form (and, with the mid tilings off, the 256-query one); 48 queries: 128 x 64
+    for nqs, env, want in ((100, {}, 0x24), (100, {"LYNSE_HIP_MID_TILINGS": "0"}, 0x42), (48, {}, 0x14)):
+        os.environ.update(env)
+        try:
+            rs, ds, cs = idx.search_batch_arrays(queries[:nqs], k, "l2")
+            ps = idx.profile_get(reset=True)
+        finally:
+            for name in env:
+                del os.environ[name]
+        assert plan_fields(ps)[2] == want and plan_fields(ps)[0] & PLAN_I8C and ps["fallback_queries"] == 0, (nqs, env, ps)
+        assert np.array_equal(rs, rows[:nqs]) and np.array_equal(ds.view(np.uint32), dists[:nqs].view(np.uint32))
     r8, d8, c8 = idx.search_batch_arrays(queries[:8], k, "l2")      # the <= 32-query tiling: same answers
     assert np.array_equal(r8, rows[:8]) and np.array_equal(d8.view(np.uint32), dists[:8].view(np.uint32))
 
