@@ -349,7 +349,7 @@ def main():
         }
         if verify is not None:
             result["verify"] = verify
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # (rank 0 at N = 1 only: the other ranks of a sharded run would sit in the barrier)
             result["cpu_baseline"] = cpu_baseline(args, N, D, K, metric)
         if world == 1 and not args.no_configs and metric == 0:
             # OUTSIDE the headline's timed region: the same workload on a second distribution (the certified int8 margin is
