@@ -1261,9 +1261,17 @@ static int launch_scan_h16(const ScanArgs& a, int metric, uint32_t grid, hipStre
 
 // certified int8 coarse pass for batches of <= 32 queries: the 128-row x 32-query tiling (two workgroups per CU, 3 + 3-stage
 // rings) over the SQ8 codes — HBM-bound like its f16 twin, at half the bytes; emission mode at run time (EMIT = -1)
-static int launch_scan_i8c_small(const ScanArgs& a, uint32_t grid, hipStream_t st, bool l2n = false) {
+static int launch_scan_i8c_small(const ScanArgs& a, uint32_t grid, hipStream_t st, bool l2n = false, bool filt = false) {
     constexpr size_t lds = (size_t)(3 * 128 + 3 * 32) * 128;
-    static bool attr_done[3] = {false, false, false};
+    static bool attr_done[4] = {false, false, false, false};
+    if (filt) {   // masked scan of a small batch (row bitmask in the epilogue): whole slabs
+        if (a.ld16 % 128 != 0 || a.row_ids || l2n) return set_error(LYNSE_ERR_INTERNAL, "the masked int8 scan needs whole 128-column slabs and a row bitmask");
+        auto kern = k_scan_h16<1, 4, 1, 1, M_IP, 3, 3, 2, false, false, 0, true, 2>;
+        if (!attr_done[3]) { LY_TRY(set_max_lds(kern, lds)); attr_done[3] = true; }
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a);
+        LY_HIP(hipGetLastError());
+        return LYNSE_OK;
+    }
     if (l2n) {   // plain-code L2 (I8Q = 4): + the norm ring
         constexpr size_t ldsn = lds + 4 * 1024;
         auto kern = k_scan_h16<1, 4, 1, 1, M_L2, 3, 3, 2, false, false, 0, false, 4>;
@@ -1756,7 +1764,7 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
                 a.candB = w.candB; a.segcnt = w.segcnt;
                 const uint32_t grid = std::min<uint32_t>(a.ntiles, (uint32_t)h->num_cu * 2);
                 if (!a.emit_all) seg_geometry(grid, 4, &a.nseg, &a.seg);
-                LY_TRY(launch_scan_i8c_small(a, grid, st, l2n));
+                LY_TRY(launch_scan_i8c_small(a, grid, st, l2n, filt));
             } else if (mid64 || mid128) {
                 a.candB = w.candB; a.segcnt = w.segcnt;
                 const uint32_t grid = std::min<uint32_t>(a.ntiles, (uint32_t)h->num_cu * (mid64 ? 2u : 1u));
@@ -2269,7 +2277,7 @@ static bool i8c_eligible(const lynse_hip_flat* h, int metric, bool filtered, uin
     // batches of <= 32 queries (the 128 x 32 tiling, HBM-bound: half the bytes = half the time) from 256K rows on — below, the scan
     // is a few tens of microseconds either way and the exact few-query kernel often answers alone (LYNSE_HIP_COARSE_SMALLQ=0: off)
     static const int smallq = []() { const char* e = getenv("LYNSE_HIP_COARSE_SMALLQ"); return e ? atoi(e) : 1; }();
-    const bool nq_ok = nqc > SCAN_BQ_SMALL || (smallq && !masked && nqc >= 1 && (coarse_env() == 2 || h->n >= 262144));
+    const bool nq_ok = nqc > SCAN_BQ_SMALL || (smallq && nqc >= 1 && (coarse_env() == 2 || h->n >= 262144));   // (masked small batches too)
     return (metric == M_IP || l2_ok || cos_ok) && !filtered && !view && nq_ok && h->dtype == LYNSE_DTYPE_F32 &&
            scan_variant() == 3 && coarse_env() != 1 && strikes >= 0 && strikes < 3 && (coarse_env() == 2 || h->n >= 65536);
 }
@@ -2360,7 +2368,7 @@ static int search_impl(lynse_hip_flat* h, const void* q_src, bool packed_queries
         // (the masked scan of 33..256 queries streams the SQ8 codes when the certified int8 pass is available: 1 B per element
         // at ~3.6 TB/s, measured 10M x 768 x 256 with a 50 % subset: 2.2 ms)
         const bool mask_i8 = i8c_eligible(h, metric, false, std::min<uint64_t>(nq, QCHUNK), caller_holds_exclusive, true);
-        const double c_scan = (mask_i8 ? (double)h->n * (double)h->dim / 3.6e12 : (double)h->n * row_b / rate) * chunks + 80e-6;
+        const double c_scan = (mask_i8 ? (double)h->n * (double)h->dim / (nq <= SCAN_BQ_SMALL ? 6.5e12 : 3.6e12) : (double)h->n * row_b / rate) * chunks + 80e-6;
         const char* fe = getenv("LYNSE_HIP_FILTER_STRATEGY");  // tests: 1 = gathered rows, 2 = masked scan (read per call)
         const int force = fe ? atoi(fe) : 0;
         return (double)n_subset * row_b <= 8e9 && (force == 1 || (force == 0 && c_direct < c_scan));

@@ -8,7 +8,8 @@ sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 import lynsedb_amd as L  # noqa: E402
 
 dev = torch.device("cuda", 0)
-n, dim, nq = 10_000_000, 768, 256
+import os
+n, dim, nq = 10_000_000, 768, int(os.environ.get("FILTERED_AB_NQ", "256"))
 idx = L.FlatIndex(None, dim, 0)
 idx.reserve(n)
 g = torch.Generator(device=dev); g.manual_seed(n)
