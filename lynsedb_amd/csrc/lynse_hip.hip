@@ -1311,9 +1311,20 @@ static int launch_scan_i8l2(const ScanArgs& a, uint32_t grid, hipStream_t st) {
 // certified int8 coarse pass for batches of 33..64 queries (128 rows x 64 queries, 4 waves, two workgroups per CU, 3 + 3 stages)
 // and of 65..128 queries (256 rows x 128 queries, 8 waves as 2 x 4, 3 + 2 stages): per row byte they do a quarter / half of the
 // MFMA and fragment-read work of the 256-query tiling, which a batch of 40 or 100 queries would otherwise pay in full
-static int launch_scan_i8c_mid(const ScanArgs& a, uint32_t grid, hipStream_t st, bool wide, bool l2n = false) {
-    static bool attr_done[6] = {false, false, false, false, false, false};
+static int launch_scan_i8c_mid(const ScanArgs& a, uint32_t grid, hipStream_t st, bool wide, bool l2n = false, bool filt = false) {
+    static bool attr_done[8] = {false, false, false, false, false, false, false, false};
     const bool rag = a.ld16 % 128 != 0;
+    if (filt) {   // masked scan (row bitmask in the epilogue): whole slabs
+        if (rag || a.row_ids || l2n) return set_error(LYNSE_ERR_INTERNAL, "the masked int8 scan needs whole 128-column slabs and a row bitmask");
+        auto gof = [&](auto kern, int slot, size_t lds, uint32_t threads) -> int {
+            if (!attr_done[slot]) { LY_TRY(set_max_lds(kern, lds)); attr_done[slot] = true; }
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, st, a);
+            LY_HIP(hipGetLastError());
+            return LYNSE_OK;
+        };
+        if (!wide) return gof(k_scan_h16<1, 4, 2, 1, M_IP, 3, 3, 2, false, false, 0, true, 2>, 6, (size_t)(3 * 128 + 3 * 64) * 128, 256);
+        return gof(k_scan_h16<2, 4, 2, 2, M_IP, 3, 2, 2, false, false, 0, true, 2>, 7, (size_t)(3 * 256 + 2 * 128) * 128, 512);
+    }
     if (l2n) {   // plain-code L2 (I8Q = 4): whole slabs, + the norm ring
         auto gol = [&](auto kern, int slot, size_t lds, uint32_t threads) -> int {
             if (!attr_done[slot]) { LY_TRY(set_max_lds(kern, lds)); attr_done[slot] = true; }
@@ -1582,7 +1593,7 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
     const bool small = nq <= SCAN_BQ_SMALL;
     // mid-size batches on the int8 codes: 33..64 queries -> the 128 x 64 tiling, 65..128 -> the 256 x 128 tiling (LYNSE_HIP_MID_TILINGS=0: off)
     const int mid_env = []() { const char* e = getenv("LYNSE_HIP_MID_TILINGS"); return e ? atoi(e) : 1; }();   // (read per call: tests flip it)
-    const bool mid_ok = mid_env && i8c && !bin_mfma && !small && !mask && !row_ids && h16;
+    const bool mid_ok = mid_env && i8c && !bin_mfma && !small && !row_ids && h16 && (!mask || (aug ? h->ld8a : h->ld8) % 128 == 0);
     const bool mid64 = mid_ok && nq <= 64, mid128 = mid_ok && !mid64 && nq <= 128;
     const bool narrow = small || mid64;   // 128-row tiles
     const uint32_t qpad = small ? SCAN_BQ_SMALL : mid64 ? 64u : mid128 ? 128u : round_up(nq, SCAN_BQ_LARGE);  // > 256 queries: a widened handle, qpad / 256 chunks per launch
@@ -1769,7 +1780,7 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
                 a.candB = w.candB; a.segcnt = w.segcnt;
                 const uint32_t grid = std::min<uint32_t>(a.ntiles, (uint32_t)h->num_cu * (mid64 ? 2u : 1u));
                 if (!a.emit_all) seg_geometry(grid, 4, &a.nseg, &a.seg);
-                LY_TRY(launch_scan_i8c_mid(a, grid, st, mid128, l2n));
+                LY_TRY(launch_scan_i8c_mid(a, grid, st, mid128, l2n, filt));
             } else if (l2n) {
                 a.candB = w.candB; a.segcnt = w.segcnt;
                 const uint32_t grid = std::min<uint32_t>(a.ntiles, (uint32_t)h->num_cu);

@@ -273,12 +273,14 @@ def test_masked_scan_runs_the_certified_int8_pass(L, oracle, metric, dim, frac, 
     r2, d2, c2 = idx.search_filtered_batch_arrays(queries, k, metric, ids)
     assert np.array_equal(r2, rows) and np.array_equal(d2.view(np.uint32), dists.view(np.uint32))
     # small batches (1 / 7 / 32 queries; shards of >= 256K rows): the 128 x 32 tiling with the mask in its epilogue
-    for nqs in (1, 7, 32):
+    # ... and mid-size ones (48 / 100 queries) on the 128 x 64 and 256 x 128 tilings
+    for nqs in (1, 7, 32, 48, 100):
         idx.profile_get(reset=True)
         rs, ds, cs = idx.search_filtered_bitset_batch_arrays(queries[:nqs], k, metric, words)
         ps = idx.profile_get(reset=True)
         fl = int(ps["last_plan"]) & 0xff
-        assert fl & PLAN_I8C_STARTED and fl & PLAN_I8C and fl & 16 and ps["fallback_queries"] == 0, (nqs, bin(fl), ps)
+        assert fl & PLAN_I8C_STARTED and fl & PLAN_I8C and bool(fl & 16) == (nqs <= 32) and ps["fallback_queries"] == 0, (nqs, bin(fl), ps)
+        assert ((int(ps["last_plan"]) >> 16) & 0xff) == (0x14 if nqs <= 64 else 0x24), (nqs, hex(int(ps["last_plan"])))
         assert np.array_equal(rs, rows[:nqs]) and np.array_equal(ds.view(np.uint32), dists[:nqs].view(np.uint32)), nqs
 
 
