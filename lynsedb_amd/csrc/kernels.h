@@ -2285,7 +2285,8 @@ __global__ void __launch_bounds__(WQ * WR * 64, (TQ * TR >= 16) ? 1 : ((WQ * WR 
 // clamp(round((v - min) * scale), 0, 255) stored as code - 128 (signed byte for the i8 MFMA), per-row sums of the
 // signed codes and of their squares, and the same for the queries.
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_sq8_minmax(const float* __restrict__ V, uint32_t ld, uint32_t D, uint64_t n,
+template <typename T>   // float rows, or the f16 bits of an F16 shard (decoded exactly)
+__global__ void __launch_bounds__(256) k_sq8_minmax(const T* __restrict__ V, uint32_t ld, uint32_t D, uint64_t n,
                                                     uint32_t* __restrict__ omin, uint32_t* __restrict__ omax,
                                                     const float* __restrict__ row_scale = nullptr) {
     // row_scale: the coded value of element (r, d) is V[r][d] * row_scale[r] (one f32 multiply) — the unit-norm rows of the
@@ -2298,7 +2299,7 @@ __global__ void __launch_bounds__(256) k_sq8_minmax(const float* __restrict__ V,
     if (d >= D) return;
     float mn = LY_INF, mx = -LY_INF;
     for (uint64_t r = r0; r < r1; ++r) {
-        const float v = row_scale ? __fmul_rn(V[r * ld + d], row_scale[r]) : V[r * ld + d];
+        const float v = row_scale ? __fmul_rn((float)V[r * ld + d], row_scale[r]) : (float)V[r * ld + d];
         if (v < mn) mn = v;
         if (v > mx) mx = v;
     }
@@ -2338,7 +2339,8 @@ __device__ __forceinline__ int sq8_code(float v, float mn, float sc) {
 }
 
 // one wave per row (or query): codes - 128 into `out` (pitch ld8, pad columns 0), sum and sum of squares of the signed codes
-__global__ void __launch_bounds__(256) k_sq8_quantize(const float* __restrict__ V, uint32_t ld, uint32_t D, uint64_t n,
+template <typename T>
+__global__ void __launch_bounds__(256) k_sq8_quantize(const T* __restrict__ V, uint32_t ld, uint32_t D, uint64_t n,
                                                       const float* __restrict__ mins, const float* __restrict__ scales,
                                                       int8_t* __restrict__ out, uint32_t ld8, int* __restrict__ sums,
                                                       int* __restrict__ sums2, uint32_t* __restrict__ stats,
@@ -2358,7 +2360,7 @@ __global__ void __launch_bounds__(256) k_sq8_quantize(const float* __restrict__ 
         for (uint32_t d = lane; d < ld8; d += 64) {
             int c = 0;
             if (d < D || (extra_col && d < D + n_extra)) {
-                const float v = d < D ? (row_scale ? __fmul_rn(V[row * ld + d], row_scale[row]) : V[row * ld + d]) : extra_col[row];
+                const float v = d < D ? (row_scale ? __fmul_rn((float)V[row * ld + d], row_scale[row]) : (float)V[row * ld + d]) : extra_col[row];
                 if (!(fabsf(v) < LY_INF)) nonfinite += 1;
                 c = sq8_code(v, mins[d], scales[d]) - 128;
                 s1 += c;

@@ -2016,9 +2016,12 @@ static int ensure_sq8_locked(lynse_hip_flat* h) {
     LY_HIP(hipMemcpyAsync(h->sq8_mm, init.data(), init.size() * 4, hipMemcpyHostToDevice, cur(h).stream));
     const uint32_t gx = (h->dim + 255) / 256;
     const uint32_t gy = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(h->n / 256, 1), (uint64_t)h->num_cu * 8);
-    hipLaunchKernelGGL(k_sq8_minmax, dim3(gx, gy), dim3(256), 0, cur(h).stream, h->rows, h->ld, h->dim, h->n, h->sq8_mm, h->sq8_mm + h->dim);
+    if (is_f16(h)) hipLaunchKernelGGL(k_sq8_minmax<_Float16>, dim3(gx, gy), dim3(256), 0, cur(h).stream, (const _Float16*)h->rows_h, h->ld16, h->dim, h->n, h->sq8_mm, h->sq8_mm + h->dim);
+    else hipLaunchKernelGGL(k_sq8_minmax<float>, dim3(gx, gy), dim3(256), 0, cur(h).stream, h->rows, h->ld, h->dim, h->n, h->sq8_mm, h->sq8_mm + h->dim);
     hipLaunchKernelGGL(k_sq8_scales, dim3(gx), dim3(256), 0, cur(h).stream, h->sq8_mm, h->sq8_mm + h->dim, h->dim, h->sq8_mins, h->sq8_scales);
-    hipLaunchKernelGGL(k_sq8_quantize, dim3((uint32_t)std::min<uint64_t>((h->n + 3) / 4, (uint64_t)h->num_cu * 16)), dim3(256), 0, cur(h).stream,
+    if (is_f16(h)) hipLaunchKernelGGL(k_sq8_quantize<_Float16>, dim3((uint32_t)std::min<uint64_t>((h->n + 3) / 4, (uint64_t)h->num_cu * 16)), dim3(256), 0, cur(h).stream,
+                       (const _Float16*)h->rows_h, h->ld16, h->dim, h->n, h->sq8_mins, h->sq8_scales, h->sq8, h->ld8, h->sq8_sum, h->sq8_sum2, h->sq8_stats);
+    else hipLaunchKernelGGL(k_sq8_quantize<float>, dim3((uint32_t)std::min<uint64_t>((h->n + 3) / 4, (uint64_t)h->num_cu * 16)), dim3(256), 0, cur(h).stream,
                        h->rows, h->ld, h->dim, h->n, h->sq8_mins, h->sq8_scales, h->sq8, h->ld8, h->sq8_sum, h->sq8_sum2, h->sq8_stats);
     LY_HIP(hipGetLastError());
     uint32_t qst[2] = {0, 0};
@@ -2053,11 +2056,14 @@ static int ensure_sq8a_locked(lynse_hip_flat* h) {
     LY_HIP(hipMemcpyAsync(h->sq8a_mm, init.data(), init.size() * 4, hipMemcpyHostToDevice, cur(h).stream));
     const uint32_t gx = (h->dim + 255) / 256;
     const uint32_t gy = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(h->n / 256, 1), (uint64_t)h->num_cu * 8);
-    hipLaunchKernelGGL(k_sq8_minmax, dim3(gx, gy), dim3(256), 0, cur(h).stream, h->rows, h->ld, h->dim, h->n, h->sq8a_mm, h->sq8a_mm + DA);
+    if (is_f16(h)) hipLaunchKernelGGL(k_sq8_minmax<_Float16>, dim3(gx, gy), dim3(256), 0, cur(h).stream, (const _Float16*)h->rows_h, h->ld16, h->dim, h->n, h->sq8a_mm, h->sq8a_mm + DA);
+    else hipLaunchKernelGGL(k_sq8_minmax<float>, dim3(gx, gy), dim3(256), 0, cur(h).stream, h->rows, h->ld, h->dim, h->n, h->sq8a_mm, h->sq8a_mm + DA);
     hipLaunchKernelGGL(k_vec_minmax, dim3((uint32_t)std::min<uint64_t>((h->n + 255) / 256, (uint64_t)h->num_cu * 8)), dim3(256), 0, cur(h).stream,
                        h->vn2, h->n, h->sq8a_mm + h->dim, h->sq8a_mm + DA + h->dim, h->aug_cols);
     hipLaunchKernelGGL(k_sq8_scales, dim3((DA + 255) / 256), dim3(256), 0, cur(h).stream, h->sq8a_mm, h->sq8a_mm + DA, DA, h->sq8a_mins, h->sq8a_scales);
-    hipLaunchKernelGGL(k_sq8_quantize, dim3((uint32_t)std::min<uint64_t>((h->n + 3) / 4, (uint64_t)h->num_cu * 16)), dim3(256), 0, cur(h).stream,
+    if (is_f16(h)) hipLaunchKernelGGL(k_sq8_quantize<_Float16>, dim3((uint32_t)std::min<uint64_t>((h->n + 3) / 4, (uint64_t)h->num_cu * 16)), dim3(256), 0, cur(h).stream,
+                       (const _Float16*)h->rows_h, h->ld16, h->dim, h->n, h->sq8a_mins, h->sq8a_scales, h->sq8a, h->ld8a, (int*)nullptr, (int*)nullptr, h->sq8a_stats, h->vn2, h->aug_cols);
+    else hipLaunchKernelGGL(k_sq8_quantize<float>, dim3((uint32_t)std::min<uint64_t>((h->n + 3) / 4, (uint64_t)h->num_cu * 16)), dim3(256), 0, cur(h).stream,
                        h->rows, h->ld, h->dim, h->n, h->sq8a_mins, h->sq8a_scales, h->sq8a, h->ld8a, (int*)nullptr, (int*)nullptr, h->sq8a_stats, h->vn2, h->aug_cols);
     LY_HIP(hipGetLastError());
     uint32_t qst[2] = {0, 0};
@@ -2092,9 +2098,13 @@ static int ensure_sq8c_locked(lynse_hip_flat* h) {
     LY_HIP(hipMemcpyAsync(h->sq8c_mm, init.data(), init.size() * 4, hipMemcpyHostToDevice, cur(h).stream));
     const uint32_t gx = (D + 255) / 256;
     const uint32_t gy = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(h->n / 256, 1), (uint64_t)h->num_cu * 8);
-    hipLaunchKernelGGL(k_sq8_minmax, dim3(gx, gy), dim3(256), 0, cur(h).stream, h->rows, h->ld, D, h->n, h->sq8c_mm, h->sq8c_mm + D, h->vrinv);
+    if (is_f16(h)) hipLaunchKernelGGL(k_sq8_minmax<_Float16>, dim3(gx, gy), dim3(256), 0, cur(h).stream, (const _Float16*)h->rows_h, h->ld16, D, h->n, h->sq8c_mm, h->sq8c_mm + D, h->vrinv);
+    else hipLaunchKernelGGL(k_sq8_minmax<float>, dim3(gx, gy), dim3(256), 0, cur(h).stream, h->rows, h->ld, D, h->n, h->sq8c_mm, h->sq8c_mm + D, h->vrinv);
     hipLaunchKernelGGL(k_sq8_scales, dim3(gx), dim3(256), 0, cur(h).stream, h->sq8c_mm, h->sq8c_mm + D, D, h->sq8c_mins, h->sq8c_scales);
-    hipLaunchKernelGGL(k_sq8_quantize, dim3((uint32_t)std::min<uint64_t>((h->n + 3) / 4, (uint64_t)h->num_cu * 16)), dim3(256), 0, cur(h).stream,
+    if (is_f16(h)) hipLaunchKernelGGL(k_sq8_quantize<_Float16>, dim3((uint32_t)std::min<uint64_t>((h->n + 3) / 4, (uint64_t)h->num_cu * 16)), dim3(256), 0, cur(h).stream,
+                       (const _Float16*)h->rows_h, h->ld16, D, h->n, h->sq8c_mins, h->sq8c_scales, h->sq8c, h->ld8, (int*)nullptr, (int*)nullptr, h->sq8c_stats,
+                       (const float*)nullptr, 0u, h->vrinv);
+    else hipLaunchKernelGGL(k_sq8_quantize<float>, dim3((uint32_t)std::min<uint64_t>((h->n + 3) / 4, (uint64_t)h->num_cu * 16)), dim3(256), 0, cur(h).stream,
                        h->rows, h->ld, D, h->n, h->sq8c_mins, h->sq8c_scales, h->sq8c, h->ld8, (int*)nullptr, (int*)nullptr, h->sq8c_stats,
                        (const float*)nullptr, 0u, h->vrinv);
     LY_HIP(hipGetLastError());
@@ -2289,7 +2299,9 @@ static bool i8c_eligible(const lynse_hip_flat* h, int metric, bool filtered, uin
     // is a few tens of microseconds either way and the exact few-query kernel often answers alone (LYNSE_HIP_COARSE_SMALLQ=0: off)
     static const int smallq = []() { const char* e = getenv("LYNSE_HIP_COARSE_SMALLQ"); return e ? atoi(e) : 1; }();
     const bool nq_ok = nqc > SCAN_BQ_SMALL || (smallq && nqc >= 1 && (coarse_env() == 2 || h->n >= 262144));   // (masked small batches too)
-    return (metric == M_IP || l2_ok || cos_ok) && !filtered && !view && nq_ok && h->dtype == LYNSE_DTYPE_F32 &&
+    // (F16 shards too: the codes are built from the exactly decoded halves, the exact rescoring uses the f16 kernels' sequential
+    // sums — any summation order is inside the bound's rounding term)
+    return (metric == M_IP || l2_ok || cos_ok) && !filtered && !view && nq_ok &&
            scan_variant() == 3 && coarse_env() != 1 && strikes >= 0 && strikes < 3 && (coarse_env() == 2 || h->n >= 65536);
 }
 

@@ -253,3 +253,27 @@ def test_f16_shard_holds_one_copy_of_its_rows(L, oracle):
     for i in range(5):
         e_ids, e_d = oracle.canonical_topk_f16(q[i], big, 10, O.L2)
         assert np.array_equal(rows[i].astype(np.uint32), e_ids) and np.array_equal(dists[i].view(np.uint32), e_d.view(np.uint32)), i
+
+
+@pytest.mark.parametrize("name,metric", [("ip", O.IP), ("l2", O.L2), ("cosine", O.COS)])
+def test_f16_shard_on_the_certified_int8_pass(L, oracle, name, metric):
+    """F16 shards take the certified int8 coarse pass like f32 ones: the SQ8 codes are built from the exactly decoded halves, the
+    survivors are rescored with the f16 kernels' sequential f32 sums (simd.rs:805-846) — 1 B per element streamed instead of 2."""
+    rng = np.random.default_rng(77)
+    n, dim, k = 300_000, 256, 10
+    data = oracle.round_f16((rng.standard_normal((n, dim)) * 2).astype(f32)).reshape(n, dim)
+    queries = (data[rng.integers(0, n, 200)] + 0.1 * rng.standard_normal((200, dim))).astype(f32)
+    idx = L.FlatIndex(None, dim, dtype="f16")
+    for b in range(0, n, 100_000):
+        idx.write(data[b:b + 100_000])
+    idx.finalize()
+    idx.profile_enable(True)
+    for nq in (200, 40, 1):
+        idx.profile_get(reset=True)
+        rows, dists, counts = idx.search_batch_arrays(queries[:nq], k, name)
+        p = idx.profile_get(reset=True)
+        assert int(p["last_plan"]) & 64 and int(p["last_plan"]) & 4 and p["fallback_queries"] == 0, (name, nq, p)
+        for qi in sorted({0, nq // 2, nq - 1}):
+            e_ids, e_d = oracle.canonical_topk_f16(queries[qi], data, k, metric)
+            assert np.array_equal(rows[qi].astype(np.uint32), e_ids), (name, nq, qi, rows[qi], e_ids)
+            assert np.array_equal(dists[qi].view(np.uint32), e_d.view(np.uint32)), (name, nq, qi)
