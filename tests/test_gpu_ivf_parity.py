@@ -612,6 +612,7 @@ def test_ivf_any_k_with_a_subset_and_wide_binary_rows(L, oracle):
     (200_000, 384, 1024, 16, 256, 10, "uniform", IP), (70_000, 128, 300, 5, 33, 100, "clustered", IP),
     (150_000, 256, 512, 12, 130, 10, "uniform", L2), (100_000, 300, 128, 9, 64, 10, "clustered", L2),
     (150_000, 384, 512, 12, 130, 10, "gaussian", COS), (80_000, 256, 100, 100, 48, 20, "clustered", COS),
+    (300_000, 128, 256, 8, 12, 10, "clustered", IP), (280_000, 256, 128, 6, 30, 5, "gaussian", L2),   # >= 256K rows: batches of 5..32 queries too
 ])
 def test_ivf_staged_path_on_the_certified_int8_pass(L, oracle, n, dim, nlist, nprobe, nq, k, kind, metric):
     rng = np.random.default_rng(n + dim + nlist + nq)
@@ -634,16 +635,17 @@ def test_ivf_staged_path_on_the_certified_int8_pass(L, oracle, n, dim, nlist, np
     p = idx.profile_get()
     assert int(p["last_plan"]) & 64, ("the staged IVF search did not start on the int8 pass", p["last_plan"])
     assert int(p["last_plan"]) & 4, ("the int8 pass overflowed on benign data", p["last_plan"])
-    for qi in sorted({0, 1, 31, 32, nq // 2, nq - 1}):
+    for qi in sorted({0, 1, min(31, nq - 1), min(32, nq - 1), nq // 2, nq - 1}):
         e_ids, e_d, _ = oracle.ivf_search(queries[qi], data, cen, off, rows, nprobe, k, metric)
         c = int(g_c[qi])
         assert c == len(e_ids), (qi, c, len(e_ids))
         assert np.array_equal(g_d[qi, :c].view(np.uint32), e_d.view(np.uint32)), (qi, g_d[qi, :c], e_d)
         assert np.array_equal(g_rows[qi, :c], e_ids), (qi, g_rows[qi, :c], e_ids)
-    # 32 queries or fewer stay on the f16 shadow: the same answers
-    r2, d2, c2 = idx.search_batch_arrays(queries[:20], k, nprobe)
-    assert not (int(idx.profile_get()["last_plan"]) & 64)
-    assert np.array_equal(r2, g_rows[:20]) and np.array_equal(d2.view(np.uint32), g_d[:20].view(np.uint32))
+    # 32 queries or fewer stay on the f16 shadow below 256K rows (from there on they take the int8 pass as well): the same answers
+    m = min(20, nq)
+    r2, d2, c2 = idx.search_batch_arrays(queries[:m], k, nprobe)
+    assert bool(int(idx.profile_get()["last_plan"]) & 64) == (n >= 262_144)
+    assert np.array_equal(r2, g_rows[:m]) and np.array_equal(d2.view(np.uint32), g_d[:m].view(np.uint32))
 
 
 def test_ivf_int8_pass_overflow_goes_back_to_the_f16_shadow(L, oracle):
