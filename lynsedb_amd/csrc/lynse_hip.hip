@@ -47,6 +47,24 @@ static int set_error(int code, const std::string& msg) {
         if (_rc != LYNSE_OK) return _rc; \
     } while (0)
 
+// hipMemset on device memory may return before the fill has run (it is ordered on the NULL stream), and the search contexts'
+// streams are created hipStreamNonBlocking: they do NOT wait for the null stream.  A kernel on a context stream could therefore
+// start before the one-time clears of a fresh workspace had landed — seen as a first search on a new index that came back with
+// zero results, once in ~10^5 cases (the arrival counter of k_small_search held garbage).  Every synchronous fill waits here.
+static int memset_done(void* p, int v, size_t n) {
+    LY_HIP(hipMemset(p, v, n));
+    LY_HIP(hipStreamSynchronize(nullptr));
+    return LYNSE_OK;
+}
+
+// ... and the same for blocking host-to-device copies of set-up data (a pageable source is staged and the DMA may still be in
+// flight when hipMemcpy returns; the kernels that read the data run on non-blocking streams)
+static int h2d_done(void* dst, const void* src, size_t n) {
+    LY_HIP(hipMemcpy(dst, src, n, hipMemcpyHostToDevice));
+    LY_HIP(hipStreamSynchronize(nullptr));
+    return LYNSE_OK;
+}
+
 extern "C" int lynse_hip_abi_version(void) { return LYNSE_HIP_ABI_VERSION; }
 
 extern "C" size_t lynse_hip_last_error(char* buf, size_t cap) {
@@ -404,7 +422,7 @@ extern "C" int lynse_hip_flat_create(uint32_t dim, int device, lynse_hip_flat** 
         return set_error(LYNSE_ERR_OUT_OF_MEMORY, "hipMalloc(stats)");
     }
     const uint32_t init[4] = {0u, 0u, 0x7f800000u, 0u};
-    (void)hipMemcpy(h->d_stats, init, sizeof init, hipMemcpyHostToDevice);
+    (void)h2d_done(h->d_stats, init, sizeof init);
     *out = h;
     return LYNSE_OK;
 }
@@ -877,7 +895,7 @@ extern "C" int lynse_hip_flat_profile_get(lynse_hip_flat* h, lynse_hip_profile* 
         LY_HIP(hipStreamSynchronize(c.stream));
         LY_HIP(hipMemcpy(&pool, c.ws.pool_total, 8, hipMemcpyDeviceToHost));
         pool_sum += pool;
-        if (reset) LY_HIP(hipMemset(c.ws.pool_total, 0, 8));
+        if (reset) LY_TRY(memset_done(c.ws.pool_total, 0, 8));
     }
     h->prof.pool_entries = pool_sum;
     *out = h->prof;
@@ -930,7 +948,7 @@ static int ensure_workspace(lynse_hip_flat* h, uint32_t k /* caller's k = output
     LY_HIP(hipMalloc(&w.marg2, (size_t)QC * 4));
     w.q16_halves = (size_t)nslab * QC * SCAN_LDK;
     LY_HIP(hipMalloc(&w.Q16, w.q16_halves * sizeof(_Float16)));
-    LY_HIP(hipMemset(w.Q16, 0, w.q16_halves * sizeof(_Float16)));
+    LY_TRY(memset_done(w.Q16, 0, w.q16_halves * sizeof(_Float16)));
     LY_HIP(hipMalloc(&w.Qf, (size_t)QC * h->dim * 4));
     LY_HIP(hipMalloc(&w.QW, (size_t)QCHUNK * h->words * 8));
     {
@@ -945,12 +963,12 @@ static int ensure_workspace(lynse_hip_flat* h, uint32_t k /* caller's k = output
     LY_HIP(hipHostMalloc(&w.h_hdr, (size_t)2 * QC * 4, hipHostMallocDefault));
     LY_HIP(hipHostMalloc(&w.h_out, H_OUT_BYTES, hipHostMallocDefault));
     LY_HIP(hipMalloc(&w.pool_total, 8));
-    LY_HIP(hipMemset(w.pool_total, 0, 8));
+    LY_TRY(memset_done(w.pool_total, 0, 8));
     LY_HIP(hipMalloc(&w.gsync, 256 + 1024 * 64));   // hand-over words + (debugging) 8 time stamps per workgroup / per (stage, query)
-    LY_HIP(hipMemset(w.gsync, 0, 256 + 1024 * 64));
+    LY_TRY(memset_done(w.gsync, 0, 256 + 1024 * 64));
     LY_HIP(hipMalloc(&w.small_part, (size_t)SMALL_NT * SMALL_MAX_Q * SMALL_MAX_K * 8));
     LY_HIP(hipMalloc(&w.small_ticket, 4));
-    LY_HIP(hipMemset(w.small_ticket, 0, 4));
+    LY_TRY(memset_done(w.small_ticket, 0, 4));
     return LYNSE_OK;
 }
 
@@ -2746,7 +2764,7 @@ static int search_large_k(lynse_hip_flat* h, const void* q_src, bool packed_quer
     const uint64_t n_ranges = (n + R - 1) / R;
     const size_t q_elems = packed_queries ? h->words : h->dim, q_bytes = q_elems * (packed_queries ? 8 : 4);
     if (kk == 0) {  // an empty subset: empty results
-        if (on_device) LY_HIP(hipMemset(out_counts, 0, nq * 4));
+        if (on_device) LY_TRY(memset_done(out_counts, 0, nq * 4));
         else memset(out_counts, 0, nq * 4);
         return LYNSE_OK;
     }
@@ -2832,9 +2850,9 @@ static int search_large_k(lynse_hip_flat* h, const void* q_src, bool packed_quer
         }
     }
     if (on_device) {
-        LY_HIP(hipMemcpy(out_rows, o_rows.data(), o_rows.size() * 8, hipMemcpyHostToDevice));
-        LY_HIP(hipMemcpy(out_dists, o_dists.data(), o_dists.size() * 4, hipMemcpyHostToDevice));
-        LY_HIP(hipMemcpy(out_counts, o_counts.data(), o_counts.size() * 4, hipMemcpyHostToDevice));
+        LY_TRY(h2d_done(out_rows, o_rows.data(), o_rows.size() * 8));
+        LY_TRY(h2d_done(out_dists, o_dists.data(), o_dists.size() * 4));
+        LY_TRY(h2d_done(out_counts, o_counts.data(), o_counts.size() * 4));
     }
     return LYNSE_OK;
 }
@@ -2987,7 +3005,7 @@ extern "C" int lynse_hip_top_k_search(const float* query, const float* candidate
         h->amax = h->vmax = h->vmin = 0.f; h->sv = 1.f; h->cos_degenerate = 0;
         const uint32_t init[4] = {0u, 0u, 0x7f800000u, 0u};
         LY_TRY(use_device(h));
-        LY_HIP(hipMemcpy(h->d_stats, init, sizeof init, hipMemcpyHostToDevice));
+        LY_TRY(h2d_done(h->d_stats, init, sizeof init));
     }
     int rc = lynse_hip_flat_append_f32(h, candidates, n);
     const uint32_t kk = (uint32_t)std::min<uint64_t>(k, n);
