@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "kernels.h"
+#include "scan_qs.h"
 #include "ivf.h"
 
 using namespace lynse;
@@ -1371,8 +1372,38 @@ static int launch_scan_i8c_mid(const ScanArgs& a, uint32_t grid, hipStream_t st,
 
 // certified int8 coarse pass: the 256 x 256 IP tiling with 3 + 2-stage rings over 128-element slabs, one kernel per
 // (ragged last slab, emission mode)
-static int launch_scan_i8c(const ScanArgs& a, uint32_t grid, hipStream_t st, bool fs = false, bool filt = false, bool f4 = false) {
+// The query-stationary tiling of the certified int8 pass (scan_qs.h): threshold stages of an unfiltered FLAT batch over whole
+// 768-byte code rows — 8 waves x 32 register-resident queries, 64-row tiles, rows-only LDS ring.  LYNSE_HIP_QS=0: the 256 x 256
+// tile of k_scan_h16 (A/B, tests; read per call).
+// LYNSE_HIP_QS selects the instantiation (A/B; the default is the fastest measured): 1 = 64-row tiles, whole-K stages, 3-stage ring,
+// ping-pong roles; 2 = 32-row tiles, 6-stage ring, fragments prefetched across the barrier; 3 = as 1 without the ping-pong roles.
+static int qs_variant() { const char* e = getenv("LYNSE_HIP_QS"); return e ? atoi(e) : 1; }
+static uint32_t qs_rows(int v) { return v == 2 ? 32u : 64u; }   // rows per tile
+static bool qs_scan_ok(const ScanArgs& a, bool fs, bool filt, bool f4) {
+    const int v = qs_variant();
+    if (v < 1 || v > 3) return false;
+    return !fs && !filt && !f4 && a.emit_all == 0 && a.ld16 == 768 && a.nslab == 6 && a.qpad == 256 && a.nq <= 256 && a.tile_stride == 0 &&
+           a.skip_stride == 0 && !a.mask && !a.row_ids && a.row1 > a.row0;
+}
+static uint32_t qs_grid(const ScanArgs& a, uint32_t num_cu) { const uint32_t rt = qs_rows(qs_variant()); return std::min<uint32_t>((a.row1 - a.row0 + rt - 1) / rt, num_cu); }
+static int launch_scan_qs(const ScanArgs& a, uint32_t grid, hipStream_t st) {
+    static bool attr_done[4] = {false, false, false, false};
+    auto go = [&](auto kern, int slot, size_t lds) -> int {
+        if (!attr_done[slot]) { LY_TRY(set_max_lds(kern, lds)); attr_done[slot] = true; }
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, a);
+        LY_HIP(hipGetLastError());
+        return LYNSE_OK;
+    };
+    switch (qs_variant()) {
+    case 2: return go(k_scan_qs<6, 1, 6, 6, true, 8, 0, 0>, 2, (size_t)6 * 6 * 32 * 128);
+    case 3: return go(k_scan_qs<6, 2, 6, 3, false, 8, 0, 0>, 3, (size_t)3 * 6 * 64 * 128);
+    default: return go(k_scan_qs<6, 2, 6, 3, false, 8, 0, 1>, 1, (size_t)3 * 6 * 64 * 128);
+    }
+}
+
+static int launch_scan_i8c(const ScanArgs& a, uint32_t grid, hipStream_t st, bool fs = false, bool filt = false, bool f4 = false, bool qs = false) {
     constexpr size_t lds = (size_t)(3 * 256 + 2 * 256) * 128;
+    if (qs) return launch_scan_qs(a, grid, st);
     static bool attr_done[16] = {false};
     auto go = [&](auto kern, int slot) -> int {
         if (!attr_done[slot]) { LY_TRY(set_max_lds(kern, lds)); attr_done[slot] = true; }
@@ -1709,7 +1740,7 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
                     sample.sample_tiles == (uint32_t)h->num_cu && (plan[1].r1 - plan[1].r0 + 255) / 256 >= (uint32_t)h->num_cu &&
                     (uint64_t)k * 50000ull > (uint64_t)sample.sample_tiles * plan_tile &&   // (the stage behind the sample runs the DENSE epilogue)
                     []() { const char* e = getenv("LYNSE_HIP_DENSE"); return !e || atoi(e) != 0; }();
-    bool plan_used_segments = false;
+    bool plan_used_segments = false, plan_used_qs = false;
     // the select behind the last stage + exact rescoring + final order in one launch (k_select_final); LYNSE_HIP_FUSED_TAIL=0:
     // the three separate kernels (A/B)
     const int fused_tail_env = []() { const char* e = getenv("LYNSE_HIP_FUSED_TAIL"); return e ? atoi(e) : 1; }();   // (read per call: tests flip it)
@@ -1817,13 +1848,17 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
                 a.dense = (!a.emit_all && a.ld16 % 128 == 0 && seen_before &&
                            (filt || (dense_env >= 0 ? dense_env != 0 : (uint64_t)k * 50000ull > seen_before))) ? 1 : 0;   // (masked: DENSE is the one epilogue compiled with the mask)
                 const bool ag = getenv("LYNSE_HIP_AG") && atoi(getenv("LYNSE_HIP_AG")) && a.ld16 % 128 == 0 && !a.emit_all && !fs_stage && !filt && !bin_mfma;
+                const bool qs = !ag && qs_scan_ok(a, fs_stage, filt, bin_mfma);   // the query-stationary tiling (scan_qs.h): two segments per workgroup and query
+                const uint32_t launch_grid = qs ? qs_grid(a, (uint32_t)h->num_cu) : grid;
+                if (qs) { seg_geometry(launch_grid, 2, &a.nseg, &a.seg); plan_used_qs = true; }
+                else
                 if (!a.emit_all) seg_geometry(grid, (a.dense ? 8 : 4) / (ag ? 2 : 1), &a.nseg, &a.seg);   // (segments per workgroup: WR, or 2 WR wave halves with DENSE)
                 if (fs_stage) {
                     a.fs_stride = sample.sample_stride; a.fs_rows = (uint32_t)h->n; a.gsync = w.gsync; a.Qf = Qf; a.marg2 = w.marg2;
                     a.thr_out = w.thr; a.k = k; a.ip_form = ip_form; a.metric = metric;
                     if (getenv("LYNSE_HIP_FS_STAMPS")) a.debug_flags |= 128;
                 }
-                LY_TRY(launch_scan_i8c(a, grid, st, fs_stage, filt, bin_mfma));
+                LY_TRY(launch_scan_i8c(a, launch_grid, st, fs_stage, filt, bin_mfma, qs));
             } else if (h16) {
                 a.candB = w.candB; a.segcnt = w.segcnt;
                 if (small) {
@@ -1915,7 +1950,7 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
         LY_HIP(hipGetLastError());
     }
     if (tl_prof && !binary) {
-        const uint64_t tiling = (small || mid64) ? 0x14u : ((mid128 || waves16 == 3 || waves16 == 2) ? 0x24u : 0x42u);
+        const uint64_t tiling = plan_used_qs ? 0x81u : (small || mid64) ? 0x14u : ((mid128 || waves16 == 3 || waves16 == 2) ? 0x24u : 0x42u);   // (0x81: query-stationary threshold stages)
         std::lock_guard<std::mutex> plk(h->prof_mu);
         h->prof.last_plan = (sample.sample_tiles ? 1u : 0u) | ((sample.sample_tiles && sample_threshold_only) ? 2u : 0u) | (i8c ? 4u : 0u) |
                             (plan_used_segments ? 8u : 0u) | (small ? 16u : 0u) | (fs ? 128u : 0u) | ((uint64_t)(plan.size() & 0xff) << 8) | (tiling << 16);

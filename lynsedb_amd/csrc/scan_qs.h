@@ -1,0 +1,333 @@
+// scan_qs.h — k_scan_qs: the QUERY-STATIONARY tiling of the certified int8 coarse pass (FLAT-IP, 33..256 queries).
+//
+// Replaces, for the threshold stages of a batch, the 256-row x 256-query tile of k_scan_h16<2,4,4,2,IP,…,I8Q=2> (kernels.h).
+// Reference work on this path: FlatMmap::search -> exact_flat_search's chunked scan (src/storage/flat_mmap.rs:2179-2256,
+// :4845-4982) — every row of the shard scored against every query of the batch.
+//
+// What bounded the 256 x 256 tile: per slab step a CU moved 32 KB of rows (HBM) AND 32 KB of query image
+// (L2) through the LDS-DMA path, and the two rings were coupled by one barrier per step.  Here the query operand never
+// crosses that path again:
+//   * a workgroup is 8 waves; wave w OWNS queries [32 w, 32 w + 32) for the whole launch and keeps their int8 image — the
+//     B operand of v_mfma_i32_32x32x32_i8 for every k-step, NSLAB x 4 fragments x 4 registers (96 for 768 dimensions) —
+//     in registers, loaded once from the L2-resident image k_i8c_prep_queries wrote;
+//   * the LDS holds ONLY rows: a ring of NS stages, one stage = RB x 32 rows x SL slabs of 128 B (24 KB), filled by
+//     global_load_lds_dwordx4 in full 128-B lines (8 rows x 128 B per instruction, the XOR slot swizzle of k_scan_h16 on the
+//     per-lane source address);
+//   * every wave reads EVERY row fragment of a stage (one ds_read_b128 per MFMA: 128 B / clk / CU of the 256 the LDS delivers)
+//     and multiplies it with its own 32 queries; the accumulators of a tile are RB x 16 registers;
+//   * a lane's 16 x RB accumulators all belong to ONE query (column lane % 32 of the wave's block), so the epilogue is a
+//     v_max3 chain against ONE register-resident integer threshold (the integer image of the certified threshold, DESIGN.md
+//     §3b), one ballot, and a rare per-element path that appends (score, row) keys to the lane's private segment;
+//   * XPF: the first fragments of step g + 1 are read before barrier g + 1 (the wait in front of barrier g covers the data of
+//     step g + 1 too), so no wave opens a step waiting for its first LDS round trip.
+// Keys, segments and counts are the ones k_select gathers (ScanArgs::candB / segcnt; two segments per workgroup and query: the
+// two wave halves of the owning wave).
+#pragma once
+
+namespace lynse {
+
+typedef int qs_i32x4 __attribute__((ext_vector_type(4)));
+typedef int qs_i32x16 __attribute__((ext_vector_type(16)));
+
+// DBG (timing experiments): 1 no MFMA, 2 no LDS fragment reads, 8 no row DMA, 16 no epilogue, 32 s_memtime phase sums, 64 waves 4-7 do not compute
+template <int NSLAB, int RB, int SL, int NS, bool XPF, int NBUF, int DBG = 0, int PING = 0>
+__global__ void __launch_bounds__(512, 2) k_scan_qs(ScanArgs a) {
+    static_assert(NSLAB % SL == 0, "a tile is a whole number of steps");
+    constexpr int TS = NSLAB / SL;          // steps per tile
+    constexpr int RT = RB * 32;             // rows per tile
+    constexpr int SB = SL * RT * 128;       // bytes per ring stage
+    constexpr int PP = SB / 1024;           // LDS-DMA instructions per stage (1 KiB each: 8 rows x 128 B)
+    static_assert(PP % 8 == 0, "the pieces of a stage split evenly over the 8 waves");
+    constexpr int PPW = PP / 8;
+    constexpr int NM = SL * 4 * RB;         // MFMAs per wave and step
+    static_assert(NM % NBUF == 0 && NBUF >= 2 && NBUF <= NM, "fragment ring");
+    static_assert(NS >= (XPF ? 4 : 3), "ring depth");
+    static_assert(NS * SB <= 160 * 1024, "LDS");
+    constexpr int WAITN = (XPF ? NS - 3 : NS - 2) * PPW;   // DMA instructions that may still be in flight at the barrier
+    static_assert(WAITN <= 63, "vmcnt");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l32 = lane & 31, hi = lane >> 5;
+    const uint32_t ntiles = (a.row1 - a.row0 + RT - 1) / RT;
+    if (blockIdx.x >= ntiles) return;
+    const uint32_t my_tiles = (ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x;
+    const uint32_t G = my_tiles * TS;
+    [[maybe_unused]] const unsigned long long t_kernel0 = (a.debug_flags & 64) ? __builtin_amdgcn_s_memtime() : 0ull;
+
+    // ---- the wave's query block: B fragments of every k-step, register-resident for the whole launch
+    const int swz = (l32 >> 1) & 7;
+    qs_i32x4 bq[NSLAB * 4];
+    {
+        const char* qimg = reinterpret_cast<const char*>(a.Q16) + (size_t)(wave * 32 + l32) * 128;
+#pragma unroll
+        for (int s = 0; s < NSLAB; ++s)
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+                bq[s * 4 + kk] = *reinterpret_cast<const qs_i32x4*>(qimg + (size_t)s * a.qpad * 128 + (((kk * 2 + hi) ^ swz) * 16));
+    }
+    // per-query constants of this lane's query (one query per lane: column lane % 32 of the wave's block)
+    const uint32_t qn = wave * 32 + l32;
+    const bool q_ok = qn < a.nq;
+    const float s_q = q_ok ? a.qinv[qn] : 0.0f, b_q = q_ok ? a.qn2[qn] : 0.0f;
+    int T = 0x7fffffff;
+    {
+        // INTEGER image of the threshold (k_scan_h16, load_qc_thr): B_q + s_q * (float)dot is monotone non-decreasing in the
+        // integer dot product, so "score >= thr" is exactly "dot >= T", T = the smallest passing dot (bisection over |dot| <= 2^29)
+        const float th = q_ok ? a.thr[qn] : 0.0f;
+        int lo = -(1 << 29), hi_ = 1 << 29;
+#pragma unroll 1
+        for (int it = 0; it < 31; ++it) {
+            const int mid = lo + ((hi_ - lo) >> 1);
+            const bool ge = (b_q + s_q * (float)mid) >= th;
+            hi_ = ge ? mid : hi_;
+            lo = ge ? lo : mid + 1;
+        }
+        T = q_ok ? lo : 0x7fffffff;
+#ifdef LYNSE_EXPERIMENTS
+        if (a.debug_flags & 2) T = 0x7fffffff;
+#endif
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the query fragments and constants are in registers before the first LDS-DMA
+
+    // ---- row stream (LDS-DMA): step gi of this workgroup = tile gi / TS, slabs [(gi % TS) SL, +SL)
+    // piece p = wave * PPW + j of a stage: slab p / (RB 4) of the step, rows (p % (RB 4)) * 8 .. +8 of the tile; lane l brings the 16 B
+    // of row (l >> 3), PHYSICAL slot (l & 7) = logical slot (l & 7) ^ ((row >> 1) & 7)
+    uint32_t v_off[PPW];
+    const char* v_base = nullptr;   // uniform: first row of the tile being issued
+    uint32_t is_tile = blockIdx.x, is_sub = 0, is_stage = 0, is_count = 0;
+    auto enter_tile = [&]() {
+        const uint32_t rbase = a.row0 + is_tile * RT;
+        const uint32_t span = a.row1 - 1 - rbase;   // rows past the last one re-read it (masked in the epilogue)
+        v_base = reinterpret_cast<const char*>(a.V16) + (size_t)rbase * a.ld16;
+#pragma unroll
+        for (int j = 0; j < PPW; ++j) {
+            const int p = wave * PPW + j;
+            uint32_t r = (p % (RB * 4)) * 8 + (lane >> 3);
+            const uint32_t col = (uint32_t)(p / (RB * 4)) * 128u + (((lane & 7) ^ ((r >> 1) & 7)) * 16);
+            r = r < span ? r : span;
+            v_off[j] = r * a.ld16 + col;
+        }
+    };
+    auto issue_piece = [&](int j) {
+        if (DBG & 8) return;
+        glds16<2>(v_base + (size_t)(is_sub * (SL * 128)) + v_off[j], smem + is_stage * SB + (wave * PPW + j) * 1024);
+    };
+    auto advance = [&]() {   // past the end the last real step is issued again (uniform DMA counts; its stage is never read)
+        is_stage = is_stage + 1 == NS ? 0 : is_stage + 1;
+        if (++is_count < G) {
+            if (++is_sub == TS) {
+                is_sub = 0;
+                is_tile += gridDim.x;
+                enter_tile();
+            }
+        }
+    };
+    enter_tile();
+#pragma unroll
+    for (int s0 = 0; s0 < NS - 1; ++s0) {
+#pragma unroll
+        for (int j = 0; j < PPW; ++j) issue_piece(j);
+        advance();
+    }
+
+    // ---- fragment reads: row r of slab sl of a stage lives at sl * RT * 128 + r * 128, logical 16-B slot c at physical c ^ ((r >> 1) & 7)
+    // lane (l32, hi) of the A fragment (rb, kk): row rb * 32 + l32, slot kk * 2 + hi  ->  (l32 * 128 + ((hi ^ swz) * 16)) ^ (kk * 32)
+    // The reads and their waits are issued by hand: hipcc answers every pending ds_read with s_waitcnt lgkmcnt(0) while LDS-DMA is in
+    // flight, which drains the NBUF-deep fragment ring once per ring revolution; LDS reads return in order, so MFMA idx only needs
+    // "at most NBUF - 1 reads outstanding" after the read for MFMA idx + NBUF - 1 has been issued.
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    const uint32_t a_lane = lds0 + (uint32_t)l32 * 128u + (uint32_t)((hi ^ swz) * 16);
+    qs_i32x4 af[NBUF];
+    auto read_frag = [&](qs_i32x4& dst, const uint32_t (&ad)[4], auto idxc) {   // MFMA idx of a step: (sl, kk, rb) = (idx / (4 RB), (idx / RB) % 4, idx % RB)
+        constexpr int idx = decltype(idxc)::value;
+        constexpr int sl = idx / (4 * RB), kk = (idx / RB) % 4, rb = idx % RB;
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(ad[kk]), "n"(sl * (RT * 128) + rb * (32 * 128)));
+    };
+    qs_i32x16 acc[RB];
+#pragma unroll
+    for (int i = 0; i < RB; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0;
+
+    uint32_t cnt = 0;            // keys in this lane's private segment
+    uint32_t tile = blockIdx.x;  // tile being computed
+    uint32_t c_stage = 0;
+    uint32_t ad_cur[4], ad_nxt[4];   // fragment addresses (per kk) in the stage being computed / the next one
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) ad_nxt[kk] = a_lane ^ (uint32_t)(kk * 32);
+    if constexpr (XPF) {   // the first fragments of step 0 (every later step: read during the step before)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * PPW) : "memory");
+        __builtin_amdgcn_s_barrier();
+        if (!(DBG & 2)) ly_static_for<NBUF - 1>([&](auto ic) { read_frag(af[decltype(ic)::value], ad_nxt, ic); });
+    }
+    constexpr bool TIMING = (DBG & 32) != 0;   // s_memtime sums per wave: DMA wait, barrier, MFMA loop, epilogue + DMA issue (a.dbg[512 + (block * 8 + wave) * 4 ..])
+    [[maybe_unused]] unsigned long long t_wait = 0, t_bar = 0, t_loop = 0, t_epi = 0, tp = TIMING ? __builtin_amdgcn_s_memtime() : 0ull;
+    [[maybe_unused]] auto stamp = [&](unsigned long long& bucket) {
+        if constexpr (TIMING) { const unsigned long long t = __builtin_amdgcn_s_memtime(); bucket += t - tp; tp = t; }
+    };
+    // the MFMAs of one step (s = the step's position in its tile); DMA_IN: the refill pieces are issued between them
+    auto mfma_step = [&](auto sc, auto dma_in) {
+        constexpr int s = decltype(sc)::value;
+        constexpr bool DMA_IN = decltype(dma_in)::value;
+        if constexpr (!XPF) {
+            if (!(DBG & 2)) ly_static_for<NBUF - 1>([&](auto ic) { read_frag(af[decltype(ic)::value], ad_cur, ic); });
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        ly_static_for<NM>([&](auto ic) {
+            constexpr int idx = decltype(ic)::value;
+            constexpr int nxt = idx + NBUF - 1;
+            if (!(DBG & 2)) {
+                if constexpr (nxt < NM) read_frag(af[nxt % NBUF], ad_cur, std::integral_constant<int, nxt>{});
+                else if constexpr (XPF) read_frag(af[nxt % NBUF], ad_nxt, std::integral_constant<int, nxt - NM>{});
+                // outstanding reads now: those for MFMAs idx .. min(nxt, last): the oldest one is this MFMA's
+                constexpr int outstanding = (nxt < NM || XPF) ? NBUF : NM - idx;
+                asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(af[idx % NBUF]) : "n"(outstanding - 1));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            constexpr int sl = idx / (4 * RB), kk = (idx / RB) % 4, rb = idx % RB;
+            constexpr int ks = (s * SL + sl) * 4 + kk;
+            if constexpr ((DBG & 1) != 0) {
+                asm volatile("" ::"v"(af[idx % NBUF]), "v"(bq[ks]));
+            } else if constexpr (ks == 0) {   // first k-step of a tile: C = 0 (no accumulator clears)
+                const qs_i32x16 z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+                acc[rb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[idx % NBUF], bq[ks], z, 0, 0, 0);
+            } else {
+                acc[rb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[idx % NBUF], bq[ks], acc[rb], 0, 0, 0);
+            }
+            if constexpr (DMA_IN) {   // the refill of the stage computed last (step g + NS - 1), spread behind the MFMAs
+                ly_static_for<PPW>([&](auto jc) {
+                    constexpr int j = decltype(jc)::value;
+                    if constexpr (idx == (NM / PPW) * j + 1) issue_piece(j);
+                });
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    };
+    auto wait_and_barrier = [&]() {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAITN) : "memory");
+        stamp(t_wait);
+        __builtin_amdgcn_s_barrier();
+        stamp(t_bar);
+        c_stage = c_stage + 1 == NS ? 0 : c_stage + 1;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            ad_cur[kk] = ad_nxt[kk];
+            ad_nxt[kk] = (a_lane ^ (uint32_t)(kk * 32)) + c_stage * SB;
+        }
+    };
+    // ---- tile epilogue: this lane's RB x 16 dot products all belong to query qn
+    auto epilogue = [&](uint32_t e_tile) {
+        if constexpr ((DBG & 16) != 0) {
+#pragma unroll
+            for (int i = 0; i < RB; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) asm volatile("" ::"v"(acc[i][r]));
+        } else {
+            int mx = acc[0][0];
+#pragma unroll
+            for (int i = 0; i < RB; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mx = mx > acc[i][r] ? mx : acc[i][r];
+            if (__builtin_expect(__ballot(mx >= T) != 0ull, 0)) {
+                const uint32_t rbase = a.row0 + e_tile * RT;
+                uint64_t* segdst = a.candB + ((size_t)qn * a.nseg + (blockIdx.x * 2 + hi)) * a.seg;
+#pragma unroll
+                for (int i = 0; i < RB; ++i) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int v = acc[i][r];
+                        if (v >= T) {
+                            const uint32_t m = rbase + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                            if (m < a.row1) {
+                                const uint64_t key = make_key(b_q + s_q * (float)v, m, false);
+                                if (cnt < a.seg) {
+                                    segdst[cnt] = key;
+                                    ++cnt;
+                                } else {
+                                    const uint32_t slot = atomicAdd(&a.count[qn], 1u);
+                                    if (slot < a.cap) a.cand[(size_t)qn * a.cap + slot] = key;
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    };
+    if constexpr (PING == 0) {
+        for (uint32_t ti = 0; ti < my_tiles; ++ti) {
+            ly_static_for<TS>([&](auto sc) {
+                stamp(t_epi);
+                wait_and_barrier();
+                if ((DBG & 64) && wave >= 4) {   // (experiment) one computing wave per SIMD: waves 4-7 only feed the ring
+#pragma unroll
+                    for (int j = 0; j < PPW; ++j) issue_piece(j);
+                } else {
+                    mfma_step(sc, std::true_type{});
+                }
+                advance();
+                if constexpr (TIMING) asm volatile("" ::"v"(acc[0][0]));
+                stamp(t_loop);
+            });
+            epilogue(tile);
+            tile += gridDim.x;
+        }
+    } else {
+        // PING-PONG (PING): the two waves of a SIMD share one matrix pipe, and with equal priority the older wave wins every slot — waves
+        // 0-3 finished a step's MFMAs first and then waited at the barrier (s_memtime: 45 % of their time) while waves 4-7 ran their
+        // MFMAs, their DMA issue and their tile epilogue one after the other.  Here the roles are explicit: the EARLY waves (0-3: one
+        // per SIMD) run  barrier -> MFMAs -> epilogue -> DMA issue,  the LATE waves (4-7)  barrier -> epilogue of the PREVIOUS tile ->
+        // DMA issue -> MFMAs:  each half's epilogue / issue work sits beside the other half's MFMAs.  (PING == 2: s_setprio 1 on the
+        // early waves' MFMAs.)
+        static_assert(PING == 0 || TS == 1, "ping-pong: one step per tile");
+        const bool late = wave >= 4;
+        bool pend = false;   // late waves: the tile computed in the previous step still has to go through the epilogue
+        for (uint32_t g = 0; g <= my_tiles; ++g) {
+            if (g < my_tiles) {
+                stamp(t_epi);
+                wait_and_barrier();
+                if (!late) {
+                    if constexpr (PING == 2) __builtin_amdgcn_s_setprio(1);
+                    mfma_step(std::integral_constant<int, 0>{}, std::false_type{});
+                    if constexpr (PING == 2) __builtin_amdgcn_s_setprio(0);
+                    if constexpr (TIMING) asm volatile("" ::"v"(acc[0][0]));
+                    stamp(t_loop);
+                    pend = true;
+                }
+            }
+            if (pend) {
+                epilogue(tile);
+                tile += gridDim.x;
+                pend = false;
+            }
+            if (g < my_tiles) {
+#pragma unroll
+                for (int j = 0; j < PPW; ++j) issue_piece(j);
+                advance();
+                if (late) {
+                    stamp(t_epi);
+                    mfma_step(std::integral_constant<int, 0>{}, std::false_type{});
+                    if constexpr (TIMING) asm volatile("" ::"v"(acc[0][0]));
+                    stamp(t_loop);
+                    pend = true;
+                }
+            }
+        }
+    }
+    if (a.seg && q_ok) a.segcnt[(size_t)qn * a.nseg + (blockIdx.x * 2 + hi)] = (uint8_t)cnt;
+    if constexpr (TIMING) {
+        if (a.dbg && lane == 0 && blockIdx.x < 64) {
+            unsigned long long* o = a.dbg + 2 * 256 + ((size_t)blockIdx.x * 8 + wave) * 4;
+            o[0] = t_wait; o[1] = t_bar; o[2] = t_loop; o[3] = t_epi;
+        }
+    }
+    if ((a.debug_flags & 64) && a.dbg && tid == 0) {   // shader cycles of this workgroup (s_memtime ticks / wall time = the clock held)
+        a.dbg[blockIdx.x * 2] = t_kernel0;
+        a.dbg[blockIdx.x * 2 + 1] = __builtin_amdgcn_s_memtime();
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+}  // namespace lynse

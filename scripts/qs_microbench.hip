@@ -1,0 +1,388 @@
+// qs_microbench.hip — stand-alone A/B of the int8 scan kernels on synthetic codes (development tool, not product):
+//   k_scan_h16<2,4,4,2,IP,…,I8Q=2>  (256 x 256 tile, query image through the LDS-DMA ring)   vs
+//   k_scan_qs<…>                     (query-stationary: B operand in registers, rows-only LDS ring; scan_qs.h)
+// 1. correctness: both kernels over a small shard (ragged last tile) against a brute-force kernel — identical key sets;
+// 2. timing: interleaved rounds over a large shard, HIP events, plus the shader clock each QS variant held
+//    (s_memtime ticks of workgroup 0 / event time) and wall-clock stamps a power sampler can be joined on.
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -mllvm -pragma-unroll-threshold=262144 \
+//        [-DLYNSE_EXPERIMENTS] -o qs_microbench scripts/qs_microbench.hip
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <atomic>
+#include <dirent.h>
+#include <fstream>
+#include <string>
+#include <thread>
+#include <type_traits>
+#include <utility>
+#include <vector>
+
+#include "../lynsedb_amd/csrc/kernels.h"
+#include "../lynsedb_amd/csrc/scan_qs.h"
+
+using namespace lynse;
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s:%d %s: %s\n", __FILE__, __LINE__, #x, hipGetErrorString(e_)); exit(1); } } while (0)
+
+__device__ __host__ inline uint32_t mix(uint64_t x) {
+    x ^= x >> 33; x *= 0xff51afd7ed558ccdull; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull; x ^= x >> 33;
+    return (uint32_t)x;
+}
+__global__ void k_fill_rows(int8_t* V, uint64_t nbytes, uint64_t seed) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i * 4 < nbytes; i += (uint64_t)gridDim.x * blockDim.x)
+        reinterpret_cast<uint32_t*>(V)[i] = mix(i + seed * 0x9e3779b97f4a7c15ull);
+}
+// queries: plain [nq][D] int8 in [-127,127] and the kernel's image [nslab][qpad][8 slots ^ swizzle][16]
+__global__ void k_fill_queries(int8_t* plain, int8_t* img, uint32_t nq, uint32_t qpad, uint32_t D, uint32_t nslab) {
+    const uint32_t q = blockIdx.x;
+    for (uint32_t i = threadIdx.x; i < nslab * 128; i += blockDim.x) {
+        int u = 0;
+        if (q < nq && i < D) { u = (int)(mix(0x1234567ull + (uint64_t)q * 100003 + i) % 255u) - 127; plain[(size_t)q * D + i] = (int8_t)u; }
+        const uint32_t s = i / 128, k = i % 128, l = k >> 4, e = k & 15, p = l ^ ((q >> 1) & 7);
+        img[(((size_t)s * qpad + q) * 8 + p) * 16 + e] = (int8_t)u;
+    }
+}
+// brute force: one workgroup per row block of 64 rows, thread = (row, query stripe)
+__global__ void __launch_bounds__(256) k_ref(const int8_t* V, uint32_t ld, uint32_t D, uint32_t n, const int8_t* Qp, uint32_t nq,
+                                             const int* T, uint64_t* out, uint32_t* out_n, uint32_t out_cap) {
+    const uint32_t row = blockIdx.x * 64 + (threadIdx.x & 63);
+    if (row >= n) return;
+    for (uint32_t q = threadIdx.x >> 6; q < nq; q += 4) {
+        int dot = 0;
+        for (uint32_t d = 0; d < D; ++d) dot += (int)V[(size_t)row * ld + d] * (int)Qp[(size_t)q * D + d];
+        if (dot >= T[q]) {
+            const uint32_t slot = atomicAdd(out_n, 1u);
+            if (slot < out_cap) out[slot] = ((uint64_t)q << 48) ^ make_key((float)dot, row, false);
+        }
+    }
+}
+
+// amdgpu hwmon: socket power (uW) and shader clock (Hz), sampled by a background thread while a variant runs
+struct Sampler {
+    std::string power_path, freq_path;
+    std::atomic<bool> on{false}, stop{false};
+    std::atomic<long long> sum_p{0}, sum_f{0}, n{0};
+    std::thread th;
+    static bool read_ll(const std::string& p, long long* v) { std::ifstream f(p); return (bool)(f >> *v); }
+    void start() {
+        char bus[64] = {0};
+        if (hipDeviceGetPCIBusId(bus, sizeof(bus), 0) == hipSuccess) {
+            for (char* c = bus; *c; ++c) *c = (char)tolower(*c);
+            const std::string hw = std::string("/sys/bus/pci/devices/") + bus + "/hwmon";
+            if (DIR* d = opendir(hw.c_str())) {
+                while (dirent* e = readdir(d)) {
+                    if (e->d_name[0] == '.') continue;
+                    const std::string base = hw + "/" + e->d_name;
+                    long long v;
+                    for (const char* pn : {"/power1_average", "/power1_input"})
+                        if (power_path.empty() && read_ll(base + pn, &v)) power_path = base + pn;
+                    if (freq_path.empty() && read_ll(base + "/freq1_input", &v)) freq_path = base + "/freq1_input";
+                }
+                closedir(d);
+            }
+            printf("device pci %s\n", bus);
+        }
+        DIR* d = power_path.empty() ? opendir("/sys/class/hwmon") : nullptr;
+        if (d) {
+            while (dirent* e = readdir(d)) {
+                const std::string base = std::string("/sys/class/hwmon/") + e->d_name;
+                std::ifstream nf(base + "/name");
+                std::string name;
+                if (!(nf >> name) || name != "amdgpu") continue;
+                long long v;
+                for (const char* pn : {"/power1_average", "/power1_input"})
+                    if (power_path.empty() && read_ll(base + pn, &v)) power_path = base + pn;
+                if (freq_path.empty() && read_ll(base + "/freq1_input", &v)) freq_path = base + "/freq1_input";
+            }
+            closedir(d);
+        }
+        printf("sampler: power %s, sclk %s\n", power_path.c_str(), freq_path.c_str());
+        th = std::thread([this]() {
+            while (!stop.load()) {
+                if (on.load()) {
+                    long long p = 0, f = 0;
+                    if (!power_path.empty()) read_ll(power_path, &p);
+                    if (!freq_path.empty()) read_ll(freq_path, &f);
+                    sum_p += p; sum_f += f; n += 1;
+                }
+                std::this_thread::sleep_for(std::chrono::milliseconds(2));
+            }
+        });
+    }
+    void begin() { sum_p = 0; sum_f = 0; n = 0; on = true; }
+    void end(double* watts, double* mhz) { on = false; const double k = (double)std::max<long long>(n.load(), 1); *watts = sum_p / k * 1e-6; *mhz = sum_f / k * 1e-6; }
+    void finish() { stop = true; if (th.joinable()) th.join(); }
+};
+
+struct Bufs {
+    int8_t *V = nullptr, *Qp = nullptr, *img = nullptr;
+    float *qinv = nullptr, *qn2 = nullptr, *thr = nullptr;
+    int* Ti = nullptr;
+    uint64_t *cand = nullptr, *candB = nullptr;
+    uint8_t* segcnt = nullptr;
+    uint32_t* count = nullptr;
+    unsigned long long* dbg = nullptr;
+    uint32_t cap = 16384;
+};
+
+static const uint32_t D = 768, NSLABS = 6, NQ = 256, QPAD = 256;
+static const uint32_t SEG_KEYS = 32768;
+
+static ScanArgs base_args(const Bufs& b, uint32_t r0, uint32_t r1, uint32_t nq) {
+    ScanArgs a{};
+    a.V16 = reinterpret_cast<const _Float16*>(b.V); a.ld16 = D; a.D = D; a.ld = D;
+    a.row0 = r0; a.row1 = r1; a.Q16 = reinterpret_cast<const _Float16*>(b.img);
+    a.qpad = QPAD; a.nq = nq; a.nslab = NSLABS;
+    a.qinv = b.qinv; a.qn2 = b.qn2; a.qrinv = b.qinv; a.thr = b.thr;
+    a.cand = b.cand; a.count = b.count; a.cap = b.cap; a.candB = b.candB; a.segcnt = b.segcnt;
+    a.emit_all = 0;
+    return a;
+}
+
+template <typename K>
+static void set_lds(K k, size_t bytes) { CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes)); }
+
+struct Variant {
+    std::string name;
+    int segs_per_wg;
+    void (*launch)(ScanArgs a, uint32_t grid, hipStream_t st);
+    bool qs;
+};
+
+template <int NSLAB, int RB, int SL, int NS, bool XPF, int NBUF, int DBG, int PP = 0>
+static void launch_qs(ScanArgs a, uint32_t grid, hipStream_t st) {
+    auto k = k_scan_qs<NSLAB, RB, SL, NS, XPF, NBUF, DBG, PP>;
+    constexpr size_t lds = (size_t)NS * SL * RB * 32 * 128;
+    static bool done = false;
+    if (!done) { set_lds(k, lds); done = true; }
+    const uint32_t nt = (a.row1 - a.row0 + RB * 32 - 1) / (RB * 32);
+    hipLaunchKernelGGL(k, dim3(std::min(grid, nt)), dim3(512), lds, st, a);
+}
+template <bool DENSE, int DBG>
+static void launch_old(ScanArgs a, uint32_t grid, hipStream_t st) {
+    auto k = k_scan_h16<2, 4, 4, 2, M_IP, 3, 2, 2, false, false, DBG, false, 2, 0, 0, DENSE>;
+    constexpr size_t lds = (size_t)(3 * 256 + 2 * 256) * 128;
+    static bool done = false;
+    if (!done) { set_lds(k, lds); done = true; }
+    a.ntiles = (a.row1 - a.row0 + 255) / 256;
+    a.dense = DENSE ? 1 : 0;
+    hipLaunchKernelGGL(k, dim3(std::min(grid, a.ntiles)), dim3(512), lds, st, a);
+}
+
+static std::vector<uint64_t> collect(const Bufs& b, uint32_t nq, uint32_t nseg, uint32_t seg) {
+    std::vector<uint32_t> cnt(nq);
+    CK(hipMemcpy(cnt.data(), b.count, nq * 4, hipMemcpyDeviceToHost));
+    std::vector<uint64_t> keys;
+    std::vector<uint64_t> tmp(b.cap);
+    for (uint32_t q = 0; q < nq; ++q) {
+        const uint32_t c = std::min(cnt[q], b.cap);
+        if (cnt[q] > b.cap) { fprintf(stderr, "query %u overflowed the shared region (%u)\n", q, cnt[q]); }
+        if (c) {
+            CK(hipMemcpy(tmp.data(), b.cand + (size_t)q * b.cap, (size_t)c * 8, hipMemcpyDeviceToHost));
+            for (uint32_t i = 0; i < c; ++i) keys.push_back(((uint64_t)q << 48) ^ tmp[i]);
+        }
+    }
+    if (nseg) {
+        std::vector<uint8_t> sc((size_t)nq * nseg);
+        std::vector<uint64_t> sk((size_t)nq * nseg * seg);
+        CK(hipMemcpy(sc.data(), b.segcnt, sc.size(), hipMemcpyDeviceToHost));
+        CK(hipMemcpy(sk.data(), b.candB, sk.size() * 8, hipMemcpyDeviceToHost));
+        for (uint32_t q = 0; q < nq; ++q)
+            for (uint32_t s = 0; s < nseg; ++s)
+                for (uint32_t i = 0; i < sc[(size_t)q * nseg + s]; ++i) keys.push_back(((uint64_t)q << 48) ^ sk[((size_t)q * nseg + s) * seg + i]);
+    }
+    std::sort(keys.begin(), keys.end());
+    return keys;
+}
+
+int main(int argc, char** argv) {
+    const uint64_t n_big = argc > 1 ? strtoull(argv[1], nullptr, 10) : 10000000ull;
+    const int rounds = argc > 2 ? atoi(argv[2]) : 5;
+    const double sigma_tight = argc > 3 ? atof(argv[3]) : 4.3;   // thresholds in units of the dot product's standard deviation
+    const int only = argc > 4 ? atoi(argv[4]) : -1;
+    const double sigma_loose = argc > 7 ? atof(argv[7]) : 3.6;
+    const int long_reps = argc > 5 ? atoi(argv[5]) : 20, long_warm = argc > 6 ? atoi(argv[6]) : 25;
+    Sampler sampler;
+    sampler.start();
+    hipDeviceProp_t prop;
+    CK(hipGetDeviceProperties(&prop, 0));
+    const uint32_t ncu = (uint32_t)prop.multiProcessorCount;
+    printf("device %s, %u CUs\n", prop.name, ncu);
+    Bufs b;
+    CK(hipMalloc(&b.V, n_big * D + 4096));
+    CK(hipMalloc(&b.Qp, (size_t)NQ * D));
+    CK(hipMalloc(&b.img, (size_t)NSLABS * QPAD * 128));
+    CK(hipMalloc(&b.qinv, NQ * 4)); CK(hipMalloc(&b.qn2, NQ * 4)); CK(hipMalloc(&b.thr, NQ * 4)); CK(hipMalloc(&b.Ti, NQ * 4));
+    CK(hipMalloc(&b.cand, (size_t)NQ * b.cap * 8));
+    CK(hipMalloc(&b.candB, (size_t)NQ * SEG_KEYS * 8));
+    CK(hipMalloc(&b.segcnt, (size_t)NQ * 4096));
+    CK(hipMalloc(&b.count, NQ * 4));
+    CK(hipMalloc(&b.dbg, 4096 * 16));
+    CK(hipMemset(b.dbg, 0, 4096 * 16));
+    hipLaunchKernelGGL(k_fill_rows, dim3(ncu * 8), dim3(256), 0, 0, b.V, n_big * D, 7ull);
+    CK(hipMemset(b.img, 0, (size_t)NSLABS * QPAD * 128));
+    hipLaunchKernelGGL(k_fill_queries, dim3(QPAD), dim3(256), 0, 0, b.Qp, b.img, NQ, QPAD, D, NSLABS);
+    CK(hipDeviceSynchronize());
+    // dot product of a uniform byte in [-128,127] with a uniform byte in [-127,127]: sd = 73.9 * 73.3 per term
+    const double sd = std::sqrt((double)D) * 73.9 * 73.3;
+    auto set_thr = [&](double sig, uint32_t nq) {
+        std::vector<float> one(NQ, 1.0f), zero(NQ, 0.0f), th(NQ);
+        std::vector<int> ti(NQ);
+        for (uint32_t q = 0; q < NQ; ++q) { th[q] = (float)std::floor(sig * sd + 1000.0 * (q % 7)); ti[q] = q < nq ? (int)th[q] : 0x7fffffff; }
+        CK(hipMemcpy(b.qinv, one.data(), NQ * 4, hipMemcpyHostToDevice));
+        CK(hipMemcpy(b.qn2, zero.data(), NQ * 4, hipMemcpyHostToDevice));
+        CK(hipMemcpy(b.thr, th.data(), NQ * 4, hipMemcpyHostToDevice));
+        CK(hipMemcpy(b.Ti, ti.data(), NQ * 4, hipMemcpyHostToDevice));
+    };
+
+    std::vector<Variant> vars;
+    vars.push_back({"old<2,4,4,2> two-level", 4, launch_old<false, 0>, false});
+    vars.push_back({"old<2,4,4,2> DENSE", 8, launch_old<true, 0>, false});
+    vars.push_back({"qs RB1 SL6 NS6 XPF NBUF8", 2, launch_qs<6, 1, 6, 6, true, 8, 0>, true});
+    vars.push_back({"qs RB2 SL3 NS6 XPF NBUF8", 2, launch_qs<6, 2, 3, 6, true, 8, 0>, true});
+    vars.push_back({"qs RB2 SL6 NS3 noXPF NBUF8", 2, launch_qs<6, 2, 6, 3, false, 8, 0>, true});
+    vars.push_back({"qs RB1 SL6 NS6 XPF NBUF8 PP1", 2, launch_qs<6, 1, 6, 6, true, 8, 0, 1>, true});
+    vars.push_back({"qs RB1 SL6 NS6 XPF NBUF8 PP2", 2, launch_qs<6, 1, 6, 6, true, 8, 0, 2>, true});
+    vars.push_back({"qs RB1 SL6 NS6 XPF NBUF12 PP1", 2, launch_qs<6, 1, 6, 6, true, 12, 0, 1>, true});
+    vars.push_back({"qs RB1 SL6 NS5 XPF NBUF8 PP1", 2, launch_qs<6, 1, 6, 5, true, 8, 0, 1>, true});
+    vars.push_back({"qs RB2 SL6 NS3 noXPF NBUF8 PP1", 2, launch_qs<6, 2, 6, 3, false, 8, 0, 1>, true});
+#ifdef LYNSE_EXPERIMENTS
+    vars.push_back({"qs RB1 SL6 NS6 XPF NBUF8 | no epilogue", 2, launch_qs<6, 1, 6, 6, true, 8, 16>, true});
+    vars.push_back({"qs RB1 SL6 NS6 XPF NBUF8 | MFMA only", 2, launch_qs<6, 1, 6, 6, true, 8, 16 + 8 + 2>, true});
+    vars.push_back({"qs RB1 SL6 NS6 XPF NBUF8 | MFMA + LDS reads", 2, launch_qs<6, 1, 6, 6, true, 8, 16 + 8>, true});
+    vars.push_back({"qs RB1 SL6 NS6 XPF NBUF8 | DMA only", 2, launch_qs<6, 1, 6, 6, true, 8, 16 + 2 + 1>, true});
+    vars.push_back({"qs RB1 SL6 NS6 XPF NBUF8 | DMA + LDS reads", 2, launch_qs<6, 1, 6, 6, true, 8, 16 + 1>, true});
+    vars.push_back({"qs RB1 SL6 NS6 XPF NBUF8 | DMA + MFMA", 2, launch_qs<6, 1, 6, 6, true, 8, 16 + 2>, true});
+    vars.push_back({"qs RB1 SL6 NS6 XPF NBUF8 | LDS reads only", 2, launch_qs<6, 1, 6, 6, true, 8, 16 + 8 + 1>, true});
+    vars.push_back({"qs RB1 SL6 NS6 XPF NBUF8 | phase timing", 2, launch_qs<6, 1, 6, 6, true, 8, 32>, true});
+    vars.push_back({"qs RB1 SL6 NS6 XPF NBUF8 PP1 | phase timing", 2, launch_qs<6, 1, 6, 6, true, 8, 32, 1>, true});
+    vars.push_back({"qs RB1 SL6 NS6 XPF NBUF8 PP1 | no epilogue", 2, launch_qs<6, 1, 6, 6, true, 8, 16, 1>, true});
+    vars.push_back({"qs RB1 SL6 NS6 | lone wave, MFMA only", 2, launch_qs<6, 1, 6, 6, true, 8, 64 + 16 + 8 + 2>, true});
+    vars.push_back({"qs RB2 SL3 NS6 | lone wave, MFMA only", 2, launch_qs<6, 2, 3, 6, true, 8, 64 + 16 + 8 + 2>, true});
+    vars.push_back({"qs RB1 SL6 NS6 | lone wave, MFMA + LDS reads", 2, launch_qs<6, 1, 6, 6, true, 8, 64 + 16 + 8>, true});
+    vars.push_back({"qs RB2 SL3 NS6 | lone wave, MFMA + LDS reads", 2, launch_qs<6, 2, 3, 6, true, 8, 64 + 16 + 8>, true});
+    vars.push_back({"qs RB1 SL6 NS6 | lone wave, MFMA + LDS + DMA", 2, launch_qs<6, 1, 6, 6, true, 8, 64 + 16>, true});
+    vars.push_back({"qs RB2 SL3 NS6 | lone wave, MFMA + LDS + DMA", 2, launch_qs<6, 2, 3, 6, true, 8, 64 + 16>, true});
+    vars.push_back({"old<2,4,4,2> | no epilogue", 4, launch_old<false, 16>, false});
+#endif
+
+    auto clear = [&](uint32_t nseg) {
+        CK(hipMemsetAsync(b.count, 0, NQ * 4, 0));
+        CK(hipMemsetAsync(b.segcnt, 0, (size_t)NQ * 4096, 0));
+        (void)nseg;
+    };
+
+    // ---- 1. correctness on a small shard with a ragged end, two query counts, two thresholds, full and starved segments
+    int bad = 0;
+    for (int pass = 0; pass < 4 && only < 0; ++pass) {
+        const uint32_t n = pass == 1 ? 8191u + 13u : 65536u + 37u, nq = pass == 2 ? 200u : 256u;
+        const double sig = pass == 3 ? 1.6 : 3.0;
+        set_thr(sig, nq);
+        uint64_t* ref_d; uint32_t* ref_n;
+        const uint32_t ref_cap = 4u << 20;
+        CK(hipMalloc(&ref_d, (size_t)ref_cap * 8)); CK(hipMalloc(&ref_n, 4)); CK(hipMemset(ref_n, 0, 4));
+        hipLaunchKernelGGL(k_ref, dim3((n + 63) / 64), dim3(256), 0, 0, b.V, D, D, n, b.Qp, nq, b.Ti, ref_d, ref_n, ref_cap);
+        CK(hipDeviceSynchronize());
+        uint32_t rn; CK(hipMemcpy(&rn, ref_n, 4, hipMemcpyDeviceToHost));
+        std::vector<uint64_t> ref(std::min(rn, ref_cap));
+        CK(hipMemcpy(ref.data(), ref_d, ref.size() * 8, hipMemcpyDeviceToHost));
+        std::sort(ref.begin(), ref.end());
+        CK(hipFree(ref_d)); CK(hipFree(ref_n));
+        for (size_t vi = 0; vi < vars.size(); ++vi) {
+            const Variant& v = vars[vi];
+            if (v.name.find('|') != std::string::npos) continue;
+            for (int starve = 0; starve < 2; ++starve) {
+                ScanArgs a = base_args(b, 0, n, nq);
+                const uint32_t tiles = v.qs ? (n + 31) / 32 : (n + 255) / 256;   // (an upper bound of the grid is enough for nseg)
+                const uint32_t grid = std::min(tiles, ncu);
+                a.nseg = grid * v.segs_per_wg;
+                a.seg = starve ? 2u : std::min<uint32_t>(255u, SEG_KEYS / a.nseg);
+                clear(a.nseg);
+                v.launch(a, ncu, 0);
+                CK(hipDeviceSynchronize());
+                std::vector<uint64_t> got = collect(b, nq, a.nseg, a.seg);
+                const bool ok = got == ref;
+                if (!ok) {
+                    ++bad;
+                    printf("MISMATCH pass %d %-34s starve %d: ref %zu keys, got %zu\n", pass, v.name.c_str(), starve, ref.size(), got.size());
+                    size_t i = 0;
+                    while (i < ref.size() && i < got.size() && ref[i] == got[i]) ++i;
+                    if (i < ref.size()) printf("   first difference at %zu: ref q %u row %u", i, (unsigned)(ref[i] >> 48) , (unsigned)(ref[i] & 0xffffffffu));
+                    if (i < got.size()) printf("  got q %u row %u", (unsigned)(got[i] >> 48), (unsigned)(got[i] & 0xffffffffu));
+                    printf("\n");
+                }
+            }
+        }
+        printf("check pass %d: n %u nq %u sigma %.1f -> %zu reference keys; mismatching variants so far %d\n", pass, n, nq, sig, ref.size(), bad);
+    }
+
+    // ---- 2. timing
+    for (double sig : {sigma_tight, sigma_loose}) {
+        set_thr(sig, NQ);
+        const uint32_t n = (uint32_t)n_big;
+        std::vector<std::vector<float>> ms(vars.size());
+        std::vector<double> clk(vars.size(), 0.0), watts(vars.size(), 0.0), smhz(vars.size(), 0.0);
+        hipEvent_t e0, e1;
+        CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+        for (int r = 0; r < rounds + 1; ++r) {
+            for (size_t vi = 0; vi < vars.size(); ++vi) {
+                if (only >= 0 && (int)vi != only) continue;
+                const Variant& v = vars[vi];
+                ScanArgs a = base_args(b, 0, n, NQ);
+                a.nseg = ncu * v.segs_per_wg;
+                a.seg = std::min<uint32_t>(255u, SEG_KEYS / a.nseg);
+                a.debug_flags = 64; a.dbg = b.dbg;
+                const int reps = long_reps;
+                for (int w = 0; w < long_warm; ++w) { if (w < 2) clear(a.nseg); v.launch(a, ncu, 0); }   // warm: clocks / power settle under THIS variant
+                clear(a.nseg);
+                CK(hipDeviceSynchronize());
+                const auto w0 = std::chrono::system_clock::now();
+                sampler.begin();
+                CK(hipEventRecord(e0, 0));
+                for (int i = 0; i < reps; ++i) v.launch(a, ncu, 0);
+                CK(hipEventRecord(e1, 0));
+                CK(hipEventSynchronize(e1));
+                const auto w1 = std::chrono::system_clock::now();
+                { double pw, mz; sampler.end(&pw, &mz); if (r == rounds) { watts[vi] = pw; smhz[vi] = mz; } }
+                float t; CK(hipEventElapsedTime(&t, e0, e1));
+                if (r > 0) ms[vi].push_back(t / reps);
+                if (v.qs) {
+                    unsigned long long tk[2];
+                    CK(hipMemcpy(tk, b.dbg, 16, hipMemcpyDeviceToHost));
+                    clk[vi] = (double)(tk[1] - tk[0]) / (t / reps * 1e3);   // ticks per microsecond = MHz (kernel span of workgroup 0 ~ launch)
+                }
+                if (r == rounds && v.name.find("phase timing") != std::string::npos) {
+                    std::vector<unsigned long long> ph(64 * 8 * 4);
+                    CK(hipMemcpy(ph.data(), b.dbg + 512, ph.size() * 8, hipMemcpyDeviceToHost));
+                    printf("PHASE %s\n", v.name.c_str());
+                    for (int blk : {0, 17}) {
+                        for (int w = 0; w < 8; ++w) {
+                            const unsigned long long* o = ph.data() + ((size_t)blk * 8 + w) * 4;
+                            const double tot = (double)(o[0] + o[1] + o[2] + o[3]);
+                            printf("PHASE block %2d wave %d: wait %5.1f%% barrier %5.1f%% loop %5.1f%% epilogue %5.1f%%  (%.0f cycles, %.0f per step)\n", blk, w,
+                                   100.0 * o[0] / tot, 100.0 * o[1] / tot, 100.0 * o[2] / tot, 100.0 * o[3] / tot, tot, tot / ((double)((n + 31) / 32) / ncu));
+                        }
+                    }
+                }
+                if (r == rounds)
+                    printf("STAMP %-44s %.6f %.6f\n", v.name.c_str(), std::chrono::duration<double>(w0.time_since_epoch()).count(),
+                           std::chrono::duration<double>(w1.time_since_epoch()).count());
+            }
+        }
+        printf("---- %u rows x %u B, %u queries, thresholds at %.1f sd: us per launch (median / min of %d rounds), TB/s of codes, s_memtime MHz\n",
+               n, D, NQ, sig, rounds);
+        for (size_t vi = 0; vi < vars.size(); ++vi) {
+            if (ms[vi].empty()) continue;
+            std::sort(ms[vi].begin(), ms[vi].end());
+            const double med = ms[vi][ms[vi].size() / 2] * 1e3, mn = ms[vi][0] * 1e3;
+            printf("%-46s %8.1f %8.1f   %5.2f TB/s   %6.0f MHz   hwmon %6.0f W %6.0f MHz\n", vars[vi].name.c_str(), med, mn, (double)n * D / med / 1e6, clk[vi], watts[vi], smhz[vi]);
+        }
+    }
+    sampler.finish();
+    printf("mismatches: %d\n", bad);
+    return bad ? 1 : 0;
+}

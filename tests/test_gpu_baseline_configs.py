@@ -64,16 +64,22 @@ def test_c2_flat_ip_768_batch256_runs_the_benchmarked_kernels(L, oracle):
     flags, stages, tiling = plan_fields(p)
     assert p["fallback_queries"] == 0
     assert p["scan_launches"] == 3 and stages == 3, p
-    assert tiling == 0x24, hex(tiling)
+    assert tiling == 0x81, hex(tiling)      # the threshold stages ran the query-stationary tiling (k_scan_qs, scan_qs.h)
     assert flags & PLAN_SAMPLED and flags & PLAN_THRESHOLD_ONLY and flags & PLAN_I8C and flags & PLAN_SEGMENTS, bin(flags)
     assert not (flags & PLAN_FUSED_SAMPLE), bin(flags)
+    # the full ranking of the default run against the oracle's exact_flat_search (ids + f32 distance bits), wave boundaries included
+    for qi in (0, 1, 31, 32, 63, 64, 100, 128, 200, 255):
+        assert_rows_equal(oracle.canonical_topk(queries[qi], data, k, O.IP), rows[qi], dists[qi], counts[qi], ("c2", qi))
+        assert rows[qi, 0] == q_rows[qi]
     # the same batch (a) with the sample stage INSIDE the launch of the first threshold stage (k_scan_h16<.., FS>: grid-wide
     # threshold hand-over; off by default — measured slower than the two launches) and (b) on the three separate tail kernels
     # instead of k_select_final, and (c) with the threshold stages on the one-wave-per-SIMD tiling (4 waves x 4 x 4 blocks,
     # accumulators in fixed AGPR tuples, the last k-step's MFMAs deferred behind the next slab's barrier; off by default —
     # measured 11 % slower): identical bits
     import os
-    for env, launches, fused in (({"LYNSE_HIP_FUSED_SAMPLE": "1"}, 2, True), ({"LYNSE_HIP_FUSED_TAIL": "0"}, 3, False), ({"LYNSE_HIP_AG": "1"}, 3, False)):
+    # ... and (d) with the threshold stages on the 256 x 256 tile of k_scan_h16 (LYNSE_HIP_QS=0: the round-3 default)
+    for env, launches, fused in (({"LYNSE_HIP_FUSED_SAMPLE": "1"}, 2, True), ({"LYNSE_HIP_FUSED_TAIL": "0"}, 3, False), ({"LYNSE_HIP_AG": "1"}, 3, False),
+                                 ({"LYNSE_HIP_QS": "0"}, 3, False)):
         os.environ.update(env)
         try:
             r_u, d_u, c_u = idx.search_batch_arrays(queries, k, "ip")
@@ -82,6 +88,8 @@ def test_c2_flat_ip_768_batch256_runs_the_benchmarked_kernels(L, oracle):
             for name in env:
                 del os.environ[name]
         assert p_u["scan_launches"] == launches and bool(plan_fields(p_u)[0] & PLAN_FUSED_SAMPLE) == fused and p_u["fallback_queries"] == 0, p_u
+        if "LYNSE_HIP_QS" in env:
+            assert plan_fields(p_u)[2] == 0x24, hex(plan_fields(p_u)[2])
         assert np.array_equal(r_u, rows) and np.array_equal(d_u.view(np.uint32), dists.view(np.uint32)) and np.array_equal(c_u, counts)
     # other batch sizes give the same answers: 40 queries (same kernels, mostly empty query columns) and 8 queries
     # (the <= 32-query tiling; from 256K rows on it streams the SQ8 codes too)
