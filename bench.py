@@ -61,6 +61,7 @@ def parse_args():
     p.add_argument("--profile-every", type=int, default=4, help="HIP-event timing of the scan launches on every n-th step of the timed region")
     p.add_argument("--settle-ms", type=float, default=60.0, help="untimed steps before the warm-up until the GPU's clocks have settled (0 = none)")
     p.add_argument("--no-configs", action="store_true", help="skip the extra keys: the other BASELINE configurations and the second data distribution")
+    p.add_argument("--launch-timeout", type=float, default=1500.0, help="--gpus N without a launcher: seconds the self-started N-rank run may take")
     p.add_argument("--in-flight", type=int, default=int(os.environ.get("LYNSE_BENCH_IN_FLIGHT", "0")),
                    help="batches in flight (lynse_hip_flat_search_submit_* / _wait): step i+1 is enqueued before step i is waited "
                         "for; 1 = the blocking entry points (one host round trip per step); 0 = default: 1 on one GPU (the "
@@ -75,8 +76,37 @@ def gen_block(block: int, rows_in_block: int, dim: int, seed: int, device) -> to
     return torch.rand((rows_in_block, dim), generator=g, device=device, dtype=torch.float32)
 
 
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` without a launcher: start N ranks with torch.distributed.run on 127.0.0.1 and pass their
+    output through (rank 0 prints the JSON line).  A rank that dies takes the others down with it (torchrun's agent kills the
+    remaining workers), and the whole run is bounded by --launch-timeout: a hang ends with a JSON error line and a non-zero exit
+    code instead of a silent stall (the fan-out this replaces: src/cluster.rs:173-217)."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    try:
+        rc = subprocess.run(cmd, env=env, timeout=args.launch_timeout).returncode
+    except subprocess.TimeoutExpired:
+        rc = 124
+    if rc != 0:
+        print(json.dumps({"metric": "queries/sec, FLAT-%s %dx%d float32, batch=%d, k=%d" % (args.metric.upper(), args.rows, args.dim, args.batch, args.k),
+                          "value": None, "n_gpus": args.gpus, "error": "the %d-rank run ended with exit code %d%s" % (
+                              args.gpus, rc, " (launch timeout %.0f s)" % args.launch_timeout if rc == 124 else "")}), flush=True)
+    return rc
+
+
 def main():
     args = parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(self_launch(args))
     # ONE JSON line on stdout: everything else that writes to fd 1 during the run (RCCL prints a version / host banner when
     # its first communicator is created) goes to stderr instead; the result line is written to the saved descriptor.
     sys.stdout.flush()
@@ -86,8 +116,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        raise SystemExit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
     local_rank %= torch.cuda.device_count()  # (a 1-GPU box can still smoke-test the N>1 code path with LYNSE_BENCH_BACKEND=gloo)
@@ -117,6 +146,12 @@ def main():
     native = False
     if world > 1 and os.environ.get("LYNSE_BENCH_EXCHANGE", "native") == "native" and (dist is None or dist.get_backend() == "nccl"):
         native = sh.enable_native_comm()   # RCCL inside the library; falls back to torch.distributed's all-gather
+        if sh.ranks_seen is not None and sh.ranks_seen != world:   # a communicator that does not span the job: no number is better than a wrong one
+            if rank == 0:
+                result_out.write(json.dumps({"metric": "queries/sec", "value": None, "n_gpus": world,
+                                             "error": "the RCCL communicator saw %s of %d ranks (%s)" % (sh.ranks_seen, world, sh.comm_error)}) + "\n")
+                result_out.flush()
+            raise SystemExit(3)
     if world == 1 and os.environ.get("LYNSE_BENCH_FORCE_COMM") == "1":
         # one GPU, but the batches in flight go through a 1-rank RCCL communicator: the exchange half of a sharded step
         # (status word in the result block, event hand-over to the exchange stream, merge kernel) without the all-gather

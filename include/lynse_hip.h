@@ -45,7 +45,8 @@ enum {
     LYNSE_ERR_DEVICE = 6,
     LYNSE_ERR_INTERNAL = 7,
     LYNSE_ERR_INDEX_NOT_BUILT = 8,
-    LYNSE_ERR_UNSUPPORTED = 9
+    LYNSE_ERR_UNSUPPORTED = 9,
+    LYNSE_ERR_TIMEOUT = 10 /* lynse_hip_flat_search_wait: the batch did not finish within the wait timeout (a peer rank is gone) */
 };
 
 /* Metric ids — DistanceMetric (src/distance/mod.rs:19-36), in-scope subset. */
@@ -387,6 +388,12 @@ int lynse_hip_flat_search_submit_packed_u64_device(lynse_hip_flat *h, lynse_hip_
                                                    uint64_t *d_out_rows, float *d_out_dists, uint32_t *d_out_counts,
                                                    lynse_hip_ticket **out);
 int lynse_hip_flat_search_wait(lynse_hip_ticket *t);
+/* Upper bound of one lynse_hip_flat_search_wait in milliseconds, process-wide.  0 (default): tickets of ONE shard wait without a
+ * limit, tickets that end in a collective (submitted with a communicator) give up after 30 s — a rank that died inside the
+ * exchange would otherwise hang its peers forever (the reference's scatter-gather times its shard calls out the same way,
+ * src/cluster.rs:173-217).  On expiry wait returns LYNSE_ERR_TIMEOUT; the ticket is freed, its context is NOT reused (the device
+ * may still be writing into it).  LYNSE_HIP_WAIT_TIMEOUT_MS sets the initial value. */
+int lynse_hip_set_wait_timeout_ms(uint32_t ms);
 
 /* ---- shard-node glue around a search (host only, no device work) ---- */
 

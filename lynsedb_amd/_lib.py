@@ -22,7 +22,7 @@ LIB_PATH = _HERE / "liblynse_hip.so"
 
 OK = 0
 ERR_INVALID_ARGUMENT, ERR_DIMENSION_MISMATCH, ERR_UNKNOWN_METRIC, ERR_NOT_FINALIZED = 1, 2, 3, 4
-ERR_OUT_OF_MEMORY, ERR_DEVICE, ERR_INTERNAL, ERR_INDEX_NOT_BUILT, ERR_UNSUPPORTED = 5, 6, 7, 8, 9
+ERR_OUT_OF_MEMORY, ERR_DEVICE, ERR_INTERNAL, ERR_INDEX_NOT_BUILT, ERR_UNSUPPORTED, ERR_TIMEOUT = 5, 6, 7, 8, 9, 10
 
 METRIC_IP, METRIC_L2, METRIC_COSINE, METRIC_HAMMING, METRIC_JACCARD, METRIC_DICE, METRIC_TANIMOTO = range(7)
 IPFORM_AUTO, IPFORM_SINGLE, IPFORM_BATCH8 = 0, 1, 2
@@ -126,6 +126,7 @@ SIGNATURES = {
     "lynse_hip_flat_search_submit_f32_device": (C.c_int, [_vp, _vp, _vp, C.c_uint64, C.c_uint32, C.c_int, _vp, _vp, _vp, C.POINTER(_vp)]),
     "lynse_hip_flat_search_submit_packed_u64_device": (C.c_int, [_vp, _vp, _vp, C.c_uint64, C.c_uint32, C.c_int, _vp, _vp, _vp, C.POINTER(_vp)]),
     "lynse_hip_flat_search_wait": (C.c_int, [_vp]),
+    "lynse_hip_set_wait_timeout_ms": (C.c_int, [C.c_uint32]),
 }
 
 if not LIB_PATH.exists():
@@ -170,6 +171,8 @@ def check(code: int) -> None:
         raise MemoryError(msg)
     if code == ERR_UNSUPPORTED:
         raise LynseUnsupportedError(code, msg)
+    if code == ERR_TIMEOUT:
+        raise TimeoutError(msg)
     raise LynseHipError(code, msg)
 
 

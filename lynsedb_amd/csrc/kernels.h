@@ -530,6 +530,16 @@ struct ScanArgs {
     float* thr_out;           // = thr (written by the select of the fused sample)
     uint32_t k;
     int ip_form, metric;
+    // Self-tightening thresholds of the query-stationary scan (k_scan_qs<.., STS>, scan_qs.h): per query dyn_ks running maxima
+    // of the coarse integer dot product over DISJOINT row partitions (partition of a row = its tile index % dyn_ks) and their
+    // minimum dyn_thr — at least dyn_ks distinct rows reach it, so with dyn_ks = k every row below dyn_thr - dyn_marg (the
+    // certified margin 2E in dot units) is out of the top-k whatever the scan has seen so far.  Seeded by k_i8c_prep_queries.
+    int* dyn_thr;          // [nq]
+    int* dyn_slot;         // [nq][32]
+    const int* dyn_marg;   // [nq]
+    uint32_t dyn_ks;
+    uint32_t dyn_warm;     // tiles per workgroup scanned first WITHOUT emission (they only feed the maxima) and again at the end
+    uint32_t dyn_pitch;    // tiles per workgroup (workgroup b owns tiles [b * dyn_pitch, +dyn_pitch)); coprime to dyn_ks
 };
 
 struct IvfTile {
@@ -2501,11 +2511,19 @@ struct I8cPrepArgs {
     // distances (neg_metric1).  E = the IP bound over the unit vectors + 9 (D + 8) 2^-24 for the f32 normalisation of the rows
     // and the reference's own dot / norm sums.
     int cosine;
+    // Seeding of the self-tightening scan (ScanArgs::dyn_*; dyn_thr == nullptr: off): the integer dot products of this query's
+    // image with seed_rows sample rows of the shard (spread over the tiles of every partition) give the first partition
+    // maxima; dyn_marg = the margin 2E (+ the float evaluation error of B_q + s_q dot on both sides) in dot units, rounded up.
+    const int8_t* codes;   // the rows the scan streams: [n_rows][ld8] signed SQ8 codes
+    uint32_t ld8, n_rows, tile_rows, dyn_ks, seed_rows;
+    int *dyn_thr, *dyn_slot, *dyn_marg;
 };
 
 __global__ void __launch_bounds__(256) k_i8c_prep_queries(I8cPrepArgs a) {
     __shared__ double red[5][4];
     __shared__ float s_sq;
+    __shared__ int s_slot[32];
+    extern __shared__ __attribute__((aligned(16))) int8_t s_u[];   // seeding only: the query's plain int8 image (nslab * 128 bytes)
     const uint32_t q = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* qv = a.Q + (size_t)q * a.D;
@@ -2584,6 +2602,14 @@ __global__ void __launch_bounds__(256) k_i8c_prep_queries(I8cPrepArgs a) {
         a.count[q] = 0u;
         a.overflow[q] = 0u;
         if (q == 0 && a.gsync) { a.gsync[0] = 0u; a.gsync[1] = 0u; a.gsync[2] = 0u; }
+        if (a.dyn_thr) {
+            // rows that can still matter have coarse_f(dot) >= coarse_f(tau) - 2E; coarse_f = fl(B_q + fl(s_q fl(dot))) is within
+            // delta of B_q + s_q dot, so s_q M > 2E + 2 delta makes every dot < tau - M fail that test
+            const double delta = 2.4e-7 * (fabs(bq) + 127.0 * (double)sq * a1);
+            double md = ceil((2.0 * E + 2.0 * delta) / (double)sq) + 1.0;
+            if (!(md < 1073741824.0)) md = 1073741824.0;
+            a.dyn_marg[q] = (int)md;
+        }
     }
     __syncthreads();
     const double inv = 1.0 / (double)s_sq;
@@ -2599,6 +2625,48 @@ __global__ void __launch_bounds__(256) k_i8c_prep_queries(I8cPrepArgs a) {
         }
         const uint32_t s = i / 128, k = i % 128, l = k >> 4, e = k & 15, p = l ^ ((q >> 1) & 7);
         a.img[(((size_t)s * a.qpad + q) * 8 + p) * 16 + e] = (int8_t)u;
+        if (a.dyn_thr) s_u[i] = (int8_t)u;
+    }
+    if (a.dyn_thr) {
+        // ---- first partition maxima: sample i belongs to partition i % ks and sits in a tile of that residue class, the classes'
+        // tiles visited with an even stride
+        const uint32_t ks = a.dyn_ks, rt = a.tile_rows;
+        const uint32_t ntiles = (a.n_rows + rt - 1) / rt;
+        if (tid < 32) s_slot[tid] = -2147483647 - 1;
+        __syncthreads();
+        const uint32_t per = a.seed_rows / ks;                       // samples per partition
+        for (uint32_t i = tid; i < per * ks; i += 256) {
+            const uint32_t p = i % ks, m = i / ks;
+            const uint32_t up = (ntiles > p) ? (ntiles - p + ks - 1) / ks : 0u;   // tiles of residue p
+            if (!up) continue;
+            const uint32_t u_idx = (uint32_t)(((uint64_t)m * up) / per);          // even spread over the class
+            uint64_t row = (uint64_t)(p + ks * u_idx) * rt + (i * 7u) % rt;
+            if (row >= a.n_rows) row = (uint64_t)(p + ks * u_idx) * rt;           // (a ragged last tile: its first row exists)
+            const int8_t* src = a.codes + row * a.ld8;
+            int dot = 0;
+            const uint32_t nb = a.nslab * 128;
+            for (uint32_t d = 0; d < nb && d < a.ld8; d += 16) {
+                typedef int i32x4_t __attribute__((ext_vector_type(4)));
+                const i32x4_t c = *reinterpret_cast<const i32x4_t*>(src + d);
+                const i32x4_t w = *reinterpret_cast<const i32x4_t*>(s_u + d);
+#if defined(__HIP_DEVICE_COMPILE__)
+                dot = __builtin_amdgcn_sdot4(c[0], w[0], dot, false);
+                dot = __builtin_amdgcn_sdot4(c[1], w[1], dot, false);
+                dot = __builtin_amdgcn_sdot4(c[2], w[2], dot, false);
+                dot = __builtin_amdgcn_sdot4(c[3], w[3], dot, false);
+#else
+                (void)c; (void)w;
+#endif
+            }
+            atomicMax(&s_slot[p], dot);
+        }
+        __syncthreads();
+        if (tid < 32) a.dyn_slot[(size_t)q * 32 + tid] = tid < (int)ks ? s_slot[tid] : 2147483647;
+        if (tid == 0) {
+            int mn = 2147483647;
+            for (uint32_t j = 0; j < ks; ++j) mn = s_slot[j] < mn ? s_slot[j] : mn;
+            a.dyn_thr[q] = mn;
+        }
     }
 }
 

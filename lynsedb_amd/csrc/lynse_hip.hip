@@ -8,6 +8,7 @@
 //     -> exact_flat_search / packed_binary_search (:1173-1230, :1345-1409) -> simd kernels.
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -16,6 +17,7 @@
 #include <mutex>
 #include <shared_mutex>
 #include <string>
+#include <thread>
 #include <type_traits>
 #include <vector>
 
@@ -183,6 +185,7 @@ struct Workspace {
     uint8_t* h_out = nullptr;        // pinned staging for small host-API results (rows then dists), H_OUT_BYTES
     unsigned long long* pool_total = nullptr;
     uint32_t* gsync = nullptr;        // hand-over words of the fused sample stage (ScanArgs::gsync)
+    int* dyn = nullptr;               // self-tightening scan (ScanArgs::dyn_*): [qcap] tau, [qcap] margin, [qcap][32] partition maxima
     uint64_t* small_part = nullptr;   // k_small_search: [workgroups][SMALL_MAX_Q][SMALL_MAX_K] keys
     uint32_t* small_ticket = nullptr;
     void release() {
@@ -190,7 +193,7 @@ struct Workspace {
         if (h_out) (void)hipHostFree(h_out);
         for (void* p : {(void*)cand, (void*)candB, (void*)segcnt, (void*)count, (void*)thr, (void*)qinv, (void*)qn2,
                         (void*)qrinv, (void*)marg2, (void*)Q16, (void*)Qf, (void*)QW, (void*)QWp, (void*)out_rows,
-                        (void*)out_dists, (void*)out_counts, (void*)pool_total, (void*)small_part, (void*)small_ticket, (void*)gsync})
+                        (void*)out_dists, (void*)out_counts, (void*)pool_total, (void*)small_part, (void*)small_ticket, (void*)gsync, (void*)dyn})
             if (p) (void)hipFree(p);
         *this = Workspace();
     }
@@ -592,13 +595,7 @@ static int append_f32_impl(lynse_hip_flat* h, const float* src, uint64_t n, hipM
         }
         (void)hipFree(stage);
     }
-    if (h->dtype == LYNSE_DTYPE_F16) {  // what the F16 segment file keeps of these rows
-        const uint64_t total = n * h->dim;
-        hipLaunchKernelGGL(k_round_rows_f16, dim3((uint32_t)std::min<uint64_t>((total + 255) / 256, (uint64_t)h->num_cu * 32)), dim3(256), 0,
-                           cur(h).stream, h->rows, h->ld, h->dim, h->n, h->n + n);
-        LY_HIP(hipGetLastError());
-    }
-    LY_HIP(hipStreamSynchronize(cur(h).stream));
+    LY_HIP(hipStreamSynchronize(cur(h).stream));   // (F16 shards returned above: they keep their rows as f16 bits only)
     h->n += n;
     return LYNSE_OK;
 }
@@ -965,6 +962,7 @@ static int ensure_workspace(lynse_hip_flat* h, uint32_t k /* caller's k = output
     LY_HIP(hipHostMalloc(&w.h_out, H_OUT_BYTES, hipHostMallocDefault));
     LY_HIP(hipMalloc(&w.pool_total, 8));
     LY_TRY(memset_done(w.pool_total, 0, 8));
+    LY_HIP(hipMalloc(&w.dyn, (size_t)QC * 34 * sizeof(int)));
     LY_HIP(hipMalloc(&w.gsync, 256 + 1024 * 64));   // hand-over words + (debugging) 8 time stamps per workgroup / per (stage, query)
     LY_TRY(memset_done(w.gsync, 0, 256 + 1024 * 64));
     LY_HIP(hipMalloc(&w.small_part, (size_t)SMALL_NT * SMALL_MAX_Q * SMALL_MAX_K * 8));
@@ -1379,15 +1377,41 @@ static int launch_scan_i8c_mid(const ScanArgs& a, uint32_t grid, hipStream_t st,
 // ping-pong roles; 2 = 32-row tiles, 6-stage ring, fragments prefetched across the barrier; 3 = as 1 without the ping-pong roles.
 static int qs_variant() { const char* e = getenv("LYNSE_HIP_QS"); return e ? atoi(e) : 1; }
 static uint32_t qs_rows(int v) { return v == 2 ? 32u : 64u; }   // rows per tile
+// Self-tightening single-launch scan (scan_qs.h, STS; LYNSE_HIP_STS=1 — OFF by default): unfiltered FLAT batches of 129..256 queries on
+// the certified int8 pass (IP, cosine) over whole 768-byte code rows, k <= 32 (one partition maximum per wanted neighbour), shards
+// large enough that every workgroup helper covers a query (8 grid >= nq) — first plan level only, the overflow ladder keeps the
+// staged plans.  Bit-identical results (tests), and MEASURED no faster than the staged plan it replaces (MI355X, 10M x 768 x 256,
+// scripts/qs_microbench.hip at the margin the benchmark data has, 2E = 0.76 sd of the scores): one launch 1986 us + query image +
+// final select against 37 + 31 + ~1880 + 31 us of sample stage, selects and threshold stages.  Without the exact-rescored
+// threshold the selects of the staged plan compute (tau_x - E instead of tau - 2E) the band of rows that must be kept is ~5x wider:
+// ~4800 keys per query are emitted (10,000 for the unluckiest query; the cap is 16,384 — 6 of 256 queries of the C2 test overflowed
+// and went down the ladder), 15-20 % of all tile epilogues take the slow path.
+static bool sts_env_on() { const char* e = getenv("LYNSE_HIP_STS"); return e && atoi(e) != 0; }
 static bool qs_scan_ok(const ScanArgs& a, bool fs, bool filt, bool f4) {
     const int v = qs_variant();
     if (v < 1 || v > 3) return false;
     return !fs && !filt && !f4 && a.emit_all == 0 && a.ld16 == 768 && a.nslab == 6 && a.qpad == 256 && a.nq <= 256 && a.tile_stride == 0 &&
            a.skip_stride == 0 && !a.mask && !a.row_ids && a.row1 > a.row0;
 }
-static uint32_t qs_grid(const ScanArgs& a, uint32_t num_cu) { const uint32_t rt = qs_rows(qs_variant()); return std::min<uint32_t>((a.row1 - a.row0 + rt - 1) / rt, num_cu); }
+// LYNSE_HIP_SCAN_CUS: workgroups (= CUs: one 144-KB workgroup per CU) of the persistent threshold-stage scans.  The scan is bound by the
+// power the chip may draw, not by its CU count: a few CUs left free cost it little and let the short latency-bound kernels of ANOTHER
+// batch in flight (query image, sample stage, selects, final rescoring) run beside it instead of between its launches.
+static uint32_t qs_grid(const ScanArgs& a, uint32_t num_cu) {
+    const uint32_t rt = qs_rows(qs_variant());
+    const char* e = getenv("LYNSE_HIP_SCAN_CUS");
+    const uint32_t cus = e && atoi(e) > 0 ? std::min<uint32_t>((uint32_t)atoi(e), num_cu) : num_cu;
+    return std::min<uint32_t>((a.row1 - a.row0 + rt - 1) / rt, cus);
+}
 static int launch_scan_qs(const ScanArgs& a, uint32_t grid, hipStream_t st) {
-    static bool attr_done[4] = {false, false, false, false};
+    static bool attr_done[5] = {false, false, false, false, false};
+    if (a.dyn_thr) {   // self-tightening thresholds: the whole shard in one launch (scan_qs.h, STS)
+        auto kern = k_scan_qs<6, 2, 6, 3, false, 8, 0, 0, 1>;
+        constexpr size_t lds = (size_t)3 * 6 * 64 * 128 + QS_STS_LDS;
+        if (!attr_done[4]) { LY_TRY(set_max_lds(kern, lds)); attr_done[4] = true; }
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, a);
+        LY_HIP(hipGetLastError());
+        return LYNSE_OK;
+    }
     auto go = [&](auto kern, int slot, size_t lds) -> int {
         if (!attr_done[slot]) { LY_TRY(set_max_lds(kern, lds)); attr_done[slot] = true; }
         hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, a);
@@ -1613,7 +1637,9 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
                      size_t* ev_used, std::vector<std::pair<size_t, uint64_t>>* scan_events, bool* sampled_plan,
                      const uint32_t* mask = nullptr, const uint32_t* row_ids = nullptr, bool i8c = false,
                      uint64_t* r_dst = nullptr, float* d_dst = nullptr, uint32_t* c2_dst = nullptr, uint32_t* any_ovf = nullptr,
-                     const float* qsrc = nullptr, bool hdr_direct = false) {
+                     const float* qsrc = nullptr, bool hdr_direct = false, bool allow_sts = true, bool* used_sts = nullptr) {
+    // allow_sts / used_sts: the self-tightening single-launch scan may answer this chunk / did (an overflow of it is retried on the
+    // staged plan of the same coarse pass, without a strike)
     // qsrc: the float queries of the chunk when they already live in device memory that stays valid for the whole search (no
     // staging copy into the workspace); nullptr = w.Qf.  hdr_direct: k_final writes counts + overflow flags straight into the
     // pinned header of the context (no copy kernel behind the search)
@@ -1662,6 +1688,11 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
         sel_attr = true;
     }
 
+    const uint32_t sts_ld8 = cosq ? h->ld8 : h->ld8;
+    const bool sts = allow_sts && sts_env_on() && level == 0 && i8c && !bin_mfma && !aug && !l2n && !small && !mid64 && !mid128 && !mask && !row_ids && h16 &&
+                     k >= 1 && k <= 32 && qs_variant() >= 1 && qs_variant() <= 3 && sts_ld8 == 768 && nslab == 6 && qpad == 256 && h->n >= 65536 &&
+                     h->n < 0xffffff00ull && (metric == M_IP || cosq);
+    if (used_sts) *used_sts = sts;
     if (bin_mfma) {
         if (nq != qpad) LY_HIP(hipMemsetAsync(w.Q16, 0, (size_t)nslab * qpad * 128, st));   // (the prep kernel writes every byte of its queries' lines, pad columns included)
         BpmPrepArgs p{};
@@ -1684,7 +1715,12 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
         p.a1 = aug ? h->sq8a_a1 : (cosq ? h->sq8c_a1 : h->sq8_a1); p.vmax = h->vmax; p.cosine = cosq ? 1 : 0; p.img = reinterpret_cast<int8_t*>(w.Q16); p.aug = aug ? (int)h->aug_cols : 0; p.l2n = l2n ? 1 : 0;
         p.sq = w.qinv; p.bq = w.qn2; p.marg2 = w.marg2; p.thr = w.thr; p.count = w.count; p.overflow = w.overflow;
         p.gsync = w.gsync;
-        hipLaunchKernelGGL(k_i8c_prep_queries, dim3(nq), dim3(256), 0, st, p);
+        if (sts) {   // seed the partition maxima of the self-tightening scan from a few sample rows (valid thresholds from the first tile on)
+            p.codes = cosq ? h->sq8c : h->sq8; p.ld8 = sts_ld8; p.n_rows = (uint32_t)h->n; p.tile_rows = 64; p.dyn_ks = k;
+            p.seed_rows = std::min<uint32_t>(1024u, 32u * k);
+            p.dyn_thr = w.dyn; p.dyn_marg = w.dyn + w.qcap; p.dyn_slot = w.dyn + 2 * (size_t)w.qcap;
+        }
+        hipLaunchKernelGGL(k_i8c_prep_queries, dim3(nq), dim3(256), sts ? (size_t)nslab * 128 : 0, st, p);
         LY_HIP(hipGetLastError());
     } else {
         // queries with index >= nq inside the padded tile must be finite: zero the image
@@ -1717,7 +1753,8 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
     // sample tile; up to k = 128 the sample as a whole supplies >= 8 k keys — a clustered shard may then overflow the first
     // stage and fall back to the contiguous plan)
     const bool can_threshold_only = h16 && !binary && !filt && !no_lane_max0 && k <= 128;
-    const std::vector<Stage> plan = make_plan(h, k, (level == 0 && (!plan_tile || no_sample)) ? 1 : level, plan_tile, can_threshold_only);
+    const std::vector<Stage> plan = sts ? std::vector<Stage>{Stage{0u, (uint32_t)h->n}}
+                                        : make_plan(h, k, (level == 0 && (!plan_tile || no_sample)) ? 1 : level, plan_tile, can_threshold_only);
     const Stage sample = (!plan.empty() && plan[0].sample_tiles) ? plan[0] : Stage{0, 0};
     *sampled_plan = sample.sample_tiles != 0;
     // sampled plan: the sample stage only has to produce a threshold -> one key per lane (its best row) instead of every
@@ -1748,7 +1785,7 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
     SelectArgs sa_last{};
     for (size_t si = 0; si < plan.size(); ++si) {
         const Stage s = plan[si];
-        const bool emit_all = si == 0;
+        const bool emit_all = si == 0 && !sts;   // (sts: the one stage is a threshold stage — its thresholds live in w.dyn and tighten while it runs)
         if (fs && si == 0) continue;   // scored inside the launch of stage 1
         const bool fs_stage = fs && si == 1;
         hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -1848,8 +1885,20 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
                 a.dense = (!a.emit_all && a.ld16 % 128 == 0 && seen_before &&
                            (filt || (dense_env >= 0 ? dense_env != 0 : (uint64_t)k * 50000ull > seen_before))) ? 1 : 0;   // (masked: DENSE is the one epilogue compiled with the mask)
                 const bool ag = getenv("LYNSE_HIP_AG") && atoi(getenv("LYNSE_HIP_AG")) && a.ld16 % 128 == 0 && !a.emit_all && !fs_stage && !filt && !bin_mfma;
-                const bool qs = !ag && qs_scan_ok(a, fs_stage, filt, bin_mfma);   // the query-stationary tiling (scan_qs.h): two segments per workgroup and query
-                const uint32_t launch_grid = qs ? qs_grid(a, (uint32_t)h->num_cu) : grid;
+                if (sts) {
+                    a.dyn_thr = w.dyn; a.dyn_marg = w.dyn + w.qcap; a.dyn_slot = w.dyn + 2 * (size_t)w.qcap; a.dyn_ks = k;
+                    a.dyn_warm = h->n >= 4000000ull ? 4u : 2u;   // tiles per workgroup that only feed the maxima first (scanned again at the end)
+                }
+                const bool qs = sts || (!ag && qs_scan_ok(a, fs_stage, filt, bin_mfma));   // the query-stationary tiling (scan_qs.h): two segments per workgroup and query
+                uint32_t launch_grid = qs ? qs_grid(a, (uint32_t)h->num_cu) : grid;
+                if (sts) {   // contiguous chunks of dyn_pitch tiles per workgroup; the pitch coprime to the partition count (scan_qs.h)
+                    const uint32_t nt = (a.row1 - a.row0 + 63) / 64;
+                    uint32_t pitch = (nt + launch_grid - 1) / launch_grid;
+                    auto gcd = [](uint32_t x, uint32_t y) { while (y) { const uint32_t t = x % y; x = y; y = t; } return x; };
+                    while (gcd(pitch, k) != 1) ++pitch;
+                    a.dyn_pitch = pitch;
+                    launch_grid = (nt + pitch - 1) / pitch;
+                }
                 if (qs) { seg_geometry(launch_grid, 2, &a.nseg, &a.seg); plan_used_qs = true; }
                 else
                 if (!a.emit_all) seg_geometry(grid, (a.dense ? 8 : 4) / (ag ? 2 : 1), &a.nseg, &a.seg);   // (segments per workgroup: WR, or 2 WR wave halves with DENSE)
@@ -1953,7 +2002,8 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
         const uint64_t tiling = plan_used_qs ? 0x81u : (small || mid64) ? 0x14u : ((mid128 || waves16 == 3 || waves16 == 2) ? 0x24u : 0x42u);   // (0x81: query-stationary threshold stages)
         std::lock_guard<std::mutex> plk(h->prof_mu);
         h->prof.last_plan = (sample.sample_tiles ? 1u : 0u) | ((sample.sample_tiles && sample_threshold_only) ? 2u : 0u) | (i8c ? 4u : 0u) |
-                            (plan_used_segments ? 8u : 0u) | (small ? 16u : 0u) | (fs ? 128u : 0u) | ((uint64_t)(plan.size() & 0xff) << 8) | (tiling << 16);
+                            (plan_used_segments ? 8u : 0u) | (small ? 16u : 0u) | (fs ? 128u : 0u) | ((uint64_t)(plan.size() & 0xff) << 8) | (tiling << 16) |
+                            (sts ? (1ull << 24) : 0ull);   // bit 24: self-tightening single-launch scan
     }
     FinalArgs fa{};
     fa.cand = w.cand; fa.count = w.count; fa.k = k; fa.out_k = out_k; fa.cap = w.cap; fa.metric = key_metric; fa.ip_form = ip_form;
@@ -2435,6 +2485,7 @@ static int search_impl(lynse_hip_flat* h, const void* q_src, bool packed_queries
     };
     // filtered search, strategy (flat_mmap.rs:549-556 switches at a fixed 50,000 ids): gather the listed shadow rows and scan
     // only those when that is cheaper than a masked scan of the whole shard — bytes over measured rates on MI355X
+    bool strategy_direct = false, strategy_known = false;
     auto choose_direct = [&]() -> bool {
         if (!filtered || binary) return false;
         const double rate = nq <= SCAN_BQ_SMALL ? 6.0e12 : 3.4e12;
@@ -2454,7 +2505,12 @@ static int search_impl(lynse_hip_flat* h, const void* q_src, bool packed_queries
         if (needs_large_k()) { rlk.unlock(); return go_large_k(); }
         // (a MASKED filtered search only needs scratch of its own context: shared lock; the gathered-rows strategy points the
         // handle's scan-side fields at the compact copy for the duration of the call: exclusive)
-        if (!user_stream && derived_ready() && !(filtered && (n_subset == 0 || choose_direct()))) {
+        // (the strategy is decided ONCE, here: its inputs — the strike counters concurrent searches bump, an environment variable —
+        // can change between two evaluations, and "masked" under the shared lock followed by "gathered" at the use site would run
+        // the gathered-rows path, which repoints handle-wide scan fields, beside concurrent readers)
+        strategy_direct = filtered && n_subset != 0 && choose_direct();
+        strategy_known = true;
+        if (!user_stream && derived_ready() && !(filtered && (n_subset == 0 || strategy_direct))) {
             LY_TRY(lease.acquire(h));
         } else {
             rlk.unlock();
@@ -2498,7 +2554,8 @@ static int search_impl(lynse_hip_flat* h, const void* q_src, bool packed_queries
     std::vector<uint64_t> sorted_subset;
     auto& fc = cur(h);   // (this search's context: 0 under the exclusive lock, the leased one under the shared lock)
     if (filtered) {
-        direct = choose_direct();
+        direct = strategy_known ? strategy_direct : choose_direct();   // (caller_holds_exclusive: evaluated here, under that lock)
+        if (direct && !xlk.owns_lock() && !caller_holds_exclusive) return set_error(LYNSE_ERR_INTERNAL, "gathered-rows filter strategy without the exclusive lock");
         if (n_subset > fc.subset_cap && (direct || !bitset_words)) {
             if (fc.d_subset) (void)hipFree(fc.d_subset);
             fc.d_subset = nullptr;
@@ -2659,8 +2716,9 @@ static int search_impl(lynse_hip_flat* h, const void* q_src, bool packed_queries
             }
             continue;
         }
+        bool allow_sts = true;
         for (int level = 0; level < 3; ++level) {  // sampled plan -> contiguous plan -> exhaustive plan (make_plan)
-            bool sampled = false;
+            bool sampled = false, used_sts = false;
             // k_final writes the results where they belong — the caller's device arrays, or the pinned (device-visible)
             // staging buffer for small host-API results: no copy kernels behind the search; only large host results go
             // through the workspace + two device-to-host copies.  One synchronisation per chunk (counts + overflow flags in
@@ -2670,7 +2728,7 @@ static int search_impl(lynse_hip_flat* h, const void* q_src, bool packed_queries
             uint64_t* r_dst = on_device ? out_rows + q0 * k : (staged ? reinterpret_cast<uint64_t*>(w.h_out) : nullptr);
             float* d_dst = on_device ? out_dists + q0 * k : (staged ? reinterpret_cast<float*>(w.h_out + rows_b) : nullptr);
             LY_TRY(run_chunk(h, nqc, kk, k, metric, level, st, &ev_used, &scan_events, &sampled, mask, direct ? h->g_ids32 : nullptr, i8c,
-                             r_dst, d_dst, on_device ? out_counts + q0 : nullptr, nullptr, qsrc, true));
+                             r_dst, d_dst, on_device ? out_counts + q0 : nullptr, nullptr, qsrc, true, allow_sts, &used_sts));
             if (!on_device && !staged) {
                 LY_HIP(hipMemcpyAsync(out_rows + q0 * k, w.out_rows, rows_b, out_kind, st));
                 LY_HIP(hipMemcpyAsync(out_dists + q0 * k, w.out_dists, dists_b, out_kind, st));
@@ -2684,6 +2742,11 @@ static int search_impl(lynse_hip_flat* h, const void* q_src, bool packed_queries
             }
             if (level == 2) return set_error(LYNSE_ERR_INTERNAL, "candidate overflow on the exhaustive plan");
             fallback_queries += nov;
+            if (used_sts) {  // the self-tightening scan overflowed (scores rising along every workgroup's chunk): the staged plan of the same coarse pass
+                allow_sts = false;
+                --level;
+                continue;
+            }
             if (i8c) {  // same plan level again with the f16 coarse pass
                 i8c = false;
                 i8c_add_strike(h, metric);
@@ -2717,7 +2780,11 @@ extern "C" int lynse_hip_flat_coarse_state(lynse_hip_flat* h, int* out_strikes, 
     return LYNSE_OK;
 }
 
-extern "C" uint64_t lynse_hip_flat_bpm_rows(const lynse_hip_flat* h) { return (h && h->bpm) ? h->n_bpm : 0; }
+extern "C" uint64_t lynse_hip_flat_bpm_rows(const lynse_hip_flat* h) {
+    if (!h) return 0;
+    std::shared_lock<std::shared_mutex> lk(const_cast<lynse_hip_flat*>(h)->rw);   // (writers reallocate these fields)
+    return h->bpm ? h->n_bpm : 0;
+}
 
 // Builds — now, not inside the first search that needs it — every derived copy a batch of `nq` queries of `metric` will read:
 // row statistics + f16 shadow (float metrics), the SQ8 codes of the certified int8 pass (IP batches of 33..256 queries over
@@ -2748,6 +2815,7 @@ extern "C" int lynse_hip_flat_prepare(lynse_hip_flat* h, int metric, uint64_t nq
 // Bytes of HBM the shard holds: source rows + every derived copy built so far (search workspaces not included).
 extern "C" uint64_t lynse_hip_flat_hbm_bytes(const lynse_hip_flat* h) {
     if (!h) return 0;
+    std::shared_lock<std::shared_mutex> lk(const_cast<lynse_hip_flat*>(h)->rw);   // (writers reallocate these fields)
     uint64_t b = 0;
     if (h->rows) b += h->capacity * h->ld * 4ull;
     if (h->rows_h) b += h->capacity * h->ld16 * 2ull;

@@ -1,4 +1,4 @@
-// scan_qs.h — k_scan_qs: the QUERY-STATIONARY tiling of the certified int8 coarse pass (FLAT-IP, 33..256 queries).
+// scan_qs.h — k_scan_qs: the QUERY-STATIONARY tiling of the certified int8 coarse pass (FLAT-IP / cosine, 129..256 queries).
 //
 // Replaces, for the threshold stages of a batch, the 256-row x 256-query tile of k_scan_h16<2,4,4,2,IP,…,I8Q=2> (kernels.h).
 // Reference work on this path: FlatMmap::search -> exact_flat_search's chunked scan (src/storage/flat_mmap.rs:2179-2256,
@@ -10,18 +10,30 @@
 //   * a workgroup is 8 waves; wave w OWNS queries [32 w, 32 w + 32) for the whole launch and keeps their int8 image — the
 //     B operand of v_mfma_i32_32x32x32_i8 for every k-step, NSLAB x 4 fragments x 4 registers (96 for 768 dimensions) —
 //     in registers, loaded once from the L2-resident image k_i8c_prep_queries wrote;
-//   * the LDS holds ONLY rows: a ring of NS stages, one stage = RB x 32 rows x SL slabs of 128 B (24 KB), filled by
+//   * the LDS holds ONLY rows: a ring of NS stages, one stage = RB x 32 rows x SL slabs of 128 B, filled by
 //     global_load_lds_dwordx4 in full 128-B lines (8 rows x 128 B per instruction, the XOR slot swizzle of k_scan_h16 on the
 //     per-lane source address);
 //   * every wave reads EVERY row fragment of a stage (one ds_read_b128 per MFMA: 128 B / clk / CU of the 256 the LDS delivers)
 //     and multiplies it with its own 32 queries; the accumulators of a tile are RB x 16 registers;
 //   * a lane's 16 x RB accumulators all belong to ONE query (column lane % 32 of the wave's block), so the epilogue is a
-//     v_max3 chain against ONE register-resident integer threshold (the integer image of the certified threshold, DESIGN.md
-//     §3b), one ballot, and a rare per-element path that appends (score, row) keys to the lane's private segment;
+//     v_max chain against ONE register-resident integer threshold (the integer image of the certified threshold, DESIGN.md
+//     §3b), one ballot, and a rare grouped path that appends (score, row) keys to the lane's private segment;
 //   * XPF: the first fragments of step g + 1 are read before barrier g + 1 (the wait in front of barrier g covers the data of
 //     step g + 1 too), so no wave opens a step waiting for its first LDS round trip.
 // Keys, segments and counts are the ones k_select gathers (ScanArgs::candB / segcnt; two segments per workgroup and query: the
 // two wave halves of the owning wave).
+//
+// STS — SELF-TIGHTENING thresholds: the whole shard in ONE launch, no sample stage, no select between stages.  One query per
+// lane makes a running threshold cheap: per query, dyn_ks (= k) maxima of the coarse integer dot product over DISJOINT row
+// partitions (partition of a row = its tile index % dyn_ks) live in global memory; their minimum tau is reached by at least k
+// distinct rows, so at ANY moment every row whose dot is below tau - M (M = the certified margin 2E in dot units) is out of the
+// top-k — however stale the value a lane holds (tau only grows).  k_i8c_prep_queries seeds the maxima from a few sample rows
+// (valid from the first tile on).  During the launch: a lane whose tile maximum beats its tau raises the tile's partition
+// maximum (fire-and-forget atomic max); one wave per workgroup re-reads the partition maxima of "its" query every few steps
+// and publishes their minimum; every lane re-reads its query's tau every few steps.  Both reads are 4-byte LDS-DMAs into a
+// landing area behind the row ring (they ride on the ring's counted waits: no register is written asynchronously, nothing
+// drains).  The first dyn_warm tiles of every workgroup only feed the maxima (no emission) and are scanned again at the end.
+// The keys of all tiles go to k_select_final exactly as a last threshold stage's would.
 #pragma once
 
 namespace lynse {
@@ -29,8 +41,10 @@ namespace lynse {
 typedef int qs_i32x4 __attribute__((ext_vector_type(4)));
 typedef int qs_i32x16 __attribute__((ext_vector_type(16)));
 
+constexpr int QS_STS_LDS = 8 * 256 + 8 * 256;   // landing areas behind the ring: per wave 64 thresholds + 64 partition maxima
+
 // DBG (timing experiments): 1 no MFMA, 2 no LDS fragment reads, 8 no row DMA, 16 no epilogue, 32 s_memtime phase sums, 64 waves 4-7 do not compute
-template <int NSLAB, int RB, int SL, int NS, bool XPF, int NBUF, int DBG = 0, int PING = 0>
+template <int NSLAB, int RB, int SL, int NS, bool XPF, int NBUF, int DBG = 0, int PING = 0, int STS = 0>
 __global__ void __launch_bounds__(512, 2) k_scan_qs(ScanArgs a) {
     static_assert(NSLAB % SL == 0, "a tile is a whole number of steps");
     constexpr int TS = NSLAB / SL;          // steps per tile
@@ -42,7 +56,9 @@ __global__ void __launch_bounds__(512, 2) k_scan_qs(ScanArgs a) {
     constexpr int NM = SL * 4 * RB;         // MFMAs per wave and step
     static_assert(NM % NBUF == 0 && NBUF >= 2 && NBUF <= NM, "fragment ring");
     static_assert(NS >= (XPF ? 4 : 3), "ring depth");
-    static_assert(NS * SB <= 160 * 1024, "LDS");
+    static_assert(NS * SB + (STS ? QS_STS_LDS : 0) <= 160 * 1024, "LDS");
+    static_assert(PING == 0 || TS == 1, "ping-pong: one step per tile");
+    static_assert(STS == 0 || (!XPF && TS == 1), "self-tightening thresholds: whole-K stages, no cross-barrier prefetch");
     constexpr int WAITN = (XPF ? NS - 3 : NS - 2) * PPW;   // DMA instructions that may still be in flight at the barrier
     static_assert(WAITN <= 63, "vmcnt");
 
@@ -51,10 +67,31 @@ __global__ void __launch_bounds__(512, 2) k_scan_qs(ScanArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l32 = lane & 31, hi = lane >> 5;
     const uint32_t ntiles = (a.row1 - a.row0 + RT - 1) / RT;
-    if (blockIdx.x >= ntiles) return;
-    const uint32_t my_tiles = (ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x;
-    const uint32_t G = my_tiles * TS;
+    // Tile order.  Staged plans: workgroup b takes tiles b, b + grid, ... (the chip sweeps the stage front to back).  STS: workgroup b
+    // owns the CONTIGUOUS tiles [b * pitch, (b + 1) * pitch) — the tiles the chip works on at any moment are spread evenly over the
+    // whole shard, so the running thresholds are representative of it whatever the insertion order (a shard sorted by score would
+    // otherwise beat its own thresholds with every new tile, the way it overflows the contiguous staged plan); the pitch is coprime
+    // to dyn_ks, so the tiles of one round fall into every partition.
+    const uint32_t pitch = STS != 0 ? a.dyn_pitch : 0u;
+    uint32_t my_tiles;
+    if constexpr (STS != 0) {
+        if ((uint64_t)blockIdx.x * pitch >= ntiles) return;
+        my_tiles = ntiles - blockIdx.x * pitch < pitch ? ntiles - blockIdx.x * pitch : pitch;
+    } else {
+        if (blockIdx.x >= ntiles) return;
+        my_tiles = (ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x;
+    }
+    // STS: ordinals 0 .. warm-1 are scanned twice — first without emission (they only feed the partition maxima), again at the end
+    uint32_t warm = 0;
+    if constexpr (STS != 0) warm = a.dyn_warm * 4u <= my_tiles ? a.dyn_warm : my_tiles / 4u;
+    const uint32_t n_ord = my_tiles + warm;      // tile ordinals of this workgroup: ordinal j is its (j < my_tiles ? j : j - my_tiles)-th tile
+    const uint32_t G = n_ord * TS;
     [[maybe_unused]] const unsigned long long t_kernel0 = (a.debug_flags & 64) ? __builtin_amdgcn_s_memtime() : 0ull;
+    auto tile_of = [&](uint32_t ord) -> uint32_t {
+        const uint32_t i = ord < my_tiles ? ord : ord - my_tiles;
+        if constexpr (STS != 0) return blockIdx.x * pitch + i;
+        else return blockIdx.x + i * gridDim.x;
+    };
 
     // ---- the wave's query block: B fragments of every k-step, register-resident for the whole launch
     const int swz = (l32 >> 1) & 7;
@@ -72,7 +109,7 @@ __global__ void __launch_bounds__(512, 2) k_scan_qs(ScanArgs a) {
     const bool q_ok = qn < a.nq;
     const float s_q = q_ok ? a.qinv[qn] : 0.0f, b_q = q_ok ? a.qn2[qn] : 0.0f;
     int T = 0x7fffffff;
-    {
+    if constexpr (STS == 0) {
         // INTEGER image of the threshold (k_scan_h16, load_qc_thr): B_q + s_q * (float)dot is monotone non-decreasing in the
         // integer dot product, so "score >= thr" is exactly "dot >= T", T = the smallest passing dot (bisection over |dot| <= 2^29)
         const float th = q_ok ? a.thr[qn] : 0.0f;
@@ -89,16 +126,42 @@ __global__ void __launch_bounds__(512, 2) k_scan_qs(ScanArgs a) {
         if (a.debug_flags & 2) T = 0x7fffffff;
 #endif
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the query fragments and constants are in registers before the first LDS-DMA
+    // STS state: tau_c = the largest tau of its query this lane has seen, T = tau_c - margin; the landing areas in LDS
+    [[maybe_unused]] int tau_c = -2147483647 - 1, dyn_m = 0, pub_last = -2147483647 - 1;
+    [[maybe_unused]] int* const land_thr = reinterpret_cast<int*>(smem + NS * SB) + wave * 64 + lane;          // tau of query qn
+    [[maybe_unused]] int* const land_slot = reinterpret_cast<int*>(smem + NS * SB + 8 * 256) + wave * 64 + lane;  // partition maximum lane % 32 of the helper query
+    [[maybe_unused]] const int* thr_src = nullptr;
+    [[maybe_unused]] const int* slot_src = nullptr;
+    [[maybe_unused]] const uint32_t hq = blockIdx.x + (uint32_t)wave * gridDim.x;   // the query whose minimum this wave republishes (if < nq)
+    [[maybe_unused]] const bool helper = STS != 0 && hq < a.nq;
+    [[maybe_unused]] uint32_t sts_step = 0;
+    [[maybe_unused]] int peek_thr = -2147483647 - 1, peek_slot = -2147483647 - 1;
+    [[maybe_unused]] auto sts_T = [&]() -> int {
+        if (!q_ok) return 0x7fffffff;
+#ifdef LYNSE_EXPERIMENTS
+        if (a.debug_flags & 2) return 0x7fffffff;
+#endif
+        return tau_c < -(1 << 30) ? -(1 << 30) - (1 << 29) : tau_c - dyn_m;   // (|dot| <= 2^29, margin <= 2^30)
+    };
+    if constexpr (STS != 0) {
+        thr_src = a.dyn_thr + (q_ok ? qn : 0u);
+        slot_src = a.dyn_slot + (size_t)(helper ? hq : 0u) * 32 + l32;
+        dyn_m = q_ok ? a.dyn_marg[qn] : 0;
+        tau_c = __hip_atomic_load(thr_src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        *land_thr = tau_c;
+        *land_slot = -2147483647 - 1;   // (nothing is published before a real set of maxima has landed)
+        T = sts_T();
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // the query fragments and constants are in registers before the first LDS-DMA
 
-    // ---- row stream (LDS-DMA): step gi of this workgroup = tile gi / TS, slabs [(gi % TS) SL, +SL)
+    // ---- row stream (LDS-DMA): step gi of this workgroup = tile ordinal gi / TS, slabs [(gi % TS) SL, +SL)
     // piece p = wave * PPW + j of a stage: slab p / (RB 4) of the step, rows (p % (RB 4)) * 8 .. +8 of the tile; lane l brings the 16 B
     // of row (l >> 3), PHYSICAL slot (l & 7) = logical slot (l & 7) ^ ((row >> 1) & 7)
     uint32_t v_off[PPW];
     const char* v_base = nullptr;   // uniform: first row of the tile being issued
-    uint32_t is_tile = blockIdx.x, is_sub = 0, is_stage = 0, is_count = 0;
+    uint32_t is_ord = 0, is_sub = 0, is_stage = 0, is_count = 0;
     auto enter_tile = [&]() {
-        const uint32_t rbase = a.row0 + is_tile * RT;
+        const uint32_t rbase = a.row0 + tile_of(is_ord) * RT;
         const uint32_t span = a.row1 - 1 - rbase;   // rows past the last one re-read it (masked in the epilogue)
         v_base = reinterpret_cast<const char*>(a.V16) + (size_t)rbase * a.ld16;
 #pragma unroll
@@ -119,7 +182,7 @@ __global__ void __launch_bounds__(512, 2) k_scan_qs(ScanArgs a) {
         if (++is_count < G) {
             if (++is_sub == TS) {
                 is_sub = 0;
-                is_tile += gridDim.x;
+                ++is_ord;
                 enter_tile();
             }
         }
@@ -152,7 +215,7 @@ __global__ void __launch_bounds__(512, 2) k_scan_qs(ScanArgs a) {
         for (int r = 0; r < 16; ++r) acc[i][r] = 0;
 
     uint32_t cnt = 0;            // keys in this lane's private segment
-    uint32_t tile = blockIdx.x;  // tile being computed
+    uint32_t c_ord = 0;          // tile ordinal being computed
     uint32_t c_stage = 0;
     uint32_t ad_cur[4], ad_nxt[4];   // fragment addresses (per kk) in the stage being computed / the next one
 #pragma unroll
@@ -205,11 +268,24 @@ __global__ void __launch_bounds__(512, 2) k_scan_qs(ScanArgs a) {
             __builtin_amdgcn_sched_barrier(0);
         });
     };
+    [[maybe_unused]] uint32_t sts_extra = 0;   // 4-byte LDS-DMAs this wave issued behind the previous step's ring pieces (they may stay in flight too)
     auto wait_and_barrier = [&]() {
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAITN) : "memory");
+        if constexpr (STS != 0) {
+            if (sts_extra == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAITN) : "memory");
+            else if (sts_extra == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAITN + 1) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAITN + 2) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAITN) : "memory");
+        }
         stamp(t_wait);
         __builtin_amdgcn_s_barrier();
         stamp(t_bar);
+        if constexpr (STS != 0) {
+            // peek at the landing areas: issued in front of the step's fragment reads (LDS reads return in order, so the first counted
+            // lgkmcnt of the MFMA loop covers them) — waiting for them behind the MFMAs cost the late waves ~150 exposed cycles per step
+            asm volatile("ds_read_b32 %0, %1" : "=v"(peek_thr) : "v"((uint32_t)(uintptr_t)(__attribute__((address_space(3))) const int*)land_thr) : "memory");
+            if (helper) asm volatile("ds_read_b32 %0, %1" : "=v"(peek_slot) : "v"((uint32_t)(uintptr_t)(__attribute__((address_space(3))) const int*)land_slot) : "memory");
+        }
         c_stage = c_stage + 1 == NS ? 0 : c_stage + 1;
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
@@ -217,37 +293,93 @@ __global__ void __launch_bounds__(512, 2) k_scan_qs(ScanArgs a) {
             ad_nxt[kk] = (a_lane ^ (uint32_t)(kk * 32)) + c_stage * SB;
         }
     };
+    // STS: re-read tau (every lane) and the helper query's partition maxima — behind the step's ring pieces, every step at first
+    [[maybe_unused]] auto sts_refresh = [&]() {
+        const uint32_t s = sts_step++;
+        sts_extra = 0;
+#ifdef LYNSE_EXPERIMENTS
+        if ((a.debug_flags & 256) && s >= 16u) return;   // (timing experiment: thresholds frozen after the first steps)
+#endif
+        if (s < 16u || (s & 3u) == 0u) {
+            sts_extra = helper ? 2u : 1u;
+            constexpr int AUX = STS == 1 ? 17 : (STS == 2 ? 16 : 0);   // sc0 sc1 (system scope: the only policy that is coherent across XCDs) / experiments: sc1, plain
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)thr_src,
+                                             (__attribute__((address_space(3))) void*)(reinterpret_cast<int*>(smem + NS * SB) + wave * 64), 4, 0, AUX);
+            if (helper)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)slot_src,
+                                                 (__attribute__((address_space(3))) void*)(reinterpret_cast<int*>(smem + NS * SB + 8 * 256) + wave * 64), 4, 0, AUX);
+        }
+    };
+    // STS, behind a step's MFMAs (NOT in front of the barrier: every cycle there is a cycle of the whole workgroup): pick up whatever
+    // has landed (a 4-byte LDS-DMA needs no wait to be READ: an early read sees the previous value, and any value tau ever held is a
+    // valid threshold); the helper wave republishes the minimum of its query's partition maxima
+    [[maybe_unused]] auto sts_pickup = [&]() {
+        // (the peeks were issued by hand in front of the MFMA loop: a volatile load through the generic pointer becomes a FLAT load
+        // behind s_waitcnt vmcnt(0) — the ring drained once per step, +9 % — and a plain LDS load the compiler can see is ordered behind
+        // every LDS-DMA in flight the same way)
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(peek_thr), "+v"(peek_slot)::"memory");
+        const int seen = peek_thr;
+        tau_c = seen > tau_c ? seen : tau_c;
+        T = sts_T();
+        if (helper && (sts_step < 20u || (sts_step & 3u) == 3u)) {   // (uniform per wave)
+            int m = peek_slot;
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) { const int t2 = __shfl_xor(m, o, 64); m = t2 < m ? t2 : m; }
+            if (lane == 0 && m > pub_last) { atomicMax(a.dyn_thr + hq, m); pub_last = m; }
+        }
+    };
     // ---- tile epilogue: this lane's RB x 16 dot products all belong to query qn
-    auto epilogue = [&](uint32_t e_tile) {
+    auto epilogue = [&](uint32_t e_tile, bool emit) {
         if constexpr ((DBG & 16) != 0) {
 #pragma unroll
             for (int i = 0; i < RB; ++i)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) asm volatile("" ::"v"(acc[i][r]));
         } else {
-            int mx = acc[0][0];
+            // maxima of the groups of four accumulators first (the slow path re-uses them), then their maximum
+            int gm[RB][4];
 #pragma unroll
             for (int i = 0; i < RB; ++i)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) mx = mx > acc[i][r] ? mx : acc[i][r];
+                for (int g = 0; g < 4; ++g) {
+                    const int m01 = acc[i][4 * g] > acc[i][4 * g + 1] ? acc[i][4 * g] : acc[i][4 * g + 1];
+                    const int m23 = acc[i][4 * g + 2] > acc[i][4 * g + 3] ? acc[i][4 * g + 2] : acc[i][4 * g + 3];
+                    gm[i][g] = m01 > m23 ? m01 : m23;
+                }
+            int mx = gm[0][0];
+#pragma unroll
+            for (int i = 0; i < RB; ++i)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) mx = mx > gm[i][g] ? mx : gm[i][g];
             if (__builtin_expect(__ballot(mx >= T) != 0ull, 0)) {
+                if constexpr (STS != 0) {
+                    // a new maximum candidate of this tile's partition (~k ln(rows) times per query and launch): fire and forget
+                    if (q_ok && mx > tau_c) atomicMax(a.dyn_slot + (size_t)qn * 32 + (e_tile % a.dyn_ks), mx);
+                    if (!emit) return;   // (uniform) a warm-up tile: scanned again at the end of the launch
+                }
                 const uint32_t rbase = a.row0 + e_tile * RT;
                 uint64_t* segdst = a.candB + ((size_t)qn * a.nseg + (blockIdx.x * 2 + hi)) * a.seg;
 #pragma unroll
                 for (int i = 0; i < RB; ++i) {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int v = acc[i][r];
-                        if (v >= T) {
-                            const uint32_t m = rbase + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                            if (m < a.row1) {
-                                const uint64_t key = make_key(b_q + s_q * (float)v, m, false);
-                                if (cnt < a.seg) {
-                                    segdst[cnt] = key;
-                                    ++cnt;
-                                } else {
-                                    const uint32_t slot = atomicAdd(&a.count[qn], 1u);
-                                    if (slot < a.cap) a.cand[(size_t)qn * a.cap + slot] = key;
+                    for (int g = 0; g < 4; ++g) {
+                        // one wave-level branch per group of four (a branch per element cost more than everything it guards)
+                        if (__builtin_expect(__ballot(gm[i][g] >= T) == 0ull, 1)) continue;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int r = 4 * g + e;
+                            const int v = acc[i][r];
+                            if (v >= T) {
+                                const uint32_t m = rbase + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                                if (m < a.row1) {
+                                    const uint64_t key = make_key(b_q + s_q * (float)v, m, false);
+                                    if (cnt < a.seg) {
+                                        segdst[cnt] = key;
+                                        ++cnt;
+                                    } else {
+                                        const uint32_t slot = atomicAdd(&a.count[qn], 1u);
+                                        if (slot < a.cap) a.cand[(size_t)qn * a.cap + slot] = key;
+                                    }
                                 }
                             }
                         }
@@ -257,7 +389,7 @@ __global__ void __launch_bounds__(512, 2) k_scan_qs(ScanArgs a) {
         }
     };
     if constexpr (PING == 0) {
-        for (uint32_t ti = 0; ti < my_tiles; ++ti) {
+        for (; c_ord < n_ord; ++c_ord) {
             ly_static_for<TS>([&](auto sc) {
                 stamp(t_epi);
                 wait_and_barrier();
@@ -267,12 +399,13 @@ __global__ void __launch_bounds__(512, 2) k_scan_qs(ScanArgs a) {
                 } else {
                     mfma_step(sc, std::true_type{});
                 }
+                if constexpr (STS != 0) sts_refresh();
                 advance();
                 if constexpr (TIMING) asm volatile("" ::"v"(acc[0][0]));
                 stamp(t_loop);
             });
-            epilogue(tile);
-            tile += gridDim.x;
+            if constexpr (STS != 0) sts_pickup();
+            epilogue(tile_of(c_ord), c_ord >= warm);
         }
     } else {
         // PING-PONG (PING): the two waves of a SIMD share one matrix pipe, and with equal priority the older wave wins every slot — waves
@@ -280,12 +413,13 @@ __global__ void __launch_bounds__(512, 2) k_scan_qs(ScanArgs a) {
         // MFMAs, their DMA issue and their tile epilogue one after the other.  Here the roles are explicit: the EARLY waves (0-3: one
         // per SIMD) run  barrier -> MFMAs -> epilogue -> DMA issue,  the LATE waves (4-7)  barrier -> epilogue of the PREVIOUS tile ->
         // DMA issue -> MFMAs:  each half's epilogue / issue work sits beside the other half's MFMAs.  (PING == 2: s_setprio 1 on the
-        // early waves' MFMAs.)
-        static_assert(PING == 0 || TS == 1, "ping-pong: one step per tile");
+        // early waves' MFMAs.)  Measured (scripts/qs_microbench.hip): within 1 % of the plain order either way — the scan is bound by
+        // the power the MFMAs, the LDS reads and the HBM stream draw together, not by how the waves take turns.
         const bool late = wave >= 4;
         bool pend = false;   // late waves: the tile computed in the previous step still has to go through the epilogue
-        for (uint32_t g = 0; g <= my_tiles; ++g) {
-            if (g < my_tiles) {
+        uint32_t e_ord = 0;
+        for (uint32_t g = 0; g <= n_ord; ++g) {
+            if (g < n_ord) {
                 stamp(t_epi);
                 wait_and_barrier();
                 if (!late) {
@@ -298,13 +432,17 @@ __global__ void __launch_bounds__(512, 2) k_scan_qs(ScanArgs a) {
                 }
             }
             if (pend) {
-                epilogue(tile);
-                tile += gridDim.x;
+                if constexpr (STS != 0) sts_pickup();
+                epilogue(tile_of(e_ord), e_ord >= warm);
+                ++e_ord;
                 pend = false;
             }
-            if (g < my_tiles) {
+            if (g < n_ord) {
+                // (the keys of the epilogue above were stored BEFORE these pieces: at the next counted wait they are older than
+                // everything that may stay in flight.  Stores issued behind a step's pieces made that wait hold back a ring piece each.)
 #pragma unroll
                 for (int j = 0; j < PPW; ++j) issue_piece(j);
+                if constexpr (STS != 0) sts_refresh();
                 advance();
                 if (late) {
                     stamp(t_epi);

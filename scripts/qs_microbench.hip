@@ -118,6 +118,45 @@ struct Sampler {
     void finish() { stop = true; if (th.joinable()) th.join(); }
 };
 
+// every dot product of a small shard (STS check)
+__global__ void __launch_bounds__(256) k_all_dots(const int8_t* V, uint32_t ld, uint32_t D, uint32_t n, const int8_t* Qp, uint32_t nq, int* out) {
+    const uint32_t row = blockIdx.x * 64 + (threadIdx.x & 63);
+    if (row >= n) return;
+    for (uint32_t q = threadIdx.x >> 6; q < nq; q += 4) {
+        int dot = 0;
+        for (uint32_t d = 0; d < D; ++d) dot += (int)V[(size_t)row * ld + d] * (int)Qp[(size_t)q * D + d];
+        out[(size_t)q * n + row] = dot;
+    }
+}
+// stand-in for the seeding of k_i8c_prep_queries: partition maxima over a few sample rows
+__global__ void __launch_bounds__(256) k_seed(const int8_t* V, uint32_t ld, uint32_t D, uint32_t n, const int8_t* Qp, uint32_t rt, uint32_t ks,
+                                              uint32_t seed_rows, int* dyn_thr, int* dyn_slot, int* dyn_marg, int marg) {
+    __shared__ int s_slot[32];
+    const uint32_t q = blockIdx.x, tid = threadIdx.x;
+    if (tid < 32) s_slot[tid] = -2147483647 - 1;
+    __syncthreads();
+    const uint32_t ntiles = (n + rt - 1) / rt, per = seed_rows / ks;
+    for (uint32_t i = tid; i < per * ks; i += 256) {
+        const uint32_t p = i % ks, m = i / ks;
+        const uint32_t up = (ntiles > p) ? (ntiles - p + ks - 1) / ks : 0u;
+        if (!up) continue;
+        const uint32_t u_idx = (uint32_t)(((uint64_t)m * up) / per);
+        uint64_t row = (uint64_t)(p + ks * u_idx) * rt + (i * 7u) % rt;
+        if (row >= n) row = (uint64_t)(p + ks * u_idx) * rt;
+        int dot = 0;
+        for (uint32_t d = 0; d < D; ++d) dot += (int)V[row * ld + d] * (int)Qp[(size_t)q * D + d];
+        atomicMax(&s_slot[p], dot);
+    }
+    __syncthreads();
+    if (tid < 32) dyn_slot[(size_t)q * 32 + tid] = tid < ks ? s_slot[tid] : 2147483647;
+    if (tid == 0) {
+        int mn = 2147483647;
+        for (uint32_t j = 0; j < ks; ++j) mn = s_slot[j] < mn ? s_slot[j] : mn;
+        dyn_thr[q] = mn;
+        dyn_marg[q] = marg;
+    }
+}
+
 struct Bufs {
     int8_t *V = nullptr, *Qp = nullptr, *img = nullptr;
     float *qinv = nullptr, *qn2 = nullptr, *thr = nullptr;
@@ -126,6 +165,7 @@ struct Bufs {
     uint8_t* segcnt = nullptr;
     uint32_t* count = nullptr;
     unsigned long long* dbg = nullptr;
+    int *dyn_thr = nullptr, *dyn_slot = nullptr, *dyn_marg = nullptr;
     uint32_t cap = 16384;
 };
 
@@ -140,6 +180,7 @@ static ScanArgs base_args(const Bufs& b, uint32_t r0, uint32_t r1, uint32_t nq) 
     a.qinv = b.qinv; a.qn2 = b.qn2; a.qrinv = b.qinv; a.thr = b.thr;
     a.cand = b.cand; a.count = b.count; a.cap = b.cap; a.candB = b.candB; a.segcnt = b.segcnt;
     a.emit_all = 0;
+    a.dyn_thr = b.dyn_thr; a.dyn_slot = b.dyn_slot; a.dyn_marg = b.dyn_marg; a.dyn_ks = 10; a.dyn_warm = 4;
     return a;
 }
 
@@ -153,14 +194,22 @@ struct Variant {
     bool qs;
 };
 
-template <int NSLAB, int RB, int SL, int NS, bool XPF, int NBUF, int DBG, int PP = 0>
+template <int NSLAB, int RB, int SL, int NS, bool XPF, int NBUF, int DBG, int PP = 0, int STS = 0>
 static void launch_qs(ScanArgs a, uint32_t grid, hipStream_t st) {
-    auto k = k_scan_qs<NSLAB, RB, SL, NS, XPF, NBUF, DBG, PP>;
-    constexpr size_t lds = (size_t)NS * SL * RB * 32 * 128;
+    auto k = k_scan_qs<NSLAB, RB, SL, NS, XPF, NBUF, DBG, PP, STS>;
+    constexpr size_t lds = (size_t)NS * SL * RB * 32 * 128 + (STS ? QS_STS_LDS : 0);
     static bool done = false;
     if (!done) { set_lds(k, lds); done = true; }
     const uint32_t nt = (a.row1 - a.row0 + RB * 32 - 1) / (RB * 32);
-    hipLaunchKernelGGL(k, dim3(std::min(grid, nt)), dim3(512), lds, st, a);
+    uint32_t g = std::min(grid, nt);
+    if (STS) {   // contiguous chunks of `pitch` tiles per workgroup, pitch coprime to the partition count
+        auto gcd = [](uint32_t x, uint32_t y) { while (y) { const uint32_t t = x % y; x = y; y = t; } return x; };
+        uint32_t pitch = (nt + g - 1) / g;
+        while (gcd(pitch, a.dyn_ks) != 1) ++pitch;
+        a.dyn_pitch = pitch;
+        g = (nt + pitch - 1) / pitch;
+    }
+    hipLaunchKernelGGL(k, dim3(g), dim3(512), lds, st, a);
 }
 template <bool DENSE, int DBG>
 static void launch_old(ScanArgs a, uint32_t grid, hipStream_t st) {
@@ -173,17 +222,17 @@ static void launch_old(ScanArgs a, uint32_t grid, hipStream_t st) {
     hipLaunchKernelGGL(k, dim3(std::min(grid, a.ntiles)), dim3(512), lds, st, a);
 }
 
-static std::vector<uint64_t> collect(const Bufs& b, uint32_t nq, uint32_t nseg, uint32_t seg) {
+static std::vector<std::vector<uint64_t>> collect_q(const Bufs& b, uint32_t nq, uint32_t nseg, uint32_t seg) {   // keys per query
     std::vector<uint32_t> cnt(nq);
     CK(hipMemcpy(cnt.data(), b.count, nq * 4, hipMemcpyDeviceToHost));
-    std::vector<uint64_t> keys;
+    std::vector<std::vector<uint64_t>> out(nq);
     std::vector<uint64_t> tmp(b.cap);
     for (uint32_t q = 0; q < nq; ++q) {
         const uint32_t c = std::min(cnt[q], b.cap);
         if (cnt[q] > b.cap) { fprintf(stderr, "query %u overflowed the shared region (%u)\n", q, cnt[q]); }
         if (c) {
             CK(hipMemcpy(tmp.data(), b.cand + (size_t)q * b.cap, (size_t)c * 8, hipMemcpyDeviceToHost));
-            for (uint32_t i = 0; i < c; ++i) keys.push_back(((uint64_t)q << 48) ^ tmp[i]);
+            out[q].assign(tmp.begin(), tmp.begin() + c);
         }
     }
     if (nseg) {
@@ -193,8 +242,15 @@ static std::vector<uint64_t> collect(const Bufs& b, uint32_t nq, uint32_t nseg, 
         CK(hipMemcpy(sk.data(), b.candB, sk.size() * 8, hipMemcpyDeviceToHost));
         for (uint32_t q = 0; q < nq; ++q)
             for (uint32_t s = 0; s < nseg; ++s)
-                for (uint32_t i = 0; i < sc[(size_t)q * nseg + s]; ++i) keys.push_back(((uint64_t)q << 48) ^ sk[((size_t)q * nseg + s) * seg + i]);
+                for (uint32_t i = 0; i < sc[(size_t)q * nseg + s]; ++i) out[q].push_back(sk[((size_t)q * nseg + s) * seg + i]);
     }
+    return out;
+}
+static std::vector<uint64_t> collect(const Bufs& b, uint32_t nq, uint32_t nseg, uint32_t seg) {
+    std::vector<uint64_t> keys;
+    const auto per = collect_q(b, nq, nseg, seg);
+    for (uint32_t q = 0; q < nq; ++q)
+        for (uint64_t k : per[q]) keys.push_back(((uint64_t)q << 48) ^ k);
     std::sort(keys.begin(), keys.end());
     return keys;
 }
@@ -205,6 +261,7 @@ int main(int argc, char** argv) {
     const double sigma_tight = argc > 3 ? atof(argv[3]) : 4.3;   // thresholds in units of the dot product's standard deviation
     const int only = argc > 4 ? atoi(argv[4]) : -1;
     const double sigma_loose = argc > 7 ? atof(argv[7]) : 3.6;
+    const double sts_marg_sd = argc > 8 ? atof(argv[8]) : 0.45;   // STS margin in units of the dot product's sd (bench data: 2E ~ 0.5 sd)
     const int long_reps = argc > 5 ? atoi(argv[5]) : 20, long_warm = argc > 6 ? atoi(argv[6]) : 25;
     Sampler sampler;
     sampler.start();
@@ -221,6 +278,7 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&b.candB, (size_t)NQ * SEG_KEYS * 8));
     CK(hipMalloc(&b.segcnt, (size_t)NQ * 4096));
     CK(hipMalloc(&b.count, NQ * 4));
+    CK(hipMalloc(&b.dyn_thr, NQ * 4)); CK(hipMalloc(&b.dyn_marg, NQ * 4)); CK(hipMalloc(&b.dyn_slot, NQ * 32 * 4));
     CK(hipMalloc(&b.dbg, 4096 * 16));
     CK(hipMemset(b.dbg, 0, 4096 * 16));
     hipLaunchKernelGGL(k_fill_rows, dim3(ncu * 8), dim3(256), 0, 0, b.V, n_big * D, 7ull);
@@ -245,6 +303,8 @@ int main(int argc, char** argv) {
     vars.push_back({"qs RB1 SL6 NS6 XPF NBUF8", 2, launch_qs<6, 1, 6, 6, true, 8, 0>, true});
     vars.push_back({"qs RB2 SL3 NS6 XPF NBUF8", 2, launch_qs<6, 2, 3, 6, true, 8, 0>, true});
     vars.push_back({"qs RB2 SL6 NS3 noXPF NBUF8", 2, launch_qs<6, 2, 6, 3, false, 8, 0>, true});
+    vars.push_back({"qs RB2 SL6 NS3 noXPF NBUF8 STS", 2, launch_qs<6, 2, 6, 3, false, 8, 0, 0, 1>, true});
+    vars.push_back({"qs RB2 SL6 NS3 noXPF NBUF8 PP1 STS", 2, launch_qs<6, 2, 6, 3, false, 8, 0, 1, 1>, true});
     vars.push_back({"qs RB1 SL6 NS6 XPF NBUF8 PP1", 2, launch_qs<6, 1, 6, 6, true, 8, 0, 1>, true});
     vars.push_back({"qs RB1 SL6 NS6 XPF NBUF8 PP2", 2, launch_qs<6, 1, 6, 6, true, 8, 0, 2>, true});
     vars.push_back({"qs RB1 SL6 NS6 XPF NBUF12 PP1", 2, launch_qs<6, 1, 6, 6, true, 12, 0, 1>, true});
@@ -261,6 +321,11 @@ int main(int argc, char** argv) {
     vars.push_back({"qs RB1 SL6 NS6 XPF NBUF8 | phase timing", 2, launch_qs<6, 1, 6, 6, true, 8, 32>, true});
     vars.push_back({"qs RB1 SL6 NS6 XPF NBUF8 PP1 | phase timing", 2, launch_qs<6, 1, 6, 6, true, 8, 32, 1>, true});
     vars.push_back({"qs RB1 SL6 NS6 XPF NBUF8 PP1 | no epilogue", 2, launch_qs<6, 1, 6, 6, true, 8, 16, 1>, true});
+    vars.push_back({"qs RB2 SL6 NS3 noXPF NBUF8 STS | no emission", 2, launch_qs<6, 2, 6, 3, false, 8, 0, 0, 1>, true});
+    vars.push_back({"qs RB2 SL6 NS3 noXPF NBUF8 STS | no emission noseedkernel", 2, launch_qs<6, 2, 6, 3, false, 8, 0, 0, 1>, true});
+    vars.push_back({"qs RB2 SL6 NS3 noXPF NBUF8 PP1 STS | no emission noseedkernel", 2, launch_qs<6, 2, 6, 3, false, 8, 0, 1, 1>, true});
+    vars.push_back({"qs RB2 SL6 NS3 noXPF NBUF8 PP1 | no emission", 2, launch_qs<6, 2, 6, 3, false, 8, 0, 1, 0>, true});
+    vars.push_back({"qs RB2 SL6 NS3 noXPF NBUF8 | no emission", 2, launch_qs<6, 2, 6, 3, false, 8, 0, 0, 0>, true});
     vars.push_back({"qs RB1 SL6 NS6 | lone wave, MFMA only", 2, launch_qs<6, 1, 6, 6, true, 8, 64 + 16 + 8 + 2>, true});
     vars.push_back({"qs RB2 SL3 NS6 | lone wave, MFMA only", 2, launch_qs<6, 2, 3, 6, true, 8, 64 + 16 + 8 + 2>, true});
     vars.push_back({"qs RB1 SL6 NS6 | lone wave, MFMA + LDS reads", 2, launch_qs<6, 1, 6, 6, true, 8, 64 + 16 + 8>, true});
@@ -295,6 +360,59 @@ int main(int argc, char** argv) {
         for (size_t vi = 0; vi < vars.size(); ++vi) {
             const Variant& v = vars[vi];
             if (v.name.find('|') != std::string::npos) continue;
+            if (v.name.find("STS") != std::string::npos) {
+                // self-tightening thresholds: the emitted set depends on timing; it must hold every (query, row) with
+                // dot >= final tau - margin, only true scores, no duplicates, and tau must be reached by >= ks rows
+                if (pass != 0 && pass != 2) continue;
+                const int marg = (int)(0.5 * sd);
+                int* dots; CK(hipMalloc(&dots, (size_t)nq * n * 4));
+                hipLaunchKernelGGL(k_all_dots, dim3((n + 63) / 64), dim3(256), 0, 0, b.V, D, D, n, b.Qp, nq, dots);
+                std::vector<int> hd((size_t)nq * n);
+                CK(hipMemcpy(hd.data(), dots, hd.size() * 4, hipMemcpyDeviceToHost));
+                CK(hipFree(dots));
+                for (int starve = 0; starve < 2; ++starve) {
+                    ScanArgs a = base_args(b, 0, n, nq);
+                    const uint32_t grid = std::min((n + 31) / 32, ncu);
+                    a.nseg = grid * v.segs_per_wg;
+                    a.seg = starve ? 4u : std::min<uint32_t>(255u, SEG_KEYS / a.nseg);
+                    clear(a.nseg);
+                    hipLaunchKernelGGL(k_seed, dim3(nq), dim3(256), 0, 0, b.V, D, D, n, b.Qp, 64u, a.dyn_ks, 320u, b.dyn_thr, b.dyn_slot, b.dyn_marg, marg);
+                    v.launch(a, ncu, 0);
+                    CK(hipDeviceSynchronize());
+                    const auto per = collect_q(b, nq, a.nseg, a.seg);
+                    std::vector<int> tau(nq);
+                    CK(hipMemcpy(tau.data(), b.dyn_thr, nq * 4, hipMemcpyDeviceToHost));
+                    size_t wrong = 0, dup = 0, missing = 0, weak = 0, expect = 0, got_n = 0;
+                    std::vector<std::vector<uint32_t>> rows_of(nq);
+                    for (uint32_t q = 0; q < nq; ++q)
+                        for (uint64_t key : per[q]) {
+                            ++got_n;
+                            const uint32_t row = (uint32_t)(key & 0xffffffffu);
+                            if (row < n && make_key((float)hd[(size_t)q * n + row], row, false) == key) rows_of[q].push_back(row);
+                            else ++wrong;
+                        }
+                    std::vector<uint32_t> cnts(nq);
+                    CK(hipMemcpy(cnts.data(), b.count, nq * 4, hipMemcpyDeviceToHost));
+                    size_t overflowed = 0;
+                    for (uint32_t q = 0; q < nq; ++q) {
+                        if (cnts[q] > b.cap) { ++overflowed; continue; }   // (the library reruns such a query on the next plan)
+                        std::sort(rows_of[q].begin(), rows_of[q].end());
+                        for (size_t i = 1; i < rows_of[q].size(); ++i) dup += rows_of[q][i] == rows_of[q][i - 1];
+                        size_t reach = 0;
+                        for (uint32_t r = 0; r < n; ++r) {
+                            const int d = hd[(size_t)q * n + r];
+                            reach += d >= tau[q];
+                            if (d >= tau[q] - marg) { ++expect; if (!std::binary_search(rows_of[q].begin(), rows_of[q].end(), r)) ++missing; }
+                        }
+                        weak += reach < a.dyn_ks;
+                    }
+                    const bool ok = !wrong && !dup && !missing && !weak;
+                    if (!ok) ++bad;
+                    printf("STS pass %d %-36s starve %d: %zu keys emitted, %zu required; wrong %zu dup %zu missing %zu taus-not-reached %zu overflowed-queries %zu%s\n", pass, v.name.c_str(), starve,
+                           got_n, expect, wrong, dup, missing, weak, overflowed, ok ? "" : "   <-- MISMATCH");
+                }
+                continue;
+            }
             for (int starve = 0; starve < 2; ++starve) {
                 ScanArgs a = base_args(b, 0, n, nq);
                 const uint32_t tiles = v.qs ? (n + 31) / 32 : (n + 255) / 256;   // (an upper bound of the grid is enough for nseg)
@@ -336,14 +454,35 @@ int main(int argc, char** argv) {
                 a.nseg = ncu * v.segs_per_wg;
                 a.seg = std::min<uint32_t>(255u, SEG_KEYS / a.nseg);
                 a.debug_flags = 64; a.dbg = b.dbg;
+                if (v.name.find("no emission") != std::string::npos) a.debug_flags |= 2;
+                if (v.name.find("nowarm") != std::string::npos) a.dyn_warm = 0;
+                if (v.name.find("norefresh") != std::string::npos) a.debug_flags |= 256;
                 const int reps = long_reps;
-                for (int w = 0; w < long_warm; ++w) { if (w < 2) clear(a.nseg); v.launch(a, ncu, 0); }   // warm: clocks / power settle under THIS variant
+                const bool sts = v.name.find("STS") != std::string::npos;
+                const bool noseed = v.name.find("noseedkernel") != std::string::npos;
+                // (the stand-in seed kernel of this tool costs ~80 us; the library seeds inside k_i8c_prep_queries.  Timed STS runs restore the
+                // seeded state with three small copies instead)
+                const bool fastseed = sts && !noseed;
+                static int *seed_thr = nullptr, *seed_slot = nullptr;
+                if (fastseed) {
+                    if (!seed_thr) { CK(hipMalloc(&seed_thr, NQ * 4)); CK(hipMalloc(&seed_slot, NQ * 32 * 4)); }
+                    hipLaunchKernelGGL(k_seed, dim3(NQ), dim3(256), 0, 0, b.V, D, D, n, b.Qp, 64u, a.dyn_ks, 320u, b.dyn_thr, b.dyn_slot, b.dyn_marg, (int)(sts_marg_sd * sd));
+                    CK(hipMemcpyAsync(seed_thr, b.dyn_thr, NQ * 4, hipMemcpyDeviceToDevice, 0));
+                    CK(hipMemcpyAsync(seed_slot, b.dyn_slot, NQ * 32 * 4, hipMemcpyDeviceToDevice, 0));
+                }
+                auto reseed = [&]() {
+                    if (!fastseed) return;
+                    CK(hipMemcpyAsync(b.dyn_thr, seed_thr, NQ * 4, hipMemcpyDeviceToDevice, 0));
+                    CK(hipMemcpyAsync(b.dyn_slot, seed_slot, NQ * 32 * 4, hipMemcpyDeviceToDevice, 0));
+                };
+                auto seed = [&]() { if (sts && !noseed && !fastseed) hipLaunchKernelGGL(k_seed, dim3(NQ), dim3(256), 0, 0, b.V, D, D, n, b.Qp, 64u, a.dyn_ks, 320u, b.dyn_thr, b.dyn_slot, b.dyn_marg, (int)(sts_marg_sd * sd)); };
+                for (int w = 0; w < long_warm; ++w) { if (w < 2) clear(a.nseg); seed(); reseed(); v.launch(a, ncu, 0); }   // warm: clocks / power settle under THIS variant
                 clear(a.nseg);
                 CK(hipDeviceSynchronize());
                 const auto w0 = std::chrono::system_clock::now();
                 sampler.begin();
                 CK(hipEventRecord(e0, 0));
-                for (int i = 0; i < reps; ++i) v.launch(a, ncu, 0);
+                for (int i = 0; i < reps; ++i) { seed(); reseed(); v.launch(a, ncu, 0); }
                 CK(hipEventRecord(e1, 0));
                 CK(hipEventSynchronize(e1));
                 const auto w1 = std::chrono::system_clock::now();
@@ -354,6 +493,17 @@ int main(int argc, char** argv) {
                     unsigned long long tk[2];
                     CK(hipMemcpy(tk, b.dbg, 16, hipMemcpyDeviceToHost));
                     clk[vi] = (double)(tk[1] - tk[0]) / (t / reps * 1e3);   // ticks per microsecond = MHz (kernel span of workgroup 0 ~ launch)
+                }
+                if (r == rounds && sts && v.name.find("no emission") == std::string::npos) {   // how many keys the launch emitted per query
+                    clear(a.nseg); reseed(); seed(); v.launch(a, ncu, 0);
+                    CK(hipDeviceSynchronize());
+                    const auto per = collect_q(b, NQ, a.nseg, a.seg);
+                    size_t mx = 0, tot = 0;
+                    for (auto& pq : per) { mx = std::max(mx, pq.size()); tot += pq.size(); }
+                    std::vector<uint32_t> cnts(NQ);
+                    CK(hipMemcpy(cnts.data(), b.count, NQ * 4, hipMemcpyDeviceToHost));
+                    uint32_t cmax = 0; for (uint32_t c : cnts) cmax = std::max(cmax, c);
+                    printf("KEYS %s: %.0f per query on average, %zu at most; shared-region count at most %u (cap %u), segment slots %u\n", v.name.c_str(), (double)tot / NQ, mx, cmax, b.cap, a.seg);
                 }
                 if (r == rounds && v.name.find("phase timing") != std::string::npos) {
                     std::vector<unsigned long long> ph(64 * 8 * 4);
