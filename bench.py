@@ -314,7 +314,8 @@ def main():
             kernel, elem_bytes, mfma_peak, mfma_unit = "k_scan_binary_rows", None, None, None
             kernel_bytes = alg_bytes
         elif i8c:
-            kernel, elem_bytes, mfma_peak, mfma_unit = "k_scan_h16<2,4,4,2,IP,i8c>", 1, MFMA_I8_PEAK_TOPS, "TOP/s"
+            qs_tiling = ((plan >> 16) & 0xff) == 0x81   # threshold stages on the query-stationary tiling (scan_qs.h)
+            kernel, elem_bytes, mfma_peak, mfma_unit = ("k_scan_qs<6,2,6,3,...> (int8, query-stationary)" if qs_tiling else "k_scan_h16<2,4,4,2,IP,i8c>"), 1, MFMA_I8_PEAK_TOPS, "TOP/s"
             kernel_bytes = float(n_local) * (-(-D // 16) * 16) * timed_steps
         else:
             kernel, elem_bytes, mfma_peak, mfma_unit = "k_scan_h16<f16>", 2, MFMA_F16_PEAK_TFLOPS, "TFLOP/s"
@@ -327,11 +328,12 @@ def main():
         frac_mfma = (mfma_rate / mfma_peak) if mfma_peak else 0.0
         traffic, traffic_note = None, "no PMC summary under profiles/ for this kernel"
         try:  # HBM bytes per launch from the committed PMC pass (bench.py itself cannot run rocprofv3 --pmc)
-            pm = json.loads((ROOT / "profiles" / "r03_pmc_traffic.json").read_text())
+            pm_file = next(f for f in ("r04_pmc_traffic.json", "r03_pmc_traffic.json") if (ROOT / "profiles" / f).exists())
+            pm = json.loads((ROOT / "profiles" / pm_file).read_text())
             pm = pm["i8c" if i8c else ("binary" if metric >= 3 else "f16")]
             traffic = int(kernel_bytes / launches * pm["ratio_hbm_over_kernel_bytes"])
-            traffic_note = "kernel stream bytes x %.4f (FETCH_SIZE, gfx950-corrected x2; %s)" % (
-                pm["ratio_hbm_over_kernel_bytes"], "profiles/r03_pmc_traffic.json")
+            traffic_note = "from profiles/: kernel stream bytes x %.4f (FETCH_SIZE of a separate rocprofv3 --pmc pass, gfx950-corrected x2; profiles/%s)" % (
+                pm["ratio_hbm_over_kernel_bytes"], pm_file)
         except Exception:
             pass
         hbm_bound = frac_hbm >= frac_mfma
@@ -352,7 +354,7 @@ def main():
             "launches_per_step": round(launches / timed_steps, 2), "timed_steps": timed_steps,
             "plan": {"sampled": bool(plan & 1), "threshold_only_sample": bool(plan & 2), "int8_coarse_pass": i8c,
                      "segmented_emission": bool(plan & 8), "fused_sample_stage": bool(plan & 128), "stages": (plan >> 8) & 0xff,
-                     "tiling": hex((plan >> 16) & 0xff)},
+                     "tiling": hex((plan >> 16) & 0xff), "self_tightening_single_launch": bool(plan & (1 << 24))},
             "note": ("rank-0 shard; time = sum of HIP-event durations of the scan launches on the launch stream, every %d-th step of the timed region" % max(args.profile_every, 1))
                     + ("; with %d batches in flight the event brackets of a launch also hold the time it waits for CUs behind other batches' kernels "
                        "(kernel durations proper: the one-GPU line / profiles/)" % in_flight if in_flight > 1 else ""),

@@ -1307,9 +1307,29 @@ static int launch_scan_i8c_small(const ScanArgs& a, uint32_t grid, hipStream_t s
     return go(k_scan_h16<1, 4, 1, 1, M_IP, 3, 3, 2, false, true, 0, false, 2>, 1);
 }
 
+// Squared L2 on the query-stationary tiling (scan_qs.h, MET = 1): threshold stages of unfiltered batches of 129..256 queries over code
+// rows of 768 bytes (64-row tiles).  Rows per tile, or 0.
+static uint32_t qs_l2_rows(const ScanArgs& a) {
+    const char* e = getenv("LYNSE_HIP_QS");
+    if (e && atoi(e) == 0) return 0;
+    if (a.emit_all != 0 || a.qpad != 256 || a.nq > 256 || a.tile_stride != 0 || a.skip_stride != 0 || a.mask || a.row_ids || a.row1 <= a.row0) return 0;
+    if (a.ld16 == 768 && a.nslab == 6) return 64;
+    return 0;
+}
+static int launch_scan_qs_l2(const ScanArgs& a, uint32_t grid, hipStream_t st) {
+    static bool attr_done = false;
+    auto kern = k_scan_qs<6, 2, 6, 3, false, 8, 0, 1, 0, 1>;
+    constexpr size_t lds = (size_t)3 * 6 * 64 * 128 + 4 * 256;
+    if (!attr_done) { LY_TRY(set_max_lds(kern, lds)); attr_done = true; }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, a);
+    LY_HIP(hipGetLastError());
+    return LYNSE_OK;
+}
+
 // squared L2 on the plain SQ8 codes (kernels.h, I8Q = 4): the <4,2,2,4> L2 tiling with 2 + 2-stage rings and the norm ring, int8
 // operands, float epilogue; whole 128-column slabs
-static int launch_scan_i8l2(const ScanArgs& a, uint32_t grid, hipStream_t st) {
+static int launch_scan_i8l2(const ScanArgs& a, uint32_t grid, hipStream_t st, bool qs = false) {
+    if (qs) return launch_scan_qs_l2(a, grid, st);
     constexpr size_t lds = (size_t)(2 * 256 + 2 * 256) * 128 + 3 * 1024;
     static bool attr_done[4] = {false, false, false, false};
     auto go = [&](auto kern, int slot) -> int {
@@ -1869,11 +1889,16 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
                 LY_TRY(launch_scan_i8c_mid(a, grid, st, mid128, l2n, filt));
             } else if (l2n) {
                 a.candB = w.candB; a.segcnt = w.segcnt;
-                const uint32_t grid = std::min<uint32_t>(a.ntiles, (uint32_t)h->num_cu);
+                uint32_t grid = std::min<uint32_t>(a.ntiles, (uint32_t)h->num_cu);
                 const uint64_t seen_before = s.sample_tiles ? 0 : (sample.sample_tiles ? std::max<uint64_t>((uint64_t)sample.sample_tiles * plan_tile, s.r0) : s.r0);
                 a.dense = (!a.emit_all && seen_before) ? 1 : 0;   // (the DENSE float epilogue, like every L2 threshold stage of the f16 shadow)
-                if (!a.emit_all) seg_geometry(grid, a.dense ? 4 : 2, &a.nseg, &a.seg);
-                LY_TRY(launch_scan_i8l2(a, grid, st));
+                const uint32_t qs_rt = qs_l2_rows(a);   // threshold stages on the query-stationary tiling (scan_qs.h, MET = 1)
+                if (qs_rt) {
+                    grid = std::min<uint32_t>((a.row1 - a.row0 + qs_rt - 1) / qs_rt, (uint32_t)h->num_cu);
+                    seg_geometry(grid, 2, &a.nseg, &a.seg);
+                    plan_used_qs = true;
+                } else if (!a.emit_all) seg_geometry(grid, a.dense ? 4 : 2, &a.nseg, &a.seg);
+                LY_TRY(launch_scan_i8l2(a, grid, st, qs_rt != 0));
             } else if (i8c) {
                 a.candB = w.candB; a.segcnt = w.segcnt;
                 const uint32_t grid = std::min<uint32_t>(a.ntiles, (uint32_t)h->num_cu);
@@ -2366,7 +2391,11 @@ static std::atomic<int>& i8c_strike_counter(lynse_hip_flat* h, int metric) {
 // batch" (IVF): the augmented form.  LYNSE_HIP_L2_PLAIN=0: always the augmented form.
 static bool l2_plain(const lynse_hip_flat* h, uint64_t nqc, bool masked) {
     static const int on = []() { const char* e = getenv("LYNSE_HIP_L2_PLAIN"); return e ? atoi(e) : 1; }();
-    return on && !masked && nqc >= 1 && nqc <= QCHUNK && h->ld8 % 128 == 0 && h->dim >= 256;   // (1M x 128, k = 100: 0.244 ms on the f16 shadow, 0.277 on the codes)
+    // (1M x 128, k = 100: 0.244 ms on the f16 shadow, 0.277 on the codes with the <4,2,2,4> tiling and 0.291 with the query-stationary
+    // L2 tiling (k_scan_qs<1,4,1,6,.., MET = 1>, built and measured in round 4: at k = 100 the first threshold lets 0.8 % of all
+    // (row, query) pairs through and the scan is bound by the emission of ~8000 keys per query, not by the tiling) — from 256
+    // dimensions on)
+    return on && !masked && nqc >= 1 && nqc <= QCHUNK && h->ld8 % 128 == 0 && h->dim >= 256;
 }
 static bool i8c_codes_ready(const lynse_hip_flat* h, int metric, uint64_t nqc = 0, bool masked = false) {
     if (metric == M_L2 && !l2_plain(h, nqc, masked)) return h->sq8a && h->n_sq8a == h->n;

@@ -44,7 +44,11 @@ typedef int qs_i32x16 __attribute__((ext_vector_type(16)));
 constexpr int QS_STS_LDS = 8 * 256 + 8 * 256;   // landing areas behind the ring: per wave 64 thresholds + 64 partition maxima
 
 // DBG (timing experiments): 1 no MFMA, 2 no LDS fragment reads, 8 no row DMA, 16 no epilogue, 32 s_memtime phase sums, 64 waves 4-7 do not compute
-template <int NSLAB, int RB, int SL, int NS, bool XPF, int NBUF, int DBG = 0, int PING = 0, int STS = 0>
+// MET: 0 = inner product / cosine (integer threshold image), 1 = squared L2 on the PLAIN codes: the int8 dot product feeds a float
+// epilogue with the exact f32 row norms (coarse distance |v|^2 - 2 s_q dot + (|q|^2 - 2 B_q), k_i8c_prep_queries l2n; the norms of a
+// tile ride in a ring of NS + 1 slots behind the row ring, one small LDS-DMA per step by wave 0).  All lanes of a wave half hold the
+// SAME rows, so a lane reads the norms of its 16 RB rows as broadcast ds_read_b128s and scores them against ONE query's constants.
+template <int NSLAB, int RB, int SL, int NS, bool XPF, int NBUF, int DBG = 0, int PING = 0, int STS = 0, int MET = 0>
 __global__ void __launch_bounds__(512, 2) k_scan_qs(ScanArgs a) {
     static_assert(NSLAB % SL == 0, "a tile is a whole number of steps");
     constexpr int TS = NSLAB / SL;          // steps per tile
@@ -56,7 +60,11 @@ __global__ void __launch_bounds__(512, 2) k_scan_qs(ScanArgs a) {
     constexpr int NM = SL * 4 * RB;         // MFMAs per wave and step
     static_assert(NM % NBUF == 0 && NBUF >= 2 && NBUF <= NM, "fragment ring");
     static_assert(NS >= (XPF ? 4 : 3), "ring depth");
-    static_assert(NS * SB + (STS ? QS_STS_LDS : 0) <= 160 * 1024, "LDS");
+    constexpr int NRM = MET == 1 ? (RT == 64 ? 256 : 1024) : 0;   // bytes of row norms per tile slot (64 floats by one dword LDS-DMA, else 256 by one dwordx4)
+    constexpr int NRM_SLOTS = NS + 1;                        // (a slot is refilled two steps after its tile was computed: late epilogues are safe)
+    constexpr int NRM_OFF = NS * SB + (STS ? QS_STS_LDS : 0);
+    static_assert(MET == 0 || (STS == 0 && TS == 1 && RT <= 256), "L2: whole-K stages; one dword / dwordx4 LDS-DMA brings a tile's norms");
+    static_assert(NRM_OFF + NRM_SLOTS * NRM <= 160 * 1024, "LDS");
     static_assert(PING == 0 || TS == 1, "ping-pong: one step per tile");
     static_assert(STS == 0 || (!XPF && TS == 1), "self-tightening thresholds: whole-K stages, no cross-barrier prefetch");
     constexpr int WAITN = (XPF ? NS - 3 : NS - 2) * PPW;   // DMA instructions that may still be in flight at the barrier
@@ -109,7 +117,21 @@ __global__ void __launch_bounds__(512, 2) k_scan_qs(ScanArgs a) {
     const bool q_ok = qn < a.nq;
     const float s_q = q_ok ? a.qinv[qn] : 0.0f, b_q = q_ok ? a.qn2[qn] : 0.0f;
     int T = 0x7fffffff;
-    if constexpr (STS == 0) {
+    // L2: pass iff |v|^2 - 2 s_q dot + c_q <= thr.  Level 1 maximises 2 s_q dot - |v|^2 against pre = (c_q - thr) LOOSENED by more than the
+    // rounding differences between that form and the exact expression (k_scan_h16, set_pre); the slow path evaluates the exact expression.
+    [[maybe_unused]] float l2_thr = 0.0f, l2_pre = LY_INF, l2_2s = 0.0f;
+    if constexpr (MET == 1) {
+        l2_thr = q_ok ? a.thr[qn] : -LY_INF;
+        l2_2s = 2.0f * s_q;
+        const float vmax2 = a.vmax2;
+        float pre = (b_q - l2_thr) - 2e-6f * (b_q + fabsf(l2_thr) + vmax2);
+        if (!(vmax2 > 0.0f) || !(fabsf(pre) < 3.0e38f)) pre = -LY_INF;   // open threshold / overflow: no pre-filter
+        l2_pre = q_ok ? pre : LY_INF;
+#ifdef LYNSE_EXPERIMENTS
+        if (a.debug_flags & 2) l2_pre = LY_INF;
+#endif
+    }
+    if constexpr (STS == 0 && MET == 0) {
         // INTEGER image of the threshold (k_scan_h16, load_qc_thr): B_q + s_q * (float)dot is monotone non-decreasing in the
         // integer dot product, so "score >= thr" is exactly "dot >= T", T = the smallest passing dot (bisection over |dot| <= 2^29)
         const float th = q_ok ? a.thr[qn] : 0.0f;
@@ -177,6 +199,16 @@ __global__ void __launch_bounds__(512, 2) k_scan_qs(ScanArgs a) {
         if (DBG & 8) return;
         glds16<2>(v_base + (size_t)(is_sub * (SL * 128)) + v_off[j], smem + is_stage * SB + (wave * PPW + j) * 1024);
     };
+    [[maybe_unused]] auto issue_norms = [&]() {   // wave 0, once per step: the f32 norms of the tile being issued (rows past the end: the array's slack)
+        if constexpr (MET == 1) {
+            if (wave == 0) {
+                const uint32_t rbase = a.row0 + tile_of(is_ord) * RT;
+                char* dst = smem + NRM_OFF + (is_count % NRM_SLOTS) * NRM;
+                if constexpr (RT == 64) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.vn2 + rbase + lane), (__attribute__((address_space(3))) void*)dst, 4, 0, 0);
+                else glds16<0>(a.vn2 + rbase + lane * 4, dst);
+            }
+        }
+    };
     auto advance = [&]() {   // past the end the last real step is issued again (uniform DMA counts; its stage is never read)
         is_stage = is_stage + 1 == NS ? 0 : is_stage + 1;
         if (++is_count < G) {
@@ -192,6 +224,7 @@ __global__ void __launch_bounds__(512, 2) k_scan_qs(ScanArgs a) {
     for (int s0 = 0; s0 < NS - 1; ++s0) {
 #pragma unroll
         for (int j = 0; j < PPW; ++j) issue_piece(j);
+        issue_norms();
         advance();
     }
 
@@ -270,7 +303,10 @@ __global__ void __launch_bounds__(512, 2) k_scan_qs(ScanArgs a) {
     };
     [[maybe_unused]] uint32_t sts_extra = 0;   // 4-byte LDS-DMAs this wave issued behind the previous step's ring pieces (they may stay in flight too)
     auto wait_and_barrier = [&]() {
-        if constexpr (STS != 0) {
+        if constexpr (MET == 1) {   // wave 0 carries one more LDS-DMA per step (the norms)
+            if (wave == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAITN + (XPF ? NS - 3 : NS - 2)) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAITN) : "memory");
+        } else if constexpr (STS != 0) {
             if (sts_extra == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAITN) : "memory");
             else if (sts_extra == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAITN + 1) : "memory");
             else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAITN + 2) : "memory");
@@ -329,12 +365,74 @@ __global__ void __launch_bounds__(512, 2) k_scan_qs(ScanArgs a) {
         }
     };
     // ---- tile epilogue: this lane's RB x 16 dot products all belong to query qn
-    auto epilogue = [&](uint32_t e_tile, bool emit) {
+    auto epilogue = [&](uint32_t e_tile, bool emit, [[maybe_unused]] uint32_t e_ord_) {
         if constexpr ((DBG & 16) != 0) {
 #pragma unroll
             for (int i = 0; i < RB; ++i)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) asm volatile("" ::"v"(acc[i][r]));
+        } else if constexpr (MET == 1) {
+            // ---- squared L2: level 1 = max over the tile of 2 s_q dot - |v|^2 per group of four rows (their norms: one broadcast
+            // ds_read_b128 per group, issued by hand — a load the compiler can see is ordered behind every LDS-DMA in flight with
+            // s_waitcnt vmcnt(0)), then ONE ballot; groups with a candidate run the exact expression
+            const uint32_t nbase = lds0 + NRM_OFF + (e_ord_ % NRM_SLOTS) * NRM + (uint32_t)hi * 16u;
+            float gmf[RB][4];
+            f32x4 nvb[2][4];   // double buffer: the norms of row block i + 1 are in flight while block i is scored
+            // (plain unrolled loops: an asm operand cannot name a variable captured by a nested lambda)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) asm volatile("ds_read_b128 %0, %1" : "=v"(nvb[0][g]) : "v"(nbase + (uint32_t)(8 * g) * 4u));
+#pragma unroll
+            for (int i = 0; i < RB; ++i) {
+                if (i + 1 < RB) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) asm volatile("ds_read_b128 %0, %1" : "=v"(nvb[(i + 1) & 1][g]) : "v"(nbase + (uint32_t)((i + 1) * 32 + 8 * g) * 4u));
+                    asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(nvb[i & 1][0]), "+v"(nvb[i & 1][1]), "+v"(nvb[i & 1][2]), "+v"(nvb[i & 1][3]));
+                } else {
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(nvb[i & 1][0]), "+v"(nvb[i & 1][1]), "+v"(nvb[i & 1][2]), "+v"(nvb[i & 1][3]));
+                }
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float p[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) p[e] = __fmaf_rn((float)acc[i][4 * g + e], l2_2s, -nvb[i & 1][g][e]);
+                    gmf[i][g] = fmaxf(fmaxf(p[0], p[1]), fmaxf(p[2], p[3]));
+                }
+            }
+            float best = gmf[0][0];
+#pragma unroll
+            for (int i = 0; i < RB; ++i)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) best = fmaxf(best, gmf[i][g]);
+            if (__builtin_expect(__ballot(best >= l2_pre) != 0ull, 0)) {
+                const uint32_t rbase = a.row0 + e_tile * RT;
+                uint64_t* segdst = a.candB + ((size_t)qn * a.nseg + (blockIdx.x * 2 + hi)) * a.seg;
+#pragma unroll
+                for (int i = 0; i < RB; ++i) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        if (__builtin_expect(__ballot(gmf[i][g] >= l2_pre) == 0ull, 1)) continue;
+                        f32x4 nv;   // (the group's norms again: the fast path keeps only two row blocks of them)
+                        asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(nv) : "v"(nbase + (uint32_t)(i * 32 + 8 * g) * 4u));
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int r = 4 * g + e;
+                            float sc = (float)acc[i][r] * s_q;            // the exact coarse expression of k_scan_h16<.., I8Q = 4>: separate mul / add
+                            sc = nv[e] - 2.0f * sc + b_q;
+                            const uint32_t m = rbase + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                            if (q_ok && sc <= l2_thr && m < a.row1) {
+                                const uint64_t key = make_key(sc, m, true);
+                                if (cnt < a.seg) {
+                                    segdst[cnt] = key;
+                                    ++cnt;
+                                } else {
+                                    const uint32_t slot = atomicAdd(&a.count[qn], 1u);
+                                    if (slot < a.cap) a.cand[(size_t)qn * a.cap + slot] = key;
+                                }
+                            }
+                        }
+                    }
+                }
+            }
         } else {
             // maxima of the groups of four accumulators first (the slow path re-uses them), then their maximum
             int gm[RB][4];
@@ -400,12 +498,13 @@ __global__ void __launch_bounds__(512, 2) k_scan_qs(ScanArgs a) {
                     mfma_step(sc, std::true_type{});
                 }
                 if constexpr (STS != 0) sts_refresh();
+                issue_norms();
                 advance();
                 if constexpr (TIMING) asm volatile("" ::"v"(acc[0][0]));
                 stamp(t_loop);
             });
             if constexpr (STS != 0) sts_pickup();
-            epilogue(tile_of(c_ord), c_ord >= warm);
+            epilogue(tile_of(c_ord), c_ord >= warm, c_ord);
         }
     } else {
         // PING-PONG (PING): the two waves of a SIMD share one matrix pipe, and with equal priority the older wave wins every slot — waves
@@ -433,7 +532,7 @@ __global__ void __launch_bounds__(512, 2) k_scan_qs(ScanArgs a) {
             }
             if (pend) {
                 if constexpr (STS != 0) sts_pickup();
-                epilogue(tile_of(e_ord), e_ord >= warm);
+                epilogue(tile_of(e_ord), e_ord >= warm, e_ord);
                 ++e_ord;
                 pend = false;
             }
@@ -443,6 +542,7 @@ __global__ void __launch_bounds__(512, 2) k_scan_qs(ScanArgs a) {
 #pragma unroll
                 for (int j = 0; j < PPW; ++j) issue_piece(j);
                 if constexpr (STS != 0) sts_refresh();
+                issue_norms();
                 advance();
                 if (late) {
                     stamp(t_epi);

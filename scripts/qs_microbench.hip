@@ -15,6 +15,7 @@
 #include <atomic>
 #include <dirent.h>
 #include <fstream>
+#include <functional>
 #include <string>
 #include <thread>
 #include <type_traits>
@@ -48,12 +49,22 @@ __global__ void k_fill_queries(int8_t* plain, int8_t* img, uint32_t nq, uint32_t
 }
 // brute force: one workgroup per row block of 64 rows, thread = (row, query stripe)
 __global__ void __launch_bounds__(256) k_ref(const int8_t* V, uint32_t ld, uint32_t D, uint32_t n, const int8_t* Qp, uint32_t nq,
-                                             const int* T, uint64_t* out, uint32_t* out_n, uint32_t out_cap) {
+                                             const int* T, uint64_t* out, uint32_t* out_n, uint32_t out_cap,
+                                             const float* vn2 = nullptr, const float* sq = nullptr, const float* bq = nullptr, const float* thr = nullptr) {
     const uint32_t row = blockIdx.x * 64 + (threadIdx.x & 63);
     if (row >= n) return;
     for (uint32_t q = threadIdx.x >> 6; q < nq; q += 4) {
         int dot = 0;
         for (uint32_t d = 0; d < D; ++d) dot += (int)V[(size_t)row * ld + d] * (int)Qp[(size_t)q * D + d];
+        if (vn2) {   // squared L2 on the plain codes: |v|^2 - 2 s_q dot + c_q <= thr (separate mul / add like the kernels)
+            float sc = (float)dot * sq[q];
+            sc = vn2[row] - 2.0f * sc + bq[q];
+            if (sc <= thr[q]) {
+                const uint32_t slot = atomicAdd(out_n, 1u);
+                if (slot < out_cap) out[slot] = ((uint64_t)q << 48) ^ make_key(sc, row, true);
+            }
+            continue;
+        }
         if (dot >= T[q]) {
             const uint32_t slot = atomicAdd(out_n, 1u);
             if (slot < out_cap) out[slot] = ((uint64_t)q << 48) ^ make_key((float)dot, row, false);
@@ -166,6 +177,7 @@ struct Bufs {
     uint32_t* count = nullptr;
     unsigned long long* dbg = nullptr;
     int *dyn_thr = nullptr, *dyn_slot = nullptr, *dyn_marg = nullptr;
+    float* vn2 = nullptr;
     uint32_t cap = 16384;
 };
 
@@ -180,6 +192,7 @@ static ScanArgs base_args(const Bufs& b, uint32_t r0, uint32_t r1, uint32_t nq) 
     a.qinv = b.qinv; a.qn2 = b.qn2; a.qrinv = b.qinv; a.thr = b.thr;
     a.cand = b.cand; a.count = b.count; a.cap = b.cap; a.candB = b.candB; a.segcnt = b.segcnt;
     a.emit_all = 0;
+    a.vn2 = b.vn2; a.vrinv = b.vn2; a.vmax2 = 400.0f;
     a.dyn_thr = b.dyn_thr; a.dyn_slot = b.dyn_slot; a.dyn_marg = b.dyn_marg; a.dyn_ks = 10; a.dyn_warm = 4;
     return a;
 }
@@ -194,10 +207,10 @@ struct Variant {
     bool qs;
 };
 
-template <int NSLAB, int RB, int SL, int NS, bool XPF, int NBUF, int DBG, int PP = 0, int STS = 0>
+template <int NSLAB, int RB, int SL, int NS, bool XPF, int NBUF, int DBG, int PP = 0, int STS = 0, int MET = 0>
 static void launch_qs(ScanArgs a, uint32_t grid, hipStream_t st) {
-    auto k = k_scan_qs<NSLAB, RB, SL, NS, XPF, NBUF, DBG, PP, STS>;
-    constexpr size_t lds = (size_t)NS * SL * RB * 32 * 128 + (STS ? QS_STS_LDS : 0);
+    auto k = k_scan_qs<NSLAB, RB, SL, NS, XPF, NBUF, DBG, PP, STS, MET>;
+    constexpr size_t lds = (size_t)NS * SL * RB * 32 * 128 + (STS ? QS_STS_LDS : 0) + (MET == 1 ? (NS + 1) * RB * 32 * 4 : 0);
     static bool done = false;
     if (!done) { set_lds(k, lds); done = true; }
     const uint32_t nt = (a.row1 - a.row0 + RB * 32 - 1) / (RB * 32);
@@ -210,6 +223,16 @@ static void launch_qs(ScanArgs a, uint32_t grid, hipStream_t st) {
         g = (nt + pitch - 1) / pitch;
     }
     hipLaunchKernelGGL(k, dim3(g), dim3(512), lds, st, a);
+}
+// the round-3 squared-L2 kernel on the plain codes (<4,2,2,4> tiling, DENSE float epilogue, norm ring)
+static void launch_old_l2(ScanArgs a, uint32_t grid, hipStream_t st) {
+    auto k = k_scan_h16<4, 2, 2, 4, M_L2, 2, 2, 2, false, false, 0, false, 4, 0, 0, true>;
+    constexpr size_t lds = (size_t)(2 * 256 + 2 * 256) * 128 + 4 * 1024;
+    static bool done = false;
+    if (!done) { set_lds(k, lds); done = true; }
+    a.ntiles = (a.row1 - a.row0 + 255) / 256;
+    a.dense = 1;
+    hipLaunchKernelGGL(k, dim3(std::min(grid, a.ntiles)), dim3(512), lds, st, a);
 }
 template <bool DENSE, int DBG>
 static void launch_old(ScanArgs a, uint32_t grid, hipStream_t st) {
@@ -278,6 +301,12 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&b.candB, (size_t)NQ * SEG_KEYS * 8));
     CK(hipMalloc(&b.segcnt, (size_t)NQ * 4096));
     CK(hipMalloc(&b.count, NQ * 4));
+    CK(hipMalloc(&b.vn2, (n_big + 4096) * 4));
+    {
+        std::vector<float> hv(n_big + 4096);
+        for (size_t i = 0; i < hv.size(); ++i) hv[i] = 200.0f + (float)(mix(i * 77 + 5) % 100000) * 1e-3f;
+        CK(hipMemcpy(b.vn2, hv.data(), hv.size() * 4, hipMemcpyHostToDevice));
+    }
     CK(hipMalloc(&b.dyn_thr, NQ * 4)); CK(hipMalloc(&b.dyn_marg, NQ * 4)); CK(hipMalloc(&b.dyn_slot, NQ * 32 * 4));
     CK(hipMalloc(&b.dbg, 4096 * 16));
     CK(hipMemset(b.dbg, 0, 4096 * 16));
@@ -287,6 +316,13 @@ int main(int argc, char** argv) {
     CK(hipDeviceSynchronize());
     // dot product of a uniform byte in [-128,127] with a uniform byte in [-127,127]: sd = 73.9 * 73.3 per term
     const double sd = std::sqrt((double)D) * 73.9 * 73.3;
+    auto set_thr_l2 = [&](double sig, uint32_t nq) {
+        std::vector<float> sq(NQ, 1.0e-3f), bq(NQ), th(NQ);
+        for (uint32_t q = 0; q < NQ; ++q) { bq[q] = 10.0f + (float)(q % 5); th[q] = q < nq ? (float)(200.0 + bq[q] - 2.0e-3 * sig * sd + 0.01 * (q % 7)) : -1e30f; }
+        CK(hipMemcpy(b.qinv, sq.data(), NQ * 4, hipMemcpyHostToDevice));
+        CK(hipMemcpy(b.qn2, bq.data(), NQ * 4, hipMemcpyHostToDevice));
+        CK(hipMemcpy(b.thr, th.data(), NQ * 4, hipMemcpyHostToDevice));
+    };
     auto set_thr = [&](double sig, uint32_t nq) {
         std::vector<float> one(NQ, 1.0f), zero(NQ, 0.0f), th(NQ);
         std::vector<int> ti(NQ);
@@ -305,6 +341,9 @@ int main(int argc, char** argv) {
     vars.push_back({"qs RB2 SL6 NS3 noXPF NBUF8", 2, launch_qs<6, 2, 6, 3, false, 8, 0>, true});
     vars.push_back({"qs RB2 SL6 NS3 noXPF NBUF8 STS", 2, launch_qs<6, 2, 6, 3, false, 8, 0, 0, 1>, true});
     vars.push_back({"qs RB2 SL6 NS3 noXPF NBUF8 PP1 STS", 2, launch_qs<6, 2, 6, 3, false, 8, 0, 1, 1>, true});
+    vars.push_back({"L2 old<4,2,2,4> DENSE", 4, launch_old_l2, false});
+    vars.push_back({"L2 qs RB2 SL6 NS3 noXPF NBUF8 PP1", 2, launch_qs<6, 2, 6, 3, false, 8, 0, 1, 0, 1>, true});
+    vars.push_back({"L2 qs RB2 SL6 NS3 noXPF NBUF8", 2, launch_qs<6, 2, 6, 3, false, 8, 0, 0, 0, 1>, true});
     vars.push_back({"qs RB1 SL6 NS6 XPF NBUF8 PP1", 2, launch_qs<6, 1, 6, 6, true, 8, 0, 1>, true});
     vars.push_back({"qs RB1 SL6 NS6 XPF NBUF8 PP2", 2, launch_qs<6, 1, 6, 6, true, 8, 0, 2>, true});
     vars.push_back({"qs RB1 SL6 NS6 XPF NBUF12 PP1", 2, launch_qs<6, 1, 6, 6, true, 12, 0, 1>, true});
@@ -357,9 +396,28 @@ int main(int argc, char** argv) {
         CK(hipMemcpy(ref.data(), ref_d, ref.size() * 8, hipMemcpyDeviceToHost));
         std::sort(ref.begin(), ref.end());
         CK(hipFree(ref_d)); CK(hipFree(ref_n));
+        std::vector<uint64_t> ref_l2;
+        {
+            set_thr_l2(sig, nq);
+            uint64_t* rd; uint32_t* rn2;
+            const uint32_t rc = 4u << 20;
+            CK(hipMalloc(&rd, (size_t)rc * 8)); CK(hipMalloc(&rn2, 4)); CK(hipMemset(rn2, 0, 4));
+            hipLaunchKernelGGL(k_ref, dim3((n + 63) / 64), dim3(256), 0, 0, b.V, D, D, n, b.Qp, nq, b.Ti, rd, rn2, rc, b.vn2, b.qinv, b.qn2, b.thr);
+            CK(hipDeviceSynchronize());
+            uint32_t rnn; CK(hipMemcpy(&rnn, rn2, 4, hipMemcpyDeviceToHost));
+            ref_l2.resize(std::min(rnn, rc));
+            CK(hipMemcpy(ref_l2.data(), rd, ref_l2.size() * 8, hipMemcpyDeviceToHost));
+            std::sort(ref_l2.begin(), ref_l2.end());
+            CK(hipFree(rd)); CK(hipFree(rn2));
+            set_thr(sig, nq);
+        }
         for (size_t vi = 0; vi < vars.size(); ++vi) {
             const Variant& v = vars[vi];
             if (v.name.find('|') != std::string::npos) continue;
+            const bool l2v = v.name.rfind("L2", 0) == 0;
+            if (l2v) set_thr_l2(sig, nq);
+            struct Restore { std::function<void()> f; ~Restore() { f(); } } restore{[&]() { if (l2v) set_thr(sig, nq); }};
+            const std::vector<uint64_t>& ref_use = l2v ? ref_l2 : ref;
             if (v.name.find("STS") != std::string::npos) {
                 // self-tightening thresholds: the emitted set depends on timing; it must hold every (query, row) with
                 // dot >= final tau - margin, only true scores, no duplicates, and tau must be reached by >= ks rows
@@ -423,6 +481,7 @@ int main(int argc, char** argv) {
                 v.launch(a, ncu, 0);
                 CK(hipDeviceSynchronize());
                 std::vector<uint64_t> got = collect(b, nq, a.nseg, a.seg);
+                const std::vector<uint64_t>& ref = ref_use;
                 const bool ok = got == ref;
                 if (!ok) {
                     ++bad;
@@ -435,13 +494,14 @@ int main(int argc, char** argv) {
                 }
             }
         }
-        printf("check pass %d: n %u nq %u sigma %.1f -> %zu reference keys; mismatching variants so far %d\n", pass, n, nq, sig, ref.size(), bad);
+        printf("check pass %d: n %u nq %u sigma %.1f -> %zu reference keys (L2: %zu); mismatching variants so far %d\n", pass, n, nq, sig, ref.size(), ref_l2.size(), bad);
     }
 
     // ---- 2. timing
     for (double sig : {sigma_tight, sigma_loose}) {
         set_thr(sig, NQ);
         const uint32_t n = (uint32_t)n_big;
+        bool prev_l2 = false;
         std::vector<std::vector<float>> ms(vars.size());
         std::vector<double> clk(vars.size(), 0.0), watts(vars.size(), 0.0), smhz(vars.size(), 0.0);
         hipEvent_t e0, e1;
@@ -458,6 +518,9 @@ int main(int argc, char** argv) {
                 if (v.name.find("nowarm") != std::string::npos) a.dyn_warm = 0;
                 if (v.name.find("norefresh") != std::string::npos) a.debug_flags |= 256;
                 const int reps = long_reps;
+                const bool l2v = v.name.rfind("L2", 0) == 0;
+                if (l2v) set_thr_l2(sig, NQ); else if (prev_l2) set_thr(sig, NQ);
+                prev_l2 = l2v;
                 const bool sts = v.name.find("STS") != std::string::npos;
                 const bool noseed = v.name.find("noseedkernel") != std::string::npos;
                 // (the stand-in seed kernel of this tool costs ~80 us; the library seeds inside k_i8c_prep_queries.  Timed STS runs restore the

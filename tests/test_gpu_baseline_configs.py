@@ -132,13 +132,22 @@ def test_l2_768_batch256_runs_the_certified_int8_pass(L, oracle):
     rows, dists, counts = idx.search_batch_arrays(queries, k, "l2")
     p = idx.profile_get(reset=True)
     flags, stages, tiling = plan_fields(p)
-    assert p["fallback_queries"] == 0 and tiling == 0x42 and flags & PLAN_I8C and flags & PLAN_SAMPLED and flags & PLAN_THRESHOLD_ONLY, (p, bin(flags))
+    # threshold stages on the query-stationary tiling in its L2 form (k_scan_qs<.., MET = 1>: int8 dot products, exact f32 row norms)
+    assert p["fallback_queries"] == 0 and tiling == 0x81 and flags & PLAN_I8C and flags & PLAN_SAMPLED and flags & PLAN_THRESHOLD_ONLY, (p, bin(flags))
     for qi in (0, 1, 31, 32, 100, 128, 200, 255):
         assert_rows_equal(oracle.canonical_topk(queries[qi], data, k, O.L2), rows[qi], dists[qi], counts[qi], ("l2", qi))
         assert rows[qi, 0] == q_rows[qi]
     import os
+    os.environ["LYNSE_HIP_QS"] = "0"     # ... and on the <4,2,2,4> tiling of k_scan_h16<.., I8Q = 4> (the round-3 default): identical bits
+    try:
+        r0, d0, c0 = idx.search_batch_arrays(queries, k, "l2")
+        p0 = idx.profile_get(reset=True)
+    finally:
+        del os.environ["LYNSE_HIP_QS"]
+    assert plan_fields(p0)[2] == 0x42 and plan_fields(p0)[0] & PLAN_I8C and p0["fallback_queries"] == 0, p0
+    assert np.array_equal(r0, rows) and np.array_equal(d0.view(np.uint32), dists.view(np.uint32)) and np.array_equal(c0, counts)
     # 100 queries: the 256 x 128 tiling of the plain-code form (and, with the mid tilings off, the 256-query one); 48 queries: 128 x 64
-    for nqs, env, want in ((100, {}, 0x24), (100, {"LYNSE_HIP_MID_TILINGS": "0"}, 0x42), (48, {}, 0x14)):
+    for nqs, env, want in ((100, {}, 0x24), (100, {"LYNSE_HIP_MID_TILINGS": "0"}, 0x81), (100, {"LYNSE_HIP_MID_TILINGS": "0", "LYNSE_HIP_QS": "0"}, 0x42), (48, {}, 0x14)):
         os.environ.update(env)
         try:
             rs, ds, cs = idx.search_batch_arrays(queries[:nqs], k, "l2")
