@@ -395,6 +395,15 @@ int lynse_hip_flat_search_wait(lynse_hip_ticket *t);
  * may still be writing into it).  LYNSE_HIP_WAIT_TIMEOUT_MS sets the initial value. */
 int lynse_hip_set_wait_timeout_ms(uint32_t ms);
 
+/* Diagnostics of the certified coarse pass (no reference counterpart: the reference scans f32 rows).  For a shard of at most `cap`
+ * (16,384) rows and 1..256 host queries: out_scores[q][row] = the COARSE score of (row, query) exactly as the scan kernels compute
+ * it (one emit-all stage of the real pipeline), in the metric's own space (IP: score; L2 / cosine: distance); out_bound[q] = the
+ * bound E the pipeline certified for |coarse - reference-order f32 score| (the margin it keeps is 2E).  coarse = 0: the f16 shadow,
+ * 1: the certified int8 pass; *out_form (may be NULL): bit 0 int8, bit 1 augmented-L2 codes, bit 2 plain-code L2 (exact f32 row
+ * norms), bit 3 unit-row cosine codes.  tests/test_gpu_certificate.py holds the bound against constructed worst cases. */
+int lynse_hip_flat_coarse_scores(lynse_hip_flat *h, const float *queries, uint64_t nq, int metric, int coarse,
+                                 float *out_scores, float *out_bound, int *out_form);
+
 /* ---- shard-node glue around a search (host only, no device work) ---- */
 
 /* Collection::filter_tombstoned_limit (src/engine.rs:3286-3308): drop the tombstoned ids, keep the order, at most

@@ -340,6 +340,17 @@ class FlatIndex:
     def hbm_bytes(self) -> int:
         return int(lib.lynse_hip_flat_hbm_bytes(self._h))
 
+    def coarse_scores(self, queries, metric, coarse: str = "i8"):
+        """Diagnostics of the certified coarse pass (`lynse_hip_flat_coarse_scores`): for a shard of <= 16,384 rows and <= 256 queries the
+        coarse score / distance of every (query, row) as the scan kernels compute it, the certified bound E per query, and the form bits."""
+        q = np.ascontiguousarray(np.atleast_2d(queries), dtype=np.float32)
+        m = metric if isinstance(metric, int) else metric_from_str(metric)
+        scores = np.empty((q.shape[0], len(self)), np.float32)
+        bound = np.empty(q.shape[0], np.float32)
+        form = C.c_int(0)
+        check(lib.lynse_hip_flat_coarse_scores(self._h, _ptr(q), q.shape[0], m, 1 if coarse in ("i8", "int8", 1, True) else 0, _ptr(scores), _ptr(bound), C.byref(form)))
+        return scores, bound, form.value
+
     def coarse_state(self) -> dict:
         """State of the coarse-pass selection: overflow strikes of the certified int8 pass (3 = switched off, -1 = off because the
         rows are not finite) and the rows covered by the SQ8 codes built so far."""

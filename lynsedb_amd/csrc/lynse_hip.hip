@@ -1650,6 +1650,9 @@ static int get_event(lynse_hip_flat* h, size_t idx, hipEvent_t* out) {
 }
 
 static bool l2_plain(const lynse_hip_flat* h, uint64_t nqc, bool masked = false);   // (defined with the other int8-pass rules)
+// lynse_hip_flat_coarse_scores: one emit-all stage over the whole (small) shard, then stop — the candidate buffer then holds the
+// coarse score of every (row, query) exactly as the scan kernels compute it
+static thread_local bool tl_coarse_dump = false;
 
 // One chunk (<= QCHUNK queries) whose inputs are already in the workspace (Qf for float metrics,
 // QW for binary).  Results land in ws.out_*.  `level` selects the stage plan (make_plan).
@@ -1773,7 +1776,7 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
     // sample tile; up to k = 128 the sample as a whole supplies >= 8 k keys — a clustered shard may then overflow the first
     // stage and fall back to the contiguous plan)
     const bool can_threshold_only = h16 && !binary && !filt && !no_lane_max0 && k <= 128;
-    const std::vector<Stage> plan = sts ? std::vector<Stage>{Stage{0u, (uint32_t)h->n}}
+    const std::vector<Stage> plan = (sts || tl_coarse_dump) ? std::vector<Stage>{Stage{0u, (uint32_t)h->n}}
                                         : make_plan(h, k, (level == 0 && (!plan_tile || no_sample)) ? 1 : level, plan_tile, can_threshold_only);
     const Stage sample = (!plan.empty() && plan[0].sample_tiles) ? plan[0] : Stage{0, 0};
     *sampled_plan = sample.sample_tiles != 0;
@@ -1993,6 +1996,7 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
             st_nseg = a.seg ? a.nseg : 0; st_seg = a.seg;
             plan_used_segments = plan_used_segments || a.seg != 0;
         }
+        if (tl_coarse_dump) return LYNSE_OK;   // (diagnostics: the emit-all stage has written one key per row and query; nothing else runs)
         if (tl_prof) {
             LY_HIP(hipEventRecord(e1, st));
             scan_events->push_back({*ev_used - 2, s.sample_tiles ? (uint64_t)s.sample_tiles * plan_tile
@@ -2794,6 +2798,57 @@ static int search_impl(lynse_hip_flat* h, const void* q_src, bool packed_queries
             std::lock_guard<std::mutex> plk(h->prof_mu);
             h->prof.last_plan |= 64u;
         }
+    }
+    return LYNSE_OK;
+}
+
+// Diagnostics of the CERTIFICATE (tests/test_gpu_certificate.py): the coarse score of every row of a small shard (n <= cap) for up
+// to 256 queries, exactly as the scan kernels compute it (one emit-all stage of the real pipeline: MFMA dot products, the kernels'
+// float expressions), in the metric's own space (IP: score, L2 / cosine: distance), and the per-query bound E the prep kernel
+// certified (the margin the pipeline keeps is 2E).  coarse = 0: the f16 shadow, 1: the certified int8 pass in the form a batch of
+// this shape would take; *out_form: bit 0 int8, bit 1 augmented-L2 codes, bit 2 plain-code L2, bit 3 unit-row cosine codes.
+extern "C" int lynse_hip_flat_coarse_scores(lynse_hip_flat* h, const float* queries, uint64_t nq, int metric, int coarse,
+                                            float* out_scores, float* out_bound, int* out_form) {
+    if (!h || !queries || !out_scores || !out_bound) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (metric < M_IP || metric > M_COS) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "float metrics only");
+    if (nq == 0 || nq > QCHUNK) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "1..256 queries");
+    LY_TRY(use_device(h));
+    std::unique_lock<std::shared_mutex> xlk;
+    LY_TRY(writer_lock(h, xlk));
+    if (h->packed_only || h->n == 0 || h->n > h->cap) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "a float shard of 1..cap rows");
+    LY_TRY(finalize_locked(h));
+    LY_TRY(ensure_workspace(h, 1));
+    const bool i8c = coarse != 0;
+    if (i8c) {
+        LY_TRY(ensure_i8c_codes_locked(h, metric, nq));
+        if (!i8c_codes_finite(h, metric, nq)) return set_error(LYNSE_ERR_UNSUPPORTED, "the shard holds non-finite values: no int8 pass");
+    }
+    Workspace& w = cur(h).ws;
+    hipStream_t st = cur(h).stream;
+    LY_HIP(hipMemcpyAsync(w.Qf, queries, (size_t)nq * h->dim * 4, hipMemcpyHostToDevice, st));
+    size_t ev_used = 0;
+    std::vector<std::pair<size_t, uint64_t>> scan_events;
+    bool sampled = false;
+    tl_coarse_dump = true;
+    const int rc = run_chunk(h, (uint32_t)nq, 1, 1, metric, 1, st, &ev_used, &scan_events, &sampled, nullptr, nullptr, i8c);
+    tl_coarse_dump = false;
+    LY_TRY(rc);
+    LY_HIP(hipStreamSynchronize(st));
+    const bool l2n = i8c && metric == M_L2 && l2_plain(h, nq, false);
+    const bool aug = i8c && metric == M_L2 && !l2n, cosq = i8c && metric == M_COS;
+    if (out_form) *out_form = (i8c ? 1 : 0) | (aug ? 2 : 0) | (l2n ? 4 : 0) | (cosq ? 8 : 0);
+    const bool key_asc = metric_ascending((aug || cosq) ? (int)M_IP : metric);
+    std::vector<uint64_t> keys(h->n);
+    std::vector<float> m2(nq);
+    LY_HIP(hipMemcpy(m2.data(), w.marg2, nq * 4, hipMemcpyDeviceToHost));
+    for (uint64_t q = 0; q < nq; ++q) {
+        LY_HIP(hipMemcpy(keys.data(), w.cand + (size_t)q * w.cap, (size_t)h->n * 8, hipMemcpyDeviceToHost));
+        for (uint64_t r = 0; r < h->n; ++r) {
+            if (key_row(keys[r]) != (uint32_t)r) return set_error(LYNSE_ERR_INTERNAL, "the emit-all stage did not leave row r in slot r");
+            const float sc = key_score(keys[r], key_asc);
+            out_scores[q * h->n + r] = (aug || cosq) ? -sc : sc;   // (those forms scan the NEGATED distance as an inner product)
+        }
+        out_bound[q] = 0.5f * m2[q];
     }
     return LYNSE_OK;
 }
