@@ -2369,6 +2369,12 @@ __global__ void __launch_bounds__(256) k_sq8_scales(const uint32_t* __restrict__
     scales[d] = range > 1e-30f ? __fdiv_rn(255.0f, range) : 0.0f;
 }
 
+// did merging the new rows' min / max into the per-dimension table move any entry?  (ordered-int images; flag |= 1)
+__global__ void __launch_bounds__(256) k_mm_changed(const uint32_t* __restrict__ now, const uint32_t* __restrict__ before, uint32_t n, uint32_t* __restrict__ flag) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n && now[i] != before[i]) atomicOr(flag, 1u);
+}
+
 // min / max of one column held as a vector (the squared row norms: column D of the augmented rows), same update rule
 __global__ void __launch_bounds__(256) k_vec_minmax(const float* __restrict__ x, uint64_t n, uint32_t* __restrict__ omin, uint32_t* __restrict__ omax,
                                                     uint32_t ncopies) {

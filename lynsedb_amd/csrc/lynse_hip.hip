@@ -268,6 +268,7 @@ struct lynse_hip_flat {
     int *sq8_sum = nullptr, *sq8_sum2 = nullptr;
     uint32_t* sq8_mm = nullptr;  // 2 x dim ordered-int min / max
     uint32_t* sq8_stats = nullptr;  // [0] max row L1 of the signed codes, [1] non-finite elements (k_sq8_quantize)
+    uint32_t* sq8_mm_prev = nullptr;  // scratch of the incremental append: the min / max table before the new rows were merged + a flag word
     uint32_t sq8_a1 = 0;
     bool sq8_finite = false;
     // the L2 form of the certified int8 pass: SQ8 codes of the AUGMENTED rows [v, |v|^2] (k_i8c_prep_queries, aug = 1), pitch
@@ -445,7 +446,7 @@ extern "C" int lynse_hip_flat_destroy(lynse_hip_flat* h) {
     for (void* p : {(void*)h->rows, (void*)h->rows_h, (void*)h->rows16, (void*)h->packed, (void*)h->vn2, (void*)h->vrinv, (void*)h->d_stats,
                     (void*)h->g_rows16, (void*)h->g_vn2, (void*)h->g_vrinv, (void*)h->g_ids32,
                     (void*)h->bpm, (void*)h->sq8c, (void*)h->sq8c_mins, (void*)h->sq8c_scales, (void*)h->sq8c_mm, (void*)h->sq8c_stats, (void*)h->sq8a, (void*)h->sq8a_mins, (void*)h->sq8a_scales, (void*)h->sq8a_mm, (void*)h->sq8a_stats,
-                    (void*)h->sq8, (void*)h->sq8_mins, (void*)h->sq8_scales, (void*)h->sq8_sum, (void*)h->sq8_sum2, (void*)h->sq8_mm, (void*)h->sq8_stats})
+                    (void*)h->sq8, (void*)h->sq8_mins, (void*)h->sq8_scales, (void*)h->sq8_sum, (void*)h->sq8_sum2, (void*)h->sq8_mm, (void*)h->sq8_stats, (void*)h->sq8_mm_prev})
         if (p) (void)hipFree(p);
     for (auto& c : h->ctx)
         if (c.stream) (void)hipStreamDestroy(c.stream);
@@ -658,6 +659,8 @@ extern "C" int lynse_hip_flat_append_packed_u64_device(lynse_hip_flat* h, const 
 
 // Row statistics for rows [n_stats, n): norms + collection stats (locked by caller).
 static int ensure_shadow_locked(lynse_hip_flat* h);
+static bool shadow_ready(const lynse_hip_flat* h) { return h->packed_only || h->n == 0 || (h->rows16 && h->n16 == h->n && h->sv16 == h->sv); }
+constexpr int LY_RESTART_EXCLUSIVE = 10001;   // search_impl_once: the f16 shadow is missing and only a shared lock is held — run again under the writer lock
 static int scan_variant();
 
 static int finalize_locked(lynse_hip_flat* h) {
@@ -705,7 +708,8 @@ static int finalize_locked(lynse_hip_flat* h) {
     // below u*|v| for every element that matters, and the hot loop saves the multiply
     h->sv = (e >= -6 && e <= 14) ? 1.0f : std::ldexp(1.0f, 13 - e);
     h->n_stats = h->n;
-    if (scan_variant() == 3) LY_TRY(ensure_shadow_locked(h));
+    // (the f16 shadow is a LAZY copy since round 4 — ensure_shadow_locked, built by the first search that runs the f16 coarse pass: a
+    // shard whose batches all take the certified int8 pass never pays its 2 B per element: 10M x 768 = 15.4 GB of the 53.9 GB)
     return LYNSE_OK;
 }
 
@@ -2122,8 +2126,40 @@ static int run_small(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
 // ------------------------------------------------------------------------------ SQ8 two-pass ----
 // ensure_sq8 (flat_mmap.rs:375-386) + SQ8Data::from_f32_parallel (:5685-5737): (re)built over ALL rows whenever rows were
 // appended since the last build (min / max are collection-wide).
+// Rows appended to a shard that already has its codes (Collection::flush hands over <= 10,000 rows at a time, src/engine.rs:93-94):
+// the new rows' per-dimension min / max are MERGED into the stored table; when no entry moves, the collection-wide fit — and with
+// it every existing code — is what a full rebuild would produce (SQ8Data::from_f32_parallel, flat_mmap.rs:5685-5737, fits min / max
+// over all rows), so only the new rows are quantised (and the max row L1 norm / the non-finite count keep accumulating).  A moved
+// entry means new scales: everything is coded again, from the already merged table.  Returns the first row that still needs codes
+// (0 = all of them) and whether `mm` already covers every row.
+static int sq8_merge_new_rows(lynse_hip_flat* h, uint32_t* mm, uint32_t D, uint64_t n_done, const float* row_scale, uint64_t* first_row, bool* mm_covers_all) {
+    *first_row = 0;
+    *mm_covers_all = false;
+    if (n_done == 0 || n_done >= h->n) return LYNSE_OK;
+    if (!h->sq8_mm_prev) LY_HIP(hipMalloc(&h->sq8_mm_prev, ((size_t)(h->dim + 64) * 2 + 1) * 4));
+    hipStream_t st = cur(h).stream;
+    uint32_t* flag = h->sq8_mm_prev + 2 * (size_t)D;
+    LY_HIP(hipMemcpyAsync(h->sq8_mm_prev, mm, (size_t)D * 8, hipMemcpyDeviceToDevice, st));
+    LY_HIP(hipMemsetAsync(flag, 0, 4, st));
+    const uint64_t nn = h->n - n_done;
+    const uint32_t gx = (D + 255) / 256;
+    const uint32_t gy = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(nn / 256, 1), (uint64_t)h->num_cu * 8);
+    if (is_f16(h)) hipLaunchKernelGGL(k_sq8_minmax<_Float16>, dim3(gx, gy), dim3(256), 0, st, (const _Float16*)h->rows_h + n_done * h->ld16, h->ld16, D, nn, mm, mm + D,
+                                      row_scale ? row_scale + n_done : nullptr);
+    else hipLaunchKernelGGL(k_sq8_minmax<float>, dim3(gx, gy), dim3(256), 0, st, h->rows + n_done * h->ld, h->ld, D, nn, mm, mm + D, row_scale ? row_scale + n_done : nullptr);
+    hipLaunchKernelGGL(k_mm_changed, dim3((2 * D + 255) / 256), dim3(256), 0, st, mm, h->sq8_mm_prev, 2 * D, flag);
+    LY_HIP(hipGetLastError());
+    uint32_t moved = 1;
+    LY_HIP(hipMemcpyAsync(&moved, flag, 4, hipMemcpyDeviceToHost, st));
+    LY_HIP(hipStreamSynchronize(st));
+    *mm_covers_all = true;
+    if (!moved) *first_row = n_done;
+    return LYNSE_OK;
+}
+
 static int ensure_sq8_locked(lynse_hip_flat* h) {
     if (h->n_sq8 == h->n && h->sq8) return LYNSE_OK;
+    bool kept = h->sq8 != nullptr && h->sq8_mins != nullptr && h->sq8_cap >= h->n;   // the existing codes survive (no reallocation)
     if (h->sq8_cap < h->n) {
         for (void* p : {(void*)h->sq8, (void*)h->sq8_sum, (void*)h->sq8_sum2})
             if (p) (void)hipFree(p);
@@ -2142,19 +2178,29 @@ static int ensure_sq8_locked(lynse_hip_flat* h) {
         LY_HIP(hipMalloc(&h->sq8_mm, (size_t)h->dim * 8));
         LY_HIP(hipMalloc(&h->sq8_stats, 8));
     }
-    LY_HIP(hipMemsetAsync(h->sq8_stats, 0, 8, cur(h).stream));
-    std::vector<uint32_t> init((size_t)h->dim * 2);
-    for (uint32_t d = 0; d < h->dim; ++d) { init[d] = f32_to_ord(INFINITY); init[h->dim + d] = f32_to_ord(-INFINITY); }
-    LY_HIP(hipMemcpyAsync(h->sq8_mm, init.data(), init.size() * 4, hipMemcpyHostToDevice, cur(h).stream));
+    uint64_t r0 = 0;
+    bool mm_done = false;
+    if (kept) LY_TRY(sq8_merge_new_rows(h, h->sq8_mm, h->dim, h->n_sq8, nullptr, &r0, &mm_done));
     const uint32_t gx = (h->dim + 255) / 256;
-    const uint32_t gy = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(h->n / 256, 1), (uint64_t)h->num_cu * 8);
-    if (is_f16(h)) hipLaunchKernelGGL(k_sq8_minmax<_Float16>, dim3(gx, gy), dim3(256), 0, cur(h).stream, (const _Float16*)h->rows_h, h->ld16, h->dim, h->n, h->sq8_mm, h->sq8_mm + h->dim);
-    else hipLaunchKernelGGL(k_sq8_minmax<float>, dim3(gx, gy), dim3(256), 0, cur(h).stream, h->rows, h->ld, h->dim, h->n, h->sq8_mm, h->sq8_mm + h->dim);
-    hipLaunchKernelGGL(k_sq8_scales, dim3(gx), dim3(256), 0, cur(h).stream, h->sq8_mm, h->sq8_mm + h->dim, h->dim, h->sq8_mins, h->sq8_scales);
-    if (is_f16(h)) hipLaunchKernelGGL(k_sq8_quantize<_Float16>, dim3((uint32_t)std::min<uint64_t>((h->n + 3) / 4, (uint64_t)h->num_cu * 16)), dim3(256), 0, cur(h).stream,
-                       (const _Float16*)h->rows_h, h->ld16, h->dim, h->n, h->sq8_mins, h->sq8_scales, h->sq8, h->ld8, h->sq8_sum, h->sq8_sum2, h->sq8_stats);
-    else hipLaunchKernelGGL(k_sq8_quantize<float>, dim3((uint32_t)std::min<uint64_t>((h->n + 3) / 4, (uint64_t)h->num_cu * 16)), dim3(256), 0, cur(h).stream,
-                       h->rows, h->ld, h->dim, h->n, h->sq8_mins, h->sq8_scales, h->sq8, h->ld8, h->sq8_sum, h->sq8_sum2, h->sq8_stats);
+    std::vector<uint32_t> init;
+    if (!mm_done) {
+        init.resize((size_t)h->dim * 2);
+        for (uint32_t d = 0; d < h->dim; ++d) { init[d] = f32_to_ord(INFINITY); init[h->dim + d] = f32_to_ord(-INFINITY); }
+        LY_HIP(hipMemcpyAsync(h->sq8_mm, init.data(), init.size() * 4, hipMemcpyHostToDevice, cur(h).stream));
+        const uint32_t gy = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(h->n / 256, 1), (uint64_t)h->num_cu * 8);
+        if (is_f16(h)) hipLaunchKernelGGL(k_sq8_minmax<_Float16>, dim3(gx, gy), dim3(256), 0, cur(h).stream, (const _Float16*)h->rows_h, h->ld16, h->dim, h->n, h->sq8_mm, h->sq8_mm + h->dim);
+        else hipLaunchKernelGGL(k_sq8_minmax<float>, dim3(gx, gy), dim3(256), 0, cur(h).stream, h->rows, h->ld, h->dim, h->n, h->sq8_mm, h->sq8_mm + h->dim);
+    }
+    if (r0 == 0) {   // a new fit: every row is coded (again)
+        LY_HIP(hipMemsetAsync(h->sq8_stats, 0, 8, cur(h).stream));
+        hipLaunchKernelGGL(k_sq8_scales, dim3(gx), dim3(256), 0, cur(h).stream, h->sq8_mm, h->sq8_mm + h->dim, h->dim, h->sq8_mins, h->sq8_scales);
+    }
+    const uint64_t nn = h->n - r0;
+    const uint32_t qgrid = (uint32_t)std::min<uint64_t>((nn + 3) / 4, (uint64_t)h->num_cu * 16);
+    if (is_f16(h)) hipLaunchKernelGGL(k_sq8_quantize<_Float16>, dim3(qgrid), dim3(256), 0, cur(h).stream,
+                       (const _Float16*)h->rows_h + r0 * h->ld16, h->ld16, h->dim, nn, h->sq8_mins, h->sq8_scales, h->sq8 + r0 * h->ld8, h->ld8, h->sq8_sum + r0, h->sq8_sum2 + r0, h->sq8_stats);
+    else hipLaunchKernelGGL(k_sq8_quantize<float>, dim3(qgrid), dim3(256), 0, cur(h).stream,
+                       h->rows + r0 * h->ld, h->ld, h->dim, nn, h->sq8_mins, h->sq8_scales, h->sq8 + r0 * h->ld8, h->ld8, h->sq8_sum + r0, h->sq8_sum2 + r0, h->sq8_stats);
     LY_HIP(hipGetLastError());
     uint32_t qst[2] = {0, 0};
     LY_HIP(hipMemcpyAsync(qst, h->sq8_stats, 8, hipMemcpyDeviceToHost, cur(h).stream));
@@ -2211,6 +2257,7 @@ static int ensure_sq8a_locked(lynse_hip_flat* h) {
 static int ensure_sq8c_locked(lynse_hip_flat* h) {
     if (h->n_sq8c == h->n && h->sq8c) return LYNSE_OK;
     const uint32_t D = h->dim;
+    const bool kept = h->sq8c != nullptr && h->sq8c_mins != nullptr && h->sq8c_cap >= h->n;
     if (h->sq8c_cap < h->n) {
         if (h->sq8c) (void)hipFree(h->sq8c);
         h->sq8c = nullptr;
@@ -2224,21 +2271,31 @@ static int ensure_sq8c_locked(lynse_hip_flat* h) {
         LY_HIP(hipMalloc(&h->sq8c_mm, (size_t)D * 8));
         LY_HIP(hipMalloc(&h->sq8c_stats, 8));
     }
-    LY_HIP(hipMemsetAsync(h->sq8c_stats, 0, 8, cur(h).stream));
-    std::vector<uint32_t> init((size_t)D * 2);
-    for (uint32_t d = 0; d < D; ++d) { init[d] = f32_to_ord(INFINITY); init[D + d] = f32_to_ord(-INFINITY); }
-    LY_HIP(hipMemcpyAsync(h->sq8c_mm, init.data(), init.size() * 4, hipMemcpyHostToDevice, cur(h).stream));
+    uint64_t r0 = 0;
+    bool mm_done = false;
+    if (kept) LY_TRY(sq8_merge_new_rows(h, h->sq8c_mm, D, h->n_sq8c, h->vrinv, &r0, &mm_done));   // (appended rows inside the fitted ranges: only they are coded)
     const uint32_t gx = (D + 255) / 256;
-    const uint32_t gy = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(h->n / 256, 1), (uint64_t)h->num_cu * 8);
-    if (is_f16(h)) hipLaunchKernelGGL(k_sq8_minmax<_Float16>, dim3(gx, gy), dim3(256), 0, cur(h).stream, (const _Float16*)h->rows_h, h->ld16, D, h->n, h->sq8c_mm, h->sq8c_mm + D, h->vrinv);
-    else hipLaunchKernelGGL(k_sq8_minmax<float>, dim3(gx, gy), dim3(256), 0, cur(h).stream, h->rows, h->ld, D, h->n, h->sq8c_mm, h->sq8c_mm + D, h->vrinv);
-    hipLaunchKernelGGL(k_sq8_scales, dim3(gx), dim3(256), 0, cur(h).stream, h->sq8c_mm, h->sq8c_mm + D, D, h->sq8c_mins, h->sq8c_scales);
-    if (is_f16(h)) hipLaunchKernelGGL(k_sq8_quantize<_Float16>, dim3((uint32_t)std::min<uint64_t>((h->n + 3) / 4, (uint64_t)h->num_cu * 16)), dim3(256), 0, cur(h).stream,
-                       (const _Float16*)h->rows_h, h->ld16, D, h->n, h->sq8c_mins, h->sq8c_scales, h->sq8c, h->ld8, (int*)nullptr, (int*)nullptr, h->sq8c_stats,
-                       (const float*)nullptr, 0u, h->vrinv);
-    else hipLaunchKernelGGL(k_sq8_quantize<float>, dim3((uint32_t)std::min<uint64_t>((h->n + 3) / 4, (uint64_t)h->num_cu * 16)), dim3(256), 0, cur(h).stream,
-                       h->rows, h->ld, D, h->n, h->sq8c_mins, h->sq8c_scales, h->sq8c, h->ld8, (int*)nullptr, (int*)nullptr, h->sq8c_stats,
-                       (const float*)nullptr, 0u, h->vrinv);
+    std::vector<uint32_t> init;
+    if (!mm_done) {
+        init.resize((size_t)D * 2);
+        for (uint32_t d = 0; d < D; ++d) { init[d] = f32_to_ord(INFINITY); init[D + d] = f32_to_ord(-INFINITY); }
+        LY_HIP(hipMemcpyAsync(h->sq8c_mm, init.data(), init.size() * 4, hipMemcpyHostToDevice, cur(h).stream));
+        const uint32_t gy = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(h->n / 256, 1), (uint64_t)h->num_cu * 8);
+        if (is_f16(h)) hipLaunchKernelGGL(k_sq8_minmax<_Float16>, dim3(gx, gy), dim3(256), 0, cur(h).stream, (const _Float16*)h->rows_h, h->ld16, D, h->n, h->sq8c_mm, h->sq8c_mm + D, h->vrinv);
+        else hipLaunchKernelGGL(k_sq8_minmax<float>, dim3(gx, gy), dim3(256), 0, cur(h).stream, h->rows, h->ld, D, h->n, h->sq8c_mm, h->sq8c_mm + D, h->vrinv);
+    }
+    if (r0 == 0) {
+        LY_HIP(hipMemsetAsync(h->sq8c_stats, 0, 8, cur(h).stream));
+        hipLaunchKernelGGL(k_sq8_scales, dim3(gx), dim3(256), 0, cur(h).stream, h->sq8c_mm, h->sq8c_mm + D, D, h->sq8c_mins, h->sq8c_scales);
+    }
+    const uint64_t nn = h->n - r0;
+    const uint32_t qgrid = (uint32_t)std::min<uint64_t>((nn + 3) / 4, (uint64_t)h->num_cu * 16);
+    if (is_f16(h)) hipLaunchKernelGGL(k_sq8_quantize<_Float16>, dim3(qgrid), dim3(256), 0, cur(h).stream,
+                       (const _Float16*)h->rows_h + r0 * h->ld16, h->ld16, D, nn, h->sq8c_mins, h->sq8c_scales, h->sq8c + r0 * h->ld8, h->ld8, (int*)nullptr, (int*)nullptr, h->sq8c_stats,
+                       (const float*)nullptr, 0u, h->vrinv + r0);
+    else hipLaunchKernelGGL(k_sq8_quantize<float>, dim3(qgrid), dim3(256), 0, cur(h).stream,
+                       h->rows + r0 * h->ld, h->ld, D, nn, h->sq8c_mins, h->sq8c_scales, h->sq8c + r0 * h->ld8, h->ld8, (int*)nullptr, (int*)nullptr, h->sq8c_stats,
+                       (const float*)nullptr, 0u, h->vrinv + r0);
     LY_HIP(hipGetLastError());
     uint32_t qst[2] = {0, 0};
     LY_HIP(hipMemcpyAsync(qst, h->sq8c_stats, 8, hipMemcpyDeviceToHost, cur(h).stream));
@@ -2471,11 +2528,28 @@ static int prof_accumulate(lynse_hip_flat* h, lynse_hip_flat::Ctx& cx, hipEvent_
     return LYNSE_OK;
 }
 
+static int search_impl_once(lynse_hip_flat* h, const void* q_src, bool packed_queries, uint64_t nq, uint32_t k,
+                            int metric, uint64_t* out_rows, float* out_dists, uint32_t* out_counts,
+                            bool on_device, hipStream_t user_stream, const uint64_t* subset, uint64_t n_subset,
+                            bool filtered, const uint64_t* bitset_words, uint64_t n_words, bool caller_holds_exclusive, bool force_shadow);
 static int search_impl(lynse_hip_flat* h, const void* q_src, bool packed_queries, uint64_t nq, uint32_t k,
                        int metric, uint64_t* out_rows, float* out_dists, uint32_t* out_counts,
                        bool on_device, hipStream_t user_stream, const uint64_t* subset = nullptr, uint64_t n_subset = 0,
                        bool filtered = false, const uint64_t* bitset_words = nullptr, uint64_t n_words = 0,
                        bool caller_holds_exclusive = false) {
+    int rc = search_impl_once(h, q_src, packed_queries, nq, k, metric, out_rows, out_dists, out_counts, on_device, user_stream, subset, n_subset,
+                              filtered, bitset_words, n_words, caller_holds_exclusive, false);
+    // (a batch that started on the int8 pass under the shared lock and now needs the f16 shadow — an overflow, or a last chunk of a
+    // different shape: once more from the top, under the writer lock, with the shadow built first)
+    if (rc == LY_RESTART_EXCLUSIVE)
+        rc = search_impl_once(h, q_src, packed_queries, nq, k, metric, out_rows, out_dists, out_counts, on_device, user_stream, subset, n_subset,
+                              filtered, bitset_words, n_words, caller_holds_exclusive, true);
+    return rc;
+}
+static int search_impl_once(lynse_hip_flat* h, const void* q_src, bool packed_queries, uint64_t nq, uint32_t k,
+                            int metric, uint64_t* out_rows, float* out_dists, uint32_t* out_counts,
+                            bool on_device, hipStream_t user_stream, const uint64_t* subset, uint64_t n_subset,
+                            bool filtered, const uint64_t* bitset_words, uint64_t n_words, bool caller_holds_exclusive, bool force_shadow) {
     // filtered: the subset is either a list of row ids (`subset`, n_subset) or BitSet words (`bitset_words`; n_subset =
     // number of set bits below len, counted by the caller)
     if (!h) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "handle is NULL");
@@ -2498,9 +2572,13 @@ static int search_impl(lynse_hip_flat* h, const void* q_src, bool packed_queries
             return !bin_mfma_eligible(h, metric, filtered, std::min<uint64_t>(nq, QCHUNK)) || (h->bpm && h->n_bpm == h->n);   // (the +-1 copy is a lazy build too)
         }
         if (h->packed_only) return true;  // (rejected below)
-        if (h->n_stats != h->n || (scan_variant() == 3 && (h->n16 != h->n || h->sv16 != h->sv))) return false;
+        if (h->n_stats != h->n) return false;
+        if (force_shadow && !shadow_ready(h)) return false;
         // (filtered: what matters is the MASKED int8 scan — a gathered-rows search goes exclusive anyway)
-        return !i8c_eligible(h, metric, false, std::min<uint64_t>(nq, QCHUNK), caller_holds_exclusive, filtered) || i8c_codes_ready(h, metric, std::min<uint64_t>(nq, QCHUNK), filtered);
+        // a batch that takes the certified int8 pass needs its codes; every other float batch the f16 shadow (a lazy copy too).  The
+        // chunks of a large batch can differ (the last one may be small): the chunk loop checks again and restarts under the writer lock
+        if (i8c_eligible(h, metric, false, std::min<uint64_t>(nq, QCHUNK), caller_holds_exclusive, filtered)) return i8c_codes_ready(h, metric, std::min<uint64_t>(nq, QCHUNK), filtered);
+        return shadow_ready(h) || small_path_ok(h, std::min<uint64_t>(nq, QCHUNK), (uint32_t)std::min<uint64_t>(k, h->n), metric, filtered);
     };
     // k beyond the candidate capacity of one pass (k > cap / 4 over more than cap rows; the reference accepts any k, and its
     // server caps at MAX_TOP_K = 10,000, src/server/mod.rs:46): row ranges of `cap` rows, each answered exactly, merged.
@@ -2579,10 +2657,17 @@ static int search_impl(lynse_hip_flat* h, const void* q_src, bool packed_queries
         if (xlk.owns_lock() && bin_mfma_eligible(h, metric, filtered, std::min<uint64_t>(nq, QCHUNK))) LY_TRY(ensure_bpm_locked(h));
     } else {
         LY_TRY(finalize_locked(h));
+        if (force_shadow && (xlk.owns_lock() || caller_holds_exclusive)) LY_TRY(ensure_shadow_locked(h));
     }
     LY_TRY(ensure_workspace(h, k));
     Workspace& w = cur(h).ws;
     hipStream_t st0 = user_stream ? user_stream : cur(h).stream;
+    // the f16 shadow, for whoever is about to scan it: built here under the writer lock, or the whole search starts over under it
+    auto need_shadow = [&]() -> int {
+        if (binary || shadow_ready(h)) return LYNSE_OK;
+        if (xlk.owns_lock() || caller_holds_exclusive) return ensure_shadow_locked(h);
+        return LY_RESTART_EXCLUSIVE;
+    };
     bool direct = false;
     std::vector<uint64_t> sorted_subset;
     auto& fc = cur(h);   // (this search's context: 0 under the exclusive lock, the leased one under the shared lock)
@@ -2667,6 +2752,7 @@ static int search_impl(lynse_hip_flat* h, const void* q_src, bool packed_queries
                 h->g_cap = n_subset;
             }
             const uint64_t pieces = n_subset * (h->ld16 / 8);
+            LY_TRY(need_shadow());   // (the gathered-rows strategy runs under the writer lock)
             hipLaunchKernelGGL(k_gather_rows16, dim3((uint32_t)std::min<uint64_t>((pieces + 255) / 256, (uint64_t)h->num_cu * 32)), dim3(256), 0,
                                st0, h->rows16, h->ld16, fc.d_subset, n_subset, h->g_rows16);
             LY_HIP(hipGetLastError());
@@ -2732,6 +2818,7 @@ static int search_impl(lynse_hip_flat* h, const void* q_src, bool packed_queries
             if (i8c && !i8c_codes_finite(h, metric, nqc, msk)) { i8c_strike_counter(h, metric).store(-1); i8c = false; }
         }
         i8c_attempted = i8c_attempted || i8c;
+        if (!binary && !i8c && !small_path_ok(h, nqc, kk, metric, filtered)) LY_TRY(need_shadow());   // this chunk scans the f16 shadow
         if (small_path_ok(h, nqc, kk, metric, filtered)) {
             // fused single-launch search: the last workgroup writes straight into the caller's device buffers, or into
             // pinned host memory (no copy kernels, one synchronisation); it cannot overflow
@@ -2783,6 +2870,7 @@ static int search_impl(lynse_hip_flat* h, const void* q_src, bool packed_queries
             if (i8c) {  // same plan level again with the f16 coarse pass
                 i8c = false;
                 i8c_add_strike(h, metric);
+                LY_TRY(need_shadow());
                 --level;
                 continue;
             }
@@ -2819,6 +2907,7 @@ extern "C" int lynse_hip_flat_coarse_scores(lynse_hip_flat* h, const float* quer
     LY_TRY(finalize_locked(h));
     LY_TRY(ensure_workspace(h, 1));
     const bool i8c = coarse != 0;
+    if (!i8c) LY_TRY(ensure_shadow_locked(h));
     if (i8c) {
         LY_TRY(ensure_i8c_codes_locked(h, metric, nq));
         if (!i8c_codes_finite(h, metric, nq)) return set_error(LYNSE_ERR_UNSUPPORTED, "the shard holds non-finite values: no int8 pass");
@@ -2893,6 +2982,8 @@ extern "C" int lynse_hip_flat_prepare(lynse_hip_flat* h, int metric, uint64_t nq
         LY_TRY(ensure_i8c_codes_locked(h, metric, nqc));
         if (!i8c_codes_finite(h, metric, nqc)) i8c_strike_counter(h, metric).store(-1);
     }
+    // a batch that does not take the int8 pass scans the f16 shadow (unless the exact few-query kernel answers it)
+    if (!i8c_eligible(h, metric, false, nqc) && !small_path_ok(h, nqc, 10, metric, false)) LY_TRY(ensure_shadow_locked(h));
     return LYNSE_OK;
 }
 
@@ -2928,7 +3019,7 @@ static int search_large_k(lynse_hip_flat* h, const void* q_src, bool packed_quer
     if (packed_queries && !binary) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "packed queries need a binary metric");
     if (!binary && h->packed_only) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "store holds packed rows; float metrics unavailable");
     if (binary) LY_TRY(ensure_packed_locked(h));
-    else LY_TRY(finalize_locked(h));
+    else { LY_TRY(finalize_locked(h)); LY_TRY(ensure_shadow_locked(h)); }   // (the row-range views below scan the f16 shadow: built for the WHOLE shard first)
     const uint64_t n = h->n, R = h->cap;
     // the subset as a sorted set of valid row ids (a BitSet's to_vec; ids >= n are skipped, duplicates count once)
     std::vector<uint64_t> ids;

@@ -378,3 +378,71 @@ def test_l2_plain_codes_hostile_data(L, oracle):
     ints = rng.integers(0, 4, (150_000, 256)).astype(f32)            # integer data: exact integer distances, huge tie groups
     qi = ints[rng.integers(0, len(ints), 140)].copy()
     run_case(L, oracle, ints, qi, 20, "l2_plain_integer_ties", metric="l2", check=(0, 1, 64, 139))
+
+
+def test_append_to_a_prepared_shard_codes_only_the_new_rows(L, oracle):
+    """Collection::flush hands ingest over in chunks of <= 10,000 rows (src/engine.rs:93-94).  Rows appended to a shard whose SQ8
+    codes exist used to invalidate every derived copy wholesale (a pass over all rows before the next search); now the new rows'
+    per-dimension min / max are merged into the stored table and, when no entry moves, ONLY the new rows are coded — the
+    collection-wide fit (flat_mmap.rs:5685-5737) is unchanged, so every existing code is what a full rebuild would produce.
+    A row outside the fitted ranges still triggers the full rebuild.  Results equal the oracle's either way."""
+    import time
+
+    n0, n1, dim, nq, k = 1_000_000, 10_000, 256, 256, 10
+    rng = np.random.default_rng(2024)
+    data = np.empty((n0 + 2 * n1, dim), f32)
+    rng.random(out=data[:n0], dtype=f32)
+    data[n0:n0 + n1] = 0.001 + 0.998 * rng.random((n1, dim), dtype=f32)     # inside the fitted ranges of 1M uniform rows
+    data[n0 + n1:] = rng.random((n1, dim), dtype=f32)
+    data[n0 + n1 + 5, 7] = 2.5                                               # ... and one value outside
+    idx = L.FlatIndex(None, dim)
+    idx.reserve(n0 + 2 * n1)
+    idx.write(data[:n0])
+    idx.finalize()
+    idx.prepare("ip", nq)
+    q_rows = np.sort(rng.integers(0, n0 + n1, nq))
+    q_rows[:4] = (n0 + 1, n0 + 17, n0 + n1 - 1, 3)                            # queries next to NEW rows too
+    queries = (data[q_rows] + 0.02 * rng.standard_normal((nq, dim)).astype(f32)).astype(f32)
+    for _ in range(3):
+        idx.search_batch_arrays(queries, k, "ip")
+    t0 = time.perf_counter()
+    idx.search_batch_arrays(queries, k, "ip")
+    steady = time.perf_counter() - t0
+    assert idx.coarse_state()["sq8_rows"] == n0
+    idx.write(data[n0:n0 + n1])
+    idx.profile_enable(True)
+    idx.profile_get(reset=True)
+    t0 = time.perf_counter()
+    rows, dists, counts = idx.search_batch_arrays(queries, k, "ip")
+    first = time.perf_counter() - t0
+    p = idx.profile_get(reset=True)
+    assert idx.coarse_state()["sq8_rows"] == n0 + n1 and int(p["last_plan"]) & 4 and p["fallback_queries"] == 0, p
+    print(f"append of {n1} rows to {n0} x {dim}: next search {first * 1e3:.2f} ms (steady search {steady * 1e3:.2f} ms)")
+    assert first - steady < 5e-3, (first, steady)     # (a rebuild over all rows: three passes over the shard; at 10M x 768 it was ~50 ms)
+    live = data[:n0 + n1]
+    for qi in (0, 1, 2, 3, 100, 255):
+        e_ids, e_d = oracle.canonical_topk(queries[qi], live, k, O.IP)
+        assert np.array_equal(rows[qi].astype(np.uint32), e_ids) and np.array_equal(dists[qi].view(np.uint32), e_d.view(np.uint32)), qi
+    assert rows[0, 0] == n0 + 1 and rows[1, 0] == n0 + 17
+    # the codes of the appended rows are the ones a fresh fit over all rows would give: same fit, same answers from a shard built in one go
+    fresh = L.FlatIndex(None, dim)
+    fresh.write(live)
+    fresh.finalize()
+    r2, d2, c2 = fresh.search_batch_arrays(queries, k, "ip")
+    assert np.array_equal(r2, rows) and np.array_equal(d2.view(np.uint32), dists.view(np.uint32))
+    m0, s0 = idx.sq8_params()
+    m1, s1 = fresh.sq8_params()
+    assert np.array_equal(m0.view(np.uint32), m1.view(np.uint32)) and np.array_equal(s0.view(np.uint32), s1.view(np.uint32))
+    # a row outside the fitted ranges: new scales, every row coded again — same contract
+    idx.write(data[n0 + n1:])
+    rows, dists, counts = idx.search_batch_arrays(queries, k, "ip")
+    assert idx.coarse_state()["sq8_rows"] == n0 + 2 * n1
+    for qi in (0, 3, 200):
+        e_ids, e_d = oracle.canonical_topk(queries[qi], data, k, O.IP)
+        assert np.array_equal(rows[qi].astype(np.uint32), e_ids) and np.array_equal(dists[qi].view(np.uint32), e_d.view(np.uint32)), qi
+    fresh2 = L.FlatIndex(None, dim)
+    fresh2.write(data)
+    fresh2.finalize()
+    m2, s2 = fresh2.sq8_params()
+    m3, s3 = idx.sq8_params()
+    assert np.array_equal(m2.view(np.uint32), m3.view(np.uint32)) and np.array_equal(s2.view(np.uint32), s3.view(np.uint32))

@@ -237,6 +237,8 @@ def test_f16_shard_holds_one_copy_of_its_rows(L, oracle):
     f32_idx = L.FlatIndex(None, dim)
     f32_idx.write(data)
     f32_idx.finalize()
+    assert f32_idx.hbm_bytes() <= n * dim * 4 * 1.3 + (1 << 20), f32_idx.hbm_bytes()   # (round 4: the f16 shadow of an f32 shard is a LAZY copy ...)
+    f32_idx.search_batch_arrays(q, 10, "ip")                                              # ... built by the first search that scans it
     assert f32_idx.hbm_bytes() >= n * dim * 6
     assert np.array_equal(idx.read_rows(0, n).view(np.uint32), data.view(np.uint32))
     for name, metric in (("ip", O.IP), ("l2", O.L2), ("cosine", O.COS)):
