@@ -382,6 +382,65 @@ class ShardedIvf:
             self.comm = None
             return False
 
+    def train(self, local_rows, n_global: int, nlist: int, max_iter: int = 20, metric: str = "ip", ivfflat_routing: bool = False,
+              reduce=None):
+        """All-reduced k-means over the whole collection (`lynse_hip_ivf_kmeans_sharded`): every rank passes ITS rows (global row
+        g = local row g // world on rank g % world; a numpy array, or a torch tensor on the rank's device) and gets the SAME centroids and
+        the assignments of its rows — kmeans_train on the union (kmeans.rs:74-139) with the centroid sums formed per rank and added over
+        the ranks.  The reduction is the library's RCCL communicator when `enable_native_comm` succeeded, else `torch.distributed`
+        (`self.dist`: gloo or nccl), else the callable `reduce(host_array)` (tests).  A collective.  IvfFlat indexes train L2 cells."""
+        import ctypes as C_
+
+        from .core import _ptr, metric_from_str
+
+        on_device = hasattr(local_rows, "data_ptr")
+        if on_device:
+            n_local, ptr = int(local_rows.shape[0]), C_.c_void_p(local_rows.data_ptr() if local_rows.shape[0] else 0)
+            device = local_rows.device.index or 0
+        else:
+            local_rows = np.ascontiguousarray(local_rows, np.float32)
+            n_local, ptr = int(local_rows.shape[0]), _ptr(local_rows) if local_rows.shape[0] else None
+            device = self.device if self.device is not None else 0
+        m = metric_from_str("l2" if ivfflat_routing else metric)
+        k = min(int(nlist), int(n_global))
+        cen = np.zeros((k, self.dim), np.float32)
+        asg = np.zeros(max(n_local, 1), np.uint32)
+        got = C_.c_uint32(0)
+
+        host_reduce = self._host_reduce(reduce, device)
+        cb = _lib.REDUCE_FN(host_reduce)
+        comm = self.comm.handle if (self.comm is not None and reduce is None) else None
+        check(lib.lynse_hip_ivf_kmeans_sharded(ptr, n_local, 1 if on_device else 0, int(n_global), self.rank, self.world, self.dim, int(nlist),
+                                               int(max_iter), m, device, comm, C_.cast(cb, C_.c_void_p), None, _ptr(cen), _ptr(asg), C_.byref(got)))
+        return cen[:got.value].copy(), asg[:n_local].copy()
+
+    def _host_reduce(self, reduce, device: int):
+        """The `lynse_hip_reduce_fn` of this shard's launcher: sums a host buffer over all ranks in place (dtype 0: f32, 1: u32)."""
+        import ctypes as C_
+
+        def host_reduce(_ctx, buf, count, dtype):
+            try:
+                arr = np.ctypeslib.as_array(C_.cast(buf, C_.POINTER(C_.c_float if dtype == 0 else C_.c_uint32)), shape=(int(count),))
+                if reduce is not None:
+                    reduce(arr)
+                elif self.dist is not None and self.world > 1:
+                    import torch
+
+                    t = torch.from_numpy(arr)                      # (shares the buffer)
+                    if dtype == 1:
+                        t = t.view(torch.int32)                    # counts stay far below 2^31
+                    if self.dist.get_backend() == "nccl":
+                        g = t.to(torch.device("cuda", device))
+                        self.dist.all_reduce(g, op=self.dist.ReduceOp.SUM)
+                        t.copy_(g.cpu())
+                    else:
+                        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+                return 0
+            except Exception:  # noqa: BLE001  (the library turns a non-zero return into an error)
+                return 1
+
+        return host_reduce
+
     @staticmethod
     def assign(rows: np.ndarray, centroids: np.ndarray, metric: str, device: Optional[int] = None) -> np.ndarray:
         """kmeans::assign_metric (kmeans.rs:237-264) on the device: nearest centroid per row = a FLAT k=1 search of the

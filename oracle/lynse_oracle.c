@@ -1412,6 +1412,60 @@ size_t lo_kmeans_train(const float *data, size_t n, size_t dim, size_t requested
     return k;
 }
 
+/* Row-sharded training (no reference counterpart: the reference's cluster mode trains one index per shard; SURVEY 8(e) names the
+ * all-reduce of the centroid sums and counts).  kmeans_train over the UNION of `world` row shards (global row g on rank g % world)
+ * with ONE difference: the centroid sums of an iteration are formed per rank (sequential over that rank's members in ascending
+ * row order, kmeans.rs:273-286 on the shard) and the per-rank sums are then added in rank order — what an all-reduce of the
+ * per-rank sums delivers (exactly for world = 2, where the order cannot matter).  Init, assignment, counts, the empty-cluster
+ * rule and the stop test see the whole collection. */
+size_t lo_kmeans_train_sharded(const float *data, size_t n, size_t dim, size_t requested, size_t max_iter,
+                               int metric, size_t world, float *centroids, uint32_t *assignments) {
+    size_t k = requested < n ? requested : n;
+    if (n == 0 || k == 0 || dim == 0 || world == 0) return 0;
+    kmeans_init(data, n, dim, k, metric, centroids);
+    uint32_t *cur = (uint32_t *)malloc(n * sizeof(uint32_t));
+    uint32_t *nxt = (uint32_t *)malloc(n * sizeof(uint32_t));
+    for (size_t i = 0; i < n; ++i) cur[i] = UINT32_MAX;
+    float *sums = (float *)malloc(k * dim * sizeof(float));
+    float *part = (float *)malloc(k * dim * sizeof(float));
+    uint32_t *counts = (uint32_t *)malloc(k * sizeof(uint32_t));
+    for (size_t it = 0; it < max_iter; ++it) {
+        lo_kmeans_assign(data, n, dim, centroids, k, metric, nxt);
+        int changed = 0;
+        for (size_t i = 0; i < n; ++i) if (nxt[i] != cur[i]) { changed = 1; break; }
+        memcpy(cur, nxt, n * sizeof(uint32_t));
+        memset(counts, 0, k * sizeof(uint32_t));
+        for (size_t i = 0; i < n; ++i) counts[cur[i]] += 1;
+        for (size_t r = 0; r < world; ++r) {
+            memset(part, 0, k * dim * sizeof(float));
+            for (size_t i = r; i < n; i += world) {
+                size_t c = cur[i];
+                for (size_t d = 0; d < dim; ++d) part[c * dim + d] = part[c * dim + d] + data[i * dim + d];
+            }
+            if (r == 0) memcpy(sums, part, k * dim * sizeof(float));
+            else for (size_t j = 0; j < k * dim; ++j) sums[j] = sums[j] + part[j];
+        }
+        size_t max_c = 0; uint32_t max_count = 0;
+        for (size_t c = 0; c < k; ++c) if (counts[c] >= max_count) { max_count = counts[c]; max_c = c; }
+        for (size_t c = 0; c < k; ++c) {
+            if (counts[c] > 0) {
+                float inv = 1.0f / (float)counts[c];
+                for (size_t d = 0; d < dim; ++d) centroids[c * dim + d] = sums[c * dim + d] * inv;
+            } else if (max_count > 1) {
+                for (size_t d = 0; d < dim; ++d) {
+                    float f = 1e-4f * (float)d;
+                    float g = 1.0f + f;
+                    centroids[c * dim + d] = centroids[max_c * dim + d] * g;
+                }
+            }
+        }
+        if (!changed) break;
+    }
+    lo_kmeans_assign(data, n, dim, centroids, k, metric, assignments);
+    free(counts); free(part); free(sums); free(nxt); free(cur);
+    return k;
+}
+
 /* ---------------------------------------------------------------------- IVF */
 
 typedef struct { float d; uint32_t i; } rank_t;

@@ -151,6 +151,10 @@ size_t lo_merge_results(const uint64_t *ids, const float *dists, size_t n, size_
 size_t lo_kmeans_train(const float *data, size_t n, size_t dim, size_t requested, size_t max_iter,
                        int metric, float *centroids /* requested*dim */,
                        uint32_t *assignments /* n */);
+/* kmeans_train over the union of `world` row shards with the centroid sums formed per shard and added in rank order (the
+ * all-reduced training of a row-sharded IVF collection; see the .c file). */
+size_t lo_kmeans_train_sharded(const float *data, size_t n, size_t dim, size_t requested, size_t max_iter,
+                               int metric, size_t world, float *centroids, uint32_t *assignments);
 void lo_kmeans_assign(const float *data, size_t n, size_t dim, const float *centroids,
                       size_t n_centroids, int metric, uint32_t *assignments); /* :237-264 */
 /* FastRng stream (kmeans.rs:21-35) for KATs. */

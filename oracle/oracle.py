@@ -87,6 +87,7 @@ class Oracle:
         s("lo_all_distances", None, _f32p, _f32p, _sz, _sz, C.c_int, C.c_int, _f32p)
         s("lo_merge_results", _sz, _u64p, _f32p, _sz, _sz, C.c_int, _u64p, _f32p)
         s("lo_kmeans_train", _sz, _f32p, _sz, _sz, _sz, _sz, C.c_int, _f32p, _u32p)
+        s("lo_kmeans_train_sharded", _sz, _f32p, _sz, _sz, _sz, _sz, C.c_int, _sz, _f32p, _u32p)
         s("lo_kmeans_assign", None, _f32p, _sz, _sz, _f32p, _sz, C.c_int, _u32p)
         s("lo_fastrng_stream", None, C.c_uint64, _sz, _f64p)
         s("lo_ivf_search", _sz, _f32p, _f32p, _u64p, _sz, _sz, _sz, _f32p, _sz, _u64p, _u32p, _sz,
@@ -329,6 +330,15 @@ class Oracle:
         k = self.lib.lo_kmeans_train(pd, n, dim, requested, max_iter, metric,
                                      cen.ctypes.data_as(_f32p), asg.ctypes.data_as(_u32p))
         return cen[:k].copy(), asg
+
+    def kmeans_train_sharded(self, data, requested, max_iter, metric, world):
+        d, pd_ = self._f(data)
+        n, dim = d.shape
+        k = min(requested, n)
+        cen = np.zeros((k, dim), np.float32)
+        asg = np.zeros(n, np.uint32)
+        got = self.lib.lo_kmeans_train_sharded(pd_, n, dim, requested, max_iter, metric, world, cen.ctypes.data_as(_f32p), asg.ctypes.data_as(_u32p))
+        return cen[:got], asg
 
     def kmeans_assign(self, data, centroids, metric):
         d, pd = self._f(data)

@@ -1,0 +1,180 @@
+"""Row-sharded IVF training on the device (`lynse_hip_ivf_kmeans_sharded`, SURVEY 8e / VERDICT r3 "missing" 2): every rank holds the
+rows g % world == rank, k-means runs over the whole collection with ONE all-reduce of the centroid sums + counts per Lloyd
+iteration, every rank ends with the same centroids and the assignments of its rows.
+
+Checked against the oracle's restatement of that algorithm (`lo_kmeans_train_sharded`: kmeans_train on the union — kmeans.rs:74-139 —
+with the sums formed per rank, sequentially, and added in rank order):
+  * two ranks as two THREADS of this process, the reduction a callback (`lynse_hip_reduce_fn`) that adds the two host buffers —
+    centroid bits and assignments equal the restatement's for ip / l2 / cosine, host rows and device-resident rows;
+  * one rank: identical to the single-index device k-means (`IvfFlatIndex.build`) and to kmeans_train itself;
+  * two gloo PROCESSES sharing the GPU: `ShardedIvf.train` through torch.distributed — same bits again, and the row-sharded index
+    built from the result answers like the oracle's IVFIndex over the union.
+"""
+import os
+import socket
+import sys
+import threading
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import oracle as O
+
+pytestmark = pytest.mark.gpu
+f32 = np.float32
+ROOT = Path(__file__).resolve().parent.parent
+NAME = {O.IP: "ip", O.L2: "l2", O.COS: "cosine"}
+
+
+@pytest.fixture(scope="module")
+def L():
+    import lynsedb_amd as L_
+
+    assert L_._lib.device_count() >= 1
+    return L_
+
+
+def clustered(rng, n, dim, nc=24, spread=0.3):
+    centers = (rng.standard_normal((nc, dim)) * 3).astype(f32)
+    return (centers[rng.integers(0, nc, n)] + spread * rng.standard_normal((n, dim))).astype(f32)
+
+
+class TwoRankSum:
+    """In-process stand-in for the all-reduce: both ranks deposit their buffer, both leave with the sum (rank order 0 + 1)."""
+
+    def __init__(self):
+        self.bar = threading.Barrier(2)
+        self.slots = [None, None]
+
+    def reducer(self, rank):
+        def reduce(arr):
+            self.slots[rank] = arr.copy()
+            self.bar.wait()
+            total = self.slots[0] + self.slots[1]
+            self.bar.wait()
+            arr[:] = total
+        return reduce
+
+
+@pytest.mark.parametrize("metric", [O.L2, O.IP, O.COS])
+@pytest.mark.parametrize("on_device", [False, True])
+def test_two_ranks_in_one_process_equal_the_restatement(L, oracle, metric, on_device):
+    import torch
+
+    from lynsedb_amd.sharded import ShardedIvf
+
+    rng = np.random.default_rng(900 + metric)
+    n, dim, nlist, iters = 20_001, 40, 96, 12          # an odd row count: the ranks hold 10,001 and 10,000 rows
+    data = clustered(rng, n, dim)
+    want_c, want_a = oracle.kmeans_train_sharded(data, nlist, iters, metric, 2)
+    hub = TwoRankSum()
+    out = [None, None]
+    errs = []
+
+    def run(rank):
+        try:
+            sh = ShardedIvf(dim, rank=rank, world=2, device=0)
+            local = np.ascontiguousarray(data[rank::2])
+            rows = torch.from_numpy(local).to("cuda:0") if on_device else local
+            out[rank] = sh.train(rows, n, nlist, iters, NAME[metric], reduce=hub.reducer(rank))
+        except Exception as e:  # noqa: BLE001
+            errs.append((rank, repr(e)))
+            hub.bar.abort()
+
+    ts = [threading.Thread(target=run, args=(r,)) for r in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(300)
+    assert not errs, errs
+    for rank in range(2):
+        cen, asg = out[rank]
+        assert cen.shape == want_c.shape and np.array_equal(cen.view(np.uint32), want_c.view(np.uint32)), (rank, np.abs(cen - want_c).max())
+        assert np.array_equal(asg, want_a[rank::2]), rank
+    # training on the union differs in the rounding of the sums only: a handful of rows on a cell border change sides
+    one_c, one_a = oracle.kmeans_train(data, nlist, iters, metric)
+    assert np.mean(np.concatenate([out[0][1], out[1][1]]) == np.concatenate([one_a[0::2], one_a[1::2]])) > 0.99
+
+
+def test_one_rank_is_the_single_index_training(L, oracle):
+    from lynsedb_amd.sharded import ShardedIvf
+
+    rng = np.random.default_rng(77)
+    n, dim, nlist, iters = 9000, 32, 50, 10
+    data = clustered(rng, n, dim)
+    sh = ShardedIvf(dim, rank=0, world=1, device=0)
+    cen, asg = sh.train(data, n, nlist, iters, "l2")
+    want_c, want_a = oracle.kmeans_train(data, nlist, iters, O.L2)
+    assert np.array_equal(cen.view(np.uint32), want_c.view(np.uint32)) and np.array_equal(asg, want_a)
+    idx = L.IvfFlatIndex.build(None, data, dim, nlist, iters, "l2", l2_partitions=False)
+    c2, a2, _, _ = idx.export()
+    assert np.array_equal(c2.view(np.uint32), cen.view(np.uint32)) and np.array_equal(a2, asg)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _gloo_worker(rank, world, port, ret):
+    sys.path.insert(0, str(ROOT))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch
+    import torch.distributed as dist
+
+    from lynsedb_amd.sharded import ShardedIvf
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rng = np.random.default_rng(4242)           # the same global data on every rank
+        n, dim, nlist, nprobe, k = 30_000, 48, 64, 6, 10
+        data = clustered(rng, n, dim)
+        queries = data[rng.integers(0, n, 24)] + 0.05 * rng.standard_normal((24, dim)).astype(np.float32)
+        sh = ShardedIvf(dim, rank=rank, world=world, device=0, group=dist)
+        local = np.ascontiguousarray(data[rank::world])
+        cen, asg = sh.train(local, n, nlist, 8, "ip")          # torch.distributed (gloo) sums the host buffers
+        sh.load_local(local, cen, asg, "ip")
+        rows, dists, counts = sh.search(queries.astype(np.float32), k, nprobe)
+        ret[rank] = (cen, asg, rows, dists, counts)
+    finally:
+        dist.destroy_process_group()
+        del torch
+
+
+def test_two_gloo_processes_train_and_search_like_the_union(L, oracle):
+    import multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    with ctx.Manager() as m:
+        ret = m.dict()
+        port = _free_port()
+        ps = [ctx.Process(target=_gloo_worker, args=(r, 2, port, ret)) for r in range(2)]
+        for p in ps:
+            p.start()
+        for p in ps:
+            p.join(600)
+            assert p.exitcode == 0
+        got = [ret[0], ret[1]]
+    rng = np.random.default_rng(4242)
+    n, dim, nlist, nprobe, k = 30_000, 48, 64, 6, 10
+    data = clustered(rng, n, dim)
+    queries = (data[rng.integers(0, n, 24)] + 0.05 * rng.standard_normal((24, dim)).astype(f32)).astype(f32)
+    want_c, want_a = oracle.kmeans_train_sharded(data, nlist, 8, O.IP, 2)
+    for rank in range(2):
+        cen, asg, rows, dists, counts = got[rank]
+        assert np.array_equal(cen.view(np.uint32), want_c.view(np.uint32)) and np.array_equal(asg, want_a[rank::2]), rank
+    # the row-sharded index answers like IVFIndex::search over the union under these centroids / lists (ivf.rs:181-348)
+    offsets, list_rows = oracle.lists_from_assignments(want_a, want_c.shape[0])
+    rows, dists, counts = got[0][2], got[0][3], got[0][4]
+    assert np.array_equal(got[1][2], rows) and np.array_equal(got[1][3].view(np.uint32), dists.view(np.uint32))
+    for qi in range(queries.shape[0]):
+        e_ids, e_d, _ = oracle.ivf_search(queries[qi], data, want_c, offsets, list_rows, nprobe, k, O.IP)
+        c = int(counts[qi])
+        assert c == len(e_ids) and np.array_equal(rows[qi, :c].astype(np.uint64), e_ids.astype(np.uint64)), qi
+        assert np.array_equal(dists[qi, :c].view(np.uint32), e_d.view(np.uint32)), qi

@@ -136,3 +136,62 @@ def test_sharded_ivf_exchange_world2():
     ret = mgr.dict()
     mp.spawn(_ivf_worker, args=(world, port, ret), nprocs=world, join=True)
     assert dict(ret) == {0: True, 1: True}
+
+
+def _reduce_worker(rank, world, port, ret):
+    sys.path.insert(0, str(ROOT))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import ctypes as C
+
+    import torch.distributed as dist
+
+    from lynsedb_amd.sharded import ShardedIvf
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sh = ShardedIvf(8, rank=rank, world=world, device=0, group=dist)
+        fn = sh._host_reduce(None, 0)                      # the lynse_hip_reduce_fn the all-reduced k-means calls (lynse_hip_ivf_kmeans_sharded)
+        f = (np.arange(1000, dtype=np.float32) * (rank + 1) * 0.37).astype(np.float32)
+        u = (np.arange(77, dtype=np.uint32) + 5 * rank).astype(np.uint32)
+        assert fn(None, f.ctypes.data_as(C.c_void_p), f.size, 0) == 0
+        assert fn(None, u.ctypes.data_as(C.c_void_p), u.size, 1) == 0
+        ret[rank] = (f.copy(), u.copy())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_kmeans_reduction_world2_and_the_restatement_it_is_tested_against():
+    """Host side of the row-sharded IVF training (lynse_hip_ivf_kmeans_sharded; the device part: tests/test_gpu_sharded_kmeans.py):
+    (1) the reduction callback of the launcher sums f32 / u32 host buffers over the gloo ranks in place; (2) the oracle's
+    restatement of the sharded algorithm (lo_kmeans_train_sharded: per-rank sequential sums added in rank order) is kmeans_train
+    itself for one rank — bit for bit — and stays within rounding of it for two (same lists on well-separated data)."""
+    import multiprocessing as mp
+
+    import oracle as O
+
+    ctx = mp.get_context("spawn")
+    with ctx.Manager() as m:
+        ret = m.dict()
+        port = _free_port()
+        ps = [ctx.Process(target=_reduce_worker, args=(r, 2, port, ret)) for r in range(2)]
+        for p in ps:
+            p.start()
+        for p in ps:
+            p.join(120)
+            assert p.exitcode == 0
+        f0, u0 = ret[0]
+        f1, u1 = ret[1]
+    want_f = (np.arange(1000, dtype=np.float32) * 0.37).astype(np.float32) + (np.arange(1000, dtype=np.float32) * 2 * 0.37).astype(np.float32)
+    assert np.array_equal(f0.view(np.uint32), want_f.view(np.uint32)) and np.array_equal(f1.view(np.uint32), want_f.view(np.uint32))
+    assert np.array_equal(u0, np.arange(77, dtype=np.uint32) * 2 + 5) and np.array_equal(u1, u0)
+    orc = O.get()
+    rng = np.random.default_rng(5)
+    centers = (rng.standard_normal((12, 24)) * 4).astype(np.float32)
+    data = (centers[rng.integers(0, 12, 5000)] + 0.3 * rng.standard_normal((5000, 24))).astype(np.float32)
+    for metric in (O.L2, O.IP, O.COS):
+        c_one, a_one = orc.kmeans_train(data, 12, 20, metric)
+        c_w1, a_w1 = orc.kmeans_train_sharded(data, 12, 20, metric, 1)
+        assert np.array_equal(c_one.view(np.uint32), c_w1.view(np.uint32)) and np.array_equal(a_one, a_w1)
+        c_w2, a_w2 = orc.kmeans_train_sharded(data, 12, 20, metric, 2)
+        assert np.allclose(c_one, c_w2, rtol=1e-5, atol=1e-5) and np.array_equal(a_one, a_w2), metric
