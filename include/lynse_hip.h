@@ -409,6 +409,28 @@ int lynse_hip_flat_search_wait(lynse_hip_ticket *t);
  * may still be writing into it).  LYNSE_HIP_WAIT_TIMEOUT_MS sets the initial value. */
 int lynse_hip_set_wait_timeout_ms(uint32_t ms);
 
+/* IVF searches in flight (IVFIndex::search, src/index/ivf.rs:181-348, under the same concurrent readers): submit ENQUEUES a batch of
+ * <= 256 queries of a float IVF index on one of the slab store's search contexts 1 .. LYNSE_HIP_CONTEXTS-1 (context 0 stays with
+ * the blocking searches, which keep working next to tickets) — query images, the centroid ranking, device-side grouping, the list
+ * scans, exact rescoring and, with a communicator, the ncclAllGather of the result blocks + the device merge — with NO host
+ * synchronisation in between; wait blocks until the batch is final in the caller's DEVICE arrays and frees the ticket.  Results
+ * are those of lynse_hip_ivf_search_f32_device / lynse_hip_ivf_search_sharded_f32_device: whatever the blocking path would have
+ * checked on the host (candidate overflow of the scans or of the centroid ranking, the all-lists-empty fallback of ivf.rs:258-265)
+ * travels as a status word and is re-answered by the blocking ladder inside wait, on every rank of a sharded index.  The index
+ * metric is used.  A shape the device-side grouping does not take (nprobe >= nlist, more than 16384 (query, list) pairs, more
+ * than 8192 lists) is answered synchronously inside submit (a sharded ticket still exchanges in flight); binary indexes and k
+ * beyond the staged pipeline return LYNSE_ERR_UNSUPPORTED.  insert / delete are refused while tickets are outstanding.  With a
+ * communicator submit is a COLLECTIVE: every rank submits and waits for the same sequence; one communicator serves the tickets of
+ * ONE handle at a time.  lynse_hip_set_wait_timeout_ms applies. */
+typedef struct lynse_hip_ivf_ticket lynse_hip_ivf_ticket;
+int lynse_hip_ivf_search_submit_f32_device(lynse_hip_ivf *h, lynse_hip_comm *c, const float *d_queries, uint64_t nq, uint32_t k,
+                                           uint32_t nprobe, uint64_t *d_out_rows, float *d_out_dists, uint32_t *d_out_counts,
+                                           lynse_hip_ivf_ticket **out);
+int lynse_hip_ivf_search_wait(lynse_hip_ivf_ticket *t);
+/* out[0..2]: tickets of this index whose local part was enqueued without a host synchronisation / answered inside submit /
+ * re-answered inside wait (monitoring; that a batch ran in flight is not visible in its results). */
+int lynse_hip_ivf_ticket_stats(lynse_hip_ivf *h, uint64_t *out);
+
 /* Diagnostics of the certified coarse pass (no reference counterpart: the reference scans f32 rows).  For a shard of at most `cap`
  * (16,384) rows and 1..256 host queries: out_scores[q][row] = the COARSE score of (row, query) exactly as the scan kernels compute
  * it (one emit-all stage of the real pipeline), in the metric's own space (IP: score; L2 / cosine: distance); out_bound[q] = the

@@ -127,6 +127,9 @@ SIGNATURES = {
     "lynse_hip_flat_search_submit_packed_u64_device": (C.c_int, [_vp, _vp, _vp, C.c_uint64, C.c_uint32, C.c_int, _vp, _vp, _vp, C.POINTER(_vp)]),
     "lynse_hip_flat_search_wait": (C.c_int, [_vp]),
     "lynse_hip_set_wait_timeout_ms": (C.c_int, [C.c_uint32]),
+    "lynse_hip_ivf_search_submit_f32_device": (C.c_int, [_vp, _vp, _vp, C.c_uint64, C.c_uint32, C.c_uint32, _vp, _vp, _vp, C.POINTER(_vp)]),
+    "lynse_hip_ivf_search_wait": (C.c_int, [_vp]),
+    "lynse_hip_ivf_ticket_stats": (C.c_int, [_vp, _vp]),
     "lynse_hip_ivf_kmeans_sharded": (C.c_int, [_vp, C.c_uint64, C.c_int, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_int,
                                               _vp, _vp, _vp, _vp, _vp, C.POINTER(C.c_uint32)]),
     "lynse_hip_flat_coarse_scores": (C.c_int, [_vp, _vp, C.c_uint64, C.c_int, C.c_int, _vp, _vp, C.POINTER(C.c_int)]),

@@ -362,14 +362,14 @@ class FlatIndex:
 class SearchTicket:
     """A batch in flight (FlatIndex.search_submit).  Keeps the tensors of the batch alive until it is waited for."""
 
-    def __init__(self, handle, keep):
-        self._t, self._keep = handle, keep
+    def __init__(self, handle, keep, ivf: bool = False):
+        self._t, self._keep, self._ivf = handle, keep, ivf
 
     def wait(self) -> None:
         t, self._t = self._t, None
         if t is not None:
             try:
-                check(lib.lynse_hip_flat_search_wait(t))
+                check((lib.lynse_hip_ivf_search_wait if self._ivf else lib.lynse_hip_flat_search_wait)(t))
             finally:
                 self._keep = None
 
@@ -449,6 +449,23 @@ class IvfFlatIndex:
         if ivfflat_routing:
             check(lib.lynse_hip_ivf_set_routing(h, 1))
         return idx
+
+    def search_submit(self, d_queries, k: int, nprobe: int, d_rows, d_dists, d_counts, comm=None) -> "SearchTicket":
+        """One batch IN FLIGHT (lynse_hip_ivf_search_submit_f32_device): <= 256 queries, torch tensors on the index's device; `wait()`
+        of the ticket makes d_rows / d_dists / d_counts final — the results of `search_device`.  Up to LYNSE_HIP_CONTEXTS - 1 batches
+        overlap on the device.  `comm`: the communicator handle of a row-sharded index (a collective then)."""
+        _sync_producer(d_queries)
+        t = C.c_void_p()
+        check(lib.lynse_hip_ivf_search_submit_f32_device(self._h, comm, C.c_void_p(d_queries.data_ptr()), d_queries.shape[0], int(k), int(nprobe),
+                                                         C.c_void_p(d_rows.data_ptr()), C.c_void_p(d_dists.data_ptr()),
+                                                         C.c_void_p(d_counts.data_ptr()), C.byref(t)))
+        return SearchTicket(t, (d_queries, d_rows, d_dists, d_counts), ivf=True)
+
+    def ticket_stats(self) -> dict:
+        """Tickets of this index so far: enqueued without a host synchronisation / answered inside submit / re-answered inside wait."""
+        out = np.zeros(3, np.uint64)
+        check(lib.lynse_hip_ivf_ticket_stats(self._h, _ptr(out)))
+        return {"in_flight": int(out[0]), "inside_submit": int(out[1]), "redone_in_wait": int(out[2])}
 
     def set_fused_search(self, on: bool = True) -> None:
         """on=False forces the staged pipeline for few-query searches too (tests, A/B); results are identical."""

@@ -583,3 +583,8 @@ __global__ void __launch_bounds__(256) k_ivf_score_positions_packed(IvfScorePack
 }
 
 }  // namespace lynse
+
+// searches in flight: OR a device flag (the all-lists-empty flag of k_ivf_group) into the status word of the ticket
+__global__ void k_or_word(uint32_t* dst, const uint32_t* src) {
+    if (*src) atomicOr(dst, 2u);
+}

@@ -3390,3 +3390,4 @@ extern "C" int lynse_hip_merge_topk_device(const void* d_blocks, uint64_t block_
 #include "shard_host.inc"
 #include "comm_host.inc"
 #include "async_host.inc"
+#include "ivf_async.inc"

@@ -513,6 +513,21 @@ class ShardedIvf:
                                               C.c_void_p(out.dists.data_ptr()), C.c_void_p(out.counts.data_ptr()),
                                               C.c_void_p(torch.cuda.current_stream().cuda_stream)))
 
+    def search_submit(self, d_queries, k: int, nprobe: int, out: "ShardOutputs"):
+        """One batch IN FLIGHT (lynse_hip_ivf_search_submit_f32_device): local list scans -> ncclAllGather -> merge enqueued on a search
+        context of the shard; the ticket's wait() makes out.rows / dists / counts final.  A collective with world > 1.  Needs the
+        native communicator (or world == 1); without it the batch is answered here and the ticket is already complete."""
+        if self.world == 1 or self.comm is not None:
+            return self.index.search_submit(d_queries, k, nprobe, out.rows, out.dists, out.counts,
+                                            comm=self.comm.handle if self.comm is not None else None)
+
+        class _Done:
+            def wait(self):
+                return None
+
+        self.search_device(d_queries, k, nprobe, out)
+        return _Done()
+
     def search_local(self, queries: np.ndarray, k: int, nprobe: int):
         """This rank's candidates: global row ids (local row l -> l * world + rank), canonical order."""
         return self.index.search_batch_arrays(queries, k, nprobe)
