@@ -61,6 +61,13 @@ def parse_args():
     p.add_argument("--profile-every", type=int, default=4, help="HIP-event timing of the scan launches on every n-th step of the timed region")
     p.add_argument("--settle-ms", type=float, default=60.0, help="untimed steps before the warm-up until the GPU's clocks have settled (0 = none)")
     p.add_argument("--no-configs", action="store_true", help="skip the extra keys: the other BASELINE configurations and the second data distribution")
+    p.add_argument("--config", default="c2", choices=["c2", "c4"],
+                   help="c2 (default): FLAT-IP 10M x 768, the headline; c4: IVF-Flat IP nlist 4096 / nprobe 32, 6.25M x 768 rows PER GPU "
+                        "(50M x 768 at --gpus 8, BASELINE.json configs[3]), centroids trained over the sharded collection")
+    p.add_argument("--rows-per-gpu", type=int, default=6_250_000, help="--config c4: rows of every rank's shard")
+    p.add_argument("--nlist", type=int, default=4096)
+    p.add_argument("--nprobe", type=int, default=32)
+    p.add_argument("--train-iters", type=int, default=2, help="--config c4: Lloyd iterations of the sharded k-means")
     p.add_argument("--launch-timeout", type=float, default=1500.0, help="--gpus N without a launcher: seconds the self-started N-rank run may take")
     p.add_argument("--in-flight", type=int, default=int(os.environ.get("LYNSE_BENCH_IN_FLIGHT", "0")),
                    help="batches in flight (lynse_hip_flat_search_submit_* / _wait): step i+1 is enqueued before step i is waited "
@@ -137,6 +144,9 @@ def main():
 
     import lynsedb_amd as L
     from lynsedb_amd.sharded import ShardedFlat
+
+    if args.config == "c4":
+        return run_c4(args, rank, local_rank, world, dev, dist, result_out)
 
     N, D, B, K = args.rows, args.dim, args.batch, args.k
     metric = L.metric_from_str(args.metric)
@@ -408,6 +418,186 @@ def main():
     if dist is not None:
         dist.barrier()
         if sh.comm is not None:   # the library's communicator goes first, while every rank is still alive
+            try:
+                sh.comm.close()
+            except Exception:  # noqa: BLE001
+                pass
+            sh.comm = None
+        dist.destroy_process_group()
+
+
+def run_c4(args, rank, local_rank, world, dev, dist, result_out):
+    """BASELINE.json configs[3]: IVF-Flat IP, nlist 4096 / nprobe 32 / k 10 over a collection row-sharded across the ranks (6.25M x
+    768 rows per GPU: 50M x 768 at 8 GPUs; "scaling": "weak").  Build inside the job, nothing supplied from outside: every rank
+    generates ITS rows (global row g = l * world + rank: unit centre g % 4096 + sigma 0.03 noise, benchmarks/ivf_kmeans_baseline.py:45-55),
+    the centroids are trained over the whole collection by the all-reduced k-means (lynse_hip_ivf_kmeans_sharded: one ncclAllReduce
+    of nlist x D sums + nlist counts per Lloyd iteration), every rank files its rows under them.  A step = one batch of 256 queries:
+    centroid ranking, local list scans (certified int8 pass), exact rescoring, ncclAllGather of the (distance, row) blocks, device
+    merge — batches in flight through lynse_hip_ivf_search_submit_f32_device, every step final inside the timed region."""
+    import lynsedb_amd as L
+    from lynsedb_amd.sharded import ShardedIvf, ShardOutputs
+
+    D, B, K, nlist, nprobe = args.dim, args.batch, args.k, args.nlist, args.nprobe
+    n_local = args.rows_per_gpu
+    N = n_local * world
+    KC = 4096
+    g = torch.Generator(device=dev)
+    g.manual_seed(7)
+    centers = torch.randn((KC, D), generator=g, device=dev)      # the same on every rank
+    centers /= centers.norm(dim=1, keepdim=True)
+    g.manual_seed(1000 + rank)                                   # the noise of this rank's rows
+    t0 = time.time()
+    rows_d = torch.empty((n_local, D), device=dev, dtype=torch.float32)
+    for b0 in range(0, n_local, 250_000):
+        e = min(n_local, b0 + 250_000)
+        gids = torch.arange(b0, e, device=dev) * world + rank
+        rows_d[b0:e] = centers[gids % KC] + 0.03 * torch.randn((e - b0, D), generator=g, device=dev)
+    torch.cuda.synchronize()
+    gen_s = time.time() - t0
+    sh = ShardedIvf(D, rank=rank, world=world, device=local_rank, group=dist)
+    native = False
+    if world > 1 and (dist is None or dist.get_backend() == "nccl"):
+        native = sh.enable_native_comm()
+    t0 = time.time()
+    cen, asg = sh.train(rows_d, N, nlist, args.train_iters, "ip")
+    torch.cuda.synchronize()
+    train_s = time.time() - t0
+    t0 = time.time()
+    sh.load_local_device(rows_d, cen, asg, "ip")
+    del rows_d
+    torch.cuda.empty_cache()
+    torch.cuda.synchronize()
+    load_s = time.time() - t0
+    # queries: perturbed rows of the collection (every rank builds the same batch: rank 0's choice is broadcast)
+    g.manual_seed(99)
+    qsel = torch.randint(0, KC, (B,), generator=g, device=dev)
+    queries = (centers[qsel] + 0.03 * torch.randn((B, D), generator=g, device=dev)).contiguous()
+    if dist is not None:
+        dist.broadcast(queries, src=0)
+    in_flight = max(1, min(args.in_flight, 3)) if args.in_flight > 0 else 3
+    if world > 1 and not native:
+        in_flight = 1
+    outs = [ShardOutputs(B, K, world, dev) for _ in range(in_flight)]
+
+    def run_steps(n):
+        if in_flight == 1:
+            for _ in range(n):
+                sh.search_device(queries, K, nprobe, outs[0])
+            return
+        pending = []
+        for i in range(n):
+            pending.append(sh.search_submit(queries, K, nprobe, outs[i % in_flight]))
+            if len(pending) >= in_flight:
+                pending.pop(0).wait()
+        for t in pending:
+            t.wait()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    import gc
+    gc.collect()
+    gc.disable()
+    run_steps(max(3, in_flight) * 2)            # first calls: derived data (SQ8 codes), workspaces, contexts
+    torch.cuda.synchronize()
+    run_steps(20)                               # clocks
+    run_steps(args.warmup)
+    sh.index.profile_enable(True)
+    sh.index.profile_get(reset=True)
+    barrier()
+    for _ in range(3):                          # scan-launch timing on three BLOCKING steps outside the timed region (tickets are not profiled)
+        sh.search_device(queries, K, nprobe, outs[0])
+    prof = sh.index.profile_get(reset=True)
+    sh.index.profile_enable(False)
+    barrier()
+    t_start = time.perf_counter()
+    run_steps(args.steps)
+    barrier()
+    elapsed = time.perf_counter() - t_start
+    barrier()
+    t_lat = time.perf_counter()
+    for _ in range(5):
+        sh.search_device(queries, K, nprobe, outs[0])
+    barrier()
+    lat_ms = (time.perf_counter() - t_lat) / 5 * 1000.0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    gc.enable()
+    stats = sh.index.ticket_stats()
+    # ---- verification, outside the timed region: (a) tickets == the blocking sharded search, bit for bit; (b) recall@k against the
+    # exact top-k of the WHOLE collection (torch fp32 matmul over every rank's rows, candidates gathered and merged)
+    o_t, o_b = ShardOutputs(B, K, world, dev), ShardOutputs(B, K, world, dev)
+    sh.search_submit(queries, K, nprobe, o_t).wait()
+    sh.search_device(queries, K, nprobe, o_b)
+    torch.cuda.synchronize()
+    same = bool(torch.equal(o_t.rows, o_b.rows) and torch.equal(o_t.dists, o_b.dists) and torch.equal(o_t.counts, o_b.counts))
+    nv = min(args.verify_queries, B)
+    best_s = torch.full((nv, K), -float("inf"), device=dev)
+    best_r = torch.zeros((nv, K), dtype=torch.int64, device=dev)
+    # (the slab-ordered rows live inside the library: this rank's rows are regenerated block-wise from the same generator state)
+    g.manual_seed(1000 + rank)
+    for b0 in range(0, n_local, 250_000):
+        e = min(n_local, b0 + 250_000)
+        gids = torch.arange(b0, e, device=dev) * world + rank
+        blk = centers[gids % KC] + 0.03 * torch.randn((e - b0, D), generator=g, device=dev)
+        sc = queries[:nv] @ blk.T
+        cs, ci = torch.cat([best_s, sc], dim=1).topk(K, dim=1)
+        allr = torch.cat([best_r, gids.unsqueeze(0).expand(nv, -1)], dim=1)
+        best_s, best_r = cs, torch.gather(allr, 1, ci)
+        del blk, sc
+    if dist is not None:
+        gs = [torch.empty_like(best_s) for _ in range(world)]
+        gr = [torch.empty_like(best_r) for _ in range(world)]
+        dist.all_gather(gs, best_s)
+        dist.all_gather(gr, best_r)
+        cs, ci = torch.cat(gs, dim=1).topk(K, dim=1)
+        best_r = torch.gather(torch.cat(gr, dim=1), 1, ci)
+    got = o_b.rows[:nv].cpu().numpy()
+    exact = best_r.cpu().numpy()
+    recall = float(np.mean([len(set(got[i].tolist()) & set(exact[i].tolist())) / K for i in range(nv)]))
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1000.0
+        qps = B * args.steps / elapsed
+        plan = int(prof.get("last_plan", 0))
+        i8c = bool(plan & 4)
+        launches = max(int(prof["scan_launches"]), 1)
+        scan_s = prof["scan_us"] * 1e-6
+        elem = 1 if i8c else 2
+        kernel_bytes = float(prof["scan_rows"]) * D * elem            # rows of the probed lists the tiled scans streamed (3 steps)
+        hbm_gbps = kernel_bytes / scan_s / 1e9 if scan_s > 0 else 0.0
+        result = {
+            "metric": "queries/sec, IVF-Flat IP %dx%d float32, nlist=%d nprobe=%d, batch=%d, k=%d" % (N, D, nlist, nprobe, B, K),
+            "value": round(qps, 1), "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "C4 IVF-Flat IP %dx%d f32 (%d unit centres + sigma 0.03), nlist=%d nprobe=%d, %d queries, k=%d"
+                                   % (N, D, KC, nlist, nprobe, B, K),
+                       "rows_per_gpu": n_local, "sharding": "row %% %d of every list, one set of centroids" % world,
+                       "training": "all-reduced k-means over the sharded collection, %d Lloyd iterations (%s)" % (
+                           args.train_iters, "ncclAllReduce inside the library" if native else ("torch.distributed" if world > 1 else "one rank")),
+                       "exchange": ("rccl all_gather of %d B/rank inside the library" % (B * K * 12 + B * 4 + 16)) if native else
+                                   ("torch.distributed" if world > 1 else "none"),
+                       "batches_in_flight": in_flight, "generate_s": round(gen_s, 1), "train_s": round(train_s, 1), "load_s": round(load_s, 1),
+                       "lists_trained": int(cen.shape[0])},
+            "roofline": {"bound": "hbm", "kernel": "k_scan_h16<..,TILED,%s> over the probed lists" % ("I8C" if i8c else "F16"),
+                         "achieved": round(hbm_gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(hbm_gbps / HBM_PEAK_GBPS, 4),
+                         "traffic": None, "launches": launches, "avg_launch_us": round(prof["scan_us"] / launches, 2),
+                         "rows_scanned_per_step": int(prof["scan_rows"] // max(int(prof["searches"]), 1)),
+                         "note": "rank-0 shard, three blocking steps outside the timed region (HIP events around the tiled scan launches); "
+                                 "bytes = rows of the probed lists x %d B/element" % elem},
+            "blocking_ms_per_batch": round(lat_ms, 4),
+            "tickets": stats,
+            "verify": {"tickets_equal_blocking_search": same, "queries": nv, "recall_at_k_vs_exact_top_k_of_the_collection": recall},
+        }
+        result_out.write(json.dumps(result) + "\n")
+        result_out.flush()
+    if dist is not None:
+        dist.barrier()
+        if sh.comm is not None:
             try:
                 sh.comm.close()
             except Exception:  # noqa: BLE001

@@ -145,7 +145,7 @@ struct IvfGroupArgs {
     uint32_t* tbase;           // out [3][gmax]: first tile of group g in window w
     uint32_t gmax;
     IvfTile* tiles;            // out [3][win_cap] (k_ivf_emit_tiles)
-    uint32_t* hdr;             // out: [0] groups, [1..3] tiles of window 0..2, [4] host path needed, [5] pairs
+    uint32_t* hdr;             // out: [0] groups, [1..3] tiles of window 0..2, [4] host path needed, [5] pairs, [6] rows of all tiles (profiling)
 };
 
 // inclusive scan of v[0, n) in place by one workgroup of NT threads; tot: NT / 64 words of LDS
@@ -240,7 +240,7 @@ __global__ void __launch_bounds__(NT) k_ivf_group(IvfGroupArgs a) {
         }
         __syncthreads();
     }
-    if (tid == 0) { a.hdr[0] = G; a.hdr[4] = s_flag; a.hdr[5] = nv; }
+    if (tid == 0) { a.hdr[0] = G; a.hdr[4] = s_flag; a.hdr[5] = nv; a.hdr[6] = 0u; }
 }
 
 // the tile records of every (window, group): one thread each
@@ -254,6 +254,7 @@ __global__ void __launch_bounds__(256) k_ivf_emit_tiles(IvfGroupArgs a) {
         const uint64_t b0 = a.offsets[gr.list], len = a.offsets[gr.list + 1] - b0;
         const uint64_t lo = wlo < len ? wlo : len, hi = whi < len ? whi : len;
         uint32_t t = a.tbase[(size_t)w * a.gmax + g];
+        if (hi > lo) atomicAdd(&a.hdr[6], (uint32_t)(hi - lo));
         for (uint64_t r = lo; r < hi; r += a.tile_rows, ++t)
             if (t < a.win_cap)
                 a.tiles[(size_t)w * a.win_cap + t] = {(uint32_t)(b0 + r), (uint32_t)(hi - r < a.tile_rows ? hi - r : a.tile_rows), gr.qimg_off, gr.pair0, gr.nq};
