@@ -3215,11 +3215,70 @@ __device__ __forceinline__ uint32_t next_pow2(uint32_t n) {
 }
 
 // Rescore keys[0..n) exactly (8 lanes per candidate); overwrite their score words.
+// scr / scr_bytes: free LDS of the caller (16-B aligned).  With enough of it the rows go THROUGH LDS: the workgroup loads a chunk
+// of candidate rows with coalesced 16-B loads (one global round trip per chunk, the next chunk's loads in flight while this one is
+// scored) and the reference-order FMA chains of exact_score run out of LDS with the query staged next to them — straight from
+// global memory a 768-d row is three dependent round trips of 2 x 32 strided 4-B loads per lane (k_select's threshold rescoring
+// of 2k = 20 rows: 9 us -> 5.6 us, twice per shard step).  Used where the rows fit ONE batch; larger pools keep the direct loads.  Row stride D + 8 floats: the eight
+// lane groups of a wave read eight different bank octets.
 template <int NT>
 __device__ __forceinline__ void rescore_keys(uint64_t* keys, uint32_t n, int metric, int ip_form,
                                              const float* qv, const float* V, uint32_t ld, uint32_t D,
-                                             bool asc, int tid, bool neg = false) {
-    // neg: the keys live in the NEGATED score space of an ascending metric run as a best-first scan (SelectArgs::neg_metric1)
+                                             bool asc, int tid, bool neg = false, char* scr = nullptr, uint32_t scr_bytes = 0) {
+    {
+        constexpr uint32_t MAXV = 8;                       // 16-B loads per thread and batch: 21 rows of 768 floats in ONE global round trip
+        const uint32_t vpr = D / 4u, stride = D + 8u;
+        const bool shape = scr && n && ip_form != LYNSE_IPFORM_F16SEQ && (D & 3u) == 0 && (ld & 3u) == 0 && (reinterpret_cast<uintptr_t>(V) & 15u) == 0 &&
+                           vpr <= MAXV * (uint32_t)NT / 8u && scr_bytes >= (D + 8u * stride) * 4u;   // (at least 8 rows per batch and per chunk, or the direct loads win)
+        if (shape) {   // (uniform over the workgroup)
+            float* q_l = reinterpret_cast<float*>(scr);
+            float* rows_l = q_l + D;
+            uint32_t R = (scr_bytes / 4u - D) / stride;                      // rows per LDS chunk
+            R = R < (uint32_t)(NT / 8) ? R : (uint32_t)(NT / 8);
+            uint32_t F = MAXV * (uint32_t)NT / vpr;                          // rows per batch of loads (held in registers until their chunk's turn)
+            F = F < (uint32_t)(NT / 8) ? F : (uint32_t)(NT / 8);
+            const int g = tid & 7;
+            const uint32_t grp = tid >> 3;
+            for (uint32_t i = tid; i < D; i += NT) q_l[i] = qv[i];
+            for (uint32_t f0 = 0; f0 < n; f0 += F) {
+                const uint32_t fn = n - f0 < F ? n - f0 : F;
+                f32x4 pre[MAXV];
+                uint32_t prow4[MAXV / 4];   // row of the batch an element belongs to, one byte each (0xff: none; rows of a batch < NT / 8 <= 255)
+#pragma unroll
+                for (uint32_t u = 0; u < MAXV / 4; ++u) prow4[u] = 0xffffffffu;
+#pragma unroll
+                for (uint32_t u = 0; u < MAXV; ++u) {
+                    const uint32_t t = (uint32_t)tid + u * NT;
+                    if (t < fn * vpr) {
+                        const uint32_t r = t / vpr, c = t - r * vpr;
+                        prow4[u / 4] = (prow4[u / 4] & ~(0xffu << (8 * (u % 4)))) | (r << (8 * (u % 4)));
+                        pre[u] = *reinterpret_cast<const f32x4*>(V + (size_t)key_row(keys[f0 + r]) * ld + c * 4u);
+                    }
+                }
+                for (uint32_t c0 = 0; c0 < fn; c0 += R) {
+                    const uint32_t rn = fn - c0 < R ? fn - c0 : R;
+                    __syncthreads();   // the previous chunk has been scored
+#pragma unroll
+                    for (uint32_t u = 0; u < MAXV; ++u) {
+                        const uint32_t r = (prow4[u / 4] >> (8 * (u % 4))) & 0xffu;
+                        if (r >= c0 && r < c0 + rn) {   // (0xff never passes: c0 + rn <= fn <= NT / 8)
+                            const uint32_t t = (uint32_t)tid + u * NT;
+                            *reinterpret_cast<f32x4*>(rows_l + (size_t)(r - c0) * stride + (t - r * vpr) * 4u) = pre[u];
+                        }
+                    }
+                    __syncthreads();
+                    if (grp < rn) {
+                        const uint32_t row = key_row(keys[f0 + c0 + grp]);
+                        float sc = exact_score<32>(metric, ip_form, q_l, rows_l + (size_t)grp * stride, D, g);
+                        if (neg) sc = -sc;
+                        if (g == 0) keys[f0 + c0 + grp] = make_key(sc, row, asc);
+                    }
+                }
+            }
+            __syncthreads();
+            return;
+        }
+    }
     const int g = tid & 7;
     const uint32_t grp = tid >> 3;
     const uint32_t rounds = (n + NT / 8 - 1) / (NT / 8);
@@ -3310,6 +3369,7 @@ struct SelectArgs {
     // != 0: `metric` only gives the KEY ORDER (M_IP: best-first); exact scores are those of metric neg_metric1 - 1, NEGATED —
     // the certified int8 pass of an ascending metric (squared L2 as an augmented inner product, k_i8c_prep_queries aug = 1)
     int neg_metric1;
+    uint32_t lds_bytes;   // dynamic LDS of the launch (keys: cap x 8 B, the rest is scratch of the exact rescoring); 0 = cap x 8
 };
 
 // k_select finds the k-th best key with an 8-pass MSB radix select over the keys in LDS (256-bin
@@ -3535,7 +3595,10 @@ __device__ __forceinline__ uint32_t select_body(const SelectArgs& a, uint64_t* k
             __syncthreads();
             const uint32_t m = s_x < mx ? s_x : mx;   // >= k: at least k keys are <= the k-th smallest
             if (m >= a.k) {
-                rescore_keys<NT>(xs, m, a.neg_metric1 ? a.neg_metric1 - 1 : a.metric, a.ip_form, a.Qf + (size_t)q * a.D, a.V, a.ld, a.D, asc, tid, a.neg_metric1 != 0);
+                // (scratch: the LDS behind the n keys of this query)
+                const uint32_t used = (n * 8u + 15u) & ~15u, lds_all = a.lds_bytes ? a.lds_bytes : a.cap * 8u;
+                rescore_keys<NT>(xs, m, a.neg_metric1 ? a.neg_metric1 - 1 : a.metric, a.ip_form, a.Qf + (size_t)q * a.D, a.V, a.ld, a.D, asc, tid, a.neg_metric1 != 0,
+                                 reinterpret_cast<char*>(keys) + used, lds_all > used ? lds_all - used : 0u);
                 // the k-th best of the m <= 256 rescored keys by RANK (keys are unique: the row is part of the key): one thread per key
                 // counts the smaller ones — m broadcast LDS reads instead of the 36 barrier-separated steps of a 256-key bitonic sort
                 __shared__ float s_taux;
@@ -3709,9 +3772,11 @@ struct SmallArgs {
     const uint64_t* list_off;
     const uint32_t* orig;
     int flag_empty;
+    unsigned long long* dbg;   // development (LYNSE_HIP_SMALL_DBG=1): s_memtime stamps [workgroup][4] + the last workgroup's [2]; NULL otherwise
 };
 
 __global__ void __launch_bounds__(SMALL_NT) k_small_search(SmallArgs a) {
+    if (a.dbg && threadIdx.x == 0) a.dbg[(size_t)blockIdx.x * 4 + 0] = wall_clock64();
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* qs = reinterpret_cast<float*>(smem);                                   // D floats: the query being scanned
     uint64_t* wl = reinterpret_cast<uint64_t*>(smem + (size_t)((a.D + 3) / 4 * 4) * 4);  // [8 waves][64] keys; later the merge lists
@@ -3780,6 +3845,7 @@ __global__ void __launch_bounds__(SMALL_NT) k_small_search(SmallArgs a) {
         }
         wl[wave * 64 + lane] = lane < (int)k ? L : KEY_SENTINEL;
         __syncthreads();
+        if (a.dbg && tid == 0) a.dbg[(size_t)blockIdx.x * 4 + 1] = wall_clock64();
         {   // merge the waves by rank: one key per thread, keys are unique apart from the sentinel.  Every wave list is sorted
             // (slots >= k hold the sentinel), so the rank of a key is the sum of eight branch-free binary searches — seven
             // dependent LDS reads with the eight lists interleaved, instead of 8 k sequential reads per thread.
@@ -3817,6 +3883,7 @@ __global__ void __launch_bounds__(SMALL_NT) k_small_search(SmallArgs a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) {
+        if (a.dbg) a.dbg[(size_t)blockIdx.x * 4 + 2] = wall_clock64();
         const uint32_t t = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         s_last = (t == gridDim.x - 1) ? 1u : 0u;
     }
@@ -3883,6 +3950,7 @@ __global__ void __launch_bounds__(SMALL_NT) k_small_search(SmallArgs a) {
         if (tid == 0) { a.out_counts[q] = kout; a.overflow[q] = (ivf && a.flag_empty && n_rows == 0) ? 1u : 0u; }
     }
     if (tid == 0) __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (a.dbg && tid == 0) a.dbg[(size_t)blockIdx.x * 4 + 3] = wall_clock64();
 }
 
 struct FinalArgs {
@@ -3914,6 +3982,7 @@ struct FinalArgs {
     // written out is (ham_dim - dot) / 2 — exact (integers below 2^24).  0 = off
     uint32_t ham_dim;
     int neg_metric1;   // as SelectArgs::neg_metric1: rescoring with metric neg_metric1 - 1, negated; the distances written out are negated back
+    uint32_t lds_bytes;   // as SelectArgs::lds_bytes
 };
 
 // k_rescore_pool: the exact rescoring of k_final spread over gridDim.y blocks per query (IVF on tightly clustered
@@ -3948,6 +4017,8 @@ __device__ __forceinline__ void final_body(const FinalArgs& a, uint64_t* keys, c
     for (uint32_t i = tid; i < np2; i += NT)
         keys[i] = i < n ? (same_launch ? __hip_atomic_load(&src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : src[i]) : KEY_SENTINEL;
     __syncthreads();
+    // (the survivors of a batch — a few dozen rows — are scored straight from global memory: staged through LDS in chunks they cost one
+    // global round trip per chunk, measured 14 us against 12 us for 53 rows of 768 floats)
     if (!exact)
         rescore_keys<NT>(keys, n, a.neg_metric1 ? a.neg_metric1 - 1 : a.metric, a.ip_form, a.Qf + (size_t)q * a.D, a.V, a.ld, a.D, asc, tid, a.neg_metric1 != 0);
     if (a.orig_ids) {  // canonical order is (distance, ORIGINAL row): swap the row word before the final sort

@@ -1644,6 +1644,14 @@ static int launch_scan_binary_rows(const BinArgs& a, int metric, uint32_t grid, 
     }
 }
 
+// dynamic LDS of the select / final kernels: the cap key slots + scratch for the LDS-staged exact rescoring (rescore_keys): 48 KB hold
+// the query and 15 rows of 768 floats per chunk; one workgroup per query either way
+constexpr size_t SEL_LDS_MAX = 150 * 1024;
+static inline uint32_t sel_lds_bytes(uint32_t cap) {
+    static const size_t extra = []() { const char* e = getenv("LYNSE_HIP_SEL_SCRATCH_KB"); return (size_t)(e ? atoi(e) : 48) * 1024; }();   // (0: the direct loads, A/B)
+    return (uint32_t)std::min<size_t>((size_t)cap * 8 + extra, SEL_LDS_MAX);
+}
+
 static int get_event(lynse_hip_flat* h, size_t idx, hipEvent_t* out) {
     while (cur(h).ev_pool.size() <= idx) {
         hipEvent_t e;
@@ -1710,9 +1718,9 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
 
     static bool sel_attr = false;
     if (!sel_attr) {
-        LY_TRY(set_max_lds(k_select<SEL_NT>, 16384 * 8));
-        LY_TRY(set_max_lds(k_final<SEL_NT>, 16384 * 8));
-        LY_TRY(set_max_lds(k_select_final<SEL_NT>, 16384 * 8));
+        LY_TRY(set_max_lds(k_select<SEL_NT>, SEL_LDS_MAX));
+        LY_TRY(set_max_lds(k_final<SEL_NT>, SEL_LDS_MAX));
+        LY_TRY(set_max_lds(k_select_final<SEL_NT>, SEL_LDS_MAX));
         sel_attr = true;
     }
 
@@ -2029,7 +2037,8 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
             sa.stamps = reinterpret_cast<unsigned long long*>(w.gsync + 64) + (size_t)si * 256 * 8;
         if (fs_stage && getenv("LYNSE_HIP_DEBUG_FS")) return LYNSE_OK;   // debugging: stop behind the fused stage (lynse_hip_debug_workspace)
         if (fused_tail && si + 1 == plan.size()) { sa_last = sa; continue; }  // the last select runs inside k_select_final
-        hipLaunchKernelGGL(k_select<SEL_NT>, dim3(nq), dim3(SEL_NT), (size_t)w.cap * 8, st, sa);
+        sa.lds_bytes = sel_lds_bytes(w.cap);
+        hipLaunchKernelGGL(k_select<SEL_NT>, dim3(nq), dim3(SEL_NT), sa.lds_bytes, st, sa);
         LY_HIP(hipGetLastError());
     }
     if (tl_prof && !binary) {
@@ -2052,7 +2061,8 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
     if (hdr_direct) { fa.h_hdr = w.h_hdr; fa.hdr_q = w.qcap; }
     if (fused_tail) {
         TailArgs ta{sa_last, fa};
-        hipLaunchKernelGGL(k_select_final<SEL_NT>, dim3(nq), dim3(SEL_NT), (size_t)w.cap * 8, st, ta);
+        ta.s.lds_bytes = ta.f.lds_bytes = sel_lds_bytes(w.cap);
+        hipLaunchKernelGGL(k_select_final<SEL_NT>, dim3(nq), dim3(SEL_NT), ta.s.lds_bytes, st, ta);
         LY_HIP(hipGetLastError());
         (void)asc;
         return LYNSE_OK;
@@ -2062,7 +2072,8 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
         LY_HIP(hipGetLastError());
         fa.exact = 1;
     }
-    hipLaunchKernelGGL(k_final<SEL_NT>, dim3(nq), dim3(SEL_NT), (size_t)w.cap * 8, st, fa);
+    fa.lds_bytes = sel_lds_bytes(w.cap);
+    hipLaunchKernelGGL(k_final<SEL_NT>, dim3(nq), dim3(SEL_NT), fa.lds_bytes, st, fa);
     LY_HIP(hipGetLastError());
     (void)asc;
     return LYNSE_OK;
@@ -2102,7 +2113,8 @@ static int run_small(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
     a.out_rows = r_dst; a.out_dists = d_dst; a.out_counts = c_dst; a.overflow = o_dst;
     // two workgroups per CU (16 waves: the scan is a chain of dependent load batches per wave), one merge list per workgroup:
     // at most SMALL_NT lists and 128 KB of them in LDS
-    const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint64_t>((uint64_t)std::min(2 * h->num_cu, SMALL_NT), 16384u / std::max<uint32_t>(k, 1)), (n_scan + 127) / 128));
+    uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint64_t>((uint64_t)std::min(2 * h->num_cu, SMALL_NT), 16384u / std::max<uint32_t>(k, 1)), (n_scan + 127) / 128));
+    if (const char* ge = getenv("LYNSE_HIP_SMALL_GRID")) grid = std::max(1u, std::min<uint32_t>(grid, (uint32_t)atoi(ge)));   // development
     const size_t lds = (size_t)((h->dim + 3) / 4 * 4) * 4 + std::max<size_t>((size_t)SMALL_NT * 8, (size_t)grid * k * 8) + (size_t)(SMALL_NT / 64) * k * 8 + 64;  // wave lists, then the merge lists + the per-wave tournament results
     static bool small_attr = false;
     if (!small_attr) { LY_TRY(set_max_lds(k_small_search, 160 * 1024 - 1024)); small_attr = true; }
@@ -2113,8 +2125,29 @@ static int run_small(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
         LY_TRY(get_event(h, (*ev_used)++, &e1));
         LY_HIP(hipEventRecord(e0, st));
     }
+    static const bool small_dbg = []() { const char* e = getenv("LYNSE_HIP_SMALL_DBG"); return e && atoi(e) != 0; }();
+    static unsigned long long* d_dbg = nullptr;
+    if (small_dbg) {   // development: where the time of the fused search goes (stderr; synchronises)
+        if (!d_dbg) LY_HIP(hipMalloc(&d_dbg, (size_t)SMALL_NT * 4 * 8));
+        LY_HIP(hipMemsetAsync(d_dbg, 0, (size_t)SMALL_NT * 4 * 8, st));
+        a.dbg = d_dbg;
+    }
     hipLaunchKernelGGL(k_small_search, dim3(grid), dim3(SMALL_NT), lds, st, a);
     LY_HIP(hipGetLastError());
+    if (small_dbg) {
+        std::vector<unsigned long long> hd((size_t)grid * 4);
+        LY_HIP(hipMemcpyAsync(hd.data(), d_dbg, hd.size() * 8, hipMemcpyDeviceToHost, st));
+        LY_HIP(hipStreamSynchronize(st));
+        unsigned long long t0 = ~0ull, s_last = 0, scan_end = 0, tick = 0, fin = 0, scan_end_min = ~0ull, scan_sum = 0, merge_sum = 0;
+        for (uint32_t b = 0; b < grid; ++b) {
+            t0 = std::min(t0, hd[b * 4]); s_last = std::max(s_last, hd[b * 4]);
+            scan_end = std::max(scan_end, hd[b * 4 + 1]); scan_end_min = std::min(scan_end_min, hd[b * 4 + 1]);
+            tick = std::max(tick, hd[b * 4 + 2]); fin = std::max(fin, hd[b * 4 + 3]);
+            scan_sum += hd[b * 4 + 1] - hd[b * 4]; merge_sum += hd[b * 4 + 2] - hd[b * 4 + 1];
+        }
+        fprintf(stderr, "k_small_search grid %u lds %zu (10 ns ticks from the first start): last start %llu, first scan end %llu, last scan end %llu, last ticket %llu, end %llu; "
+                        "mean scan %llu, mean wave merge %llu\n", grid, lds, s_last - t0, scan_end_min - t0, scan_end - t0, tick - t0, fin - t0, scan_sum / grid, merge_sum / grid);
+    }
     if (timed) {
         LY_HIP(hipEventRecord(e1, st));
         scan_events->push_back({*ev_used - 2, (uint64_t)h->n * nq});
@@ -2332,8 +2365,8 @@ static int run_chunk_sq8(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t ou
     const uint32_t nslab = (h->dim + 127) / 128, qpad = SCAN_BQ_LARGE;
     static bool attr = false;
     if (!attr) {
-        LY_TRY(set_max_lds(k_select<SEL_NT>, 16384 * 8));
-        LY_TRY(set_max_lds(k_final<SEL_NT>, 16384 * 8));
+        LY_TRY(set_max_lds(k_select<SEL_NT>, SEL_LDS_MAX));
+        LY_TRY(set_max_lds(k_final<SEL_NT>, SEL_LDS_MAX));
         attr = true;
     }
     LY_HIP(hipMemsetAsync(w.Q16, 0, (size_t)nslab * qpad * 128, st));
@@ -2370,7 +2403,8 @@ static int run_chunk_sq8(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t ou
         sa.exact = 1; sa.emit_all_n = si == 0 ? (int)(s.r1 - s.r0) : -1;
         sa.Qf = w.Qf; sa.V = h->rows; sa.ld = h->ld; sa.D = h->dim;
         sa.candB = w.candB; sa.segcnt = w.segcnt; sa.seg = a.seg; sa.nseg = a.seg ? a.nseg : 0;
-        hipLaunchKernelGGL(k_select<SEL_NT>, dim3(nq), dim3(SEL_NT), (size_t)w.cap * 8, st, sa);
+        sa.lds_bytes = sel_lds_bytes(w.cap);
+        hipLaunchKernelGGL(k_select<SEL_NT>, dim3(nq), dim3(SEL_NT), sa.lds_bytes, st, sa);
         LY_HIP(hipGetLastError());
     }
     FinalArgs fa{};
@@ -2387,7 +2421,8 @@ static int run_chunk_sq8(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t ou
         LY_HIP(hipGetLastError());
     }
     fa.exact = 1;
-    hipLaunchKernelGGL(k_final<SEL_NT>, dim3(nq), dim3(SEL_NT), (size_t)w.cap * 8, st, fa);
+    fa.lds_bytes = sel_lds_bytes(w.cap);
+    hipLaunchKernelGGL(k_final<SEL_NT>, dim3(nq), dim3(SEL_NT), fa.lds_bytes, st, fa);
     LY_HIP(hipGetLastError());
     return LYNSE_OK;
 }

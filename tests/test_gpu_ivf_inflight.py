@@ -173,12 +173,15 @@ def test_ivf_shapes_the_grouping_does_not_take_and_the_rules(L, oracle):
     assert _same(_host(o), _host(ob))
     _assert_oracle(oracle, q[7], data, cen, off, rows, nlist, k, IP, _host(o), 7)
     # more tickets than contexts 1..3: an error, not a deadlock; insert / delete are refused while tickets are outstanding
-    outs = [_tensors(torch, nq, k, dev) for _ in range(4)]
+    import os
+
+    n_ctx = max(1, min(8, int(os.environ.get("LYNSE_HIP_CONTEXTS", "4"))))   # (context 0 stays with the blocking searches)
+    outs = [_tensors(torch, nq, k, dev) for _ in range(9)]
     tickets = []
     with pytest.raises(Exception, match="in flight"):
-        for i in range(4):
+        for i in range(9):
             tickets.append(idx.search_submit(dq, k, 3, *outs[i]))
-    assert len(tickets) == 3
+    assert len(tickets) == n_ctx - 1
     with pytest.raises(Exception, match="in flight"):
         idx.insert(data[:10])
     with pytest.raises(Exception, match="in flight"):
@@ -187,11 +190,11 @@ def test_ivf_shapes_the_grouping_does_not_take_and_the_rules(L, oracle):
         t.wait()
     idx.insert(data[:10])                               # free again
     assert len(idx) == n + 10
-    t = idx.search_submit(dq, k, 3, *outs[3])           # a new store behind the handle: derived data is rebuilt by the first submit
+    t = idx.search_submit(dq, k, 3, *outs[8])           # a new store behind the handle: derived data is rebuilt by the first submit
     t.wait()
     ob = _tensors(torch, nq, k, dev)
     idx.search_device(dq, k, 3, *ob)
-    assert _same(_host(outs[3]), _host(ob))
+    assert _same(_host(outs[8]), _host(ob))
     # more than 256 queries, k = 0
     with pytest.raises(Exception):
         idx.search_submit(torch.as_tensor(np.zeros((300, dim), f32), device=dev), k, 3, *_tensors(torch, 300, k, dev))
