@@ -380,6 +380,16 @@ int lynse_hip_ivf_kmeans_sharded(const float *rows_local, uint64_t n_local, int 
                                  int device, lynse_hip_comm *c, lynse_hip_reduce_fn reduce, void *reduce_ctx,
                                  float *out_centroids, uint32_t *out_assignments, uint32_t *out_k);
 
+/* IVFIndex::build (src/index/ivf.rs:132-179) for ONE RANK of a row-sharded collection, in one call: lynse_hip_ivf_kmeans_sharded over the
+ * rank's device-resident rows (global row g = local row g / world on rank g % world), then the rank's slab store under the shared
+ * centroids with global row ids (lynse_hip_ivf_set_row_map(h, world, rank)) and the shard routing rule (no all-lists-empty fallback
+ * when world > 1) — the index lynse_hip_ivf_search_sharded_f32_device and the IVF tickets search.  A collective; every rank needs at
+ * least one row.  ivfflat_routing != 0: IvfFlatMmap semantics (L2 cells, src/storage/ivf_flat_mmap.rs:56-159). */
+int lynse_hip_ivf_build_sharded_device(const float *d_rows_local, uint64_t n_local, uint64_t n_global, uint32_t rank,
+                                       uint32_t world, uint32_t dim, uint32_t nlist, uint32_t max_iter, int metric,
+                                       int ivfflat_routing, int device, lynse_hip_comm *c, lynse_hip_reduce_fn reduce,
+                                       void *reduce_ctx, lynse_hip_ivf **out);
+
 /* ---- searches in flight: submit / wait ----
  *
  * The reference serves concurrent readers (Arc<RwLock<Collection>> with inner.read() on the search path,

@@ -132,6 +132,8 @@ SIGNATURES = {
     "lynse_hip_ivf_ticket_stats": (C.c_int, [_vp, _vp]),
     "lynse_hip_ivf_kmeans_sharded": (C.c_int, [_vp, C.c_uint64, C.c_int, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_int,
                                               _vp, _vp, _vp, _vp, _vp, C.POINTER(C.c_uint32)]),
+    "lynse_hip_ivf_build_sharded_device": (C.c_int, [_vp, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_int,
+                                                    _vp, _vp, _vp, C.POINTER(_vp)]),
     "lynse_hip_flat_coarse_scores": (C.c_int, [_vp, _vp, C.c_uint64, C.c_int, C.c_int, _vp, _vp, C.POINTER(C.c_int)]),
 }
 

@@ -414,6 +414,26 @@ class ShardedIvf:
                                                int(max_iter), m, device, comm, C_.cast(cb, C_.c_void_p), None, _ptr(cen), _ptr(asg), C_.byref(got)))
         return cen[:got.value].copy(), asg[:n_local].copy()
 
+    def build_device(self, d_local_rows, n_global: int, nlist: int, max_iter: int = 20, metric: str = "ip", ivfflat_routing: bool = False,
+                     reduce=None) -> None:
+        """`train` + `load_local_device` behind ONE C-ABI call (`lynse_hip_ivf_build_sharded_device`): this rank's rows are a torch tensor
+        on its device; afterwards `search_device / search_submit / search` answer over the whole collection.  A collective."""
+        import ctypes as C_
+
+        from .core import IvfFlatIndex, _sync_producer, metric_from_str
+
+        _sync_producer(d_local_rows)
+        device = d_local_rows.device.index or 0
+        host_reduce = self._host_reduce(reduce, device)
+        cb = _lib.REDUCE_FN(host_reduce)
+        comm = self.comm.handle if (self.comm is not None and reduce is None) else None
+        h = C_.c_void_p()
+        check(lib.lynse_hip_ivf_build_sharded_device(C_.c_void_p(d_local_rows.data_ptr()), int(d_local_rows.shape[0]), int(n_global), self.rank, self.world,
+                                                     self.dim, int(nlist), int(max_iter), metric_from_str(metric), 1 if ivfflat_routing else 0, device,
+                                                     comm, C_.cast(cb, C_.c_void_p), None, C_.byref(h)))
+        self.index = IvfFlatIndex(h, self.dim)
+        self.metric = metric
+
     def _host_reduce(self, reduce, device: int):
         """The `lynse_hip_reduce_fn` of this shard's launcher: sums a host buffer over all ranks in place (dtype 0: f32, 1: u32)."""
         import ctypes as C_

@@ -18,6 +18,11 @@ for M in l2 cosine; do
   python scripts/summarize_pmc.py gpurun_out/r04_$M gpurun_out/r04/r04_${M}_pmc k_scan >> gpurun_out/r04/sum.log 2>&1
   f=$(find gpurun_out/r04_$M/stats -name "*kernel_stats.csv" | head -1); cp "$f" gpurun_out/r04/r04_${M}_kernel_stats.csv
 done
+# --config c4 (IVF tickets, one GPU = one eighth of the 50M collection): the line and a kernel trace of it
+(time timeout 600 python bench.py --config c4 --steps 30 --warmup 3) > gpurun_out/r04/bench_c4.json 2> gpurun_out/r04/bench_c4.err
+export TMPDIR=/tmp; R=$(pwd)
+(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/r04_c4bench -o c4 --output-format csv -- bash -c "cd $R && python bench.py --config c4 --steps 30 --warmup 3" > $R/gpurun_out/r04/prof_c4bench.log 2>&1)
+f=$(find gpurun_out/r04_c4bench -name "*kernel_stats.csv" | head -1); cp "$f" gpurun_out/r04/r04_c4_tickets_kernel_stats.csv
 S="timeout 300 python bench.py --no-cpu-baseline --no-configs --no-verify --steps 60 --warmup 5 --rows 1250000"
 LYNSE_BENCH_FORCE_COMM=1 $S --in-flight 3 > gpurun_out/r04/shard_1p25m_in_flight_1rank_comm.json 2>/dev/null
 $S --in-flight 3 > gpurun_out/r04/shard_1p25m_in_flight.json 2>/dev/null

@@ -112,6 +112,54 @@ def test_one_rank_is_the_single_index_training(L, oracle):
     assert np.array_equal(c2.view(np.uint32), cen.view(np.uint32)) and np.array_equal(a2, asg)
 
 
+def test_build_sharded_device_in_one_call(L, oracle):
+    """`lynse_hip_ivf_build_sharded_device`: one rank = the single-index device build; two ranks (threads + callback reduction) = the
+    restatement's centroids, and their merged answers are IVFIndex::search over the union under those centroids."""
+    import torch
+
+    from lynsedb_amd.sharded import ShardedIvf
+
+    rng = np.random.default_rng(5)
+    n, dim, nlist, iters, nprobe, k = 16_000, 32, 48, 6, 5, 10
+    data = clustered(rng, n, dim)
+    queries = (data[rng.integers(0, n, 20)] + 0.05 * rng.standard_normal((20, dim))).astype(f32)
+    one = ShardedIvf(dim, rank=0, world=1, device=0)
+    one.build_device(torch.from_numpy(data).to("cuda:0"), n, nlist, iters, "l2")
+    c1, a1, _, _ = one.index.export()
+    want_c, want_a = oracle.kmeans_train(data, nlist, iters, O.L2)
+    assert np.array_equal(c1.view(np.uint32), want_c.view(np.uint32)) and np.array_equal(a1, want_a)
+    hub = TwoRankSum()
+    shards, errs = [None, None], []
+
+    def run(rank):
+        try:
+            sh = ShardedIvf(dim, rank=rank, world=2, device=0)
+            sh.build_device(torch.from_numpy(np.ascontiguousarray(data[rank::2])).to("cuda:0"), n, nlist, iters, "l2", reduce=hub.reducer(rank))
+            shards[rank] = sh
+        except Exception as e:  # noqa: BLE001
+            errs.append((rank, repr(e)))
+            hub.bar.abort()
+
+    ts = [threading.Thread(target=run, args=(r,)) for r in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(300)
+    assert not errs, errs
+    want_c, want_a = oracle.kmeans_train_sharded(data, nlist, iters, O.L2, 2)
+    for rank in range(2):
+        c, a, _, _ = shards[rank].index.export()
+        assert np.array_equal(c.view(np.uint32), want_c.view(np.uint32)) and np.array_equal(a, want_a[rank::2]), rank
+    offsets, list_rows = oracle.lists_from_assignments(want_a, want_c.shape[0])
+    parts = [shards[r].search_local(queries, k, nprobe) for r in range(2)]
+    for qi in range(queries.shape[0]):
+        e_ids, e_d, _ = oracle.ivf_search(queries[qi], data, want_c, offsets, list_rows, nprobe, k, O.L2)
+        ids = np.concatenate([parts[r][0][qi, :int(parts[r][2][qi])] for r in range(2)])
+        ds = np.concatenate([parts[r][1][qi, :int(parts[r][2][qi])] for r in range(2)])
+        m_ids, m_d = oracle.merge_results(ids.astype(np.uint64), ds, k, O.L2)
+        assert np.array_equal(np.asarray(m_ids, np.uint64), e_ids.astype(np.uint64)) and np.array_equal(np.asarray(m_d, f32).view(np.uint32), e_d.view(np.uint32)), qi
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
