@@ -61,9 +61,10 @@ def parse_args():
     p.add_argument("--profile-every", type=int, default=4, help="HIP-event timing of the scan launches on every n-th step of the timed region")
     p.add_argument("--settle-ms", type=float, default=60.0, help="untimed steps before the warm-up until the GPU's clocks have settled (0 = none)")
     p.add_argument("--no-configs", action="store_true", help="skip the extra keys: the other BASELINE configurations and the second data distribution")
-    p.add_argument("--config", default="c2", choices=["c2", "c4"],
+    p.add_argument("--config", default="c2", choices=["c2", "c4", "c5"],
                    help="c2 (default): FLAT-IP 10M x 768, the headline; c4: IVF-Flat IP nlist 4096 / nprobe 32, 6.25M x 768 rows PER GPU "
-                        "(50M x 768 at --gpus 8, BASELINE.json configs[3]), centroids trained over the sharded collection")
+                        "(50M x 768 at --gpus 8, BASELINE.json configs[3]), centroids trained over the sharded collection; c5: packed-binary Hamming, "
+                        "12.5M x 1024-bit fingerprints PER GPU (100M at --gpus 8, configs[4]), k = 50")
     p.add_argument("--rows-per-gpu", type=int, default=6_250_000, help="--config c4: rows of every rank's shard")
     p.add_argument("--nlist", type=int, default=4096)
     p.add_argument("--nprobe", type=int, default=32)
@@ -147,6 +148,8 @@ def main():
 
     if args.config == "c4":
         return run_c4(args, rank, local_rank, world, dev, dist, result_out)
+    if args.config == "c5":
+        return run_c5(args, rank, local_rank, world, dev, dist, result_out)
 
     N, D, B, K = args.rows, args.dim, args.batch, args.k
     metric = L.metric_from_str(args.metric)
@@ -606,6 +609,164 @@ def run_c4(args, rank, local_rank, world, dev, dist, result_out):
         dist.destroy_process_group()
 
 
+def run_c5(args, rank, local_rank, world, dev, dist, result_out):
+    """BASELINE.json configs[4]: packed-binary Hamming over 1024-bit fingerprints, k = 50, the collection row-sharded across the ranks
+    (12.5M rows per GPU: 100M at 8 GPUs; "scaling": "weak").  A step = one batch of 256 packed queries: the +-1 FP4 MFMA scan of the
+    shard (exact: margin 0), selects, ncclAllGather of the (distance, row) blocks, device merge — batches in flight through
+    lynse_hip_flat_search_submit_packed_u64_device.  Integer path: ids and distances are bit-exact (checked against the oracle's
+    packed search on a sample of this rank's rows and against the blocking sharded search)."""
+    import lynsedb_amd as L
+    import oracle as O
+    from lynsedb_amd.sharded import ShardedFlat
+
+    bits, B = 1024, args.batch
+    K = 50 if args.k == 10 else args.k
+    W = bits // 64
+    n_local = 12_500_000 if args.rows == 10_000_000 else max(1, args.rows // world)
+    N = n_local * world
+    metric = L.metric_from_str("hamming")
+    sh = ShardedFlat(bits, rank=rank, world=world, device=local_rank, group=dist)
+    native = False
+    if world > 1 and (dist is None or dist.get_backend() == "nccl"):
+        native = sh.enable_native_comm()
+    sh.index.reserve(n_local)
+    g = torch.Generator(device=dev)
+    g.manual_seed(4242 + rank)
+    t0 = time.time()
+    first_words = None
+    for b0 in range(0, n_local, 2_500_000):
+        nb = min(2_500_000, n_local - b0)
+        w = torch.randint(-2**63, 2**63 - 1, (nb, W), generator=g, device=dev, dtype=torch.int64)
+        if first_words is None:
+            first_words = w[:min(nb, 200_000)].clone()      # the sample the oracle checks, and the source of the queries
+        sh.index.write_packed_device(w)
+        del w
+    sh.index.finalize()
+    torch.cuda.synchronize()
+    build_s = time.time() - t0
+    t0 = time.time()
+    sh.index.prepare(metric, B)                             # the +-1 FP4 copy of the batched scan
+    torch.cuda.synchronize()
+    prepare_s = time.time() - t0
+    # queries: rows of rank 0's shard with 16 bits flipped (every rank gets the same batch)
+    queries = first_words[torch.arange(B, device=dev) * 701 % first_words.shape[0]].clone()
+    queries[:, 0] ^= 0xFFFF
+    if dist is not None:
+        dist.broadcast(queries, src=0)
+    in_flight = max(1, min(args.in_flight, 4)) if args.in_flight > 0 else (1 if world == 1 else 3)
+    if world > 1 and not native:
+        in_flight = 1
+    outs = [sh.alloc_outputs(B, K) for _ in range(in_flight)]
+
+    def run_steps(n):
+        if in_flight == 1:
+            for _ in range(n):
+                sh.search_packed_device(queries, K, metric, outs[0])
+            return
+        pending = []
+        for i in range(n):
+            pending.append(sh.search_submit(queries, K, metric, outs[i % in_flight]))
+            if len(pending) >= in_flight:
+                pending.pop(0).wait()
+        for t in pending:
+            t.wait()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    import gc
+    gc.collect()
+    gc.disable()
+    run_steps(max(3, in_flight) * 2)
+    torch.cuda.synchronize()
+    run_steps(20)
+    run_steps(args.warmup)
+    sh.index.profile_enable(args.profile_every)
+    sh.index.profile_get(reset=True)
+    barrier()
+    t_start = time.perf_counter()
+    run_steps(args.steps)
+    barrier()
+    elapsed = time.perf_counter() - t_start
+    prof = sh.index.profile_get(reset=True)
+    sh.index.profile_enable(False)
+    barrier()
+    t_lat = time.perf_counter()
+    for _ in range(5):
+        sh.search_packed_device(queries, K, metric, outs[0])
+    barrier()
+    lat_ms = (time.perf_counter() - t_lat) / 5 * 1000.0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    gc.enable()
+    # ---- verification (outside the timed region): tickets == blocking sharded search; the scan kernels against the oracle on a
+    # 200k-row index of this rank's first rows (same kernels, same batch: bit-exact ids and distances)
+    o_t, o_b = sh.alloc_outputs(B, K), sh.alloc_outputs(B, K)
+    sh.search_submit(queries, K, metric, o_t).wait()
+    sh.search_packed_device(queries, K, metric, o_b)
+    torch.cuda.synchronize()
+    same = bool(torch.equal(o_t.rows, o_b.rows) and torch.equal(o_t.dists, o_b.dists) and torch.equal(o_t.counts, o_b.counts))
+    small = L.FlatIndex(None, bits, local_rank)
+    small.write_packed_device(first_words)
+    small.finalize()
+    sr = torch.zeros((B, K), dtype=torch.int64, device=dev)
+    sd = torch.zeros((B, K), dtype=torch.float32, device=dev)
+    sc = torch.zeros(B, dtype=torch.int32, device=dev)
+    small.search_packed_device(queries, K, metric, sr, sd, sc)
+    torch.cuda.synchronize()
+    host_rows = first_words.cpu().numpy().view(np.uint64)
+    host_q = queries.cpu().numpy().view(np.uint64)
+    orc = O.get()
+    exact = True
+    for qi in (0, B // 2, B - 1):
+        e_ids, e_d = orc.canonical_topk_packed(host_q[qi], host_rows, K, O.HAMMING)
+        exact = exact and np.array_equal(sr[qi].cpu().numpy().astype(np.uint32)[:len(e_ids)], e_ids) and np.array_equal(sd[qi].cpu().numpy()[:len(e_ids)], e_d)
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1000.0
+        qps = B * args.steps / elapsed
+        launches = max(int(prof["scan_launches"]), 1)
+        scan_s = prof["scan_us"] * 1e-6
+        timed_steps = max(int(prof["searches"]), 1)
+        mfma = B >= 72                                       # >= 72 queries: the +-1 GEMM on the FP4 MFMA streams one nibble per bit
+        kernel_bytes = float(n_local) * (bits // 2 if mfma else bits // 8) * timed_steps
+        hbm_gbps = kernel_bytes / scan_s / 1e9 if scan_s > 0 else 0.0
+        ops = 2.0 * B * float(prof["scan_rows"]) * bits
+        result = {
+            "metric": "queries/sec, packed-binary Hamming %dx%d-bit, batch=%d, k=%d" % (N, bits, B, K),
+            "value": round(qps, 1), "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64",
+            "data": "synthetic",
+            "config": {"workload": "C5 packed-binary Hamming %dx%d-bit uniform random fingerprints, %d queries = rows with 16 bits flipped, k=%d" % (N, bits, B, K),
+                       "rows_per_gpu": n_local, "sharding": "row %% %d" % world,
+                       "exchange": ("rccl all_gather of %d B/rank inside the library" % (B * K * 12 + B * 4 + 16)) if native else ("torch.distributed" if world > 1 else "none"),
+                       "batches_in_flight": in_flight, "build_s": round(build_s, 1), "derived_build_s": round(prepare_s, 2),
+                       "hbm_bytes_per_gpu": int(sh.index.hbm_bytes())},
+            "roofline": {"bound": "hbm", "kernel": "k_scan_h16<2,4,4,2,IP,fp4> (v_mfma_scale_f32_32x32x64_f8f6f4) over the +-1 FP4 copy" if mfma else "k_scan_binary_rows",
+                         "achieved": round(hbm_gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(hbm_gbps / HBM_PEAK_GBPS, 4), "traffic": None,
+                         "mfma_TOPs": round(ops / scan_s / 1e12, 1) if (mfma and scan_s > 0) else None,
+                         "launches": launches, "avg_launch_us": round(prof["scan_us"] / launches, 2), "timed_steps": timed_steps,
+                         "note": "rank-0 shard; bytes = rows x %d B (%s); HIP events around the scan launches of every %d-th step" % (
+                             bits // 2 if mfma else bits // 8, "one FP4 nibble per bit" if mfma else "packed words", max(args.profile_every, 1))},
+            "blocking_ms_per_batch": round(lat_ms, 4),
+            "verify": {"tickets_equal_blocking_search": same, "oracle_bit_exact_on_200k_row_sample": bool(exact)},
+        }
+        result_out.write(json.dumps(result) + "\n")
+        result_out.flush()
+    if dist is not None:
+        dist.barrier()
+        if sh.comm is not None:
+            try:
+                sh.comm.close()
+            except Exception:  # noqa: BLE001
+                pass
+            sh.comm = None
+        dist.destroy_process_group()
+
+
 def oracle_distance_bits(index, queries, out, B, K):
     """Every (row, distance) pair the timed batch returned against the ORACLE's bit pattern: the rows come back from the
     index (HBM copy), the oracle scores them with the reference's batch-8 IP kernel (simd.rs:1452-1525, the form every row of
@@ -813,7 +974,8 @@ def other_configs(dev):
             ok = ok and np.array_equal(r[i].astype(np.uint32), e_ids) and np.array_equal(dd[i].view(np.uint32), e_d.view(np.uint32))
         return {"workload": "C3 FLAT-L2 SIFT-like 1000000x128, 256 queries, k=100", "ms": round(ms, 4), "queries_per_s": round(256 / ms * 1e3, 1),
                 "scan_us": us, "GBps": gbps, "frac_of_hbm_peak": round(gbps / HBM_PEAK_GBPS, 4), "bytes": "f16 shadow rows (incl. the re-scanned sample rows)",
-                "fallback_queries": int(p["fallback_queries"]), "oracle_parity": bool(ok)}
+                "fallback_queries": int(p["fallback_queries"]), "stages": (int(p.get("last_plan", 0)) >> 8) & 0xff,
+                "rescored_per_query": round(p["pool_entries"] / max(int(p["searches"]) * 256, 1), 1), "oracle_parity": bool(ok)}
 
     def c5():
         n, bits = 12_500_000, 1024

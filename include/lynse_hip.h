@@ -9,7 +9,8 @@
  *
  * Conventions (mirroring the reference boundary):
  *  - inputs are borrowed for the duration of the call; outputs are CALLER-allocated, fixed size
- *    (nq*k), short results are padded and the true length is written to out_counts[q];
+ *    (nq*k), short results are padded (row ~0, distance +inf / -inf: the worst of the metric) and the true length is
+ *    written to out_counts[q];
  *  - empty store or k == 0 -> counts 0, not an error (flat_mmap.rs:832-835); k > N clamps (:836);
  *  - rows returned are ROW INDICES (u32 per segment in the reference, u64 here after the row map),
  *    best-first; ties are ordered by row ascending — the order VectorStore::merge_results imposes

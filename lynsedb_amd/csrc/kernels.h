@@ -3946,6 +3946,11 @@ __global__ void __launch_bounds__(SMALL_NT) k_small_search(SmallArgs a) {
                     a.out_dists[(size_t)q * a.out_k + round] = key_score(best, asc);
                 }
             }
+            // short results are padded like k_final's (row ~0, the worst distance of the metric)
+            for (uint32_t i = kout + lane; i < a.out_k; i += 64) {
+                a.out_rows[(size_t)q * a.out_k + i] = ~0ull;
+                a.out_dists[(size_t)q * a.out_k + i] = asc ? LY_INF : -LY_INF;
+            }
         }
         if (tid == 0) { a.out_counts[q] = kout; a.overflow[q] = (ivf && a.flag_empty && n_rows == 0) ? 1u : 0u; }
     }

@@ -225,6 +225,30 @@ class ShardedFlat:
                                               C.c_void_p(out.rows.data_ptr()), C.c_void_p(out.dists.data_ptr()),
                                               C.c_void_p(out.counts.data_ptr()), C.c_void_p(stream)))
 
+    def search_packed_device(self, d_qwords, k: int, metric: int, out: ShardOutputs) -> None:
+        """`search_device` for the packed-binary metrics: queries are packed u64 words (an int64 torch tensor [nq, words])."""
+        import torch
+
+        nq = d_qwords.shape[0]
+        torch.cuda.current_stream().synchronize()
+        if self.world == 1:
+            self.index.search_packed_device(d_qwords, k, metric, out.rows, out.dists, out.counts)
+            return
+        if self.comm is not None:
+            check(lib.lynse_hip_flat_search_sharded_packed_u64_device(
+                self.index.handle, self.comm.handle, C.c_void_p(d_qwords.data_ptr()), nq, k, metric,
+                C.c_void_p(out.rows.data_ptr()), C.c_void_p(out.dists.data_ptr()), C.c_void_p(out.counts.data_ptr())))
+            return
+        pr, pd, pc = out.local_ptrs()
+        check(lib.lynse_hip_flat_search_packed_u64_device(self.index.handle, C.c_void_p(d_qwords.data_ptr()), nq, k, metric,
+                                                          C.c_void_p(pr), C.c_void_p(pd), C.c_void_p(pc), None))
+        self.dist.all_gather_into_tensor(out.gathered, out.local)
+        stream = torch.cuda.current_stream().cuda_stream
+        check(lib.lynse_hip_merge_topk_device(C.c_void_p(out.gathered.data_ptr()), out.block_bytes, out.rows_off,
+                                              out.dists_off, out.counts_off, self.world, nq, k, metric,
+                                              C.c_void_p(out.rows.data_ptr()), C.c_void_p(out.dists.data_ptr()),
+                                              C.c_void_p(out.counts.data_ptr()), C.c_void_p(stream)))
+
     def search_submit(self, d_queries, k: int, metric: int, out: ShardOutputs):
         """One batch IN FLIGHT (lynse_hip_flat_search_submit_*): scan -> ncclAllGather -> merge enqueued on a search context of
         the shard; returns a ticket whose wait() makes out.rows / dists / counts final.  A collective with world > 1 (every
@@ -240,7 +264,10 @@ class ShardedFlat:
         if self.world == 1 or self.comm is not None:  # (a 1-rank communicator still runs the exchange half: status word, merge)
             return self.index.search_submit(d_queries, k, metric, out.rows, out.dists, out.counts,
                                             comm=self.comm.handle if self.comm is not None else None)
-        self.search_device(d_queries, k, metric, out)
+        if d_queries.is_floating_point():
+            self.search_device(d_queries, k, metric, out)
+        else:
+            self.search_packed_device(d_queries, k, metric, out)
         return _Done()
 
     def search(self, queries: np.ndarray, k: int, metric: int):

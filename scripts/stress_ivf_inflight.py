@@ -43,6 +43,8 @@ def host(o):
 
 while time.time() - t0 < budget and (max_cases is None or cases < max_cases):
     n = int(rng.choice([700, 9000, 40000, 90000, 150000]))
+    if os.environ.get("STRESS_N"):
+        n = int(os.environ["STRESS_N"])
     metric = int(rng.choice([O.IP, O.IP, O.L2, O.COS]))
     dim = int(rng.choice([8, 48, 64, 128, 256]))
     if n * dim > 24_000_000:
@@ -79,35 +81,58 @@ while time.time() - t0 < budget and (max_cases is None or cases < max_cases):
         batches.append(b)
     dq = [torch.as_tensor(b, device=dev) for b in batches]
     blocking = []
-    for q in dq:
-        o = outs(nq, k)
-        idx.search_device(q, k, nprobe, *o)
-        blocking.append(host(o))
+    case = (n, dim, nlist, nprobe, nq, k, depth, nb, NAME[metric], kind, empties)
+    try:
+        for q in dq:
+            o = outs(nq, k)
+            idx.search_device(q, k, nprobe, *o)
+            blocking.append(host(o))
+    except Exception as e:  # noqa: BLE001
+        print("BLOCKING SEARCH FAILED", case, repr(e), flush=True)
+        bad.append(case)
+        cases += 1
+        continue
     res = [outs(nq, k) for _ in batches]
     pending = []
-    for i in range(nb):
-        pending.append(idx.search_submit(dq[i], k, nprobe, *res[i], comm=COMM.handle if COMM is not None else None))
-        if len(pending) >= depth:
-            pending.pop(0).wait()
-    for t in pending:
-        t.wait()
+    try:
+        for i in range(nb):
+            pending.append(idx.search_submit(dq[i], k, nprobe, *res[i], comm=COMM.handle if COMM is not None else None))
+            if len(pending) >= depth:
+                pending.pop(0).wait()
+        for t in pending:
+            t.wait()
+    except Exception as e:  # noqa: BLE001
+        print("TICKET FAILED", case, repr(e), flush=True)
+        bad.append(case)
+        cases += 1
+        for t in pending:
+            try:
+                t.wait()
+            except Exception:  # noqa: BLE001
+                pass
+        continue
     st = idx.ticket_stats()
     for key in totals:
         totals[key] += st[key]
     ok = True
+    why = []
     for i in range(nb):
         g = host(res[i])
         if not (np.array_equal(g[0], blocking[i][0]) and np.array_equal(g[1].view(np.uint32), blocking[i][1].view(np.uint32)) and np.array_equal(g[2], blocking[i][2])):
             ok = False
+            dq_ = [int(x) for x in np.nonzero((g[2] != blocking[i][2]) | np.any(g[0] != blocking[i][0], axis=1))[0][:4]]
+            why.append(("ticket != blocking", i, dq_, [int(g[2][x]) for x in dq_], [int(blocking[i][2][x]) for x in dq_]))
         for qi in {0, nq - 1, int(rng.integers(0, nq))}:
             e_ids, e_d, _ = orc.ivf_search(batches[i][qi], data, cen, off, rows, nprobe, k, metric)
-            c = int(g[2][qi])
-            if c != len(e_ids) or not np.array_equal(g[0][qi, :c], e_ids.astype(np.uint64)) or not np.array_equal(g[1][qi, :c].view(np.uint32), e_d.view(np.uint32)):
-                ok = False
+            for tag, gg in (("ticket", g), ("blocking", blocking[i])):
+                c = int(gg[2][qi])
+                if c != len(e_ids) or not np.array_equal(gg[0][qi, :c], e_ids.astype(np.uint64)) or not np.array_equal(gg[1][qi, :c].view(np.uint32), e_d.view(np.uint32)):
+                    ok = False
+                    why.append((tag + " != oracle", i, qi, c, len(e_ids)))
     cases += 1
     if not ok:
         bad.append((n, dim, nlist, nprobe, nq, k, depth, nb, NAME[metric], kind, empties))
-        print("MISMATCH", bad[-1], flush=True)
+        print("MISMATCH", bad[-1], why[:4], st, flush=True)
     del idx
 print("cases %d mismatches %d tickets %s comm %s seconds %.0f" % (cases, len(bad), totals, COMM is not None, time.time() - t0))
 sys.exit(1 if bad else 0)

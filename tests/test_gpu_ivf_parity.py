@@ -710,3 +710,40 @@ def test_ivf_device_side_grouping_equals_the_host_path(L, oracle, metric, monkey
     for qi in (0, 100, 255):
         e_ids, e_d, _ = oracle.ivf_search(big[qi], data, cen, off, rows, 40, k, metric)
         assert np.array_equal(got["1"][0][qi, :len(e_ids)], e_ids) and np.array_equal(got["1"][1][qi, :len(e_ids)].view(np.uint32), e_d.view(np.uint32))
+
+
+def test_all_lists_fallback_with_many_lists_and_padding_of_short_results(L, oracle):
+    """Found by scripts/stress_ivf_inflight.py (round 4).  (1) A query whose probed lists are all empty scans EVERY list (ivf.rs:258-265):
+    with more than 64 lists the first position window emitted a0 x nlist keys per query — a0 was sized for nprobe lists — and every plan
+    overflowed ('candidate overflow on the exhaustive IVF plan').  (2) Results shorter than k are padded the same way by the fused
+    few-query search and by the staged pipeline (row ~0, the worst distance of the metric)."""
+    rng = np.random.default_rng(4045)
+    n, dim, nlist, k = 40_000, 64, 300, 10
+    data = rng.random((n, dim), dtype=f32)
+    cen, asg, off, rows = oracle_ivf(oracle, data, nlist, L2, iters=2)
+    far = (150.0 + np.arange(2 * dim, dtype=f32)).reshape(2, dim)      # two centroids that own no row
+    cen = np.concatenate([cen, far])
+    off, rows = oracle.lists_from_assignments(asg, cen.shape[0])
+    idx = L.IvfFlatIndex.load(data, cen, asg, "l2")
+    for nq in (1, 33, 256):
+        qs = (data[rng.integers(0, n, nq)] + 0.05 * rng.standard_normal((nq, dim))).astype(f32)
+        qs[nq // 2] = far[1]                                            # nprobe = 1: only an empty list is probed
+        g_rows, g_d, g_c = idx.search_batch_arrays(qs, k, 1)
+        for qi in sorted({0, nq // 2, nq - 1}):
+            e_ids, e_d, _ = oracle.ivf_search(qs[qi], data, cen, off, rows, 1, k, L2)
+            c = int(g_c[qi])
+            assert c == len(e_ids) and np.array_equal(g_rows[qi, :c], e_ids) and np.array_equal(g_d[qi, :c].view(np.uint32), e_d.view(np.uint32)), (nq, qi)
+        assert int(g_c[nq // 2]) == k                                   # every row was a candidate
+    # short results: 300 lists over 700 rows, nprobe 1 -> a handful of rows per query, k = 50
+    small = data[:700]
+    cen2, asg2, off2, rows2 = oracle_ivf(oracle, small, 300, L2, iters=2)
+    idx2 = L.IvfFlatIndex.load(small, cen2, asg2, "l2")
+    q4 = (small[rng.integers(0, 700, 4)] + 0.001).astype(f32)
+    fused = idx2.search_batch_arrays(q4, 50, 1)
+    idx2.set_fused_search(False)
+    staged = idx2.search_batch_arrays(q4, 50, 1)
+    assert np.array_equal(fused[2], staged[2]) and int(fused[2].min()) < 50    # (a query that probes an empty list scans every row: 50 results)
+    assert np.array_equal(fused[0], staged[0]) and np.array_equal(fused[1].view(np.uint32), staged[1].view(np.uint32))
+    for qi in range(4):
+        c = int(fused[2][qi])
+        assert np.all(fused[0][qi, c:] == np.uint64(0xFFFFFFFFFFFFFFFF)) and np.all(np.isposinf(fused[1][qi, c:]))
