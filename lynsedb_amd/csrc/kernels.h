@@ -3292,7 +3292,9 @@ __device__ __forceinline__ void rescore_keys(uint64_t* keys, uint32_t n, int met
         float s0 = 0.0f, s1 = 0.0f;
         if (n) {
             s0 = exact_score<32>(metric, ip_form, qv, V + (size_t)row0 * ld, D, g);
-            s1 = exact_score<32>(metric, ip_form, qv, V + (size_t)row1 * ld, D, g);
+            // (uniform: the second row of the trip exists for SOME lane group — a pool of <= NT / 8 rows, the usual case, used to score
+            // a dummy row here: three more dependent round trips)
+            if ((r + 1) * (uint32_t)(NT / 8) < n) s1 = exact_score<32>(metric, ip_form, qv, V + (size_t)row1 * ld, D, g);
         }
         if (neg) { s0 = -s0; s1 = -s1; }
         if (ok0 && g == 0) keys[i0] = make_key(s0, row0, asc);
