@@ -1,0 +1,47 @@
+"""`bench.py --config c4 / c5` end to end at reduced sizes (one GPU, and two gloo ranks sharing it): the line is printed, names the
+workload BASELINE.json names, and its own verification legs are green (tickets == the blocking search; recall against the exact
+top-k of the whole collection for IVF, the oracle's packed search for Hamming)."""
+import json
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def run_bench(args, env=None):
+    e = dict(os.environ)
+    e.update(env or {})
+    e.pop("WORLD_SIZE", None)
+    e.pop("RANK", None)
+    p = subprocess.run([sys.executable, str(ROOT / "bench.py")] + args, cwd=str(ROOT), env=e, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("gpus", [1, 2])
+def test_bench_config_c4_prints_a_verified_line(gpus):
+    env = {"LYNSE_BENCH_BACKEND": "gloo"} if gpus > 1 else None       # two ranks share the one GPU of a test box: no RCCL between them
+    d = run_bench(["--config", "c4", "--gpus", str(gpus), "--rows-per-gpu", "150000", "--nlist", "512", "--nprobe", "16", "--steps", "4", "--warmup", "1"], env)
+    assert d["n_gpus"] == gpus and d["scaling"] == "weak" and d["unit"] == "queries/s" and d["value"] > 0
+    assert "IVF-Flat IP %dx768" % (150000 * gpus) in d["metric"] and d["config"]["lists_trained"] == 512
+    assert d["verify"]["tickets_equal_blocking_search"] is True
+    assert d["verify"]["recall_at_k_vs_exact_top_k_of_the_collection"] >= 0.8      # (IVF is approximate: 512 lists over 4096 generating centres, 2 Lloyd iterations)
+    assert d["roofline"]["bound"] == "hbm" and d["roofline"]["achieved"] > 0
+    if gpus == 1:
+        assert d["tickets"]["in_flight"] > 0 and d["tickets"]["redone_in_wait"] == 0
+
+
+@pytest.mark.parametrize("gpus", [1, 2])
+def test_bench_config_c5_prints_a_verified_line(gpus):
+    env = {"LYNSE_BENCH_BACKEND": "gloo"} if gpus > 1 else None
+    d = run_bench(["--config", "c5", "--gpus", str(gpus), "--rows", str(600000 * gpus), "--steps", "4", "--warmup", "1"], env)
+    assert d["n_gpus"] == gpus and d["dtype"] == "u64" and d["value"] > 0
+    assert "Hamming %dx1024-bit" % (600000 * gpus) in d["metric"] and "k=50" in d["metric"]
+    assert d["verify"] == {"tickets_equal_blocking_search": True, "oracle_bit_exact_on_200k_row_sample": True}
