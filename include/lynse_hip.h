@@ -88,7 +88,8 @@ typedef struct lynse_hip_profile {
                                  on the certified int8 pass (bit 2 tells what the LAST run used: an overflow retries on the f16
                                  pass), bit 7 the sample stage ran INSIDE the launch of the first threshold stage (one scan launch less than
                                  stages), bits 8..15 number of scan stages, bits 16..23 wave tiling
-                                 (0x24 = <2,4,4,2>, 0x42 = <4,2,2,4>, 0x14 = <1,4,1,1>) — lets a test pin the kernel
+                                 (0x24 = <2,4,4,2>, 0x42 = <4,2,2,4>, 0x14 = <1,4,1,1>, 0x81 = the query-stationary k_scan_qs), bit 24 the self-tightening
+                                 single-launch scan, bit 25 the sample stage ran on the query-stationary tiling — lets a test pin the kernel
                                  instantiation a benchmark configuration runs */
 } lynse_hip_profile;
 

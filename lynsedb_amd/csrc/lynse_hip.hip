@@ -1450,6 +1450,25 @@ static int launch_scan_qs(const ScanArgs& a, uint32_t grid, hipStream_t st) {
     }
 }
 
+// The threshold-only SAMPLE stage on the query-stationary tiling (scan_qs.h, SMP = 1): the sample rows as 64-row tiles, four per workgroup
+// on a full chip (one 144-KB workgroup per CU), 4 keys per workgroup and query = 1024 keys per query.  LYNSE_HIP_QS_SAMPLE=0: the 256 x 256 sample tiles of k_scan_h16 (A/B; read per call).
+static bool qs_sample_ok(const ScanArgs& a, bool fs, bool filt, bool f4, uint32_t plan_tile) {
+    const char* e = getenv("LYNSE_HIP_QS_SAMPLE");
+    const int v = qs_variant();
+    if ((e && atoi(e) == 0) || (v != 1 && v != 3)) return false;
+    return !fs && !filt && !f4 && a.emit_all == 2 && plan_tile == 256 && a.ld16 == 768 && a.nslab == 6 && a.qpad == 256 && a.nq <= 256 && a.tile_stride >= 256 &&
+           a.skip_stride == 0 && !a.mask && !a.row_ids && a.row1 > a.row0;
+}
+static int launch_scan_qs_sample(const ScanArgs& a, uint32_t grid, hipStream_t st) {
+    static bool attr_done = false;
+    auto kern = k_scan_qs<6, 2, 6, 3, false, 8, 0, 0, 0, 0, 1>;
+    constexpr size_t lds = (size_t)3 * 6 * 64 * 128;
+    if (!attr_done) { LY_TRY(set_max_lds(kern, lds)); attr_done = true; }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, a);
+    LY_HIP(hipGetLastError());
+    return LYNSE_OK;
+}
+
 static int launch_scan_i8c(const ScanArgs& a, uint32_t grid, hipStream_t st, bool fs = false, bool filt = false, bool f4 = false, bool qs = false) {
     constexpr size_t lds = (size_t)(3 * 256 + 2 * 256) * 128;
     if (qs) return launch_scan_qs(a, grid, st);
@@ -1813,7 +1832,7 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
                     sample.sample_tiles == (uint32_t)h->num_cu && (plan[1].r1 - plan[1].r0 + 255) / 256 >= (uint32_t)h->num_cu &&
                     (uint64_t)k * 50000ull > (uint64_t)sample.sample_tiles * plan_tile &&   // (the stage behind the sample runs the DENSE epilogue)
                     []() { const char* e = getenv("LYNSE_HIP_DENSE"); return !e || atoi(e) != 0; }();
-    bool plan_used_segments = false, plan_used_qs = false;
+    bool plan_used_segments = false, plan_used_qs = false, plan_qs_sample = false;
     // the select behind the last stage + exact rescoring + final order in one launch (k_select_final); LYNSE_HIP_FUSED_TAIL=0:
     // the three separate kernels (A/B)
     const int fused_tail_env = []() { const char* e = getenv("LYNSE_HIP_FUSED_TAIL"); return e ? atoi(e) : 1; }();   // (read per call: tests flip it)
@@ -1824,6 +1843,7 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
         const bool emit_all = si == 0 && !sts;   // (sts: the one stage is a threshold stage — its thresholds live in w.dyn and tighten while it runs)
         if (fs && si == 0) continue;   // scored inside the launch of stage 1
         const bool fs_stage = fs && si == 1;
+        uint32_t qs_sample_keys = 0;   // != 0: the sample stage ran on the query-stationary tiling and left this many keys per query
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (tl_prof) {
             LY_TRY(get_event(h, (*ev_used)++, &e0));
@@ -1930,6 +1950,18 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
                     a.dyn_thr = w.dyn; a.dyn_marg = w.dyn + w.qcap; a.dyn_slot = w.dyn + 2 * (size_t)w.qcap; a.dyn_ks = k;
                     a.dyn_warm = h->n >= 4000000ull ? 4u : 2u;   // tiles per workgroup that only feed the maxima first (scanned again at the end)
                 }
+                // the threshold-only sample stage on the query-stationary tiling (4 keys per workgroup and query; the same sample rows)
+                if (s.sample_tiles && !sts && qs_sample_ok(a, fs_stage, filt, bin_mfma, plan_tile)) {
+                    const uint32_t nt64 = s.sample_tiles * 4u;
+                    const uint32_t sgrid = std::min<uint32_t>(nt64, (uint32_t)h->num_cu);   // one 144-KB workgroup per CU: a second round of workgroups pays the launch ramp and the query image again (40 us against 30)
+                    if ((uint64_t)sgrid * 4u >= 8ull * k && sgrid * 4u <= w.cap) {
+                        a.ntiles = nt64;
+                        LY_TRY(launch_scan_qs_sample(a, sgrid, st));
+                        qs_sample_keys = sgrid * 4u;
+                        plan_qs_sample = true;
+                    }
+                }
+                if (!qs_sample_keys) {
                 const bool qs = sts || (!ag && qs_scan_ok(a, fs_stage, filt, bin_mfma));   // the query-stationary tiling (scan_qs.h): two segments per workgroup and query
                 uint32_t launch_grid = qs ? qs_grid(a, (uint32_t)h->num_cu) : grid;
                 if (sts) {   // contiguous chunks of dyn_pitch tiles per workgroup; the pitch coprime to the partition count (scan_qs.h)
@@ -1949,6 +1981,7 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
                     if (getenv("LYNSE_HIP_FS_STAMPS")) a.debug_flags |= 128;
                 }
                 LY_TRY(launch_scan_i8c(a, launch_grid, st, fs_stage, filt, bin_mfma, qs));
+                }
             } else if (h16) {
                 a.candB = w.candB; a.segcnt = w.segcnt;
                 if (small) {
@@ -2028,7 +2061,7 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
         if (!binary && emit_all && sample_threshold_only) {
             sa.threshold_only = 1;
             sa.drop_sentinels = 1;  // a lane whose rows are all masked / out of range wrote the sentinel
-            sa.emit_all_n = (int)(s.sample_tiles * sample_keys_per_tile);
+            sa.emit_all_n = qs_sample_keys ? (int)qs_sample_keys : (int)(s.sample_tiles * sample_keys_per_tile);
         }
         sa.Qf = Qf; sa.V = score_rows(h); sa.ld = score_ld(h); sa.D = h->dim;
         sa.candB = w.candB; sa.segcnt = w.segcnt; sa.seg = st_seg; sa.nseg = st_nseg;
@@ -2046,7 +2079,7 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
         std::lock_guard<std::mutex> plk(h->prof_mu);
         h->prof.last_plan = (sample.sample_tiles ? 1u : 0u) | ((sample.sample_tiles && sample_threshold_only) ? 2u : 0u) | (i8c ? 4u : 0u) |
                             (plan_used_segments ? 8u : 0u) | (small ? 16u : 0u) | (fs ? 128u : 0u) | ((uint64_t)(plan.size() & 0xff) << 8) | (tiling << 16) |
-                            (sts ? (1ull << 24) : 0ull);   // bit 24: self-tightening single-launch scan
+                            (sts ? (1ull << 24) : 0ull) | (plan_qs_sample ? (1ull << 25) : 0ull);   // bit 24: self-tightening single-launch scan; bit 25: sample stage on the query-stationary tiling
     }
     FinalArgs fa{};
     fa.cand = w.cand; fa.count = w.count; fa.k = k; fa.out_k = out_k; fa.cap = w.cap; fa.metric = key_metric; fa.ip_form = ip_form;

@@ -48,7 +48,13 @@ constexpr int QS_STS_LDS = 8 * 256 + 8 * 256;   // landing areas behind the ring
 // epilogue with the exact f32 row norms (coarse distance |v|^2 - 2 s_q dot + (|q|^2 - 2 B_q), k_i8c_prep_queries l2n; the norms of a
 // tile ride in a ring of NS + 1 slots behind the row ring, one small LDS-DMA per step by wave 0).  All lanes of a wave half hold the
 // SAME rows, so a lane reads the norms of its 16 RB rows as broadcast ds_read_b128s and scores them against ONE query's constants.
-template <int NSLAB, int RB, int SL, int NS, bool XPF, int NBUF, int DBG = 0, int PING = 0, int STS = 0, int MET = 0>
+// SMP = 1: the THRESHOLD-ONLY SAMPLE STAGE of a staged plan on this tiling (it was the 256 x 256 tile of k_scan_h16: one tile per CU, 30 us
+// of launch ramp, 196-KB query image and ring fill for 65,536 rows).  a.ntiles tiles of 64 rows: tile t = rows (t / 4) * a.tile_stride +
+// (t % 4) * 64 ... of the shard (the same sample rows); no threshold, no segments — every lane keeps the best TWO (coarse score, row) of
+// all the rows it sees for its query and writes them to cand[query][(blockIdx.x * 2 + hi) * 2 + t]: 4 keys per workgroup and query,
+// gridDim.x * 4 per query.  Any k distinct real rows bound the k-th best score from below, so k_select's threshold-only rule turns the
+// k-th best of these keys into a valid first threshold exactly as it does with the lane-max keys of the old sample tiles.
+template <int NSLAB, int RB, int SL, int NS, bool XPF, int NBUF, int DBG = 0, int PING = 0, int STS = 0, int MET = 0, int SMP = 0>
 __global__ void __launch_bounds__(512, 2) k_scan_qs(ScanArgs a) {
     static_assert(NSLAB % SL == 0, "a tile is a whole number of steps");
     constexpr int TS = NSLAB / SL;          // steps per tile
@@ -67,6 +73,7 @@ __global__ void __launch_bounds__(512, 2) k_scan_qs(ScanArgs a) {
     static_assert(NRM_OFF + NRM_SLOTS * NRM <= 160 * 1024, "LDS");
     static_assert(PING == 0 || TS == 1, "ping-pong: one step per tile");
     static_assert(STS == 0 || (!XPF && TS == 1), "self-tightening thresholds: whole-K stages, no cross-barrier prefetch");
+    static_assert(SMP == 0 || (STS == 0 && MET == 0 && RT == 64 && TS == 1), "sample stage: 64-row tiles of the IP / cosine form");
     constexpr int WAITN = (XPF ? NS - 3 : NS - 2) * PPW;   // DMA instructions that may still be in flight at the barrier
     static_assert(WAITN <= 63, "vmcnt");
 
@@ -74,7 +81,11 @@ __global__ void __launch_bounds__(512, 2) k_scan_qs(ScanArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l32 = lane & 31, hi = lane >> 5;
-    const uint32_t ntiles = (a.row1 - a.row0 + RT - 1) / RT;
+    const uint32_t ntiles = SMP != 0 ? a.ntiles : (a.row1 - a.row0 + RT - 1) / RT;
+    auto tile_row0 = [&](uint32_t t) -> uint32_t {   // first row of tile t
+        if constexpr (SMP != 0) return a.row0 + (t >> 2) * a.tile_stride + (t & 3u) * (uint32_t)RT;
+        else return a.row0 + t * RT;
+    };
     // Tile order.  Staged plans: workgroup b takes tiles b, b + grid, ... (the chip sweeps the stage front to back).  STS: workgroup b
     // owns the CONTIGUOUS tiles [b * pitch, (b + 1) * pitch) — the tiles the chip works on at any moment are spread evenly over the
     // whole shard, so the running thresholds are representative of it whatever the insertion order (a shard sorted by score would
@@ -131,7 +142,7 @@ __global__ void __launch_bounds__(512, 2) k_scan_qs(ScanArgs a) {
         if (a.debug_flags & 2) l2_pre = LY_INF;
 #endif
     }
-    if constexpr (STS == 0 && MET == 0) {
+    if constexpr (STS == 0 && MET == 0 && SMP == 0) {
         // INTEGER image of the threshold (k_scan_h16, load_qc_thr): B_q + s_q * (float)dot is monotone non-decreasing in the
         // integer dot product, so "score >= thr" is exactly "dot >= T", T = the smallest passing dot (bisection over |dot| <= 2^29)
         const float th = q_ok ? a.thr[qn] : 0.0f;
@@ -183,7 +194,7 @@ __global__ void __launch_bounds__(512, 2) k_scan_qs(ScanArgs a) {
     const char* v_base = nullptr;   // uniform: first row of the tile being issued
     uint32_t is_ord = 0, is_sub = 0, is_stage = 0, is_count = 0;
     auto enter_tile = [&]() {
-        const uint32_t rbase = a.row0 + tile_of(is_ord) * RT;
+        const uint32_t rbase = tile_row0(tile_of(is_ord));
         const uint32_t span = a.row1 - 1 - rbase;   // rows past the last one re-read it (masked in the epilogue)
         v_base = reinterpret_cast<const char*>(a.V16) + (size_t)rbase * a.ld16;
 #pragma unroll
@@ -364,9 +375,32 @@ __global__ void __launch_bounds__(512, 2) k_scan_qs(ScanArgs a) {
             if (lane == 0 && m > pub_last) { atomicMax(a.dyn_thr + hq, m); pub_last = m; }
         }
     };
+    // SMP: the best two (coarse score, row) of every row this lane has seen for its query (sorted: [0] is the better one)
+    [[maybe_unused]] float smp_s[2] = {-LY_INF, -LY_INF};
+    [[maybe_unused]] uint32_t smp_m[2] = {0xffffffffu, 0xffffffffu};
     // ---- tile epilogue: this lane's RB x 16 dot products all belong to query qn
     auto epilogue = [&](uint32_t e_tile, bool emit, [[maybe_unused]] uint32_t e_ord_) {
-        if constexpr ((DBG & 16) != 0) {
+        if constexpr (SMP != 0) {
+            const uint32_t rbase = tile_row0(e_tile);
+#pragma unroll
+            for (int i = 0; i < RB; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    uint32_t m = rbase + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    float sc = b_q + s_q * (float)acc[i][r];      // the coarse score of the threshold stages' keys
+                    if (!(m < a.row1)) { m = 0xffffffffu; sc = -LY_INF; }
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {   // insertion into the sorted pair (a row without a score never displaces one with)
+                        const bool better = smp_m[t] == 0xffffffffu ? m != 0xffffffffu : (m != 0xffffffffu && sc > smp_s[t]);
+                        const float ts = smp_s[t];
+                        const uint32_t tm = smp_m[t];
+                        smp_s[t] = better ? sc : ts;
+                        smp_m[t] = better ? m : tm;
+                        sc = better ? ts : sc;
+                        m = better ? tm : m;
+                    }
+                }
+        } else if constexpr ((DBG & 16) != 0) {
 #pragma unroll
             for (int i = 0; i < RB; ++i)
 #pragma unroll
@@ -551,6 +585,15 @@ __global__ void __launch_bounds__(512, 2) k_scan_qs(ScanArgs a) {
                     stamp(t_loop);
                     pend = true;
                 }
+            }
+        }
+    }
+    if constexpr (SMP != 0) {
+        if (q_ok) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const uint32_t slot = (blockIdx.x * 2 + hi) * 2 + t;
+                if (slot < a.cap) a.cand[(size_t)qn * a.cap + slot] = smp_m[t] == 0xffffffffu ? KEY_SENTINEL : make_key(smp_s[t], smp_m[t], false);
             }
         }
     }

@@ -21,6 +21,7 @@ f32 = np.float32
 
 PLAN_SAMPLED, PLAN_THRESHOLD_ONLY, PLAN_I8C, PLAN_SEGMENTS, PLAN_SMALL, PLAN_FUSED_SAMPLE = 1, 2, 4, 8, 16, 128
 PLAN_STS = 1 << 24   # the self-tightening single-launch scan (k_scan_qs<.., STS>)
+PLAN_QS_SAMPLE = 1 << 25   # the threshold-only sample stage ran on the query-stationary tiling (k_scan_qs<.., SMP>)
 
 
 def plan_fields(p):
@@ -68,6 +69,7 @@ def test_c2_flat_ip_768_batch256_runs_the_benchmarked_kernels(L, oracle):
     assert tiling == 0x81, hex(tiling)      # the threshold stages ran the query-stationary tiling (k_scan_qs, scan_qs.h)
     assert flags & PLAN_SAMPLED and flags & PLAN_THRESHOLD_ONLY and flags & PLAN_I8C and flags & PLAN_SEGMENTS, bin(flags)
     assert not (flags & PLAN_FUSED_SAMPLE) and not (int(p["last_plan"]) & PLAN_STS), hex(int(p["last_plan"]))
+    assert int(p["last_plan"]) & PLAN_QS_SAMPLE, hex(int(p["last_plan"]))      # ... and so did the sample stage (LYNSE_HIP_QS_SAMPLE=0 below: the 256 x 256 sample tiles)
     # the full ranking of the default run against the oracle's exact_flat_search (ids + f32 distance bits), wave boundaries included
     for qi in (0, 1, 31, 32, 63, 64, 100, 128, 200, 255):
         assert_rows_equal(oracle.canonical_topk(queries[qi], data, k, O.IP), rows[qi], dists[qi], counts[qi], ("c2", qi))
@@ -83,7 +85,7 @@ def test_c2_flat_ip_768_batch256_runs_the_benchmarked_kernels(L, oracle):
     # (e) as ONE scan launch with self-tightening thresholds (k_scan_qs<.., STS>; LYNSE_HIP_STS=1, off by default: measured no
     # faster — a query that overflows there goes down the ladder to the staged plan, results identical either way)
     for env, launches, fused in (({"LYNSE_HIP_FUSED_SAMPLE": "1"}, 2, True), ({"LYNSE_HIP_FUSED_TAIL": "0"}, 3, False), ({"LYNSE_HIP_AG": "1"}, 3, False),
-                                 ({"LYNSE_HIP_QS": "0"}, 3, False), ({"LYNSE_HIP_QS": "2"}, 3, False), ({"LYNSE_HIP_QS": "3"}, 3, False),
+                                 ({"LYNSE_HIP_QS": "0"}, 3, False), ({"LYNSE_HIP_QS": "2"}, 3, False), ({"LYNSE_HIP_QS": "3"}, 3, False), ({"LYNSE_HIP_QS_SAMPLE": "0"}, 3, False),
                                  ({"LYNSE_HIP_STS": "1"}, None, False)):
         os.environ.update(env)
         try:
@@ -96,6 +98,8 @@ def test_c2_flat_ip_768_batch256_runs_the_benchmarked_kernels(L, oracle):
             assert p_u["scan_launches"] == launches and bool(plan_fields(p_u)[0] & PLAN_FUSED_SAMPLE) == fused and p_u["fallback_queries"] == 0, p_u
         if env.get("LYNSE_HIP_QS") == "0":
             assert plan_fields(p_u)[2] == 0x24, hex(plan_fields(p_u)[2])
+        if env.get("LYNSE_HIP_QS") in ("0", "2") or "LYNSE_HIP_QS_SAMPLE" in env:
+            assert not (int(p_u["last_plan"]) & PLAN_QS_SAMPLE), hex(int(p_u["last_plan"]))
         if "LYNSE_HIP_STS" in env:   # (the plan on record is the last one run: the single launch, or the staged rerun of the queries that overflowed)
             assert p_u["scan_launches"] >= 1 and (int(p_u["last_plan"]) & PLAN_STS or p_u["fallback_queries"] > 0), p_u
         assert np.array_equal(r_u, rows) and np.array_equal(d_u.view(np.uint32), dists.view(np.uint32)) and np.array_equal(c_u, counts)
