@@ -510,6 +510,21 @@ __global__ void __launch_bounds__(256) k_gather_rows_f32(const float* __restrict
 }
 
 
+// dst[pos[i]] = src[i] (IVFIndex::insert on the device: the new rows go to their slab positions of the re-assembled store)
+__global__ void __launch_bounds__(256) k_scatter_rows_f32(const float* __restrict__ src, uint32_t src_ld, const uint32_t* __restrict__ pos,
+                                                          uint64_t m, float* __restrict__ dst, uint32_t dst_ld, uint32_t width) {
+    const uint32_t per_row = (dst_ld + 3) / 4;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < m * per_row; i += (uint64_t)gridDim.x * 256) {
+        const uint64_t r = i / per_row;
+        const uint32_t c0 = (uint32_t)(i % per_row) * 4;
+        const float* s = src + (size_t)r * src_ld;
+        float* d = dst + (size_t)pos[r] * dst_ld;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (c0 + e < dst_ld) d[c0 + e] = (c0 + e < width) ? s[c0 + e] : 0.0f;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // k_ivf_score_positions — the exact scores of a list of slab positions against ONE query, as (score, ORIGINAL row) keys.
 // IVF search with k beyond the candidate capacity of the staged pipeline (k > cap / 4: IVFIndex::search accepts any k,
