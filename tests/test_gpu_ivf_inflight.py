@@ -239,3 +239,58 @@ def test_sharded_ivf_tickets_with_a_one_rank_communicator(L, oracle):
             e_ids, e_d, _ = oracle.ivf_search(b[qi], data, cen, off, rows, nprobe, k, IP)
             assert int(c[qi]) == len(e_ids) and np.array_equal(r[qi, :len(e_ids)], e_ids.astype(np.uint64) * 3 + 1), qi
             assert np.array_equal(d[qi, :len(e_ids)].view(np.uint32), e_d.view(np.uint32)), qi
+
+
+def test_ivf_tickets_from_three_threads(L, oracle):
+    """Three submitting threads, one ticket each at a time (contexts 1..3), next to a fourth thread running blocking searches: every
+    answer equals the blocking call's."""
+    import threading
+
+    import torch
+
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(99)
+    n, dim, nlist, nprobe, nq, k = 80_000, 128, 128, 6, 96, 10
+    data, cen, asg, off, rows, idx = _index(L, oracle, rng, n, dim, nlist, IP)
+    batches = [(data[rng.integers(0, n, nq)] + 0.05 * rng.standard_normal((nq, dim))).astype(f32) for _ in range(12)]
+    dq = [torch.as_tensor(b, device=dev) for b in batches]
+    want = []
+    for q in dq:
+        o = _tensors(torch, nq, k, dev)
+        idx.search_device(q, k, nprobe, *o)
+        want.append(_host(o))
+    got = [None] * len(batches)
+    errs = []
+
+    def submitter(tid):
+        try:
+            torch.cuda.set_device(0)
+            for rep in range(3):
+                for i in range(tid, len(batches), 3):
+                    o = _tensors(torch, nq, k, dev)
+                    torch.cuda.synchronize()
+                    idx.search_submit(dq[i], k, nprobe, *o).wait()
+                    got[i] = _host(o)
+        except Exception as e:  # noqa: BLE001
+            errs.append((tid, repr(e)))
+
+    def blocker():
+        try:
+            torch.cuda.set_device(0)
+            for rep in range(20):
+                o = _tensors(torch, nq, k, dev)
+                idx.search_device(dq[rep % len(dq)], k, nprobe, *o)
+                assert _same(_host(o), want[rep % len(dq)])
+        except Exception as e:  # noqa: BLE001
+            errs.append(("blocking", repr(e)))
+
+    ts = [threading.Thread(target=submitter, args=(t,)) for t in range(3)] + [threading.Thread(target=blocker)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(300)
+    assert not errs, errs
+    for i in range(len(batches)):
+        assert _same(got[i], want[i]), i
+    st = idx.ticket_stats()
+    assert st["in_flight"] == 36 and st["inside_submit"] == 0, st
