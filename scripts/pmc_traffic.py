@@ -24,6 +24,9 @@ for r in csv.DictReader(open(f)):
     mq = re.search(r"lynse::k_scan_qs<([^>]*)>", r["Kernel_Name"])   # the query-stationary tiling: threshold stages of the int8 pass
     m = re.search(r"lynse::k_scan_h16<([^>]*)>", r["Kernel_Name"])
     if mq:
+        qa = [x.strip() for x in mq.group(1).split(",")]
+        if len(qa) > 10 and qa[10] == "1":
+            continue   # SMP: the sample stage on the same tiling (its 65,536 rows are streamed again by the threshold stages)
         key = ("i8c", "0")
         kname[key] = "k_scan_qs<%s>" % mq.group(1)
     elif m:
