@@ -596,6 +596,11 @@ def run_c4(args, rank, local_rank, world, dev, dist, result_out):
             "tickets": stats,
             "verify": {"tickets_equal_blocking_search": same, "queries": nv, "recall_at_k_vs_exact_top_k_of_the_collection": recall},
         }
+        if not args.no_cpu_baseline and world == 1:
+            try:
+                result["cpu_baseline"] = cpu_baseline_ivf(args, N, D, K, nlist, nprobe, KC)
+            except Exception as e:  # noqa: BLE001
+                result["cpu_baseline"] = {"error": repr(e)}
         result_out.write(json.dumps(result) + "\n")
         result_out.flush()
     if dist is not None:
@@ -754,6 +759,11 @@ def run_c5(args, rank, local_rank, world, dev, dist, result_out):
             "blocking_ms_per_batch": round(lat_ms, 4),
             "verify": {"tickets_equal_blocking_search": same, "oracle_bit_exact_on_200k_row_sample": bool(exact)},
         }
+        if not args.no_cpu_baseline and world == 1:
+            try:
+                result["cpu_baseline"] = cpu_baseline(args, N, bits, K, metric)
+            except Exception as e:  # noqa: BLE001
+                result["cpu_baseline"] = {"error": repr(e)}
         result_out.write(json.dumps(result) + "\n")
         result_out.flush()
     if dist is not None:
@@ -1064,6 +1074,50 @@ def other_configs(dev):
     return out
 
 
+def cpu_baseline_ivf(args, N, D, K, nlist, nprobe, KC):
+    """SURVEY 8(d), C4: the oracle's restatement of IVFIndex::search (ivf.rs:181-348: centroid ranking, the probed lists scored one row
+    after the other — the reference's candidate scoring is serial) timed on ONE host core over a reduced collection of the same recipe:
+    1,000,000 rows, the same nlist / nprobe, centroids = the 4096 generating centres with every row filed under its own centre (any
+    centroids + assignments are an IVFIndex; a CPU k-means of this size would take hours).  The time of a query = ranking the nlist
+    centroids + scoring the probed rows; the second part is scaled by the rows ratio to the full collection."""
+    import oracle as O
+
+    orc = O.get()
+    n_s = min(N, 1_000_000)
+    rng = np.random.default_rng(7)
+    centers = rng.standard_normal((KC, D)).astype(np.float32)
+    centers /= np.linalg.norm(centers, axis=1, keepdims=True)
+    data = np.empty((n_s, D), np.float32)
+    for b0 in range(0, n_s, 100_000):
+        e = min(n_s, b0 + 100_000)
+        data[b0:e] = centers[np.arange(b0, e) % KC] + 0.03 * rng.standard_normal((e - b0, D)).astype(np.float32)
+    asg = (np.arange(n_s) % KC).astype(np.uint32)
+    cen = centers if nlist == KC else centers[:nlist]
+    if nlist != KC:
+        asg = (asg % nlist).astype(np.uint32)
+    off, rows = orc.lists_from_assignments(asg, cen.shape[0])
+    warm, trials = 5, 30
+    qs = (centers[rng.integers(0, KC, warm + trials)] + 0.03 * rng.standard_normal((warm + trials, D))).astype(np.float32)
+    for i in range(warm):
+        orc.ivf_search(qs[i], data, cen, off, rows, nprobe, K, O.IP)
+    ts, tc = [], []
+    for i in range(warm, warm + trials):
+        t0 = time.perf_counter()
+        orc.ivf_search(qs[i], data, cen, off, rows, nprobe, K, O.IP)
+        ts.append(time.perf_counter() - t0)
+        t0 = time.perf_counter()
+        orc.all_distances(qs[i], cen, O.IP)          # the centroid-ranking share (the same single-row kernel over nlist rows)
+        tc.append(time.perf_counter() - t0)
+    ts.sort()
+    tc.sort()
+    med, med_c = ts[len(ts) // 2], tc[len(tc) // 2]
+    full = med_c + max(med - med_c, 0.0) * (N / n_s)
+    return {"value": round(1.0 / full, 2), "unit": "queries/s", "cores": 1, "kind": "port",
+            "sample": "%d-row sample (of %d) of the same recipe, nlist=%d nprobe=%d, %d warm-ups + %d timed single queries, median %.3f ms per query on the "
+                      "sample (%.3f ms of it the centroid ranking); the probed-list share scaled by the rows ratio" % (n_s, N, cen.shape[0], nprobe, warm, trials, med * 1e3, med_c * 1e3),
+            "median_ms_per_query_on_sample": round(med * 1e3, 3)}
+
+
 def cpu_baseline(args, N, D, K, metric):
     """The oracle's restatement of the reference's chunked rayon scan (flat_mmap.rs:4845-4982; chunks of
     max(n / threads, 512) rows, AVX2+FMA batch-8 kernel, per-chunk top-k, serial merge) timed on this host's cores over a
@@ -1085,14 +1139,16 @@ def cpu_baseline(args, N, D, K, metric):
     def timed(threads, warm, trials):
         orc.pool_start(threads)
         try:
-            data = orc.fill_uniform_mt(sample, D, args.seed)
-            qs = data[rng.integers(0, sample, size=warm + trials)] + 0.03 * rng.standard_normal((warm + trials, D)).astype(np.float32)
-            if metric >= 3:
-                words = orc.pack_binary(data)
-                qw = orc.pack_binary(qs)
+            if metric >= 3:   # packed fingerprints generated as words (D bits per row), queries = rows with 16 bits flipped
+                W = (D + 63) // 64
+                words = rng.integers(0, np.iinfo(np.int64).max, size=(sample, W), dtype=np.int64).view(np.uint64)
+                qw = words[rng.integers(0, sample, size=warm + trials)].copy()
+                qw[:, 0] ^= np.uint64(0xFFFF)
                 run = lambda i: orc.packed_binary_search(qw[i], words, K, metric, n_threads=threads, mt=True)  # noqa: E731
                 nbytes = words.nbytes
             else:
+                data = orc.fill_uniform_mt(sample, D, args.seed)
+                qs = data[rng.integers(0, sample, size=warm + trials)] + 0.03 * rng.standard_normal((warm + trials, D)).astype(np.float32)
                 run = lambda i: orc.flat_search(qs[i], data, K, metric, n_threads=threads, mt=True)  # noqa: E731
                 nbytes = data.nbytes
             for i in range(warm):

@@ -36,12 +36,13 @@ def test_bench_config_c4_prints_a_verified_line(gpus):
     assert d["roofline"]["bound"] == "hbm" and d["roofline"]["achieved"] > 0
     if gpus == 1:
         assert d["tickets"]["in_flight"] > 0 and d["tickets"]["redone_in_wait"] == 0
+        assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] == 1 and d["cpu_baseline"]["value"] > 0, d["cpu_baseline"]
 
 
 @pytest.mark.parametrize("gpus", [1, 2])
 def test_bench_config_c5_prints_a_verified_line(gpus):
     env = {"LYNSE_BENCH_BACKEND": "gloo"} if gpus > 1 else None
-    d = run_bench(["--config", "c5", "--gpus", str(gpus), "--rows", str(600000 * gpus), "--steps", "4", "--warmup", "1"], env)
+    d = run_bench(["--config", "c5", "--gpus", str(gpus), "--rows", str(600000 * gpus), "--steps", "4", "--warmup", "1", "--no-cpu-baseline"], env)
     assert d["n_gpus"] == gpus and d["dtype"] == "u64" and d["value"] > 0
     assert "Hamming %dx1024-bit" % (600000 * gpus) in d["metric"] and "k=50" in d["metric"]
     assert d["verify"] == {"tickets_equal_blocking_search": True, "oracle_bit_exact_on_200k_row_sample": True}
