@@ -1415,8 +1415,14 @@ static bool sts_env_on() { const char* e = getenv("LYNSE_HIP_STS"); return e && 
 static bool qs_scan_ok(const ScanArgs& a, bool fs, bool filt, bool f4) {
     const int v = qs_variant();
     if (v < 1 || v > 3) return false;
-    return !fs && !filt && !f4 && a.emit_all == 0 && a.ld16 == 768 && a.nslab == 6 && a.qpad == 256 && a.nq <= 256 && a.tile_stride == 0 &&
-           a.skip_stride == 0 && !a.mask && !a.row_ids && a.row1 > a.row0;
+    // filt: the MASKED threshold stages of a subset-filtered search (row bitmask; k_scan_qs<.., MSK>) — LYNSE_HIP_QS_MASKED=0: the DENSE
+    // masked epilogue of k_scan_h16 (A/B; read per call)
+    if (filt) {
+        const char* e = getenv("LYNSE_HIP_QS_MASKED");
+        if ((e && atoi(e) == 0) || v == 2 || !a.mask || a.row_ids) return false;
+    }
+    return !fs && !f4 && a.emit_all == 0 && a.ld16 == 768 && a.nslab == 6 && a.qpad == 256 && a.nq <= 256 && a.tile_stride == 0 &&
+           (filt || (a.skip_stride == 0 && !a.mask)) && !a.row_ids && a.row1 > a.row0;
 }
 // LYNSE_HIP_SCAN_CUS: workgroups (= CUs: one 144-KB workgroup per CU) of the persistent threshold-stage scans.  The scan is bound by the
 // power the chip may draw, not by its CU count: a few CUs left free cost it little and let the short latency-bound kernels of ANOTHER
@@ -1443,6 +1449,7 @@ static int launch_scan_qs(const ScanArgs& a, uint32_t grid, hipStream_t st) {
         LY_HIP(hipGetLastError());
         return LYNSE_OK;
     };
+    if (a.mask) return go(k_scan_qs<6, 2, 6, 3, false, 8, 0, 1, 0, 0, 0, 1>, 0, (size_t)3 * 6 * 64 * 128);   // masked threshold stages (MSK)
     switch (qs_variant()) {
     case 2: return go(k_scan_qs<6, 1, 6, 6, true, 8, 0, 0>, 2, (size_t)6 * 6 * 32 * 128);
     case 3: return go(k_scan_qs<6, 2, 6, 3, false, 8, 0, 0>, 3, (size_t)3 * 6 * 64 * 128);

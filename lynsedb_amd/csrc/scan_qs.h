@@ -54,7 +54,11 @@ constexpr int QS_STS_LDS = 8 * 256 + 8 * 256;   // landing areas behind the ring
 // all the rows it sees for its query and writes them to cand[query][(blockIdx.x * 2 + hi) * 2 + t]: 4 keys per workgroup and query,
 // gridDim.x * 4 per query.  Any k distinct real rows bound the k-th best score from below, so k_select's threshold-only rule turns the
 // k-th best of these keys into a valid first threshold exactly as it does with the lane-max keys of the old sample tiles.
-template <int NSLAB, int RB, int SL, int NS, bool XPF, int NBUF, int DBG = 0, int PING = 0, int STS = 0, int MET = 0, int SMP = 0>
+// MSK = 1: the MASKED threshold stages of a subset-filtered search (FlatMmap::search_filtered as a row bitmask): a key is
+// emitted only for rows whose bit is set in a.mask, and the 256-row tiles of the emit-all sample stage (tile t at t * a.skip_stride,
+// t < a.skip_tiles: their rows are candidates already) are computed but emit nothing.  Both checks live in the rare slow path / once per
+// tile: the scan itself runs at the speed of the unfiltered one.
+template <int NSLAB, int RB, int SL, int NS, bool XPF, int NBUF, int DBG = 0, int PING = 0, int STS = 0, int MET = 0, int SMP = 0, int MSK = 0>
 __global__ void __launch_bounds__(512, 2) k_scan_qs(ScanArgs a) {
     static_assert(NSLAB % SL == 0, "a tile is a whole number of steps");
     constexpr int TS = NSLAB / SL;          // steps per tile
@@ -74,6 +78,7 @@ __global__ void __launch_bounds__(512, 2) k_scan_qs(ScanArgs a) {
     static_assert(PING == 0 || TS == 1, "ping-pong: one step per tile");
     static_assert(STS == 0 || (!XPF && TS == 1), "self-tightening thresholds: whole-K stages, no cross-barrier prefetch");
     static_assert(SMP == 0 || (STS == 0 && MET == 0 && RT == 64 && TS == 1), "sample stage: 64-row tiles of the IP / cosine form");
+    static_assert(MSK == 0 || (STS == 0 && MET == 0 && SMP == 0), "masked threshold stages: the IP / cosine form");
     constexpr int WAITN = (XPF ? NS - 3 : NS - 2) * PPW;   // DMA instructions that may still be in flight at the barrier
     static_assert(WAITN <= 63, "vmcnt");
 
@@ -490,6 +495,9 @@ __global__ void __launch_bounds__(512, 2) k_scan_qs(ScanArgs a) {
                     if (!emit) return;   // (uniform) a warm-up tile: scanned again at the end of the launch
                 }
                 const uint32_t rbase = a.row0 + e_tile * RT;
+                if constexpr (MSK != 0) {   // (uniform) a tile of the emit-all sample stage: its rows are candidates already
+                    if (a.skip_stride && rbase % a.skip_stride < 256u && rbase / a.skip_stride < a.skip_tiles) return;
+                }
                 uint64_t* segdst = a.candB + ((size_t)qn * a.nseg + (blockIdx.x * 2 + hi)) * a.seg;
 #pragma unroll
                 for (int i = 0; i < RB; ++i) {
@@ -503,7 +511,7 @@ __global__ void __launch_bounds__(512, 2) k_scan_qs(ScanArgs a) {
                             const int v = acc[i][r];
                             if (v >= T) {
                                 const uint32_t m = rbase + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                                if (m < a.row1) {
+                                if (m < a.row1 && (MSK == 0 || ((a.mask[m >> 5] >> (m & 31)) & 1u))) {   // (the mask word is read only for rows that beat the threshold)
                                     const uint64_t key = make_key(b_q + s_q * (float)v, m, false);
                                     if (cnt < a.seg) {
                                         segdst[cnt] = key;

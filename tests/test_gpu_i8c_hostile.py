@@ -269,6 +269,17 @@ def test_masked_scan_runs_the_certified_int8_pass(L, oracle, metric, dim, frac, 
         assert int(counts[qi]) == k
         assert np.array_equal(rows[qi].astype(np.uint64), e_ids.astype(np.uint64)), (qi, rows[qi], e_ids)
         assert np.array_equal(dists[qi].view(np.uint32), e_d.view(np.uint32)), (qi, dists[qi], e_d)
+    # 768-column IP codes: the masked threshold stages run the query-stationary tiling (k_scan_qs<.., MSK>, round 4); LYNSE_HIP_QS_MASKED=0 =
+    # the DENSE masked epilogue of k_scan_h16 — identical answers
+    tiling = (int(p["last_plan"]) >> 16) & 0xff
+    assert tiling == (0x81 if (metric == "ip" and dim == 768) else 0x24), hex(tiling)
+    if tiling == 0x81:
+        monkeypatch.setenv("LYNSE_HIP_QS_MASKED", "0")
+        r0, d0, c0 = idx.search_filtered_bitset_batch_arrays(queries, k, metric, words)
+        p0 = idx.profile_get(reset=True)
+        monkeypatch.delenv("LYNSE_HIP_QS_MASKED")
+        assert ((int(p0["last_plan"]) >> 16) & 0xff) == 0x24 and p0["fallback_queries"] == 0
+        assert np.array_equal(r0, rows) and np.array_equal(d0.view(np.uint32), dists.view(np.uint32)) and np.array_equal(c0, counts)
     # the id-list entry point builds the same bitmask
     r2, d2, c2 = idx.search_filtered_batch_arrays(queries, k, metric, ids)
     assert np.array_equal(r2, rows) and np.array_equal(d2.view(np.uint32), dists.view(np.uint32))
