@@ -1730,7 +1730,14 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
     const bool small = nq <= SCAN_BQ_SMALL;
     // mid-size batches on the int8 codes: 33..64 queries -> the 128 x 64 tiling, 65..128 -> the 256 x 128 tiling (LYNSE_HIP_MID_TILINGS=0: off)
     const int mid_env = []() { const char* e = getenv("LYNSE_HIP_MID_TILINGS"); return e ? atoi(e) : 1; }();   // (read per call: tests flip it)
-    const bool mid_ok = mid_env && i8c && !bin_mfma && !small && !row_ids && h16 && (!mask || (aug ? h->ld8a : h->ld8) % 128 == 0);
+    // ... unless the query-stationary tiling takes the batch (768-column codes of the IP / cosine / plain-L2 forms; a row bitmask only on
+    // the IP / cosine form): waves without queries skip their MFMAs there, and it beats both mid tilings from 33 queries on (10M x 768, IP:
+    // 40 / 64 / 100 / 128 queries 1.28 / 1.32 / 1.48 / 1.49 -> 1.22 / 1.25 / 1.29 / 1.31 ms; L2 1.39 / 1.43 / 1.81 / 1.89 -> 1.34 / 1.38 / 1.57 /
+    // 1.62).  LYNSE_HIP_QS_MID=0: the mid tilings (A/B, tests; read per call)
+    const bool qs_mid = []() { const char* e = getenv("LYNSE_HIP_QS_MID"); return !e || atoi(e) != 0; }() && qs_variant() >= 1 && qs_variant() <= 3 && i8c && !bin_mfma &&
+                        !small && !row_ids && h16 && !aug && h->ld8 == 768 && nq <= 256 &&
+                        (!mask || (!l2n && qs_variant() != 2 && []() { const char* e = getenv("LYNSE_HIP_QS_MASKED"); return !e || atoi(e) != 0; }()));
+    const bool mid_ok = mid_env && !qs_mid && i8c && !bin_mfma && !small && !row_ids && h16 && (!mask || (aug ? h->ld8a : h->ld8) % 128 == 0);
     const bool mid64 = mid_ok && nq <= 64, mid128 = mid_ok && !mid64 && nq <= 128;
     const bool narrow = small || mid64;   // 128-row tiles
     const uint32_t qpad = small ? SCAN_BQ_SMALL : mid64 ? 64u : mid128 ? 128u : round_up(nq, SCAN_BQ_LARGE);  // > 256 queries: a widened handle, qpad / 256 chunks per launch

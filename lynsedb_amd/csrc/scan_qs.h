@@ -131,6 +131,9 @@ __global__ void __launch_bounds__(512, 2) k_scan_qs(ScanArgs a) {
     // per-query constants of this lane's query (one query per lane: column lane % 32 of the wave's block)
     const uint32_t qn = wave * 32 + l32;
     const bool q_ok = qn < a.nq;
+    // a wave whose 32 queries all lie beyond the batch (65..224 queries) only feeds the ring: no fragment reads, MFMAs or epilogue —
+    // the scan is bound by the power the matrix pipe draws, idle MFMAs are not free
+    const bool wave_live = (uint32_t)wave * 32u < a.nq;
     const float s_q = q_ok ? a.qinv[qn] : 0.0f, b_q = q_ok ? a.qn2[qn] : 0.0f;
     int T = 0x7fffffff;
     // L2: pass iff |v|^2 - 2 s_q dot + c_q <= thr.  Level 1 maximises 2 s_q dot - |v|^2 against pre = (c_q - thr) LOOSENED by more than the
@@ -533,7 +536,7 @@ __global__ void __launch_bounds__(512, 2) k_scan_qs(ScanArgs a) {
             ly_static_for<TS>([&](auto sc) {
                 stamp(t_epi);
                 wait_and_barrier();
-                if ((DBG & 64) && wave >= 4) {   // (experiment) one computing wave per SIMD: waves 4-7 only feed the ring
+                if (((DBG & 64) && wave >= 4) || !wave_live) {   // (experiment: one computing wave per SIMD) / no queries: only feed the ring
 #pragma unroll
                     for (int j = 0; j < PPW; ++j) issue_piece(j);
                 } else {
@@ -546,7 +549,7 @@ __global__ void __launch_bounds__(512, 2) k_scan_qs(ScanArgs a) {
                 stamp(t_loop);
             });
             if constexpr (STS != 0) sts_pickup();
-            epilogue(tile_of(c_ord), c_ord >= warm, c_ord);
+            if (wave_live) epilogue(tile_of(c_ord), c_ord >= warm, c_ord);
         }
     } else {
         // PING-PONG (PING): the two waves of a SIMD share one matrix pipe, and with equal priority the older wave wins every slot — waves
@@ -565,7 +568,7 @@ __global__ void __launch_bounds__(512, 2) k_scan_qs(ScanArgs a) {
                 wait_and_barrier();
                 if (!late) {
                     if constexpr (PING == 2) __builtin_amdgcn_s_setprio(1);
-                    mfma_step(std::integral_constant<int, 0>{}, std::false_type{});
+                    if (wave_live) mfma_step(std::integral_constant<int, 0>{}, std::false_type{});
                     if constexpr (PING == 2) __builtin_amdgcn_s_setprio(0);
                     if constexpr (TIMING) asm volatile("" ::"v"(acc[0][0]));
                     stamp(t_loop);
@@ -574,7 +577,7 @@ __global__ void __launch_bounds__(512, 2) k_scan_qs(ScanArgs a) {
             }
             if (pend) {
                 if constexpr (STS != 0) sts_pickup();
-                epilogue(tile_of(e_ord), e_ord >= warm, e_ord);
+                if (wave_live) epilogue(tile_of(e_ord), e_ord >= warm, e_ord);
                 ++e_ord;
                 pend = false;
             }
@@ -588,7 +591,7 @@ __global__ void __launch_bounds__(512, 2) k_scan_qs(ScanArgs a) {
                 advance();
                 if (late) {
                     stamp(t_epi);
-                    mfma_step(std::integral_constant<int, 0>{}, std::false_type{});
+                    if (wave_live) mfma_step(std::integral_constant<int, 0>{}, std::false_type{});
                     if constexpr (TIMING) asm volatile("" ::"v"(acc[0][0]));
                     stamp(t_loop);
                     pend = true;

@@ -106,7 +106,18 @@ def test_c2_flat_ip_768_batch256_runs_the_benchmarked_kernels(L, oracle):
     # other batch sizes give the same answers: 40 queries (same kernels, mostly empty query columns) and 8 queries
     # (the <= 32-query tiling; from 256K rows on it streams the SQ8 codes too)
     r40, d40, c40 = idx.search_batch_arrays(queries[:40], k, "ip")
+    p40 = idx.profile_get(reset=True)
+    assert plan_fields(p40)[2] == 0x81 and p40["fallback_queries"] == 0, p40          # 33..256 queries over 768-column codes: k_scan_qs
     assert np.array_equal(r40, rows[:40]) and np.array_equal(d40.view(np.uint32), dists[:40].view(np.uint32))
+    for nqs, want in ((40, 0x14), (100, 0x24)):                                         # LYNSE_HIP_QS_MID=0: the mid tilings of k_scan_h16
+        os.environ["LYNSE_HIP_QS_MID"] = "0"
+        try:
+            rm, dm, cm = idx.search_batch_arrays(queries[:nqs], k, "ip")
+            pm = idx.profile_get(reset=True)
+        finally:
+            del os.environ["LYNSE_HIP_QS_MID"]
+        assert plan_fields(pm)[2] == want and pm["fallback_queries"] == 0, (nqs, pm)
+        assert np.array_equal(rm, rows[:nqs]) and np.array_equal(dm.view(np.uint32), dists[:nqs].view(np.uint32))
     r8, d8, c8 = idx.search_batch_arrays(queries[:8], k, "ip")
     p8 = idx.profile_get(reset=True)
     assert plan_fields(p8)[0] & PLAN_SMALL and plan_fields(p8)[2] == 0x14
@@ -150,8 +161,10 @@ def test_l2_768_batch256_runs_the_certified_int8_pass(L, oracle):
         del os.environ["LYNSE_HIP_QS"]
     assert plan_fields(p0)[2] == 0x42 and plan_fields(p0)[0] & PLAN_I8C and p0["fallback_queries"] == 0, p0
     assert np.array_equal(r0, rows) and np.array_equal(d0.view(np.uint32), dists.view(np.uint32)) and np.array_equal(c0, counts)
-    # 100 queries: the 256 x 128 tiling of the plain-code form (and, with the mid tilings off, the 256-query one); 48 queries: 128 x 64
-    for nqs, env, want in ((100, {}, 0x24), (100, {"LYNSE_HIP_MID_TILINGS": "0"}, 0x81), (100, {"LYNSE_HIP_MID_TILINGS": "0", "LYNSE_HIP_QS": "0"}, 0x42), (48, {}, 0x14)):
+    # 100 and 48 queries: the query-stationary tiling too (waves without queries skip their MFMAs; round 4); LYNSE_HIP_QS_MID=0: the 256 x 128 /
+    # 128 x 64 tilings of the plain-code form, and with the mid tilings off as well the 256-query tilings
+    for nqs, env, want in ((100, {}, 0x81), (100, {"LYNSE_HIP_QS_MID": "0"}, 0x24), (100, {"LYNSE_HIP_QS_MID": "0", "LYNSE_HIP_MID_TILINGS": "0"}, 0x81),
+                           (100, {"LYNSE_HIP_MID_TILINGS": "0", "LYNSE_HIP_QS": "0"}, 0x42), (48, {}, 0x81), (48, {"LYNSE_HIP_QS_MID": "0"}, 0x14)):
         os.environ.update(env)
         try:
             rs, ds, cs = idx.search_batch_arrays(queries[:nqs], k, "l2")
