@@ -3226,19 +3226,25 @@ __device__ __forceinline__ void rescore_keys(uint64_t* keys, uint32_t n, int met
                                              const float* qv, const float* V, uint32_t ld, uint32_t D,
                                              bool asc, int tid, bool neg = false, char* scr = nullptr, uint32_t scr_bytes = 0) {
     {
-        constexpr uint32_t MAXV = 8;                       // 16-B loads per thread and batch: 21 rows of 768 floats in ONE global round trip
-        const uint32_t vpr = D / 4u, stride = D + 8u;
-        const bool shape = scr && n && ip_form != LYNSE_IPFORM_F16SEQ && (D & 3u) == 0 && (ld & 3u) == 0 && (reinterpret_cast<uintptr_t>(V) & 15u) == 0 &&
-                           vpr <= MAXV * (uint32_t)NT / 8u && scr_bytes >= (D + 8u * stride) * 4u;   // (at least 8 rows per batch and per chunk, or the direct loads win)
+        constexpr uint32_t MAXV = 8;                       // 16-B loads per thread and batch: 21 rows of 768 floats (42 of 768 halves) in ONE global round trip
+        // F16 shards (LYNSE_IPFORM_F16SEQ: V addresses f16 bits, ld counts floats = two halves): the rows are staged as halves and
+        // exact_score_f16seq reads them from LDS — straight from global memory its 64-element steps are one dependent round trip each
+        // (12 per 768-d row: the selects of an F16 shard took 72 / 130 us against 23 / 35 on an f32 shard)
+        const bool f16 = ip_form == LYNSE_IPFORM_F16SEQ;
+        const uint32_t row_b = D * (f16 ? 2u : 4u);        // bytes of a row
+        const uint32_t vpr = row_b / 16u, stride_b = row_b + 32u;   // 16-B pieces per row; LDS row stride (the eight lane groups of a wave on different banks)
+        const bool shape = scr && n && (D & (f16 ? 7u : 3u)) == 0 && (ld & 3u) == 0 && (reinterpret_cast<uintptr_t>(V) & 15u) == 0 &&
+                           vpr <= MAXV * (uint32_t)NT / 8u && scr_bytes >= D * 4u + 8u * stride_b;   // (at least 8 rows per batch and per chunk, or the direct loads win)
         if (shape) {   // (uniform over the workgroup)
             float* q_l = reinterpret_cast<float*>(scr);
-            float* rows_l = q_l + D;
-            uint32_t R = (scr_bytes / 4u - D) / stride;                      // rows per LDS chunk
+            char* rows_l = scr + (size_t)D * 4u;
+            uint32_t R = (scr_bytes - D * 4u) / stride_b;                    // rows per LDS chunk
             R = R < (uint32_t)(NT / 8) ? R : (uint32_t)(NT / 8);
             uint32_t F = MAXV * (uint32_t)NT / vpr;                          // rows per batch of loads (held in registers until their chunk's turn)
             F = F < (uint32_t)(NT / 8) ? F : (uint32_t)(NT / 8);
             const int g = tid & 7;
             const uint32_t grp = tid >> 3;
+            const char* Vb = reinterpret_cast<const char*>(V);
             for (uint32_t i = tid; i < D; i += NT) q_l[i] = qv[i];
             for (uint32_t f0 = 0; f0 < n; f0 += F) {
                 const uint32_t fn = n - f0 < F ? n - f0 : F;
@@ -3252,7 +3258,7 @@ __device__ __forceinline__ void rescore_keys(uint64_t* keys, uint32_t n, int met
                     if (t < fn * vpr) {
                         const uint32_t r = t / vpr, c = t - r * vpr;
                         prow4[u / 4] = (prow4[u / 4] & ~(0xffu << (8 * (u % 4)))) | (r << (8 * (u % 4)));
-                        pre[u] = *reinterpret_cast<const f32x4*>(V + (size_t)key_row(keys[f0 + r]) * ld + c * 4u);
+                        pre[u] = *reinterpret_cast<const f32x4*>(Vb + (size_t)key_row(keys[f0 + r]) * ld * 4u + c * 16u);
                     }
                 }
                 for (uint32_t c0 = 0; c0 < fn; c0 += R) {
@@ -3263,13 +3269,13 @@ __device__ __forceinline__ void rescore_keys(uint64_t* keys, uint32_t n, int met
                         const uint32_t r = (prow4[u / 4] >> (8 * (u % 4))) & 0xffu;
                         if (r >= c0 && r < c0 + rn) {   // (0xff never passes: c0 + rn <= fn <= NT / 8)
                             const uint32_t t = (uint32_t)tid + u * NT;
-                            *reinterpret_cast<f32x4*>(rows_l + (size_t)(r - c0) * stride + (t - r * vpr) * 4u) = pre[u];
+                            *reinterpret_cast<f32x4*>(rows_l + (size_t)(r - c0) * stride_b + (t - r * vpr) * 16u) = pre[u];
                         }
                     }
                     __syncthreads();
                     if (grp < rn) {
                         const uint32_t row = key_row(keys[f0 + c0 + grp]);
-                        float sc = exact_score<32>(metric, ip_form, q_l, rows_l + (size_t)grp * stride, D, g);
+                        float sc = exact_score<16>(metric, ip_form, q_l, reinterpret_cast<const float*>(rows_l + (size_t)grp * stride_b), D, g);   // (LDS reads: 16 steps in flight are plenty)
                         if (neg) sc = -sc;
                         if (g == 0) keys[f0 + c0 + grp] = make_key(sc, row, asc);
                     }
@@ -4024,10 +4030,15 @@ __device__ __forceinline__ void final_body(const FinalArgs& a, uint64_t* keys, c
     for (uint32_t i = tid; i < np2; i += NT)
         keys[i] = i < n ? (same_launch ? __hip_atomic_load(&src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : src[i]) : KEY_SENTINEL;
     __syncthreads();
-    // (the survivors of a batch — a few dozen rows — are scored straight from global memory: staged through LDS in chunks they cost one
-    // global round trip per chunk, measured 14 us against 12 us for 53 rows of 768 floats)
-    if (!exact)
-        rescore_keys<NT>(keys, n, a.neg_metric1 ? a.neg_metric1 - 1 : a.metric, a.ip_form, a.Qf + (size_t)q * a.D, a.V, a.ld, a.D, asc, tid, a.neg_metric1 != 0);
+    // (the survivors of a batch — a few dozen rows — are scored straight from global memory on f32 shards: staged through LDS in chunks
+    // they cost one global round trip per chunk, measured 14 us against 12 us for 53 rows of 768 floats.  F16 shards stage them: half the
+    // bytes per row, and the f16 kernels' sequential sums are a dependent round trip per 64 elements otherwise)
+    if (!exact) {
+        const bool f16 = a.ip_form == LYNSE_IPFORM_F16SEQ;
+        const uint32_t used = (np2 > 512u ? np2 : 512u) * 8u, lds_all = a.lds_bytes ? a.lds_bytes : a.cap * 8u;   // (the rank sort below writes keys[256 .. 512))
+        rescore_keys<NT>(keys, n, a.neg_metric1 ? a.neg_metric1 - 1 : a.metric, a.ip_form, a.Qf + (size_t)q * a.D, a.V, a.ld, a.D, asc, tid, a.neg_metric1 != 0,
+                         f16 ? reinterpret_cast<char*>(keys) + used : nullptr, (f16 && lds_all > used) ? lds_all - used : 0u);
+    }
     if (a.orig_ids) {  // canonical order is (distance, ORIGINAL row): swap the row word before the final sort
         for (uint32_t i = tid; i < n; i += NT) keys[i] = (keys[i] & 0xffffffff00000000ull) | a.orig_ids[key_row(keys[i])];
         __syncthreads();
