@@ -1411,6 +1411,16 @@ static uint32_t qs_rows(int v) { return v == 2 ? 32u : 64u; }   // rows per tile
 // threshold the selects of the staged plan compute (tau_x - E instead of tau - 2E) the band of rows that must be kept is ~5x wider:
 // ~4800 keys per query are emitted (10,000 for the unluckiest query; the cap is 16,384 — 6 of 256 queries of the C2 test overflowed
 // and went down the ladder), 15-20 % of all tile epilogues take the slow path.
+// Row widths the query-stationary tiling is instantiated for: whole 128-column slabs, 2..6 of them (256 / 384 / 512 / 640 / 768 columns of
+// codes: the B operand of a wave is NSLAB x 16 registers).  The masked (MSK) and plain-L2 (MET) forms and the A/B variants exist for 768
+// columns only.  LYNSE_HIP_QS_WIDTHS=0: 768 columns only (A/B; read per call).
+static bool qs_width_ok(uint32_t ld, uint32_t nslab, bool only768 = false) {
+    if (ld == 768 && nslab == 6) return true;
+    if (only768 || qs_variant() != 1) return false;
+    const char* e = getenv("LYNSE_HIP_QS_WIDTHS");
+    if (e && atoi(e) == 0) return false;
+    return nslab >= 2 && nslab <= 5 && ld == nslab * 128u;
+}
 static bool sts_env_on() { const char* e = getenv("LYNSE_HIP_STS"); return e && atoi(e) != 0; }
 static bool qs_scan_ok(const ScanArgs& a, bool fs, bool filt, bool f4) {
     const int v = qs_variant();
@@ -1421,7 +1431,7 @@ static bool qs_scan_ok(const ScanArgs& a, bool fs, bool filt, bool f4) {
         const char* e = getenv("LYNSE_HIP_QS_MASKED");
         if ((e && atoi(e) == 0) || v == 2 || !a.mask || a.row_ids) return false;
     }
-    return !fs && !f4 && a.emit_all == 0 && a.ld16 == 768 && a.nslab == 6 && a.qpad == 256 && a.nq <= 256 && a.tile_stride == 0 &&
+    return !fs && !f4 && a.emit_all == 0 && qs_width_ok(a.ld16, a.nslab, filt) && a.qpad == 256 && a.nq <= 256 && a.tile_stride == 0 &&
            (filt || (a.skip_stride == 0 && !a.mask)) && !a.row_ids && a.row1 > a.row0;
 }
 // LYNSE_HIP_SCAN_CUS: workgroups (= CUs: one 144-KB workgroup per CU) of the persistent threshold-stage scans.  The scan is bound by the
@@ -1450,6 +1460,20 @@ static int launch_scan_qs(const ScanArgs& a, uint32_t grid, hipStream_t st) {
         return LYNSE_OK;
     };
     if (a.mask) return go(k_scan_qs<6, 2, 6, 3, false, 8, 0, 1, 0, 0, 0, 1>, 0, (size_t)3 * 6 * 64 * 128);   // masked threshold stages (MSK)
+    static bool attr_w[8] = {false};
+    auto gow = [&](auto kern, int slot, size_t lds) -> int {
+        if (!attr_w[slot]) { LY_TRY(set_max_lds(kern, lds)); attr_w[slot] = true; }
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, a);
+        LY_HIP(hipGetLastError());
+        return LYNSE_OK;
+    };
+    switch (a.nslab) {   // the narrower code rows (qs_width_ok)
+    case 2: return gow(k_scan_qs<2, 2, 2, 3, false, 8, 0, 1>, 2, (size_t)3 * 2 * 64 * 128);
+    case 3: return gow(k_scan_qs<3, 2, 3, 3, false, 8, 0, 1>, 3, (size_t)3 * 3 * 64 * 128);
+    case 4: return gow(k_scan_qs<4, 2, 4, 3, false, 8, 0, 1>, 4, (size_t)3 * 4 * 64 * 128);
+    case 5: return gow(k_scan_qs<5, 2, 5, 3, false, 8, 0, 1>, 5, (size_t)3 * 5 * 64 * 128);
+    default: break;
+    }
     switch (qs_variant()) {
     case 2: return go(k_scan_qs<6, 1, 6, 6, true, 8, 0, 0>, 2, (size_t)6 * 6 * 32 * 128);
     case 3: return go(k_scan_qs<6, 2, 6, 3, false, 8, 0, 0>, 3, (size_t)3 * 6 * 64 * 128);
@@ -1463,17 +1487,24 @@ static bool qs_sample_ok(const ScanArgs& a, bool fs, bool filt, bool f4, uint32_
     const char* e = getenv("LYNSE_HIP_QS_SAMPLE");
     const int v = qs_variant();
     if ((e && atoi(e) == 0) || (v != 1 && v != 3)) return false;
-    return !fs && !filt && !f4 && a.emit_all == 2 && plan_tile == 256 && a.ld16 == 768 && a.nslab == 6 && a.qpad == 256 && a.nq <= 256 && a.tile_stride >= 256 &&
+    return !fs && !filt && !f4 && a.emit_all == 2 && plan_tile == 256 && qs_width_ok(a.ld16, a.nslab) && a.qpad == 256 && a.nq <= 256 && a.tile_stride >= 256 &&
            a.skip_stride == 0 && !a.mask && !a.row_ids && a.row1 > a.row0;
 }
 static int launch_scan_qs_sample(const ScanArgs& a, uint32_t grid, hipStream_t st) {
-    static bool attr_done = false;
-    auto kern = k_scan_qs<6, 2, 6, 3, false, 8, 0, 0, 0, 0, 1>;
-    constexpr size_t lds = (size_t)3 * 6 * 64 * 128;
-    if (!attr_done) { LY_TRY(set_max_lds(kern, lds)); attr_done = true; }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, a);
-    LY_HIP(hipGetLastError());
-    return LYNSE_OK;
+    static bool attr_done[8] = {false};
+    auto go = [&](auto kern, int slot, size_t lds) -> int {
+        if (!attr_done[slot]) { LY_TRY(set_max_lds(kern, lds)); attr_done[slot] = true; }
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, a);
+        LY_HIP(hipGetLastError());
+        return LYNSE_OK;
+    };
+    switch (a.nslab) {
+    case 2: return go(k_scan_qs<2, 2, 2, 3, false, 8, 0, 0, 0, 0, 1>, 2, (size_t)3 * 2 * 64 * 128);
+    case 3: return go(k_scan_qs<3, 2, 3, 3, false, 8, 0, 0, 0, 0, 1>, 3, (size_t)3 * 3 * 64 * 128);
+    case 4: return go(k_scan_qs<4, 2, 4, 3, false, 8, 0, 0, 0, 0, 1>, 4, (size_t)3 * 4 * 64 * 128);
+    case 5: return go(k_scan_qs<5, 2, 5, 3, false, 8, 0, 0, 0, 0, 1>, 5, (size_t)3 * 5 * 64 * 128);
+    default: return go(k_scan_qs<6, 2, 6, 3, false, 8, 0, 0, 0, 0, 1>, 6, (size_t)3 * 6 * 64 * 128);
+    }
 }
 
 static int launch_scan_i8c(const ScanArgs& a, uint32_t grid, hipStream_t st, bool fs = false, bool filt = false, bool f4 = false, bool qs = false) {
@@ -1735,7 +1766,8 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
     // 40 / 64 / 100 / 128 queries 1.28 / 1.32 / 1.48 / 1.49 -> 1.22 / 1.25 / 1.29 / 1.31 ms; L2 1.39 / 1.43 / 1.81 / 1.89 -> 1.34 / 1.38 / 1.57 /
     // 1.62).  LYNSE_HIP_QS_MID=0: the mid tilings (A/B, tests; read per call)
     const bool qs_mid = []() { const char* e = getenv("LYNSE_HIP_QS_MID"); return !e || atoi(e) != 0; }() && qs_variant() >= 1 && qs_variant() <= 3 && i8c && !bin_mfma &&
-                        !small && !row_ids && h16 && !aug && h->ld8 == 768 && nq <= 256 &&
+                        !small && !row_ids && h16 && !aug && qs_width_ok(h->ld8, (h->dim + 127) / 128, l2n || mask != nullptr) && nq <= 256 &&
+                        (h->ld8 == 768 || nq > 64) &&   // (narrower rows: the 128 x 64 tiling keeps 33..64 queries — 6M x 256, 40 queries: 0.34 ms against 0.37)
                         (!mask || (!l2n && qs_variant() != 2 && []() { const char* e = getenv("LYNSE_HIP_QS_MASKED"); return !e || atoi(e) != 0; }()));
     const bool mid_ok = mid_env && !qs_mid && i8c && !bin_mfma && !small && !row_ids && h16 && (!mask || (aug ? h->ld8a : h->ld8) % 128 == 0);
     const bool mid64 = mid_ok && nq <= 64, mid128 = mid_ok && !mid64 && nq <= 128;

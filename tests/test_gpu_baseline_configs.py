@@ -273,3 +273,39 @@ def test_c5_hamming_10m_1024bit_k50(L, oracle, nq):
         for name, metric in (("tanimoto", O.JACCARD), ("dice", O.DICE)):
             r, d, c = idx.search_packed_arrays(qw, k, name)
             assert_rows_equal(oracle.canonical_topk_packed(qw[0], words, k, metric), r[0], d[0], c[0], ("c5", name))
+
+
+@pytest.mark.parametrize("dim,metric", [(256, "ip"), (384, "cosine"), (512, "ip"), (640, "ip"), (500, "ip")])
+def test_query_stationary_tiling_on_narrower_code_rows(L, oracle, dim, metric):
+    """k_scan_qs<NSLAB, ...> for 2..5 slabs of 128 code columns (round 4): batches of 65..256 queries take it (tiling 0x81) with the
+    sample stage on the same tiling; 33..64 queries keep the 128 x 64 tiling; LYNSE_HIP_QS_WIDTHS=0 is the round-3 path — identical bits,
+    and the oracle's answers.  (500 dimensions: codes padded to 512 columns.)"""
+    import os
+
+    rng = np.random.default_rng(600 + dim)
+    n, k = 400_000, 10
+    data = rng.random((n, dim), dtype=f32) if metric == "ip" else rng.standard_normal((n, dim)).astype(f32)
+    queries = (data[rng.integers(0, n, 256)] + 0.03 * rng.standard_normal((256, dim))).astype(f32)
+    idx = L.FlatIndex(None, dim)
+    idx.write(data)
+    idx.finalize()
+    idx.profile_enable(True)
+    m = {"ip": O.IP, "cosine": O.COS}[metric]
+    for nq, want in ((256, 0x81), (100, 0x81), (48, 0x14)):
+        idx.profile_get(reset=True)
+        rows, dists, counts = idx.search_batch_arrays(queries[:nq], k, metric)
+        p = idx.profile_get(reset=True)
+        flags, stages, tiling = plan_fields(p)
+        assert tiling == want and flags & PLAN_I8C and p["fallback_queries"] == 0, (nq, hex(tiling), p)
+        assert bool(int(p["last_plan"]) & PLAN_QS_SAMPLE) == (want == 0x81), hex(int(p["last_plan"]))
+        os.environ["LYNSE_HIP_QS_WIDTHS"] = "0"
+        try:
+            r0, d0, c0 = idx.search_batch_arrays(queries[:nq], k, metric)
+            p0 = idx.profile_get(reset=True)
+        finally:
+            del os.environ["LYNSE_HIP_QS_WIDTHS"]
+        assert plan_fields(p0)[2] != 0x81 and p0["fallback_queries"] == 0, p0
+        assert np.array_equal(r0, rows) and np.array_equal(d0.view(np.uint32), dists.view(np.uint32)) and np.array_equal(c0, counts)
+        for qi in sorted({0, nq // 2, nq - 1}):
+            e_ids, e_d = oracle.canonical_topk(queries[qi], data, k, m)
+            assert np.array_equal(rows[qi].astype(np.uint32), e_ids) and np.array_equal(dists[qi].view(np.uint32), e_d.view(np.uint32)), (nq, qi)
