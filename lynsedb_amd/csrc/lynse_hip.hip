@@ -1419,7 +1419,7 @@ static bool qs_width_ok(uint32_t ld, uint32_t nslab, bool only768 = false) {
     if (only768 || qs_variant() != 1) return false;
     const char* e = getenv("LYNSE_HIP_QS_WIDTHS");
     if (e && atoi(e) == 0) return false;
-    return nslab >= 2 && nslab <= 5 && ld == nslab * 128u;
+    return ((nslab >= 2 && nslab <= 5) || nslab == 8) && ld == nslab * 128u;   // (8 slabs = 1024 columns: 32-row tiles, B = 128 registers)
 }
 static bool sts_env_on() { const char* e = getenv("LYNSE_HIP_STS"); return e && atoi(e) != 0; }
 static bool qs_scan_ok(const ScanArgs& a, bool fs, bool filt, bool f4) {
@@ -1438,7 +1438,7 @@ static bool qs_scan_ok(const ScanArgs& a, bool fs, bool filt, bool f4) {
 // power the chip may draw, not by its CU count: a few CUs left free cost it little and let the short latency-bound kernels of ANOTHER
 // batch in flight (query image, sample stage, selects, final rescoring) run beside it instead of between its launches.
 static uint32_t qs_grid(const ScanArgs& a, uint32_t num_cu) {
-    const uint32_t rt = qs_rows(qs_variant());
+    const uint32_t rt = a.nslab == 8 ? 32u : qs_rows(qs_variant());   // (1024 columns: 32-row tiles)
     const char* e = getenv("LYNSE_HIP_SCAN_CUS");
     const uint32_t cus = e && atoi(e) > 0 ? std::min<uint32_t>((uint32_t)atoi(e), num_cu) : num_cu;
     return std::min<uint32_t>((a.row1 - a.row0 + rt - 1) / rt, cus);
@@ -1472,6 +1472,7 @@ static int launch_scan_qs(const ScanArgs& a, uint32_t grid, hipStream_t st) {
     case 3: return gow(k_scan_qs<3, 2, 3, 3, false, 8, 0, 1>, 3, (size_t)3 * 3 * 64 * 128);
     case 4: return gow(k_scan_qs<4, 2, 4, 3, false, 8, 0, 1>, 4, (size_t)3 * 4 * 64 * 128);
     case 5: return gow(k_scan_qs<5, 2, 5, 3, false, 8, 0, 1>, 5, (size_t)3 * 5 * 64 * 128);
+    case 8: return gow(k_scan_qs<8, 1, 8, 4, false, 8, 0, 1>, 7, (size_t)4 * 8 * 32 * 128);
     default: break;
     }
     switch (qs_variant()) {
@@ -1487,7 +1488,7 @@ static bool qs_sample_ok(const ScanArgs& a, bool fs, bool filt, bool f4, uint32_
     const char* e = getenv("LYNSE_HIP_QS_SAMPLE");
     const int v = qs_variant();
     if ((e && atoi(e) == 0) || (v != 1 && v != 3)) return false;
-    return !fs && !filt && !f4 && a.emit_all == 2 && plan_tile == 256 && qs_width_ok(a.ld16, a.nslab) && a.qpad == 256 && a.nq <= 256 && a.tile_stride >= 256 &&
+    return !fs && !filt && !f4 && a.emit_all == 2 && plan_tile == 256 && a.nslab != 8 && qs_width_ok(a.ld16, a.nslab) && a.qpad == 256 && a.nq <= 256 && a.tile_stride >= 256 &&
            a.skip_stride == 0 && !a.mask && !a.row_ids && a.row1 > a.row0;
 }
 static int launch_scan_qs_sample(const ScanArgs& a, uint32_t grid, hipStream_t st) {

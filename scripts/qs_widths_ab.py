@@ -8,7 +8,7 @@ sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 import lynsedb_amd as L  # noqa: E402
 dev = torch.device("cuda", 0)
 n = int(os.environ.get("ROWS", 6_000_000))
-for dim in (256, 384, 512, 640):
+for dim in [int(x) for x in os.environ.get("DIMS", "256,384,512,640").split(",")]:
     idx = L.FlatIndex(None, dim, 0); idx.reserve(n)
     g = torch.Generator(device=dev); g.manual_seed(dim)
     for b in range(0, n, 500_000):
