@@ -1319,16 +1319,29 @@ static uint32_t qs_l2_rows(const ScanArgs& a) {
     if (e && atoi(e) == 0) return 0;
     if (a.emit_all != 0 || a.qpad != 256 || a.nq > 256 || a.tile_stride != 0 || a.skip_stride != 0 || a.mask || a.row_ids || a.row1 <= a.row0) return 0;
     if (a.ld16 == 768 && a.nslab == 6) return 64;
+    // 256 / 384 / 512 / 640 columns (LYNSE_HIP_QS_WIDTHS=0 or an A/B variant of LYNSE_HIP_QS: 768 only)
+    const char* w = getenv("LYNSE_HIP_QS_WIDTHS");
+    if ((w && atoi(w) == 0) || (e && atoi(e) != 1)) return 0;
+    // (6M rows, 256 queries: 256 / 384 columns 0.772 / 0.916 ms on the <4,2,2,4> tiling against 0.773 / 0.929 here — the float epilogue weighs more the
+    // fewer MFMAs a tile has; 512 / 640 columns 1.125 / 1.347 -> 1.106 / 1.307; 100 queries: 0.65 / 0.80 / 0.94 / 1.11 -> 0.61 / 0.72 / 0.83 / 0.94)
+    if (a.nslab >= 2 && a.nslab <= 5 && a.ld16 == a.nslab * 128u && (a.nslab >= 4 || a.nq <= 128)) return 64;
     return 0;
 }
 static int launch_scan_qs_l2(const ScanArgs& a, uint32_t grid, hipStream_t st) {
-    static bool attr_done = false;
-    auto kern = k_scan_qs<6, 2, 6, 3, false, 8, 0, 1, 0, 1>;
-    constexpr size_t lds = (size_t)3 * 6 * 64 * 128 + 4 * 256;
-    if (!attr_done) { LY_TRY(set_max_lds(kern, lds)); attr_done = true; }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, a);
-    LY_HIP(hipGetLastError());
-    return LYNSE_OK;
+    static bool attr_done[8] = {false};
+    auto go = [&](auto kern, int slot, size_t lds) -> int {
+        if (!attr_done[slot]) { LY_TRY(set_max_lds(kern, lds)); attr_done[slot] = true; }
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, a);
+        LY_HIP(hipGetLastError());
+        return LYNSE_OK;
+    };
+    switch (a.nslab) {
+    case 2: return go(k_scan_qs<2, 2, 2, 3, false, 8, 0, 1, 0, 1>, 2, (size_t)3 * 2 * 64 * 128 + 4 * 256);
+    case 3: return go(k_scan_qs<3, 2, 3, 3, false, 8, 0, 1, 0, 1>, 3, (size_t)3 * 3 * 64 * 128 + 4 * 256);
+    case 4: return go(k_scan_qs<4, 2, 4, 3, false, 8, 0, 1, 0, 1>, 4, (size_t)3 * 4 * 64 * 128 + 4 * 256);
+    case 5: return go(k_scan_qs<5, 2, 5, 3, false, 8, 0, 1, 0, 1>, 5, (size_t)3 * 5 * 64 * 128 + 4 * 256);
+    default: return go(k_scan_qs<6, 2, 6, 3, false, 8, 0, 1, 0, 1>, 6, (size_t)3 * 6 * 64 * 128 + 4 * 256);
+    }
 }
 
 // squared L2 on the plain SQ8 codes (kernels.h, I8Q = 4): the <4,2,2,4> L2 tiling with 2 + 2-stage rings and the norm ring, int8
@@ -1767,7 +1780,7 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
     // 40 / 64 / 100 / 128 queries 1.28 / 1.32 / 1.48 / 1.49 -> 1.22 / 1.25 / 1.29 / 1.31 ms; L2 1.39 / 1.43 / 1.81 / 1.89 -> 1.34 / 1.38 / 1.57 /
     // 1.62).  LYNSE_HIP_QS_MID=0: the mid tilings (A/B, tests; read per call)
     const bool qs_mid = []() { const char* e = getenv("LYNSE_HIP_QS_MID"); return !e || atoi(e) != 0; }() && qs_variant() >= 1 && qs_variant() <= 3 && i8c && !bin_mfma &&
-                        !small && !row_ids && h16 && !aug && qs_width_ok(h->ld8, (h->dim + 127) / 128, l2n || mask != nullptr) && nq <= 256 &&
+                        !small && !row_ids && h16 && !aug && qs_width_ok(h->ld8, (h->dim + 127) / 128, mask != nullptr) && !(l2n && (h->dim + 127) / 128 == 8) && nq <= 256 &&   // (plain-L2: not on the 32-row tiles of 1024 columns)
                         (h->ld8 == 768 || nq > 64) &&   // (narrower rows: the 128 x 64 tiling keeps 33..64 queries — 6M x 256, 40 queries: 0.34 ms against 0.37)
                         (!mask || (!l2n && qs_variant() != 2 && []() { const char* e = getenv("LYNSE_HIP_QS_MASKED"); return !e || atoi(e) != 0; }()));
     const bool mid_ok = mid_env && !qs_mid && i8c && !bin_mfma && !small && !row_ids && h16 && (!mask || (aug ? h->ld8a : h->ld8) % 128 == 0);

@@ -15,7 +15,7 @@ for dim in [int(x) for x in os.environ.get("DIMS", "256,384,512,640").split(",")
         idx.write_device(torch.rand((min(500_000, n - b), dim), generator=g, device=dev))
     idx.finalize()
     q_all = torch.rand((256, dim), generator=g, device=dev)
-    for metric in ("ip", "cosine"):
+    for metric in os.environ.get("METRICS", "ip,cosine").split(","):
         for nq in (256, 100, 40):
             dq = q_all[:nq].contiguous()
             res = {}

@@ -309,3 +309,36 @@ def test_query_stationary_tiling_on_narrower_code_rows(L, oracle, dim, metric):
         for qi in sorted({0, nq // 2, nq - 1}):
             e_ids, e_d = oracle.canonical_topk(queries[qi], data, k, m)
             assert np.array_equal(rows[qi].astype(np.uint32), e_ids) and np.array_equal(dists[qi].view(np.uint32), e_d.view(np.uint32)), (nq, qi)
+
+
+@pytest.mark.parametrize("dim", [256, 512, 640])
+def test_plain_l2_on_the_query_stationary_tiling_at_other_widths(L, oracle, dim):
+    """k_scan_qs<NSLAB, .., MET = 1> for 2..5 slabs: 65..128 queries at every width, 129..256 queries from 512 columns on (below, the <4,2,2,4>
+    tiling is as fast).  Oracle parity and identical bits with LYNSE_HIP_QS_WIDTHS=0."""
+    import os
+
+    rng = np.random.default_rng(700 + dim)
+    n, k = 400_000, 10
+    data = rng.standard_normal((n, dim)).astype(f32)
+    queries = (data[rng.integers(0, n, 256)] + 0.05 * rng.standard_normal((256, dim))).astype(f32)
+    idx = L.FlatIndex(None, dim)
+    idx.write(data)
+    idx.finalize()
+    idx.profile_enable(True)
+    for nq in (256, 100):
+        idx.profile_get(reset=True)
+        rows, dists, counts = idx.search_batch_arrays(queries[:nq], k, "l2")
+        p = idx.profile_get(reset=True)
+        flags, stages, tiling = plan_fields(p)
+        assert tiling == (0x81 if (nq == 100 or dim >= 512) else 0x42) and flags & PLAN_I8C and p["fallback_queries"] == 0, (nq, hex(tiling), p)
+        os.environ["LYNSE_HIP_QS_WIDTHS"] = "0"
+        try:
+            r0, d0, c0 = idx.search_batch_arrays(queries[:nq], k, "l2")
+            p0 = idx.profile_get(reset=True)
+        finally:
+            del os.environ["LYNSE_HIP_QS_WIDTHS"]
+        assert plan_fields(p0)[2] != 0x81 and p0["fallback_queries"] == 0, p0
+        assert np.array_equal(r0, rows) and np.array_equal(d0.view(np.uint32), dists.view(np.uint32)) and np.array_equal(c0, counts)
+        for qi in sorted({0, nq // 2, nq - 1}):
+            e_ids, e_d = oracle.canonical_topk(queries[qi], data, k, O.L2)
+            assert np.array_equal(rows[qi].astype(np.uint32), e_ids) and np.array_equal(dists[qi].view(np.uint32), e_d.view(np.uint32)), (nq, qi)
