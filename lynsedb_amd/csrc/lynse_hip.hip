@@ -1444,7 +1444,14 @@ static bool qs_scan_ok(const ScanArgs& a, bool fs, bool filt, bool f4) {
         const char* e = getenv("LYNSE_HIP_QS_MASKED");
         if ((e && atoi(e) == 0) || v == 2 || !a.mask || a.row_ids) return false;
     }
-    return !fs && !f4 && a.emit_all == 0 && qs_width_ok(a.ld16, a.nslab, filt) && a.qpad == 256 && a.nq <= 256 && a.tile_stride == 0 &&
+    // f4: batched Hamming on the FP4 MFMA (k_scan_qs<.., F4>): 1024-bit fingerprints = 512 B of nibbles = 4 slabs; its plans carry an emit-all
+    // sample whose tiles the kernel skips (a.skip_stride).  LYNSE_HIP_QS_F4=0: the 256 x 256 tile of k_scan_h16<.., I8Q = 3> (A/B; read per call)
+    if (f4) {
+        const char* e = getenv("LYNSE_HIP_QS_F4");
+        return !(e && atoi(e) == 0) && v == 1 && !fs && !filt && a.emit_all == 0 && a.ld16 == 512 && a.nslab == 4 && a.qpad == 256 && a.nq <= 256 &&
+               a.tile_stride == 0 && !a.mask && !a.row_ids && a.row1 > a.row0;
+    }
+    return !fs && a.emit_all == 0 && qs_width_ok(a.ld16, a.nslab, filt) && a.qpad == 256 && a.nq <= 256 && a.tile_stride == 0 &&
            (filt || (a.skip_stride == 0 && !a.mask)) && !a.row_ids && a.row1 > a.row0;
 }
 // LYNSE_HIP_SCAN_CUS: workgroups (= CUs: one 144-KB workgroup per CU) of the persistent threshold-stage scans.  The scan is bound by the
@@ -1523,6 +1530,15 @@ static int launch_scan_qs_sample(const ScanArgs& a, uint32_t grid, hipStream_t s
 
 static int launch_scan_i8c(const ScanArgs& a, uint32_t grid, hipStream_t st, bool fs = false, bool filt = false, bool f4 = false, bool qs = false) {
     constexpr size_t lds = (size_t)(3 * 256 + 2 * 256) * 128;
+    if (qs && f4) {   // batched Hamming on the query-stationary tiling (scan_qs.h, F4)
+        static bool attr_f4 = false;
+        auto kern = k_scan_qs<4, 2, 4, 3, false, 8, 0, 1, 0, 0, 0, 0, 1>;
+        constexpr size_t qlds = (size_t)3 * 4 * 64 * 128;
+        if (!attr_f4) { LY_TRY(set_max_lds(kern, qlds)); attr_f4 = true; }
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), qlds, st, a);
+        LY_HIP(hipGetLastError());
+        return LYNSE_OK;
+    }
     if (qs) return launch_scan_qs(a, grid, st);
     static bool attr_done[16] = {false};
     auto go = [&](auto kern, int slot) -> int {
@@ -2134,7 +2150,7 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
         hipLaunchKernelGGL(k_select<SEL_NT>, dim3(nq), dim3(SEL_NT), sa.lds_bytes, st, sa);
         LY_HIP(hipGetLastError());
     }
-    if (tl_prof && !binary) {
+    if (tl_prof && (!binary || bin_mfma)) {   // (batched Hamming on the matrix pipe runs the float pipeline's plans)
         const uint64_t tiling = plan_used_qs ? 0x81u : (small || mid64) ? 0x14u : ((mid128 || waves16 == 3 || waves16 == 2) ? 0x24u : 0x42u);   // (0x81: query-stationary threshold stages)
         std::lock_guard<std::mutex> plk(h->prof_mu);
         h->prof.last_plan = (sample.sample_tiles ? 1u : 0u) | ((sample.sample_tiles && sample_threshold_only) ? 2u : 0u) | (i8c ? 4u : 0u) |

@@ -58,7 +58,11 @@ constexpr int QS_STS_LDS = 8 * 256 + 8 * 256;   // landing areas behind the ring
 // emitted only for rows whose bit is set in a.mask, and the 256-row tiles of the emit-all sample stage (tile t at t * a.skip_stride,
 // t < a.skip_tiles: their rows are candidates already) are computed but emit nothing.  Both checks live in the rare slow path / once per
 // tile: the scan itself runs at the speed of the unfiltered one.
-template <int NSLAB, int RB, int SL, int NS, bool XPF, int NBUF, int DBG = 0, int PING = 0, int STS = 0, int MET = 0, int SMP = 0, int MSK = 0>
+// F4 = 1: batched HAMMING as a +-1 GEMM: the operands are FP4 nibbles (+1.0 / -1.0 / 0, exact in E2M1; k_bits_to_fp4 rows, the
+// query image of k_bpm_prep_queries) on v_mfma_scale_f32_32x32x64_f8f6f4 with unit scales.  A 128-B line holds 256 elements = four k-steps
+// of 64, so rings, fragments and the B-register layout are those of the int8 form; the f32 accumulators hold exact integers and are
+// converted where the integer epilogue reads them.  The emit-all sample tiles of the plan (a.skip_stride) are computed but emit nothing.
+template <int NSLAB, int RB, int SL, int NS, bool XPF, int NBUF, int DBG = 0, int PING = 0, int STS = 0, int MET = 0, int SMP = 0, int MSK = 0, int F4 = 0>
 __global__ void __launch_bounds__(512, 2) k_scan_qs(ScanArgs a) {
     static_assert(NSLAB % SL == 0, "a tile is a whole number of steps");
     constexpr int TS = NSLAB / SL;          // steps per tile
@@ -79,6 +83,7 @@ __global__ void __launch_bounds__(512, 2) k_scan_qs(ScanArgs a) {
     static_assert(STS == 0 || (!XPF && TS == 1), "self-tightening thresholds: whole-K stages, no cross-barrier prefetch");
     static_assert(SMP == 0 || (STS == 0 && MET == 0 && RT == 64 && TS == 1), "sample stage: 64-row tiles of the IP / cosine form");
     static_assert(MSK == 0 || (STS == 0 && MET == 0 && SMP == 0), "masked threshold stages: the IP / cosine form");
+    static_assert(F4 == 0 || (STS == 0 && MET == 0 && SMP == 0 && MSK == 0 && DBG == 0), "FP4 Hamming: plain threshold stages");
     constexpr int WAITN = (XPF ? NS - 3 : NS - 2) * PPW;   // DMA instructions that may still be in flight at the barrier
     static_assert(WAITN <= 63, "vmcnt");
 
@@ -260,11 +265,14 @@ __global__ void __launch_bounds__(512, 2) k_scan_qs(ScanArgs a) {
         constexpr int sl = idx / (4 * RB), kk = (idx / RB) % 4, rb = idx % RB;
         asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(ad[kk]), "n"(sl * (RT * 128) + rb * (32 * 128)));
     };
-    qs_i32x16 acc[RB];
+    using acc_t = std::conditional_t<F4 != 0, f32x16, qs_i32x16>;
+    acc_t acc[RB];
 #pragma unroll
     for (int i = 0; i < RB; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0;
+    [[maybe_unused]] int f4_unit = 0x7f7f7f7f;   // E8M0 scale bytes 127 = 2^0 (ly_mfma_fp4: kept opaque in a VGPR across the loop)
+    if constexpr (F4 != 0) asm volatile("" : "+v"(f4_unit));
 
     uint32_t cnt = 0;            // keys in this lane's private segment
     uint32_t c_ord = 0;          // tile ordinal being computed
@@ -305,6 +313,13 @@ __global__ void __launch_bounds__(512, 2) k_scan_qs(ScanArgs a) {
             constexpr int ks = (s * SL + sl) * 4 + kk;
             if constexpr ((DBG & 1) != 0) {
                 asm volatile("" ::"v"(af[idx % NBUF]), "v"(bq[ks]));
+            } else if constexpr (F4 != 0) {
+                if constexpr (ks == 0) {
+                    const f32x16 z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+                    acc[rb] = ly_mfma_fp4(af[idx % NBUF], bq[ks], z, f4_unit);
+                } else {
+                    acc[rb] = ly_mfma_fp4(af[idx % NBUF], bq[ks], acc[rb], f4_unit);
+                }
             } else if constexpr (ks == 0) {   // first k-step of a tile: C = 0 (no accumulator clears)
                 const qs_i32x16 z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
                 acc[rb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[idx % NBUF], bq[ks], z, 0, 0, 0);
@@ -476,14 +491,20 @@ __global__ void __launch_bounds__(512, 2) k_scan_qs(ScanArgs a) {
                 }
             }
         } else {
+            // (F4: the f32 accumulators hold exact integers)
+            int av[RB][16];
+#pragma unroll
+            for (int i = 0; i < RB; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) av[i][r] = (int)acc[i][r];
             // maxima of the groups of four accumulators first (the slow path re-uses them), then their maximum
             int gm[RB][4];
 #pragma unroll
             for (int i = 0; i < RB; ++i)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const int m01 = acc[i][4 * g] > acc[i][4 * g + 1] ? acc[i][4 * g] : acc[i][4 * g + 1];
-                    const int m23 = acc[i][4 * g + 2] > acc[i][4 * g + 3] ? acc[i][4 * g + 2] : acc[i][4 * g + 3];
+                    const int m01 = av[i][4 * g] > av[i][4 * g + 1] ? av[i][4 * g] : av[i][4 * g + 1];
+                    const int m23 = av[i][4 * g + 2] > av[i][4 * g + 3] ? av[i][4 * g + 2] : av[i][4 * g + 3];
                     gm[i][g] = m01 > m23 ? m01 : m23;
                 }
             int mx = gm[0][0];
@@ -498,7 +519,7 @@ __global__ void __launch_bounds__(512, 2) k_scan_qs(ScanArgs a) {
                     if (!emit) return;   // (uniform) a warm-up tile: scanned again at the end of the launch
                 }
                 const uint32_t rbase = a.row0 + e_tile * RT;
-                if constexpr (MSK != 0) {   // (uniform) a tile of the emit-all sample stage: its rows are candidates already
+                if constexpr (MSK != 0 || F4 != 0) {   // (uniform) a tile of the emit-all sample stage: its rows are candidates already
                     if (a.skip_stride && rbase % a.skip_stride < 256u && rbase / a.skip_stride < a.skip_tiles) return;
                 }
                 uint64_t* segdst = a.candB + ((size_t)qn * a.nseg + (blockIdx.x * 2 + hi)) * a.seg;
@@ -511,7 +532,7 @@ __global__ void __launch_bounds__(512, 2) k_scan_qs(ScanArgs a) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             const int r = 4 * g + e;
-                            const int v = acc[i][r];
+                            const int v = av[i][r];
                             if (v >= T) {
                                 const uint32_t m = rbase + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
                                 if (m < a.row1 && (MSK == 0 || ((a.mask[m >> 5] >> (m & 31)) & 1u))) {   // (the mask word is read only for rows that beat the threshold)

@@ -269,6 +269,20 @@ def test_c5_hamming_10m_1024bit_k50(L, oracle, nq):
     for qi in sorted({0, nq // 3, nq // 2, nq - 1}):
         assert_rows_equal(oracle.canonical_topk_packed(qw[qi], words, k, O.HAMMING), rows[qi], dists[qi], counts[qi], ("c5", nq, qi))
     assert np.all(dists == np.round(dists))
+    if nq == 256:   # the +-1 FP4 GEMM on the query-stationary tiling (k_scan_qs<.., F4>, round 4); LYNSE_HIP_QS_F4=0: the 256 x 256 tile — identical bits
+        import os
+
+        assert plan_fields(p)[2] == 0x81, hex(plan_fields(p)[2])
+        for nqs, env in ((256, {"LYNSE_HIP_QS_F4": "0"}), (100, {}), (100, {"LYNSE_HIP_QS_F4": "0"})):
+            os.environ.update(env)
+            try:
+                r0, d0, c0 = idx.search_packed_arrays(qw[:nqs], k, "hamming")
+                p0 = idx.profile_get(reset=True)
+            finally:
+                for name in env:
+                    del os.environ[name]
+            assert (plan_fields(p0)[2] == 0x81) == (not env) and p0["fallback_queries"] == 0, (nqs, env, p0)
+            assert np.array_equal(r0, rows[:nqs]) and np.array_equal(d0, dists[:nqs]) and np.array_equal(c0, counts[:nqs]), (nqs, env)
     if nq == 1:   # Tanimoto / Dice on the same fingerprints (the sparse-fingerprint use of config 5)
         for name, metric in (("tanimoto", O.JACCARD), ("dice", O.DICE)):
             r, d, c = idx.search_packed_arrays(qw, k, name)
