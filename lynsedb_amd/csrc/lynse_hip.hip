@@ -1448,7 +1448,8 @@ static bool qs_scan_ok(const ScanArgs& a, bool fs, bool filt, bool f4) {
     // sample whose tiles the kernel skips (a.skip_stride).  LYNSE_HIP_QS_F4=0: the 256 x 256 tile of k_scan_h16<.., I8Q = 3> (A/B; read per call)
     if (f4) {
         const char* e = getenv("LYNSE_HIP_QS_F4");
-        return !(e && atoi(e) == 0) && v == 1 && !fs && !filt && a.emit_all == 0 && a.ld16 == 512 && a.nslab == 4 && a.qpad == 256 && a.nq <= 256 &&
+        return !(e && atoi(e) == 0) && v == 1 && !fs && !filt && a.emit_all == 0 && (a.nslab == 2 || a.nslab == 4 || a.nslab == 8) && a.ld16 == a.nslab * 128u &&   // 512 / 1024 / 2048-bit rows
+               a.qpad == 256 && a.nq <= 256 &&
                a.tile_stride == 0 && !a.mask && !a.row_ids && a.row1 > a.row0;
     }
     return !fs && a.emit_all == 0 && qs_width_ok(a.ld16, a.nslab, filt) && a.qpad == 256 && a.nq <= 256 && a.tile_stride == 0 &&
@@ -1531,13 +1532,16 @@ static int launch_scan_qs_sample(const ScanArgs& a, uint32_t grid, hipStream_t s
 static int launch_scan_i8c(const ScanArgs& a, uint32_t grid, hipStream_t st, bool fs = false, bool filt = false, bool f4 = false, bool qs = false) {
     constexpr size_t lds = (size_t)(3 * 256 + 2 * 256) * 128;
     if (qs && f4) {   // batched Hamming on the query-stationary tiling (scan_qs.h, F4)
-        static bool attr_f4 = false;
-        auto kern = k_scan_qs<4, 2, 4, 3, false, 8, 0, 1, 0, 0, 0, 0, 1>;
-        constexpr size_t qlds = (size_t)3 * 4 * 64 * 128;
-        if (!attr_f4) { LY_TRY(set_max_lds(kern, qlds)); attr_f4 = true; }
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), qlds, st, a);
-        LY_HIP(hipGetLastError());
-        return LYNSE_OK;
+        static bool attr_f4[3] = {false, false, false};
+        auto gof = [&](auto kern, int slot, size_t qlds) -> int {
+            if (!attr_f4[slot]) { LY_TRY(set_max_lds(kern, qlds)); attr_f4[slot] = true; }
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(512), qlds, st, a);
+            LY_HIP(hipGetLastError());
+            return LYNSE_OK;
+        };
+        if (a.nslab == 2) return gof(k_scan_qs<2, 2, 2, 3, false, 8, 0, 1, 0, 0, 0, 0, 1>, 0, (size_t)3 * 2 * 64 * 128);   // 512-bit rows
+        if (a.nslab == 8) return gof(k_scan_qs<8, 1, 8, 4, false, 8, 0, 1, 0, 0, 0, 0, 1>, 2, (size_t)4 * 8 * 32 * 128);   // 2048-bit rows: 32-row tiles
+        return gof(k_scan_qs<4, 2, 4, 3, false, 8, 0, 1, 0, 0, 0, 0, 1>, 1, (size_t)3 * 4 * 64 * 128);
     }
     if (qs) return launch_scan_qs(a, grid, st);
     static bool attr_done[16] = {false};
