@@ -356,3 +356,37 @@ def test_plain_l2_on_the_query_stationary_tiling_at_other_widths(L, oracle, dim)
         for qi in sorted({0, nq // 2, nq - 1}):
             e_ids, e_d = oracle.canonical_topk(queries[qi], data, k, O.L2)
             assert np.array_equal(rows[qi].astype(np.uint32), e_ids) and np.array_equal(dists[qi].view(np.uint32), e_d.view(np.uint32)), (nq, qi)
+
+
+@pytest.mark.parametrize("bits", [512, 2048])
+def test_batched_hamming_on_the_query_stationary_tiling_at_other_widths(L, oracle, bits):
+    """k_scan_qs<.., F4> for 512- and 2048-bit fingerprints (2 / 8 slabs of FP4 nibbles): 100 and 256 packed queries, bit-exact against the
+    oracle and identical to the 256 x 256 tile (LYNSE_HIP_QS_F4=0)."""
+    import os
+
+    from lynsedb_amd.datasets import packed_bernoulli
+
+    n, k = 600_000, 50
+    words = packed_bernoulli(n, bits, 0.5, 77)
+    idx = L.FlatIndex(None, bits)
+    idx.write_packed(words)
+    idx.finalize()
+    rng = np.random.default_rng(bits)
+    qw = words[rng.integers(0, n, 256)].copy()
+    qw ^= packed_bernoulli(256, bits, 0.5, 78) & packed_bernoulli(256, bits, 0.5, 79) & packed_bernoulli(256, bits, 0.5, 80)
+    idx.profile_enable(True)
+    for nq in (256, 100):
+        idx.profile_get(reset=True)
+        rows, dists, counts = idx.search_packed_arrays(qw[:nq], k, "hamming")
+        p = idx.profile_get(reset=True)
+        assert plan_fields(p)[2] == 0x81 and p["fallback_queries"] == 0, (nq, p)
+        os.environ["LYNSE_HIP_QS_F4"] = "0"
+        try:
+            r0, d0, c0 = idx.search_packed_arrays(qw[:nq], k, "hamming")
+            p0 = idx.profile_get(reset=True)
+        finally:
+            del os.environ["LYNSE_HIP_QS_F4"]
+        assert plan_fields(p0)[2] != 0x81 and p0["fallback_queries"] == 0, p0
+        assert np.array_equal(r0, rows) and np.array_equal(d0, dists) and np.array_equal(c0, counts)
+        for qi in sorted({0, nq // 2, nq - 1}):
+            assert_rows_equal(oracle.canonical_topk_packed(qw[qi], words, k, O.HAMMING), rows[qi], dists[qi], counts[qi], (bits, nq, qi))
