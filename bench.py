@@ -750,7 +750,8 @@ def run_c5(args, rank, local_rank, world, dev, dist, result_out):
                        "exchange": ("rccl all_gather of %d B/rank inside the library" % (B * K * 12 + B * 4 + 16)) if native else ("torch.distributed" if world > 1 else "none"),
                        "batches_in_flight": in_flight, "build_s": round(build_s, 1), "derived_build_s": round(prepare_s, 2),
                        "hbm_bytes_per_gpu": int(sh.index.hbm_bytes())},
-            "roofline": {"bound": "hbm", "kernel": "k_scan_h16<2,4,4,2,IP,fp4> (v_mfma_scale_f32_32x32x64_f8f6f4) over the +-1 FP4 copy" if mfma else "k_scan_binary_rows",
+            "roofline": {"bound": "hbm", "kernel": (("k_scan_qs<4,2,4,3,...,F4>" if ((int(prof.get("last_plan", 0)) >> 16) & 0xff) == 0x81 else "k_scan_h16<2,4,4,2,IP,fp4>") +
+                                                      " (v_mfma_scale_f32_32x32x64_f8f6f4) over the +-1 FP4 copy") if mfma else "k_scan_binary_rows",
                          "achieved": round(hbm_gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(hbm_gbps / HBM_PEAK_GBPS, 4), "traffic": None,
                          "mfma_TOPs": round(ops / scan_s / 1e12, 1) if (mfma and scan_s > 0) else None,
                          "launches": launches, "avg_launch_us": round(prof["scan_us"] / launches, 2), "timed_steps": timed_steps,
@@ -1009,7 +1010,8 @@ def other_configs(dev):
             c = torch.zeros(nq, dtype=torch.int32, device=dev)
             fn = lambda: idx.search_packed_device(dq, 50, "hamming", rows, d, c)  # noqa: E731
             ms = _time_calls(fn, 2, 6) * 1e3
-            us, gbps, _ = _scan_profile(idx, fn, 3, bits // 8)
+            us, gbps, pp = _scan_profile(idx, fn, 3, bits // 8)
+            qs_f4 = ((int(pp.get("last_plan", 0)) >> 16) & 0xff) == 0x81
             r, dd = rows.cpu().numpy(), d.cpu().numpy()
             ok = True
             for i in sorted({0, nq - 1}):
@@ -1019,7 +1021,7 @@ def other_configs(dev):
             mfma = nq >= 72
             kb = gbps * (4.0 if mfma else 1.0)
             res["nq%d" % nq] = {"ms": round(ms, 4), "queries_per_s": round(nq / ms * 1e3, 1), "scan_us": us, "packed_GBps": gbps,
-                                "kernel": "k_scan_h16<2,4,4,2,IP,fp4> (v_mfma_scale_f32_32x32x64_f8f6f4) over the +-1 FP4 copy" if mfma else "k_scan_binary_rows",
+                                "kernel": (("k_scan_qs<4,2,4,3,...,F4>" if qs_f4 else "k_scan_h16<2,4,4,2,IP,fp4>") + " (v_mfma_scale_f32_32x32x64_f8f6f4) over the +-1 FP4 copy") if mfma else "k_scan_binary_rows",
                                 "GBps": round(kb, 1), "frac_of_hbm_peak": round(kb / HBM_PEAK_GBPS, 4),
                                 "mfma_TOPs": round(2.0 * nq * n * bits / (us * 1e-6) / 1e12, 1) if mfma and us else None, "oracle_parity": bool(ok)}
         return res
