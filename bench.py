@@ -856,7 +856,7 @@ def same_shard_variants(idx, queries, B, K, N, D):
                      "int8_coarse_pass": bool(plan & 4), "fallback_queries": int(p["fallback_queries"]),
                      "rescored_per_query": round(p["pool_entries"] / max(p["searches"] * B, 1), 1)}
     # small batches on the same shard (the 128-row x 32-query tiling; from 256K rows on it streams the SQ8 codes as well): HBM-bound
-    for nq in (1, 32):
+    for nq in (1, 32, 128):
         dq = queries[:nq].contiguous()
         r1 = torch.zeros((nq, K), dtype=torch.int64, device=queries.device)
         d1 = torch.zeros((nq, K), dtype=torch.float32, device=queries.device)
