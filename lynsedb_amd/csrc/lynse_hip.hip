@@ -1738,7 +1738,10 @@ static int launch_scan_binary_rows(const BinArgs& a, int metric, uint32_t grid, 
 // dynamic LDS of the select / final kernels: the cap key slots + scratch for the LDS-staged exact rescoring (rescore_keys): 48 KB hold
 // the query and 15 rows of 768 floats per chunk; one workgroup per query either way
 constexpr size_t SEL_LDS_MAX = 150 * 1024;
-static inline uint32_t sel_lds_bytes(uint32_t cap) {
+static inline uint32_t sel_lds_bytes(uint32_t cap, uint32_t nq = 0) {
+    // (a widened pass — thousands of queries per launch, the k-means assignment — is bound by how many of its one-per-query workgroups
+    // fit a CU: no scratch there, 4096 key slots stay 32 KB instead of 80 KB)
+    if (nq > 512) return cap * 8u;
     static const size_t extra = []() { const char* e = getenv("LYNSE_HIP_SEL_SCRATCH_KB"); return (size_t)(e ? atoi(e) : 48) * 1024; }();   // (0: the direct loads, A/B)
     return (uint32_t)std::min<size_t>((size_t)cap * 8 + extra, SEL_LDS_MAX);
 }
@@ -2150,7 +2153,7 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
             sa.stamps = reinterpret_cast<unsigned long long*>(w.gsync + 64) + (size_t)si * 256 * 8;
         if (fs_stage && getenv("LYNSE_HIP_DEBUG_FS")) return LYNSE_OK;   // debugging: stop behind the fused stage (lynse_hip_debug_workspace)
         if (fused_tail && si + 1 == plan.size()) { sa_last = sa; continue; }  // the last select runs inside k_select_final
-        sa.lds_bytes = sel_lds_bytes(w.cap);
+        sa.lds_bytes = sel_lds_bytes(w.cap, nq);
         hipLaunchKernelGGL(k_select<SEL_NT>, dim3(nq), dim3(SEL_NT), sa.lds_bytes, st, sa);
         LY_HIP(hipGetLastError());
     }
@@ -2174,7 +2177,7 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
     if (hdr_direct) { fa.h_hdr = w.h_hdr; fa.hdr_q = w.qcap; }
     if (fused_tail) {
         TailArgs ta{sa_last, fa};
-        ta.s.lds_bytes = ta.f.lds_bytes = sel_lds_bytes(w.cap);
+        ta.s.lds_bytes = ta.f.lds_bytes = sel_lds_bytes(w.cap, nq);
         hipLaunchKernelGGL(k_select_final<SEL_NT>, dim3(nq), dim3(SEL_NT), ta.s.lds_bytes, st, ta);
         LY_HIP(hipGetLastError());
         (void)asc;
@@ -2185,7 +2188,7 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
         LY_HIP(hipGetLastError());
         fa.exact = 1;
     }
-    fa.lds_bytes = sel_lds_bytes(w.cap);
+    fa.lds_bytes = sel_lds_bytes(w.cap, nq);
     hipLaunchKernelGGL(k_final<SEL_NT>, dim3(nq), dim3(SEL_NT), fa.lds_bytes, st, fa);
     LY_HIP(hipGetLastError());
     (void)asc;
@@ -2516,7 +2519,7 @@ static int run_chunk_sq8(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t ou
         sa.exact = 1; sa.emit_all_n = si == 0 ? (int)(s.r1 - s.r0) : -1;
         sa.Qf = w.Qf; sa.V = h->rows; sa.ld = h->ld; sa.D = h->dim;
         sa.candB = w.candB; sa.segcnt = w.segcnt; sa.seg = a.seg; sa.nseg = a.seg ? a.nseg : 0;
-        sa.lds_bytes = sel_lds_bytes(w.cap);
+        sa.lds_bytes = sel_lds_bytes(w.cap, nq);
         hipLaunchKernelGGL(k_select<SEL_NT>, dim3(nq), dim3(SEL_NT), sa.lds_bytes, st, sa);
         LY_HIP(hipGetLastError());
     }
@@ -2534,7 +2537,7 @@ static int run_chunk_sq8(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t ou
         LY_HIP(hipGetLastError());
     }
     fa.exact = 1;
-    fa.lds_bytes = sel_lds_bytes(w.cap);
+    fa.lds_bytes = sel_lds_bytes(w.cap, nq);
     hipLaunchKernelGGL(k_final<SEL_NT>, dim3(nq), dim3(SEL_NT), fa.lds_bytes, st, fa);
     LY_HIP(hipGetLastError());
     return LYNSE_OK;
