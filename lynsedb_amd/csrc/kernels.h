@@ -3535,6 +3535,30 @@ __device__ __forceinline__ uint32_t select_body(const SelectArgs& a, uint64_t* k
         // ---- k-th smallest key (keys are unique: the low word is the row).  Float metrics only need the k-th SCORE (every
         // tie of it survives the margin cut anyway): four passes over the score word instead of eight over the whole key.
         const int last_shift = a.exact ? 0 : 32;
+        if (a.k == 1u) {
+            // the nearest row only (every k-means assignment pass, top-1 searches): the smallest key is a block-wide minimum, not
+            // four / eight histogram passes (s_memtime stamps, 4096 keys: 23k of this kernel's 56k cycles were the radix select)
+            __shared__ uint64_t s_wmin[NT / 64];
+            uint64_t mn = ~0ull;
+            for (uint32_t i = tid; i < n; i += NT) {
+                const uint64_t kv = keys[i];
+                mn = kv < mn ? kv : mn;
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const uint64_t other = __shfl_xor(mn, o, 64);
+                mn = other < mn ? other : mn;
+            }
+            if (lane == 0) s_wmin[tid >> 6] = mn;
+            __syncthreads();
+            if (tid == 0) {
+                uint64_t m = s_wmin[0];
+#pragma unroll
+                for (int w = 1; w < NT / 64; ++w) m = s_wmin[w] < m ? s_wmin[w] : m;
+                s_prefix = a.exact ? m : (m & ~0xffffffffull);   // (what the passes down to last_shift leave)
+            }
+            __syncthreads();
+        } else
         for (int shift = 56; shift >= last_shift; shift -= 8) {
             if (tid < 256) hist[tid] = 0;
             __syncthreads();

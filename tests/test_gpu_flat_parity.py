@@ -160,6 +160,38 @@ def test_float_parity_uniform(L, oracle, metric, n, dim, nq, k):
         assert np.array_equal(rows[qi, :c].astype(np.uint32), e_ids), (qi, rows[qi, :c], e_ids)
 
 
+@pytest.mark.parametrize("metric", [IP, L2, COS, HAM, JAC])
+@pytest.mark.parametrize("nq", [3, 40, 300])
+def test_top1_takes_the_minimum_key_path(L, oracle, metric, nq):
+    """k = 1 (the k-means assignment's shape): select_body finds the smallest key by a block-wide minimum instead of the radix
+    passes.  Uniform rows, rows duplicated beyond k (ties go to the lowest row) and a self match; 0 ulp on the distance."""
+    rng = np.random.default_rng(1000 + nq)
+    n, dim = 30000, 64
+    if metric in (HAM, JAC):
+        data = (rng.random((n, dim)) < 0.4).astype(f32)
+        queries = (rng.random((nq, dim)) < 0.4).astype(f32)
+    else:
+        data = rng.random((n, dim), dtype=f32)
+        queries = rng.random((nq, dim), dtype=f32)
+    data[20000:20050] = data[77]          # 51 copies of one row: the tie of the best score must resolve to row 77
+    if metric == IP:                      # (the largest row wins every IP query: copies of it, the lowest row of the tie)
+        data[123] = f32(0.999)
+        data[25000:25010] = data[123]
+    queries[0] = data[77]
+    queries[1] = data[n - 1]
+    idx = make_index(L, data)
+    sel = np.arange(nq) if nq <= 40 else np.concatenate([np.arange(8), rng.choice(nq, 12, replace=False)])
+    if nq <= 40:   # (3 queries: the fused single-launch search and the staged pipeline both)
+        check_batch(L, oracle, idx, data, queries, 1, metric)
+    rows, dists, counts = idx.search_batch_arrays(queries, 1, NAME[metric])
+    assert int(rows[0, 0]) == (123 if metric == IP else 77)
+    for qi in sel:
+        e_ids, e_d = oracle.canonical_topk(queries[qi], data, 1, metric)
+        assert int(counts[qi]) == 1
+        assert np.array_equal(dists[qi, :1].view(np.uint32), e_d.view(np.uint32)), (qi, dists[qi, :1], e_d)
+        assert int(rows[qi, 0]) == int(e_ids[0]), (qi, rows[qi, :1], e_ids)
+
+
 @pytest.mark.parametrize("metric", [IP, L2, COS])
 def test_float_parity_gaussian_mixed_scale(L, oracle, metric):
     """Signed data with very different row norms: stresses the f16 scale + certified margin."""
