@@ -3921,68 +3921,101 @@ __global__ void __launch_bounds__(SMALL_NT) k_small_search(SmallArgs a) {
     }
     __syncthreads();
     if (!s_last) return;
-    const uint32_t nlist = gridDim.x;
-    uint64_t* lists = wl;  // [nlist][k] staged in LDS (the launch sizes the dynamic LDS for it)
+    // Merge of the gridDim.x sorted lists WITHOUT a tournament (two k-round tournaments — a DPP wave minimum and a dependent LDS
+    // read per rank and level — were 7.8 us of the 24.6 us kernel on 100k x 128, whatever the number of lists):
+    //   1. one head (best key) per list and thread; its rank among the 64 heads of the wave by v_readlane counting; the wave's
+    //      kout smallest heads land rank-ordered in wh[wave][.];
+    //   2. T = the kout-th smallest of all heads (rank over the eight sorted wave rows: branch-free binary searches).  kout lists
+    //      start at or below T, so kout keys <= T exist and no key above T is among the kout best;  fewer than kout non-empty
+    //      lists: T = the sentinel (every real key is a candidate);
+    //   3. the (at most kout) lists whose head is <= T read their keys <= T (agent-scope loads, 8 in flight) into the candidate
+    //      array in LDS — a few dozen keys on ordinary data, kout * k at the very worst;
+    //   4. every candidate's rank by counting (keys are unique): rank < kout writes output slot `rank`.
+    const uint32_t nlist = gridDim.x;                 // <= SMALL_NT: one list per thread
+    uint64_t* wh = wl;                                // [NWAVE][64]
+    uint64_t* cnd = wl + (size_t)NWAVE * 64;          // candidates (the launch sizes the dynamic LDS: min(k, nlist) * k slots, rounded up to a power of two)
+    __shared__ uint64_t s_T;
+    __shared__ uint32_t s_m;
+    auto rank_rows = [&](uint64_t x) -> uint32_t {    // keys of wh smaller than x (every row sorted, sentinel-padded)
+        uint32_t pos[NWAVE];
+#pragma unroll
+        for (int w = 0; w < NWAVE; ++w) pos[w] = 0;
+#pragma unroll
+        for (int step = 32; step >= 1; step >>= 1) {
+#pragma unroll
+            for (int w = 0; w < NWAVE; ++w) pos[w] += (wh[w * 64 + pos[w] + step - 1] < x) ? (uint32_t)step : 0u;
+        }
+        uint32_t r = 0;
+#pragma unroll
+        for (int w = 0; w < NWAVE; ++w) r += pos[w] + ((wh[w * 64 + pos[w]] < x) ? 1u : 0u);
+        return r;
+    };
     for (uint32_t q = 0; q < a.nq; ++q) {
         const uint32_t n_rows = ivf ? enter_lists(q) : a.n;
         const uint32_t kout = k < n_rows ? k : n_rows;
+        const uint64_t* src = a.part + (size_t)q * nlist * k;
         __syncthreads();
-        {   // the query's lists are contiguous: eight independent loads in flight per thread (one load per trip waited a full L2
-            // round trip per key: 26 us for 512 lists of 32 keys)
-            const uint64_t* src = a.part + (size_t)q * nlist * k;
-            const uint32_t total = nlist * k;
-            for (uint32_t base = tid; base < total; base += SMALL_NT * 8) {
+        const bool owner = (uint32_t)tid < nlist;
+        const uint64_t head = owner ? __hip_atomic_load(&src[(size_t)tid * k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : KEY_SENTINEL;
+        wh[tid] = KEY_SENTINEL;
+        if (tid == 0) { s_T = KEY_SENTINEL; s_m = 0; }
+        uint32_t hr = 0;   // heads of this wave below mine
+#pragma unroll
+        for (int j = 0; j < 64; ++j) hr += readlane_u64(head, j) < head ? 1u : 0u;
+        __syncthreads();
+        if (head != KEY_SENTINEL && hr < kout) wh[wave * 64 + hr] = head;
+        __syncthreads();
+        {
+            const uint64_t mine = wh[tid];
+            if (mine != KEY_SENTINEL && kout && rank_rows(mine) == kout - 1) s_T = mine;
+        }
+        __syncthreads();
+        const uint64_t T = s_T;
+        if (head != KEY_SENTINEL && head <= T) {
+            cnd[atomicAdd(&s_m, 1u)] = head;
+            // (loading the first 16 keys of every list up front instead — one round trip, no second one here — was slower: 8192
+            // strided 8-byte loads against 512 + a few dozen; the merge 6.4 us against 5.1 us)
+            for (uint32_t j0 = 1; j0 < k; j0 += 8) {
                 uint64_t v[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const uint32_t i = base + u * SMALL_NT;
-                    v[u] = i < total ? __hip_atomic_load(&src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : KEY_SENTINEL;
-                }
+                for (int u = 0; u < 8; ++u)
+                    v[u] = j0 + u < k ? __hip_atomic_load(&src[(size_t)tid * k + j0 + u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : KEY_SENTINEL;
+                bool more = true;
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
-                    const uint32_t i = base + u * SMALL_NT;
-                    if (i < total) lists[i] = v[u];
+                    more = more && v[u] != KEY_SENTINEL && v[u] <= T;   // (the list is sorted: the first key above T ends it)
+                    if (more) cnd[atomicAdd(&s_m, 1u)] = v[u];
                 }
+                if (!more) break;
             }
         }
         __syncthreads();
-        // two barrier-free tournaments: every wave merges the (at most 64) lists its lanes own into its kout best keys, then
-        // wave 0 merges the eight wave results and writes the outputs — one wave-wide minimum per rank and level
-        uint64_t* wres = lists + (size_t)nlist * k;  // [NWAVE][k]
-        {
-            const uint32_t li = wave * 64 + lane;
-            const bool owner = li < nlist;
-            uint32_t head = 0;
-            uint64_t cur = owner ? lists[(size_t)li * k] : KEY_SENTINEL;
-            for (uint32_t round = 0; round < kout; ++round) {
-                const uint64_t best = wave_min_u64(cur);
-                if (lane == 0) wres[wave * k + round] = best;
-                if (owner && cur == best && best != KEY_SENTINEL) {  // keys are unique: exactly one owner advances
-                    ++head;
-                    cur = head < k ? lists[(size_t)li * k + head] : KEY_SENTINEL;
+        const uint32_t m = s_m;
+        if (m <= 512u) {
+            for (uint32_t i = tid; i < m; i += SMALL_NT) {
+                const uint64_t mine = cnd[i];
+                uint32_t r = 0;
+                for (uint32_t j = 0; j < m; ++j) r += cnd[j] < mine ? 1u : 0u;
+                if (r < kout) {
+                    a.out_rows[(size_t)q * a.out_k + r] = (uint64_t)key_row(mine) * a.row_stride + a.row_offset;
+                    a.out_dists[(size_t)q * a.out_k + r] = key_score(mine, asc);
                 }
+            }
+        } else {
+            // rows stored in score order put whole lists below T (k = 64: up to 63 * 64 + 1 candidates, m^2 / 512 compares per
+            // thread): sort instead (the candidate slots are sized to a power of two)
+            const uint32_t np2 = next_pow2(m);
+            for (uint32_t i = m + tid; i < np2; i += SMALL_NT) cnd[i] = KEY_SENTINEL;
+            bitonic_sort_lds<SMALL_NT>(cnd, np2, tid);
+            for (uint32_t r = tid; r < kout; r += SMALL_NT) {
+                a.out_rows[(size_t)q * a.out_k + r] = (uint64_t)key_row(cnd[r]) * a.row_stride + a.row_offset;
+                a.out_dists[(size_t)q * a.out_k + r] = key_score(cnd[r], asc);
             }
         }
-        __syncthreads();
-        if (wave == 0) {
-            uint32_t head = 0;
-            uint64_t cur = (lane < NWAVE && kout) ? wres[lane * k] : KEY_SENTINEL;
-            for (uint32_t round = 0; round < kout; ++round) {
-                const uint64_t best = wave_min_u64(cur);
-                if (lane < NWAVE && cur == best && best != KEY_SENTINEL) {
-                    ++head;
-                    cur = head < kout ? wres[lane * k + head] : KEY_SENTINEL;
-                }
-                if (lane == 0) {
-                    a.out_rows[(size_t)q * a.out_k + round] = (uint64_t)key_row(best) * a.row_stride + a.row_offset;
-                    a.out_dists[(size_t)q * a.out_k + round] = key_score(best, asc);
-                }
-            }
-            // short results are padded like k_final's (row ~0, the worst distance of the metric)
-            for (uint32_t i = kout + lane; i < a.out_k; i += 64) {
-                a.out_rows[(size_t)q * a.out_k + i] = ~0ull;
-                a.out_dists[(size_t)q * a.out_k + i] = asc ? LY_INF : -LY_INF;
-            }
+        // short results are padded like k_final's (row ~0, the worst distance of the metric)
+        for (uint32_t i = kout + tid; i < a.out_k; i += SMALL_NT) {
+            a.out_rows[(size_t)q * a.out_k + i] = ~0ull;
+            a.out_dists[(size_t)q * a.out_k + i] = asc ? LY_INF : -LY_INF;
         }
         if (tid == 0) { a.out_counts[q] = kout; a.overflow[q] = (ivf && a.flag_empty && n_rows == 0) ? 1u : 0u; }
     }

@@ -2228,10 +2228,11 @@ static int run_small(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
     a.part = w.small_part; a.ticket = w.small_ticket;
     a.out_rows = r_dst; a.out_dists = d_dst; a.out_counts = c_dst; a.overflow = o_dst;
     // two workgroups per CU (16 waves: the scan is a chain of dependent load batches per wave), one merge list per workgroup:
-    // at most SMALL_NT lists and 128 KB of them in LDS
+    // at most SMALL_NT lists (one per thread of the last workgroup) and 128 KB of them in the hand-over buffer
     uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint64_t>((uint64_t)std::min(2 * h->num_cu, SMALL_NT), 16384u / std::max<uint32_t>(k, 1)), (n_scan + 127) / 128));
     if (const char* ge = getenv("LYNSE_HIP_SMALL_GRID")) grid = std::max(1u, std::min<uint32_t>(grid, (uint32_t)atoi(ge)));   // development
-    const size_t lds = (size_t)((h->dim + 3) / 4 * 4) * 4 + std::max<size_t>((size_t)SMALL_NT * 8, (size_t)grid * k * 8) + (size_t)(SMALL_NT / 64) * k * 8 + 64;  // wave lists, then the merge lists + the per-wave tournament results
+    auto pow2_at_least = [](uint32_t v) { uint32_t p = 2; while (p < v) p <<= 1; return p; };
+    const size_t lds = (size_t)((h->dim + 3) / 4 * 4) * 4 + (size_t)SMALL_NT * 8 + (size_t)pow2_at_least(std::min<uint32_t>(k, grid) * k) * 8 + 64;  // the query, the wave lists (later the heads of the merge), the merge's candidate keys
     static bool small_attr = false;
     if (!small_attr) { LY_TRY(set_max_lds(k_small_search, 160 * 1024 - 1024)); small_attr = true; }
     hipEvent_t e0 = nullptr, e1 = nullptr;

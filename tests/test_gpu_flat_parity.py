@@ -192,6 +192,41 @@ def test_top1_takes_the_minimum_key_path(L, oracle, metric, nq):
         assert int(rows[qi, 0]) == int(e_ids[0]), (qi, rows[qi, :1], e_ids)
 
 
+@pytest.mark.parametrize("k", [1, 10, 33, 64])
+@pytest.mark.parametrize("order", ["random", "best_first", "best_last", "one_block"])
+def test_fused_search_merge_of_the_workgroup_lists(L, oracle, k, order):
+    """k_small_search's last-workgroup merge (threshold from the list heads, candidates ranked by counting; more than 512
+    candidates: sorted).  Rows stored in score order put whole lists under the threshold (k = 64: thousands of candidates);
+    `one_block` keeps every good row inside 128 consecutive rows (one workgroup's share: fewer good lists than k)."""
+    rng = np.random.default_rng(k * 7 + len(order))
+    n, dim = 70000, 16
+    data = rng.random((n, dim), dtype=f32)
+    q = rng.random((4, dim), dtype=f32)
+    s = data @ q[0]
+    if order == "best_first":
+        data = data[np.argsort(-s, kind="stable")]
+    elif order == "best_last":
+        data = data[np.argsort(s, kind="stable")]
+    elif order == "one_block":
+        data *= f32(0.01)
+        data[4096:4224] = rng.random((128, dim), dtype=f32)
+    idx = make_index(L, data)
+    for nq in (1, 4):
+        rows, dists, counts = idx.search_batch_arrays(q[:nq], k, "ip")
+        for qi in range(nq):
+            e_ids, e_d = oracle.canonical_topk(q[qi], data, k, IP)
+            assert int(counts[qi]) == k
+            assert np.array_equal(rows[qi, :k].astype(np.uint32), e_ids), (order, k, qi, rows[qi, :k], e_ids)
+            assert np.array_equal(dists[qi, :k].view(np.uint32), e_d.view(np.uint32))
+    small = make_index(L, data[:40])          # one workgroup, fewer rows than k: every key is a candidate, short result padded
+    rows, dists, counts = small.search_batch_arrays(q[:2], k, "l2")
+    for qi in range(2):
+        e_ids, e_d = oracle.canonical_topk(q[qi], data[:40], k, L2)
+        c = int(counts[qi])
+        assert c == min(k, 40) and np.array_equal(rows[qi, :c].astype(np.uint32), e_ids)
+        assert np.array_equal(dists[qi, :c].view(np.uint32), e_d.view(np.uint32))
+
+
 @pytest.mark.parametrize("metric", [IP, L2, COS])
 def test_float_parity_gaussian_mixed_scale(L, oracle, metric):
     """Signed data with very different row norms: stresses the f16 scale + certified margin."""
