@@ -3364,6 +3364,7 @@ struct SelectArgs {
     int drop_sentinels;  // filtered search: the emit-all stage wrote KEY_SENTINEL for rows outside the subset
     int threshold_only;  // lane-max sample stage: derive the threshold, keep NO candidate (the rows are scanned again)
     int tighten;         // float coarse passes: threshold from the exact rescoring of the >= k best coarse rows (tau_x -/+ E)
+    int hand_exact;      // k_select_final only: when every survivor was among the rows rescored for the threshold, they go on with those exact scores
     // segmented emission of the scan stage that ran before this select (ScanArgs::candB / segcnt): nseg segments of
     // `seg` slots per query, segcnt[q][s] keys in segment s.  nseg == 0: none.
     const uint64_t* candB;
@@ -3531,6 +3532,9 @@ __device__ __forceinline__ uint32_t select_body(const SelectArgs& a, uint64_t* k
     float tau = 0.0f;
     float cut_exact = asc ? LY_INF : -LY_INF;   // tau_x -/+ E; unused when not tightened
     bool tightened = false;
+    __shared__ uint64_t xs[256];   // the keys <= kth, rescored exactly (threshold tightening)
+    __shared__ uint32_t s_x;
+    uint32_t tight_m = 0;          // their number when ALL of them fitted xs
     {
         // ---- k-th smallest key (keys are unique: the low word is the row).  Float metrics only need the k-th SCORE (every
         // tie of it survives the margin cut anyway): four passes over the score word instead of eight over the whole key.
@@ -3612,8 +3616,6 @@ __device__ __forceinline__ uint32_t select_body(const SelectArgs& a, uint64_t* k
         // >= tau - E) and typically one E tighter: with the wide int8 margins that is ~5x fewer keys emitted, kept and
         // rescored in every later stage.
         if (!a.exact && a.tighten && a.k <= 128u) {
-            __shared__ uint64_t xs[256];
-            __shared__ uint32_t s_x;
             const uint32_t mx = a.k * 2u < 256u ? a.k * 2u : 256u;
             if (tid == 0) s_x = 0;
             __syncthreads();
@@ -3646,6 +3648,7 @@ __device__ __forceinline__ uint32_t select_body(const SelectArgs& a, uint64_t* k
                 const float e1 = 0.5f * a.marg2[q];
                 cut_exact = asc ? tau_x + e1 : tau_x - e1;
                 tightened = tau_x == tau_x;  // (NaN scores: keep the coarse rule)
+                tight_m = s_x <= mx ? m : 0u;
             }
             __syncthreads();
         }
@@ -3687,6 +3690,18 @@ __device__ __forceinline__ uint32_t select_body(const SelectArgs& a, uint64_t* k
         __syncthreads();
         keep = s_keep;
         sorted_path = keep > a.keep_max;
+        // Nothing but the keys <= kth survived and all of them were rescored for the threshold a moment ago (a decisive best row:
+        // every k-means assignment, clustered collections): they go on with those exact scores, the final rescoring reads no row again
+        if (a.hand_exact && tightened && tight_m && keep == tight_m) {
+            __syncthreads();
+            for (uint32_t i = tid; i < tight_m; i += NT) gkeys[i] = xs[i];
+            if (tid == 0) {
+                a.count[q] = keep;
+                a.thr[q] = thr_new;
+            }
+            *rescored = true;
+            return keep;
+        }
     }
 
     if (sorted_path) {

@@ -2177,6 +2177,7 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
     if (hdr_direct) { fa.h_hdr = w.h_hdr; fa.hdr_q = w.qcap; }
     if (fused_tail) {
         TailArgs ta{sa_last, fa};
+        ta.s.hand_exact = getenv("LYNSE_HIP_HAND_EXACT") ? atoi(getenv("LYNSE_HIP_HAND_EXACT")) : 1;   // (0: the final rescoring always reads its rows, A/B)
         ta.s.lds_bytes = ta.f.lds_bytes = sel_lds_bytes(w.cap, nq);
         hipLaunchKernelGGL(k_select_final<SEL_NT>, dim3(nq), dim3(SEL_NT), ta.s.lds_bytes, st, ta);
         LY_HIP(hipGetLastError());

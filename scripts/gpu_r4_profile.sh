@@ -27,6 +27,11 @@ S="timeout 300 python bench.py --no-cpu-baseline --no-configs --no-verify --step
 LYNSE_BENCH_FORCE_COMM=1 $S --in-flight 3 > gpurun_out/r04/shard_1p25m_in_flight_1rank_comm.json 2>/dev/null
 $S --in-flight 3 > gpurun_out/r04/shard_1p25m_in_flight.json 2>/dev/null
 $S --in-flight 1 > gpurun_out/r04/shard_1p25m_blocking.json 2>/dev/null
+# where the IVF training goes (2M-row build), the select stamps in the assignment's shape, the phases of the single-query search
+bash scripts/gpu_c4_train_prof.sh > gpurun_out/r04/c4_train_prof.log 2>&1
+cp gpurun_out/tp/c4/u_kernel_stats.csv gpurun_out/r04/r04_c4_train_kernel_stats.csv
+python scripts/dbg_assign_stamps.py > gpurun_out/r04/assign_stamps.log 2>&1
+python scripts/c1_phases.py 2> gpurun_out/r04/c1_phases.log > /dev/null
 find gpurun_out -name "*kernel_trace.csv" -size +3M -delete
 find gpurun_out -name "*counter_collection.csv" -size +12M -delete
 tail -3 gpurun_out/r04/bench_full.err

@@ -228,6 +228,35 @@ def test_fused_search_merge_of_the_workgroup_lists(L, oracle, k, order):
 
 
 @pytest.mark.parametrize("metric", [IP, L2, COS])
+@pytest.mark.parametrize("k,nq", [(1, 40), (5, 40), (5, 256), (10, 130)])
+def test_decisive_best_rows_keep_their_threshold_rescoring(L, oracle, metric, k, nq, monkeypatch):
+    """Every query has a family of exactly k near-copies in the shard and nothing else within the coarse margin: the survivors of
+    the last select are the rows it rescored for the threshold, and k_select_final hands their exact scores on
+    (SelectArgs::hand_exact) instead of rescoring them again.  Same answer as the oracle, and as LYNSE_HIP_HAND_EXACT=0."""
+    rng = np.random.default_rng(300 + k + nq)
+    n, dim = 80000, 96
+    data = (rng.random((n, dim), dtype=f32) * f32(0.2)).astype(f32)
+    queries = (rng.random((nq, dim), dtype=f32) + f32(0.5)).astype(f32)
+    slots = rng.choice(n, size=(nq, k), replace=False)
+    for qi in range(nq):
+        for j in range(k):
+            data[slots[qi, j]] = queries[qi] * f32(1.0 + 0.002 * j) + rng.standard_normal(dim).astype(f32) * f32(1e-3)
+    idx = make_index(L, data)
+    rows, dists, counts = idx.search_batch_arrays(queries, k, NAME[metric])
+    monkeypatch.setenv("LYNSE_HIP_HAND_EXACT", "0")
+    rows0, dists0, counts0 = idx.search_batch_arrays(queries, k, NAME[metric])
+    monkeypatch.delenv("LYNSE_HIP_HAND_EXACT")
+    assert np.array_equal(rows, rows0) and np.array_equal(dists.view(np.uint32), dists0.view(np.uint32)) and np.array_equal(counts, counts0)
+    for qi in list(range(6)) + [nq - 1]:
+        e_ids, e_d = oracle.canonical_topk(queries[qi], data, k, metric)
+        assert int(counts[qi]) == k
+        assert np.array_equal(rows[qi, :k].astype(np.uint32), e_ids), (qi, rows[qi, :k], e_ids)
+        assert np.array_equal(dists[qi, :k].view(np.uint32), e_d.view(np.uint32))
+        if metric != IP:
+            assert set(int(r) for r in rows[qi, :k]) == set(int(r) for r in slots[qi])
+
+
+@pytest.mark.parametrize("metric", [IP, L2, COS])
 def test_float_parity_gaussian_mixed_scale(L, oracle, metric):
     """Signed data with very different row norms: stresses the f16 scale + certified margin."""
     rng = np.random.default_rng(99)
