@@ -1348,6 +1348,9 @@ constexpr int HK = 64;  // K elements per slab
 // 4 no query-image DMA, 8 no row DMA, 16 no epilogue.  FILT compiles the subset-filter paths in (mask / row_ids of ScanArgs): they
 // cost registers the unfiltered kernel does not have to spare (56 B/lane of scratch and 13 % of its speed when they
 // were runtime branches).
+#ifndef LYNSE_ZEROC
+#define LYNSE_ZEROC 1   // (0: the DENSE float epilogue clears its accumulators, A/B build)
+#endif
 template <int WQ, int WR, int TQ, int TR, int METRIC, int NSV, int NSQ, int NT_HINT, bool TILED = false, bool RAG = true, int DBG = 0, bool FILT = false,
           int I8Q = 0, int EMIT = -1, int PLACE = 0, bool DENSE = false, bool PRIO = false, bool QCREG = true, int FS = 0>
 __global__ void __launch_bounds__(WQ * WR * 64, (TQ * TR >= 16) ? 1 : ((WQ * WR >= 8) ? (WQ * WR / 4) : 2)) k_scan_h16(ScanArgs a) {
@@ -1376,6 +1379,7 @@ __global__ void __launch_bounds__(WQ * WR * 64, (TQ * TR >= 16) ? 1 : ((WQ * WR 
     constexpr bool I8C = I8Q == 2 || F4;
     static_assert(!I8C || METRIC == M_IP, "certified int8 coarse pass: IP only");
     constexpr bool AG = I8Q == 2 && TQ * TR == 16;   // one wave per SIMD: accumulators in fixed AGPR tuples (ly_mfma_i8_agpr)
+    constexpr bool ZEROC = DENSE && I8Q == 0 && !TILED && !FILT && LYNSE_ZEROC;   // (= DENSEF below) the float DENSE threshold stages: tiles start from src C = 0
 #ifndef LYNSE_DEFER
 #define LYNSE_DEFER 1
 #endif
@@ -1798,6 +1802,13 @@ __global__ void __launch_bounds__(WQ * WR * 64, (TQ * TR >= 16) ? 1 : ((WQ * WR 
                                 __builtin_bit_cast(i32x4, af[cur][i]), __builtin_bit_cast(i32x4, bf[cur][j]),
                                 __builtin_bit_cast(i32x16, acc[i][j]), 0, 0, 0));
                         } else {
+                            if constexpr (ZEROC) {
+                                // the first k-step of a tile starts from the constant 0 (src C = 0): the DENSE epilogue leaves the 16 x TR x TQ
+                                // accumulators as they are instead of clearing them with one v_mov each
+                                const f32x16 z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+                                if (kk == 0 && s_in_tile == 0) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[cur][i], bf[cur][j], z, 0, 0, 0);
+                                else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[cur][i], bf[cur][j], acc[i][j], 0, 0, 0);
+                            } else
                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[cur][i], bf[cur][j], acc[i][j], 0, 0, 0);
                         }
                     }
@@ -2251,12 +2262,14 @@ __global__ void __launch_bounds__(WQ * WR * 64, (TQ * TR >= 16) ? 1 : ((WQ * WR 
                     }
 #pragma unroll
                     for (int j = 0; j < TQ; ++j) segpk = (segpk & ~(0xffu << (8 * j))) | (cnt[j] << (8 * j));
+                    if constexpr (!ZEROC) {
 #pragma unroll
                     for (int i = 0; i < TR; ++i)
 #pragma unroll
                         for (int j = 0; j < TQ; ++j)
 #pragma unroll
                             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+                    }
                 }
             }
             if constexpr (FS != 0) {
