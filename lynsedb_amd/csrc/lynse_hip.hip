@@ -988,7 +988,7 @@ struct Stage {
 //          of emitted keys per query in the first full stage);
 // level 1: contiguous plan [0,S0) [S0,8*S0) ... (all other kernels; retry after an overflow of level 0);
 // level 2: exhaustive plan, stages of cap/2 rows — cannot overflow.
-static std::vector<Stage> make_plan(const lynse_hip_flat* h, uint32_t k, int level, uint32_t tile_rows, bool threshold_only_sample = false) {
+static std::vector<Stage> make_plan(const lynse_hip_flat* h, uint32_t k, int level, uint32_t tile_rows, bool threshold_only_sample = false, uint32_t growth_hint = 0) {
     std::vector<Stage> plan;
     const uint64_t n = h->n;
     if (n == 0) return plan;
@@ -1017,7 +1017,7 @@ static std::vector<Stage> make_plan(const lynse_hip_flat* h, uint32_t k, int lev
             s0.sample_stride = (uint32_t)stride;
             plan.push_back(s0);
             static const uint64_t genv = []() { const char* e = getenv("LYNSE_HIP_SAMPLE_GROWTH"); return e ? (uint64_t)atoi(e) : 0ull; }();
-            const uint64_t gmax = genv ? genv : (threshold_only_sample ? 32ull : 16ull);  // measured best on 10M and 1.25M rows
+            const uint64_t gmax = genv ? genv : growth_hint ? growth_hint : (threshold_only_sample ? 32ull : 16ull);  // measured best on 10M and 1.25M rows
             const uint64_t g = std::max<uint64_t>(2, std::min<uint64_t>(gmax, h->cap / (8ull * std::max<uint32_t>(k, 1))));
             uint64_t seen = S, b = 0;
             while (b < n) {
@@ -1892,7 +1892,11 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
     // stage and fall back to the contiguous plan)
     const bool can_threshold_only = h16 && !binary && !filt && !no_lane_max0 && k <= 128;
     const std::vector<Stage> plan = (sts || tl_coarse_dump) ? std::vector<Stage>{Stage{0u, (uint32_t)h->n}}
-                                        : make_plan(h, k, (level == 0 && (!plan_tile || no_sample)) ? 1 : level, plan_tile, can_threshold_only);
+                                        : make_plan(h, k, (level == 0 && (!plan_tile || no_sample)) ? 1 : level, plan_tile, can_threshold_only,
+                                                    // large k on the float tilings: the epilogue's cost is the emissions (one sample threshold over 1M x 128,
+                                                    // k = 100, admits 1400 rows per query: 87 of the stage's 163 us) — a second threshold stage a quarter of the
+                                                    // way in halves them (same box, alternating: 0.241 -> 0.233 ms per batch)
+                                                    (h16 && !i8c && !binary && k >= 64) ? 4u : 0u);
     const Stage sample = (!plan.empty() && plan[0].sample_tiles) ? plan[0] : Stage{0, 0};
     *sampled_plan = sample.sample_tiles != 0;
     // sampled plan: the sample stage only has to produce a threshold -> one key per lane (its best row) instead of every
