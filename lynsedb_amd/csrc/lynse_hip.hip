@@ -69,6 +69,25 @@ static int h2d_done(void* dst, const void* src, size_t n) {
     return LYNSE_OK;
 }
 
+// The end of a blocking search: hipStreamSynchronize spins on the completion signal for ~100 us and then parks the thread on an
+// interrupt (ROCclr) — a batch over 10M rows runs 1.8 ms, so every blocking step paid the wake-up (~20-25 us between k_select_final
+// and the next batch's first kernel in the kernel trace).  Poll the stream instead for up to LYNSE_HIP_SPIN_US (default 20 ms: any
+// batch this library answers; the reference's own search burns every core of its rayon pool while it runs), then block as before.
+static int stream_wait(hipStream_t st) {
+    static const int64_t spin_us = []() { const char* e = getenv("LYNSE_HIP_SPIN_US"); return e ? (int64_t)atoll(e) : (int64_t)20000; }();
+    if (spin_us > 0) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (uint32_t it = 0;; ++it) {
+            const hipError_t q = hipStreamQuery(st);
+            if (q == hipSuccess) return LYNSE_OK;
+            if (q != hipErrorNotReady) return set_error(LYNSE_ERR_DEVICE, std::string("hipStreamQuery: ") + hipGetErrorString(q));
+            if ((it & 15u) == 15u && std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() > spin_us) break;
+        }
+    }
+    LY_HIP(hipStreamSynchronize(st));
+    return LYNSE_OK;
+}
+
 extern "C" int lynse_hip_abi_version(void) { return LYNSE_HIP_ABI_VERSION; }
 
 extern "C" size_t lynse_hip_last_error(char* buf, size_t cap) {
@@ -1991,13 +2010,12 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
             a.debug_flags = dbg;
             if (dbg & 2) a.emit_all = 0;
             if (dbg & 64) {  // phase timing of the LAST (largest) stage: 256 blocks x 8 waves x 4 counters, printed by the host
+                // one region of 8192 words per stage, the LAST stage first (scripts/phase_timing.py reads it at offset 0), cleared per batch
                 static unsigned long long* d_dbg = nullptr;
                 if (!d_dbg) LY_HIP(hipMalloc(&d_dbg, 4096 * 32 * 8));
-                LY_HIP(hipMemsetAsync(d_dbg, 0, 4096 * 32 * 8, st));
-                a.dbg = d_dbg;
-                if (si + 1 == plan.size()) {
-                    g_dbg_ptr = d_dbg;
-                }
+                if (si == 0) LY_HIP(hipMemsetAsync(d_dbg, 0, 4096 * 32 * 8, st));
+                a.dbg = d_dbg + (size_t)std::min<size_t>(plan.size() - 1 - si, 15) * 8192;
+                g_dbg_ptr = d_dbg;
             }
             const int variant = scan_variant();
             if (i8c && small) {
@@ -2041,7 +2059,7 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
                 if (s.sample_tiles && !sts && qs_sample_ok(a, fs_stage, filt, bin_mfma, plan_tile)) {
                     const uint32_t nt64 = s.sample_tiles * 4u;
                     const uint32_t sgrid = std::min<uint32_t>(nt64, (uint32_t)h->num_cu);   // one 144-KB workgroup per CU: a second round of workgroups pays the launch ramp and the query image again (40 us against 30)
-                    if ((uint64_t)sgrid * 4u >= 8ull * k && sgrid * 4u <= w.cap) {
+                    if ((uint64_t)sgrid * 4u >= 8ull * k && sgrid * 4u <= w.cap && (nt64 + sgrid - 1) / sgrid <= 32u) {   // (<= 32 tiles per workgroup: the packed position of a sample key, scan_qs.h)
                         a.ntiles = nt64;
                         LY_TRY(launch_scan_qs_sample(a, sgrid, st));
                         qs_sample_keys = sgrid * 4u;
@@ -3016,7 +3034,7 @@ static int search_impl_once(lynse_hip_flat* h, const void* q_src, bool packed_qu
                 LY_HIP(hipMemcpyAsync(out_rows + q0 * k, w.out_rows, rows_b, out_kind, st));
                 LY_HIP(hipMemcpyAsync(out_dists + q0 * k, w.out_dists, dists_b, out_kind, st));
             }
-            LY_HIP(hipStreamSynchronize(st));  // (counts + overflow flags: written into the pinned header by k_final)
+            LY_TRY(stream_wait(st));  // (counts + overflow flags: written into the pinned header by k_final)
             uint32_t nov = 0;
             for (uint32_t i = 0; i < nqc; ++i) nov += w.h_hdr[w.qcap + i] ? 1 : 0;
             if (nov == 0) {

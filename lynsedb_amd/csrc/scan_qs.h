@@ -140,65 +140,20 @@ __global__ void __launch_bounds__(512, 2) k_scan_qs(ScanArgs a) {
     // the scan is bound by the power the matrix pipe draws, idle MFMAs are not free
     const bool wave_live = (uint32_t)wave * 32u < a.nq;
     const float s_q = q_ok ? a.qinv[qn] : 0.0f, b_q = q_ok ? a.qn2[qn] : 0.0f;
-    int T = 0x7fffffff;
-    // L2: pass iff |v|^2 - 2 s_q dot + c_q <= thr.  Level 1 maximises 2 s_q dot - |v|^2 against pre = (c_q - thr) LOOSENED by more than the
-    // rounding differences between that form and the exact expression (k_scan_h16, set_pre); the slow path evaluates the exact expression.
-    [[maybe_unused]] float l2_thr = 0.0f, l2_pre = LY_INF, l2_2s = 0.0f;
-    if constexpr (MET == 1) {
-        l2_thr = q_ok ? a.thr[qn] : -LY_INF;
-        l2_2s = 2.0f * s_q;
-        const float vmax2 = a.vmax2;
-        float pre = (b_q - l2_thr) - 2e-6f * (b_q + fabsf(l2_thr) + vmax2);
-        if (!(vmax2 > 0.0f) || !(fabsf(pre) < 3.0e38f)) pre = -LY_INF;   // open threshold / overflow: no pre-filter
-        l2_pre = q_ok ? pre : LY_INF;
-#ifdef LYNSE_EXPERIMENTS
-        if (a.debug_flags & 2) l2_pre = LY_INF;
-#endif
-    }
-    if constexpr (STS == 0 && MET == 0 && SMP == 0) {
-        // INTEGER image of the threshold (k_scan_h16, load_qc_thr): B_q + s_q * (float)dot is monotone non-decreasing in the
-        // integer dot product, so "score >= thr" is exactly "dot >= T", T = the smallest passing dot (bisection over |dot| <= 2^29)
-        const float th = q_ok ? a.thr[qn] : 0.0f;
-        int lo = -(1 << 29), hi_ = 1 << 29;
-#pragma unroll 1
-        for (int it = 0; it < 31; ++it) {
-            const int mid = lo + ((hi_ - lo) >> 1);
-            const bool ge = (b_q + s_q * (float)mid) >= th;
-            hi_ = ge ? mid : hi_;
-            lo = ge ? lo : mid + 1;
-        }
-        T = q_ok ? lo : 0x7fffffff;
-#ifdef LYNSE_EXPERIMENTS
-        if (a.debug_flags & 2) T = 0x7fffffff;
-#endif
-    }
-    // STS state: tau_c = the largest tau of its query this lane has seen, T = tau_c - margin; the landing areas in LDS
-    [[maybe_unused]] int tau_c = -2147483647 - 1, dyn_m = 0, pub_last = -2147483647 - 1;
-    [[maybe_unused]] int* const land_thr = reinterpret_cast<int*>(smem + NS * SB) + wave * 64 + lane;          // tau of query qn
-    [[maybe_unused]] int* const land_slot = reinterpret_cast<int*>(smem + NS * SB + 8 * 256) + wave * 64 + lane;  // partition maximum lane % 32 of the helper query
-    [[maybe_unused]] const int* thr_src = nullptr;
-    [[maybe_unused]] const int* slot_src = nullptr;
-    [[maybe_unused]] const uint32_t hq = blockIdx.x + (uint32_t)wave * gridDim.x;   // the query whose minimum this wave republishes (if < nq)
-    [[maybe_unused]] const bool helper = STS != 0 && hq < a.nq;
-    [[maybe_unused]] uint32_t sts_step = 0;
-    [[maybe_unused]] int peek_thr = -2147483647 - 1, peek_slot = -2147483647 - 1;
-    [[maybe_unused]] auto sts_T = [&]() -> int {
-        if (!q_ok) return 0x7fffffff;
-#ifdef LYNSE_EXPERIMENTS
-        if (a.debug_flags & 2) return 0x7fffffff;
-#endif
-        return tau_c < -(1 << 30) ? -(1 << 30) - (1 << 29) : tau_c - dyn_m;   // (|dot| <= 2^29, margin <= 2^30)
-    };
-    if constexpr (STS != 0) {
-        thr_src = a.dyn_thr + (q_ok ? qn : 0u);
-        slot_src = a.dyn_slot + (size_t)(helper ? hq : 0u) * 32 + l32;
-        dyn_m = q_ok ? a.dyn_marg[qn] : 0;
-        tau_c = __hip_atomic_load(thr_src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        *land_thr = tau_c;
-        *land_slot = -2147483647 - 1;   // (nothing is published before a real set of maxima has landed)
-        T = sts_T();
-    }
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // the query fragments and constants are in registers before the first LDS-DMA
+    // (the threshold of this lane's query: loaded HERE, in front of the ring prologue — a load issued behind the LDS-DMA pieces returns
+    // behind them, and the bisection below would wait out the first HBM round trip of the ring)
+    [[maybe_unused]] const float thr_q = (q_ok && STS == 0 && SMP == 0) ? a.thr[qn] : 0.0f;
+    // Round 5: the ring prologue is issued BEFORE anything waits for the fragments and constants above.  It used to follow an
+    // s_waitcnt vmcnt(0): fragments + constants (1.8 us, L2), 12 LDS-DMA pieces per wave (1.6 us of issue) and the first HBM round trip
+    // (2.4 us) ran one after the other in every launch (s_memtime stamps of the sample stage: 5.8 us before its first MFMA); now the
+    // pieces are in flight while the fragments arrive and the integer threshold is bisected.  Loads return in order: the counted wait
+    // behind the prologue leaves exactly this wave's pieces outstanding.
+    asm volatile("" ::: "memory");   // (the fragment / constant loads stay in front of the pieces)
+    // SMP + debug_flags & 64: phase stamps of the sample stage per workgroup (a.dbg[block * 8 ..]: entry, fragments + constants loaded,
+    // ring primed [1] / fragments + constants in registers [2] (round 5: the ring is primed first), first stage landed, tiles done, keys written; [6] = s_memrealtime at entry: launch skew across the grid)
+    [[maybe_unused]] unsigned long long smp_t[4] = {0ull, 0ull, 0ull, 0ull}, smp_rt = 0ull;
+    [[maybe_unused]] const bool smp_stamps = SMP != 0 && (a.debug_flags & 64) != 0;
+    if constexpr (SMP != 0) { if (smp_stamps) smp_rt = __builtin_amdgcn_s_memrealtime(); }
 
     // ---- row stream (LDS-DMA): step gi of this workgroup = tile ordinal gi / TS, slabs [(gi % TS) SL, +SL)
     // piece p = wave * PPW + j of a stage: slab p / (RB 4) of the step, rows (p % (RB 4)) * 8 .. +8 of the tile; lane l brings the 16 B
@@ -251,6 +206,76 @@ __global__ void __launch_bounds__(512, 2) k_scan_qs(ScanArgs a) {
         issue_norms();
         advance();
     }
+    if constexpr (SMP != 0) { if (smp_stamps) smp_t[0] = __builtin_amdgcn_s_memtime(); }
+
+    int T = 0x7fffffff;
+    // L2: pass iff |v|^2 - 2 s_q dot + c_q <= thr.  Level 1 maximises 2 s_q dot - |v|^2 against pre = (c_q - thr) LOOSENED by more than the
+    // rounding differences between that form and the exact expression (k_scan_h16, set_pre); the slow path evaluates the exact expression.
+    [[maybe_unused]] float l2_thr = 0.0f, l2_pre = LY_INF, l2_2s = 0.0f;
+    if constexpr (MET == 1) {
+        l2_thr = q_ok ? thr_q : -LY_INF;
+        l2_2s = 2.0f * s_q;
+        const float vmax2 = a.vmax2;
+        float pre = (b_q - l2_thr) - 2e-6f * (b_q + fabsf(l2_thr) + vmax2);
+        if (!(vmax2 > 0.0f) || !(fabsf(pre) < 3.0e38f)) pre = -LY_INF;   // open threshold / overflow: no pre-filter
+        l2_pre = q_ok ? pre : LY_INF;
+#ifdef LYNSE_EXPERIMENTS
+        if (a.debug_flags & 2) l2_pre = LY_INF;
+#endif
+    }
+    if constexpr (STS == 0 && MET == 0 && SMP == 0) {
+        // INTEGER image of the threshold (k_scan_h16, load_qc_thr): B_q + s_q * (float)dot is monotone non-decreasing in the
+        // integer dot product, so "score >= thr" is exactly "dot >= T", T = the smallest passing dot (bisection over |dot| <= 2^29)
+        const float th = thr_q;
+        int lo = -(1 << 29), hi_ = 1 << 29;
+#pragma unroll 1
+        for (int it = 0; it < 31; ++it) {
+            const int mid = lo + ((hi_ - lo) >> 1);
+            const bool ge = (b_q + s_q * (float)mid) >= th;
+            hi_ = ge ? mid : hi_;
+            lo = ge ? lo : mid + 1;
+        }
+        T = q_ok ? lo : 0x7fffffff;
+#ifdef LYNSE_EXPERIMENTS
+        if (a.debug_flags & 2) T = 0x7fffffff;
+#endif
+    }
+    // STS state: tau_c = the largest tau of its query this lane has seen, T = tau_c - margin; the landing areas in LDS
+    [[maybe_unused]] int tau_c = -2147483647 - 1, dyn_m = 0, pub_last = -2147483647 - 1;
+    [[maybe_unused]] int* const land_thr = reinterpret_cast<int*>(smem + NS * SB) + wave * 64 + lane;          // tau of query qn
+    [[maybe_unused]] int* const land_slot = reinterpret_cast<int*>(smem + NS * SB + 8 * 256) + wave * 64 + lane;  // partition maximum lane % 32 of the helper query
+    [[maybe_unused]] const int* thr_src = nullptr;
+    [[maybe_unused]] const int* slot_src = nullptr;
+    [[maybe_unused]] const uint32_t hq = blockIdx.x + (uint32_t)wave * gridDim.x;   // the query whose minimum this wave republishes (if < nq)
+    [[maybe_unused]] const bool helper = STS != 0 && hq < a.nq;
+    [[maybe_unused]] uint32_t sts_step = 0;
+    [[maybe_unused]] int peek_thr = -2147483647 - 1, peek_slot = -2147483647 - 1;
+    [[maybe_unused]] auto sts_T = [&]() -> int {
+        if (!q_ok) return 0x7fffffff;
+#ifdef LYNSE_EXPERIMENTS
+        if (a.debug_flags & 2) return 0x7fffffff;
+#endif
+        return tau_c < -(1 << 30) ? -(1 << 30) - (1 << 29) : tau_c - dyn_m;   // (|dot| <= 2^29, margin <= 2^30)
+    };
+    if constexpr (STS != 0) {
+        thr_src = a.dyn_thr + (q_ok ? qn : 0u);
+        slot_src = a.dyn_slot + (size_t)(helper ? hq : 0u) * 32 + l32;
+        dyn_m = q_ok ? a.dyn_marg[qn] : 0;
+        tau_c = __hip_atomic_load(thr_src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        *land_thr = tau_c;
+        *land_slot = -2147483647 - 1;   // (nothing is published before a real set of maxima has landed)
+        T = sts_T();
+    }
+    // the query fragments and constants are in registers; this wave's (NS - 1) PPW ring pieces (wave 0, L2 form: + the norm pieces) stay in flight
+    if constexpr (MET == 1) {
+        if (wave == 0) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NS - 1) * PPW + (NS - 1)) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NS - 1) * PPW) : "memory");
+    } else if constexpr ((DBG & 8) != 0 || STS != 0) {   // (STS: its loads above were issued behind the pieces)
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NS - 1) * PPW) : "memory");
+    }
+    if constexpr (SMP != 0) { if (smp_stamps) smp_t[1] = __builtin_amdgcn_s_memtime(); }
 
     // ---- fragment reads: row r of slab sl of a stage lives at sl * RT * 128 + r * 128, logical 16-B slot c at physical c ^ ((r >> 1) & 7)
     // lane (l32, hi) of the A fragment (rb, kk): row rb * 32 + l32, slot kk * 2 + hi  ->  (l32 * 128 + ((hi ^ swz) * 16)) ^ (kk * 32)
@@ -263,7 +288,11 @@ __global__ void __launch_bounds__(512, 2) k_scan_qs(ScanArgs a) {
     auto read_frag = [&](qs_i32x4& dst, const uint32_t (&ad)[4], auto idxc) {   // MFMA idx of a step: (sl, kk, rb) = (idx / (4 RB), (idx / RB) % 4, idx % RB)
         constexpr int idx = decltype(idxc)::value;
         constexpr int sl = idx / (4 * RB), kk = (idx / RB) % 4, rb = idx % RB;
+#ifdef LYNSE_QS_AF_AGPR   // experiment (round 5): the A fragments land in AGPRs (does the LDS return then stop blocking the matrix pipe?)
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=a"(dst) : "v"(ad[kk]), "n"(sl * (RT * 128) + rb * (32 * 128)));
+#else
         asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(ad[kk]), "n"(sl * (RT * 128) + rb * (32 * 128)));
+#endif
     };
     using acc_t = std::conditional_t<F4 != 0, f32x16, qs_i32x16>;
     acc_t acc[RB];
@@ -306,13 +335,25 @@ __global__ void __launch_bounds__(512, 2) k_scan_qs(ScanArgs a) {
                 else if constexpr (XPF) read_frag(af[nxt % NBUF], ad_nxt, std::integral_constant<int, nxt - NM>{});
                 // outstanding reads now: those for MFMAs idx .. min(nxt, last): the oldest one is this MFMA's
                 constexpr int outstanding = (nxt < NM || XPF) ? NBUF : NM - idx;
+#ifdef LYNSE_QS_AF_AGPR
+                asm volatile("s_waitcnt lgkmcnt(%1)" : "+a"(af[idx % NBUF]) : "n"(outstanding - 1));
+#else
                 asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(af[idx % NBUF]) : "n"(outstanding - 1));
+#endif
             }
             __builtin_amdgcn_sched_barrier(0);
             constexpr int sl = idx / (4 * RB), kk = (idx / RB) % 4, rb = idx % RB;
             constexpr int ks = (s * SL + sl) * 4 + kk;
             if constexpr ((DBG & 1) != 0) {
                 asm volatile("" ::"v"(af[idx % NBUF]), "v"(bq[ks]));
+            } else if constexpr ((DBG & 128) != 0) {
+                // energy experiment (round 5): the same MACs as TWO v_mfma_i32_16x16x64_i8 (16K MACs each from the same 16 B per lane and
+                // operand) — timing / power only, the accumulators do not hold the scan's dot products
+                qs_i32x4 c0 = __builtin_shufflevector(acc[rb], acc[rb], 0, 1, 2, 3), c1 = __builtin_shufflevector(acc[rb], acc[rb], 4, 5, 6, 7);
+                c0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[idx % NBUF], bq[ks], c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[idx % NBUF], bq[ks], c1, 0, 0, 0);
+                acc[rb][0] = c0[0]; acc[rb][1] = c0[1]; acc[rb][2] = c0[2]; acc[rb][3] = c0[3];
+                acc[rb][4] = c1[0]; acc[rb][5] = c1[1]; acc[rb][6] = c1[2]; acc[rb][7] = c1[3];
             } else if constexpr (F4 != 0) {
                 if constexpr (ks == 0) {
                     const f32x16 z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -398,30 +439,34 @@ __global__ void __launch_bounds__(512, 2) k_scan_qs(ScanArgs a) {
             if (lane == 0 && m > pub_last) { atomicMax(a.dyn_thr + hq, m); pub_last = m; }
         }
     };
-    // SMP: the best two (coarse score, row) of every row this lane has seen for its query (sorted: [0] is the better one)
-    [[maybe_unused]] float smp_s[2] = {-LY_INF, -LY_INF};
-    [[maybe_unused]] uint32_t smp_m[2] = {0xffffffffu, 0xffffffffu};
+    // SMP: the best two rows this lane has seen for its query, as PACKED integers (dot & ~1023) | (tile ordinal of the workgroup << 5 |
+    // accumulator slot): smp1 >= smp2.  Round 5: the sample stage spent 40k of its 54k cycles in this epilogue (s_memtime stamps: 10k
+    // per 64-row tile against 3.6k for a threshold-stage tile) — two sorted (float score, row) pairs per lane cost ~28 VALU operations
+    // per accumulator; the packed form costs three (v_and_or, v_med3, v_max).  The low 10 bits of the dot product make room for the
+    // position: the key's score is the coarse score of (dot rounded DOWN to a multiple of 1024) <= the row's true coarse score (B_q + s_q x
+    // is monotone in x), so "k distinct real rows score at least tau" still holds for the k-th best key — a threshold looser by at most
+    // 1023 s_q (0.7 % of one standard deviation of the scores at 768 dimensions), never an invalid one.  Needs <= 32 tiles per workgroup
+    // (host: launch_scan_qs_sample's caller).
+    [[maybe_unused]] int smp1 = -2147483647 - 1, smp2 = -2147483647 - 1;
     // ---- tile epilogue: this lane's RB x 16 dot products all belong to query qn
     auto epilogue = [&](uint32_t e_tile, bool emit, [[maybe_unused]] uint32_t e_ord_) {
         if constexpr (SMP != 0) {
             const uint32_t rbase = tile_row0(e_tile);
+            const int pos0 = (int)((e_ord_ & 31u) << 5);
+            const bool whole = rbase + RT <= a.row1;   // (uniform) every row of the tile exists: all but the shard's last tile
 #pragma unroll
             for (int i = 0; i < RB; ++i)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    uint32_t m = rbase + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    float sc = b_q + s_q * (float)acc[i][r];      // the coarse score of the threshold stages' keys
-                    if (!(m < a.row1)) { m = 0xffffffffu; sc = -LY_INF; }
-#pragma unroll
-                    for (int t = 0; t < 2; ++t) {   // insertion into the sorted pair (a row without a score never displaces one with)
-                        const bool better = smp_m[t] == 0xffffffffu ? m != 0xffffffffu : (m != 0xffffffffu && sc > smp_s[t]);
-                        const float ts = smp_s[t];
-                        const uint32_t tm = smp_m[t];
-                        smp_s[t] = better ? sc : ts;
-                        smp_m[t] = better ? m : tm;
-                        sc = better ? ts : sc;
-                        m = better ? tm : m;
+                    int t = (acc[i][r] & ~1023) | (pos0 | (i * 16 + r));
+                    if (!whole) {
+                        const uint32_t m = rbase + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                        t = m < a.row1 ? t : -2147483647 - 1;
                     }
+                    // (smp1 >= smp2) the new second-best is the median of the three, the new best their maximum
+                    const int lo3 = smp1 < t ? smp1 : t, hi3 = smp1 < t ? t : smp1;
+                    smp2 = smp2 > lo3 ? smp2 : lo3;
+                    smp1 = hi3;
                 }
         } else if constexpr ((DBG & 16) != 0) {
 #pragma unroll
@@ -557,6 +602,7 @@ __global__ void __launch_bounds__(512, 2) k_scan_qs(ScanArgs a) {
             ly_static_for<TS>([&](auto sc) {
                 stamp(t_epi);
                 wait_and_barrier();
+                if constexpr (SMP != 0) { if (smp_stamps && c_ord == 0) smp_t[2] = __builtin_amdgcn_s_memtime(); }
                 if (((DBG & 64) && wave >= 4) || !wave_live) {   // (experiment: one computing wave per SIMD) / no queries: only feed the ring
 #pragma unroll
                     for (int j = 0; j < PPW; ++j) issue_piece(j);
@@ -621,11 +667,19 @@ __global__ void __launch_bounds__(512, 2) k_scan_qs(ScanArgs a) {
         }
     }
     if constexpr (SMP != 0) {
+        if (smp_stamps) smp_t[3] = __builtin_amdgcn_s_memtime();
         if (q_ok) {
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 const uint32_t slot = (blockIdx.x * 2 + hi) * 2 + t;
-                if (slot < a.cap) a.cand[(size_t)qn * a.cap + slot] = smp_m[t] == 0xffffffffu ? KEY_SENTINEL : make_key(smp_s[t], smp_m[t], false);
+                const int pk = t == 0 ? smp1 : smp2;
+                uint64_t key = KEY_SENTINEL;
+                if (pk != -2147483647 - 1) {
+                    const uint32_t pos = (uint32_t)pk & 1023u, r = pos & 15u;
+                    const uint32_t m = tile_row0(tile_of(pos >> 5)) + ((pos >> 4) & 1u) * 32u + (r & 3u) + 8u * (r >> 2) + 4u * (uint32_t)hi;
+                    key = make_key(b_q + s_q * (float)(pk & ~1023), m, false);
+                }
+                if (slot < a.cap) a.cand[(size_t)qn * a.cap + slot] = key;
             }
         }
     }
@@ -636,6 +690,13 @@ __global__ void __launch_bounds__(512, 2) k_scan_qs(ScanArgs a) {
             o[0] = t_wait; o[1] = t_bar; o[2] = t_loop; o[3] = t_epi;
         }
     }
+    if constexpr (SMP != 0) {
+        if (smp_stamps && a.dbg && tid == 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            unsigned long long* o = a.dbg + (size_t)blockIdx.x * 8;
+            o[0] = t_kernel0; o[1] = smp_t[0]; o[2] = smp_t[1]; o[3] = smp_t[2]; o[4] = smp_t[3]; o[5] = __builtin_amdgcn_s_memtime(); o[6] = smp_rt;
+        }
+    } else
     if ((a.debug_flags & 64) && a.dbg && tid == 0) {   // shader cycles of this workgroup (s_memtime ticks / wall time = the clock held)
         a.dbg[blockIdx.x * 2] = t_kernel0;
         a.dbg[blockIdx.x * 2 + 1] = __builtin_amdgcn_s_memtime();

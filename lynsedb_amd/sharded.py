@@ -437,6 +437,8 @@ class ShardedIvf:
         host_reduce = self._host_reduce(reduce, device)
         cb = _lib.REDUCE_FN(host_reduce)
         comm = self.comm.handle if (self.comm is not None and reduce is None) else None
+        if self.world > 1 and comm is None and self.dist is None and reduce is None:
+            raise ValueError("ShardedIvf.train over more than one rank needs a reduction: enable_native_comm(), a torch.distributed group, or reduce=")
         check(lib.lynse_hip_ivf_kmeans_sharded(ptr, n_local, 1 if on_device else 0, int(n_global), self.rank, self.world, self.dim, int(nlist),
                                                int(max_iter), m, device, comm, C_.cast(cb, C_.c_void_p), None, _ptr(cen), _ptr(asg), C_.byref(got)))
         return cen[:got.value].copy(), asg[:n_local].copy()
@@ -454,6 +456,8 @@ class ShardedIvf:
         host_reduce = self._host_reduce(reduce, device)
         cb = _lib.REDUCE_FN(host_reduce)
         comm = self.comm.handle if (self.comm is not None and reduce is None) else None
+        if self.world > 1 and comm is None and self.dist is None and reduce is None:
+            raise ValueError("ShardedIvf.build_device over more than one rank needs a reduction: enable_native_comm(), a torch.distributed group, or reduce=")
         h = C_.c_void_p()
         check(lib.lynse_hip_ivf_build_sharded_device(C_.c_void_p(d_local_rows.data_ptr()), int(d_local_rows.shape[0]), int(n_global), self.rank, self.world,
                                                      self.dim, int(nlist), int(max_iter), metric_from_str(metric), 1 if ivfflat_routing else 0, device,
@@ -470,6 +474,8 @@ class ShardedIvf:
                 arr = np.ctypeslib.as_array(C_.cast(buf, C_.POINTER(C_.c_float if dtype == 0 else C_.c_uint32)), shape=(int(count),))
                 if reduce is not None:
                     reduce(arr)
+                elif self.world > 1 and self.dist is None:
+                    return 1   # no reduction backend for more than one rank: every rank would train its own centroids, silently
                 elif self.dist is not None and self.world > 1:
                     import torch
 

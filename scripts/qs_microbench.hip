@@ -24,6 +24,7 @@
 
 #include "../lynsedb_amd/csrc/kernels.h"
 #include "../lynsedb_amd/csrc/scan_qs.h"
+#include "../lynsedb_amd/csrc/scan_qs2.h"
 
 using namespace lynse;
 
@@ -224,6 +225,16 @@ static void launch_qs(ScanArgs a, uint32_t grid, hipStream_t st) {
     }
     hipLaunchKernelGGL(k, dim3(g), dim3(512), lds, st, a);
 }
+// one wave per SIMD, two 32-query blocks per wave (scan_qs2.h)
+template <int NSLAB, int RB, int NS, int NBUF, int DBG>
+static void launch_qs2(ScanArgs a, uint32_t grid, hipStream_t st) {
+    auto k = k_scan_qs2<NSLAB, RB, NS, NBUF, DBG>;
+    constexpr size_t lds = (size_t)NS * NSLAB * RB * 32 * 128;
+    static bool done = false;
+    if (!done) { set_lds(k, lds); done = true; }
+    const uint32_t nt = (a.row1 - a.row0 + RB * 32 - 1) / (RB * 32);
+    hipLaunchKernelGGL(k, dim3(std::min(grid, nt)), dim3(256), lds, st, a);
+}
 // the round-3 squared-L2 kernel on the plain codes (<4,2,2,4> tiling, DENSE float epilogue, norm ring)
 static void launch_old_l2(ScanArgs a, uint32_t grid, hipStream_t st) {
     auto k = k_scan_h16<4, 2, 2, 4, M_L2, 2, 2, 2, false, false, 0, false, 4, 0, 0, true>;
@@ -349,6 +360,9 @@ int main(int argc, char** argv) {
     vars.push_back({"qs RB1 SL6 NS6 XPF NBUF12 PP1", 2, launch_qs<6, 1, 6, 6, true, 12, 0, 1>, true});
     vars.push_back({"qs RB1 SL6 NS5 XPF NBUF8 PP1", 2, launch_qs<6, 1, 6, 5, true, 8, 0, 1>, true});
     vars.push_back({"qs RB2 SL6 NS3 noXPF NBUF8 PP1", 2, launch_qs<6, 2, 6, 3, false, 8, 0, 1>, true});
+    vars.push_back({"qs2 4w x 64q RB2 NS3 NBUF8", 2, launch_qs2<6, 2, 3, 8, 0>, true});
+    vars.push_back({"qs2 4w x 64q RB2 NS3 NBUF12", 2, launch_qs2<6, 2, 3, 12, 0>, true});
+    vars.push_back({"qs2 4w x 64q RB1 NS6 NBUF8", 2, launch_qs2<6, 1, 6, 8, 0>, true});
 #ifdef LYNSE_EXPERIMENTS
     vars.push_back({"qs RB1 SL6 NS6 XPF NBUF8 | no epilogue", 2, launch_qs<6, 1, 6, 6, true, 8, 16>, true});
     vars.push_back({"qs RB1 SL6 NS6 XPF NBUF8 | MFMA only", 2, launch_qs<6, 1, 6, 6, true, 8, 16 + 8 + 2>, true});
@@ -372,6 +386,20 @@ int main(int argc, char** argv) {
     vars.push_back({"qs RB1 SL6 NS6 | lone wave, MFMA + LDS + DMA", 2, launch_qs<6, 1, 6, 6, true, 8, 64 + 16>, true});
     vars.push_back({"qs RB2 SL3 NS6 | lone wave, MFMA + LDS + DMA", 2, launch_qs<6, 2, 3, 6, true, 8, 64 + 16>, true});
     vars.push_back({"old<2,4,4,2> | no epilogue", 4, launch_old<false, 16>, false});
+    vars.push_back({"qs RB2 SL6 NS3 PP1 | no epilogue", 2, launch_qs<6, 2, 6, 3, false, 8, 16, 1>, true});
+    vars.push_back({"qs RB2 SL6 NS3 PP1 | MFMA only 32x32x32", 2, launch_qs<6, 2, 6, 3, false, 8, 16 + 8 + 2, 1>, true});
+    vars.push_back({"qs RB2 SL6 NS3 PP1 | MFMA only 16x16x64", 2, launch_qs<6, 2, 6, 3, false, 8, 128 + 16 + 8 + 2, 1>, true});
+    vars.push_back({"qs RB2 SL6 NS3 PP1 | MFMA + LDS reads", 2, launch_qs<6, 2, 6, 3, false, 8, 16 + 8, 1>, true});
+    vars.push_back({"qs RB2 SL6 NS3 PP1 | DMA + MFMA", 2, launch_qs<6, 2, 6, 3, false, 8, 16 + 2, 1>, true});
+    vars.push_back({"qs RB2 SL6 NS3 PP1 | DMA only", 2, launch_qs<6, 2, 6, 3, false, 8, 16 + 2 + 1, 1>, true});
+    vars.push_back({"qs2 4w x 64q RB2 NS3 NBUF8 | no epilogue", 2, launch_qs2<6, 2, 3, 8, 16>, true});
+    vars.push_back({"qs2 4w x 64q RB2 NS3 NBUF8 | MFMA only", 2, launch_qs2<6, 2, 3, 8, 16 + 8 + 2>, true});
+    vars.push_back({"qs2 4w x 64q RB2 NS3 NBUF8 | MFMA + LDS reads", 2, launch_qs2<6, 2, 3, 8, 16 + 8>, true});
+    vars.push_back({"qs2 4w x 64q RB2 NS3 NBUF8 | DMA + MFMA", 2, launch_qs2<6, 2, 3, 8, 16 + 2>, true});
+    vars.push_back({"qs2 4w x 64q RB2 NS3 NBUF8 | phase timing qs2", 2, launch_qs2<6, 2, 3, 8, 32>, true});
+    vars.push_back({"qs2 4w x 64q RB2 NS3 NBUF8 | MFMA + LDS reads, phase timing qs2", 2, launch_qs2<6, 2, 3, 8, 32 + 16 + 8>, true});
+    vars.push_back({"qs2 4w x 64q RB2 NS3 NBUF8 | LDS reads only", 2, launch_qs2<6, 2, 3, 8, 16 + 8 + 1>, true});
+    vars.push_back({"qs RB2 SL6 NS3 PP1 | LDS reads only", 2, launch_qs<6, 2, 6, 3, false, 8, 16 + 8 + 1, 1>, true});
 #endif
 
     auto clear = [&](uint32_t nseg) {
@@ -568,6 +596,20 @@ int main(int argc, char** argv) {
                     uint32_t cmax = 0; for (uint32_t c : cnts) cmax = std::max(cmax, c);
                     printf("KEYS %s: %.0f per query on average, %zu at most; shared-region count at most %u (cap %u), segment slots %u\n", v.name.c_str(), (double)tot / NQ, mx, cmax, b.cap, a.seg);
                 }
+                if (r == rounds && v.name.find("phase timing qs2") != std::string::npos) {
+                    std::vector<unsigned long long> ph(64 * 4 * 4);
+                    CK(hipMemcpy(ph.data(), b.dbg + 4096, ph.size() * 8, hipMemcpyDeviceToHost));
+                    printf("PHASE %s\n", v.name.c_str());
+                    for (int blk : {0, 17}) {
+                        for (int w = 0; w < 4; ++w) {
+                            const unsigned long long* o = ph.data() + ((size_t)blk * 4 + w) * 4;
+                            const double tot = (double)(o[0] + o[1] + o[2] + o[3]);
+                            const double steps = (double)((n + 63) / 64) / ncu;
+                            printf("PHASE block %2d wave %d: per step  wait %6.0f  barrier %6.0f  loop %6.0f  epilogue+issue %6.0f  (sum %.0f ticks)\n", blk, w,
+                                   o[0] / steps, o[1] / steps, o[2] / steps, o[3] / steps, tot / steps);
+                        }
+                    }
+                } else
                 if (r == rounds && v.name.find("phase timing") != std::string::npos) {
                     std::vector<unsigned long long> ph(64 * 8 * 4);
                     CK(hipMemcpy(ph.data(), b.dbg + 512, ph.size() * 8, hipMemcpyDeviceToHost));
