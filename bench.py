@@ -58,7 +58,8 @@ def parse_args():
     p.add_argument("--verify-queries", type=int, default=16)
     p.add_argument("--stage0", type=int, default=0, help="override the stage-0 row count of the scan plan")
     p.add_argument("--growth", type=int, default=0, help="override the stage growth factor of the scan plan")
-    p.add_argument("--profile-every", type=int, default=4, help="HIP-event timing of the scan launches on every n-th step of the timed region")
+    p.add_argument("--profile-every", type=int, default=0, help="HIP-event timing of the scan launches on every n-th step of the timed region "
+                   "(0 = default: 4; one GPU with batches in flight: 6, and those steps run as BLOCKING calls on a drained device)")
     p.add_argument("--settle-ms", type=float, default=60.0, help="untimed steps before the warm-up until the GPU's clocks have settled (0 = none)")
     p.add_argument("--no-configs", action="store_true", help="skip the extra keys: the other BASELINE configurations and the second data distribution")
     p.add_argument("--config", default="c2", choices=["c2", "c4", "c5"],
@@ -211,13 +212,21 @@ def main():
     # here step i+1 is ENQUEUED (scan -> selects -> rescoring [-> all-gather -> merge]) before step i is waited for, each on
     # its own search context and output buffers.  Every one of the K steps is complete — overflow flags checked, results
     # final — inside the timed region.
-    in_flight = max(1, min(args.in_flight, 4)) if args.in_flight > 0 else (1 if world == 1 else 3)
+    # Round 5: ONE GPU keeps 2 batches in flight too.  Between two blocking calls the device idles for the host's turn-around
+    # (completion -> Python -> the next call's first launch: 27-34 us in the kernel trace of every step, 1.5 % of the 10M step); a
+    # second ticket hides it.  The steps whose scan launches carry HIP events (roofline) still run as blocking calls on a drained
+    # device, so that an event bracket holds one kernel and nothing it waited behind.
+    in_flight = max(1, min(args.in_flight, 4)) if args.in_flight > 0 else (2 if world == 1 else 3)
     if world > 1 and not native:
         in_flight = 1   # (the torch.distributed fallback of the exchange is a blocking collective)
+    if args.profile_every <= 0:
+        args.profile_every = 6 if (world == 1 and in_flight > 1) else 4
     outs = [sh.alloc_outputs(B, K) for _ in range(in_flight)]
     out = outs[0]
 
-    def run_steps(n):
+    def run_steps(n, drain_every=0):
+        # drain_every = n > 0 (one GPU, timed region): step 0, n, 2n, ... is the library's profiled search (profile_enable(n) counts
+        # searches from 0): it runs blocking, after the tickets in flight have been waited for
         if in_flight == 1:
             for _ in range(n):
                 sh.search_device(queries, K, metric, out)
@@ -226,6 +235,12 @@ def main():
         trace = os.environ.get("LYNSE_BENCH_TRACE_STEPS") == "1"   # (development: completions that come > 1 ms apart, to stderr)
         last = time.perf_counter()
         for i in range(n):
+            if drain_every and i % drain_every == 0:
+                for t in pending:
+                    t.wait()
+                pending = []
+                sh.search_device(queries, K, metric, out)
+                continue
             pending.append(sh.search_submit(queries, K, metric, outs[i % in_flight]))
             if len(pending) >= in_flight:
                 pending.pop(0).wait()
@@ -280,7 +295,7 @@ def main():
     sh.index.profile_get(reset=True)
     barrier()
     t_start = time.perf_counter()
-    run_steps(args.steps)
+    run_steps(args.steps, args.profile_every if (world == 1 and in_flight > 1) else 0)
     barrier()
     elapsed = time.perf_counter() - t_start
     prof = sh.index.profile_get(reset=True)
@@ -370,7 +385,8 @@ def main():
                      "tiling": hex((plan >> 16) & 0xff), "self_tightening_single_launch": bool(plan & (1 << 24))},
             "note": ("rank-0 shard; time = sum of HIP-event durations of the scan launches on the launch stream, every %d-th step of the timed region" % max(args.profile_every, 1))
                     + ("; with %d batches in flight the event brackets of a launch also hold the time it waits for CUs behind other batches' kernels "
-                       "(kernel durations proper: the one-GPU line / profiles/)" % in_flight if in_flight > 1 else ""),
+                       "(kernel durations proper: the one-GPU line / profiles/)" % in_flight if (in_flight > 1 and world > 1) else "")
+                    + ("; %d batches in flight, the event-timed steps run as blocking calls on a drained device" % in_flight if (in_flight > 1 and world == 1) else ""),
         }
         result = {
             "metric": "queries/sec, FLAT-%s %dx%d float32, batch=%d, k=%d" % (args.metric.upper(), N, D, B, K),
@@ -688,7 +704,7 @@ def run_c5(args, rank, local_rank, world, dev, dist, result_out):
     torch.cuda.synchronize()
     run_steps(20)
     run_steps(args.warmup)
-    sh.index.profile_enable(args.profile_every)
+    sh.index.profile_enable((args.profile_every if args.profile_every > 0 else 4))
     sh.index.profile_get(reset=True)
     barrier()
     t_start = time.perf_counter()
@@ -756,7 +772,7 @@ def run_c5(args, rank, local_rank, world, dev, dist, result_out):
                          "mfma_TOPs": round(ops / scan_s / 1e12, 1) if (mfma and scan_s > 0) else None,
                          "launches": launches, "avg_launch_us": round(prof["scan_us"] / launches, 2), "timed_steps": timed_steps,
                          "note": "rank-0 shard; bytes = rows x %d B (%s); HIP events around the scan launches of every %d-th step" % (
-                             bits // 2 if mfma else bits // 8, "one FP4 nibble per bit" if mfma else "packed words", max(args.profile_every, 1))},
+                             bits // 2 if mfma else bits // 8, "one FP4 nibble per bit" if mfma else "packed words", (args.profile_every if args.profile_every > 0 else 4))},
             "blocking_ms_per_batch": round(lat_ms, 4),
             "verify": {"tickets_equal_blocking_search": same, "oracle_bit_exact_on_200k_row_sample": bool(exact)},
         }

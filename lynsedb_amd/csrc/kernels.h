@@ -3201,6 +3201,14 @@ __device__ __forceinline__ uint64_t wave_min_u64(uint64_t v) {  // the minimum o
     return a < b ? a : b;
 }
 
+__device__ __forceinline__ uint64_t wave_or_u64(uint64_t v) {  // the OR over the 64 lanes, in every lane (DPP row rotations + one readlane per row)
+    v |= dpp_u64<0x128>(v);
+    v |= dpp_u64<0x124>(v);
+    v |= dpp_u64<0x122>(v);
+    v |= dpp_u64<0x121>(v);
+    return (readlane_u64(v, 0) | readlane_u64(v, 16)) | (readlane_u64(v, 32) | readlane_u64(v, 48));
+}
+
 // ------------------------------------------------------------------------------------------------
 // Block-wide bitonic sort of npow2 u64 keys in LDS (ascending).
 // ------------------------------------------------------------------------------------------------
@@ -3575,8 +3583,28 @@ __device__ __forceinline__ uint32_t select_body(const SelectArgs& a, uint64_t* k
                 s_prefix = a.exact ? m : (m & ~0xffffffffull);   // (what the passes down to last_shift leave)
             }
             __syncthreads();
-        } else
-        for (int shift = 56; shift >= last_shift; shift -= 8) {
+        } else {
+        // Round 5: digits every key shares are not worth a pass.  The candidates of a select are the rows near one threshold: their
+        // score images agree in sign, exponent and the leading mantissa bits (s_memtime stamps: ~2.5k cycles per pass, four per select
+        // and three selects per batch).  One OR-reduction of key ^ keys[0] finds the highest differing bit; the passes above it would
+        // put every key into the same bin and leave the rank unchanged — their digits go into the prefix directly.
+        int first_shift = 56;
+        {
+            __shared__ uint64_t s_wor[NT / 64];
+            const uint64_t k0 = keys[0];
+            uint64_t df = 0;
+            for (uint32_t i = tid; i < n; i += NT) df |= keys[i] ^ k0;
+            df = wave_or_u64(df);   // (DPP: six ds_bpermute round trips per 32-bit half cost as much as the pass they save)
+            if (lane == 0) s_wor[tid >> 6] = df;
+            __syncthreads();
+            df = 0;
+#pragma unroll
+            for (int w = 0; w < NT / 64; ++w) df |= s_wor[w];
+            while (first_shift >= last_shift && (df >> first_shift) == 0ull) first_shift -= 8;   // (uniform)
+            if (first_shift < 56 && tid == 0) s_prefix = k0 & (~0ull << (first_shift + 8));
+            __syncthreads();
+        }
+        for (int shift = first_shift; shift >= last_shift; shift -= 8) {
             if (tid < 256) hist[tid] = 0;
             __syncthreads();
             const uint64_t prefix = s_prefix;
@@ -3616,6 +3644,7 @@ __device__ __forceinline__ uint32_t select_body(const SelectArgs& a, uint64_t* k
                 }
             }
             __syncthreads();
+        }
         }
         stamp(2);
         kth = a.exact ? s_prefix : (s_prefix | 0xffffffffull);  // float: every row of the k-th score counts as <= kth
@@ -4191,6 +4220,57 @@ __global__ void __launch_bounds__(NT) k_select_final(TailArgs a) {
     __syncthreads();
     final_body<NT>(a.f, keys, q, n, a.f.exact != 0 || rescored, true);
     if (a.s.stamps && threadIdx.x == 0) a.s.stamps[(size_t)q * 8 + 6] = __builtin_amdgcn_s_memtime();
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_assign_pick — the arg-best epilogue of the k-means ASSIGNMENT pass (kmeans::assign_metric, kmeans.rs:237-264).
+// The assignment scores every data row ("query") against every centroid ("row" of the centroid store).  Its scan runs in the
+// lane-max mode of k_scan_h16 (emit_all = 2): per centroid tile every lane keeps the best two centroids of those it scored for a data
+// row, so the nkeys = tiles x 16 (IP tiling) / x 8 (L2, cosine tiling) keys of a data row hold its two best COARSE centroids (the
+// runner-up overall is either the best of its lane or the second of the winner's lane).  One wave per data row finds them:
+//   gap(best, runner-up) > 2E (the certified margin of k_prep_queries)  =>  exact(best) >= coarse(best) - E > coarse(c) + E >= exact(c)
+//   for every other centroid c: the row is assigned WITHOUT exact rescoring, to the centroid the reference's strict first-smaller rule
+//   picks (no tie is possible);
+//   otherwise the row goes onto the redo list and is answered by the exact top-1 search (a handful on any real data).
+// It replaces, in this shape, the emit-all scan (4096 keys per data row: 268 MB per 8192-row launch) + k_select_final<512> (446 us per
+// launch, 60 % of the training time: profiles/r04_c4_train_kernel_stats.csv).
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_assign_pick(const uint64_t* __restrict__ cand, uint32_t cap, uint32_t nkeys, const float* __restrict__ marg2,
+                                                     int asc, uint32_t nq, uint32_t q_base, uint32_t* __restrict__ out_ids,
+                                                     uint32_t* __restrict__ redo_list, uint32_t* __restrict__ redo_count) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= nq) return;   // (uniform per wave)
+    const uint64_t* keys = cand + (size_t)q * cap;
+    uint64_t b1 = KEY_SENTINEL, b2 = KEY_SENTINEL;   // this lane's best two (b1 <= b2)
+    for (uint32_t i0 = 0; i0 < nkeys; i0 += 256) {   // four loads in flight per lane
+        uint64_t kv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const uint32_t i = i0 + u * 64 + lane; kv[u] = i < nkeys ? keys[i] : KEY_SENTINEL; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint64_t lo = kv[u] < b1 ? kv[u] : b1, hi = kv[u] < b1 ? b1 : kv[u];
+            b1 = lo;
+            b2 = hi < b2 ? hi : b2;
+        }
+    }
+    const uint64_t best = wave_min_u64(b1);
+    const uint64_t second = wave_min_u64(b1 == best ? b2 : b1);   // (keys are unique: the centroid id is the low word)
+    if (lane == 0) {
+        bool decisive = false;
+        if (best != KEY_SENTINEL) {
+            if (second == KEY_SENTINEL) decisive = true;   // one centroid
+            else {
+                const float sb = key_score(best, asc != 0), ss = key_score(second, asc != 0), m2 = marg2[q];
+                decisive = asc ? (ss - sb > m2) : (sb - ss > m2);   // (NaN / infinite margins compare false: redo)
+            }
+        }
+        if (decisive) out_ids[q_base + q] = key_row(best);
+        else {
+            out_ids[q_base + q] = 0xffffffffu;
+            redo_list[atomicAdd(redo_count, 1u)] = q_base + q;
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------

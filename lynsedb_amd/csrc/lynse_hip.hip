@@ -1779,6 +1779,9 @@ static bool l2_plain(const lynse_hip_flat* h, uint64_t nqc, bool masked = false)
 // lynse_hip_flat_coarse_scores: one emit-all stage over the whole (small) shard, then stop — the candidate buffer then holds the
 // coarse score of every (row, query) exactly as the scan kernels compute it
 static thread_local bool tl_coarse_dump = false;
+// flat_assign_top1_device: the lane-max scan of the k-means assignment over EVERY tile of the (small) centroid store, then stop —
+// k_assign_pick reads the keys (kernels.h)
+static thread_local bool tl_assign = false;
 
 // One chunk (<= QCHUNK queries) whose inputs are already in the workspace (Qf for float metrics,
 // QW for binary).  Results land in ws.out_*.  `level` selects the stage plan (make_plan).
@@ -1910,7 +1913,11 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
     // sample tile; up to k = 128 the sample as a whole supplies >= 8 k keys — a clustered shard may then overflow the first
     // stage and fall back to the contiguous plan)
     const bool can_threshold_only = h16 && !binary && !filt && !no_lane_max0 && k <= 128;
-    const std::vector<Stage> plan = (sts || tl_coarse_dump) ? std::vector<Stage>{Stage{0u, (uint32_t)h->n}}
+    Stage assign_stage{0u, (uint32_t)h->n};   // (tl_assign) every 256-row tile of the store as a "sample" tile: lane-max keys, no threshold
+    assign_stage.sample_tiles = (uint32_t)((h->n + 255) / 256);
+    assign_stage.sample_stride = 256;
+    const std::vector<Stage> plan = tl_assign ? std::vector<Stage>{assign_stage}
+                                    : (sts || tl_coarse_dump) ? std::vector<Stage>{Stage{0u, (uint32_t)h->n}}
                                         : make_plan(h, k, (level == 0 && (!plan_tile || no_sample)) ? 1 : level, plan_tile, can_threshold_only,
                                                     // large k on the float tilings: the epilogue's cost is the emissions (one sample threshold over 1M x 128,
                                                     // k = 100, admits 1400 rows per query: 87 of the stage's 163 us) — a second threshold stage a quarter of the
@@ -1957,6 +1964,7 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
             LY_HIP(hipEventRecord(e0, st));
         }
         uint32_t st_nseg = 0, st_seg = 0;  // segmented emission of this stage (k_select gathers)
+        int a_emit_all_last = -1;
         if (binary && !bin_mfma) {
             BinArgs b{};
             b.P = h->packed; b.W = h->words; b.row0 = s.r0; b.row1 = s.r1; b.QW = w.QW; b.nq = nq;
@@ -2102,7 +2110,7 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
                     // at every threshold tightness measured: 1M x 128 and 4M x 128 / 768, k = 10 and 100)
                     a.dense = (!a.emit_all && waves16 == 0 && metric != M_IP && !filt && seen_before && (dense_env >= 0 ? dense_env != 0 : true)) ? 1 : 0;
                     if (!a.emit_all) seg_geometry(grid, a.dense ? 4 : ((waves16 == 3 || waves16 == 2) ? 4 : 2), &a.nseg, &a.seg);
-                    if (qchunks > 1 && !(plan.size() == 1 && a.emit_all == 1))
+                    if (qchunks > 1 && !(plan.size() == 1 && (a.emit_all == 1 || (tl_assign && a.emit_all == 2))))
                         return set_error(LYNSE_ERR_INTERNAL, "the widened pipeline runs single-stage emit-all plans only");
 #ifdef LYNSE_EXPERIMENTS
                     if (waves16 == 2) { LY_TRY((launch_scan_h16<2, 4, 4, 2, 2, 2, false>(a, metric, grid, st))); }
@@ -2144,10 +2152,15 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
             }
 #endif
             (void)variant;
+            a_emit_all_last = (int)a.emit_all;
             st_nseg = a.seg ? a.nseg : 0; st_seg = a.seg;
             plan_used_segments = plan_used_segments || a.seg != 0;
         }
         if (tl_coarse_dump) return LYNSE_OK;   // (diagnostics: the emit-all stage has written one key per row and query; nothing else runs)
+        if (tl_assign) {
+            if (a_emit_all_last != 2) return set_error(LYNSE_ERR_INTERNAL, "the assignment scan must run in lane-max mode");
+            return LYNSE_OK;   // (k_assign_pick reads the lane-max keys)
+        }
         if (tl_prof) {
             LY_HIP(hipEventRecord(e1, st));
             scan_events->push_back({*ev_used - 2, s.sample_tiles ? (uint64_t)s.sample_tiles * plan_tile
@@ -2215,6 +2228,54 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
     hipLaunchKernelGGL(k_final<SEL_NT>, dim3(nq), dim3(SEL_NT), fa.lds_bytes, st, fa);
     LY_HIP(hipGetLastError());
     (void)asc;
+    return LYNSE_OK;
+}
+
+// kmeans::assign_metric (kmeans.rs:237-264) for the device k-means: the nearest centroid of every data row, WITHOUT the general
+// top-1 search.  `h` is the centroid store (a widened handle: h->qchunk data rows per pass, <= cap centroids), d_q the data rows in
+// device memory.  Per pass of <= qchunk data rows: query image + certified margin (k_prep_queries), ONE lane-max scan over all
+// centroid tiles (run_chunk under tl_assign), k_assign_pick.  d_ids[i] = the centroid of row i, or 0xffffffff for the rows whose two
+// best coarse centroids lie within the certified margin: their indices come back in d_redo[0 .. *d_redo_count) and the caller answers
+// them with the exact top-1 search (lynse_hip_flat_search_f32_device), whose first-strictly-smaller rule they need.
+// Returns LYNSE_ERR_UNSUPPORTED when the shape is not the one this path is built for (the caller falls back to the search).
+static int flat_assign_top1_device(lynse_hip_flat* h, const float* d_q, uint64_t nq, int metric, uint32_t* d_ids, uint32_t* d_redo,
+                                   uint32_t* d_redo_count) {
+    if (!h || !d_q || !d_ids || !d_redo || !d_redo_count) return set_error(LYNSE_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (metric < M_IP || metric > M_COS) return set_error(LYNSE_ERR_UNSUPPORTED, "float metrics only");
+    LY_WRITER(h, lk);
+    LY_TRY(use_device(h));
+    if (scan_variant() != 3 || h->n == 0 || h->n > h->cap || h->qchunk <= QCHUNK || h->packed_only || h->dtype != LYNSE_DTYPE_F32)
+        return set_error(LYNSE_ERR_UNSUPPORTED, "not the widened float shape of the assignment pass");
+    struct Slot0 { int prev; Slot0() : prev(tl_ctx_slot) { tl_ctx_slot = 0; } ~Slot0() { tl_ctx_slot = prev; } } scope;
+    LY_TRY(finalize_locked(h));
+    if (metric == M_COS && h->cos_degenerate) return set_error(LYNSE_ERR_UNSUPPORTED, "degenerate norms: the exact search answers");
+    LY_TRY(ensure_shadow_locked(h));
+    LY_TRY(ensure_workspace(h, 1));
+    Workspace& w = cur(h).ws;
+    hipStream_t st = cur(h).stream;
+    const uint32_t ntiles = (uint32_t)((h->n + 255) / 256);
+    const uint32_t nkeys = ntiles * ((metric == M_IP) ? 16u : 8u);   // 2 WR lanes per tile and data row x their best two (<2,4,4,2> / <4,2,2,4>)
+    if (nkeys > w.cap) return set_error(LYNSE_ERR_UNSUPPORTED, "lane-max keys exceed the candidate slots");
+    LY_HIP(hipMemsetAsync(d_redo_count, 0, 4, st));
+    size_t ev_used = 0;
+    std::vector<std::pair<size_t, uint64_t>> scan_events;
+    struct Flag { Flag() { tl_assign = true; } ~Flag() { tl_assign = false; } } flag;
+    const bool prof_prev = tl_prof;
+    tl_prof = false;
+    int rc = LYNSE_OK;
+    for (uint64_t q0 = 0; q0 < nq && rc == LYNSE_OK; q0 += w.qcap) {
+        const uint32_t nqc = (uint32_t)std::min<uint64_t>(w.qcap, nq - q0);
+        bool sampled = false;
+        rc = run_chunk(h, nqc, 1, 1, metric, 0, st, &ev_used, &scan_events, &sampled, nullptr, nullptr, false, nullptr, nullptr, nullptr, nullptr,
+                       d_q + q0 * h->dim, false, false, nullptr);
+        if (rc != LYNSE_OK) break;
+        hipLaunchKernelGGL(k_assign_pick, dim3((nqc + 3) / 4), dim3(256), 0, st, w.cand, w.cap, nkeys, w.marg2, metric_ascending(metric) ? 1 : 0,
+                           nqc, (uint32_t)q0, d_ids, d_redo, d_redo_count);
+        if (hipGetLastError() != hipSuccess) rc = set_error(LYNSE_ERR_DEVICE, "k_assign_pick launch failed");
+    }
+    tl_prof = prof_prev;
+    if (rc != LYNSE_OK) { (void)hipStreamSynchronize(st); return rc; }
+    LY_HIP(hipStreamSynchronize(st));
     return LYNSE_OK;
 }
 
