@@ -325,8 +325,8 @@ struct lynse_hip_flat {
     uint32_t* g_ids32 = nullptr;
     uint64_t g_cap = 0;
 
-    bool profiling = false;
-    uint32_t prof_rate = 1;              // every prof_rate-th search records its events (lynse_hip_flat_profile_enable(h, n))
+    std::atomic<bool> profiling{false};   // (read by searches without the lock: atomics)
+    std::atomic<uint32_t> prof_rate{1};              // every prof_rate-th search records its events (lynse_hip_flat_profile_enable(h, n))
     std::atomic<uint32_t> prof_seq{0};
     lynse_hip_profile prof{};
 };
@@ -401,7 +401,8 @@ static int writer_lock(lynse_hip_flat* h, std::unique_lock<std::shared_mutex>& l
 
 // decides whether the search starting on this thread is a timed one (profiling on, and its turn at the sampling rate)
 static bool profile_begin_search(lynse_hip_flat* h) {
-    tl_prof = h->profiling && (h->prof_rate <= 1 || h->prof_seq.fetch_add(1) % h->prof_rate == 0);
+    const uint32_t rate = h->prof_rate.load();
+    tl_prof = h->profiling.load() && (rate <= 1 || h->prof_seq.fetch_add(1) % rate == 0);
     return tl_prof;
 }
 
@@ -1069,7 +1070,7 @@ static int launch_scan(lynse_hip_flat* h, const ScanArgs& a, int metric, uint32_
     constexpr int NT = WQ * WR * 64;
     constexpr int BQ = WQ * TQ * 32;
     const size_t lds = scan_lds_bytes(BQ);
-    static bool attr_done[3] = {false, false, false};
+    static std::atomic<bool> attr_done[3] = {false, false, false};
     auto go = [&](auto kern, int slot) -> int {
         if (!attr_done[slot]) {
             LY_TRY(set_max_lds(kern, lds));
@@ -1093,7 +1094,7 @@ static int launch_scan_glds(const ScanArgs& a, int metric, bool scale, uint32_t 
     constexpr int BQ = WQ * TQ * 32;
     constexpr int BR = WR * TR * 32;
     const size_t lds = (size_t)NS * (BR * GL_BK * 4 + BQ * GL_BK * 2) + (metric == M_IP ? 0 : (size_t)NS * 1024);  // + per-tile norm ring
-    static bool attr_done[12] = {false};
+    static std::atomic<bool> attr_done[12] = {false};
     static const int nt_hint = []() { const char* e = getenv("LYNSE_HIP_SCAN_NT"); return e ? atoi(e) : 1; }();
     auto go = [&](auto kern, int slot) -> int {
         if (!attr_done[slot]) {
@@ -1173,7 +1174,7 @@ static int launch_scan_h16(const ScanArgs& a, int metric, uint32_t grid, hipStre
     constexpr int BQ = WQ * TQ * 32, BR = WR * TR * 32;
     constexpr size_t rings = (size_t)(NSV * BR + NSQ * BQ) * (HK * 2);
     const size_t lds = (rings + (NSV + 1) * 1024 <= 160 * 1024) ? rings + (NSV + 1) * 1024 : rings;
-    static bool attr_done[64] = {false};
+    static std::atomic<bool> attr_done[64] = {false};
     auto go = [&](auto kern, int slot) -> int {
         if (!attr_done[slot]) { LY_TRY(set_max_lds(kern, lds)); attr_done[slot] = true; }
         hipLaunchKernelGGL(kern, dim3(grid, grid_y), dim3(WQ * WR * 64), lds, st, a);
@@ -1304,7 +1305,7 @@ static int launch_scan_h16(const ScanArgs& a, int metric, uint32_t grid, hipStre
 // rings) over the SQ8 codes — HBM-bound like its f16 twin, at half the bytes; emission mode at run time (EMIT = -1)
 static int launch_scan_i8c_small(const ScanArgs& a, uint32_t grid, hipStream_t st, bool l2n = false, bool filt = false) {
     constexpr size_t lds = (size_t)(3 * 128 + 3 * 32) * 128;
-    static bool attr_done[4] = {false, false, false, false};
+    static std::atomic<bool> attr_done[4] = {false, false, false, false};
     if (filt) {   // masked scan of a small batch (row bitmask in the epilogue): whole slabs
         if (a.ld16 % 128 != 0 || a.row_ids || l2n) return set_error(LYNSE_ERR_INTERNAL, "the masked int8 scan needs whole 128-column slabs and a row bitmask");
         auto kern = k_scan_h16<1, 4, 1, 1, M_IP, 3, 3, 2, false, false, 0, true, 2>;
@@ -1347,7 +1348,7 @@ static uint32_t qs_l2_rows(const ScanArgs& a) {
     return 0;
 }
 static int launch_scan_qs_l2(const ScanArgs& a, uint32_t grid, hipStream_t st) {
-    static bool attr_done[8] = {false};
+    static std::atomic<bool> attr_done[8] = {false};
     auto go = [&](auto kern, int slot, size_t lds) -> int {
         if (!attr_done[slot]) { LY_TRY(set_max_lds(kern, lds)); attr_done[slot] = true; }
         hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, a);
@@ -1368,7 +1369,7 @@ static int launch_scan_qs_l2(const ScanArgs& a, uint32_t grid, hipStream_t st) {
 static int launch_scan_i8l2(const ScanArgs& a, uint32_t grid, hipStream_t st, bool qs = false) {
     if (qs) return launch_scan_qs_l2(a, grid, st);
     constexpr size_t lds = (size_t)(2 * 256 + 2 * 256) * 128 + 3 * 1024;
-    static bool attr_done[4] = {false, false, false, false};
+    static std::atomic<bool> attr_done[4] = {false, false, false, false};
     auto go = [&](auto kern, int slot) -> int {
         if (!attr_done[slot]) { LY_TRY(set_max_lds(kern, lds)); attr_done[slot] = true; }
         hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, a);
@@ -1386,7 +1387,7 @@ static int launch_scan_i8l2(const ScanArgs& a, uint32_t grid, hipStream_t st, bo
 // and of 65..128 queries (256 rows x 128 queries, 8 waves as 2 x 4, 3 + 2 stages): per row byte they do a quarter / half of the
 // MFMA and fragment-read work of the 256-query tiling, which a batch of 40 or 100 queries would otherwise pay in full
 static int launch_scan_i8c_mid(const ScanArgs& a, uint32_t grid, hipStream_t st, bool wide, bool l2n = false, bool filt = false) {
-    static bool attr_done[8] = {false, false, false, false, false, false, false, false};
+    static std::atomic<bool> attr_done[8] = {false, false, false, false, false, false, false, false};
     const bool rag = a.ld16 % 128 != 0;
     if (filt) {   // masked scan (row bitmask in the epilogue): whole slabs
         if (rag || a.row_ids || l2n) return set_error(LYNSE_ERR_INTERNAL, "the masked int8 scan needs whole 128-column slabs and a row bitmask");
@@ -1484,7 +1485,7 @@ static uint32_t qs_grid(const ScanArgs& a, uint32_t num_cu) {
     return std::min<uint32_t>((a.row1 - a.row0 + rt - 1) / rt, cus);
 }
 static int launch_scan_qs(const ScanArgs& a, uint32_t grid, hipStream_t st) {
-    static bool attr_done[5] = {false, false, false, false, false};
+    static std::atomic<bool> attr_done[5] = {false, false, false, false, false};
     if (a.dyn_thr) {   // self-tightening thresholds: the whole shard in one launch (scan_qs.h, STS)
         auto kern = k_scan_qs<6, 2, 6, 3, false, 8, 0, 0, 1>;
         constexpr size_t lds = (size_t)3 * 6 * 64 * 128 + QS_STS_LDS;
@@ -1500,7 +1501,7 @@ static int launch_scan_qs(const ScanArgs& a, uint32_t grid, hipStream_t st) {
         return LYNSE_OK;
     };
     if (a.mask) return go(k_scan_qs<6, 2, 6, 3, false, 8, 0, 1, 0, 0, 0, 1>, 0, (size_t)3 * 6 * 64 * 128);   // masked threshold stages (MSK)
-    static bool attr_w[8] = {false};
+    static std::atomic<bool> attr_w[8] = {false};
     auto gow = [&](auto kern, int slot, size_t lds) -> int {
         if (!attr_w[slot]) { LY_TRY(set_max_lds(kern, lds)); attr_w[slot] = true; }
         hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, a);
@@ -1532,7 +1533,7 @@ static bool qs_sample_ok(const ScanArgs& a, bool fs, bool filt, bool f4, uint32_
            a.skip_stride == 0 && !a.mask && !a.row_ids && a.row1 > a.row0;
 }
 static int launch_scan_qs_sample(const ScanArgs& a, uint32_t grid, hipStream_t st) {
-    static bool attr_done[8] = {false};
+    static std::atomic<bool> attr_done[8] = {false};
     auto go = [&](auto kern, int slot, size_t lds) -> int {
         if (!attr_done[slot]) { LY_TRY(set_max_lds(kern, lds)); attr_done[slot] = true; }
         hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, a);
@@ -1551,7 +1552,7 @@ static int launch_scan_qs_sample(const ScanArgs& a, uint32_t grid, hipStream_t s
 static int launch_scan_i8c(const ScanArgs& a, uint32_t grid, hipStream_t st, bool fs = false, bool filt = false, bool f4 = false, bool qs = false) {
     constexpr size_t lds = (size_t)(3 * 256 + 2 * 256) * 128;
     if (qs && f4) {   // batched Hamming on the query-stationary tiling (scan_qs.h, F4)
-        static bool attr_f4[3] = {false, false, false};
+        static std::atomic<bool> attr_f4[3] = {false, false, false};
         auto gof = [&](auto kern, int slot, size_t qlds) -> int {
             if (!attr_f4[slot]) { LY_TRY(set_max_lds(kern, qlds)); attr_f4[slot] = true; }
             hipLaunchKernelGGL(kern, dim3(grid), dim3(512), qlds, st, a);
@@ -1563,7 +1564,7 @@ static int launch_scan_i8c(const ScanArgs& a, uint32_t grid, hipStream_t st, boo
         return gof(k_scan_qs<4, 2, 4, 3, false, 8, 0, 1, 0, 0, 0, 0, 1>, 1, (size_t)3 * 4 * 64 * 128);
     }
     if (qs) return launch_scan_qs(a, grid, st);
-    static bool attr_done[16] = {false};
+    static std::atomic<bool> attr_done[16] = {false};
     auto go = [&](auto kern, int slot) -> int {
         if (!attr_done[slot]) { LY_TRY(set_max_lds(kern, lds)); attr_done[slot] = true; }
         hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, a);
@@ -1611,7 +1612,7 @@ static int launch_scan_i8c(const ScanArgs& a, uint32_t grid, hipStream_t st, boo
     // stages over whole 128-column slabs (LYNSE_HIP_AG=1; the sample stages keep the 8-wave kernels)
     const int ag_env = []() { const char* e = getenv("LYNSE_HIP_AG"); return e ? atoi(e) : 0; }();   // (read per call: A/B, tests)
     if (ag_env && a.ld16 % 128 == 0 && a.emit_all == 0 && !fs) {
-        static bool ag_attr[2] = {false, false};
+        static std::atomic<bool> ag_attr[2] = {false, false};
         auto go4 = [&](auto kern, int slot) -> int {
             if (!ag_attr[slot]) { LY_TRY(set_max_lds(kern, lds)); ag_attr[slot] = true; }
             hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a);
@@ -1623,10 +1624,10 @@ static int launch_scan_i8c(const ScanArgs& a, uint32_t grid, hipStream_t st, boo
     }
     if (a.ld16 % 128 == 0) {
         static const int prio = []() { const char* e = getenv("LYNSE_HIP_PRIO"); return e ? atoi(e) : 0; }();
-        static bool prattr = false;
+        static std::atomic<bool> prattr = false;
         if (a.emit_all == 0 && prio) { auto k = k_scan_h16<2, 4, 4, 2, M_IP, 3, 2, 2, false, false, 0, false, 2, 0, 0, false, true>; if (!prattr) { LY_TRY(set_max_lds(k, lds)); prattr = true; } hipLaunchKernelGGL(k, dim3(grid), dim3(512), lds, st, a); LY_HIP(hipGetLastError()); return LYNSE_OK; }
         static const int place = []() { const char* e = getenv("LYNSE_HIP_PLACE"); return e ? atoi(e) : 0; }();
-        static bool pattr[2] = {false, false};
+        static std::atomic<bool> pattr[2] = {false, false};
         if (a.emit_all == 0 && place == 1) { auto k = k_scan_h16<2, 4, 4, 2, M_IP, 3, 2, 2, false, false, 0, false, 2, 0, 1>; if (!pattr[0]) { LY_TRY(set_max_lds(k, lds)); pattr[0] = true; } hipLaunchKernelGGL(k, dim3(grid), dim3(512), lds, st, a); LY_HIP(hipGetLastError()); return LYNSE_OK; }
         if (a.emit_all == 0 && place == 2) { auto k = k_scan_h16<2, 4, 4, 2, M_IP, 3, 2, 2, false, false, 0, false, 2, 0, 2>; if (!pattr[1]) { LY_TRY(set_max_lds(k, lds)); pattr[1] = true; } hipLaunchKernelGGL(k, dim3(grid), dim3(512), lds, st, a); LY_HIP(hipGetLastError()); return LYNSE_OK; }
         if (fs) {  // fused sample stage: sample tile + in-launch thresholds + the first threshold stage (kernels.h, FS)
@@ -1692,7 +1693,7 @@ static int ensure_shadow_locked(lynse_hip_flat* h) {
 }
 
 static int launch_scan_binary(const BinArgs& a, int metric, uint32_t grid, size_t lds, hipStream_t st) {
-    static bool attr_done[3] = {false, false, false};
+    static std::atomic<bool> attr_done[3] = {false, false, false};
     auto go = [&](auto kern, int slot) -> int {
         if (!attr_done[slot]) {
             LY_TRY(set_max_lds(kern, 160 * 1024 - 64));
@@ -1723,7 +1724,7 @@ static int launch_scan_binary_wide(const BinArgs& a, int metric, uint32_t grid, 
 // lane-per-row batched kernel: WCAP = the power of two >= words
 template <int KIND>
 static int launch_scan_binary_rows_k(const BinArgs& a, uint32_t grid, hipStream_t st) {
-    static bool attr_done[12] = {false};
+    static std::atomic<bool> attr_done[12] = {false};
     auto go = [&](auto kern, int wcap, int slot) -> int {
         const size_t lds = (size_t)4 * 64 * bin_rows_stride(wcap);
         if (!attr_done[slot]) { LY_TRY(set_max_lds(kern, lds)); attr_done[slot] = true; }
@@ -1840,7 +1841,7 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
     if (mask || row_ids) ip_form = LYNSE_IPFORM_SINGLE;
     if (h->dtype == LYNSE_DTYPE_F16) ip_form = LYNSE_IPFORM_F16SEQ;  // every f16 path of the reference uses the sequential kernels  // search_filtered scores every row with the single-row kernels (flat_mmap.rs:553-560)
 
-    static bool sel_attr = false;
+    static std::atomic<bool> sel_attr = false;
     if (!sel_attr) {
         LY_TRY(set_max_lds(k_select<SEL_NT>, SEL_LDS_MAX));
         LY_TRY(set_max_lds(k_final<SEL_NT>, SEL_LDS_MAX));
@@ -2322,7 +2323,7 @@ static int run_small(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
     if (const char* ge = getenv("LYNSE_HIP_SMALL_GRID")) grid = std::max(1u, std::min<uint32_t>(grid, (uint32_t)atoi(ge)));   // development
     auto pow2_at_least = [](uint32_t v) { uint32_t p = 2; while (p < v) p <<= 1; return p; };
     const size_t lds = (size_t)((h->dim + 3) / 4 * 4) * 4 + (size_t)SMALL_NT * 8 + (size_t)pow2_at_least(std::min<uint32_t>(k, grid) * k) * 8 + 64;  // the query, the wave lists (later the heads of the merge), the merge's candidate keys
-    static bool small_attr = false;
+    static std::atomic<bool> small_attr = false;
     if (!small_attr) { LY_TRY(set_max_lds(k_small_search, 160 * 1024 - 1024)); small_attr = true; }
     hipEvent_t e0 = nullptr, e1 = nullptr;
     const bool timed = tl_prof && ev_used && scan_events;
@@ -2569,7 +2570,7 @@ static int run_chunk_sq8(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t ou
     const bool ip = metric == M_IP;
     const int m1 = ip ? M_IP : M_L2;  // cosine ranks the codes by squared L2 too (:5887-5890)
     const uint32_t nslab = (h->dim + 127) / 128, qpad = SCAN_BQ_LARGE;
-    static bool attr = false;
+    static std::atomic<bool> attr = false;
     if (!attr) {
         LY_TRY(set_max_lds(k_select<SEL_NT>, SEL_LDS_MAX));
         LY_TRY(set_max_lds(k_final<SEL_NT>, SEL_LDS_MAX));
@@ -2592,7 +2593,7 @@ static int run_chunk_sq8(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t ou
         a.candB = w.candB; a.segcnt = w.segcnt;
         if (!a.emit_all) seg_geometry(grid, 2, &a.nseg, &a.seg);
         constexpr size_t lds = (size_t)(2 * 256 + 2 * 256) * 128 + 3 * 1024;
-        static bool a2[2] = {false, false};
+        static std::atomic<bool> a2[2] = {false, false};
         if (ip) {
             auto kern = k_scan_h16<4, 2, 2, 4, M_IP, 2, 2, 2, false, true, 0, false, 1>;
             if (!a2[0]) { LY_TRY(set_max_lds(kern, lds)); a2[0] = true; }
@@ -3604,7 +3605,7 @@ static int merge_topk_device_impl(const void* d_blocks, uint64_t block_bytes, ui
     if (total > 8192) return set_error(LYNSE_ERR_UNSUPPORTED, "n_lists * k exceeds the merge kernel capacity (8192)");
     uint32_t np2 = 2;
     while (np2 < total) np2 <<= 1;
-    static bool attr = false;
+    static std::atomic<bool> attr = false;
     if (!attr) {
         LY_TRY(set_max_lds(k_merge<256>, 8192 * 12));
         attr = true;
@@ -3626,6 +3627,40 @@ extern "C" int lynse_hip_merge_topk_device(const void* d_blocks, uint64_t block_
     return merge_topk_device_impl(d_blocks, block_bytes, rows_off, dists_off, counts_off, n_lists, nq, k, metric, d_out_rows,
                                   d_out_dists, d_out_counts, stream, 0, nullptr);
 }
+
+// ---------------------------------------------------------------------------------------------- bounded waits ----
+// Every host wait that ends in a COLLECTIVE (the all-gather of a sharded batch, the all-reduce of a Lloyd iteration) is bounded: a rank
+// that died or returned early must not strand its peers inside hipStreamSynchronize for good.  The reference's coordinator retries a
+// shard once and errors (src/cluster.rs:243-261).  lynse_hip_set_wait_timeout_ms / LYNSE_HIP_WAIT_TIMEOUT_MS; 0 = 30 s for waits behind a
+// collective, unbounded for one shard alone.
+static std::atomic<uint32_t> g_wait_timeout_ms{[]() { const char* e = getenv("LYNSE_HIP_WAIT_TIMEOUT_MS"); return e ? (uint32_t)atoll(e) : 0u; }()};
+extern "C" int lynse_hip_set_wait_timeout_ms(uint32_t ms) { g_wait_timeout_ms.store(ms); return LYNSE_OK; }
+static uint32_t collective_timeout_ms() { const uint32_t to = g_wait_timeout_ms.load(); return to ? to : 30000u; }
+
+// hipEventSynchronize with an upper bound: polls the event (spinning first: a batch is a millisecond or two), sleeps in between
+static int event_wait_bounded(hipEvent_t ev, uint32_t timeout_ms) {
+    if (timeout_ms == 0) { LY_HIP(hipEventSynchronize(ev)); return LYNSE_OK; }
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        const hipError_t q = hipEventQuery(ev);
+        if (q == hipSuccess) return LYNSE_OK;
+        if (q != hipErrorNotReady) return set_error(LYNSE_ERR_DEVICE, std::string("hipEventQuery: ") + hipGetErrorString(q));
+        const auto el = std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
+        if (el > (int64_t)timeout_ms * 1000) return set_error(LYNSE_ERR_TIMEOUT, "the batch did not finish within the wait timeout (a rank of the collective is gone?)");
+        if (el > 2000) std::this_thread::sleep_for(std::chrono::microseconds(el > 100000 ? 1000 : 50));
+    }
+}
+// ... of everything enqueued on `st` so far, through an event of the caller (created on first use)
+static int stream_wait_bounded(hipStream_t st, hipEvent_t* ev, uint32_t timeout_ms) {
+    if (!*ev) LY_HIP(hipEventCreateWithFlags(ev, hipEventDisableTiming));
+    LY_HIP(hipEventRecord(*ev, st));
+    return event_wait_bounded(*ev, timeout_ms);
+}
+// Status word of a result block (comm_block_layout): bit 0 = a query of that shard overflowed its candidate buffers (the batch is
+// re-answered on the next plan level, on every rank); any other bit = that rank FAILED while it built its block — it still takes
+// part in the exchange (with an empty block), so that its peers learn of it from the merged word instead of from a timeout.
+constexpr uint32_t STATUS_OVERFLOW = 1u;
+static inline bool status_failed(uint32_t st) { return (st & ~STATUS_OVERFLOW) != 0u; }
 
 #include "ivf_host.inc"
 #include "shard_host.inc"

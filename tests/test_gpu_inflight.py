@@ -237,3 +237,45 @@ def test_sharded_submit_with_a_one_rank_communicator(L, oracle):
         r, d, c = o.rows.cpu().numpy().view(np.uint64), o.dists.cpu().numpy(), o.counts.cpu().numpy()
         for qi in (0, 63, nq - 1):
             _assert_oracle(oracle, b[qi], data, k, IP, r[qi], d[qi], c[qi], qi)
+
+
+def test_a_ticket_that_needs_the_lazy_f16_shadow_while_int8_tickets_are_outstanding(L, oracle):
+    """the f16 shadow is a lazy copy — a shard that has only answered int8 batches does not hold it.  A batch that needs it
+    (<= 32 queries on a shard under 256K rows; L2 below 256 dimensions) submitted while int8 tickets are outstanding used to fail in
+    submit ("cannot be pipelined"), and on a sharded collection that rank's peers stalled in the all-gather.  Now submit builds the
+    copy under the handle's exclusive lock; both kinds of ticket are in flight together and equal the oracle."""
+    import torch
+
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(17)
+    n, dim, k = 100_000, 64, 10
+    data = rng.random((n, dim), dtype=f32)
+    for with_comm in (False, True):
+        idx = L.FlatIndex(None, dim)
+        idx.write(data)
+        idx.finalize()
+        comm = None
+        if with_comm:
+            from lynsedb_amd.sharded import NativeComm
+            try:
+                comm = NativeComm(None, 0, 1, 0)      # a 1-rank communicator: the sharded code path without a second GPU
+            except Exception as e:  # noqa: BLE001
+                pytest.skip("RCCL unavailable: %r" % (e,))
+        big = (data[rng.integers(0, n, 64)] + 0.02 * rng.standard_normal((64, dim))).astype(f32)     # 64 queries, IP: certified int8 pass
+        small = (data[rng.integers(0, n, 8)] + 0.02 * rng.standard_normal((8, dim))).astype(f32)     # 8 queries: the f16 shadow (shard < 256K rows)
+        l2q = (data[rng.integers(0, n, 40)] + 0.02 * rng.standard_normal((40, dim))).astype(f32)     # L2 at 64 dimensions: the f16 shadow
+        dbig, dsmall, dl2 = (torch.as_tensor(x, device=dev) for x in (big, small, l2q))
+        o1, o2, o3, o4 = _tensors(torch, 64, k, dev), _tensors(torch, 8, k, dev), _tensors(torch, 40, k, dev), _tensors(torch, 64, k, dev)
+        kw = {"comm": comm.handle} if comm is not None else {}
+        t1 = idx.search_submit(dbig, k, "ip", *o1, **kw)
+        t2 = idx.search_submit(dsmall, k, "ip", *o2, **kw)     # needs the shadow while t1 is outstanding
+        t3 = idx.search_submit(dl2, k, "l2", *o3, **kw)
+        t4 = idx.search_submit(dbig, k, "ip", *o4, **kw)
+        for t in (t1, t2, t3, t4):
+            t.wait()
+        for (o, q, metric, name) in ((o1, big, IP, "big"), (o2, small, IP, "small"), (o3, l2q, L2, "l2"), (o4, big, IP, "big again")):
+            r, d, c = _host(o)
+            for qi in (0, len(q) - 1):
+                _assert_oracle(oracle, q[qi], data, k, metric, r[qi], d[qi], c[qi], (with_comm, name, qi))
+        if comm is not None:
+            comm.close()
