@@ -4237,40 +4237,77 @@ __global__ void __launch_bounds__(NT) k_select_final(TailArgs a) {
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_assign_pick(const uint64_t* __restrict__ cand, uint32_t cap, uint32_t nkeys, const float* __restrict__ marg2,
                                                      int asc, uint32_t nq, uint32_t q_base, uint32_t* __restrict__ out_ids,
-                                                     uint32_t* __restrict__ redo_list, uint32_t* __restrict__ redo_count) {
-    const int lane = threadIdx.x & 63;
-    const uint32_t q = blockIdx.x * 4 + (threadIdx.x >> 6);
+                                                     uint32_t* __restrict__ redo_list, uint32_t* __restrict__ redo_count,
+                                                     const float* __restrict__ Qf, const float* __restrict__ V, uint32_t ld, uint32_t D,
+                                                     int metric, int ip_form) {
+    // Near-ties (round 5, second step): with more lists than the data has clusters the sibling centroids of a cluster score within the
+    // f16 margin of each other for MOST rows (6.25M x 768, 1024 clusters under 4096 lists: the redo path answered so many rows that
+    // training took 19 s).  The lane-max keys come in pairs — slot 2j = the best, slot 2j + 1 = the second best centroid of one scan
+    // lane — so the set S of centroids within 2E of the best coarse score is COMPLETE whenever no second-best key lies inside the
+    // margin (then every scan lane holds at most one member of S, its best).  The members of S (<= ASSIGN_CMAX) are scored exactly with
+    // the reference's single-row kernels, 8 lanes per candidate, and the canonical minimum (score, centroid id) — the reference's
+    // first-strictly-smaller rule — is the assignment.  Only rows with a hidden candidate or an over-full S go to the redo list.
+    constexpr uint32_t ASSIGN_CMAX = 16;
+    __shared__ uint64_t s_c[4][ASSIGN_CMAX];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const uint32_t q = blockIdx.x * 4 + (uint32_t)w;
     if (q >= nq) return;   // (uniform per wave)
+    const bool up = asc != 0;
     const uint64_t* keys = cand + (size_t)q * cap;
-    uint64_t b1 = KEY_SENTINEL, b2 = KEY_SENTINEL;   // this lane's best two (b1 <= b2)
+    uint64_t b1 = KEY_SENTINEL;
     for (uint32_t i0 = 0; i0 < nkeys; i0 += 256) {   // four loads in flight per lane
         uint64_t kv[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) { const uint32_t i = i0 + u * 64 + lane; kv[u] = i < nkeys ? keys[i] : KEY_SENTINEL; }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const uint64_t lo = kv[u] < b1 ? kv[u] : b1, hi = kv[u] < b1 ? b1 : kv[u];
-            b1 = lo;
-            b2 = hi < b2 ? hi : b2;
-        }
+        for (int u = 0; u < 4; ++u) b1 = kv[u] < b1 ? kv[u] : b1;
     }
     const uint64_t best = wave_min_u64(b1);
-    const uint64_t second = wave_min_u64(b1 == best ? b2 : b1);   // (keys are unique: the centroid id is the low word)
-    if (lane == 0) {
-        bool decisive = false;
-        if (best != KEY_SENTINEL) {
-            if (second == KEY_SENTINEL) decisive = true;   // one centroid
-            else {
-                const float sb = key_score(best, asc != 0), ss = key_score(second, asc != 0), m2 = marg2[q];
-                decisive = asc ? (ss - sb > m2) : (sb - ss > m2);   // (NaN / infinite margins compare false: redo)
+    const float sb = key_score(best, up), m2 = marg2[q];
+    bool hidden = false;
+    uint32_t ncand = 0;
+    if (best != KEY_SENTINEL) {
+        for (uint32_t i0 = 0; i0 < nkeys; i0 += 64) {   // (the keys again: L2-resident, 2 KB per row)
+            const uint32_t i = i0 + lane;
+            const uint64_t key = i < nkeys ? keys[i] : KEY_SENTINEL;
+            const float sc = key_score(key, up);
+            const bool in = key != KEY_SENTINEL && (up ? (sc - sb <= m2) : (sb - sc <= m2));   // (NaN compares false)
+            const bool second = (i & 1u) != 0u;
+            hidden = hidden || __ballot(in && second) != 0ull;
+            const uint64_t m = __ballot(in && !second);
+            if (in && !second) {
+                const uint32_t pos = ncand + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                if (pos < ASSIGN_CMAX) s_c[w][pos] = key;
             }
+            ncand += (uint32_t)__popcll(m);
         }
-        if (decisive) out_ids[q_base + q] = key_row(best);
-        else {
+    }
+    // (sb - sb <= m2 holds for the best key itself unless the score or the margin is NaN / the difference of infinities: then ncand = 0)
+    const bool decided = best != KEY_SENTINEL && !hidden && ncand >= 1 && ncand <= ASSIGN_CMAX;
+    if (!decided) {   // (uniform)
+        if (lane == 0) {
             out_ids[q_base + q] = 0xffffffffu;
             redo_list[atomicAdd(redo_count, 1u)] = q_base + q;
         }
+        return;
     }
+    if (ncand == 1) {   // the best coarse centroid is alone inside the margin: exact(best) > exact(c) for every other c, no rescoring
+        if (lane == 0) out_ids[q_base + q] = key_row(best);
+        return;
+    }
+    __builtin_amdgcn_wave_barrier();
+    const float* qv = Qf + (size_t)(q_base + q) * D;
+    const int g = lane & 7;
+    uint64_t bestx = KEY_SENTINEL;
+    for (uint32_t r0 = 0; r0 < ncand; r0 += 8) {   // 8 candidates per trip, 8 lanes each (uniform control flow inside exact_score)
+        const uint32_t j = r0 + (uint32_t)(lane >> 3);
+        const uint32_t crow = key_row(s_c[w][j < ncand ? j : 0u]);
+        const float sc = exact_score<32>(metric, ip_form, qv, V + (size_t)crow * ld, D, g);
+        const uint64_t key = j < ncand ? make_key(sc, crow, up) : KEY_SENTINEL;
+        const uint64_t mn = wave_min_u64(key);
+        bestx = mn < bestx ? mn : bestx;
+    }
+    if (lane == 0) out_ids[q_base + q] = key_row(bestx);
 }
 
 // ------------------------------------------------------------------------------------------------

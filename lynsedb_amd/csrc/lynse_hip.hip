@@ -2270,8 +2270,10 @@ static int flat_assign_top1_device(lynse_hip_flat* h, const float* d_q, uint64_t
         rc = run_chunk(h, nqc, 1, 1, metric, 0, st, &ev_used, &scan_events, &sampled, nullptr, nullptr, false, nullptr, nullptr, nullptr, nullptr,
                        d_q + q0 * h->dim, false, false, nullptr);
         if (rc != LYNSE_OK) break;
+        int ip_form = h->ip_form;
+        if (ip_form == LYNSE_IPFORM_AUTO) ip_form = h->n < 4096 ? LYNSE_IPFORM_SINGLE : LYNSE_IPFORM_BATCH8;   // (run_chunk's rule)
         hipLaunchKernelGGL(k_assign_pick, dim3((nqc + 3) / 4), dim3(256), 0, st, w.cand, w.cap, nkeys, w.marg2, metric_ascending(metric) ? 1 : 0,
-                           nqc, (uint32_t)q0, d_ids, d_redo, d_redo_count);
+                           nqc, (uint32_t)q0, d_ids, d_redo, d_redo_count, d_q, score_rows(h), score_ld(h), h->dim, metric, ip_form);
         if (hipGetLastError() != hipSuccess) rc = set_error(LYNSE_ERR_DEVICE, "k_assign_pick launch failed");
     }
     tl_prof = prof_prev;
