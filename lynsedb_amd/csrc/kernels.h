@@ -2421,33 +2421,52 @@ __global__ void __launch_bounds__(256) k_sq8_quantize(const T* __restrict__ V, u
     // entries) — the squared row norm of the L2 form of the certified int8 pass (k_i8c_prep_queries, aug); sums / sums2 may be
     // NULL then
     // stats[0] = max over rows of sum |code - 128| (the query-quantisation term of the certified int8 bound),
-    // stats[1] = number of non-finite elements (the certified int8 coarse pass is only valid without them)
+    // stats[1] = number of non-finite elements (the certified int8 coarse pass is only valid without them),
+    // round 5 (the Cauchy-Schwarz forms of the two quantisation terms, k_i8c_prep_queries):
+    // stats[2] = max over rows of sum (code - 128)^2 (an exact integer), stats[3] = float bits of an UPPER bound of max over rows of
+    // sum eps_d^2, eps_d = (v_d - min_d) scale_d - code_d the residual of the row's own quantisation in real arithmetic: the f32
+    // evaluation of (v - min) scale is off by <= 255 * 2^-22 < 6.1e-5 per element, so sum eps^2 <= sum e^2 + 2 * 6.1e-5 * sum |e| +
+    // D * (6.1e-5)^2 for the computed residuals e; the f32 sums carry a relative 1e-5 on top.
     const int lane = threadIdx.x & 63;
     const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
-    uint32_t a1max = 0, nonfinite = 0;
+    uint32_t a1max = 0, a2max = 0, nonfinite = 0;
+    float e2max = 0.0f;
     for (uint64_t row = wave; row < n; row += nwaves) {
         int s1 = 0, s2 = 0, l1 = 0;
+        float e2 = 0.0f, e1 = 0.0f;
         for (uint32_t d = lane; d < ld8; d += 64) {
             int c = 0;
             if (d < D || (extra_col && d < D + n_extra)) {
                 const float v = d < D ? (row_scale ? __fmul_rn((float)V[row * ld + d], row_scale[row]) : (float)V[row * ld + d]) : extra_col[row];
                 if (!(fabsf(v) < LY_INF)) nonfinite += 1;
-                c = sq8_code(v, mins[d], scales[d]) - 128;
+                const int code = sq8_code(v, mins[d], scales[d]);
+                c = code - 128;
                 s1 += c;
                 s2 += c * c;
                 l1 += c < 0 ? -c : c;
+                const float e = __fsub_rn(__fmul_rn(__fsub_rn(v, mins[d]), scales[d]), (float)code);   // (the value sq8_code rounded, minus the code)
+                const float ea = fabsf(e);
+                if (ea == ea) { e2 = __fmaf_rn(e, e, e2); e1 += ea; }
             }
             out[row * ld8 + d] = (int8_t)c;
         }
-        for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); l1 += __shfl_xor(l1, o, 64); }
+        for (int o = 32; o > 0; o >>= 1) {
+            s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); l1 += __shfl_xor(l1, o, 64);
+            e2 += __shfl_xor(e2, o, 64); e1 += __shfl_xor(e1, o, 64);
+        }
         if (lane == 0 && sums) { sums[row] = s1; sums2[row] = s2; }
         a1max = a1max > (uint32_t)l1 ? a1max : (uint32_t)l1;
+        a2max = a2max > (uint32_t)s2 ? a2max : (uint32_t)s2;
+        const float e2b = (e2 + 1.22e-4f * e1 + (float)(D + n_extra) * 3.8e-9f) * 1.00002f;
+        e2max = e2b > e2max ? e2b : e2max;
     }
     for (int o = 32; o > 0; o >>= 1) nonfinite += __shfl_xor(nonfinite, o, 64);
     if (lane == 0 && stats) {
         atomicMax(&stats[0], a1max);
         if (nonfinite) atomicAdd(&stats[1], nonfinite);
+        atomicMax(&stats[2], a2max);
+        atomicMax(&stats[3], __float_as_uint(e2max));   // (non-negative floats order like their bit patterns)
     }
 }
 
@@ -2505,6 +2524,8 @@ struct I8cPrepArgs {
     uint32_t D, qpad, nslab;
     const float *mins, *scales;
     uint32_t a1;         // max row L1 norm of the signed codes
+    uint32_t a2sq;       // max row sum of squares of the signed codes (0: not collected — the L1 forms alone)
+    float eps2;          // upper bound of the max row sum of squared quantisation residuals (0: not collected)
     float vmax;          // max row norm
     int8_t* img;
     float *sq, *bq, *marg2, *thr;  // s_q -> ScanArgs::qinv, B_q -> ScanArgs::qn2
@@ -2564,7 +2585,7 @@ __global__ void __launch_bounds__(256) k_i8c_prep_queries(I8cPrepArgs a) {
         if (!a.aug) return (double)qv[i];
         return i < a.D ? 2.0 * (double)qv[i] : -1.0 / (double)a.aug;
     };
-    double wmax = 0.0, sw = 0.0, swabs = 0.0, sqm = 0.0, s2 = 0.0;
+    double wmax = 0.0, sw = 0.0, swabs = 0.0, sqm = 0.0, s2 = 0.0, sw2 = 0.0;
     for (uint32_t i = tid; i < DA; i += 256) {
         const double x = qel(i);
         const float sc = a.scales[i];
@@ -2572,6 +2593,7 @@ __global__ void __launch_bounds__(256) k_i8c_prep_queries(I8cPrepArgs a) {
         wmax = fmax(wmax, fabs(w));
         sw += w;
         swabs += fabs(w);
+        sw2 += w * w;
         sqm += x * (double)a.mins[i];
         if (i < a.D) { const double o = (double)qv[i]; s2 += o * o; }   // |q|^2 of the ORIGINAL query
     }
@@ -2581,15 +2603,13 @@ __global__ void __launch_bounds__(256) k_i8c_prep_queries(I8cPrepArgs a) {
         swabs += __shfl_xor(swabs, o, 64);
         sqm += __shfl_xor(sqm, o, 64);
         s2 += __shfl_xor(s2, o, 64);
+        sw2 += __shfl_xor(sw2, o, 64);
     }
-    if (lane == 0) { red[0][wave] = wmax; red[1][wave] = sw; red[2][wave] = swabs; red[3][wave] = sqm; red[4][wave] = s2; }
+    __shared__ double red2[2][4];
+    if (lane == 0) { red[0][wave] = wmax; red[1][wave] = sw; red[2][wave] = swabs; red[3][wave] = sqm; red[4][wave] = s2; red2[0][wave] = sw2; }
     __syncthreads();
-    if (tid == 0) {
+    if (tid == 0) {   // the query's scale first: the image (below) needs it, and the bound needs the image's residuals
         wmax = fmax(fmax(red[0][0], red[0][1]), fmax(red[0][2], red[0][3]));
-        sw = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
-        swabs = (red[2][0] + red[2][1]) + (red[2][2] + red[2][3]);
-        sqm = (red[3][0] + red[3][1]) + (red[3][2] + red[3][3]);
-        s2 = (red[4][0] + red[4][1]) + (red[4][2] + red[4][3]);
         float sq = 1.0f;
         if (wmax > 0.0 && wmax < 1.0e30) {
             sq = (float)(wmax / 127.0);
@@ -2597,6 +2617,40 @@ __global__ void __launch_bounds__(256) k_i8c_prep_queries(I8cPrepArgs a) {
             if (!(sq > 0.0f)) sq = 1.1754944e-38f;
         }
         s_sq = sq;
+    }
+    __syncthreads();
+    // ---- the int8 image + sum eta_d^2 (eta_d = w_d / s_q - u_d: the residual of the query's own quantisation)
+    const double inv = 1.0 / (double)s_sq;
+    const uint32_t total = a.nslab * 128;
+    double eta2 = 0.0;
+    for (uint32_t i = tid; i < total; i += 256) {
+        int u = 0;
+        if (i < DA) {
+            const float sc = a.scales[i];
+            const double w = sc > 0.0f ? qel(i) / (double)sc : 0.0;
+            const double t = w * inv;
+            double r = rint(t);
+            r = r < -127.0 ? -127.0 : (r > 127.0 ? 127.0 : r);
+            u = (r == r) ? (int)r : 0;
+            const double eta = t - (double)u;
+            if (eta == eta) eta2 += eta * eta;
+        }
+        const uint32_t s = i / 128, k = i % 128, l = k >> 4, e = k & 15, p = l ^ ((q >> 1) & 7);
+        a.img[(((size_t)s * a.qpad + q) * 8 + p) * 16 + e] = (int8_t)u;
+        if (a.dyn_thr) s_u[i] = (int8_t)u;
+    }
+    for (int o = 32; o > 0; o >>= 1) eta2 += __shfl_xor(eta2, o, 64);
+    if (lane == 0) red2[1][wave] = eta2;
+    __syncthreads();
+    if (tid == 0) {
+        wmax = fmax(fmax(red[0][0], red[0][1]), fmax(red[0][2], red[0][3]));
+        sw = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+        swabs = (red[2][0] + red[2][1]) + (red[2][2] + red[2][3]);
+        sqm = (red[3][0] + red[3][1]) + (red[3][2] + red[3][3]);
+        s2 = (red[4][0] + red[4][1]) + (red[4][2] + red[4][3]);
+        sw2 = (red2[0][0] + red2[0][1]) + (red2[0][2] + red2[0][3]);
+        eta2 = (red2[1][0] + red2[1][1]) + (red2[1][2] + red2[1][3]);
+        const float sq = s_sq;
         const double bq = sqm + 128.0 * sw - (a.aug ? s2 : 0.0) - (a.cosine ? 1.0 : 0.0);
         const float bqf = (float)bq;
         const double a1 = (double)a.a1;
@@ -2604,11 +2658,20 @@ __global__ void __launch_bounds__(256) k_i8c_prep_queries(I8cPrepArgs a) {
         const double ref_term = a.cosine ? 9.0 * ((double)a.D + 8.0) * 5.9604645e-8
                                 : a.aug  ? 8.0 * ((double)a.D + 8.0) * 5.9604645e-8 * (s2 + (double)a.vmax * (double)a.vmax)
                                          : gam * sqrt(s2) * (double)a.vmax;
-        double E = 0.5001 * swabs + 0.5001 * (double)sq * a1 + 2.5e-7 * (fabs(bq) + (a.cosine ? 1.0 : fabs(s2)) + 127.0 * (double)sq * a1) + ref_term;
+        // The two quantisation terms of q.v - coarse = s_q sum eta_d c'_d + sum w_d eps_d.  Hoelder (round 2): |.| <= 0.5 s_q A1 and
+        // <= 0.50004 sum |w_d| — every residual at its worst, all of one sign.  Cauchy-Schwarz (round 5): |.| <= s_q ||eta|| ||c'|| and
+        // <= ||w|| ||eps||, with ||eta|| of THIS query (computed above), ||w|| of this query, and the largest ||c'||, ||eps|| any row of
+        // the shard has (k_sq8_quantize, stats[2..3]).  Both hold for every (row, query), so does their minimum; on data whose
+        // residuals are not aligned (anything but the constructed worst case of tests/test_gpu_certificate.py) the second is ~1.5x
+        // tighter: fewer keys emitted, kept and rescored at every stage.
+        double tq = 0.5001 * (double)sq * a1, tr = 0.5001 * swabs;
+        if (a.a2sq) { const double c2 = 1.0002 * (double)sq * sqrt(eta2) * sqrt((double)a.a2sq); tq = c2 < tq ? c2 : tq; }
+        if (a.eps2 > 0.0f) { const double c2 = 1.0002 * sqrt(sw2) * sqrt((double)a.eps2); tr = c2 < tr ? c2 : tr; }
+        double E = tr + tq + 2.5e-7 * (fabs(bq) + (a.cosine ? 1.0 : fabs(s2)) + 127.0 * (double)sq * a1) + ref_term;
         float bq_out = bqf;
         if (a.l2n) {
             const double vm2 = (double)a.vmax * (double)a.vmax;
-            E = 2.0 * (0.5001 * swabs + 0.5001 * (double)sq * a1) + 5.0e-7 * (2.0 * fabs(bq) + s2 + vm2 + 2.0 * 127.0 * (double)sq * a1) +
+            E = 2.0 * (tr + tq) + 5.0e-7 * (2.0 * fabs(bq) + s2 + vm2 + 2.0 * 127.0 * (double)sq * a1) +
                 8.0 * ((double)a.D + 8.0) * 5.9604645e-8 * (s2 + vm2);
             bq_out = (float)(s2 - 2.0 * bq);
         }
@@ -2631,21 +2694,6 @@ __global__ void __launch_bounds__(256) k_i8c_prep_queries(I8cPrepArgs a) {
         }
     }
     __syncthreads();
-    const double inv = 1.0 / (double)s_sq;
-    const uint32_t total = a.nslab * 128;
-    for (uint32_t i = tid; i < total; i += 256) {
-        int u = 0;
-        if (i < DA) {
-            const float sc = a.scales[i];
-            const double w = sc > 0.0f ? qel(i) / (double)sc : 0.0;
-            double r = rint(w * inv);
-            r = r < -127.0 ? -127.0 : (r > 127.0 ? 127.0 : r);
-            u = (r == r) ? (int)r : 0;
-        }
-        const uint32_t s = i / 128, k = i % 128, l = k >> 4, e = k & 15, p = l ^ ((q >> 1) & 7);
-        a.img[(((size_t)s * a.qpad + q) * 8 + p) * 16 + e] = (int8_t)u;
-        if (a.dyn_thr) s_u[i] = (int8_t)u;
-    }
     if (a.dyn_thr) {
         // ---- first partition maxima: sample i belongs to partition i % ks and sits in a tile of that residue class, the classes'
         // tiles visited with an even stride

@@ -289,7 +289,8 @@ struct lynse_hip_flat {
     uint32_t* sq8_mm = nullptr;  // 2 x dim ordered-int min / max
     uint32_t* sq8_stats = nullptr;  // [0] max row L1 of the signed codes, [1] non-finite elements (k_sq8_quantize)
     uint32_t* sq8_mm_prev = nullptr;  // scratch of the incremental append: the min / max table before the new rows were merged + a flag word
-    uint32_t sq8_a1 = 0;
+    uint32_t sq8_a1 = 0, sq8_a2sq = 0;   // max row L1 / sum of squares of the signed codes
+    float sq8_eps2 = 0.0f;                 // bound of the max row sum of squared quantisation residuals (k_sq8_quantize stats[3])
     bool sq8_finite = false;
     // the L2 form of the certified int8 pass: SQ8 codes of the AUGMENTED rows [v, |v|^2] (k_i8c_prep_queries, aug = 1), pitch
     // ld8a = round_up(dim + 1, 128) (whole 128-column slabs: the non-ragged scan kernels), built lazily on the first L2 batch
@@ -299,7 +300,8 @@ struct lynse_hip_flat {
     uint64_t n_sq8a = 0, sq8a_cap = 0;
     float *sq8a_mins = nullptr, *sq8a_scales = nullptr;
     uint32_t *sq8a_mm = nullptr, *sq8a_stats = nullptr;
-    uint32_t sq8a_a1 = 0;
+    uint32_t sq8a_a1 = 0, sq8a_a2sq = 0;   // max row L1 / sum of squares of the signed codes
+    float sq8a_eps2 = 0.0f;                 // bound of the max row sum of squared quantisation residuals (k_sq8_quantize stats[3])
     bool sq8a_finite = false;
     std::atomic<int> i8c_strikes_l2{0};
     // the cosine form: SQ8 codes of the UNIT rows fl(v_d * rinv[row]) (pitch ld8), built lazily on the first cosine batch of
@@ -308,7 +310,8 @@ struct lynse_hip_flat {
     uint64_t n_sq8c = 0, sq8c_cap = 0;
     float *sq8c_mins = nullptr, *sq8c_scales = nullptr;
     uint32_t *sq8c_mm = nullptr, *sq8c_stats = nullptr;
-    uint32_t sq8c_a1 = 0;
+    uint32_t sq8c_a1 = 0, sq8c_a2sq = 0;   // max row L1 / sum of squares of the signed codes
+    float sq8c_eps2 = 0.0f;                 // bound of the max row sum of squared quantisation residuals (k_sq8_quantize stats[3])
     bool sq8c_finite = false;
     std::atomic<int> i8c_strikes_cos{0};
     // certified int8 coarse pass (FLAT-IP batches of 33..256 queries): -1 = off (env / strikes), else overflow strikes so far
@@ -1873,7 +1876,9 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
         I8cPrepArgs p{};
         p.Q = Qf; p.D = h->dim; p.qpad = qpad; p.nslab = nslab; p.mins = aug ? h->sq8a_mins : (cosq ? h->sq8c_mins : h->sq8_mins);
         p.scales = aug ? h->sq8a_scales : (cosq ? h->sq8c_scales : h->sq8_scales);
-        p.a1 = aug ? h->sq8a_a1 : (cosq ? h->sq8c_a1 : h->sq8_a1); p.vmax = h->vmax; p.cosine = cosq ? 1 : 0; p.img = reinterpret_cast<int8_t*>(w.Q16); p.aug = aug ? (int)h->aug_cols : 0; p.l2n = l2n ? 1 : 0;
+        p.a1 = aug ? h->sq8a_a1 : (cosq ? h->sq8c_a1 : h->sq8_a1); p.vmax = h->vmax;
+        static const bool cs_env = []() { const char* e = getenv("LYNSE_HIP_I8C_CS"); return !e || atoi(e) != 0; }();   // (0: the Hoelder terms alone, A/B)
+        if (cs_env) { p.a2sq = aug ? h->sq8a_a2sq : (cosq ? h->sq8c_a2sq : h->sq8_a2sq); p.eps2 = aug ? h->sq8a_eps2 : (cosq ? h->sq8c_eps2 : h->sq8_eps2); } p.cosine = cosq ? 1 : 0; p.img = reinterpret_cast<int8_t*>(w.Q16); p.aug = aug ? (int)h->aug_cols : 0; p.l2n = l2n ? 1 : 0;
         p.sq = w.qinv; p.bq = w.qn2; p.marg2 = w.marg2; p.thr = w.thr; p.count = w.count; p.overflow = w.overflow;
         p.gsync = w.gsync;
         if (sts) {   // seed the partition maxima of the self-tightening scan from a few sample rows (valid thresholds from the first tile on)
@@ -2419,7 +2424,7 @@ static int ensure_sq8_locked(lynse_hip_flat* h) {
         LY_HIP(hipMalloc(&h->sq8_mins, (size_t)h->dim * 4));
         LY_HIP(hipMalloc(&h->sq8_scales, (size_t)h->dim * 4));
         LY_HIP(hipMalloc(&h->sq8_mm, (size_t)h->dim * 8));
-        LY_HIP(hipMalloc(&h->sq8_stats, 8));
+        LY_HIP(hipMalloc(&h->sq8_stats, 16));   // (four words: k_sq8_quantize)
     }
     uint64_t r0 = 0;
     bool mm_done = false;
@@ -2435,7 +2440,7 @@ static int ensure_sq8_locked(lynse_hip_flat* h) {
         else hipLaunchKernelGGL(k_sq8_minmax<float>, dim3(gx, gy), dim3(256), 0, cur(h).stream, h->rows, h->ld, h->dim, h->n, h->sq8_mm, h->sq8_mm + h->dim);
     }
     if (r0 == 0) {   // a new fit: every row is coded (again)
-        LY_HIP(hipMemsetAsync(h->sq8_stats, 0, 8, cur(h).stream));
+        LY_HIP(hipMemsetAsync(h->sq8_stats, 0, 16, cur(h).stream));
         hipLaunchKernelGGL(k_sq8_scales, dim3(gx), dim3(256), 0, cur(h).stream, h->sq8_mm, h->sq8_mm + h->dim, h->dim, h->sq8_mins, h->sq8_scales);
     }
     const uint64_t nn = h->n - r0;
@@ -2445,10 +2450,12 @@ static int ensure_sq8_locked(lynse_hip_flat* h) {
     else hipLaunchKernelGGL(k_sq8_quantize<float>, dim3(qgrid), dim3(256), 0, cur(h).stream,
                        h->rows + r0 * h->ld, h->ld, h->dim, nn, h->sq8_mins, h->sq8_scales, h->sq8 + r0 * h->ld8, h->ld8, h->sq8_sum + r0, h->sq8_sum2 + r0, h->sq8_stats);
     LY_HIP(hipGetLastError());
-    uint32_t qst[2] = {0, 0};
-    LY_HIP(hipMemcpyAsync(qst, h->sq8_stats, 8, hipMemcpyDeviceToHost, cur(h).stream));
+    uint32_t qst[4] = {0, 0, 0, 0};
+    LY_HIP(hipMemcpyAsync(qst, h->sq8_stats, 16, hipMemcpyDeviceToHost, cur(h).stream));
     LY_HIP(hipStreamSynchronize(cur(h).stream));  // `init` is a temporary
     h->sq8_a1 = qst[0];
+    h->sq8_a2sq = qst[2];
+    memcpy(&h->sq8_eps2, &qst[3], 4);
     h->sq8_finite = qst[1] == 0;
     h->n_sq8 = h->n;
     return LYNSE_OK;
@@ -2469,9 +2476,9 @@ static int ensure_sq8a_locked(lynse_hip_flat* h) {
         LY_HIP(hipMalloc(&h->sq8a_mins, (size_t)DA * 4));
         LY_HIP(hipMalloc(&h->sq8a_scales, (size_t)DA * 4));
         LY_HIP(hipMalloc(&h->sq8a_mm, (size_t)DA * 8));
-        LY_HIP(hipMalloc(&h->sq8a_stats, 8));
+        LY_HIP(hipMalloc(&h->sq8a_stats, 16));   // (four words: k_sq8_quantize)
     }
-    LY_HIP(hipMemsetAsync(h->sq8a_stats, 0, 8, cur(h).stream));
+    LY_HIP(hipMemsetAsync(h->sq8a_stats, 0, 16, cur(h).stream));
     std::vector<uint32_t> init((size_t)DA * 2);
     for (uint32_t d = 0; d < DA; ++d) { init[d] = f32_to_ord(INFINITY); init[DA + d] = f32_to_ord(-INFINITY); }
     LY_HIP(hipMemcpyAsync(h->sq8a_mm, init.data(), init.size() * 4, hipMemcpyHostToDevice, cur(h).stream));
@@ -2487,10 +2494,12 @@ static int ensure_sq8a_locked(lynse_hip_flat* h) {
     else hipLaunchKernelGGL(k_sq8_quantize<float>, dim3((uint32_t)std::min<uint64_t>((h->n + 3) / 4, (uint64_t)h->num_cu * 16)), dim3(256), 0, cur(h).stream,
                        h->rows, h->ld, h->dim, h->n, h->sq8a_mins, h->sq8a_scales, h->sq8a, h->ld8a, (int*)nullptr, (int*)nullptr, h->sq8a_stats, h->vn2, h->aug_cols);
     LY_HIP(hipGetLastError());
-    uint32_t qst[2] = {0, 0};
-    LY_HIP(hipMemcpyAsync(qst, h->sq8a_stats, 8, hipMemcpyDeviceToHost, cur(h).stream));
+    uint32_t qst[4] = {0, 0, 0, 0};
+    LY_HIP(hipMemcpyAsync(qst, h->sq8a_stats, 16, hipMemcpyDeviceToHost, cur(h).stream));
     LY_HIP(hipStreamSynchronize(cur(h).stream));  // `init` is a temporary
     h->sq8a_a1 = qst[0];
+    h->sq8a_a2sq = qst[2];
+    memcpy(&h->sq8a_eps2, &qst[3], 4);
     h->sq8a_finite = qst[1] == 0;
     h->n_sq8a = h->n;
     return LYNSE_OK;
@@ -2512,7 +2521,7 @@ static int ensure_sq8c_locked(lynse_hip_flat* h) {
         LY_HIP(hipMalloc(&h->sq8c_mins, (size_t)D * 4));
         LY_HIP(hipMalloc(&h->sq8c_scales, (size_t)D * 4));
         LY_HIP(hipMalloc(&h->sq8c_mm, (size_t)D * 8));
-        LY_HIP(hipMalloc(&h->sq8c_stats, 8));
+        LY_HIP(hipMalloc(&h->sq8c_stats, 16));   // (four words: k_sq8_quantize)
     }
     uint64_t r0 = 0;
     bool mm_done = false;
@@ -2528,7 +2537,7 @@ static int ensure_sq8c_locked(lynse_hip_flat* h) {
         else hipLaunchKernelGGL(k_sq8_minmax<float>, dim3(gx, gy), dim3(256), 0, cur(h).stream, h->rows, h->ld, D, h->n, h->sq8c_mm, h->sq8c_mm + D, h->vrinv);
     }
     if (r0 == 0) {
-        LY_HIP(hipMemsetAsync(h->sq8c_stats, 0, 8, cur(h).stream));
+        LY_HIP(hipMemsetAsync(h->sq8c_stats, 0, 16, cur(h).stream));
         hipLaunchKernelGGL(k_sq8_scales, dim3(gx), dim3(256), 0, cur(h).stream, h->sq8c_mm, h->sq8c_mm + D, D, h->sq8c_mins, h->sq8c_scales);
     }
     const uint64_t nn = h->n - r0;
@@ -2540,10 +2549,12 @@ static int ensure_sq8c_locked(lynse_hip_flat* h) {
                        h->rows + r0 * h->ld, h->ld, D, nn, h->sq8c_mins, h->sq8c_scales, h->sq8c + r0 * h->ld8, h->ld8, (int*)nullptr, (int*)nullptr, h->sq8c_stats,
                        (const float*)nullptr, 0u, h->vrinv + r0);
     LY_HIP(hipGetLastError());
-    uint32_t qst[2] = {0, 0};
-    LY_HIP(hipMemcpyAsync(qst, h->sq8c_stats, 8, hipMemcpyDeviceToHost, cur(h).stream));
+    uint32_t qst[4] = {0, 0, 0, 0};
+    LY_HIP(hipMemcpyAsync(qst, h->sq8c_stats, 16, hipMemcpyDeviceToHost, cur(h).stream));
     LY_HIP(hipStreamSynchronize(cur(h).stream));  // `init` is a temporary
     h->sq8c_a1 = qst[0];
+    h->sq8c_a2sq = qst[2];
+    memcpy(&h->sq8c_eps2, &qst[3], 4);
     h->sq8c_finite = qst[1] == 0;
     h->n_sq8c = h->n;
     return LYNSE_OK;
