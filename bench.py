@@ -358,7 +358,7 @@ def main():
         frac_mfma = (mfma_rate / mfma_peak) if mfma_peak else 0.0
         traffic, traffic_note = None, "no PMC summary under profiles/ for this kernel"
         try:  # HBM bytes per launch from the committed PMC pass (bench.py itself cannot run rocprofv3 --pmc)
-            pm_file = next(f for f in ("r04_pmc_traffic.json", "r03_pmc_traffic.json") if (ROOT / "profiles" / f).exists())
+            pm_file = next(f for f in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json") if (ROOT / "profiles" / f).exists())
             pm = json.loads((ROOT / "profiles" / pm_file).read_text())
             pm = pm["i8c" if i8c else ("binary" if metric >= 3 else "f16")]
             traffic = int(kernel_bytes / launches * pm["ratio_hbm_over_kernel_bytes"])

@@ -157,6 +157,32 @@ def test_device_kmeans_matches_oracle_at_scale(L, oracle, n, dim, nlist, iters, 
 
 
 @pytest.mark.parametrize("metric", [IP, L2, COS])
+def test_kmeans_assignment_with_the_arg_best_epilogue_equals_the_search_path(L, oracle, metric, monkeypatch):
+    """kmeans::assign_metric (kmeans.rs:237-264) through the lane-max scan + k_assign_pick (DESIGN 3.4; SURVEY 2a K9) against the same
+    build with every row going through the exact top-1 search (LYNSE_HIP_ASSIGN_FAST=0) and against the oracle — on data made of
+    NEAR-TIES: 40 clusters under 200 lists (sibling centroids of a cluster score within the f16 margin of each other for most rows: the
+    in-margin candidates are rescored exactly inside the pick kernel), duplicated rows, and integer-valued rows whose inner products
+    tie exactly between candidates (the first-strictly-smaller rule = lowest centroid id must win)."""
+    rng = np.random.default_rng(7700 + metric)
+    n, dim, nlist, iters = 30_000, 96, 200, 4
+    centers = rng.standard_normal((40, dim)).astype(f32)
+    data = (centers[rng.integers(0, 40, n)] + 0.25 * rng.standard_normal((n, dim))).astype(f32)
+    data[5000:7000] = data[4999]                                   # 2000 copies of one row
+    data[9000:12000] = rng.integers(-2, 3, size=(3000, dim)).astype(f32)   # small integers: exact ties between candidates
+    built = {}
+    for fast in ("1", "0"):
+        monkeypatch.setenv("LYNSE_HIP_ASSIGN_FAST", fast)
+        idx = L.IvfFlatIndex.build(None, data, dim, nlist, iters, NAME[metric], l2_partitions=False)
+        built[fast] = idx.export()[:2]
+        del idx
+    assert np.array_equal(built["1"][1], built["0"][1]), int((built["1"][1] != built["0"][1]).sum())
+    assert np.array_equal(built["1"][0].view(np.uint32), built["0"][0].view(np.uint32))
+    e_cen, e_asg = oracle.kmeans_train(data, nlist, iters, metric)
+    assert np.array_equal(built["1"][1], e_asg), int((built["1"][1] != e_asg).sum())
+    assert np.array_equal(built["1"][0].view(np.uint32), e_cen.view(np.uint32))
+
+
+@pytest.mark.parametrize("metric", [IP, L2, COS])
 def test_ivfindex_insert_and_delete_keep_the_centroids(L, oracle, metric):
     """IVFIndex::insert / ::delete (ivf.rs:350-441): build -> add rows -> search -> delete rows -> search.  New rows are
     assigned to the EXISTING centroids (kmeans::assign_metric's loop, restated by oracle.kmeans_assign) and appended; a
