@@ -3709,11 +3709,18 @@ __device__ __forceinline__ uint32_t select_body(const SelectArgs& a, uint64_t* k
             const uint32_t mx = a.k * 2u < 256u ? a.k * 2u : 256u;
             if (tid == 0) s_x = 0;
             __syncthreads();
-            for (uint32_t i = tid; i < n; i += NT) {
-                const uint64_t key = keys[i];
-                if (key <= kth) {
-                    const uint32_t slot = atomicAdd(&s_x, 1u);
-                    if (slot < mx) xs[slot] = key;
+            for (uint32_t i0 = 0; i0 < n; i0 += NT) {   // (one LDS atomic per wave and trip, not one per key: they serialise)
+                const uint32_t i = i0 + tid;
+                const uint64_t key = i < n ? keys[i] : KEY_SENTINEL;
+                const bool in = i < n && key <= kth;
+                const uint64_t m = __ballot(in);
+                if (m) {
+                    uint32_t base = 0;
+                    const int leader = __builtin_ctzll(m);
+                    if (lane == leader) base = atomicAdd(&s_x, (uint32_t)__popcll(m));
+                    base = __shfl(base, leader, 64);
+                    const uint32_t slot = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                    if (in && slot < mx) xs[slot] = key;
                 }
             }
             __syncthreads();

@@ -2194,6 +2194,8 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
             sa.stamps = reinterpret_cast<unsigned long long*>(w.gsync + 64) + (size_t)si * 256 * 8;
         if (fs_stage && getenv("LYNSE_HIP_DEBUG_FS")) return LYNSE_OK;   // debugging: stop behind the fused stage (lynse_hip_debug_workspace)
         if (fused_tail && si + 1 == plan.size()) { sa_last = sa; continue; }  // the last select runs inside k_select_final
+        // (round 5, tried: the LAST select without the exact-rescored threshold, its coarse-rule survivors all rescored in the final pass —
+        // 116 instead of 35 rows per query, two rounds of the final rescoring: 10M step +10 us, shard step +6 us; dropped)
         sa.lds_bytes = sel_lds_bytes(w.cap, nq);
         hipLaunchKernelGGL(k_select<SEL_NT>, dim3(nq), dim3(SEL_NT), sa.lds_bytes, st, sa);
         LY_HIP(hipGetLastError());
