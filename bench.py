@@ -214,21 +214,24 @@ def main():
     # here step i+1 is ENQUEUED (scan -> selects -> rescoring [-> all-gather -> merge]) before step i is waited for, each on
     # its own search context and output buffers.  Every one of the K steps is complete — overflow flags checked, results
     # final — inside the timed region.
-    # Round 5: ONE GPU keeps 2 batches in flight too.  Between two blocking calls the device idles for the host's turn-around
-    # (completion -> Python -> the next call's first launch: 27-34 us in the kernel trace of every step, 1.5 % of the 10M step); a
-    # second ticket hides it.  The steps whose scan launches carry HIP events (roofline) still run as blocking calls on a drained
-    # device, so that an event bracket holds one kernel and nothing it waited behind.
-    in_flight = max(1, min(args.in_flight, 4)) if args.in_flight > 0 else (2 if world == 1 else 3)
+    # One GPU: the timed steps are BLOCKING calls by default (kernel durations under rocprofv3 and the HIP-event brackets of the roofline
+    # then agree; with tickets in flight a kernel's profiler duration includes the time it waits for CUs behind another batch).  Between
+    # two blocking calls the device idles for the host's turn-around (completion -> Python -> the next call's first launch: 27-34 us in
+    # the kernel trace of every step, 1.5 % of the 10M step); `--in-flight 2` hides it behind a second ticket (the steps whose scan
+    # launches carry HIP events still run as blocking calls on a drained device) — that figure is reported as
+    # `two_in_flight_ms_per_step`, measured right behind the timed region.
+    in_flight = max(1, min(args.in_flight, 4)) if args.in_flight > 0 else (1 if world == 1 else 3)
     if world > 1 and not native:
         in_flight = 1   # (the torch.distributed fallback of the exchange is a blocking collective)
     if args.profile_every <= 0:
-        args.profile_every = 6 if (world == 1 and in_flight > 1) else 4
-    outs = [sh.alloc_outputs(B, K) for _ in range(in_flight)]
-    out = outs[0]
+        args.profile_every = 6 if (world == 1 and in_flight > 1) else 4   # (one GPU with --in-flight N: fewer drained steps)
+    outs_default = [sh.alloc_outputs(B, K) for _ in range(in_flight)]
+    out = outs_default[0]
 
-    def run_steps(n, drain_every=0):
+    def run_steps(n, drain_every=0, in_flight=in_flight, outs=None):
         # drain_every = n > 0 (one GPU, timed region): step 0, n, 2n, ... is the library's profiled search (profile_enable(n) counts
         # searches from 0): it runs blocking, after the tickets in flight have been waited for
+        outs = outs if outs is not None else outs_default
         if in_flight == 1:
             for _ in range(n):
                 sh.search_device(queries, K, metric, out)
@@ -310,6 +313,15 @@ def main():
         sh.search_device(queries, K, metric, out)
     barrier()
     lat_ms = (time.perf_counter() - t_lat) / lat_steps * 1000.0
+    two_ms = None
+    if world == 1 and in_flight == 1 and not args.no_configs:   # (outside the timed region; not in the lean profiling command) the same K steps with two tickets in flight
+        outs2 = [sh.alloc_outputs(B, K) for _ in range(2)]
+        run_steps(4, 0, 2, outs2)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        run_steps(args.steps, 0, 2, outs2)
+        torch.cuda.synchronize()
+        two_ms = (time.perf_counter() - t2) / args.steps * 1000.0
     if dist is not None:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -411,6 +423,7 @@ def main():
                        "hbm_bytes_per_gpu": int(hbm_bytes), "hbm_bytes_over_f32_rows": round(hbm_bytes / max(n_local * D * 4, 1), 3)},
             "roofline": roofline,
             "blocking_ms_per_batch": round(lat_ms, 4),
+            "two_in_flight_ms_per_step": (round(two_ms, 4) if two_ms is not None else None),
             "pipeline_us_per_step": round(prof["total_us"] / max(prof["searches"], 1), 1),
             "rescored_per_query": round(prof["pool_entries"] / max(prof["searches"] * B, 1), 1),
             "fallback_queries": int(prof["fallback_queries"]),
@@ -427,7 +440,7 @@ def main():
                 result["same_shard_variants"] = same_shard_variants(sh.index, queries, B, K, n_local, D)
             except Exception as e:  # noqa: BLE001
                 result["same_shard_variants"] = {"error": repr(e)}
-            del sh, outs, out
+            del sh, outs_default, out
             torch.cuda.empty_cache()
             try:
                 result["second_distribution"] = second_distribution(args, dev)
