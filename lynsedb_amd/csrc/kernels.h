@@ -276,6 +276,8 @@ __device__ __forceinline__ float exact_score(int metric, int ip_form, const floa
 // statistics (max |v|, max / min-nonzero squared norm, count of degenerate tiny-norm rows) that
 // parameterise the certified f16 error margin.  One wave per row.
 // stats[0]=bits(max|v|) stats[1]=bits(max n2) stats[2]=bits(min nonzero n2) stats[3]=#rows with 0<n2<1e-30
+// stats[4]=bit 0: some element is not an integer (NaN counts), bit 1: some element is negative — 0 for SIFT-like u8 / count data:
+// k_prep_queries' exactness rule
 // ------------------------------------------------------------------------------------------------
 template <typename T>  // float rows, or the f16 bits of an F16 shard
 __global__ void __launch_bounds__(256) k_row_stats(const T* __restrict__ V, uint32_t ld, uint32_t D,
@@ -285,7 +287,7 @@ __global__ void __launch_bounds__(256) k_row_stats(const T* __restrict__ V, uint
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
     float amax = 0.0f, n2max = 0.0f, n2min = LY_INF;
-    uint32_t ndegen = 0;
+    uint32_t ndegen = 0, nonint = 0;
     for (uint32_t row = row0 + wave; row < row1; row += nwaves) {
         const T* v = V + (size_t)row * ld;
         float s = 0.0f;
@@ -293,6 +295,7 @@ __global__ void __launch_bounds__(256) k_row_stats(const T* __restrict__ V, uint
             float x = (float)v[i];
             s = __fmaf_rn(x, x, s);
             amax = fmaxf(amax, fabsf(x));
+            nonint |= ((x != truncf(x)) ? 1u : 0u) | ((x < 0.0f) ? 2u : 0u);
         }
         for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
         if (lane == 0) {
@@ -309,6 +312,10 @@ __global__ void __launch_bounds__(256) k_row_stats(const T* __restrict__ V, uint
         atomicMax(&stats[1], __float_as_uint(n2max));
         if (n2min < LY_INF) atomicMin(&stats[2], __float_as_uint(n2min));
         if (ndegen) atomicAdd(&stats[3], ndegen);
+    }
+    {
+        const uint32_t bits = (__ballot((nonint & 1u) != 0u) != 0ull ? 1u : 0u) | (__ballot((nonint & 2u) != 0u) != 0ull ? 2u : 0u);
+        if (bits && lane == 0) atomicOr(&stats[4], bits);
     }
 }
 
@@ -366,6 +373,15 @@ struct PrepArgs {
     float sv;            // row scale (power of two)
     float vmax, vmin;    // max / min-nonzero row norm
     int cos_degenerate;  // rows with 0 < |v|^2 < 1e-30 exist
+    // Exactness rule (round 5): every element of the shard is an INTEGER of magnitude <= amax_v (k_row_stats, stats[4] / stats[0]).  If
+    // the query is integer-valued too, both sides are exact in f16 (|x| <= 2048) and D aq av, D aq^2, D av^2 and D dmax^2 are all below
+    // 2^24 (aq, av = max |q_i|, max |v_i|; dmax = the largest |q_i - v_i| possible: max(aq, av) when both sides are non-negative, else
+    // aq + av), then every product and every partial sum of the coarse pass AND of the reference's f32 kernels (simd.rs:1343-1581: IP,
+    // squared L2 as sum (q_i - v_i)^2) is an integer below 2^24 — both compute the TRUE value, whatever their summation order: E = 0,
+    // the thresholds are exact, nothing but real ties of the k-th score is kept beside the k best (SIFT / GIST-style u8 collections:
+    // BASELINE config 3).
+    int rows_integer, rows_nonneg;
+    float amax_v;
     _Float16* Q16;
     float *qinv, *qn2, *qrinv, *marg2, *thr;
     uint32_t* count;
@@ -379,21 +395,28 @@ __global__ void __launch_bounds__(256) k_prep_queries(PrepArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* qv = a.Q + (size_t)q * a.D;
     float amax = 0.0f, s2 = 0.0f, s1 = 0.0f;
+    bool nonint = false, qneg = false;
     for (uint32_t i = tid; i < a.D; i += 256) {
         float x = qv[i];
         amax = fmaxf(amax, fabsf(x));
         s2 = __fmaf_rn(x, x, s2);
         s1 += fabsf(x);
+        nonint = nonint || x != truncf(x);
+        qneg = qneg || x < 0.0f;
     }
     for (int o = 32; o > 0; o >>= 1) {
         amax = fmaxf(amax, __shfl_xor(amax, o, 64));
         s2 += __shfl_xor(s2, o, 64);
         s1 += __shfl_xor(s1, o, 64);
     }
-    if (lane == 0) { red[0][wave] = amax; red[1][wave] = s2; red[2][wave] = s1; }
+    __shared__ uint32_t s_nonint[4];
+    const uint32_t wave_bits = (__ballot(nonint) != 0ull ? 1u : 0u) | (__ballot(qneg) != 0ull ? 2u : 0u);
+    if (lane == 0) { red[0][wave] = amax; red[1][wave] = s2; red[2][wave] = s1; s_nonint[wave] = wave_bits; }
     __syncthreads();
     if (tid == 0) {
         amax = fmaxf(fmaxf(red[0][0], red[0][1]), fmaxf(red[0][2], red[0][3]));
+        const uint32_t q_bits = s_nonint[0] | s_nonint[1] | s_nonint[2] | s_nonint[3];
+        const bool q_integer = (q_bits & 1u) == 0u, q_nonneg = (q_bits & 2u) == 0u;
         s2 = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
         s1 = (red[2][0] + red[2][1]) + (red[2][2] + red[2][3]);
         int e = (amax > 0.0f && amax < LY_INF) ? ilogbf(amax) : 13;
@@ -425,6 +448,13 @@ __global__ void __launch_bounds__(256) k_prep_queries(PrepArgs a) {
             }
         }
         if (!(E == E) || E > 3.0e38f) E = 3.0e38f;
+        {   // the exactness rule (PrepArgs::rows_integer): integer rows x integer query, everything below 2^24
+            const float aq = amax, av = a.amax_v, dmax = (a.rows_nonneg && q_nonneg) ? fmaxf(aq, av) : aq + av;
+            const float big = fmaxf(fmaxf(aq * av, dmax * dmax), fmaxf(aq * aq, av * av));
+            if (a.rows_integer && q_integer && a.metric != M_COS && a.sv == 1.0f && aq <= 2048.0f && av <= 2048.0f &&
+                (float)a.D * big * 1.0001f < 16777216.0f)
+                E = 0.0f;
+        }
         a.qinv[q] = 1.0f / (sq * a.sv);
         a.qn2[q] = s2;
         a.qrinv[q] = s2 > 0.0f ? 1.0f / qn : 0.0f;

@@ -24,6 +24,7 @@
 
 #include "kernels.h"
 #include "scan_qs.h"
+#include "scan_qh.h"
 #include "ivf.h"
 
 using namespace lynse;
@@ -268,7 +269,8 @@ struct lynse_hip_flat {
     uint64_t n_stats = 0;        // rows covered by vn2/vrinv/stats
     uint64_t stats_capacity = 0;
     float *vn2 = nullptr, *vrinv = nullptr;
-    uint32_t* d_stats = nullptr;  // 4 words, see k_row_stats
+    uint32_t* d_stats = nullptr;  // 5 words, see k_row_stats
+    int rows_integer = 0, rows_nonneg = 0;   // every element of the shard is an integer / non-negative (k_row_stats stats[4]; k_prep_queries' exactness rule)
     float amax = 0.f, vmax = 0.f, vmin = 0.f, sv = 1.f;
     int cos_degenerate = 0;
 
@@ -444,13 +446,13 @@ extern "C" int lynse_hip_flat_create(uint32_t dim, int device, lynse_hip_flat** 
         delete h;
         return set_error(LYNSE_ERR_DEVICE, std::string("hipStreamCreate: ") + hipGetErrorString(e));
     }
-    e = hipMalloc(&h->d_stats, 4 * sizeof(uint32_t));
+    e = hipMalloc(&h->d_stats, 5 * sizeof(uint32_t));
     if (e != hipSuccess) {
         (void)hipStreamDestroy(cur(h).stream);
         delete h;
         return set_error(LYNSE_ERR_OUT_OF_MEMORY, "hipMalloc(stats)");
     }
-    const uint32_t init[4] = {0u, 0u, 0x7f800000u, 0u};
+    const uint32_t init[5] = {0u, 0u, 0x7f800000u, 0u, 0u};
     (void)h2d_done(h->d_stats, init, sizeof init);
     *out = h;
     return LYNSE_OK;
@@ -717,7 +719,7 @@ static int finalize_locked(lynse_hip_flat* h) {
         hipLaunchKernelGGL(k_row_stats<float>, dim3(blocks), dim3(256), 0, cur(h).stream, h->rows, h->ld, h->dim,
                            (uint32_t)h->n_stats, (uint32_t)h->n, h->vn2, h->vrinv, h->d_stats);
     LY_HIP(hipGetLastError());
-    uint32_t st[4];
+    uint32_t st[5];
     LY_HIP(hipMemcpyAsync(st, h->d_stats, sizeof st, hipMemcpyDeviceToHost, cur(h).stream));
     LY_HIP(hipStreamSynchronize(cur(h).stream));
     float f[3];
@@ -726,6 +728,8 @@ static int finalize_locked(lynse_hip_flat* h) {
     h->vmax = std::sqrt(f[1]);
     h->vmin = (st[2] == 0x7f800000u) ? 0.0f : std::sqrt(f[2]);
     h->cos_degenerate = st[3] ? 1 : 0;
+    h->rows_integer = ((st[4] & 1u) == 0u && getenv("LYNSE_HIP_NO_EXACT_INT") == nullptr) ? 1 : 0;
+    h->rows_nonneg = (st[4] & 2u) == 0u ? 1 : 0;
     int e = (h->amax > 0.0f && std::isfinite(h->amax)) ? std::ilogb(h->amax) : 13;
     e = std::max(-100, std::min(100, e));
     // no scaling when max|v| in [2^-6, 2^15): the f16 subnormal floor (2^-25 absolute) is then far
@@ -1552,6 +1556,65 @@ static int launch_scan_qs_sample(const ScanArgs& a, uint32_t grid, hipStream_t s
     }
 }
 
+// The query-stationary tiling of the f16 shadow at low dimension (scan_qh.h): threshold stages of an unfiltered FLAT batch of 33..256
+// queries on the float path over rows of 1 or 2 whole 64-element slabs (64 / 128 columns: BASELINE config 3).  OFF by default
+// (LYNSE_HIP_QH=1: 32 queries per wave, two workgroups per CU; =2: 64 queries per wave; read per call): bit-identical results (tests),
+// MEASURED 4 % / 20 % slower than the 256 x 256 tile of k_scan_h16 on C3 (1M x 128, k = 100: 0.224-0.227 / 0.261-0.265 against
+// 0.215-0.217 ms per batch, same box, alternating) — without emission it is the faster scan (78k against ~100k ticks per 738k-row
+// stage), with it every 64-row step of every workgroup holds a key and the grouped slow path (norm re-read, four ballots, the exact
+// expression) costs as much as the MFMAs of the step; DESIGN 4.3 has the phase table.
+static int qh_variant() { const char* e = getenv("LYNSE_HIP_QH"); return e ? atoi(e) : 0; }   // 0 off, 1 = 32 queries per wave, two workgroups per CU, 2 = 64 queries per wave
+static bool qh_scan_ok(const ScanArgs& a, bool filt, uint32_t qchunks) {
+    const int v = qh_variant();
+    if (v != 1 && v != 2) return false;
+    return !filt && a.emit_all == 0 && qchunks == 1 && a.qpad == 256 && a.nq <= 256 && a.tile_stride == 0 && a.skip_stride == 0 && !a.mask && !a.row_ids &&
+           !a.tiles && a.row1 > a.row0 && (a.nslab == 1 || a.nslab == 2) && a.ld16 == a.nslab * 64u;
+}
+static uint32_t qh_grid(const ScanArgs& a, uint32_t num_cu, uint32_t* segs_per_wg) {
+    const bool two = qh_variant() == 2;
+    *segs_per_wg = two ? 4u : 2u;
+    const uint32_t rt = two ? 128u : 64u;
+    return std::min<uint32_t>((a.row1 - a.row0 + rt - 1) / rt, two ? num_cu : 2u * num_cu);
+}
+static int launch_scan_qh(const ScanArgs& a, int metric, uint32_t grid, hipStream_t st) {
+    static std::atomic<bool> attr_done[16] = {false};
+    auto go = [&](auto kern, int slot, size_t lds) -> int {
+        if (!attr_done[slot]) { LY_TRY(set_max_lds(kern, lds)); attr_done[slot] = true; }
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, a);
+        LY_HIP(hipGetLastError());
+        return LYNSE_OK;
+    };
+    if (qh_variant() == 2) {   // 64 queries per wave, 128-row tiles, one workgroup per CU
+        constexpr size_t stg = 8 * 256 * 12, nrm = 5 * 512 + stg;   // norm ring (L2 / cosine) + the waves' key staging regions
+        if (a.nslab == 1) {
+            switch (metric) {
+            case M_IP: return go(k_scan_qh<1, M_IP, 4, 8, 2>, 0, (size_t)4 * 1 * 128 * 128 + stg);
+            case M_L2: return go(k_scan_qh<1, M_L2, 4, 8, 2>, 1, (size_t)4 * 1 * 128 * 128 + nrm);
+            default: return go(k_scan_qh<1, M_COS, 4, 8, 2>, 2, (size_t)4 * 1 * 128 * 128 + nrm);
+            }
+        }
+        switch (metric) {
+        case M_IP: return go(k_scan_qh<2, M_IP, 4, 8, 2>, 3, (size_t)4 * 2 * 128 * 128 + stg);
+        case M_L2: return go(k_scan_qh<2, M_L2, 4, 8, 2>, 4, (size_t)4 * 2 * 128 * 128 + nrm);
+        default: return go(k_scan_qh<2, M_COS, 4, 8, 2>, 5, (size_t)4 * 2 * 128 * 128 + nrm);
+        }
+    }
+    // 32 queries per wave, 64-row tiles, two workgroups per CU (<= 80 KB of LDS each)
+    constexpr size_t stg1 = 8 * 96 * 12, nrm1 = 5 * 256 + stg1;
+    if (a.nslab == 1) {
+        switch (metric) {
+        case M_IP: return go(k_scan_qh<1, M_IP, 4, 4, 1>, 6, (size_t)4 * 1 * 64 * 128 + stg1);
+        case M_L2: return go(k_scan_qh<1, M_L2, 4, 4, 1>, 7, (size_t)4 * 1 * 64 * 128 + nrm1);
+        default: return go(k_scan_qh<1, M_COS, 4, 4, 1>, 8, (size_t)4 * 1 * 64 * 128 + nrm1);
+        }
+    }
+    switch (metric) {
+    case M_IP: return go(k_scan_qh<2, M_IP, 4, 4, 1>, 9, (size_t)4 * 2 * 64 * 128 + stg1);
+    case M_L2: return go(k_scan_qh<2, M_L2, 4, 4, 1>, 10, (size_t)4 * 2 * 64 * 128 + nrm1);
+    default: return go(k_scan_qh<2, M_COS, 4, 4, 1>, 11, (size_t)4 * 2 * 64 * 128 + nrm1);
+    }
+}
+
 static int launch_scan_i8c(const ScanArgs& a, uint32_t grid, hipStream_t st, bool fs = false, bool filt = false, bool f4 = false, bool qs = false) {
     constexpr size_t lds = (size_t)(3 * 256 + 2 * 256) * 128;
     if (qs && f4) {   // batched Hamming on the query-stationary tiling (scan_qs.h, F4)
@@ -1893,7 +1956,7 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
         LY_HIP(hipMemsetAsync(w.Q16, 0, (size_t)nslab * qpad * (glds ? GL_BK : (h16 ? HK : SCAN_LDK)) * sizeof(_Float16), st));
         PrepArgs p{};
         p.Q = Qf; p.D = h->dim; p.nq = nq; p.qpad = qpad; p.nslab = nslab; p.metric = metric; p.layout = glds ? 1 : (h16 ? 2 : 0);
-        p.sv = h->sv; p.vmax = h->vmax; p.vmin = h->vmin; p.cos_degenerate = h->cos_degenerate;
+        p.sv = h->sv; p.vmax = h->vmax; p.vmin = h->vmin; p.cos_degenerate = h->cos_degenerate; p.rows_integer = h->rows_integer; p.rows_nonneg = h->rows_nonneg; p.amax_v = h->amax;
         p.Q16 = w.Q16; p.qinv = w.qinv; p.qn2 = w.qn2; p.qrinv = w.qrinv; p.marg2 = w.marg2; p.thr = w.thr;
         p.count = w.count; p.overflow = w.overflow;
         hipLaunchKernelGGL(k_prep_queries, dim3(nq), dim3(256), 0, st, p);
@@ -1951,7 +2014,7 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
                     sample.sample_tiles == (uint32_t)h->num_cu && (plan[1].r1 - plan[1].r0 + 255) / 256 >= (uint32_t)h->num_cu &&
                     (uint64_t)k * 50000ull > (uint64_t)sample.sample_tiles * plan_tile &&   // (the stage behind the sample runs the DENSE epilogue)
                     []() { const char* e = getenv("LYNSE_HIP_DENSE"); return !e || atoi(e) != 0; }();
-    bool plan_used_segments = false, plan_used_qs = false, plan_qs_sample = false;
+    bool plan_used_segments = false, plan_used_qs = false, plan_qs_sample = false, plan_used_qh = false;
     // the select behind the last stage + exact rescoring + final order in one launch (k_select_final); LYNSE_HIP_FUSED_TAIL=0:
     // the three separate kernels (A/B)
     const int fused_tail_env = []() { const char* e = getenv("LYNSE_HIP_FUSED_TAIL"); return e ? atoi(e) : 1; }();   // (read per call: tests flip it)
@@ -2107,6 +2170,12 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
                     const uint32_t grid = std::min<uint32_t>(a.ntiles, (uint32_t)h->num_cu * 2);
                     if (!a.emit_all) seg_geometry(grid, 4, &a.nseg, &a.seg);
                     LY_TRY((launch_scan_h16<1, 4, 1, 1, 3, 3, false>(a, metric, grid, st)));
+                } else if (qh_scan_ok(a, filt, qchunks)) {   // the query-stationary tiling of the low-dimensional f16 shadow (scan_qh.h): four segments per workgroup and query
+                    uint32_t segs = 0;
+                    const uint32_t grid = qh_grid(a, (uint32_t)h->num_cu, &segs);
+                    seg_geometry(grid, segs, &a.nseg, &a.seg);
+                    plan_used_qh = true;
+                    LY_TRY(launch_scan_qh(a, metric, grid, st));
                 } else {
                     const uint32_t grid = std::min<uint32_t>(a.ntiles, (uint32_t)h->num_cu);
                     // DENSE epilogue (<4,2,2,4>, L2 / cosine, unfiltered; kernels.h).  Its segments are per wave half.
@@ -2201,7 +2270,7 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
         LY_HIP(hipGetLastError());
     }
     if (tl_prof && (!binary || bin_mfma)) {   // (batched Hamming on the matrix pipe runs the float pipeline's plans)
-        const uint64_t tiling = plan_used_qs ? 0x81u : (small || mid64) ? 0x14u : ((mid128 || waves16 == 3 || waves16 == 2) ? 0x24u : 0x42u);   // (0x81: query-stationary threshold stages)
+        const uint64_t tiling = plan_used_qs ? 0x81u : plan_used_qh ? 0x82u : (small || mid64) ? 0x14u : ((mid128 || waves16 == 3 || waves16 == 2) ? 0x24u : 0x42u);   // (0x81: query-stationary threshold stages; 0x82: those of the low-dimensional f16 shadow, scan_qh.h)
         std::lock_guard<std::mutex> plk(h->prof_mu);
         h->prof.last_plan = (sample.sample_tiles ? 1u : 0u) | ((sample.sample_tiles && sample_threshold_only) ? 2u : 0u) | (i8c ? 4u : 0u) |
                             (plan_used_segments ? 8u : 0u) | (small ? 16u : 0u) | (fs ? 128u : 0u) | ((uint64_t)(plan.size() & 0xff) << 8) | (tiling << 16) |
@@ -3538,8 +3607,8 @@ extern "C" int lynse_hip_top_k_search(const float* query, const float* candidate
     {   // empty the shard (capacity and buffers stay)
         std::unique_lock<std::shared_mutex> lk(h->rw);
         h->n = 0; h->n_stats = 0; h->n16 = 0; h->n_packed = 0; h->n_sq8 = 0; h->n_sq8a = 0; h->n_sq8c = 0; h->n_bpm = 0; h->i8c_strikes.store(0); h->i8c_strikes_l2.store(0); h->i8c_strikes_cos.store(0);
-        h->amax = h->vmax = h->vmin = 0.f; h->sv = 1.f; h->cos_degenerate = 0;
-        const uint32_t init[4] = {0u, 0u, 0x7f800000u, 0u};
+        h->amax = h->vmax = h->vmin = 0.f; h->sv = 1.f; h->cos_degenerate = 0; h->rows_integer = 0; h->rows_nonneg = 0;
+        const uint32_t init[5] = {0u, 0u, 0x7f800000u, 0u, 0u};
         LY_TRY(use_device(h));
         LY_TRY(h2d_done(h->d_stats, init, sizeof init));
     }

@@ -1,0 +1,403 @@
+// scan_qh.h — k_scan_qh: the QUERY-STATIONARY tiling for the f16 shadow at LOW dimension (64 .. 256 columns: BASELINE config 3,
+// SIFT-like 1M x 128, squared L2, k = 100).  Threshold stages of an unfiltered FLAT batch of 33..256 queries on the float path.
+//
+// Reference work on this path: FlatMmap::search -> exact_flat_search's chunked scan (src/storage/flat_mmap.rs:2179-2256, :2132-2176;
+// the distance kernels src/distance/simd.rs:1529-1581) — every row of the shard scored against every query of the batch.
+//
+// What bounded the 256-row x 256-query tile of k_scan_h16<4,2,2,4> there: at 128 columns a tile is two slab steps, so the
+// float epilogue (one value per (row, query) pair: as many VALU operations as the two steps have MFMA cycles) and the tile boundary —
+// eight waves draining into the epilogue together — weigh as much as the MFMAs; nothing overlapped them.  Here:
+//   * the query operand is REGISTER-resident for the whole launch, as in k_scan_qs (scan_qs.h) — and at <= 256 columns it is small:
+//     a wave owns 64 queries (two 32-query blocks, 2 x NSLAB x 16 registers), so every ds_read_b128 row fragment feeds TWO MFMAs
+//     (k_scan_qs: one) and the four SIMDs of a CU cover the 256 queries with ONE wave each;
+//   * the second wave of a SIMD takes the OTHER half of the tile's rows (128-row tiles: waves 0-3 rows 0..63, waves 4-7 rows 64..127)
+//     and runs half a step out of phase (the ping-pong roles of k_scan_qs): early waves  barrier -> MFMAs -> epilogue -> DMA issue,
+//     late waves  barrier -> epilogue of the PREVIOUS tile -> DMA issue -> MFMAs — one wave's VALU epilogue sits beside the other
+//     wave's MFMAs on the same SIMD;
+//   * the LDS holds only rows (a ring of NS whole-K stages of 128 rows, global_load_lds_dwordx4 in full 128-B lines, the XOR slot
+//     swizzle of k_scan_h16 on the source address) and, for L2 / cosine, a small ring of the tile's f32 row norms;
+//   * the epilogue is the DENSE float epilogue of k_scan_h16 (the same level-1 value against the same loosened threshold, the same
+//     exact coarse expression and keys): per group of four rows one maximum, one ballot per tile, a rare grouped slow path that appends
+//     (score, row) keys to the lane's private segment (four segments per workgroup and query: row half x wave half).
+// Byte layouts are those of k_scan_h16: f16 rows with a pitch of ld16 halves (whole 64-element slabs), the query image of
+// k_prep_queries (layout 2: [slab][q][8 slots ^ ((q >> 1) & 7)][16 B]) — a 16-element k-step of v_mfma_f32_32x32x16_f16 is 32 bytes
+// of a row, exactly the k-step of the int8 form.
+#pragma once
+
+namespace lynse {
+
+typedef float qh_f32x2 __attribute__((ext_vector_type(2)));
+
+// QB = query blocks of 32 per wave.
+//   QB = 2: a wave owns 64 queries; 128-row tiles, waves 0-3 rows 0..63, waves 4-7 rows 64..127; one 512-thread workgroup per CU
+//           (two waves per SIMD, 256 registers each); every row fragment read feeds two MFMAs.
+//   QB = 1: a wave owns 32 queries (the layout of k_scan_qs); 64-row tiles, every wave reads every row fragment; 128 registers per
+//           wave, TWO workgroups per CU (four waves per SIMD): the branchy float epilogue of one workgroup runs under the MFMAs of
+//           the other, and twice as many waves fill each other's LDS / branch bubbles.
+// debug_flags & 2 = no emission, & 64 = s_memtime phase sums (scripts/qh_phase_timing.py)
+template <int NSLAB, int MET, int NS, int NBUF, int QB>
+__global__ void __launch_bounds__(512, (QB == 1 ? 4 : 2)) k_scan_qh(ScanArgs a) {
+    static_assert(QB == 1 || QB == 2, "query blocks per wave");
+    constexpr int RT = 64 * QB;              // rows per tile
+    constexpr int SB = NSLAB * RT * 128;     // bytes per ring stage (a whole tile, all K)
+    constexpr int PP = SB / 1024;            // LDS-DMA instructions per stage (1 KiB each: 8 rows x 128 B)
+    constexpr int PPW = PP / 8;              // ... per wave
+    static_assert(PP % 8 == 0, "the pieces of a stage split evenly over the 8 waves");
+    constexpr int NR = NSLAB * 4 * 2;        // fragment reads per wave and step (slab, k-step, row block); each feeds QB MFMAs
+    static_assert(NR % NBUF == 0 && NBUF >= 2 && NBUF <= NR, "fragment ring");
+    static_assert(NS >= 3, "ring depth");
+    constexpr bool NORMS = MET != M_IP;
+    constexpr bool ASC = MET != M_IP;
+    constexpr int NRM = RT * 4;              // bytes of row norms per tile slot (one one-dword LDS-DMA of wave 0 per 64 rows)
+    constexpr int NRM_SLOTS = NS + 1;        // (a slot is refilled two steps after its tile was computed: the late waves' epilogues are safe)
+    constexpr int NRM_OFF = NS * SB;
+    static_assert(NRM_OFF + (NORMS ? NRM_SLOTS * NRM : 0) <= (QB == 1 ? 80 : 160) * 1024, "LDS");
+    // Key staging (round 5): the keys a wave emits are collected in ITS region of the LDS — each with the slot of its lane's private
+    // segment (ScanArgs::candB, as in k_scan_qs) — and stored when the region is full and at the end of the launch.  A key stored straight to global
+    // memory rides on vmcnt in front of the ring pieces of its step, and the next counted wait in front of the barrier then waits for its
+    // write acknowledgement: at 128 columns a step is as short as that round trip (~1.8 us) and with k = 100 every step of every workgroup
+    // holds a key (s_memtime: 148k of a stage's ticks with emission against 78k without — the SAME cost at a tenth of the keys per step
+    // that emit).  LDS appends ride on lgkmcnt; nothing of the epilogue touches vmcnt any more.
+    constexpr int EW = QB == 1 ? 96 : 256;   // keys per wave region (8 B key + 4 B slot index each)
+    constexpr int STG_OFF = NRM_OFF + (NORMS ? NRM_SLOTS * NRM : 0);
+    static_assert(STG_OFF + 8 * EW * 12 <= (QB == 1 ? 80 : 160) * 1024, "LDS");
+    constexpr int NXW = NORMS ? QB : 0;      // LDS-DMAs wave 0 issues per step on top of its ring pieces
+    constexpr int WAITN = (NS - 2) * PPW;    // ring pieces that may still be in flight at the barrier
+    static_assert((NS - 1) * (PPW + NXW) <= 63, "vmcnt");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wq = QB == 2 ? (wave & 3) : wave, wr = QB == 2 ? (wave >> 2) : 0;
+    const bool late = wave >= 4;
+    const int l32 = lane & 31, hi = lane >> 5;
+    const uint32_t ntiles = (a.row1 - a.row0 + RT - 1) / RT;
+    if (blockIdx.x >= ntiles) return;
+    const uint32_t n_ord = (ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x;   // this workgroup's tiles: blockIdx.x, + gridDim.x, ...
+    auto tile_of = [&](uint32_t ord) -> uint32_t { return blockIdx.x + ord * gridDim.x; };
+    const uint32_t ldb = a.ld16 * 2u;        // row pitch in bytes
+
+    // ---- the wave's query blocks: B fragments of every k-step, register-resident for the whole launch
+    const int swz = (l32 >> 1) & 7;
+    qs_i32x4 bq[QB][NSLAB * 4];
+#pragma unroll
+    for (int j = 0; j < QB; ++j) {
+        const char* qimg = reinterpret_cast<const char*>(a.Q16) + (size_t)(wq * (32 * QB) + j * 32 + l32) * 128;
+#pragma unroll
+        for (int s = 0; s < NSLAB; ++s)
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+                bq[j][s * 4 + kk] = *reinterpret_cast<const qs_i32x4*>(qimg + (size_t)s * a.qpad * 128 + (((kk * 2 + hi) ^ swz) * 16));
+    }
+    // per-query constants of this lane's queries (column lane % 32 of each block)
+    uint32_t qn[QB];
+    bool ok[QB];
+    float c_qinv[QB], c_extra[QB], c_thr[QB], c_lim[QB];   // c_lim: what the level-1 value is compared with (k_scan_h16, set_pre)
+    const bool wave_live = (uint32_t)wq * (32u * QB) < a.nq;     // a wave whose queries all lie beyond the batch only feeds the ring
+#pragma unroll
+    for (int j = 0; j < QB; ++j) {
+        qn[j] = (uint32_t)(wq * (32 * QB) + j * 32 + l32);
+        ok[j] = qn[j] < a.nq;
+        const uint32_t n = ok[j] ? qn[j] : 0u;
+        c_qinv[j] = ok[j] ? a.qinv[n] : 0.0f;
+        c_extra[j] = MET == M_L2 ? (ok[j] ? a.qn2[n] : 0.0f) : (MET == M_COS ? (ok[j] ? a.qrinv[n] : 0.0f) : 0.0f);
+        c_thr[j] = ok[j] ? a.thr[n] : 0.0f;
+        float lim;
+        if constexpr (MET == M_IP) {
+            lim = c_thr[j];                                        // (IP: the level-1 value is the score itself)
+        } else if constexpr (MET == M_L2) {
+            const float qn2 = c_extra[j], vmax2 = a.vmax2;
+            lim = (qn2 - c_thr[j]) - 2e-6f * (qn2 + fabsf(c_thr[j]) + vmax2);
+            if (!(vmax2 > 0.0f)) lim = -LY_INF;
+            if (!(fabsf(lim) < 3.0e38f)) lim = -LY_INF;            // inf / NaN (open threshold, overflow): no pre-filter
+        } else {
+            const float den = c_qinv[j] * c_extra[j];              // qinv / |q|
+            lim = ((1.0f - c_thr[j]) - 1e-6f * (1.0f + fabsf(c_thr[j]))) / den;
+            lim = lim - fabsf(lim) * 2e-6f;
+            if (!(den > 0.0f)) lim = -LY_INF;
+            if (!(fabsf(lim) < 3.0e38f)) lim = -LY_INF;
+        }
+        if (a.debug_flags & 2) lim = LY_INF;                       // (timing experiments: no emission)
+        c_lim[j] = ok[j] ? lim : LY_INF;
+    }
+    asm volatile("" ::: "memory");   // (the fragment / constant loads stay in front of the ring pieces)
+
+    // ---- row stream (LDS-DMA): step g of this workgroup = its g-th tile.  Piece p = wave * PPW + j of a stage: slab p / (RT / 8), rows
+    // (p % (RT / 8)) * 8 .. +8 of the tile; lane l brings the 16 B of row (l >> 3), PHYSICAL slot (l & 7) = logical slot (l & 7) ^ ((row >> 1) & 7)
+    uint32_t v_off[PPW];
+    const char* v_base = nullptr;   // uniform: first row of the tile being issued
+    uint32_t is_ord = 0, is_stage = 0, is_count = 0;
+    auto enter_tile = [&]() {
+        const uint32_t rbase = a.row0 + tile_of(is_ord) * RT;
+        const uint32_t span = a.row1 - 1 - rbase;   // rows past the last one re-read it (masked in the epilogue)
+        v_base = reinterpret_cast<const char*>(a.V16) + (size_t)rbase * ldb;
+#pragma unroll
+        for (int j = 0; j < PPW; ++j) {
+            const int p = wave * PPW + j;
+            uint32_t r = (p % (RT / 8)) * 8 + (lane >> 3);
+            const uint32_t col = (uint32_t)(p / (RT / 8)) * 128u + (((lane & 7) ^ ((r >> 1) & 7)) * 16);
+            r = r < span ? r : span;
+            v_off[j] = r * ldb + col;
+        }
+    };
+    auto issue_pieces = [&]() {
+#pragma unroll
+        for (int j = 0; j < PPW; ++j) glds16<2>(v_base + v_off[j], smem + is_stage * SB + (wave * PPW + j) * 1024);
+        if constexpr (NORMS) {   // wave 0: the f32 norms of the tile being issued (rows past the end: the arrays' slack of 256 floats)
+            if (wave == 0) {
+                const float* src = (MET == M_L2 ? a.vn2 : a.vrinv) + (a.row0 + tile_of(is_ord) * RT) + lane;
+                char* dst = smem + NRM_OFF + (is_count % NRM_SLOTS) * NRM;
+#pragma unroll
+                for (int t = 0; t < QB; ++t)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 64 * t), (__attribute__((address_space(3))) void*)(dst + 256 * t), 4, 0, 0);
+            }
+        }
+    };
+    auto advance = [&]() {   // past the end the last real tile is issued again (uniform DMA counts; its stage is never read)
+        is_stage = is_stage + 1 == NS ? 0 : is_stage + 1;
+        if (++is_count < n_ord) {
+            ++is_ord;
+            enter_tile();
+        }
+    };
+    enter_tile();
+#pragma unroll
+    for (int s0 = 0; s0 < NS - 1; ++s0) {
+        issue_pieces();
+        advance();
+    }
+    // the query fragments and constants are in registers; this wave's (NS - 1) stages of ring pieces stay in flight
+    if (wave == 0) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NS - 1) * (PPW + NXW)) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NS - 1) * PPW) : "memory");
+
+    // ---- fragment reads: row r of slab sl of a stage lives at sl * RT * 128 + r * 128, logical 16-B slot c at physical c ^ ((r >> 1) & 7)
+    // lane (l32, hi) of the A fragment (sl, kk, rb): row wr * 64 + rb * 32 + l32, slot kk * 2 + hi.  Reads and waits are issued by hand
+    // (hipcc answers every ds_read it can see with s_waitcnt vmcnt(0) while LDS-DMA is in flight); LDS reads return in order.
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    const uint32_t a_lane = lds0 + (uint32_t)(wr * 64 + l32) * 128u + (uint32_t)((hi ^ swz) * 16);
+    qs_i32x4 af[NBUF];
+    uint32_t ad_cur[4];
+    auto read_frag = [&](qs_i32x4& dst, const uint32_t (&ad)[4], auto idxc) {   // read idx of a step: (sl, kk, rb) = (idx / 8, (idx / 2) % 4, idx % 2)
+        constexpr int idx = decltype(idxc)::value;
+        constexpr int sl = idx / 8, kk = (idx / 2) % 4, rb = idx % 2;
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(ad[kk]), "n"(sl * (RT * 128) + rb * (32 * 128)));
+    };
+    f32x16 acc[2][QB];   // [row block][query block]
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < QB; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    uint32_t e_cnt = 0;   // (uniform) keys staged in this wave's LDS region
+    uint32_t cnt[QB];     // keys in this lane's private segment of each of its queries
+#pragma unroll
+    for (int j = 0; j < QB; ++j) cnt[j] = 0u;
+    uint32_t c_stage = NS - 1;    // (incremented before use: the first step computes stage 0)
+    typedef _Float16 qh_h8 __attribute__((ext_vector_type(8)));
+    auto mfma_step = [&]() {
+        ly_static_for<NBUF - 1>([&](auto ic) { read_frag(af[decltype(ic)::value], ad_cur, ic); });
+        __builtin_amdgcn_sched_barrier(0);
+        ly_static_for<NR>([&](auto ic) {
+            constexpr int idx = decltype(ic)::value;
+            constexpr int nxt = idx + NBUF - 1;
+            if constexpr (nxt < NR) read_frag(af[nxt % NBUF], ad_cur, std::integral_constant<int, nxt>{});
+            constexpr int outstanding = nxt < NR ? NBUF : NR - idx;   // reads for MFMAs idx .. min(nxt, last): the oldest is this one's
+            asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(af[idx % NBUF]) : "n"(outstanding - 1));
+            __builtin_amdgcn_sched_barrier(0);
+            constexpr int sl = idx / 8, kk = (idx / 2) % 4, rb = idx % 2;
+            constexpr int ks = sl * 4 + kk;
+            const qh_h8 av = __builtin_bit_cast(qh_h8, af[idx % NBUF]);
+            ly_static_for<QB>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                if constexpr (ks == 0) {   // first k-step of a tile: C = 0 (no accumulator clears)
+                    const f32x16 z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+                    acc[rb][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, __builtin_bit_cast(qh_h8, bq[j][ks]), z, 0, 0, 0);
+                } else {
+                    acc[rb][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, __builtin_bit_cast(qh_h8, bq[j][ks]), acc[rb][j], 0, 0, 0);
+                }
+            });
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    };
+    auto wait_and_barrier = [&]() {
+        if (wave == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * (PPW + NXW)) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAITN) : "memory");
+        __builtin_amdgcn_s_barrier();
+        c_stage = c_stage + 1 == NS ? 0 : c_stage + 1;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) ad_cur[kk] = (a_lane ^ (uint32_t)(kk * 32)) + c_stage * SB;
+    };
+
+    const uint32_t e_base = lds0 + (uint32_t)STG_OFF + (uint32_t)wave * (uint32_t)(EW * 12);   // keys [EW] u64, then slot indices into candB [EW] u32
+    auto flush_keys = [&]() {   // (a full region — rare — and once at the end of the launch: plain stores into the lanes' private segments)
+        for (uint32_t e = (uint32_t)lane; e < e_cnt; e += 64u) {
+            uint64_t key;
+            uint32_t idx;
+            asm volatile("ds_read_b64 %0, %2\n\tds_read_b32 %1, %3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(key), "=&v"(idx) : "v"(e_base + e * 8u), "v"(e_base + (uint32_t)(EW * 8) + e * 4u) : "memory");
+            a.candB[idx] = key;
+        }
+        e_cnt = 0;
+    };
+    // ---- tile epilogue: this lane's 2 x 16 values per query block belong to ONE query each; rows wr * 64 + rb * 32 + (r & 3) + 8 (r >> 2) + 4 hi
+    auto epilogue = [&](uint32_t e_tile, [[maybe_unused]] uint32_t e_ord_) {
+        const uint32_t nbase = lds0 + NRM_OFF + (e_ord_ % NRM_SLOTS) * NRM + (uint32_t)(wr * 64) * 4u + (uint32_t)hi * 16u;
+        // the norms of the wave's 16 rows of row block i (broadcast reads: all lanes of a wave half hold the same rows)
+        auto read_norms = [&](f32x4 (&nv)[4], int i) {
+            if constexpr (NORMS) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) asm volatile("ds_read_b128 %0, %1" : "=v"(nv[g]) : "v"(nbase + (uint32_t)(i * 32 + 8 * g) * 4u));
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(nv[0]), "+v"(nv[1]), "+v"(nv[2]), "+v"(nv[3]));
+            }
+        };
+        // level 1: the maximum per group of four rows of 2 q.v - |v|^2 (L2) / q.v / |v| (cosine) / the score itself (IP)
+        auto level1 = [&](const f32x4 (&nv)[4], int i, int j, int g) -> float {
+            const float mm = MET == M_L2 ? 2.0f * c_qinv[j] : c_qinv[j];
+            const qh_f32x2 m2 = {mm, mm};
+            const qh_f32x2 x01 = {acc[i][j][4 * g], acc[i][j][4 * g + 1]}, x23 = {acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+            qh_f32x2 p01, p23;
+            if constexpr (MET == M_L2) {
+                const qh_f32x2 n01 = {-nv[g][0], -nv[g][1]}, n23 = {-nv[g][2], -nv[g][3]};
+                p01 = __builtin_elementwise_fma(x01, m2, n01);
+                p23 = __builtin_elementwise_fma(x23, m2, n23);
+            } else if constexpr (MET == M_COS) {
+                const qh_f32x2 n01 = {nv[g][0], nv[g][1]}, n23 = {nv[g][2], nv[g][3]};
+                p01 = x01 * n01;
+                p23 = x23 * n23;
+            } else {
+                p01 = x01 * m2;
+                p23 = x23 * m2;
+            }
+            return fmaxf(fmaxf(p01[0], p01[1]), fmaxf(p23[0], p23[1]));
+        };
+        float gm[2][QB][4];
+        float best[QB];
+#pragma unroll
+        for (int j = 0; j < QB; ++j) best[j] = -LY_INF;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            f32x4 nv[4];
+            read_norms(nv, i);
+#pragma unroll
+            for (int j = 0; j < QB; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float m = level1(nv, i, j, g);
+                    gm[i][j][g] = m;
+                    best[j] = fmaxf(best[j], m);
+                }
+        }
+        bool any = false;
+#pragma unroll
+        for (int j = 0; j < QB; ++j) any = any || best[j] >= c_lim[j];
+        if (__builtin_expect(__ballot(any) == 0ull, 1)) return;
+        const uint32_t rbase = a.row0 + e_tile * RT + (uint32_t)(wr * 64);
+        const uint32_t sgm = (blockIdx.x * (uint32_t)QB + (uint32_t)wr) * 2u + (uint32_t)hi;
+#pragma unroll
+        for (int j = 0; j < QB; ++j) {
+            if (QB > 1 && __builtin_expect(__ballot(best[j] >= c_lim[j]) == 0ull, 1)) continue;
+            const uint32_t seg0 = (qn[j] * a.nseg + sgm) * a.seg;   // this lane's private segment of query qn[j] in candB
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                bool hit_i = false;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) hit_i = hit_i || gm[i][j][g] >= c_lim[j];
+                if (__builtin_expect(__ballot(hit_i) == 0ull, 1)) continue;
+                f32x4 nv[4];   // (the row block's norms again: the fast path keeps one row block of them)
+                read_norms(nv, i);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    // one wave-level branch per group of four (a branch per element cost more than everything it guards)
+                    if (__builtin_expect(__ballot(gm[i][j][g] >= c_lim[j]) == 0ull, 1)) continue;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int r = 4 * g + e;
+                        float sc = acc[i][j][r] * c_qinv[j];   // the exact coarse expression of k_scan_h16 (score(): separate mul / add)
+                        if constexpr (MET == M_L2) sc = nv[g][e] - 2.0f * sc + c_extra[j];
+                        if constexpr (MET == M_COS) sc = 1.0f - sc * nv[g][e] * c_extra[j];
+                        const uint32_t m = rbase + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                        const bool pass = ok[j] && m < a.row1 && (ASC ? (sc <= c_thr[j]) : (sc >= c_thr[j])) && !(a.debug_flags & 2);
+                        const bool st = pass && cnt[j] < a.seg;
+                        const uint64_t pm = __ballot(st);
+                        if (pm) {   // (uniform) append the passing lanes' keys to the wave's staging region
+                            const uint32_t np = (uint32_t)__popcll(pm);
+                            if (e_cnt + np > (uint32_t)EW) flush_keys();
+                            const uint32_t slot = e_cnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(pm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pm, 0u));
+                            if (st) {
+                                const uint64_t key = make_key(sc, m, ASC);
+                                const uint32_t idx = seg0 + cnt[j];
+                                ++cnt[j];
+                                asm volatile("ds_write_b64 %0, %1\n\tds_write_b32 %2, %3" ::"v"(e_base + slot * 8u), "v"(key), "v"(e_base + (uint32_t)(EW * 8) + slot * 4u), "v"(idx) : "memory");
+                            }
+                            e_cnt += np;
+                        }
+                        if (__builtin_expect(__ballot(pass && !st) != 0ull, 0)) {   // a full private segment (massive ties): the shared region
+                            if (pass && !st) {
+                                const uint32_t gs = atomicAdd(&a.count[qn[j]], 1u);
+                                if (gs < a.cap) a.cand[(size_t)qn[j] * a.cap + gs] = make_key(sc, m, ASC);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    };
+
+    // ---- main loop (ping-pong roles, scan_qs.h): the early waves (0-3: one per SIMD) run
+    // barrier -> MFMAs -> epilogue -> DMA issue, the late waves (4-7) barrier -> epilogue of the PREVIOUS tile -> DMA issue -> MFMAs.
+    // ONE loop over half steps with ONE copy of the MFMA step and ONE of the epilogue (two inlined copies of either made the compiler
+    // keep two sets of accumulators and copy 64 registers per step): an even half step opens with the barrier; the early waves compute
+    // in the even half steps and finish their tile in the odd ones, the late waves the other way round.
+    bool have = false;   // a computed tile is waiting for its epilogue
+    uint32_t e_ord = 0;
+    // debug_flags & 64: s_memtime sums per wave (a.dbg[(block * 8 + wave) * 4 ..]: DMA wait + barrier, MFMA step, epilogue, DMA issue)
+    const bool timing = (a.debug_flags & 64) != 0 && a.dbg != nullptr;
+    unsigned long long t_ph[4] = {0ull, 0ull, 0ull, 0ull}, tp = timing ? __builtin_amdgcn_s_memtime() : 0ull;
+    auto stamp = [&](int b) {
+        if (timing) {
+            asm volatile("" ::"v"(acc[0][0][0]), "v"(acc[1][QB - 1][15]));
+            const unsigned long long t = __builtin_amdgcn_s_memtime();
+            t_ph[b] += t - tp;
+            tp = t;
+        }
+    };
+    for (uint32_t ph = 0; ph <= 2u * n_ord; ++ph) {
+        const uint32_t g = ph >> 1;
+        if (!(ph & 1u) && g < n_ord) { wait_and_barrier(); stamp(0); }
+        if (((ph & 1u) != 0u) == late) {
+            if (g < n_ord) {
+                if (wave_live) mfma_step();
+                have = true;
+                stamp(1);
+            }
+        } else {
+            if (have) {
+                if (wave_live) epilogue(tile_of(e_ord), e_ord);
+                ++e_ord;
+                have = false;
+                stamp(2);
+            }
+            // (the keys of the epilogue above were stored BEFORE these pieces: at the next counted wait they are older than everything
+            // that may stay in flight)
+            if (g < n_ord) {
+                issue_pieces();
+                advance();
+                stamp(3);
+            }
+        }
+    }
+    if (timing && lane == 0 && blockIdx.x < 256) {
+        unsigned long long* o = a.dbg + ((size_t)blockIdx.x * 8 + wave) * 4;
+        o[0] = t_ph[0]; o[1] = t_ph[1]; o[2] = t_ph[2]; o[3] = t_ph[3];
+    }
+    flush_keys();
+    if (a.seg) {
+#pragma unroll
+        for (int j = 0; j < QB; ++j)
+            if (ok[j]) a.segcnt[(size_t)qn[j] * a.nseg + (blockIdx.x * (uint32_t)QB + (uint32_t)wr) * 2u + (uint32_t)hi] = (uint8_t)cnt[j];
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+}  // namespace lynse
