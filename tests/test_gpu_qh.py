@@ -179,3 +179,108 @@ def test_qh_after_appends_and_on_an_f16_shard(L, oracle):
             cc = int(c[qi])
             assert cc == len(e_ids) and np.array_equal(d[qi][:cc].view(np.uint32), e_d.view(np.uint32)) and \
                 np.array_equal(r[qi][:cc].astype(np.uint64), e_ids.astype(np.uint64)), ("f16", name, qi)
+
+
+def _int_case(L, oracle, data, queries, metrics, ks, tag, dtype=None, expect_exact=None, strict=()):
+    """Integer-valued rows: search on a shard with the exactness rule and on one without it (LYNSE_HIP_NO_EXACT_INT), both equal to
+    the oracle bit for bit; expect_exact: True -> the rule must have narrowed the rescoring pool to (about) k rows per query,
+    False -> the pools must be the same (the rule did not apply)."""
+    dim = data.shape[1]
+
+    def build(no_rule):
+        if no_rule:
+            os.environ["LYNSE_HIP_NO_EXACT_INT"] = "1"
+        try:
+            if dtype == "f16":
+                idx = L.FlatIndex(None, dim, 0, dtype="f16")
+                idx.write_f16_bits(data.astype(np.float16).view(np.uint16))
+            else:
+                idx = L.FlatIndex(None, dim)
+                idx.write(data)
+            idx.finalize()
+        finally:
+            os.environ.pop("LYNSE_HIP_NO_EXACT_INT", None)
+        idx.profile_enable(True)
+        return idx
+
+    a, b = build(False), build(True)
+    nq = queries.shape[0]
+    for name in metrics:
+        for k in ks:
+            a.profile_get(reset=True); b.profile_get(reset=True)
+            ra, da, ca = a.search_batch_arrays(queries, k, name)
+            rb, db, cb = b.search_batch_arrays(queries, k, name)
+            pa, pb = a.profile_get(reset=True), b.profile_get(reset=True)
+            assert np.array_equal(ra, rb) and np.array_equal(da.view(np.uint32), db.view(np.uint32)) and np.array_equal(ca, cb), (tag, name, k)
+            for qi in sorted({0, 1, nq // 2, nq - 1}):
+                if dtype == "f16":
+                    e_ids, e_d = oracle.canonical_topk_f16(queries[qi], data, k, METRICS[name])
+                else:
+                    e_ids, e_d = oracle.canonical_topk(queries[qi], data, k, METRICS[name])
+                c = int(ca[qi])
+                assert c == len(e_ids) and np.array_equal(da[qi][:c].view(np.uint32), e_d.view(np.uint32)) and \
+                    np.array_equal(ra[qi][:c].astype(np.uint64), e_ids.astype(np.uint64)), (tag, name, k, qi)
+            if expect_exact is True and name != "cosine":
+                assert pa["pool_entries"] <= pb["pool_entries"], (tag, name, k, pa, pb)
+            if name in strict:     # (the rule must have applied: fewer rows inside the margin than with it)
+                assert pa["pool_entries"] < pb["pool_entries"], (tag, name, k, pa, pb)
+            if expect_exact is False:
+                assert pa["pool_entries"] == pb["pool_entries"], (tag, name, k, pa, pb)
+
+
+def test_exactness_rule_of_integer_collections_and_its_limits(L, oracle):
+    """k_prep_queries' exactness rule: E = 0 only when rows and query are integers, exact in f16 (<= 2048) and
+    D aq av, D aq^2, D av^2, D dmax^2 < 2^24.  Inside the bounds the zero-margin search equals the oracle (ties everywhere: small
+    integer alphabets); outside them the rule must not apply (same pools as a shard built without it)."""
+    rng = np.random.default_rng(99)
+    nq = 64
+    for n in (70_000, 60_000):    # (60,000 rows: under the int8 pass's 65,536 — IP batches run the float path too, contiguous plan)
+        # (a) signed integers, dmax = aq + av: D = 64, |x| <= 100: 64 * 200^2 = 2.56M
+        data = rng.integers(-100, 101, (n, 64)).astype(f32)
+        queries = rng.integers(-100, 101, (nq, 64)).astype(f32)
+        _int_case(L, oracle, data, queries, ("l2", "ip", "cosine"), (10, 100), ("signed", n), expect_exact=True, strict=("l2",))
+        # (b) tiny alphabet {0, 1, 2}: massive ties at every rank
+        data = rng.integers(0, 3, (n, 128)).astype(f32)
+        queries = rng.integers(0, 3, (nq, 128)).astype(f32)
+        _int_case(L, oracle, data, queries, ("l2", "ip"), (10, 64), ("ternary", n), expect_exact=True)
+    n = 70_000
+    # (c) just inside the bound: D = 128, non-negative, max 361: 128 * 361^2 = 16.68M < 2^24
+    data = rng.integers(0, 362, (n, 128)).astype(f32)
+    queries = rng.integers(0, 362, (nq, 128)).astype(f32)
+    _int_case(L, oracle, data, queries, ("l2", "ip"), (10,), "inside", expect_exact=True, strict=("l2",))
+    # (d) just outside: max 363: 128 * 363^2 = 16.87M > 2^24 -> the certified margin (same pools as without the rule)
+    data = rng.integers(0, 364, (n, 128)).astype(f32)
+    data[0, 0] = 363.0
+    queries = rng.integers(0, 364, (nq, 128)).astype(f32)
+    queries[0, 0] = 363.0
+    _int_case(L, oracle, data, queries, ("l2", "ip"), (10,), "outside", expect_exact=False)
+    # (e) one non-integer element in the shard, or beyond the exact f16 integers (4097): the rule is off for the shard
+    data = rng.integers(0, 100, (n, 64)).astype(f32)
+    queries = rng.integers(0, 100, (nq, 64)).astype(f32)
+    d2 = data.copy(); d2[n - 1, 63] = 0.5
+    _int_case(L, oracle, d2, queries, ("l2",), (10,), "one fraction", expect_exact=False)
+    d3 = data.copy(); d3[5, 5] = 4097.0
+    _int_case(L, oracle, d3, queries, ("l2", "ip"), (10,), "beyond f16", expect_exact=False)
+    # (f) an F16 shard of integers (VectorDtype::F16: sequential f32 sums in the reference — exact all the same)
+    data = rng.integers(0, 200, (n, 128)).astype(f32)
+    queries = rng.integers(0, 200, (nq, 128)).astype(f32)
+    _int_case(L, oracle, data, queries, ("l2", "ip"), (10,), "f16 shard", dtype="f16", expect_exact=True, strict=("l2",))
+    # (g) the flag follows appends: integers first (rule on), then a block with fractions (rule off from then on)
+    idx = L.FlatIndex(None, 64)
+    base = rng.integers(0, 50, (n, 64)).astype(f32)
+    idx.write(base); idx.finalize(); idx.profile_enable(True)
+    q = rng.integers(0, 50, (nq, 64)).astype(f32)
+    idx.profile_get(reset=True)
+    r1, dd1, c1 = idx.search_batch_arrays(q, 10, "l2")
+    p1 = idx.profile_get(reset=True)
+    extra = (rng.integers(0, 50, (5000, 64)) + 0.25).astype(f32)
+    idx.write(extra); idx.finalize()
+    r2, dd2, c2 = idx.search_batch_arrays(q, 10, "l2")
+    p2 = idx.profile_get(reset=True)
+    allrows = np.concatenate([base, extra])
+    for qi in (0, 31, 63):
+        e_ids, e_d = oracle.canonical_topk(q[qi], base, 10, O.L2)
+        assert np.array_equal(r1[qi].astype(np.uint64), e_ids.astype(np.uint64)) and np.array_equal(dd1[qi].view(np.uint32), e_d.view(np.uint32))
+        e_ids, e_d = oracle.canonical_topk(q[qi], allrows, 10, O.L2)
+        assert np.array_equal(r2[qi].astype(np.uint64), e_ids.astype(np.uint64)) and np.array_equal(dd2[qi].view(np.uint32), e_d.view(np.uint32))
+    assert p1["pool_entries"] <= p2["pool_entries"], (p1, p2)
