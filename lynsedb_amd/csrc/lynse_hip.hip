@@ -2263,6 +2263,9 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
             sa.stamps = reinterpret_cast<unsigned long long*>(w.gsync + 64) + (size_t)si * 256 * 8;
         if (fs_stage && getenv("LYNSE_HIP_DEBUG_FS")) return LYNSE_OK;   // debugging: stop behind the fused stage (lynse_hip_debug_workspace)
         if (fused_tail && si + 1 == plan.size()) { sa_last = sa; continue; }  // the last select runs inside k_select_final
+        // (round 5, tried: the survivors of the last select handed to the final rescoring in LDS instead of through cand[q] — a store, its
+        // acknowledgement and a load less in the tail's chain: 10M 1.8216 / 1.8213 / 1.8527 against 1.8206 / 1.8455 / 1.8381 ms, shard
+        // 0.2835 / 0.2875 / 0.2824 against 0.2877 / 0.2884 / 0.2950: nothing, removed again, scripts/gpu_r5_tail1.sh)
         // (round 5, tried: the LAST select without the exact-rescored threshold, its coarse-rule survivors all rescored in the final pass —
         // 116 instead of 35 rows per query, two rounds of the final rescoring: 10M step +10 us, shard step +6 us; dropped)
         sa.lds_bytes = sel_lds_bytes(w.cap, nq);
