@@ -1615,6 +1615,10 @@ static int launch_scan_qh(const ScanArgs& a, int metric, uint32_t grid, hipStrea
     }
 }
 
+// (round 5, measured and removed: 1024-bit Hamming on a 64-queries-per-wave form of k_scan_qh — k_scan_qh<4, M_IP, 4, 8, QB = 2, one row block
+// per wave, FP4 MFMA>: every row fragment read feeds two MFMAs, half the LDS fragment returns per MFMA.  Bit-identical, and SLOWER: C5 share
+// 1.900 / 1.916 / 1.928 against 1.705 / 1.708 / 1.725 ms per batch, same box, alternating (scripts/gpu_r5_c5.sh): with one 32-row block per
+// wave a step is 32 MFMAs between two barriers, and a wave's epilogue / DMA issue is no longer covered by its SIMD partner's MFMAs.)
 static int launch_scan_i8c(const ScanArgs& a, uint32_t grid, hipStream_t st, bool fs = false, bool filt = false, bool f4 = false, bool qs = false) {
     constexpr size_t lds = (size_t)(3 * 256 + 2 * 256) * 128;
     if (qs && f4) {   // batched Hamming on the query-stationary tiling (scan_qs.h, F4)
@@ -3743,11 +3747,13 @@ static int stream_wait_bounded(hipStream_t st, hipEvent_t* ev, uint32_t timeout_
     LY_HIP(hipEventRecord(*ev, st));
     return event_wait_bounded(*ev, timeout_ms);
 }
-// Status word of a result block (comm_block_layout): bit 0 = a query of that shard overflowed its candidate buffers (the batch is
-// re-answered on the next plan level, on every rank); any other bit = that rank FAILED while it built its block — it still takes
-// part in the exchange (with an empty block), so that its peers learn of it from the merged word instead of from a timeout.
-constexpr uint32_t STATUS_OVERFLOW = 1u;
-static inline bool status_failed(uint32_t st) { return (st & ~STATUS_OVERFLOW) != 0u; }
+// Status word of a result block (comm_block_layout), OR-ed over the ranks by the merge.  The low byte asks for the batch to be
+// answered again, on every rank: bit 0 = a query of that shard overflowed its candidate buffers (next plan level), bit 1 = an IVF query
+// whose probed lists are all empty (k_or_word: the scan-every-list fallback of ivf.rs:258-265).  Any bit ABOVE the low byte = that rank
+// FAILED while it built its block (the failing rank fills the word's bytes with 2: hipMemsetAsync) — it still takes part in the
+// exchange (with an empty block), so that its peers learn of it from the merged word instead of from a timeout.
+constexpr uint32_t STATUS_OVERFLOW = 1u, STATUS_EMPTY_LISTS = 2u, STATUS_REDO = STATUS_OVERFLOW | STATUS_EMPTY_LISTS;
+static inline bool status_failed(uint32_t st) { return (st & 0xffffff00u) != 0u; }
 
 #include "ivf_host.inc"
 #include "shard_host.inc"

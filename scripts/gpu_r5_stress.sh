@@ -1,0 +1,14 @@
+#!/bin/bash
+# round 5, final binary: randomised parity sweeps (seeds on the command lines; stress_parity.py now also draws integer collections with
+# integer queries and the k_scan_qh variants) + the bare `bench.py --gpus 2` self-launch under gloo
+mkdir -p gpurun_out/r05s
+(timeout 400 python scripts/stress_parity.py 360 51 2>&1 | tail -4) > gpurun_out/r05s/stress_parity.log
+(timeout 240 python scripts/stress_ivf.py 150 52 2>&1 | tail -3) > gpurun_out/r05s/stress_ivf.log
+(timeout 200 python scripts/stress_inflight.py 100 53 2>&1 | tail -3) > gpurun_out/r05s/stress_inflight.log
+(STRESS_COMM=1 timeout 200 python scripts/stress_inflight.py 60 54 2>&1 | grep -vE "^(RCCL|HIP version|ROCm version|Hostname|Librccl)" | tail -3) > gpurun_out/r05s/stress_inflight_comm.log
+(timeout 330 python scripts/stress_ivf_inflight.py 240 55 2>&1 | tail -3) > gpurun_out/r05s/stress_ivf_inflight.log
+(STRESS_COMM=1 timeout 240 python scripts/stress_ivf_inflight.py 120 56 2>&1 | grep -vE "^(RCCL|HIP version|ROCm version|Hostname|Librccl)" | tail -3) > gpurun_out/r05s/stress_ivf_inflight_comm.log
+(timeout 300 python scripts/stress_i8c_batches.py 180 57 2>&1 | tail -3) > gpurun_out/r05s/stress_i8c_batches.log
+(timeout 300 python scripts/stress_ivf_large.py 180 58 2>&1 | tail -3) > gpurun_out/r05s/stress_ivf_large.log
+(LYNSE_BENCH_BACKEND=gloo timeout 400 python bench.py --gpus 2 --rows 2000000 --steps 5 --warmup 2 --no-cpu-baseline 2>/dev/null | tail -1 | cut -c1-400) > gpurun_out/r05s/gloo2_self_launch.log
+for f in gpurun_out/r05s/*.log; do echo "== $f"; cat $f; done

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised parity sweep (GPU): FLAT exact / filtered / SQ8 / f16-dtype / binary searches with random shapes against the
 oracle.  Usage: python scripts/stress_parity.py [seconds] [seed] -> prints the number of cases and any mismatch."""
-import sys, time
+import os, sys, time
 from pathlib import Path
 import numpy as np
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
@@ -25,16 +25,22 @@ while time.time() - t0 < budget and (max_cases is None or cases < max_cases):
     metric = int(rng.choice([O.IP, O.L2, O.COS])) if mode != "binary" else int(rng.choice([O.HAMMING, O.JACCARD, O.DICE]))
     if n * dim > 40_000_000:
         continue
-    kind = rng.integers(0, 3)
+    kind = rng.integers(0, 4)
+    os.environ["LYNSE_HIP_QH"] = str(int(rng.integers(0, 3)))   # (read per call) the threshold stages of 64 / 128-column float batches: k_scan_h16 / k_scan_qh variants
     if mode == "binary":
         data = (rng.random((n, dim)) < 0.4).astype(np.float32)
     elif kind == 0:
         data = rng.standard_normal((n, dim)).astype(np.float32)
     elif kind == 1:
         data = rng.integers(0, 3, (n, dim)).astype(np.float32)  # heavy exact ties
+    elif kind == 3:   # integer collections (the exactness rule of k_prep_queries when the queries are integers too): signed or not, up to ~300
+        hi = int(rng.choice([2, 16, 100, 256, 300]))
+        data = rng.integers(-hi if rng.random() < 0.5 else 0, hi + 1, (n, dim)).astype(np.float32)
     else:
         data = (rng.random((n, dim)) * rng.choice([1e-3, 1.0, 300.0])).astype(np.float32)
     queries = data[rng.integers(0, n, nq)] + (0.1 * rng.standard_normal((nq, dim)).astype(np.float32) if mode != "binary" else 0)
+    if mode != "binary" and kind in (1, 3) and rng.random() < 0.6:   # integer queries: rows of the shard, half of them with integer noise
+        queries = data[rng.integers(0, n, nq)] + rng.integers(-2, 3, (nq, dim)).astype(np.float32) * (rng.random((nq, 1)) < 0.5)
     queries = np.ascontiguousarray(queries, np.float32)
     try:
         if mode == "f16":

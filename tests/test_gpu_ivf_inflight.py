@@ -241,6 +241,45 @@ def test_sharded_ivf_tickets_with_a_one_rank_communicator(L, oracle):
             assert np.array_equal(d[qi, :len(e_ids)].view(np.uint32), e_d.view(np.uint32)), qi
 
 
+def test_sharded_ivf_ticket_with_an_all_lists_empty_query_is_answered_again_not_failed(L, oracle):
+    """The status word of a result block carries TWO kinds of flags (csrc/lynse_hip.hip, STATUS_*): the low byte asks for the batch to be
+    answered again — bit 0 a candidate overflow, bit 1 an IVF query whose probed lists are all empty (ivf.rs:258-265) — and only bits above
+    it mean that a rank failed.  Round 5 first read bit 1 as a failure: every such ticket through a communicator raised (found by
+    scripts/stress_ivf_inflight.py with STRESS_COMM=1, not by a test — this is that test)."""
+    import torch
+
+    from lynsedb_amd.sharded import NativeComm, ShardedIvf, ShardOutputs
+
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(32)
+    n, dim, nlist, nq, k, nprobe = 30_000, 64, 40, 64, 10, 2
+    data, cen, asg, off, rows, _ = _index(L, oracle, rng, n, dim, nlist, L2, nc=10)
+    far = (200.0 + np.arange(3 * dim, dtype=f32)).reshape(3, dim)      # three centroids that own no row
+    cen = np.concatenate([cen, far])
+    off, rows = oracle.lists_from_assignments(asg, cen.shape[0])
+    sh = ShardedIvf(dim, rank=0, world=1, device=0, group=None)
+    sh.load_local(data, cen, asg, "l2")
+    sh.comm = NativeComm(None, 0, 1, 0)
+    qs = (data[rng.integers(0, n, nq)] + 0.05 * rng.standard_normal((nq, dim))).astype(f32)
+    clean = qs.copy()
+    qs[41] = far[1]
+    dqs = [torch.as_tensor(x, device=dev) for x in (clean, qs, clean)]
+    outs = [ShardOutputs(nq, k, 1, dev) for _ in dqs]
+    tickets = [sh.search_submit(dq, k, nprobe, o) for dq, o in zip(dqs, outs)]
+    for t in tickets:
+        t.wait()                      # (raised LynseHipError "another rank ... failed" before the fix)
+    assert sh.index.ticket_stats() == {"in_flight": 3, "inside_submit": 0, "redone_in_wait": 1}
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0].rows, outs[2].rows) and torch.equal(outs[0].dists, outs[2].dists)
+    c1 = outs[1].counts.cpu().numpy()
+    assert int(c1[41]) == k          # every list was scanned for it
+    r, d = outs[1].rows.cpu().numpy().view(np.uint64), outs[1].dists.cpu().numpy()
+    for qi in (0, 41, nq - 1):
+        e_ids, e_d, _ = oracle.ivf_search(qs[qi], data, cen, off, rows, nprobe, k, L2)
+        assert int(c1[qi]) == len(e_ids) and np.array_equal(r[qi, :len(e_ids)], e_ids.astype(np.uint64)), qi
+        assert np.array_equal(d[qi, :len(e_ids)].view(np.uint32), e_d.view(np.uint32)), qi
+
+
 def test_ivf_tickets_from_three_threads(L, oracle):
     """Three submitting threads, one ticket each at a time (contexts 1..3), next to a fourth thread running blocking searches: every
     answer equals the blocking call's."""
