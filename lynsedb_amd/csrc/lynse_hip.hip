@@ -1563,18 +1563,17 @@ static int launch_scan_qs_sample(const ScanArgs& a, uint32_t grid, hipStream_t s
 // 0.215-0.217 ms per batch, same box, alternating) — without emission it is the faster scan (78k against ~100k ticks per 738k-row
 // stage), with it every 64-row step of every workgroup holds a key and the grouped slow path (norm re-read, four ballots, the exact
 // expression) costs as much as the MFMAs of the step; DESIGN 4.3 has the phase table.
-static int qh_variant() { const char* e = getenv("LYNSE_HIP_QH"); return e ? atoi(e) : 0; }   // 0 off, 1 = 32 queries per wave, two workgroups per CU, 2 = 64 queries per wave
-static bool qh_scan_ok(const ScanArgs& a, bool filt, uint32_t qchunks) {
+constexpr int QH_DEFAULT = 1;
+static int qh_variant() { const char* e = getenv("LYNSE_HIP_QH"); return e ? atoi(e) : QH_DEFAULT; }   // 0 = k_scan_h16, 1 = k_scan_qh
+static bool qh_scan_ok(const ScanArgs& a, bool filt, uint32_t qchunks, int level) {
     const int v = qh_variant();
-    if (v != 1 && v != 2) return false;
+    if (v != 1 || level != 0) return false;   // (the plan ladder's later levels run k_scan_h16: k_scan_qh may hand a batch with massive ties to it)
     return !filt && a.emit_all == 0 && qchunks == 1 && a.qpad == 256 && a.nq <= 256 && a.tile_stride == 0 && a.skip_stride == 0 && !a.mask && !a.row_ids &&
            !a.tiles && a.row1 > a.row0 && (a.nslab == 1 || a.nslab == 2) && a.ld16 == a.nslab * 64u;
 }
 static uint32_t qh_grid(const ScanArgs& a, uint32_t num_cu, uint32_t* segs_per_wg) {
-    const bool two = qh_variant() == 2;
-    *segs_per_wg = two ? 4u : 2u;
-    const uint32_t rt = two ? 128u : 64u;
-    return std::min<uint32_t>((a.row1 - a.row0 + rt - 1) / rt, two ? num_cu : 2u * num_cu);
+    *segs_per_wg = 1u;   // (one segment per workgroup and query: the deferred emission of scan_qh.h)
+    return std::min<uint32_t>((a.row1 - a.row0 + 63u) / 64u, 2u * num_cu);
 }
 static int launch_scan_qh(const ScanArgs& a, int metric, uint32_t grid, hipStream_t st) {
     static std::atomic<bool> attr_done[16] = {false};
@@ -1584,34 +1583,19 @@ static int launch_scan_qh(const ScanArgs& a, int metric, uint32_t grid, hipStrea
         LY_HIP(hipGetLastError());
         return LYNSE_OK;
     };
-    if (qh_variant() == 2) {   // 64 queries per wave, 128-row tiles, one workgroup per CU
-        constexpr size_t stg = 8 * 256 * 12, nrm = 5 * 512 + stg;   // norm ring (L2 / cosine) + the waves' key staging regions
-        if (a.nslab == 1) {
-            switch (metric) {
-            case M_IP: return go(k_scan_qh<1, M_IP, 4, 8, 2>, 0, (size_t)4 * 1 * 128 * 128 + stg);
-            case M_L2: return go(k_scan_qh<1, M_L2, 4, 8, 2>, 1, (size_t)4 * 1 * 128 * 128 + nrm);
-            default: return go(k_scan_qh<1, M_COS, 4, 8, 2>, 2, (size_t)4 * 1 * 128 * 128 + nrm);
-            }
-        }
-        switch (metric) {
-        case M_IP: return go(k_scan_qh<2, M_IP, 4, 8, 2>, 3, (size_t)4 * 2 * 128 * 128 + stg);
-        case M_L2: return go(k_scan_qh<2, M_L2, 4, 8, 2>, 4, (size_t)4 * 2 * 128 * 128 + nrm);
-        default: return go(k_scan_qh<2, M_COS, 4, 8, 2>, 5, (size_t)4 * 2 * 128 * 128 + nrm);
-        }
-    }
     // 32 queries per wave, 64-row tiles, two workgroups per CU (<= 80 KB of LDS each)
-    constexpr size_t stg1 = 8 * 96 * 12, nrm1 = 5 * 256 + stg1;
+    constexpr size_t stg1 = 8 * 144 * 24 + 1024, nrm1 = 4 * 256 + stg1;   // (three ring stages: the LDS of the fourth is the staging regions')
     if (a.nslab == 1) {
         switch (metric) {
-        case M_IP: return go(k_scan_qh<1, M_IP, 4, 4, 1>, 6, (size_t)4 * 1 * 64 * 128 + stg1);
-        case M_L2: return go(k_scan_qh<1, M_L2, 4, 4, 1>, 7, (size_t)4 * 1 * 64 * 128 + nrm1);
-        default: return go(k_scan_qh<1, M_COS, 4, 4, 1>, 8, (size_t)4 * 1 * 64 * 128 + nrm1);
+        case M_IP: return go(k_scan_qh<1, M_IP, 3, 2, 1>, 6, (size_t)3 * 1 * 64 * 128 + stg1);
+        case M_L2: return go(k_scan_qh<1, M_L2, 3, 2, 1>, 7, (size_t)3 * 1 * 64 * 128 + nrm1);
+        default: return go(k_scan_qh<1, M_COS, 3, 2, 1>, 8, (size_t)3 * 1 * 64 * 128 + nrm1);
         }
     }
     switch (metric) {
-    case M_IP: return go(k_scan_qh<2, M_IP, 4, 4, 1>, 9, (size_t)4 * 2 * 64 * 128 + stg1);
-    case M_L2: return go(k_scan_qh<2, M_L2, 4, 4, 1>, 10, (size_t)4 * 2 * 64 * 128 + nrm1);
-    default: return go(k_scan_qh<2, M_COS, 4, 4, 1>, 11, (size_t)4 * 2 * 64 * 128 + nrm1);
+    case M_IP: return go(k_scan_qh<2, M_IP, 3, 2, 1>, 9, (size_t)3 * 2 * 64 * 128 + stg1);
+    case M_L2: return go(k_scan_qh<2, M_L2, 3, 2, 1>, 10, (size_t)3 * 2 * 64 * 128 + nrm1);
+    default: return go(k_scan_qh<2, M_COS, 3, 2, 1>, 11, (size_t)3 * 2 * 64 * 128 + nrm1);
     }
 }
 
@@ -2174,7 +2158,7 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
                     const uint32_t grid = std::min<uint32_t>(a.ntiles, (uint32_t)h->num_cu * 2);
                     if (!a.emit_all) seg_geometry(grid, 4, &a.nseg, &a.seg);
                     LY_TRY((launch_scan_h16<1, 4, 1, 1, 3, 3, false>(a, metric, grid, st)));
-                } else if (qh_scan_ok(a, filt, qchunks)) {   // the query-stationary tiling of the low-dimensional f16 shadow (scan_qh.h): four segments per workgroup and query
+                } else if (qh_scan_ok(a, filt, qchunks, level)) {   // the query-stationary tiling of the low-dimensional f16 shadow (scan_qh.h): four segments per workgroup and query
                     uint32_t segs = 0;
                     const uint32_t grid = qh_grid(a, (uint32_t)h->num_cu, &segs);
                     seg_geometry(grid, segs, &a.nseg, &a.seg);

@@ -34,10 +34,10 @@ typedef float qh_f32x2 __attribute__((ext_vector_type(2)));
 //   QB = 1: a wave owns 32 queries (the layout of k_scan_qs); 64-row tiles, every wave reads every row fragment; 128 registers per
 //           wave, TWO workgroups per CU (four waves per SIMD): the branchy float epilogue of one workgroup runs under the MFMAs of
 //           the other, and twice as many waves fill each other's LDS / branch bubbles.
-// debug_flags & 2 = no emission, & 64 = s_memtime phase sums (scripts/qh_phase_timing.py)
+// One segment of candB per workgroup and query (nseg = grid).  debug_flags & 2 = no emission, & 64 = s_memtime phase sums (scripts/qh_phase_timing.py)
 template <int NSLAB, int MET, int NS, int NBUF, int QB>
 __global__ void __launch_bounds__(512, (QB == 1 ? 4 : 2)) k_scan_qh(ScanArgs a) {
-    static_assert(QB == 1 || QB == 2, "query blocks per wave");
+    static_assert(QB == 1, "query blocks per wave: the 64-queries-per-wave form (QB = 2) measured 10-20 % slower and is not instantiated any more");
     constexpr int RT = 64 * QB;              // rows per tile
     constexpr int SB = NSLAB * RT * 128;     // bytes per ring stage (a whole tile, all K)
     constexpr int PP = SB / 1024;            // LDS-DMA instructions per stage (1 KiB each: 8 rows x 128 B)
@@ -52,15 +52,19 @@ __global__ void __launch_bounds__(512, (QB == 1 ? 4 : 2)) k_scan_qh(ScanArgs a) 
     constexpr int NRM_SLOTS = NS + 1;        // (a slot is refilled two steps after its tile was computed: the late waves' epilogues are safe)
     constexpr int NRM_OFF = NS * SB;
     static_assert(NRM_OFF + (NORMS ? NRM_SLOTS * NRM : 0) <= (QB == 1 ? 80 : 160) * 1024, "LDS");
-    // Key staging (round 5): the keys a wave emits are collected in ITS region of the LDS — each with the slot of its lane's private
-    // segment (ScanArgs::candB, as in k_scan_qs) — and stored when the region is full and at the end of the launch.  A key stored straight to global
-    // memory rides on vmcnt in front of the ring pieces of its step, and the next counted wait in front of the barrier then waits for its
-    // write acknowledgement: at 128 columns a step is as short as that round trip (~1.8 us) and with k = 100 every step of every workgroup
-    // holds a key (s_memtime: 148k of a stage's ticks with emission against 78k without — the SAME cost at a tenth of the keys per step
-    // that emit).  LDS appends ride on lgkmcnt; nothing of the epilogue touches vmcnt any more.
-    constexpr int EW = QB == 1 ? 96 : 256;   // keys per wave region (8 B key + 4 B slot index each)
+    // Deferred emission (round 5).  A key stored straight to global memory rides on vmcnt in front of the ring pieces of its step, and the
+    // next counted wait in front of the barrier then waits for its write acknowledgement: at 128 columns a step is as short as that round
+    // trip (~1.8 us) and with k = 100 every step of every workgroup holds a key (s_memtime: 148k of a stage's ticks with emission against
+    // 78k without).  And the grouped slow path — norm re-read, the exact expression, the pass test, the key — ran ~100 instructions with one
+    // or two of 64 lanes active, per hit about as long as the MFMAs of the step.  Here the tile epilogue only STAGES the groups of four
+    // values whose level-1 maximum passes: the lane appends (4 accumulators, first row, query) to its wave's LDS region (appends ride on
+    // lgkmcnt; one ballot per group).  The region is worked off when it is full — rare — and at the end of the launch, one ENTRY per lane:
+    // norms from global memory, the exact expression of k_scan_h16, the pass test, the key, a slot of the workgroup's segment of that
+    // query (one LDS counter per query), a plain store.
+    constexpr int EW = QB == 1 ? (NS == 3 ? 144 : 64) : 128;   // groups per wave region (16 B of accumulators + first row + query)
     constexpr int STG_OFF = NRM_OFF + (NORMS ? NRM_SLOTS * NRM : 0);
-    static_assert(STG_OFF + 8 * EW * 12 <= (QB == 1 ? 80 : 160) * 1024, "LDS");
+    constexpr int QCNT_OFF = STG_OFF + 8 * EW * 24;   // u32[256]: keys of this workgroup per query
+    static_assert(QCNT_OFF + 256 * 4 <= (QB == 1 ? 80 : 160) * 1024, "LDS");
     constexpr int NXW = NORMS ? QB : 0;      // LDS-DMAs wave 0 issues per step on top of its ring pieces
     constexpr int WAITN = (NS - 2) * PPW;    // ring pieces that may still be in flight at the barrier
     static_assert((NS - 1) * (PPW + NXW) <= 63, "vmcnt");
@@ -190,10 +194,7 @@ __global__ void __launch_bounds__(512, (QB == 1 ? 4 : 2)) k_scan_qh(ScanArgs a) 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-    uint32_t e_cnt = 0;   // (uniform) keys staged in this wave's LDS region
-    uint32_t cnt[QB];     // keys in this lane's private segment of each of its queries
-#pragma unroll
-    for (int j = 0; j < QB; ++j) cnt[j] = 0u;
+    uint32_t e_cnt = 0;   // (uniform) groups staged in this wave's LDS region
     uint32_t c_stage = NS - 1;    // (incremented before use: the first step computes stage 0)
     typedef _Float16 qh_h8 __attribute__((ext_vector_type(8)));
     auto mfma_step = [&]() {
@@ -230,13 +231,48 @@ __global__ void __launch_bounds__(512, (QB == 1 ? 4 : 2)) k_scan_qh(ScanArgs a) 
         for (int kk = 0; kk < 4; ++kk) ad_cur[kk] = (a_lane ^ (uint32_t)(kk * 32)) + c_stage * SB;
     };
 
-    const uint32_t e_base = lds0 + (uint32_t)STG_OFF + (uint32_t)wave * (uint32_t)(EW * 12);   // keys [EW] u64, then slot indices into candB [EW] u32
-    auto flush_keys = [&]() {   // (a full region — rare — and once at the end of the launch: plain stores into the lanes' private segments)
+    const uint32_t e_base = lds0 + (uint32_t)STG_OFF + (uint32_t)wave * (uint32_t)(EW * 24);   // accumulators [EW] 16 B, then (first row, query) [EW] 8 B
+    if (tid < 256) asm volatile("ds_write_b32 %0, %1" ::"v"(lds0 + (uint32_t)QCNT_OFF + (uint32_t)tid * 4u), "v"(0u) : "memory");   // (the first barrier of the main loop orders it before any flush)
+    // Every load of the flush is inline assembly that waits for itself: a load the compiler can see leaves "a register may still be
+    // written by a memory operation" on the rare path, and where that path joins the main loop again the compiler answers with
+    // s_waitcnt vmcnt(0) in front of the next reuse of such a register — behind the ring pieces of EVERY step (measured: the DMA-issue
+    // phase 7k -> 30k ticks per stage, the ring drained once per step).
+    auto flush_groups = [&]() __attribute__((always_inline)) {   // (a full region — rare — and once at the end of the launch; its waits drain the ring)
+        const uint32_t qcnt0 = lds0 + (uint32_t)QCNT_OFF;
         for (uint32_t e = (uint32_t)lane; e < e_cnt; e += 64u) {
-            uint64_t key;
-            uint32_t idx;
-            asm volatile("ds_read_b64 %0, %2\n\tds_read_b32 %1, %3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(key), "=&v"(idx) : "v"(e_base + e * 8u), "v"(e_base + (uint32_t)(EW * 8) + e * 4u) : "memory");
-            a.candB[idx] = key;
+            f32x4 x;
+            uint64_t mq;
+            asm volatile("ds_read_b128 %0, %2\n\tds_read_b64 %1, %3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(x), "=&v"(mq) : "v"(e_base + e * 16u), "v"(e_base + (uint32_t)(EW * 16) + e * 8u) : "memory");
+            const uint32_t m0 = (uint32_t)mq, q = (uint32_t)(mq >> 32);
+            float qi, thr, ex = 0.0f;
+            f32x4 nv = {0.0f, 0.0f, 0.0f, 0.0f};
+            if constexpr (MET == M_IP) {
+                asm volatile("global_load_dword %0, %2, off\n\tglobal_load_dword %1, %3, off\n\ts_waitcnt vmcnt(0)" : "=&v"(qi), "=&v"(thr) : "v"(a.qinv + q), "v"(a.thr + q) : "memory");
+            } else {   // (m0 is a multiple of 4: one 16-B load of the four rows' norms; rows past the end: the arrays' slack)
+                const float* exs = MET == M_L2 ? a.qn2 : a.qrinv;
+                const float* nrm = MET == M_L2 ? a.vn2 : a.vrinv;
+                asm volatile("global_load_dword %0, %4, off\n\tglobal_load_dword %1, %5, off\n\tglobal_load_dword %2, %6, off\n\tglobal_load_dwordx4 %3, %7, off\n\ts_waitcnt vmcnt(0)"
+                             : "=&v"(qi), "=&v"(thr), "=&v"(ex), "=&v"(nv) : "v"(a.qinv + q), "v"(a.thr + q), "v"(exs + q), "v"(nrm + m0) : "memory");
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                float sc = x[t] * qi;   // the exact coarse expression of k_scan_h16 (score(): separate mul / add)
+                if constexpr (MET == M_L2) sc = nv[t] - 2.0f * sc + ex;
+                if constexpr (MET == M_COS) sc = 1.0f - sc * nv[t] * ex;
+                const uint32_t m = m0 + (uint32_t)t;
+                if (m < a.row1 && (ASC ? (sc <= thr) : (sc >= thr))) {
+                    const uint64_t key = make_key(sc, m, ASC);
+                    uint32_t slot;
+                    asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=&v"(slot) : "v"(qcnt0 + q * 4u), "v"(1u) : "memory");
+                    if (slot < a.seg) {
+                        a.candB[((size_t)q * a.nseg + blockIdx.x) * a.seg + slot] = key;
+                    } else {   // a full segment (massive ties): the shared region
+                        uint32_t gs;
+                        asm volatile("global_atomic_add %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)" : "=&v"(gs) : "v"(a.count + q), "v"(1u) : "memory");
+                        if (gs < a.cap) a.cand[(size_t)q * a.cap + gs] = key;
+                    }
+                }
+            }
         }
         e_cnt = 0;
     };
@@ -292,53 +328,38 @@ __global__ void __launch_bounds__(512, (QB == 1 ? 4 : 2)) k_scan_qh(ScanArgs a) 
 #pragma unroll
         for (int j = 0; j < QB; ++j) any = any || best[j] >= c_lim[j];
         if (__builtin_expect(__ballot(any) == 0ull, 1)) return;
-        const uint32_t rbase = a.row0 + e_tile * RT + (uint32_t)(wr * 64);
-        const uint32_t sgm = (blockIdx.x * (uint32_t)QB + (uint32_t)wr) * 2u + (uint32_t)hi;
+        const uint32_t rbase = a.row0 + e_tile * RT + (uint32_t)(wr * 64) + 4u * (uint32_t)hi;
+        // The region is worked off BETWEEN tiles, where no accumulator is live (main loop: below half full after every tile).  A tile that
+        // adds more than the free half in one go (hundreds of rows inside the threshold of one query block in 64 rows: massive ties) marks
+        // the queries of the groups that do not fit as overflowed (count > cap: k_select flags them, the batch goes down the plan ladder,
+        // whose levels run k_scan_h16).  A flush inside this walk would sit between live accumulators: its spill reloads are scratch loads,
+        // and where that rare path joins the loop again the compiler waits for them with s_waitcnt vmcnt(0) — behind the ring pieces of
+        // EVERY step (measured: the DMA-issue phase 7k -> 30k ticks per stage).
 #pragma unroll
         for (int j = 0; j < QB; ++j) {
-            if (QB > 1 && __builtin_expect(__ballot(best[j] >= c_lim[j]) == 0ull, 1)) continue;
-            const uint32_t seg0 = (qn[j] * a.nseg + sgm) * a.seg;   // this lane's private segment of query qn[j] in candB
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                bool hit_i = false;
-#pragma unroll
-                for (int g = 0; g < 4; ++g) hit_i = hit_i || gm[i][j][g] >= c_lim[j];
-                if (__builtin_expect(__ballot(hit_i) == 0ull, 1)) continue;
-                f32x4 nv[4];   // (the row block's norms again: the fast path keeps one row block of them)
-                read_norms(nv, i);
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    // one wave-level branch per group of four (a branch per element cost more than everything it guards)
-                    if (__builtin_expect(__ballot(gm[i][j][g] >= c_lim[j]) == 0ull, 1)) continue;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int r = 4 * g + e;
-                        float sc = acc[i][j][r] * c_qinv[j];   // the exact coarse expression of k_scan_h16 (score(): separate mul / add)
-                        if constexpr (MET == M_L2) sc = nv[g][e] - 2.0f * sc + c_extra[j];
-                        if constexpr (MET == M_COS) sc = 1.0f - sc * nv[g][e] * c_extra[j];
-                        const uint32_t m = rbase + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                        const bool pass = ok[j] && m < a.row1 && (ASC ? (sc <= c_thr[j]) : (sc >= c_thr[j])) && !(a.debug_flags & 2);
-                        const bool st = pass && cnt[j] < a.seg;
-                        const uint64_t pm = __ballot(st);
-                        if (pm) {   // (uniform) append the passing lanes' keys to the wave's staging region
-                            const uint32_t np = (uint32_t)__popcll(pm);
-                            if (e_cnt + np > (uint32_t)EW) flush_keys();
-                            const uint32_t slot = e_cnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(pm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pm, 0u));
-                            if (st) {
-                                const uint64_t key = make_key(sc, m, ASC);
-                                const uint32_t idx = seg0 + cnt[j];
-                                ++cnt[j];
-                                asm volatile("ds_write_b64 %0, %1\n\tds_write_b32 %2, %3" ::"v"(e_base + slot * 8u), "v"(key), "v"(e_base + (uint32_t)(EW * 8) + slot * 4u), "v"(idx) : "memory");
-                            }
-                            e_cnt += np;
-                        }
-                        if (__builtin_expect(__ballot(pass && !st) != 0ull, 0)) {   // a full private segment (massive ties): the shared region
-                            if (pass && !st) {
-                                const uint32_t gs = atomicAdd(&a.count[qn[j]], 1u);
-                                if (gs < a.cap) a.cand[(size_t)qn[j] * a.cap + gs] = make_key(sc, m, ASC);
-                            }
-                        }
+                    // (rows past the end of the stage re-read its last row and their norm slots hold the arrays' slack: a group that lies
+                    // wholly behind row1 is no hit whatever its values; a group that straddles it is filtered per row by the flush)
+                    const bool hit = gm[i][j][g] >= c_lim[j] && rbase + (uint32_t)(i * 32 + 8 * g) < a.row1;
+                    const uint64_t pm = __ballot(hit);
+                    if (__builtin_expect(pm == 0ull, 1)) continue;   // (uniform)
+                    // stage the group of the lanes that passed level 1: rows rbase + i 32 + 8 g + {0..3}, this lane's query
+                    const uint32_t np = (uint32_t)__popcll(pm);
+                    if (__builtin_expect(e_cnt + np > (uint32_t)EW, 0)) {
+                        if (hit) __hip_atomic_fetch_add(&a.count[qn[j]], a.cap + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (no return value: nothing to wait for)
+                        continue;
                     }
+                    const uint32_t slot = e_cnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(pm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pm, 0u));
+                    if (hit) {
+                        const f32x4 x = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+                        const uint32_t m0 = rbase + (uint32_t)(i * 32 + 8 * g);
+                        asm volatile("ds_write_b128 %0, %1\n\tds_write_b64 %2, %3" ::"v"(e_base + slot * 16u), "v"(x), "v"(e_base + (uint32_t)(EW * 16) + slot * 8u),
+                                     "v"((uint64_t)m0 | ((uint64_t)qn[j] << 32)) : "memory");
+                    }
+                    e_cnt += np;
                 }
             }
         }
@@ -376,6 +397,7 @@ __global__ void __launch_bounds__(512, (QB == 1 ? 4 : 2)) k_scan_qh(ScanArgs a) 
                 if (wave_live) epilogue(tile_of(e_ord), e_ord);
                 ++e_ord;
                 have = false;
+                if (__builtin_expect(e_cnt > (uint32_t)(EW / 2), 0)) flush_groups();   // (uniform; no accumulator is live here)
                 stamp(2);
             }
             // (the keys of the epilogue above were stored BEFORE these pieces: at the next counted wait they are older than everything
@@ -391,11 +413,12 @@ __global__ void __launch_bounds__(512, (QB == 1 ? 4 : 2)) k_scan_qh(ScanArgs a) 
         unsigned long long* o = a.dbg + ((size_t)blockIdx.x * 8 + wave) * 4;
         o[0] = t_ph[0]; o[1] = t_ph[1]; o[2] = t_ph[2]; o[3] = t_ph[3];
     }
-    flush_keys();
-    if (a.seg) {
-#pragma unroll
-        for (int j = 0; j < QB; ++j)
-            if (ok[j]) a.segcnt[(size_t)qn[j] * a.nseg + (blockIdx.x * (uint32_t)QB + (uint32_t)wr) * 2u + (uint32_t)hi] = (uint8_t)cnt[j];
+    flush_groups();
+    __syncthreads();   // every wave's groups are worked off: the workgroup's key counts per query are final
+    if (a.seg && tid < 256 && (uint32_t)tid < a.nq) {
+        uint32_t n;
+        asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(n) : "v"(lds0 + (uint32_t)QCNT_OFF + (uint32_t)tid * 4u) : "memory");
+        a.segcnt[(size_t)tid * a.nseg + blockIdx.x] = (uint8_t)(n < a.seg ? n : a.seg);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }

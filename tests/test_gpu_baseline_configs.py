@@ -6,7 +6,7 @@ ran through `profile_get()["last_plan"]` (include/lynse_hip.h):
   C2  FLAT-IP 2.4M x 768, 256 queries, k=10 : certified int8 coarse pass on the <2,4,4,2> tiling, sampled plan with the
       threshold-only (lane-max) sample stage + 2 threshold stages = 3 scan launches, no fallback — the kernels
       bench.py times (flat_mmap.rs:4845-4982)
-  C3  FLAT-L2 SIFT-like 1M x 128, 256 queries, k=100 : <4,2,2,4> tiling, sampled plan, zero margin on the integer rows; A/B against k_scan_qh (benchmarks/sift_io.py:87-89)
+  C3  FLAT-L2 SIFT-like 1M x 128, 256 queries, k=100 : k_scan_qh threshold stages (scan_qh.h), sampled plan, zero margin on the integer rows; A/B against the <4,2,2,4> tiling (benchmarks/sift_io.py:87-89)
   C4  IVF-IP 768-d, nlist=4096, nprobe=32, 520k rows: centroid store right at the 4096-row single / batch-8 boundary,
       nprobe >= nlist, subset-filtered (src/index/ivf.rs:181-348)
   C5  Hamming 10M x 1024-bit, k=50, nq in {1, 256}: massive ties at the k-th distance (flat_mmap.rs:1345-1409)
@@ -194,21 +194,21 @@ def test_c3_flat_l2_sift_like_1m_k100(L, oracle):
     rows, dists, counts = idx.search_batch_arrays(queries, k, "l2")
     p = idx.profile_get(reset=True)
     flags, stages, tiling = plan_fields(p)
-    assert p["fallback_queries"] == 0 and tiling == 0x42 and flags & PLAN_SAMPLED and stages >= 2, (p, bin(flags))
+    # threshold stages on the query-stationary tiling of the low-dimensional f16 shadow (k_scan_qh, scan_qh.h; round 5)
+    assert p["fallback_queries"] == 0 and tiling == 0x82 and flags & PLAN_SAMPLED and stages >= 2, (p, bin(flags))
     for qi in (0, 1, 63, 64, 127, 128, 200, 255):
         assert_rows_equal(oracle.canonical_topk(queries[qi], data, k, O.L2), rows[qi], dists[qi], counts[qi], ("c3", qi))
     # integer rows x integer queries below the 2^24 bounds: the coarse pass is exact, the margin zero (k_prep_queries' exactness rule,
     # round 5) — exactly k rows per query reach the final rescoring unless the k-th distance ties
     assert p["pool_entries"] <= int(1.2 * nq * k), p
-    for qh in ("1", "2"):      # the query-stationary tilings of scan_qh.h (opt-in): identical bits
-        os.environ["LYNSE_HIP_QH"] = qh
-        try:
-            r0, d0, c0 = idx.search_batch_arrays(queries, k, "l2")
-            p0 = idx.profile_get(reset=True)
-        finally:
-            del os.environ["LYNSE_HIP_QH"]
-        assert plan_fields(p0)[2] == 0x82 and p0["fallback_queries"] == 0, p0
-        assert np.array_equal(r0, rows) and np.array_equal(d0.view(np.uint32), dists.view(np.uint32)) and np.array_equal(c0, counts)
+    os.environ["LYNSE_HIP_QH"] = "0"     # ... and on the <4,2,2,4> tiling of k_scan_h16 (the default up to round 4): identical bits
+    try:
+        r0, d0, c0 = idx.search_batch_arrays(queries, k, "l2")
+        p0 = idx.profile_get(reset=True)
+    finally:
+        del os.environ["LYNSE_HIP_QH"]
+    assert plan_fields(p0)[2] == 0x42 and p0["fallback_queries"] == 0, p0
+    assert np.array_equal(r0, rows) and np.array_equal(d0.view(np.uint32), dists.view(np.uint32)) and np.array_equal(c0, counts)
     # integer-valued data: squared distances are exact integers and tie often — the canonical (distance, row) order decides
     assert np.all(dists[0] == np.round(dists[0]))
     # IP and cosine over the same store, k=100 (IP: lane-max sample up to k = 128 on the <2,4,4,2> tiling)

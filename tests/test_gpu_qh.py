@@ -1,10 +1,10 @@
-"""`-m gpu` parity tests of k_scan_qh (lynsedb_amd/csrc/scan_qh.h; opt-in: LYNSE_HIP_QH=1 / 2): the query-stationary threshold stages of
+"""`-m gpu` parity tests of k_scan_qh (lynsedb_amd/csrc/scan_qh.h; LYNSE_HIP_QH=0: k_scan_h16): the query-stationary threshold stages of
 the float path over the f16 shadow at 64 / 128 columns, and of the exactness rule of integer-valued collections (k_prep_queries:
 zero margin when rows and query are integers below the 2^24 bounds; BASELINE config 3 is the full-size case of both,
 tests/test_gpu_baseline_configs.py::test_c3_*).
 
 Every case goes through the C-ABI, is compared bit for bit (row ids and f32 distance bits) with the CPU oracle
-(FlatMmap::search -> exact_flat_search, src/storage/flat_mmap.rs:905-1026, :2132-2256) and with the same search on the default
+(FlatMmap::search -> exact_flat_search, src/storage/flat_mmap.rs:905-1026, :2132-2256) and with the same search on the
 256 x 256 tile of k_scan_h16, and pins the tiling it ran through `profile_get()["last_plan"]`.
 """
 import os
@@ -41,20 +41,18 @@ def check(oracle, data, queries, k, name, rows, dists, counts, picks, tag):
         assert np.array_equal(rows[qi][:c].astype(np.uint64), e_ids.astype(np.uint64)), (tag, qi, rows[qi][:c], e_ids)
 
 
-QH = os.environ.get("LYNSE_HIP_QH_TEST", "1")     # the k_scan_qh variant under test (1: two workgroups per CU, 2: 64 queries per wave)
-
-
 def run_ab(idx, queries, k, name):
-    """-> results + plan of k_scan_qh (LYNSE_HIP_QH read per call) and the plan of the default tiling; asserts identical bits"""
+    """-> results + plan of the default (k_scan_qh where its shapes apply) and the plan of the same search on k_scan_h16 (LYNSE_HIP_QH=0, read
+    per call); asserts identical bits"""
     idx.profile_get(reset=True)
-    os.environ["LYNSE_HIP_QH"] = QH
+    r, d, c = idx.search_batch_arrays(queries, k, name)
+    p = idx.profile_get(reset=True)
+    os.environ["LYNSE_HIP_QH"] = "0"
     try:
-        r, d, c = idx.search_batch_arrays(queries, k, name)
-        p = idx.profile_get(reset=True)
+        r0, d0, c0 = idx.search_batch_arrays(queries, k, name)
+        p0 = idx.profile_get(reset=True)
     finally:
         del os.environ["LYNSE_HIP_QH"]
-    r0, d0, c0 = idx.search_batch_arrays(queries, k, name)
-    p0 = idx.profile_get(reset=True)
     assert np.array_equal(r, r0) and np.array_equal(d.view(np.uint32), d0.view(np.uint32)) and np.array_equal(c, c0), (name, k)
     return r, d, c, p, p0
 
@@ -77,9 +75,10 @@ def test_qh_threshold_stages_equal_the_oracle_and_the_256x256_tile(L, oracle, di
     for name in ("l2", "ip", "cosine"):
         for nq, k in ((256, 10), (256, 100), (100, 10), (40, 100), (160, 10)):
             r, d, c, p, p0 = run_ab(idx, queries[:nq], k, name)
-            # (k = 100 over Gaussian rows may send the batch down the plan ladder on either tiling: the fallback count is not pinned)
-            assert tiling_of(p0) != 0x82 and p["fallback_queries"] == p0["fallback_queries"], (name, nq, k, p, p0)
-            if name != "ip":      # (IP batches of a shard this size stream the certified int8 codes: k_scan_h16<.., I8Q = 2>)
+            # (k = 100 over Gaussian rows may send the batch down the plan ladder on either tiling — whose later levels run k_scan_h16: neither
+            # the fallback count nor the tiling of a batch that fell back is pinned)
+            assert tiling_of(p0) != 0x82, (name, nq, k, p, p0)
+            if name != "ip" and p["fallback_queries"] == 0:      # (IP batches of a shard this size stream the certified int8 codes: k_scan_h16<.., I8Q = 2>)
                 assert tiling_of(p) == 0x82, (name, nq, k, p)
             picks = sorted({0, 1, 31, 32, 33, 63, 64, nq // 2, nq - 2, nq - 1} & set(range(nq)))
             check(oracle, data, queries, k, name, r, d, c, picks, (dim, name, nq, k))
@@ -99,7 +98,7 @@ def test_qh_inner_product_form_below_the_int8_pass(L, oracle):
     for name in ("ip", "l2", "cosine"):
         for k in (10, 64):
             r, d, c, p, p0 = run_ab(idx, queries, k, name)
-            assert p["fallback_queries"] == 0 and tiling_of(p) == 0x82 and tiling_of(p0) != 0x82, (name, k, p, p0)
+            assert tiling_of(p0) != 0x82 and (p["fallback_queries"] != 0 or tiling_of(p) == 0x82), (name, k, p, p0)
             check(oracle, data, queries, k, name, r, d, c, (0, 31, 32, 100, 255), (name, k))
 
 
@@ -130,7 +129,7 @@ def test_qh_integer_data_with_massive_ties(L, oracle):
         idx_m.profile_enable(True)
         for k in (10, 100):
             r, d, c, p, p0 = run_ab(idx, queries, k, "l2")    # (10,000 copies of one row: the queries near it go down the plan ladder)
-            if k == 10:   # (k = 100 on a shard this small: an emit-all sample stage, whose tiles the later stages skip — k_scan_h16)
+            if k == 10 and p["fallback_queries"] == 0:   # (k = 100 on a shard this small: an emit-all sample stage, whose tiles the later stages skip — k_scan_h16)
                 assert tiling_of(p) == 0x82, (n, k, p)
             check(oracle, data, queries, k, "l2", r, d, c, (0, 3, 64, 200, 255), (n, k))
             idx_m.profile_get(reset=True)
