@@ -1599,6 +1599,37 @@ static int launch_scan_qh(const ScanArgs& a, int metric, uint32_t grid, hipStrea
     }
 }
 
+// The threshold-only SAMPLE stage of the same plans on k_scan_qh<.., SMP> (scan_qh.h): the sample rows as 64-row tiles, two workgroups per CU,
+// 4 keys per workgroup and query.  LYNSE_HIP_QH_SAMPLE=0: the 256 x 256 sample tiles of k_scan_h16<.., EMIT = 2> (A/B; read per call).
+static bool qh_sample_ok(const ScanArgs& a, bool filt, uint32_t qchunks, int level, uint32_t plan_tile) {
+    const char* e = getenv("LYNSE_HIP_QH_SAMPLE");
+    if ((e && atoi(e) == 0) || qh_variant() != 1 || level != 0) return false;
+    return !filt && a.emit_all == 2 && plan_tile == 256 && qchunks == 1 && a.qpad == 256 && a.nq <= 256 && a.tile_stride >= 256 && a.skip_stride == 0 && !a.mask && !a.row_ids &&
+           !a.tiles && a.row1 > a.row0 && (a.nslab == 1 || a.nslab == 2) && a.ld16 == a.nslab * 64u;
+}
+static int launch_scan_qh_sample(const ScanArgs& a, int metric, uint32_t grid, hipStream_t st) {
+    static std::atomic<bool> attr_done[8] = {false};
+    auto go = [&](auto kern, int slot, size_t lds) -> int {
+        if (!attr_done[slot]) { LY_TRY(set_max_lds(kern, lds)); attr_done[slot] = true; }
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, a);
+        LY_HIP(hipGetLastError());
+        return LYNSE_OK;
+    };
+    constexpr size_t stg1 = 8 * 144 * 24 + 1024, nrm1 = 4 * 256 + stg1;
+    if (a.nslab == 1) {
+        switch (metric) {
+        case M_IP: return go(k_scan_qh<1, M_IP, 3, 2, 1, 1>, 0, (size_t)3 * 1 * 64 * 128 + stg1);
+        case M_L2: return go(k_scan_qh<1, M_L2, 3, 2, 1, 1>, 1, (size_t)3 * 1 * 64 * 128 + nrm1);
+        default: return go(k_scan_qh<1, M_COS, 3, 2, 1, 1>, 2, (size_t)3 * 1 * 64 * 128 + nrm1);
+        }
+    }
+    switch (metric) {
+    case M_IP: return go(k_scan_qh<2, M_IP, 3, 2, 1, 1>, 3, (size_t)3 * 2 * 64 * 128 + stg1);
+    case M_L2: return go(k_scan_qh<2, M_L2, 3, 2, 1, 1>, 4, (size_t)3 * 2 * 64 * 128 + nrm1);
+    default: return go(k_scan_qh<2, M_COS, 3, 2, 1, 1>, 5, (size_t)3 * 2 * 64 * 128 + nrm1);
+    }
+}
+
 // (round 5, measured and removed: 1024-bit Hamming on a 64-queries-per-wave form of k_scan_qh — k_scan_qh<4, M_IP, 4, 8, QB = 2, one row block
 // per wave, FP4 MFMA>: every row fragment read feeds two MFMAs, half the LDS fragment returns per MFMA.  Bit-identical, and SLOWER: C5 share
 // 1.900 / 1.916 / 1.928 against 1.705 / 1.708 / 1.725 ms per batch, same box, alternating (scripts/gpu_r5_c5.sh): with one 32-row block per
@@ -2158,7 +2189,17 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
                     const uint32_t grid = std::min<uint32_t>(a.ntiles, (uint32_t)h->num_cu * 2);
                     if (!a.emit_all) seg_geometry(grid, 4, &a.nseg, &a.seg);
                     LY_TRY((launch_scan_h16<1, 4, 1, 1, 3, 3, false>(a, metric, grid, st)));
-                } else if (qh_scan_ok(a, filt, qchunks, level)) {   // the query-stationary tiling of the low-dimensional f16 shadow (scan_qh.h): four segments per workgroup and query
+                } else if (s.sample_tiles && qh_sample_ok(a, filt, qchunks, level, plan_tile) &&
+                           (uint64_t)std::min<uint32_t>(s.sample_tiles * 4u, 2u * (uint32_t)h->num_cu) * 4u >= 8ull * k &&
+                           std::min<uint32_t>(s.sample_tiles * 4u, 2u * (uint32_t)h->num_cu) * 4u <= w.cap &&
+                           (s.sample_tiles * 4u + std::min<uint32_t>(s.sample_tiles * 4u, 2u * (uint32_t)h->num_cu) - 1) / std::min<uint32_t>(s.sample_tiles * 4u, 2u * (uint32_t)h->num_cu) <= 32u) {
+                    // the threshold-only sample stage on k_scan_qh<.., SMP>: 4 keys per workgroup and query, <= 32 tiles per workgroup (the packed position of a key)
+                    const uint32_t nt64 = s.sample_tiles * 4u, sgrid = std::min<uint32_t>(nt64, 2u * (uint32_t)h->num_cu);
+                    a.ntiles = nt64;
+                    LY_TRY(launch_scan_qh_sample(a, metric, sgrid, st));
+                    qs_sample_keys = sgrid * 4u;
+                    plan_used_qh = true;
+                } else if (qh_scan_ok(a, filt, qchunks, level)) {   // the query-stationary tiling of the low-dimensional f16 shadow (scan_qh.h): one segment per workgroup and query
                     uint32_t segs = 0;
                     const uint32_t grid = qh_grid(a, (uint32_t)h->num_cu, &segs);
                     seg_geometry(grid, segs, &a.nseg, &a.seg);

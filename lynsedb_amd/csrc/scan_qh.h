@@ -35,7 +35,14 @@ typedef float qh_f32x2 __attribute__((ext_vector_type(2)));
 //           wave, TWO workgroups per CU (four waves per SIMD): the branchy float epilogue of one workgroup runs under the MFMAs of
 //           the other, and twice as many waves fill each other's LDS / branch bubbles.
 // One segment of candB per workgroup and query (nseg = grid).  debug_flags & 2 = no emission, & 64 = s_memtime phase sums (scripts/qh_phase_timing.py)
-template <int NSLAB, int MET, int NS, int NBUF, int QB>
+// SMP = 1: the THRESHOLD-ONLY SAMPLE STAGE of a staged plan on this tiling (it was one 256-row tile of k_scan_h16<.., EMIT = 2> per CU:
+// 23 us of launch ramp, query image and ring fill for 65,536 rows).  a.ntiles tiles of 64 rows, tile t = rows (t / 4) * a.tile_stride +
+// (t % 4) * 64 ... of the shard (the same sample rows); no threshold, no staging — every lane keeps the best TWO rows of those it sees for
+// its query as PACKED key words (the score word of make_key rounded UP to a multiple of 1024 — towards 'worse': the key claims no better
+// score than the row has — with the tile ordinal and the accumulator slot in the low 10 bits) and writes them to
+// cand[query][(blockIdx.x * 2 + hi) * 2 + t]: 4 keys per workgroup and query.  Any k distinct real rows bound the k-th best score, so
+// k_select's threshold-only rule turns the k-th best of these keys into a valid first threshold as it does with k_scan_qs<.., SMP>'s.
+template <int NSLAB, int MET, int NS, int NBUF, int QB, int SMP = 0>
 __global__ void __launch_bounds__(512, (QB == 1 ? 4 : 2)) k_scan_qh(ScanArgs a) {
     static_assert(QB == 1, "query blocks per wave: the 64-queries-per-wave form (QB = 2) measured 10-20 % slower and is not instantiated any more");
     constexpr int RT = 64 * QB;              // rows per tile
@@ -75,8 +82,12 @@ __global__ void __launch_bounds__(512, (QB == 1 ? 4 : 2)) k_scan_qh(ScanArgs a) 
     const int wq = QB == 2 ? (wave & 3) : wave, wr = QB == 2 ? (wave >> 2) : 0;
     const bool late = wave >= 4;
     const int l32 = lane & 31, hi = lane >> 5;
-    const uint32_t ntiles = (a.row1 - a.row0 + RT - 1) / RT;
+    const uint32_t ntiles = SMP != 0 ? a.ntiles : (a.row1 - a.row0 + RT - 1) / RT;
     if (blockIdx.x >= ntiles) return;
+    auto tile_row0 = [&](uint32_t t) -> uint32_t {   // first row of tile t
+        if constexpr (SMP != 0) return a.row0 + (t >> 2) * a.tile_stride + (t & 3u) * (uint32_t)RT;
+        else return a.row0 + t * RT;
+    };
     const uint32_t n_ord = (ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x;   // this workgroup's tiles: blockIdx.x, + gridDim.x, ...
     auto tile_of = [&](uint32_t ord) -> uint32_t { return blockIdx.x + ord * gridDim.x; };
     const uint32_t ldb = a.ld16 * 2u;        // row pitch in bytes
@@ -132,7 +143,7 @@ __global__ void __launch_bounds__(512, (QB == 1 ? 4 : 2)) k_scan_qh(ScanArgs a) 
     const char* v_base = nullptr;   // uniform: first row of the tile being issued
     uint32_t is_ord = 0, is_stage = 0, is_count = 0;
     auto enter_tile = [&]() {
-        const uint32_t rbase = a.row0 + tile_of(is_ord) * RT;
+        const uint32_t rbase = tile_row0(tile_of(is_ord));
         const uint32_t span = a.row1 - 1 - rbase;   // rows past the last one re-read it (masked in the epilogue)
         v_base = reinterpret_cast<const char*>(a.V16) + (size_t)rbase * ldb;
 #pragma unroll
@@ -149,7 +160,7 @@ __global__ void __launch_bounds__(512, (QB == 1 ? 4 : 2)) k_scan_qh(ScanArgs a) 
         for (int j = 0; j < PPW; ++j) glds16<2>(v_base + v_off[j], smem + is_stage * SB + (wave * PPW + j) * 1024);
         if constexpr (NORMS) {   // wave 0: the f32 norms of the tile being issued (rows past the end: the arrays' slack of 256 floats)
             if (wave == 0) {
-                const float* src = (MET == M_L2 ? a.vn2 : a.vrinv) + (a.row0 + tile_of(is_ord) * RT) + lane;
+                const float* src = (MET == M_L2 ? a.vn2 : a.vrinv) + tile_row0(tile_of(is_ord)) + lane;
                 char* dst = smem + NRM_OFF + (is_count % NRM_SLOTS) * NRM;
 #pragma unroll
                 for (int t = 0; t < QB; ++t)
@@ -277,7 +288,38 @@ __global__ void __launch_bounds__(512, (QB == 1 ? 4 : 2)) k_scan_qh(ScanArgs a) 
         e_cnt = 0;
     };
     // ---- tile epilogue: this lane's 2 x 16 values per query block belong to ONE query each; rows wr * 64 + rb * 32 + (r & 3) + 8 (r >> 2) + 4 hi
+    [[maybe_unused]] uint32_t smp1 = 0xffffffffu, smp2 = 0xffffffffu;   // SMP: the two smallest packed key words this lane has seen (smp1 <= smp2)
     auto epilogue = [&](uint32_t e_tile, [[maybe_unused]] uint32_t e_ord_) {
+        if constexpr (SMP != 0) {
+            static_assert(QB == 1, "sample stage: one query block per wave");
+            const uint32_t nb = lds0 + NRM_OFF + (e_ord_ % NRM_SLOTS) * NRM + (uint32_t)hi * 16u;
+            const uint32_t rb0 = tile_row0(e_tile) + 4u * (uint32_t)hi;
+            const bool whole = tile_row0(e_tile) + (uint32_t)RT <= a.row1;   // (uniform) every row of the tile exists: all but the shard's last tile
+            const uint32_t pos0 = (e_ord_ & 31u) << 5;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                f32x4 nv[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+                if constexpr (NORMS) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) asm volatile("ds_read_b128 %0, %1" : "=v"(nv[g]) : "v"(nb + (uint32_t)(i * 32 + 8 * g) * 4u));
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(nv[0]), "+v"(nv[1]), "+v"(nv[2]), "+v"(nv[3]));
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float sc = acc[i][0][r] * c_qinv[0];   // the exact coarse expression of k_scan_h16 (score())
+                    if constexpr (MET == M_L2) sc = nv[r >> 2][r & 3] - 2.0f * sc + c_extra[0];
+                    if constexpr (MET == M_COS) sc = 1.0f - sc * nv[r >> 2][r & 3] * c_extra[0];
+                    uint32_t o = (uint32_t)(make_key(sc, 0u, ASC) >> 32);
+                    o = o > 0xfffffbffu ? 0xfffffc00u : ((o + 1023u) & ~1023u);   // rounded up to a multiple of 1024 (saturating)
+                    uint32_t t = o | pos0 | (uint32_t)(i * 16 + r);
+                    if (!whole) t = (rb0 + (uint32_t)(i * 32 + (r & 3) + 8 * (r >> 2))) < a.row1 ? t : 0xffffffffu;
+                    const uint32_t hi3 = smp1 > t ? smp1 : t;
+                    smp1 = smp1 < t ? smp1 : t;
+                    smp2 = smp2 < hi3 ? smp2 : hi3;
+                }
+            }
+            return;
+        }
         const uint32_t nbase = lds0 + NRM_OFF + (e_ord_ % NRM_SLOTS) * NRM + (uint32_t)(wr * 64) * 4u + (uint32_t)hi * 16u;
         // the norms of the wave's 16 rows of row block i (broadcast reads: all lanes of a wave half hold the same rows)
         auto read_norms = [&](f32x4 (&nv)[4], int i) {
@@ -397,7 +439,7 @@ __global__ void __launch_bounds__(512, (QB == 1 ? 4 : 2)) k_scan_qh(ScanArgs a) 
                 if (wave_live) epilogue(tile_of(e_ord), e_ord);
                 ++e_ord;
                 have = false;
-                if (__builtin_expect(e_cnt > (uint32_t)(EW / 2), 0)) flush_groups();   // (uniform; no accumulator is live here)
+                if constexpr (SMP == 0) { if (__builtin_expect(e_cnt > (uint32_t)(EW / 2), 0)) flush_groups(); }   // (uniform; no accumulator is live here)
                 stamp(2);
             }
             // (the keys of the epilogue above were stored BEFORE these pieces: at the next counted wait they are older than everything
@@ -412,6 +454,24 @@ __global__ void __launch_bounds__(512, (QB == 1 ? 4 : 2)) k_scan_qh(ScanArgs a) 
     if (timing && lane == 0 && blockIdx.x < 256) {
         unsigned long long* o = a.dbg + ((size_t)blockIdx.x * 8 + wave) * 4;
         o[0] = t_ph[0]; o[1] = t_ph[1]; o[2] = t_ph[2]; o[3] = t_ph[3];
+    }
+    if constexpr (SMP != 0) {
+        if (ok[0]) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const uint32_t slot = (blockIdx.x * 2u + (uint32_t)hi) * 2u + (uint32_t)t;
+                const uint32_t pk = t == 0 ? smp1 : smp2;
+                uint64_t key = KEY_SENTINEL;
+                if (pk != 0xffffffffu) {
+                    const uint32_t pos = pk & 1023u, r = pos & 15u;
+                    const uint32_t m = tile_row0(tile_of(pos >> 5)) + ((pos >> 4) & 1u) * 32u + (r & 3u) + 8u * (r >> 2) + 4u * (uint32_t)hi;
+                    key = ((uint64_t)(pk & ~1023u) << 32) | (uint64_t)m;
+                }
+                if (slot < a.cap) a.cand[(size_t)qn[0] * a.cap + slot] = key;
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        return;
     }
     flush_groups();
     __syncthreads();   // every wave's groups are worked off: the workgroup's key counts per query are final
