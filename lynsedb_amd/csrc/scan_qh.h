@@ -331,14 +331,16 @@ __global__ void __launch_bounds__(512, (QB == 1 ? 4 : 2)) k_scan_qh(ScanArgs a) 
         };
         // level 1: the maximum per group of four rows of 2 q.v - |v|^2 (L2) / q.v / |v| (cosine) / the score itself (IP)
         auto level1 = [&](const f32x4 (&nv)[4], int i, int j, int g) -> float {
-            const float mm = MET == M_L2 ? 2.0f * c_qinv[j] : c_qinv[j];
+            const float mm = MET == M_L2 ? -2.0f * c_qinv[j] : c_qinv[j];
             const qh_f32x2 m2 = {mm, mm};
             const qh_f32x2 x01 = {acc[i][j][4 * g], acc[i][j][4 * g + 1]}, x23 = {acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
             qh_f32x2 p01, p23;
             if constexpr (MET == M_L2) {
-                const qh_f32x2 n01 = {-nv[g][0], -nv[g][1]}, n23 = {-nv[g][2], -nv[g][3]};
+                // (the NEGATED level-1 value |v|^2 - 2 q.v with its minimum: the norms enter the fma as they are — negating them cost 16 v_xor per tile)
+                const qh_f32x2 n01 = {nv[g][0], nv[g][1]}, n23 = {nv[g][2], nv[g][3]};
                 p01 = __builtin_elementwise_fma(x01, m2, n01);
                 p23 = __builtin_elementwise_fma(x23, m2, n23);
+                return -fminf(fminf(p01[0], p01[1]), fminf(p23[0], p23[1]));
             } else if constexpr (MET == M_COS) {
                 const qh_f32x2 n01 = {nv[g][0], nv[g][1]}, n23 = {nv[g][2], nv[g][3]};
                 p01 = x01 * n01;
@@ -371,6 +373,7 @@ __global__ void __launch_bounds__(512, (QB == 1 ? 4 : 2)) k_scan_qh(ScanArgs a) 
         for (int j = 0; j < QB; ++j) any = any || best[j] >= c_lim[j];
         if (__builtin_expect(__ballot(any) == 0ull, 1)) return;
         const uint32_t rbase = a.row0 + e_tile * RT + (uint32_t)(wr * 64) + 4u * (uint32_t)hi;
+        const bool whole = a.row0 + e_tile * RT + (uint32_t)RT <= a.row1;   // (uniform) every row of the tile exists: all but the stage's last tile
         // The region is worked off BETWEEN tiles, where no accumulator is live (main loop: below half full after every tile).  A tile that
         // adds more than the free half in one go (hundreds of rows inside the threshold of one query block in 64 rows: massive ties) marks
         // the queries of the groups that do not fit as overflowed (count > cap: k_select flags them, the batch goes down the plan ladder,
@@ -385,7 +388,7 @@ __global__ void __launch_bounds__(512, (QB == 1 ? 4 : 2)) k_scan_qh(ScanArgs a) 
                 for (int g = 0; g < 4; ++g) {
                     // (rows past the end of the stage re-read its last row and their norm slots hold the arrays' slack: a group that lies
                     // wholly behind row1 is no hit whatever its values; a group that straddles it is filtered per row by the flush)
-                    const bool hit = gm[i][j][g] >= c_lim[j] && rbase + (uint32_t)(i * 32 + 8 * g) < a.row1;
+                    const bool hit = gm[i][j][g] >= c_lim[j] && (whole || rbase + (uint32_t)(i * 32 + 8 * g) < a.row1);
                     const uint64_t pm = __ballot(hit);
                     if (__builtin_expect(pm == 0ull, 1)) continue;   // (uniform)
                     // stage the group of the lanes that passed level 1: rows rbase + i 32 + 8 g + {0..3}, this lane's query
