@@ -496,6 +496,8 @@ __global__ void __launch_bounds__(512, 2) k_scan_qs(ScanArgs a) {
                 for (int g = 0; g < 4; ++g) {
                     float p[4];
 #pragma unroll
+                    // (round 5, measured: the packed form of this line — v_pk_fma_f32 on pairs, negated form — is SLOWER here: 10M x 768 L2 2.27-2.28
+                    // against 2.10-2.11 ms, same box, alternating: 256 registers are in use and the pairs cost moves)
                     for (int e = 0; e < 4; ++e) p[e] = __fmaf_rn((float)acc[i][4 * g + e], l2_2s, -nvb[i & 1][g][e]);
                     gmf[i][g] = fmaxf(fmaxf(p[0], p[1]), fmaxf(p[2], p[3]));
                 }
