@@ -7,33 +7,30 @@
 // What bounded the 256-row x 256-query tile of k_scan_h16<4,2,2,4> there: at 128 columns a tile is two slab steps, so the
 // float epilogue (one value per (row, query) pair: as many VALU operations as the two steps have MFMA cycles) and the tile boundary —
 // eight waves draining into the epilogue together — weigh as much as the MFMAs; nothing overlapped them.  Here:
-//   * the query operand is REGISTER-resident for the whole launch, as in k_scan_qs (scan_qs.h) — and at <= 256 columns it is small:
-//     a wave owns 64 queries (two 32-query blocks, 2 x NSLAB x 16 registers), so every ds_read_b128 row fragment feeds TWO MFMAs
-//     (k_scan_qs: one) and the four SIMDs of a CU cover the 256 queries with ONE wave each;
-//   * the second wave of a SIMD takes the OTHER half of the tile's rows (128-row tiles: waves 0-3 rows 0..63, waves 4-7 rows 64..127)
-//     and runs half a step out of phase (the ping-pong roles of k_scan_qs): early waves  barrier -> MFMAs -> epilogue -> DMA issue,
-//     late waves  barrier -> epilogue of the PREVIOUS tile -> DMA issue -> MFMAs — one wave's VALU epilogue sits beside the other
-//     wave's MFMAs on the same SIMD;
-//   * the LDS holds only rows (a ring of NS whole-K stages of 128 rows, global_load_lds_dwordx4 in full 128-B lines, the XOR slot
-//     swizzle of k_scan_h16 on the source address) and, for L2 / cosine, a small ring of the tile's f32 row norms;
-//   * the epilogue is the DENSE float epilogue of k_scan_h16 (the same level-1 value against the same loosened threshold, the same
-//     exact coarse expression and keys): per group of four rows one maximum, one ballot per tile, a rare grouped slow path that appends
-//     (score, row) keys to the lane's private segment (four segments per workgroup and query: row half x wave half).
+//   * the query operand is REGISTER-resident for the whole launch, as in k_scan_qs (scan_qs.h): wave w owns queries [32 w, 32 w + 32)
+//     and keeps their f16 image — the B operand of v_mfma_f32_32x32x16_f16 for every k-step, NSLAB x 16 registers (32 at 128 columns);
+//   * a wave needs 128 registers and a workgroup 78 KB of LDS, so TWO workgroups share a CU (four waves per SIMD): the branchy float
+//     epilogue of one runs under the MFMAs of the other, and twice as many waves fill each other's LDS / branch bubbles;
+//   * inside a workgroup the two waves of a SIMD run half a step out of phase (the ping-pong roles of k_scan_qs): early waves
+//     barrier -> MFMAs -> epilogue -> DMA issue, late waves  barrier -> epilogue of the PREVIOUS tile -> DMA issue -> MFMAs;
+//   * the LDS holds only rows (a ring of NS whole-K stages of 64 rows, global_load_lds_dwordx4 in full 128-B lines, the XOR slot
+//     swizzle of k_scan_h16 on the source address), for L2 / cosine a small ring of the tile's f32 row norms, and the waves' staging
+//     regions of the deferred emission (below);
+//   * level 1 of the epilogue is that of the DENSE float epilogue of k_scan_h16 (the same value against the same loosened threshold),
+//     the exact coarse expression and the keys are k_scan_h16's — computed one staged group per lane between tiles, not by one or two
+//     active lanes inside the tile epilogue.
 // Byte layouts are those of k_scan_h16: f16 rows with a pitch of ld16 halves (whole 64-element slabs), the query image of
 // k_prep_queries (layout 2: [slab][q][8 slots ^ ((q >> 1) & 7)][16 B]) — a 16-element k-step of v_mfma_f32_32x32x16_f16 is 32 bytes
 // of a row, exactly the k-step of the int8 form.
+// Measured and not kept: 64 queries per wave on 128-row tiles with one workgroup per CU (every fragment read feeds two
+// MFMAs: 10-20 % slower), keys stored straight to global memory, keys staged one by one with the exact test inside the tile epilogue.
 #pragma once
 
 namespace lynse {
 
 typedef float qh_f32x2 __attribute__((ext_vector_type(2)));
 
-// QB = query blocks of 32 per wave.
-//   QB = 2: a wave owns 64 queries; 128-row tiles, waves 0-3 rows 0..63, waves 4-7 rows 64..127; one 512-thread workgroup per CU
-//           (two waves per SIMD, 256 registers each); every row fragment read feeds two MFMAs.
-//   QB = 1: a wave owns 32 queries (the layout of k_scan_qs); 64-row tiles, every wave reads every row fragment; 128 registers per
-//           wave, TWO workgroups per CU (four waves per SIMD): the branchy float epilogue of one workgroup runs under the MFMAs of
-//           the other, and twice as many waves fill each other's LDS / branch bubbles.
+// QB = query blocks of 32 per wave: 1 (the template keeps the parameter of the measured 64-queries-per-wave form; static_assert below).
 // One segment of candB per workgroup and query (nseg = grid).  debug_flags & 2 = no emission, & 64 = s_memtime phase sums (scripts/qh_phase_timing.py)
 // SMP = 1: the THRESHOLD-ONLY SAMPLE STAGE of a staged plan on this tiling (it was one 256-row tile of k_scan_h16<.., EMIT = 2> per CU:
 // 23 us of launch ramp, query image and ring fill for 65,536 rows).  a.ntiles tiles of 64 rows, tile t = rows (t / 4) * a.tile_stride +
