@@ -62,7 +62,7 @@ __global__ void __launch_bounds__(512, (QB == 1 ? 4 : 2)) k_scan_qh(ScanArgs a) 
     // 78k without).  And the grouped slow path — norm re-read, the exact expression, the pass test, the key — ran ~100 instructions with one
     // or two of 64 lanes active, per hit about as long as the MFMAs of the step.  Here the tile epilogue only STAGES the groups of four
     // values whose level-1 maximum passes: the lane appends (4 accumulators, first row, query) to its wave's LDS region (appends ride on
-    // lgkmcnt; one ballot per group).  The region is worked off when it is full — rare — and at the end of the launch, one ENTRY per lane:
+    // lgkmcnt; one ballot per group).  The region is worked off BETWEEN tiles once it is half full and at the end of the launch, one ENTRY per lane:
     // norms from global memory, the exact expression of k_scan_h16, the pass test, the key, a slot of the workgroup's segment of that
     // query (one LDS counter per query), a plain store.
     constexpr int EW = QB == 1 ? (NS == 3 ? 144 : 64) : 128;   // groups per wave region (16 B of accumulators + first row + query)
@@ -245,7 +245,7 @@ __global__ void __launch_bounds__(512, (QB == 1 ? 4 : 2)) k_scan_qh(ScanArgs a) 
     // written by a memory operation" on the rare path, and where that path joins the main loop again the compiler answers with
     // s_waitcnt vmcnt(0) in front of the next reuse of such a register — behind the ring pieces of EVERY step (measured: the DMA-issue
     // phase 7k -> 30k ticks per stage, the ring drained once per step).
-    auto flush_groups = [&]() __attribute__((always_inline)) {   // (a full region — rare — and once at the end of the launch; its waits drain the ring)
+    auto flush_groups = [&]() __attribute__((always_inline)) {   // (between tiles once the region is half full, and once at the end of the launch; its waits drain the ring)
         const uint32_t qcnt0 = lds0 + (uint32_t)QCNT_OFF;
         for (uint32_t e = (uint32_t)lane; e < e_cnt; e += 64u) {
             f32x4 x;
