@@ -1607,6 +1607,14 @@ static bool qh_sample_ok(const ScanArgs& a, bool filt, uint32_t qchunks, int lev
     return !filt && a.emit_all == 2 && plan_tile == 256 && qchunks == 1 && a.qpad == 256 && a.nq <= 256 && a.tile_stride >= 256 && a.skip_stride == 0 && !a.mask && !a.row_ids &&
            !a.tiles && a.row1 > a.row0 && (a.nslab == 1 || a.nslab == 2) && a.ld16 == a.nslab * 64u;
 }
+// -> the grid of the sample launch (0: the sample stage stays on k_scan_h16): two workgroups per CU, enough keys for k_select's threshold-only
+// rule (>= 8 k), inside the candidate buffer, <= 32 tiles per workgroup (the packed position of a sample key, scan_qh.h)
+static uint32_t qh_sample_grid(const ScanArgs& a, uint32_t sample_tiles, bool filt, uint32_t qchunks, int level, uint32_t plan_tile, uint32_t k, uint32_t cap, uint32_t num_cu) {
+    if (!sample_tiles || !qh_sample_ok(a, filt, qchunks, level, plan_tile)) return 0;
+    const uint32_t nt64 = sample_tiles * 4u, sgrid = std::min<uint32_t>(nt64, 2u * num_cu);
+    const bool ok = (uint64_t)sgrid * 4u >= 8ull * k && sgrid * 4u <= cap && (nt64 + sgrid - 1) / sgrid <= 32u;
+    return ok ? sgrid : 0u;
+}
 static int launch_scan_qh_sample(const ScanArgs& a, int metric, uint32_t grid, hipStream_t st) {
     static std::atomic<bool> attr_done[8] = {false};
     auto go = [&](auto kern, int slot, size_t lds) -> int {
@@ -2189,13 +2197,9 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
                     const uint32_t grid = std::min<uint32_t>(a.ntiles, (uint32_t)h->num_cu * 2);
                     if (!a.emit_all) seg_geometry(grid, 4, &a.nseg, &a.seg);
                     LY_TRY((launch_scan_h16<1, 4, 1, 1, 3, 3, false>(a, metric, grid, st)));
-                } else if (s.sample_tiles && qh_sample_ok(a, filt, qchunks, level, plan_tile) &&
-                           (uint64_t)std::min<uint32_t>(s.sample_tiles * 4u, 2u * (uint32_t)h->num_cu) * 4u >= 8ull * k &&
-                           std::min<uint32_t>(s.sample_tiles * 4u, 2u * (uint32_t)h->num_cu) * 4u <= w.cap &&
-                           (s.sample_tiles * 4u + std::min<uint32_t>(s.sample_tiles * 4u, 2u * (uint32_t)h->num_cu) - 1) / std::min<uint32_t>(s.sample_tiles * 4u, 2u * (uint32_t)h->num_cu) <= 32u) {
-                    // the threshold-only sample stage on k_scan_qh<.., SMP>: 4 keys per workgroup and query, <= 32 tiles per workgroup (the packed position of a key)
-                    const uint32_t nt64 = s.sample_tiles * 4u, sgrid = std::min<uint32_t>(nt64, 2u * (uint32_t)h->num_cu);
-                    a.ntiles = nt64;
+                } else if (const uint32_t sgrid = qh_sample_grid(a, s.sample_tiles, filt, qchunks, level, plan_tile, k, w.cap, (uint32_t)h->num_cu)) {
+                    // the threshold-only sample stage on k_scan_qh<.., SMP>: 4 keys per workgroup and query
+                    a.ntiles = s.sample_tiles * 4u;
                     LY_TRY(launch_scan_qh_sample(a, metric, sgrid, st));
                     qs_sample_keys = sgrid * 4u;
                     plan_used_qh = true;
