@@ -431,6 +431,11 @@ extern "C" int lynse_hip_flat_create(uint32_t dim, int device, lynse_hip_flat** 
     h->dim = dim;
     h->ld = round_up(dim, 4);
     h->ld16 = round_up(dim, 8);
+    // 48..63 and 96..127 columns: the f16 rows are padded (zeros) to a whole 64-element slab — at most a third more shadow bytes, and the
+    // float batches of such a shard (deep-96, GloVe-100 ...) run the whole-slab kernels: k_scan_qh (scan_qh.h) and the non-ragged
+    // k_scan_h16 variants.  LYNSE_HIP_SHADOW_PAD=0: the 8-element pitch (A/B, tests; read when the handle is created)
+    if (((dim >= 48 && dim < 64) || (dim >= 96 && dim < 128)) && !(getenv("LYNSE_HIP_SHADOW_PAD") && atoi(getenv("LYNSE_HIP_SHADOW_PAD")) == 0))
+        h->ld16 = round_up(dim, 64);
     h->ld8 = round_up(dim, 16);
     h->ld_bpm = round_up(dim, 256) / 2;
     h->ld8a = round_up(dim + 1, 128);

@@ -283,3 +283,37 @@ def test_exactness_rule_of_integer_collections_and_its_limits(L, oracle):
         e_ids, e_d = oracle.canonical_topk(q[qi], allrows, 10, O.L2)
         assert np.array_equal(r2[qi].astype(np.uint64), e_ids.astype(np.uint64)) and np.array_equal(dd2[qi].view(np.uint32), e_d.view(np.uint32))
     assert p1["pool_entries"] <= p2["pool_entries"], (p1, p2)
+
+
+@pytest.mark.parametrize("dim", [100, 56])
+def test_padded_shadow_puts_96_to_127_and_48_to_63_columns_on_the_whole_slab_kernels(L, oracle, dim):
+    """48..63 / 96..127 columns: the f16 shadow is padded to a whole 64-element slab (zeros), so float batches of such a shard run
+    k_scan_qh (tiling 0x82); LYNSE_HIP_SHADOW_PAD=0 (read when the handle is created) keeps the 8-element pitch and the ragged
+    k_scan_h16 variants.  Same bits either way, and the oracle's."""
+    n, nq = 200_003, 200
+    rng = np.random.default_rng(dim)
+    data = rng.standard_normal((n, dim)).astype(f32)
+    queries = (data[rng.integers(0, n, nq)] + 0.05 * rng.standard_normal((nq, dim)).astype(f32)).astype(f32)
+    idx = L.FlatIndex(None, dim)
+    idx.write(data)
+    idx.finalize()
+    idx.profile_enable(True)
+    os.environ["LYNSE_HIP_SHADOW_PAD"] = "0"
+    try:
+        idx0 = L.FlatIndex(None, dim)
+    finally:
+        del os.environ["LYNSE_HIP_SHADOW_PAD"]
+    idx0.write(data)
+    idx0.finalize()
+    idx0.profile_enable(True)
+    for name in ("l2", "cosine"):
+        for k in (10, 100):
+            idx.profile_get(reset=True); idx0.profile_get(reset=True)
+            r, d, c = idx.search_batch_arrays(queries, k, name)
+            r0, d0, c0 = idx0.search_batch_arrays(queries, k, name)
+            p, p0 = idx.profile_get(reset=True), idx0.profile_get(reset=True)
+            assert np.array_equal(r, r0) and np.array_equal(d.view(np.uint32), d0.view(np.uint32)) and np.array_equal(c, c0), (dim, name, k)
+            assert tiling_of(p0) != 0x82, (dim, name, k, p0)
+            if k == 10 and p["fallback_queries"] == 0:   # (k = 100 on a shard this small: an emit-all sample stage, whose tiles the later stages skip — k_scan_h16)
+                assert tiling_of(p) == 0x82, (dim, name, k, p)
+            check(oracle, data, queries, k, name, r, d, c, (0, 1, 99, 199), (dim, name, k))
