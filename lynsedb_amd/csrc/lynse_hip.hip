@@ -2841,7 +2841,7 @@ static void i8c_add_strike(lynse_hip_flat* h, int metric) {
     std::atomic<int>& c = i8c_strike_counter(h, metric);
     if (c.load() >= 0) c.fetch_add(1);
 }
-static bool i8c_eligible(const lynse_hip_flat* h, int metric, bool filtered, uint64_t nqc, bool view = false, bool masked = false) {
+static bool i8c_eligible(const lynse_hip_flat* h, int metric, bool filtered, uint64_t nqc, bool view = false, bool masked = false, bool ivf = false) {
     // filtered: a subset filter on the gathered-rows strategy (never int8); masked: a subset filter as a row bitmask — the
     // masked int8 scan (whole 128-column slabs only)
     // view: a row-range view of search_large_k (h->n is the range): the SQ8 codes belong to the whole shard
@@ -2862,6 +2862,16 @@ static bool i8c_eligible(const lynse_hip_flat* h, int metric, bool filtered, uin
     const bool nq_ok = nqc > SCAN_BQ_SMALL || (smallq && nqc >= 1 && (coarse_env() == 2 || h->n >= 262144));   // (masked small batches too)
     // (F16 shards too: the codes are built from the exactly decoded halves, the exact rescoring uses the f16 kernels' sequential
     // sums — any summation order is inside the bound's rounding term)
+    // FLAT-IP over rows of one or two whole 64-element slabs (64 / 128 columns, and the padded 48..63 / 96..127): batches of 33..256
+    // queries run the float pass on the f16 shadow — k_scan_qh (scan_qh.h) is faster there than the 256 x 256 int8 tile over 128-byte code
+    // rows and its margin ~2.5x tighter (round 5, 1M rows, 256 queries: 64 columns k = 10 / 100 0.222 / 0.318 -> 0.137 / 0.166 ms, 100 columns
+    // 0.234 / 0.344 -> 0.169 / 0.188, 128 columns 0.163 / 0.273 -> 0.175 / 0.193; 100 queries 0.157 -> 0.127).  LYNSE_HIP_IP_LOWD=i8: the int8 pass
+    // (read per call: tests; ivf: the list scans of an IVF store run the work-list tilings of k_scan_h16 either way — they keep the codes)
+    const char* lowd_env = getenv("LYNSE_HIP_IP_LOWD");
+    const bool lowd_i8 = lowd_env && !strcmp(lowd_env, "i8");
+    if (metric == M_IP && !lowd_i8 && !ivf && !masked && !filtered && coarse_env() != 2 && nqc > SCAN_BQ_SMALL && nqc <= QCHUNK && h->ld16 % 64 == 0 && h->ld16 <= 128 &&
+        qh_variant() == 1)
+        return false;
     return (metric == M_IP || l2_ok || cos_ok) && !filtered && !view && nq_ok &&
            scan_variant() == 3 && coarse_env() != 1 && strikes >= 0 && strikes < 3 && (coarse_env() == 2 || h->n >= 65536);
 }

@@ -14,6 +14,17 @@ import pytest
 import oracle as O
 
 pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _int8_pass_at_every_width():
+    """These tests are about the certified int8 pass itself.  Since round 5 FLAT-IP batches over 64 / 128-column rows run the float pass
+    (k_scan_qh is faster there); LYNSE_HIP_IP_LOWD=i8 (read per call) keeps them on the int8 pass at those widths too."""
+    import os
+
+    os.environ["LYNSE_HIP_IP_LOWD"] = "i8"
+    yield
+    del os.environ["LYNSE_HIP_IP_LOWD"]
 f32 = np.float32
 
 PLAN_I8C, PLAN_I8C_STARTED = 4, 64

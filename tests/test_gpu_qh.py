@@ -78,8 +78,17 @@ def test_qh_threshold_stages_equal_the_oracle_and_the_256x256_tile(L, oracle, di
             # (k = 100 over Gaussian rows may send the batch down the plan ladder on either tiling — whose later levels run k_scan_h16: neither
             # the fallback count nor the tiling of a batch that fell back is pinned)
             assert tiling_of(p0) != 0x82, (name, nq, k, p, p0)
-            if name != "ip" and p["fallback_queries"] == 0:      # (IP batches of a shard this size stream the certified int8 codes: k_scan_h16<.., I8Q = 2>)
+            if p["fallback_queries"] == 0:      # (FLAT-IP batches over 64 / 128-column rows run the float pass too: round 5)
                 assert tiling_of(p) == 0x82, (name, nq, k, p)
+            if name == "ip":                    # LYNSE_HIP_IP_LOWD=i8 (read per call): the certified int8 pass (plan flag 4) — identical bits
+                os.environ["LYNSE_HIP_IP_LOWD"] = "i8"
+                try:
+                    r8, d8, c8 = idx.search_batch_arrays(queries[:nq], k, name)
+                    p8 = idx.profile_get(reset=True)
+                finally:
+                    del os.environ["LYNSE_HIP_IP_LOWD"]
+                assert np.array_equal(r8, r) and np.array_equal(d8.view(np.uint32), d.view(np.uint32)) and np.array_equal(c8, c), (name, nq, k)
+                assert tiling_of(p8) != 0x82 and (p8["fallback_queries"] != 0 or int(p8["last_plan"]) & 4), (name, nq, k, p8)
             picks = sorted({0, 1, 31, 32, 33, 63, 64, nq // 2, nq - 2, nq - 1} & set(range(nq)))
             check(oracle, data, queries, k, name, r, d, c, picks, (dim, name, nq, k))
 
