@@ -370,12 +370,15 @@ int lynse_hip_ivf_search_sharded_f32_device(lynse_hip_ivf *h, lynse_hip_comm *c,
 /* Row-sharded IVF TRAINING: k-means over the whole collection (src/index/kmeans.rs:74-139) with every rank holding only its rows
  * (global row g = local row g / world on rank g % world).  Same FastRng sample + farthest-first init, assignment, last-maximum /
  * empty-cluster rules and stop test as training on the union; the centroid sums are formed per rank (sequential over the rank's
- * members, kmeans.rs:273-286) and added over the ranks — ONE all-reduce of nlist * dim floats + nlist counts per Lloyd iteration
- * (SURVEY 8e).  Every rank gets the same centroids (out_centroids: nlist x dim, *out_k lists trained) and the assignments of its
- * rows; load the shard with lynse_hip_ivf_load / _load_device afterwards.  The reduction: the library's communicator `c`
- * (ncclAllReduce), or — c == NULL — the launcher's callback, which sums a HOST buffer of `count` elements over all ranks in place
- * (dtype 0: f32, 1: u32; 0 = success).  rows_on_device: rows_local is device memory.  A collective.  (No reference counterpart:
- * the reference's cluster mode trains one index per shard node.) */
+ * members, kmeans.rs:273-286) and added over the ranks IN RANK ORDER, ((p0 + p1) + p2) + ... with f32 adds — the result is defined
+ * bit for bit at every world size (an all-reduce associates as it likes from three ranks on).  Per Lloyd iteration: nlist * dim
+ * floats per rank + nlist + 1 integer words.  Every rank gets the same centroids (out_centroids: nlist x dim, *out_k
+ * lists trained) and the assignments of its rows; load the shard with lynse_hip_ivf_load / _load_device afterwards.  The
+ * reduction: the library's communicator `c` (on device buffers: ncclAllGather of the per-rank sums + a rank-ordered add kernel +
+ * one integer ncclAllReduce), or — c == NULL — the launcher's callback, which sums a HOST buffer of `count` elements over all
+ * ranks in place (dtype 0: f32 in any order — only ever one non-zero contribution per element —, 1: u32, 2: f32 in RANK order as
+ * above; 0 = success).  rows_on_device: rows_local is device memory.  A collective.  (No reference counterpart: the reference's
+ * cluster mode trains one index per shard node.) */
 typedef int (*lynse_hip_reduce_fn)(void *ctx, void *buf, uint64_t count, int dtype);
 int lynse_hip_ivf_kmeans_sharded(const float *rows_local, uint64_t n_local, int rows_on_device, uint64_t n_global,
                                  uint32_t rank, uint32_t world, uint32_t dim, uint32_t nlist, uint32_t max_iter, int metric,

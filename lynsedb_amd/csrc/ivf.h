@@ -302,6 +302,28 @@ __global__ void __launch_bounds__(256) k_kmeans_sums(const float* __restrict__ V
     }
 }
 
+// Row-sharded training (lynse_hip_ivf_kmeans_sharded through the communicator): the per-rank centroid sums arrive as one
+// all-gathered array [world][count]; they are added in RANK order — ((p0 + p1) + p2) + ... with f32 adds, the order of the oracle's
+// lo_kmeans_train_sharded — so the centroids are defined bit for bit at every world size (a ring / tree all-reduce associates
+// differently per chunk from world 3 on).
+__global__ void __launch_bounds__(256) k_sum_rank_order(const float* __restrict__ parts, uint32_t world, uint64_t count,
+                                                        float* __restrict__ out) {
+    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < count; j += (uint64_t)gridDim.x * blockDim.x) {
+        float s = parts[j];
+        for (uint32_t r = 1; r < world; ++r) s = __fadd_rn(s, parts[(size_t)r * count + j]);
+        out[j] = s;
+    }
+}
+
+// ... and the words that ride along as ONE integer all-reduce: the rank's member count of every list (from the offsets the sums
+// kernel reads) + "an assignment changed on this rank" (the stop test of the whole collection, kmeans.rs:127-129)
+__global__ void __launch_bounds__(256) k_counts_from_offsets(const uint64_t* __restrict__ offsets, uint32_t k, uint32_t changed,
+                                                             uint32_t* __restrict__ out /* k + 1 */) {
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < k) out[c] = (uint32_t)(offsets[c + 1] - offsets[c]);
+    else if (c == k) out[k] = changed;
+}
+
 // distance of every sample row to one point + running min-rank (kmeans.rs:170-182)
 __global__ void __launch_bounds__(256) k_kmeans_minrank(const float* __restrict__ S, uint32_t ld, uint32_t D, uint32_t n,
                                                         const float* __restrict__ point, int metric,

@@ -21,6 +21,7 @@
 #include <thread>
 #include <type_traits>
 #include <vector>
+#include <sched.h>
 
 #include "kernels.h"
 #include "scan_qs.h"
@@ -72,17 +73,25 @@ static int h2d_done(void* dst, const void* src, size_t n) {
 
 // The end of a blocking search: hipStreamSynchronize spins on the completion signal for ~100 us and then parks the thread on an
 // interrupt (ROCclr) — a batch over 10M rows runs 1.8 ms, so every blocking step paid the wake-up (~20-25 us between k_select_final
-// and the next batch's first kernel in the kernel trace).  Poll the stream instead for up to LYNSE_HIP_SPIN_US (default 20 ms: any
-// batch this library answers; the reference's own search burns every core of its rayon pool while it runs), then block as before.
+// and the next batch's first kernel in the kernel trace).  Poll the stream instead: a tight poll for the first 200 us (the latency-shaped
+// searches end inside it), then a poll with sched_yield() between the queries — a thread that has something to enqueue, or another
+// blocked reader of the same handle, gets the core (eight blocked readers were eight spinning cores) — for up to
+// LYNSE_HIP_SPIN_US in all (default 5 ms: any batch this library answers at the BASELINE sizes), then block as before.
 static int stream_wait(hipStream_t st) {
-    static const int64_t spin_us = []() { const char* e = getenv("LYNSE_HIP_SPIN_US"); return e ? (int64_t)atoll(e) : (int64_t)20000; }();
+    static const int64_t spin_us = []() { const char* e = getenv("LYNSE_HIP_SPIN_US"); return e ? (int64_t)atoll(e) : (int64_t)5000; }();
     if (spin_us > 0) {
         const auto t0 = std::chrono::steady_clock::now();
+        bool polite = false;
         for (uint32_t it = 0;; ++it) {
             const hipError_t q = hipStreamQuery(st);
             if (q == hipSuccess) return LYNSE_OK;
             if (q != hipErrorNotReady) return set_error(LYNSE_ERR_DEVICE, std::string("hipStreamQuery: ") + hipGetErrorString(q));
-            if ((it & 15u) == 15u && std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() > spin_us) break;
+            if (polite) sched_yield();
+            if (polite || (it & 15u) == 15u) {
+                const int64_t us = std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
+                if (us > spin_us) break;
+                if (us > 200) polite = true;
+            }
         }
     }
     LY_HIP(hipStreamSynchronize(st));
@@ -1562,18 +1571,18 @@ static int launch_scan_qs_sample(const ScanArgs& a, uint32_t grid, hipStream_t s
 }
 
 // The query-stationary tiling of the f16 shadow at low dimension (scan_qh.h): threshold stages of an unfiltered FLAT batch of 33..256
-// queries on the float path over rows of 1 or 2 whole 64-element slabs (64 / 128 columns: BASELINE config 3).  OFF by default
-// (LYNSE_HIP_QH=1: 32 queries per wave, two workgroups per CU; =2: 64 queries per wave; read per call): bit-identical results (tests),
-// MEASURED 4 % / 20 % slower than the 256 x 256 tile of k_scan_h16 on C3 (1M x 128, k = 100: 0.224-0.227 / 0.261-0.265 against
-// 0.215-0.217 ms per batch, same box, alternating) — without emission it is the faster scan (78k against ~100k ticks per 738k-row
-// stage), with it every 64-row step of every workgroup holds a key and the grouped slow path (norm re-read, four ballots, the exact
-// expression) costs as much as the MFMAs of the step; DESIGN 4.3 has the phase table.
+// queries on the float path over rows of 1 or 2 whole 64-element slabs (64 / 128 columns: BASELINE config 3).  ON by default since the
+// deferred emission of round 5 (LYNSE_HIP_QH=0: k_scan_h16's 256 x 256 tile, A/B; read per call): bit-identical results (tests), C3
+// 0.190-0.194 against 0.213-0.219 ms per batch on the same box; DESIGN 4.3 has the phase table and what the first versions lost to
+// (keys stored straight to global memory stalled the ring; a grouped slow path as long as the MFMAs of its step).
 constexpr int QH_DEFAULT = 1;
 static int qh_variant() { const char* e = getenv("LYNSE_HIP_QH"); return e ? atoi(e) : QH_DEFAULT; }   // 0 = k_scan_h16, 1 = k_scan_qh
+// the batch SHAPE k_scan_qh takes (shared with i8c_eligible, which sends FLAT-IP batches of this shape to the float pass only because
+// this kernel runs them: ADVICE r5): 33..256 queries — one 256-query chunk —, rows of one or two whole 64-element slabs
+static bool qh_shape(uint32_t ld16, uint64_t nq) { return qh_variant() == 1 && nq > SCAN_BQ_SMALL && nq <= QCHUNK && (ld16 == 64u || ld16 == 128u); }
 static bool qh_scan_ok(const ScanArgs& a, bool filt, uint32_t qchunks, int level) {
-    const int v = qh_variant();
-    if (v != 1 || level != 0) return false;   // (the plan ladder's later levels run k_scan_h16: k_scan_qh may hand a batch with massive ties to it)
-    return !filt && a.emit_all == 0 && qchunks == 1 && a.qpad == 256 && a.nq <= 256 && a.tile_stride == 0 && a.skip_stride == 0 && !a.mask && !a.row_ids &&
+    if (level != 0) return false;   // (the plan ladder's later levels run k_scan_h16: k_scan_qh may hand a batch with massive ties to it)
+    return qh_shape(a.ld16, a.nq) && !filt && a.emit_all == 0 && qchunks == 1 && a.qpad == 256 && a.tile_stride == 0 && a.skip_stride == 0 && !a.mask && !a.row_ids &&
            !a.tiles && a.row1 > a.row0 && (a.nslab == 1 || a.nslab == 2) && a.ld16 == a.nslab * 64u;
 }
 static uint32_t qh_grid(const ScanArgs& a, uint32_t num_cu, uint32_t* segs_per_wg) {
@@ -2869,8 +2878,9 @@ static bool i8c_eligible(const lynse_hip_flat* h, int metric, bool filtered, uin
     // (read per call: tests; ivf: the list scans of an IVF store run the work-list tilings of k_scan_h16 either way — they keep the codes)
     const char* lowd_env = getenv("LYNSE_HIP_IP_LOWD");
     const bool lowd_i8 = lowd_env && !strcmp(lowd_env, "i8");
-    if (metric == M_IP && !lowd_i8 && !ivf && !masked && !filtered && coarse_env() != 2 && nqc > SCAN_BQ_SMALL && nqc <= QCHUNK && h->ld16 % 64 == 0 && h->ld16 <= 128 &&
-        qh_variant() == 1)
+    // (gated on the very shape predicate qh_scan_ok applies — a batch k_scan_qh would not take must not lose the int8 pass to the slower
+    // 256 x 256 f16 tile; `view` = the gathered rows of a subset filter, a widened handle never comes here with <= 256 queries)
+    if (metric == M_IP && !lowd_i8 && !ivf && !masked && !filtered && !view && coarse_env() != 2 && h->qchunk <= QCHUNK && qh_shape(h->ld16, nqc))
         return false;
     return (metric == M_IP || l2_ok || cos_ok) && !filtered && !view && nq_ok &&
            scan_variant() == 3 && coarse_env() != 1 && strikes >= 0 && strikes < 3 && (coarse_env() == 2 || h->n >= 65536);

@@ -466,12 +466,15 @@ class ShardedIvf:
         self.metric = metric
 
     def _host_reduce(self, reduce, device: int):
-        """The `lynse_hip_reduce_fn` of this shard's launcher: sums a host buffer over all ranks in place (dtype 0: f32, 1: u32)."""
+        """The `lynse_hip_reduce_fn` of this shard's launcher: sums a host buffer over all ranks in place (dtype 0: f32 in any order — the
+        init sample, one owner per row —, 1: u32, 2: f32 in RANK order, ((p0 + p1) + p2) + ...: the centroid sums of a Lloyd iteration,
+        whose bits `lo_kmeans_train_sharded` defines for every world size; an all-reduce associates as it likes from three ranks on, so
+        this one is an all-gather + a sequential add).  `reduce(arr)` (tests) must add in rank order itself."""
         import ctypes as C_
 
         def host_reduce(_ctx, buf, count, dtype):
             try:
-                arr = np.ctypeslib.as_array(C_.cast(buf, C_.POINTER(C_.c_float if dtype == 0 else C_.c_uint32)), shape=(int(count),))
+                arr = np.ctypeslib.as_array(C_.cast(buf, C_.POINTER(C_.c_uint32 if dtype == 1 else C_.c_float)), shape=(int(count),))
                 if reduce is not None:
                     reduce(arr)
                 elif self.world > 1 and self.dist is None:
@@ -480,6 +483,16 @@ class ShardedIvf:
                     import torch
 
                     t = torch.from_numpy(arr)                      # (shares the buffer)
+                    if dtype == 2:
+                        on_gpu = self.dist.get_backend() == "nccl"
+                        src = t.to(torch.device("cuda", device)) if on_gpu else t
+                        parts = [torch.empty_like(src) for _ in range(self.world)]
+                        self.dist.all_gather(parts, src)
+                        total = parts[0].clone()
+                        for r in range(1, self.world):
+                            total += parts[r]                       # one IEEE f32 add per element and rank, in rank order
+                        t.copy_(total.cpu() if on_gpu else total)
+                        return 0
                     if dtype == 1:
                         t = t.view(torch.int32)                    # counts stay far below 2^31
                     if self.dist.get_backend() == "nccl":

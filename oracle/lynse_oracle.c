@@ -1415,9 +1415,10 @@ size_t lo_kmeans_train(const float *data, size_t n, size_t dim, size_t requested
 /* Row-sharded training (no reference counterpart: the reference's cluster mode trains one index per shard; SURVEY 8(e) names the
  * all-reduce of the centroid sums and counts).  kmeans_train over the UNION of `world` row shards (global row g on rank g % world)
  * with ONE difference: the centroid sums of an iteration are formed per rank (sequential over that rank's members in ascending
- * row order, kmeans.rs:273-286 on the shard) and the per-rank sums are then added in rank order — what an all-reduce of the
- * per-rank sums delivers (exactly for world = 2, where the order cannot matter).  Init, assignment, counts, the empty-cluster
- * rule and the stop test see the whole collection. */
+ * row order, kmeans.rs:273-286 on the shard) and the per-rank sums are then added in RANK order, ((p0 + p1) + p2) + ... with f32
+ * adds.  This order is the SPECIFICATION of the sharded training at every world size: the product gathers the per-rank sums and
+ * adds them in this order (an all-reduce would associate differently per chunk from three ranks on).  Init, assignment, counts,
+ * the empty-cluster rule and the stop test see the whole collection. */
 size_t lo_kmeans_train_sharded(const float *data, size_t n, size_t dim, size_t requested, size_t max_iter,
                                int metric, size_t world, float *centroids, uint32_t *assignments) {
     size_t k = requested < n ? requested : n;

@@ -274,6 +274,14 @@ static void scenario_dead_peer() {
         const int rc = lynse_hip_flat_search_sharded_f32_device(h, c, q.data(), 64, 10, 0, o.rows.data(), o.dists.data(), o.counts.data());
         CHECK(rc == LYNSE_ERR_TIMEOUT, "blocking sharded flat: rc %d (%s)", rc, last_error().c_str());
         CHECK(ms_since(t0) < 3000.0, "blocking sharded flat waited %.0f ms", ms_since(t0));
+        // the communicator is marked failed: the next sharded call returns at once (it would queue behind the hung collective and wait
+        // out the bound again), blocking entry point and submit alike
+        const auto t1 = std::chrono::steady_clock::now();
+        const int rc2 = lynse_hip_flat_search_sharded_f32_device(h, c, q.data(), 64, 10, 0, o.rows.data(), o.dists.data(), o.counts.data());
+        CHECK(rc2 == LYNSE_ERR_DEVICE && ms_since(t1) < 100.0, "second call on a timed-out communicator: rc %d after %.0f ms (%s)", rc2, ms_since(t1), last_error().c_str());
+        lynse_hip_ticket* t2 = nullptr;
+        const int rc3 = lynse_hip_flat_search_submit_f32_device(h, c, q.data(), 64, 10, 0, o.rows.data(), o.dists.data(), o.counts.data(), &t2);
+        CHECK(rc3 == LYNSE_ERR_DEVICE && t2 == nullptr, "submit on a timed-out communicator: rc %d", rc3);
         lynse_hip_flat_destroy(h); lynse_hip_comm_destroy(c);
     }
     {   // (c) IVF ticket and (d) blocking sharded IVF search

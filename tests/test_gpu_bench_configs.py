@@ -1,4 +1,5 @@
-"""`bench.py --config c4 / c5` end to end at reduced sizes (one GPU, and two gloo ranks sharing it): the line is printed, names the
+"""`bench.py --config c4 / c5` (and the headline c2) end to end at reduced sizes (one GPU, and 2 / 4 / 8 gloo ranks sharing it — the
+first real 8-GPU run must not also be the first run of the 8-rank code path): the line is printed, names the
 workload BASELINE.json names, and its own verification legs are green (tickets == the blocking search; recall against the exact
 top-k of the whole collection for IVF, the oracle's packed search for Hamming)."""
 import json
@@ -25,7 +26,7 @@ def run_bench(args, env=None):
     return json.loads(lines[0])
 
 
-@pytest.mark.parametrize("gpus", [1, 2])
+@pytest.mark.parametrize("gpus", [1, 2, 4])
 def test_bench_config_c4_prints_a_verified_line(gpus):
     env = {"LYNSE_BENCH_BACKEND": "gloo"} if gpus > 1 else None       # two ranks share the one GPU of a test box: no RCCL between them
     d = run_bench(["--config", "c4", "--gpus", str(gpus), "--rows-per-gpu", "150000", "--nlist", "512", "--nprobe", "16", "--steps", "4", "--warmup", "1"], env)
@@ -39,10 +40,20 @@ def test_bench_config_c4_prints_a_verified_line(gpus):
         assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] == 1 and d["cpu_baseline"]["value"] > 0, d["cpu_baseline"]
 
 
-@pytest.mark.parametrize("gpus", [1, 2])
+@pytest.mark.parametrize("gpus", [1, 2, 8])
 def test_bench_config_c5_prints_a_verified_line(gpus):
     env = {"LYNSE_BENCH_BACKEND": "gloo"} if gpus > 1 else None
     d = run_bench(["--config", "c5", "--gpus", str(gpus), "--rows", str(600000 * gpus), "--steps", "4", "--warmup", "1", "--no-cpu-baseline"], env)
     assert d["n_gpus"] == gpus and d["dtype"] == "u64" and d["value"] > 0
     assert "Hamming %dx1024-bit" % (600000 * gpus) in d["metric"] and "k=50" in d["metric"]
     assert d["verify"] == {"tickets_equal_blocking_search": True, "oracle_bit_exact_on_200k_row_sample": True}
+
+
+@pytest.mark.parametrize("gpus", [4, 8])
+def test_bench_headline_runs_sharded_over_4_and_8_ranks(gpus):
+    """The headline workload (FLAT-IP, 256 queries, k = 10) row-sharded over 4 / 8 gloo ranks that share the one GPU: tickets in flight, the
+    exchange (torch all-gather under gloo) + canonical merge, recall against the exact top-k of the WHOLE collection."""
+    d = run_bench(["--gpus", str(gpus), "--rows", "400000", "--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--no-configs", "--settle-ms", "0"],
+                  {"LYNSE_BENCH_BACKEND": "gloo"})
+    assert d["n_gpus"] == gpus and d["scaling"] == "strong" and d["value"] > 0
+    assert d["verify"]["recall_at_k_tolerant"] == 1.0, d["verify"]

@@ -1,4 +1,4 @@
-"""world_size-2 `gloo` test of the multi-GPU exchange step on CPU (no GPU needed).
+"""world_size-2 / 4 / 8 `gloo` tests of the multi-GPU exchange step on CPU (no GPU needed).
 
 Covers the N>1 path of lynsedb_amd/sharded.py: the row partition rule (global row g on rank g % G),
 the fixed-size per-rank result block, the all-gather and the canonical (distance, row) k-way merge
@@ -64,16 +64,15 @@ def _worker(rank, world, port, metric, ret):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("metric", [0, 1, 3])  # IP (descending), L2, Hamming (heavy ties)
-def test_allgather_merge_world2(metric):
+@pytest.mark.parametrize("world,metric", [(2, 0), (2, 1), (2, 3), (4, 0), (4, 3), (8, 1), (8, 3)])  # IP (descending), L2, Hamming (heavy ties)
+def test_allgather_merge(world, metric):
     import torch.multiprocessing as mp
 
-    world = 2
     port = _free_port()
     mgr = mp.Manager()
     ret = mgr.dict()
     mp.spawn(_worker, args=(world, port, metric, ret), nprocs=world, join=True)
-    assert dict(ret) == {0: True, 1: True}
+    assert dict(ret) == {r: True for r in range(world)}
 
 
 def _ivf_worker(rank, world, port, ret):
@@ -127,15 +126,21 @@ def _ivf_worker(rank, world, port, ret):
         dist.destroy_process_group()
 
 
-def test_sharded_ivf_exchange_world2():
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_sharded_ivf_exchange(world):
     import torch.multiprocessing as mp
 
-    world = 2
     port = _free_port()
     mgr = mp.Manager()
     ret = mgr.dict()
     mp.spawn(_ivf_worker, args=(world, port, ret), nprocs=world, join=True)
-    assert dict(ret) == {0: True, 1: True}
+    assert dict(ret) == {r: True for r in range(world)}
+
+
+def _ordered_values(rank, n=1000):
+    """f32 values whose sum depends on the order of the additions (magnitudes spread over 2^24 and both signs)."""
+    rng = np.random.default_rng(1000 + rank)
+    return (rng.standard_normal(n) * np.exp2(rng.integers(-12, 13, n))).astype(np.float32)
 
 
 def _reduce_worker(rank, world, port, ret):
@@ -146,6 +151,7 @@ def _reduce_worker(rank, world, port, ret):
 
     import torch.distributed as dist
 
+    import oracle as O
     from lynsedb_amd.sharded import ShardedIvf
 
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -154,18 +160,58 @@ def _reduce_worker(rank, world, port, ret):
         fn = sh._host_reduce(None, 0)                      # the lynse_hip_reduce_fn the all-reduced k-means calls (lynse_hip_ivf_kmeans_sharded)
         f = (np.arange(1000, dtype=np.float32) * (rank + 1) * 0.37).astype(np.float32)
         u = (np.arange(77, dtype=np.uint32) + 5 * rank).astype(np.uint32)
+        o = _ordered_values(rank)
         assert fn(None, f.ctypes.data_as(C.c_void_p), f.size, 0) == 0
         assert fn(None, u.ctypes.data_as(C.c_void_p), u.size, 1) == 0
-        ret[rank] = (f.copy(), u.copy())
+        assert fn(None, o.ctypes.data_as(C.c_void_p), o.size, 2) == 0      # dtype 2: f32 in RANK order
+        # the sharded Lloyd loop restated over the launcher's reduction (every rank holds the rows g % world == rank; the device
+        # half of lynse_hip_ivf_kmeans_sharded is tests/test_gpu_sharded_kmeans.py): centroids + assignments must be the oracle's
+        # lo_kmeans_train_sharded(world) bit for bit — the rank-ordered sum is what makes that true beyond two ranks
+        orc = O.get()
+        rng = np.random.default_rng(5)
+        nlist, dim, n, iters = 12, 24, 3000, 20
+        centers = (rng.standard_normal((nlist, dim)) * 4).astype(np.float32)
+        data = (centers[rng.integers(0, nlist, n)] + 0.3 * rng.standard_normal((n, dim))).astype(np.float32)
+        km = {}
+        for metric in (O.L2, O.IP):
+            cen, _ = orc.kmeans_train(data, nlist, 0, metric)      # max_iter 0: the FastRng sample + farthest-first init (kmeans.rs:141-196)
+            cen = cen.copy()
+            local = np.ascontiguousarray(data[rank::world])
+            cur = np.full(local.shape[0], 0xFFFFFFFF, np.uint32)
+            for _ in range(iters):
+                nxt = orc.kmeans_assign(local, cen, metric)
+                words = np.zeros(nlist + 1, np.uint32)
+                words[:nlist] = np.bincount(nxt, minlength=nlist).astype(np.uint32)
+                words[nlist] = 1 if not np.array_equal(nxt, cur) else 0
+                cur = nxt
+                sums = np.zeros((nlist, dim), np.float32)
+                np.add.at(sums, cur.astype(np.int64), local)       # unbuffered: one f32 add per member row, ascending row order (kmeans.rs:273-286)
+                flat = sums.reshape(-1)
+                assert fn(None, flat.ctypes.data_as(C.c_void_p), flat.size, 2) == 0
+                assert fn(None, words.ctypes.data_as(C.c_void_p), words.size, 1) == 0
+                counts = words[:nlist]
+                max_c = nlist - 1 - int(np.argmax(counts[::-1]))  # max_by_key keeps the LAST maximum (kmeans.rs:105-110)
+                for c in range(nlist):
+                    if counts[c] > 0:
+                        cen[c] = sums[c] * (np.float32(1.0) / np.float32(counts[c]))
+                    elif counts[max_c] > 1:
+                        cen[c] = cen[max_c] * (np.float32(1.0) + np.float32(1e-4) * np.arange(dim, dtype=np.float32))
+                if words[nlist] == 0:
+                    break
+            km[int(metric)] = (cen.copy(), orc.kmeans_assign(local, cen, metric))
+        ret[rank] = (f.copy(), u.copy(), o.copy(), km)
     finally:
         dist.destroy_process_group()
 
 
-def test_sharded_kmeans_reduction_world2_and_the_restatement_it_is_tested_against():
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_sharded_kmeans_reduction_and_the_restatement_it_is_tested_against(world):
     """Host side of the row-sharded IVF training (lynse_hip_ivf_kmeans_sharded; the device part: tests/test_gpu_sharded_kmeans.py):
-    (1) the reduction callback of the launcher sums f32 / u32 host buffers over the gloo ranks in place; (2) the oracle's
-    restatement of the sharded algorithm (lo_kmeans_train_sharded: per-rank sequential sums added in rank order) is kmeans_train
-    itself for one rank — bit for bit — and stays within rounding of it for two (same lists on well-separated data)."""
+    (1) the reduction callback of the launcher sums f32 / u32 host buffers over the gloo ranks in place, and its RANK-ORDERED form
+    (dtype 2) returns ((p0 + p1) + p2) + ... bit for bit on values whose sum depends on the order; (2) the sharded Lloyd loop run
+    over that callback by `world` gloo processes ends with the centroids and assignments of the oracle's restatement
+    (lo_kmeans_train_sharded: per-rank sequential sums added in rank order) — bit for bit at 2, 4 and 8 ranks; (3) that
+    restatement is kmeans_train itself for one rank and stays within rounding of it otherwise."""
     import multiprocessing as mp
 
     import oracle as O
@@ -174,24 +220,42 @@ def test_sharded_kmeans_reduction_world2_and_the_restatement_it_is_tested_agains
     with ctx.Manager() as m:
         ret = m.dict()
         port = _free_port()
-        ps = [ctx.Process(target=_reduce_worker, args=(r, 2, port, ret)) for r in range(2)]
+        ps = [ctx.Process(target=_reduce_worker, args=(r, world, port, ret)) for r in range(world)]
         for p in ps:
             p.start()
         for p in ps:
-            p.join(120)
+            p.join(300)
             assert p.exitcode == 0
-        f0, u0 = ret[0]
-        f1, u1 = ret[1]
-    want_f = (np.arange(1000, dtype=np.float32) * 0.37).astype(np.float32) + (np.arange(1000, dtype=np.float32) * 2 * 0.37).astype(np.float32)
-    assert np.array_equal(f0.view(np.uint32), want_f.view(np.uint32)) and np.array_equal(f1.view(np.uint32), want_f.view(np.uint32))
-    assert np.array_equal(u0, np.arange(77, dtype=np.uint32) * 2 + 5) and np.array_equal(u1, u0)
+        got = [ret[r] for r in range(world)]
+    want_f = np.zeros(1000, np.float32)
+    want_o = _ordered_values(0)
+    for r in range(world):
+        want_f = want_f + (np.arange(1000, dtype=np.float32) * (r + 1) * 0.37).astype(np.float32)
+        if r:
+            want_o = want_o + _ordered_values(r)
+    want_u = np.arange(77, dtype=np.uint32) * world + 5 * sum(range(world))
+    rev = _ordered_values(world - 1)
+    for r in range(world - 2, -1, -1):
+        rev = rev + _ordered_values(r)
+    if world > 2:
+        assert not np.array_equal(rev.view(np.uint32), want_o.view(np.uint32))   # (the order matters on these values)
+    for f, u, o, _ in got:
+        assert np.allclose(f, want_f, rtol=1e-6)
+        assert np.array_equal(u, want_u)
+        assert np.array_equal(o.view(np.uint32), want_o.view(np.uint32))
     orc = O.get()
     rng = np.random.default_rng(5)
     centers = (rng.standard_normal((12, 24)) * 4).astype(np.float32)
-    data = (centers[rng.integers(0, 12, 5000)] + 0.3 * rng.standard_normal((5000, 24))).astype(np.float32)
+    data = (centers[rng.integers(0, 12, 3000)] + 0.3 * rng.standard_normal((3000, 24))).astype(np.float32)
+    for metric in (O.L2, O.IP):
+        c_w, a_w = orc.kmeans_train_sharded(data, 12, 20, metric, world)
+        for r in range(world):
+            cen, asg = got[r][3][int(metric)]
+            assert np.array_equal(cen.view(np.uint32), c_w.view(np.uint32)), (world, r, metric)
+            assert np.array_equal(asg, a_w[r::world]), (world, r, metric)
     for metric in (O.L2, O.IP, O.COS):
         c_one, a_one = orc.kmeans_train(data, 12, 20, metric)
         c_w1, a_w1 = orc.kmeans_train_sharded(data, 12, 20, metric, 1)
         assert np.array_equal(c_one.view(np.uint32), c_w1.view(np.uint32)) and np.array_equal(a_one, a_w1)
-        c_w2, a_w2 = orc.kmeans_train_sharded(data, 12, 20, metric, 2)
-        assert np.allclose(c_one, c_w2, rtol=1e-5, atol=1e-5) and np.array_equal(a_one, a_w2), metric
+        c_w, a_w = orc.kmeans_train_sharded(data, 12, 20, metric, world)
+        assert np.allclose(c_one, c_w, rtol=1e-5, atol=1e-5) and np.array_equal(a_one, a_w), metric
