@@ -18,8 +18,19 @@
  *  - distances: IP raw dot (descending), L2 squared, cosine distance, Hamming/Jaccard/Dice as f32;
  *  - every function returns a status code (LynseError variants, src/error.rs:5-52); the message is
  *    available per thread from lynse_hip_last_error(); nothing throws or aborts across the ABI;
- *  - a handle may be searched from several threads (calls serialise on an internal mutex);
- *    append/finalize are exclusive, like `&mut self` in FlatMmap::write.
+ *  - NON-FINITE VALUES.  The reference compares distances with partial_cmp(..).unwrap_or(Equal) (flat_mmap.rs:2141-2149,
+ *    :2170-2176): a NaN distance is "equal" to everything, is never admitted once a top-k array is full and stays wherever the first
+ *    fill put it — the result depends on the row order and the thread count.  This boundary pins ONE order instead: a NaN score is
+ *    reported as the WORST value of the metric (+inf for the distances, -inf for IP) and ranks behind every better score, ties by
+ *    ascending row like any other tie; +inf / -inf scores are ordinary values of the order.  A query with a NaN element (cosine: or
+ *    an infinite one) scores NaN against every row: an unfiltered FLAT search answers it with rows 0 .. min(k, N) - 1 at the worst
+ *    value — the rows the reference's first fill keeps.  Rows may hold NaN / +-inf elements (the certified int8 pass switches itself
+ *    off for such a shard).  Pinned by tests/test_gpu_flat_parity.py::test_nan_and_infinite_rows_and_queries.
+ *  - a handle may be searched from several threads: unfiltered searches run under a SHARED lock, each on one of the handle's
+ *    search contexts (stream + workspace, up to LYNSE_HIP_CONTEXTS = 8 at a time, further callers wait for a free one) — the
+ *    Arc<RwLock<Collection>>::read of the reference (src/python/mod.rs:950, :1187); append / finalize / lazy builds of derived copies
+ *    and the gathered-rows strategy of a subset filter take the lock EXCLUSIVE, like `&mut self` in FlatMmap::write, and are
+ *    refused while tickets of lynse_hip_flat_search_submit_* are outstanding.
  *  - there is NO CPU fallback: without a usable HIP device every compute entry returns
  *    LYNSE_ERR_DEVICE.
  */

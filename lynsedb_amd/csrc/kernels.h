@@ -4195,6 +4195,12 @@ struct FinalArgs {
     uint32_t ham_dim;
     int neg_metric1;   // as SelectArgs::neg_metric1: rescoring with metric neg_metric1 - 1, negated; the distances written out are negated back
     uint32_t lds_bytes;   // as SelectArgs::lds_bytes
+    // The NaN rule of the boundary (include/lynse_hip.h): a NaN score is reported as the WORST value of the metric and ranks behind every
+    // better score, ties by ascending row (make_key).  A query with a NaN element — cosine: or an infinite one — scores NaN against EVERY row,
+    // and nothing ever passes a threshold of the staged pipeline for it: its answer is written here directly, rows 0 .. min(k, nan_rows) - 1 at
+    // the worst value (what the rule gives, and the rows the reference's first fill keeps, flat_mmap.rs:2141-2149).  nan_rows = rows of the
+    // store for an unfiltered FLAT search over f32 / f16 rows, 0 = rule off (subset filters, IVF slabs, binary metrics).
+    uint32_t nan_rows;
 };
 
 // k_rescore_pool: the exact rescoring of k_final spread over gridDim.y blocks per query (IVF on tightly clustered
@@ -4222,6 +4228,25 @@ template <int NT>
 __device__ __forceinline__ void final_body(const FinalArgs& a, uint64_t* keys, const uint32_t q, uint32_t n, const bool exact, const bool same_launch = false) {
     const int tid = threadIdx.x;
     const bool asc = metric_ascending(a.metric);
+    if (a.nan_rows) {   // (uniform) FinalArgs::nan_rows: the query whose every score is NaN
+        const int real_metric = a.neg_metric1 ? a.neg_metric1 - 1 : a.metric;
+        const float* qv = a.Qf + (size_t)q * a.D;
+        int bad = 0;
+        for (uint32_t i = tid; i < a.D; i += NT) { const float x = qv[i]; bad |= (x != x || (real_metric == M_COS && fabsf(x) == LY_INF)) ? 1 : 0; }
+        if (__syncthreads_or(bad)) {
+            const uint32_t cnt = a.k < a.nan_rows ? a.k : a.nan_rows;
+            for (uint32_t i = tid; i < a.out_k; i += NT) {
+                a.out_rows[(size_t)q * a.out_k + i] = i < cnt ? (uint64_t)i * a.row_stride + a.row_offset : ~0ull;
+                a.out_dists[(size_t)q * a.out_k + i] = metric_ascending(real_metric) ? LY_INF : -LY_INF;
+            }
+            if (tid == 0) {
+                a.out_counts[q] = cnt;
+                if (a.out_counts2) a.out_counts2[q] = cnt;
+                if (a.h_hdr) { a.h_hdr[q] = cnt; a.h_hdr[a.hdr_q + q] = 0u; }   // (nothing overflowed: there is nothing to answer again)
+            }
+            return;
+        }
+    }
     if (n > a.cap) n = a.cap;
     const uint32_t np2 = next_pow2(n < 2 ? 2 : n);
     const uint64_t* src = a.cand + (size_t)q * a.cap;

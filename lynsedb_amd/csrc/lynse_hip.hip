@@ -2332,6 +2332,7 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
     fa.neg_metric1 = (aug || cosq) ? metric + 1 : 0;
     fa.exact = binary ? 1 : 0; fa.Qf = Qf; fa.V = score_rows(h); fa.ld = score_ld(h); fa.D = h->dim;
     fa.row_stride = h->row_stride; fa.row_offset = h->row_offset;
+    fa.nan_rows = (!binary && !mask && !row_ids && h->n <= 0xffffffffull) ? (uint32_t)h->n : 0u;   // (FinalArgs::nan_rows: the all-NaN query of an unfiltered FLAT search)
     fa.out_rows = r_dst ? r_dst : w.out_rows; fa.out_dists = d_dst ? d_dst : w.out_dists; fa.out_counts = w.out_counts;
     fa.out_counts2 = c2_dst;
     fa.pool_total = tl_prof ? w.pool_total : nullptr;

@@ -36,3 +36,14 @@ def oracle_portable():
 @pytest.fixture(scope="session")
 def golden_dir():
     return ROOT / "tests" / "golden"
+
+
+def oracle_for_every_query(fn, nq, workers=None):
+    """[fn(0), ..., fn(nq - 1)] — the oracle's single-query calls of a whole batch, run from a thread pool: the calls are plain C through
+    ctypes (the GIL is released), re-entrant, and memory-bound, so the host's cores answer all 256 queries of a BASELINE batch in the
+    time the single-threaded loop needed for a dozen (the config tests checked 4-10 of 256 queries against the oracle)."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    workers = workers or max(1, min(32, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)))
+    with ThreadPoolExecutor(max_workers=workers) as ex:
+        return list(ex.map(fn, range(nq)))

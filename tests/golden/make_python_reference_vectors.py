@@ -6,7 +6,8 @@ Writes tests/golden/python_reference_vectors.json (inputs + expected outputs —
 
 Covered reference functions (python/lynse/cluster.py): _hash_u64 (:156-158) and the bucket rule
 (:1273, :1364-1370), _merge_pairs (:535-556), _is_ascending_index (:182), and
-result_view._parse_index_mode; benchmarks/sift_io.py read_fvecs/read_ivecs (:10-53).
+result_view._parse_index_mode; benchmarks/sift_io.py read_fvecs/read_ivecs (:10-53); the search-result block codec
+_encode_search_binary / _split_search_binary (:230-283).
 The Rust core (`lynse._core`) cannot be built/imported here, so no reference arithmetic is run.
 """
 import json
@@ -94,6 +95,36 @@ with tempfile.TemporaryDirectory() as td:
     goti = np.asarray(sift_io.read_ivecs(pi))
 out["fvecs"] = {"hex": raw.hex(), "shape": list(got.shape), "values": got.astype(float).ravel().tolist()}
 out["ivecs"] = {"hex": raw_i.hex(), "shape": list(goti.shape), "values": goti.astype(int).ravel().tolist()}
+
+# --- the search-result block codec (cluster.py:230-241 _split_search_binary, :270-283 _encode_search_binary — the Python twins of
+# encode_search_result_binary, src/rpc.rs:1156-1177, and decode_search_result_binary, src/cluster.rs:404-435): blocks ENCODED by the
+# reference, and what the reference DECODES from them (single blocks, and several blocks back to back in one frame)
+crng = np.random.default_rng(11)
+codec = []
+codec_cases = [
+    ([], [], None),
+    ([7], [0.5], None),
+    ([0, 2**32 + 5, 2**64 - 1], [1.0, -0.0, float(np.float32(3.4e38))], None),
+    ([3, 1, 2], [float("inf"), float("-inf"), 1e-45], None),
+    ([10, 11], [0.25, 0.75], [{"name": "a", "tag": 1}, {"name": "b", "nested": {"x": [1, 2, 3]}}]),
+    ([5], [2.0], [{"text": "snow\u2603 / quote\" / backslash\\"}]),
+]
+for _ in range(6):
+    m = int(crng.integers(1, 40))
+    codec_cases.append(([int(x) for x in crng.integers(0, 2**63, m, dtype=np.uint64)], [float(np.float32(x)) for x in crng.standard_normal(m)], None))
+for ids, dists, fields in codec_cases:
+    blob = cluster._encode_search_binary(ids, dists, fields)
+    d_ids, d_dists, d_fields, d_off = cluster._split_search_binary(blob, 0)
+    codec.append({"ids": [str(i) for i in ids], "dists_f32_bits": [int(np.float32(d).view(np.uint32)) for d in dists], "fields": fields,
+                  "hex": blob.hex(), "decoded_ids": [str(i) for i in d_ids],
+                  "decoded_dists_f32_bits": [int(np.float32(d).view(np.uint32)) for d in d_dists], "decoded_fields": d_fields, "next_offset": d_off})
+out["search_block_codec"] = codec
+frame = b"".join(bytes.fromhex(c["hex"]) for c in codec[:6])
+offs, off = [], 0
+for _ in range(6):
+    _i, _d, _f, off = cluster._split_search_binary(frame, off)
+    offs.append(off)
+out["search_block_frame"] = {"hex": frame.hex(), "next_offsets": offs}
 
 dst = Path(__file__).resolve().parent / "python_reference_vectors.json"
 dst.write_text(json.dumps(out, indent=1))

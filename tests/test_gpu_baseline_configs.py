@@ -17,6 +17,7 @@ import numpy as np
 import pytest
 
 import oracle as O
+from conftest import oracle_for_every_query
 
 pytestmark = pytest.mark.gpu
 f32 = np.float32
@@ -73,8 +74,10 @@ def test_c2_flat_ip_768_batch256_runs_the_benchmarked_kernels(L, oracle):
     assert not (flags & PLAN_FUSED_SAMPLE) and not (int(p["last_plan"]) & PLAN_STS), hex(int(p["last_plan"]))
     assert int(p["last_plan"]) & PLAN_QS_SAMPLE, hex(int(p["last_plan"]))      # ... and so did the sample stage (LYNSE_HIP_QS_SAMPLE=0 below: the 256 x 256 sample tiles)
     # the full ranking of the default run against the oracle's exact_flat_search (ids + f32 distance bits), wave boundaries included
-    for qi in (0, 1, 31, 32, 63, 64, 100, 128, 200, 255):
-        assert_rows_equal(oracle.canonical_topk(queries[qi], data, k, O.IP), rows[qi], dists[qi], counts[qi], ("c2", qi))
+    # — ALL 256 queries, every wave / query-column position of the tilings (the variants below are then compared with this run)
+    want = oracle_for_every_query(lambda qi: oracle.canonical_topk(queries[qi], data, k, O.IP), nq)
+    for qi in range(nq):
+        assert_rows_equal(want[qi], rows[qi], dists[qi], counts[qi], ("c2", qi))
         assert rows[qi, 0] == q_rows[qi]
     # the same batch (a) with the sample stage INSIDE the launch of the first threshold stage (k_scan_h16<.., FS>: grid-wide
     # threshold hand-over; off by default — measured slower than the two launches) and (b) on the three separate tail kernels
@@ -151,8 +154,9 @@ def test_l2_768_batch256_runs_the_certified_int8_pass(L, oracle):
     flags, stages, tiling = plan_fields(p)
     # threshold stages on the query-stationary tiling in its L2 form (k_scan_qs<.., MET = 1>: int8 dot products, exact f32 row norms)
     assert p["fallback_queries"] == 0 and tiling == 0x81 and flags & PLAN_I8C and flags & PLAN_SAMPLED and flags & PLAN_THRESHOLD_ONLY, (p, bin(flags))
-    for qi in (0, 1, 31, 32, 100, 128, 200, 255):
-        assert_rows_equal(oracle.canonical_topk(queries[qi], data, k, O.L2), rows[qi], dists[qi], counts[qi], ("l2", qi))
+    want = oracle_for_every_query(lambda qi: oracle.canonical_topk(queries[qi], data, k, O.L2), nq)      # all 256 queries
+    for qi in range(nq):
+        assert_rows_equal(want[qi], rows[qi], dists[qi], counts[qi], ("l2", qi))
         assert rows[qi, 0] == q_rows[qi]
     import os
     os.environ["LYNSE_HIP_QS"] = "0"     # ... and on the <4,2,2,4> tiling of k_scan_h16<.., I8Q = 4> (the round-3 default): identical bits
@@ -196,8 +200,9 @@ def test_c3_flat_l2_sift_like_1m_k100(L, oracle):
     flags, stages, tiling = plan_fields(p)
     # threshold stages on the query-stationary tiling of the low-dimensional f16 shadow (k_scan_qh, scan_qh.h; round 5)
     assert p["fallback_queries"] == 0 and tiling == 0x82 and flags & PLAN_SAMPLED and stages >= 2, (p, bin(flags))
-    for qi in (0, 1, 63, 64, 127, 128, 200, 255):
-        assert_rows_equal(oracle.canonical_topk(queries[qi], data, k, O.L2), rows[qi], dists[qi], counts[qi], ("c3", qi))
+    want = oracle_for_every_query(lambda qi: oracle.canonical_topk(queries[qi], data, k, O.L2), nq)      # all 256 queries (integer rows: ties decided by the canonical order)
+    for qi in range(nq):
+        assert_rows_equal(want[qi], rows[qi], dists[qi], counts[qi], ("c3", qi))
     # integer rows x integer queries below the 2^24 bounds: the coarse pass is exact, the margin zero (k_prep_queries' exactness rule,
     # round 5) — exactly k rows per query reach the final rescoring unless the k-th distance ties
     assert p["pool_entries"] <= int(1.2 * nq * k), p
@@ -216,8 +221,9 @@ def test_c3_flat_l2_sift_like_1m_k100(L, oracle):
         r, d, c = idx.search_batch_arrays(queries, k, name)
         pp = idx.profile_get(reset=True)
         assert pp["fallback_queries"] == 0
-        for qi in (0, 100, 255):
-            assert_rows_equal(oracle.canonical_topk(queries[qi], data, k, metric), r[qi], d[qi], c[qi], ("c3", name, qi))
+        want = oracle_for_every_query(lambda qi: oracle.canonical_topk(queries[qi], data, k, metric), nq)
+        for qi in range(nq):
+            assert_rows_equal(want[qi], r[qi], d[qi], c[qi], ("c3", name, qi))
 
 
 def test_c4_ivf_ip_768_nlist4096_nprobe32(L, oracle):
@@ -240,9 +246,9 @@ def test_c4_ivf_ip_768_nlist4096_nprobe32(L, oracle):
     nq = 64
     queries = (data[rng.integers(0, n, nq)] + 0.02 * rng.standard_normal((nq, dim)).astype(f32)).astype(f32)
     g_rows, g_d, g_c = idx.search_batch_arrays(queries, k, nprobe)
-    for qi in (0, 1, 7, 31, 32, 33, 50, 63):
-        e_ids, e_d, _ = oracle.ivf_search(queries[qi], data, cen, off, rows_l, nprobe, k, O.IP)
-        assert_rows_equal((e_ids, e_d), g_rows[qi], g_d[qi], g_c[qi], ("c4", qi))
+    want = oracle_for_every_query(lambda qi: oracle.ivf_search(queries[qi], data, cen, off, rows_l, nprobe, k, O.IP)[:2], nq)      # every query of the batch
+    for qi in range(nq):
+        assert_rows_equal(want[qi], g_rows[qi], g_d[qi], g_c[qi], ("c4", qi))
     # single query (config 4 latency shape) and nprobe >= nlist (every list probed = exact search in IVF order)
     r1, d1, c1 = idx.search_batch_arrays(queries[5:6], k, nprobe)
     e_ids, e_d, _ = oracle.ivf_search(queries[5], data, cen, off, rows_l, nprobe, k, O.IP)
@@ -280,8 +286,9 @@ def test_c5_hamming_10m_1024bit_k50(L, oracle, nq):
     rows, dists, counts = idx.search_packed_arrays(qw, k, "hamming")
     p = idx.profile_get(reset=True)
     assert p["fallback_queries"] == 0
-    for qi in sorted({0, nq // 3, nq // 2, nq - 1}):
-        assert_rows_equal(oracle.canonical_topk_packed(qw[qi], words, k, O.HAMMING), rows[qi], dists[qi], counts[qi], ("c5", nq, qi))
+    want = oracle_for_every_query(lambda qi: oracle.canonical_topk_packed(qw[qi], words, k, O.HAMMING), nq)      # every query of the batch
+    for qi in range(nq):
+        assert_rows_equal(want[qi], rows[qi], dists[qi], counts[qi], ("c5", nq, qi))
     assert np.all(dists == np.round(dists))
     if nq == 256:   # the +-1 FP4 GEMM on the query-stationary tiling (k_scan_qs<.., F4>, round 4); LYNSE_HIP_QS_F4=0: the 256 x 256 tile — identical bits
         import os

@@ -137,3 +137,87 @@ def test_f16_shadow_bound_holds_with_aligned_roundings(L, oracle, metric_name, m
     print(f"certificate f16 {metric_name} {'F16' if f16_rows else 'f32'} rows: max |coarse - exact| / E = {ratio:.4f} at {worst}")
     if metric == O.IP and not f16_rows:
         assert ratio > 0.5, ratio     # (the bound also carries the subnormal floor and the accumulation terms: not met as tightly as the int8 one)
+
+
+# ---- the Cauchy-Schwarz forms of the two quantisation terms as the BINDING ones (VERDICT r5 "weak" 2) ---------------------------------
+# E's terms are min(Hoelder, Cauchy-Schwarz) each (k_i8c_prep_queries): |sum w eps| <= ||w|| max_rows ||eps|| and
+# |s_q sum eta c'| <= s_q ||eta|| max_rows ||c'||.  The aligned worst case above makes both forms coincide; here the residual vector is
+# PARALLEL to its partner with varying magnitudes, so Cauchy-Schwarz holds with equality while Hoelder is ~1.5x slack — a wrong
+# max ||eps|| / max ||c'|| statistic (not refreshed by an append, or without the f32 evaluation error of the residual) would put the
+# constructed pair outside the bound.
+def _cs_case(kind, dim, n, rng):
+    """Rows with SQ8 fit min 0 / scale 64 in every dimension from SPREAD anchors (16 rows; each holds 0 and 255/64 in dim / 16 of the
+    dimensions and the exact mid code elsewhere: small norms), filler rows near the mid code, and ONE target row.
+      kind "eps_w": the target row's quantisation residuals are eps_d = 0.4999 u_d / 127 for query 0's integer image u (query 0 is exactly
+                    representable: eta = 0); every other row keeps |eps| <= 0.2.
+      kind "eta_c": every row sits on code points (eps = 0); the target row has the largest ||c'|| (codes spread over the whole range) and
+                    query 0's rounding residuals are eta_d = 0.4999 c'_d / 127."""
+    delta, s_q, R = 1.0 / 64.0, 2.0 ** -10, 16
+    anchors = np.full((R, dim), 128.0)
+    for d in range(dim):
+        anchors[d % R, d] = 0.0
+        anchors[(d + R // 2) % R, d] = 255.0
+    filler_codes = rng.integers(100, 157, (n - R - 1, dim)).astype(np.float64)
+    u = rng.integers(20, 127, dim).astype(np.float64) * rng.choice([-1.0, 1.0], dim)      # (|u_d| <= 126 beside u_0: no w_d + eta_d above 127)
+    u[0] = 127.0                                                    # fixes s_q = max |w| / 127 = 2^-10 exactly
+    if kind == "eps_w":
+        filler = filler_codes + rng.uniform(-0.2, 0.2, filler_codes.shape)
+        target = rng.integers(108, 149, dim).astype(np.float64) + 0.4999 * u / 127.0
+        w0 = u                                                       # in units of s_q
+    else:
+        filler = filler_codes
+        cprime = rng.integers(30, 128, dim).astype(np.float64) * rng.choice([-1.0, 1.0], dim)
+        cprime[1] = -127.0
+        target = cprime + 128.0
+        w0 = u + 0.4999 * cprime / 127.0
+    base = (np.vstack([anchors, filler]) * delta).astype(f32)
+    nq = 6
+    q = (rng.integers(40, 127, (nq, dim)) + rng.uniform(-0.49, 0.49, (nq, dim))) * rng.choice([-1.0, 1.0], (nq, dim))
+    q[0] = w0
+    q[:, 0] = 127.0
+    queries = (q * s_q / delta).astype(f32)
+    return base, (target * delta).astype(f32)[None, :], queries, u
+
+
+@pytest.mark.parametrize("kind", ["eps_w", "eta_c"])
+@pytest.mark.parametrize("appended", [False, True])
+def test_cauchy_schwarz_term_is_binding_and_met_on_a_fresh_shard_and_after_an_append(L, oracle, kind, appended):
+    rng = np.random.default_rng(21)
+    dim, n = 128, 4096
+    base, target, queries, u = _cs_case(kind, dim, n, rng)
+    idx = L.FlatIndex(None, dim)
+    if appended:      # the shard answers (and builds its codes + statistics) WITHOUT the target row first; the append must raise max ||eps|| / max ||c'||
+        idx.write(base)
+        idx.finalize()
+        s0, b0, form0 = idx.coarse_scores(queries, "ip", "i8")
+        assert form0 == FORM_I8
+        ex0 = exact_scores(oracle, queries, base, O.IP, False)
+        assert (np.abs(s0.astype(np.float64) - ex0) / b0.astype(np.float64)[:, None]).max() <= 1.0
+        idx.write(target)
+        idx.finalize()
+    else:
+        idx.write(np.vstack([base, target]))
+        idx.finalize()
+    data = np.vstack([base, target])
+    scores, bound, form = idx.coarse_scores(queries, "ip", "i8")
+    assert form == FORM_I8 and scores.shape == (queries.shape[0], n)
+    exact = exact_scores(oracle, queries, data, O.IP, False)
+    ratio = np.abs(scores.astype(np.float64) - exact) / bound.astype(np.float64)[:, None]
+    worst = np.unravel_index(np.argmax(ratio), ratio.shape)
+    # the two forms of the binding term for query 0, in real arithmetic (what k_i8c_prep_queries evaluates in f64)
+    s_q = 2.0 ** -10
+    if kind == "eps_w":
+        cs = s_q * np.linalg.norm(u) * 0.4999 * np.linalg.norm(u) / 127.0          # ||w|| ||eps||: eps = 0.4999 u / 127
+        hoelder = 0.5 * s_q * np.abs(u).sum()
+    else:
+        cp = (data[-1].astype(np.float64) * 64.0) - 128.0
+        cs = s_q * (0.4999 * np.linalg.norm(cp) / 127.0) * np.linalg.norm(cp)      # s_q ||eta|| ||c'||: eta = 0.4999 c' / 127
+        hoelder = 0.5 * s_q * np.abs(cp).sum()
+    print(f"certificate C-S {kind} {'after an append' if appended else 'fresh shard'}: max |coarse - exact| / E = {ratio.max():.4f} at {worst}; "
+          f"Cauchy-Schwarz term {cs:.4f} vs Hoelder {hoelder:.4f}; E(q0) = {float(bound[0]):.4f}")
+    assert cs < 0.8 * hoelder                                   # Cauchy-Schwarz is the strictly smaller form here ...
+    assert float(bound[0]) < 1.02 * hoelder                     # ... and the one E is made of (Hoelder alone would already exceed E)
+    assert ratio.max() <= 1.0, (float(ratio.max()), worst)
+    assert worst == (0, n - 1) and ratio.max() > 0.9, (float(ratio.max()), worst)      # met by the constructed pair, to within the 2 % safety factor + the f32 terms
+    if appended:
+        assert float(bound[0]) > 1.5 * float(b0[0]), (float(bound[0]), float(b0[0]))   # the append raised the statistic the bound is made of

@@ -757,3 +757,57 @@ def test_batched_hamming_on_the_matrix_pipe_equals_the_popcount_kernels(L, oracl
         c = int(counts[qi])
         assert c == len(e_ids) and np.array_equal(rows[qi, :c].astype(np.uint32), e_ids) and np.array_equal(dists[qi, :c], e_d), qi
     assert idx.coarse_state()["bpm_rows"] == n                                 # the +-1 copy was built: the MFMA path ran
+
+
+def _nan_rule_model(oracle, q, data, k, metric):
+    """The order include/lynse_hip.h pins for non-finite scores: the reference kernels' own arithmetic per (query, row) — the oracle's
+    single-pair kernels propagate NaN / inf like simd.rs does —, a NaN score replaced by the WORST value of the metric, then the
+    canonical (score best-first, row ascending) order."""
+    d = np.asarray(oracle.all_distances(q, data, metric), f32)
+    asc = metric != IP
+    d = np.where(np.isnan(d), f32(np.inf if asc else -np.inf), d)
+    order = np.lexsort((np.arange(len(d)), d if asc else -d))
+    return order[:k].astype(np.uint64), d[order[:k]]
+
+
+@pytest.mark.parametrize("n,dim,nq,k", [(64, 96, 1, 64), (64, 96, 8, 64), (64, 96, 40, 64), (5000, 96, 3, 20), (5000, 96, 40, 20),
+                                         (100_000, 128, 2, 10), (300_000, 128, 64, 10), (300_000, 256, 64, 10)])
+def test_nan_and_infinite_rows_and_queries(L, oracle, n, dim, nq, k):
+    """NaN / +-inf elements in rows and in queries through lynse_hip_flat_search_f32 (VERDICT r5 'weak' 3): the reference leaves the order
+    of NaN distances to partial_cmp(..).unwrap_or(Equal) (flat_mmap.rs:2141-2149) — here ONE order is pinned, on every path the shapes
+    below reach (the fused few-query search, the <= 32-query tiling, the 33..256-query tilings with the int8 pass switched off by the
+    non-finite rows, sampled and contiguous plans): NaN = the worst value of the metric, ties by row; a query that scores NaN against
+    every row gets rows 0 .. k - 1."""
+    rng = np.random.default_rng(3 + n + nq)
+    data = rng.standard_normal((n, dim)).astype(f32)
+    sp = rng.choice(n, 12, replace=False)
+    data[sp[0:4], 3] = np.nan
+    data[sp[4:6], 5] = np.inf
+    data[sp[6:8], 5] = -np.inf
+    data[sp[8], 1] = np.inf
+    data[sp[8], 2] = -np.inf                                # (IP / L2 of this row: inf - inf)
+    queries = rng.standard_normal((nq, dim)).astype(f32)
+    queries[:, 1] = np.abs(queries[:, 1])
+    queries[:, 2] = np.abs(queries[:, 2])
+    if nq > 1:
+        queries[-1, 7] = np.nan                             # every score NaN
+    if nq > 2:
+        queries[-2, 9] = np.inf                             # IP: +-inf / NaN by row; L2: +inf everywhere; cosine: NaN everywhere
+    idx = make_index(L, data)
+    idx.finalize()
+    for metric in (IP, L2, COS):
+        for fused in ((True, False) if (nq <= 4 and k <= 64) else (True,)):
+            idx.set_fused_search(fused)
+            try:
+                rows, dists, counts = idx.search_batch_arrays(queries, k, NAME[metric])
+            finally:
+                idx.set_fused_search(True)
+            for qi in range(nq):
+                e_r, e_d = _nan_rule_model(oracle, queries[qi], data, k, metric)
+                c = int(counts[qi])
+                assert c == len(e_r), (NAME[metric], fused, qi, c)
+                assert np.array_equal(rows[qi, :c].astype(np.uint64), e_r), (NAME[metric], fused, qi, rows[qi, :8], e_r[:8])
+                assert np.array_equal(dists[qi, :c].view(np.uint32), e_d.view(np.uint32)), (NAME[metric], fused, qi, dists[qi, :8], e_d[:8])
+    if nq > 1:      # the all-NaN query of the pinned rule, spelled out
+        rows, dists, counts = idx.search_batch_arrays(queries, k, "cosine")
+        assert int(counts[-1]) == min(k, n) and np.array_equal(rows[-1, :min(k, n)], np.arange(min(k, n), dtype=rows.dtype)) and np.all(np.isposinf(dists[-1, :min(k, n)]))
