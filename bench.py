@@ -1245,7 +1245,7 @@ def other_configs(dev):
                                   "scan_bytes_per_row": dim * elem, "scan_GBps": round(gbps, 1),
                                   "frac_of_hbm_peak": round(gbps / HBM_PEAK_GBPS, 4),
                                   "frac_of_hbm_peak_end_to_end": round(rows_step * dim * elem / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
-                                  "path": "fused few-query search: 2 launches (centroid ranking + probed lists), f32 rows" if fused else "staged: routing, grouped tiled scans, selects",
+                                  "path": "fused few-query search: 2 launches (centroid ranking, probed lists), every row scored exactly from the f32 slab; scan_us = the list-scan launch" if fused else "staged: routing, grouped tiled scans, selects",
                                   "binding": binding_of("c4_share_nq%d" % nq)}
             del ivf, flat
             torch.cuda.empty_cache()

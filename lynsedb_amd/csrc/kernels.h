@@ -393,6 +393,12 @@ __global__ void __launch_bounds__(256) k_prep_queries(PrepArgs a) {
     __shared__ float s_sq;
     const uint32_t q = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (q >= a.nq) {   // (uniform) a pad column of the query tile (the grid covers qpad queries): a ZERO image — finite scores for the MFMAs; it used to be a
+                       // hipMemsetAsync of the whole image in front of this kernel: a 5-us launch of its own in every batch (round 6)
+        const uint32_t per = a.layout == 0 ? (uint32_t)SCAN_LDK : (a.layout == 2 ? 64u : 32u);   // halves of one (slab, query) line
+        for (uint32_t i = tid; i < a.nslab * per; i += 256) a.Q16[((size_t)(i / per) * a.qpad + q) * per + (i % per)] = (_Float16)0.0f;
+        return;
+    }
     const float* qv = a.Q + (size_t)q * a.D;
     float amax = 0.0f, s2 = 0.0f, s1 = 0.0f;
     bool nonint = false, qneg = false;
@@ -2552,6 +2558,7 @@ __global__ void __launch_bounds__(256) k_sq8_prep_queries(const float* __restric
 struct I8cPrepArgs {
     const float* Q;
     uint32_t D, qpad, nslab;
+    uint32_t nq;         // queries of the batch; blocks nq .. qpad - 1 of the grid write the ZERO image of a pad column (0 = the grid is the batch)
     const float *mins, *scales;
     uint32_t a1;         // max row L1 norm of the signed codes
     uint32_t a2sq;       // max row sum of squares of the signed codes (0: not collected — the L1 forms alone)
@@ -2596,6 +2603,10 @@ __global__ void __launch_bounds__(256) k_i8c_prep_queries(I8cPrepArgs a) {
     extern __shared__ __attribute__((aligned(16))) int8_t s_u[];   // seeding only: the query's plain int8 image (nslab * 128 bytes)
     const uint32_t q = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (a.nq && q >= a.nq) {   // (uniform) a pad column of the query tile: zero image (was a hipMemsetAsync launch in front of this kernel)
+        for (uint32_t i = tid; i < a.nslab * 128; i += 256) a.img[((size_t)(i / 128) * a.qpad + q) * 128 + (i % 128)] = 0;
+        return;
+    }
     const float* qv = a.Q + (size_t)q * a.D;
     const uint32_t DA = a.D + (uint32_t)a.aug;     // dimensions of the coded vectors
     double qrn = 1.0;                               // cosine: 1 / |q| (0 for a zero query: every coarse score is -1 = distance 1)
@@ -2811,6 +2822,7 @@ __global__ void __launch_bounds__(256) k_bits_to_fp4(const uint64_t* __restrict_
 struct BpmPrepArgs {
     const uint64_t* QW;   // nq x W packed query words
     uint32_t W, D, qpad, nslab;   // nslab: 128-B slabs of 256 columns
+    uint32_t nq;          // queries of the batch: blocks nq .. qpad - 1 write the zero image of a pad column
     uint8_t* img;
     float *sq, *bq, *marg2, *thr;
     uint32_t *count, *overflow;
@@ -2820,6 +2832,10 @@ __global__ void __launch_bounds__(256) k_bpm_prep_queries(BpmPrepArgs a) {
     const uint32_t q = blockIdx.x;
     const int tid = threadIdx.x;
     const uint32_t total = a.nslab * 128;   // bytes of this query's image
+    if (a.nq && q >= a.nq) {   // (uniform) pad column of the query tile
+        for (uint32_t i = tid; i < total; i += 256) a.img[((size_t)(i / 128) * a.qpad + q) * 128 + (i % 128)] = 0;
+        return;
+    }
     for (uint32_t i = tid; i < total; i += 256) {
         uint32_t byte = 0;
 #pragma unroll
@@ -3949,9 +3965,9 @@ struct SmallArgs {
     unsigned long long* dbg;   // development (LYNSE_HIP_SMALL_DBG=1): s_memtime stamps [workgroup][4] + the last workgroup's [2]; NULL otherwise
 };
 
-__global__ void __launch_bounds__(SMALL_NT) k_small_search(SmallArgs a) {
-    if (a.dbg && threadIdx.x == 0) a.dbg[(size_t)blockIdx.x * 4 + 0] = wall_clock64();
+__global__ void __launch_bounds__(SMALL_NT, 4) k_small_search(SmallArgs a) {   // (4 waves per SIMD = two workgroups per CU: the grid of run_small is sized for that)
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (a.dbg && threadIdx.x == 0) a.dbg[(size_t)blockIdx.x * 4 + 0] = wall_clock64();
     float* qs = reinterpret_cast<float*>(smem);                                   // D floats: the query being scanned
     uint64_t* wl = reinterpret_cast<uint64_t*>(smem + (size_t)((a.D + 3) / 4 * 4) * 4);  // [8 waves][64] keys; later the merge lists
     __shared__ uint32_t s_last;
@@ -3959,10 +3975,11 @@ __global__ void __launch_bounds__(SMALL_NT) k_small_search(SmallArgs a) {
     const bool asc = a.metric != M_IP;
     const uint32_t k = a.k;
     constexpr int NWAVE = SMALL_NT / 64;
-    const uint32_t rows_per_pass = gridDim.x * NWAVE * 16;   // a group of 8 lanes scores TWO rows per pass (two load streams in flight)
+    const bool ivf = a.probes != nullptr;
+    const uint32_t parts = gridDim.x;
+    const uint32_t rows_per_pass = parts * NWAVE * 16;   // a group of 8 lanes scores TWO rows per pass (two load streams in flight)
     // IVF mode: the probed lists of the query laid end to end — s_pre[i] = rows before list i, s_start[i] = its slab position
     __shared__ uint32_t s_pre[SMALL_MAX_K + 1], s_start[SMALL_MAX_K];
-    const bool ivf = a.probes != nullptr;
     auto enter_lists = [&](uint32_t q) -> uint32_t {  // (called by every thread; ends with the arrays visible to all)
         __syncthreads();
         if (wave == 0) {
@@ -3985,6 +4002,8 @@ __global__ void __launch_bounds__(SMALL_NT) k_small_search(SmallArgs a) {
         while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (s_pre[mid] <= v) lo = mid; else hi = mid; }
         return s_start[lo] + (v - s_pre[lo]);
     };
+    // (round 6, measured and removed: touching the rows of the first pass — one dword per 128-B line — before the query has reached LDS,
+    // so that the scan's first loads find their lines on the way: C1 31.9 / 32.7 against 31.2 / 31.9 us — nothing; the scan is bandwidth-bound)
     for (uint32_t q = 0; q < a.nq; ++q) {
         __syncthreads();
         for (uint32_t i = tid; i < a.D; i += SMALL_NT) qs[i] = a.Qf[(size_t)q * a.D + i];
@@ -4010,8 +4029,8 @@ __global__ void __launch_bounds__(SMALL_NT) k_small_search(SmallArgs a) {
             // out-of-range rows re-read the last row (uniform control flow inside exact_score) and are dropped afterwards
             uint32_t ca = ra < n_rows ? ra : n_rows - 1, cb = rb < n_rows ? rb : n_rows - 1;
             if (ivf) { ca = slab_pos(ca); cb = slab_pos(cb); }
-            const float sa = exact_score(a.metric, a.ip_form, qs, a.V + (size_t)ca * a.ld, a.D, g);
-            const float sb = exact_score(a.metric, a.ip_form, qs, a.V + (size_t)cb * a.ld, a.D, g);
+            const float sa = exact_score<16>(a.metric, a.ip_form, qs, a.V + (size_t)ca * a.ld, a.D, g);
+            const float sb = exact_score<16>(a.metric, a.ip_form, qs, a.V + (size_t)cb * a.ld, a.D, g);
             if (ivf && a.orig) { ca = a.orig[ca]; cb = a.orig[cb]; }
             else if (!ivf) { ca = ra; cb = rb; }
             offer(ra < n_rows ? make_key(sa, ca, asc) : KEY_SENTINEL);
@@ -4038,7 +4057,7 @@ __global__ void __launch_bounds__(SMALL_NT) k_small_search(SmallArgs a) {
                 return r;
             };
             const uint64_t mine = wl[tid];
-            uint64_t* dst = a.part + ((size_t)q * gridDim.x + blockIdx.x) * k;  // [nq][workgroups][k]: a query's lists are contiguous
+            uint64_t* dst = a.part + ((size_t)q * parts + blockIdx.x) * k;  // [nq][workgroups][k]: a query's lists are contiguous
             // 8-byte agent-scope atomics on both sides of the hand-off (write-through stores, L2-served loads): no cache
             // write-back / invalidate fences around the ticket (cdna_hip_programming.md G16, 'valid forms')
             if (mine != KEY_SENTINEL) {
@@ -4059,10 +4078,10 @@ __global__ void __launch_bounds__(SMALL_NT) k_small_search(SmallArgs a) {
     if (tid == 0) {
         if (a.dbg) a.dbg[(size_t)blockIdx.x * 4 + 2] = wall_clock64();
         const uint32_t t = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_last = (t == gridDim.x - 1) ? 1u : 0u;
+        s_last = (t == parts - 1) ? 1u : 0u;
     }
     __syncthreads();
-    if (!s_last) return;
+    if (s_last) {
     // Merge of the gridDim.x sorted lists WITHOUT a tournament (two k-round tournaments — a DPP wave minimum and a dependent LDS
     // read per rank and level — were 7.8 us of the 24.6 us kernel on 100k x 128, whatever the number of lists):
     //   1. one head (best key) per list and thread; its rank among the 64 heads of the wave by v_readlane counting; the wave's
@@ -4073,7 +4092,7 @@ __global__ void __launch_bounds__(SMALL_NT) k_small_search(SmallArgs a) {
     //   3. the (at most kout) lists whose head is <= T read their keys <= T (agent-scope loads, 8 in flight) into the candidate
     //      array in LDS — a few dozen keys on ordinary data, kout * k at the very worst;
     //   4. every candidate's rank by counting (keys are unique): rank < kout writes output slot `rank`.
-    const uint32_t nlist = gridDim.x;                 // <= SMALL_NT: one list per thread
+    const uint32_t nlist = parts;                     // <= SMALL_NT: one list per thread
     uint64_t* wh = wl;                                // [NWAVE][64]
     uint64_t* cnd = wl + (size_t)NWAVE * 64;          // candidates (the launch sizes the dynamic LDS: min(k, nlist) * k slots, rounded up to a power of two)
     __shared__ uint64_t s_T;
@@ -4099,6 +4118,18 @@ __global__ void __launch_bounds__(SMALL_NT) k_small_search(SmallArgs a) {
         __syncthreads();
         const bool owner = (uint32_t)tid < nlist;
         const uint64_t head = owner ? __hip_atomic_load(&src[(size_t)tid * k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : KEY_SENTINEL;
+        // (round 6) few lists with many keys — the centroid ranking of an IVF search: 8..64 lists x nprobe = 32 keys: EVERY key of every list is
+        // fetched here, in the round trip of the heads (<= 4 per thread), instead of one dependent round trip per 8 keys of a list below the
+        // cut (that merge took 10 us of the 26-us ranking launch with 8 lists, k = 32)
+        const bool all_keys = nlist * k <= 4u * (uint32_t)SMALL_NT;
+        uint64_t allk[4] = {KEY_SENTINEL, KEY_SENTINEL, KEY_SENTINEL, KEY_SENTINEL};
+        if (all_keys) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t i = (uint32_t)tid + (uint32_t)u * (uint32_t)SMALL_NT;
+                if (i < nlist * k) allk[u] = __hip_atomic_load(&src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
         wh[tid] = KEY_SENTINEL;
         if (tid == 0) { s_T = KEY_SENTINEL; s_m = 0; }
         uint32_t hr = 0;   // heads of this wave below mine
@@ -4113,7 +4144,11 @@ __global__ void __launch_bounds__(SMALL_NT) k_small_search(SmallArgs a) {
         }
         __syncthreads();
         const uint64_t T = s_T;
-        if (head != KEY_SENTINEL && head <= T) {
+        if (all_keys) {   // (uniform) at most kout lists start at or below T: <= min(k, lists) * k candidates, the slots the launch sized
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (allk[u] != KEY_SENTINEL && allk[u] <= T) cnd[atomicAdd(&s_m, 1u)] = allk[u];
+        } else if (head != KEY_SENTINEL && head <= T) {
             cnd[atomicAdd(&s_m, 1u)] = head;
             // (loading the first 16 keys of every list up front instead — one round trip, no second one here — was slower: 8192
             // strided 8-byte loads against 512 + a few dozen; the merge 6.4 us against 5.1 us)
@@ -4163,7 +4198,15 @@ __global__ void __launch_bounds__(SMALL_NT) k_small_search(SmallArgs a) {
     }
     if (tid == 0) __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (a.dbg && tid == 0) a.dbg[(size_t)blockIdx.x * 4 + 3] = wall_clock64();
+    }   // s_last
 }
+
+// (round 6, measured and removed: k_small_search_ivf2 — the centroid ranking and the probed lists of a few-query IVF search in ONE launch, the
+// ranking's probe list handed over grid-wide through a flag in device memory (release fence in the merging workgroup, relaxed polls with
+// s_sleep in the others, a bounded wait with a two-launch fallback).  1.6M x 768, nlist 1024, nprobe 32, one query: 73.3-73.8 us against
+// 69.8-71.5 us for the two launches, same box, alternating — a grid-wide hand-over costs more than the kernel boundary it replaces, as the
+// fused sample stage of round 2 already found (first versions: an agent-scope release / acquire fence in EVERY wave = an L2 write-back /
+// invalidate each: 110 us; acquire-ordered polls: 180 us).  scripts/gpu_r6_k1.sh)
 
 struct FinalArgs {
     const uint64_t* cand;

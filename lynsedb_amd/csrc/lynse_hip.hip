@@ -1012,8 +1012,8 @@ static int ensure_workspace(lynse_hip_flat* h, uint32_t k /* caller's k = output
     LY_HIP(hipMalloc(&w.gsync, 256 + 1024 * 64));   // hand-over words + (debugging) 8 time stamps per workgroup / per (stage, query)
     LY_TRY(memset_done(w.gsync, 0, 256 + 1024 * 64));
     LY_HIP(hipMalloc(&w.small_part, (size_t)SMALL_NT * SMALL_MAX_Q * SMALL_MAX_K * 8));
-    LY_HIP(hipMalloc(&w.small_ticket, 4));
-    LY_TRY(memset_done(w.small_ticket, 0, 4));
+    LY_HIP(hipMalloc(&w.small_ticket, 16));
+    LY_TRY(memset_done(w.small_ticket, 0, 16));
     return LYNSE_OK;
 }
 
@@ -1962,11 +1962,12 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
                      h->n < 0xffffff00ull && (metric == M_IP || cosq);
     if (used_sts) *used_sts = sts;
     if (bin_mfma) {
-        if (nq != qpad) LY_HIP(hipMemsetAsync(w.Q16, 0, (size_t)nslab * qpad * 128, st));   // (the prep kernel writes every byte of its queries' lines, pad columns included)
+        // (the prep kernels write every byte of the image: the lines of their queries, pad columns included, and — blocks nq .. qpad - 1 of the
+        // grid — zero lines for the pad queries of the tile; up to round 5 a hipMemsetAsync of the image ran in front: a launch of its own)
         BpmPrepArgs p{};
-        p.QW = w.QW; p.W = h->words; p.D = h->dim; p.qpad = qpad; p.nslab = nslab; p.img = reinterpret_cast<uint8_t*>(w.Q16);
+        p.QW = w.QW; p.W = h->words; p.D = h->dim; p.qpad = qpad; p.nslab = nslab; p.nq = nq; p.img = reinterpret_cast<uint8_t*>(w.Q16);
         p.sq = w.qinv; p.bq = w.qn2; p.marg2 = w.marg2; p.thr = w.thr; p.count = w.count; p.overflow = w.overflow;
-        hipLaunchKernelGGL(k_bpm_prep_queries, dim3(nq), dim3(256), 0, st, p);
+        hipLaunchKernelGGL(k_bpm_prep_queries, dim3(qpad), dim3(256), 0, st, p);
         LY_HIP(hipGetLastError());
     } else if (binary) {
         std::vector<float> thr0(nq, INFINITY);
@@ -1975,10 +1976,8 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
         LY_HIP(hipMemsetAsync(w.overflow, 0, nq * 4, st));
         LY_HIP(hipStreamSynchronize(st));  // thr0 is a stack/heap temporary
     } else if (i8c) {
-        if (nq != qpad || (aug ? h->dim + h->aug_cols : h->dim) % 128 != 0)  // (a full chunk of whole slabs overwrites every byte of the image)
-            LY_HIP(hipMemsetAsync(w.Q16, 0, (size_t)nslab * qpad * 128, st));
         I8cPrepArgs p{};
-        p.Q = Qf; p.D = h->dim; p.qpad = qpad; p.nslab = nslab; p.mins = aug ? h->sq8a_mins : (cosq ? h->sq8c_mins : h->sq8_mins);
+        p.Q = Qf; p.D = h->dim; p.qpad = qpad; p.nslab = nslab; p.nq = nq; p.mins = aug ? h->sq8a_mins : (cosq ? h->sq8c_mins : h->sq8_mins);
         p.scales = aug ? h->sq8a_scales : (cosq ? h->sq8c_scales : h->sq8_scales);
         p.a1 = aug ? h->sq8a_a1 : (cosq ? h->sq8c_a1 : h->sq8_a1); p.vmax = h->vmax;
         static const bool cs_env = []() { const char* e = getenv("LYNSE_HIP_I8C_CS"); return !e || atoi(e) != 0; }();   // (0: the Hoelder terms alone, A/B)
@@ -1990,17 +1989,16 @@ static int run_chunk(lynse_hip_flat* h, uint32_t nq, uint32_t k, uint32_t out_k,
             p.seed_rows = std::min<uint32_t>(1024u, 32u * k);
             p.dyn_thr = w.dyn; p.dyn_marg = w.dyn + w.qcap; p.dyn_slot = w.dyn + 2 * (size_t)w.qcap;
         }
-        hipLaunchKernelGGL(k_i8c_prep_queries, dim3(nq), dim3(256), sts ? (size_t)nslab * 128 : 0, st, p);
+        hipLaunchKernelGGL(k_i8c_prep_queries, dim3(qpad), dim3(256), sts ? (size_t)nslab * 128 : 0, st, p);
         LY_HIP(hipGetLastError());
     } else {
-        // queries with index >= nq inside the padded tile must be finite: zero the image
-        LY_HIP(hipMemsetAsync(w.Q16, 0, (size_t)nslab * qpad * (glds ? GL_BK : (h16 ? HK : SCAN_LDK)) * sizeof(_Float16), st));
+        // queries with index >= nq inside the padded tile must be finite: blocks nq .. qpad - 1 of the grid write zero lines
         PrepArgs p{};
         p.Q = Qf; p.D = h->dim; p.nq = nq; p.qpad = qpad; p.nslab = nslab; p.metric = metric; p.layout = glds ? 1 : (h16 ? 2 : 0);
         p.sv = h->sv; p.vmax = h->vmax; p.vmin = h->vmin; p.cos_degenerate = h->cos_degenerate; p.rows_integer = h->rows_integer; p.rows_nonneg = h->rows_nonneg; p.amax_v = h->amax;
         p.Q16 = w.Q16; p.qinv = w.qinv; p.qn2 = w.qn2; p.qrinv = w.qrinv; p.marg2 = w.marg2; p.thr = w.thr;
         p.count = w.count; p.overflow = w.overflow;
-        hipLaunchKernelGGL(k_prep_queries, dim3(nq), dim3(256), 0, st, p);
+        hipLaunchKernelGGL(k_prep_queries, dim3(qpad), dim3(256), 0, st, p);
         LY_HIP(hipGetLastError());
     }
 
