@@ -5,9 +5,9 @@ CPU fallback: the import fails loudly if the extension has not been built.
 """
 from . import _lib  # noqa: F401  (raises ImportError when the HIP extension is missing)
 from .core import (BitSet, Collection, DatabaseManager, FlatIndex, IvfFlatIndex, SearchResult,  # noqa: F401
-                   default_device, merge_topk, metric_from_index_mode, metric_from_str,
+                   default_device, visible_devices, merge_topk, metric_from_index_mode, metric_from_str,
                    py_compute_distance, py_top_k_search)
 
-__all__ = ["BitSet", "Collection", "DatabaseManager", "FlatIndex", "IvfFlatIndex", "SearchResult", "default_device",
+__all__ = ["BitSet", "Collection", "DatabaseManager", "FlatIndex", "IvfFlatIndex", "SearchResult", "default_device", "visible_devices",
            "merge_topk", "metric_from_index_mode", "metric_from_str", "py_compute_distance", "py_top_k_search"]
 __version__ = "0.1.0"

@@ -28,12 +28,34 @@ from ._lib import check, lib
 _METRIC_IS_BINARY = {_lib.METRIC_HAMMING, _lib.METRIC_JACCARD, _lib.METRIC_DICE, _lib.METRIC_TANIMOTO}
 
 
+def visible_devices() -> list:
+    """`LYNSE_HIP_DEVICES` (the build's one addition to the reference's env-only configuration, next to `RAYON_NUM_THREADS` /
+    `LYNSE_SEGMENT_TARGET_BYTES`): a comma-separated list of HIP device ordinals this process may use, e.g. "2,3" — rank r of a node-local
+    job takes entry r % len.  Unset: every device the runtime shows."""
+    v = os.environ.get("LYNSE_HIP_DEVICES", "").strip()
+    if v:
+        try:
+            devs = [int(x) for x in v.split(",") if x.strip() != ""]
+        except ValueError:
+            raise ValueError(f"LYNSE_HIP_DEVICES must be a comma-separated list of device ordinals, got {v!r}") from None
+        if not devs or min(devs) < 0:
+            raise ValueError(f"LYNSE_HIP_DEVICES must name at least one non-negative device ordinal, got {v!r}")
+        return devs
+    return list(range(max(_lib.device_count(), 1)))
+
+
 def default_device() -> int:
-    """Device ordinal: LYNSE_HIP_DEVICE, else LOCAL_RANK (one process per GPU), else 0."""
-    for var in ("LYNSE_HIP_DEVICE", "LOCAL_RANK"):
-        v = os.environ.get(var)
-        if v is not None and v != "":
-            return int(v)
+    """Device ordinal: LYNSE_HIP_DEVICE, else entry LOCAL_RANK % len of LYNSE_HIP_DEVICES, else LOCAL_RANK (one process per GPU), else the
+    first entry of LYNSE_HIP_DEVICES, else 0."""
+    v = os.environ.get("LYNSE_HIP_DEVICE")
+    if v is not None and v != "":
+        return int(v)
+    rank = os.environ.get("LOCAL_RANK")
+    if os.environ.get("LYNSE_HIP_DEVICES", "").strip():
+        devs = visible_devices()
+        return devs[int(rank) % len(devs)] if rank not in (None, "") else devs[0]
+    if rank not in (None, ""):
+        return int(rank)
     return 0
 
 
@@ -894,6 +916,47 @@ class Collection:
                subset=None) -> SearchResult:
         res = self.batch_search(np.asarray(vector, dtype=np.float32).reshape(1, -1), k, where_expr, nprobe, subset=subset)
         return res[0]
+
+    def search_profile(self, vector, k: Optional[int] = None, where_expr: Optional[str] = None, nprobe: Optional[int] = None,
+                       approx: Optional[bool] = None, eps: Optional[float] = None, subset=None) -> dict:
+        """`Collection.search_profile` (src/python/mod.rs:1240-1271 over Collection::search_with_profile, src/engine.rs:5005-5054): the
+        search + a `QueryProfile` (engine.rs:6906-6919) with the reference's field names — query_kind, vector_field, index_path
+        ("ann_index" / "flat_mmap_filtered" / "flat_mmap", engine.rs:5163-5177), total_vectors, filter_expression, filter_matches,
+        scanned_vectors (= filter_matches or total_vectors, as estimate_scanned_vectors does, :5179-5193), result_count, filter_us, search_us,
+        rerank_us, total_us.  `device` is this build's addition: what `lynse_hip_flat_profile_get` / `lynse_hip_ivf_profile_get` measured for the
+        search with HIP events on the search stream (pipeline_us, scan_us, scan_launches, rows and bytes the scan launches streamed,
+        rescored_candidates, fallback_queries).  The precomputed filter is `subset=` (the field store that resolves `where_expr` is out of scope)."""
+        import time
+
+        started = time.perf_counter()
+        filter_us, filter_matches = 0, None
+        if where_expr:
+            raise NotImplementedError("`where_expr` needs the field store (out of scope, SURVEY.md §2); pass the resolved row filter as subset=")
+        if subset is not None:
+            t0 = time.perf_counter()
+            filter_matches = int(self._subset_rows(subset).size)
+            filter_us = int((time.perf_counter() - t0) * 1e6)
+        target = self._ivf if self._ivf is not None else self._flat
+        target.profile_enable(True)
+        target.profile_get(reset=True)
+        t0 = time.perf_counter()
+        try:
+            res = self.search(vector, k, None, nprobe, approx, eps, subset=subset)
+        finally:
+            dev = target.profile_get(reset=True)
+            target.profile_enable(False)
+        search_us = int((time.perf_counter() - t0) * 1e6)
+        total = int(self.shape()[0])
+        profile = {"query_kind": "vector", "vector_field": "default",
+                   "index_path": "ann_index" if self._ivf is not None else ("flat_mmap_filtered" if subset is not None else "flat_mmap"),
+                   "total_vectors": total, "filter_expression": None, "filter_matches": filter_matches,
+                   "scanned_vectors": filter_matches if filter_matches is not None else total, "result_count": len(res),
+                   "filter_us": filter_us, "search_us": search_us, "rerank_us": 0, "total_us": int((time.perf_counter() - started) * 1e6),
+                   "device": {"pipeline_us": float(dev["total_us"]), "scan_us": float(dev["scan_us"]), "scan_launches": int(dev["scan_launches"]),
+                              "scan_rows": int(dev["scan_rows"]), "scan_bytes": int(dev["scan_bytes"]), "rescored_candidates": int(dev["pool_entries"]),
+                              "fallback_queries": int(dev["fallback_queries"]), "plan": int(dev["last_plan"])}}
+        return {"items": {"k": res._k, "ids": [int(x) for x in res.ids()], "scores": [float(x) for x in res.distances()], "index": res.index_mode()},
+                "profile": profile}
 
     def batch_search(self, vectors, k: Optional[int] = None, where_expr: Optional[str] = None,
                      nprobe: Optional[int] = None, subset=None) -> list:

@@ -24,7 +24,7 @@
 
 #include "../lynsedb_amd/csrc/kernels.h"
 #include "../lynsedb_amd/csrc/scan_qs.h"
-#include "../lynsedb_amd/csrc/scan_qs2.h"
+#include "scan_qs2.h"   // (the measured-negative one-wave-per-SIMD form: kept beside this microbenchmark, not in the product directory)
 
 using namespace lynse;
 

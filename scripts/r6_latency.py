@@ -67,7 +67,11 @@ def c3():
     idx = L.FlatIndex(None, 128, 0)
     idx.write(data)
     idx.finalize()
-    for nq, k in ((256, 100), (32, 100), (256, 10)):
+    import os
+    shapes = ((256, 100), (32, 100), (256, 10))
+    if os.environ.get("LAT_C3_ONLY"):      # e.g. LAT_C3_ONLY=0: the first shape only (kernel timelines)
+        shapes = (shapes[int(os.environ["LAT_C3_ONLY"])],)
+    for nq, k in shapes:
         dq = torch.as_tensor(qs[:nq], device=dev)
         rows = torch.zeros((nq, k), dtype=torch.int64, device=dev)
         d = torch.zeros((nq, k), dtype=torch.float32, device=dev)

@@ -214,3 +214,24 @@ def test_reference_partition_rule_matches_the_golden_hashes(golden_dir):
         assert bucket_of_id(db, coll, item) == e["bucket4096"]
         for world in (1, 2, 4, 8):
             assert shard_of_id(db, coll, item, world) == e["bucket4096"] % world
+
+
+def test_lynse_hip_devices_env_selects_the_device_of_a_rank(monkeypatch):
+    """`LYNSE_HIP_DEVICES`: the ordinals this process may use; LOCAL_RANK indexes the list, LYNSE_HIP_DEVICE overrides."""
+    import lynsedb_amd as L
+
+    for var in ("LYNSE_HIP_DEVICE", "LOCAL_RANK", "LYNSE_HIP_DEVICES"):
+        monkeypatch.delenv(var, raising=False)
+    assert L.default_device() == 0
+    monkeypatch.setenv("LYNSE_HIP_DEVICES", "2, 3,5")
+    assert L.visible_devices() == [2, 3, 5] and L.default_device() == 2
+    monkeypatch.setenv("LOCAL_RANK", "4")
+    assert L.default_device() == 3                      # entry 4 % 3
+    monkeypatch.setenv("LYNSE_HIP_DEVICE", "7")
+    assert L.default_device() == 7
+    monkeypatch.delenv("LYNSE_HIP_DEVICE")
+    monkeypatch.setenv("LYNSE_HIP_DEVICES", "x,1")
+    with pytest.raises(ValueError):
+        L.default_device()
+    monkeypatch.delenv("LYNSE_HIP_DEVICES")
+    assert L.default_device() == 4                      # LOCAL_RANK alone: one process per GPU

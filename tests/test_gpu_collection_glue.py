@@ -175,3 +175,33 @@ def test_ivfflat_search_uses_the_metric_of_the_call(L, oracle):
         idx.search(queries[0], k, nprobe, "manhattan")  # valid in the reference, outside this path
     with pytest.raises(ValueError, match="Unknown metric"):
         idx.search(queries[0], k, nprobe, "bogus")
+
+
+def test_search_profile_carries_the_reference_fields(L, oracle):
+    """`Collection.search_profile` (src/python/mod.rs:1240-1271, QueryProfile engine.rs:6906-6919; the reference's own test
+    engine.rs:9145-9158): the result of `search` + the profile dict with the reference's field names, index_path "flat_mmap" /
+    "flat_mmap_filtered" / "ann_index", and this build's `device` block from the library's HIP-event profile."""
+    rng = np.random.default_rng(5)
+    n, dim, k = 20_000, 64, 5
+    data = rng.standard_normal((n, dim)).astype(f32)
+    coll = L.Collection("c", dim)
+    coll.add_items(data, list(range(100, 100 + n)))
+    coll.commit()
+    q = (data[77] + 0.01 * rng.standard_normal(dim)).astype(f32)
+    want = coll.search(q, k)
+    out = coll.search_profile(q, k)
+    p = out["profile"]
+    assert set(p) >= {"query_kind", "vector_field", "index_path", "total_vectors", "filter_expression", "filter_matches", "scanned_vectors",
+                      "result_count", "filter_us", "search_us", "rerank_us", "total_us"}
+    assert p["query_kind"] == "vector" and p["vector_field"] == "default" and p["index_path"] == "flat_mmap"
+    assert p["total_vectors"] == n and p["scanned_vectors"] == n and p["filter_matches"] is None and p["result_count"] == k and p["rerank_us"] == 0
+    assert p["search_us"] > 0 and p["total_us"] >= p["search_us"]
+    assert p["device"]["scan_launches"] >= 1 and p["device"]["scan_us"] > 0 and p["device"]["pipeline_us"] >= p["device"]["scan_us"] * 0.99
+    assert out["items"]["ids"] == want.ids().tolist() and out["items"]["k"] == k and out["items"]["index"] == "FLAT-IP"
+    assert out["items"]["ids"][0] == 177
+    sub = np.arange(0, n, 4, dtype=np.uint64)
+    pf = coll.search_profile(q, k, subset=sub)["profile"]
+    assert pf["index_path"] == "flat_mmap_filtered" and pf["filter_matches"] == sub.size and pf["scanned_vectors"] == sub.size
+    coll.build_index("IVF-IP", {"n_clusters": 32, "nprobe": 4})
+    pi = coll.search_profile(q, k, nprobe=4)["profile"]
+    assert pi["index_path"] == "ann_index" and pi["result_count"] == k
