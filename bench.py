@@ -1199,7 +1199,7 @@ def other_configs(dev):
                 rows_d[b0:e] = blk / (blk.norm(dim=1, keepdim=True) + 1e-12)
                 del blk
             t0 = time.time()
-            ivf = L.IvfFlatIndex.build_device(rows_d, dim, nlist, 20, "ip", l2_partitions=False)   # IVFIndex: k-means with the routing metric, 20 rounds (ivf.rs:163-170)
+            ivf = L.IvfFlatIndex.build_device(rows_d, dim, nlist, int(os.environ.get("LYNSE_BENCH_C4_ITERS", "20")), "ip", l2_partitions=False)   # IVFIndex: k-means with the routing metric, 20 rounds (ivf.rs:163-170; the profiler runs of scripts/gpu_r6_profile.sh train 2)
             torch.cuda.synchronize()
             r = {"centres": KC, "build_s": round(time.time() - t0, 2)}
             qsel = torch.randint(0, n, (256,), generator=g, device=dev)
@@ -1253,7 +1253,8 @@ def other_configs(dev):
 
         first = one(4096)      # as many generating centres as lists: recall 1.0 by construction
         res.update({kk: vv for kk, vv in first.items() if kk != "centres"})
-        res["second_dataset_1024_centres"] = one(1024)   # lists do not coincide with the clusters: recall is a measurement
+        if not os.environ.get("LYNSE_BENCH_C4_NO_SECOND"):   # (profiler runs: the search kernels of the first data set are what is profiled)
+            res["second_dataset_1024_centres"] = one(1024)   # lists do not coincide with the clusters: recall is a measurement
         res["oracle_parity"] = "tests/test_gpu_baseline_configs.py::test_c4_* (520k rows: the 19 GB share is not copied to the host here)"
         return res
 
