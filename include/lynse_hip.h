@@ -353,6 +353,9 @@ typedef struct lynse_hip_comm lynse_hip_comm;
 int lynse_hip_comm_load_rccl(const char *path /* NULL = search */);
 int lynse_hip_comm_unique_id(uint8_t *id128);
 int lynse_hip_comm_create(const uint8_t *id128, int rank, int world, int device, lynse_hip_comm **out);
+/* A BLOCKING collective of a communicator that timed out (LYNSE_ERR_TIMEOUT: a rank is gone) leaves its all-gather / merge enqueued: the
+ * communicator is marked failed — every later sharded call or submit on it returns LYNSE_ERR_DEVICE at once — and the output buffers of the
+ * call that timed out must stay allocated until lynse_hip_comm_destroy. */
 int lynse_hip_comm_destroy(lynse_hip_comm *c);
 int lynse_hip_comm_rank(const lynse_hip_comm *c);
 int lynse_hip_comm_world(const lynse_hip_comm *c);
