@@ -37,6 +37,7 @@ import torch  # noqa: E402
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F16_PEAK_TFLOPS = 2500.0  # dense f16/bf16 MFMA peak (no sparsity)
 MFMA_I8_PEAK_TOPS = 5000.0     # dense int8 MFMA: twice the f16 rate (MI355X_MICROARCH.md: i8 = 2x K per instruction at the same issue rate)
+MFMA_FP4_PEAK_TOPS = 10000.0   # dense FP4 / FP6 MFMA (MI355X_MICROARCH.md: ~10 PF dense; v_mfma_scale_f32_32x32x64_f8f6f4)
 GEN_BLOCK = 100_000     # rows per generation block (flat_search_bench.py:71-77 batches of 100k)
 
 
@@ -641,7 +642,7 @@ def run_c4(args, rank, local_rank, world, dev, dist, result_out):
                                    ("torch.distributed" if world > 1 else "none"),
                        "batches_in_flight": in_flight, "generate_s": round(gen_s, 1), "train_s": round(train_s, 1), "load_s": round(load_s, 1),
                        "lists_trained": int(cen.shape[0])},
-            "roofline": {"bound": "hbm", "kernel": "k_scan_h16<..,TILED,%s> over the probed lists" % ("I8C" if i8c else "F16"),
+            "roofline": {"bound": "hbm", "kernel": "k_scan_h16<..,TILED,%s> over the probed lists" % ("I8C" if i8c else "F16"), "binding": binding_of("c4_share_nq256"),
                          "achieved": round(hbm_gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(hbm_gbps / HBM_PEAK_GBPS, 4),
                          "traffic": None, "launches": launches, "avg_launch_us": round(prof["scan_us"] / launches, 2),
                          "rows_scanned_per_step": int(prof["scan_rows"] // max(int(prof["searches"]), 1)),
@@ -825,9 +826,17 @@ def run_c5(args, rank, local_rank, world, dev, dist, result_out):
                        "exchange": ("rccl all_gather of %d B/rank inside the library" % (B * K * 12 + B * 4 + 16)) if native else ("torch.distributed" if world > 1 else "none"),
                        "batches_in_flight": in_flight, "build_s": round(build_s, 1), "derived_build_s": round(prepare_s, 2),
                        "hbm_bytes_per_gpu": int(sh.index.hbm_bytes())},
-            "roofline": {"bound": "hbm", "kernel": (("k_scan_qs<4,2,4,3,...,F4>" if ((int(prof.get("last_plan", 0)) >> 16) & 0xff) == 0x81 else "k_scan_h16<2,4,4,2,IP,fp4>") +
-                                                      " (v_mfma_scale_f32_32x32x64_f8f6f4) over the +-1 FP4 copy") if mfma else "k_scan_binary_rows",
-                         "achieved": round(hbm_gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(hbm_gbps / HBM_PEAK_GBPS, 4), "traffic": None,
+            # the binding resource from the committed PMC pass (profiles/rNN_binding.json): the FP4 matrix pipe for the batched form (62 % busy at
+            # 1.75 GHz, HBM at 0.56), HBM for the popcount kernels — `bound` / `frac` follow it, both live rates stay on the line
+            "roofline": {"bound": "mfma" if (mfma and (binding_of("c5_share_nq256") or {}).get("binding", "").startswith("matrix pipe")) else "hbm",
+                         "kernel": (("k_scan_qs<4,2,4,3,...,F4>" if ((int(prof.get("last_plan", 0)) >> 16) & 0xff) == 0x81 else "k_scan_h16<2,4,4,2,IP,fp4>") +
+                                    " (v_mfma_scale_f32_32x32x64_f8f6f4) over the +-1 FP4 copy") if mfma else "k_scan_binary_rows",
+                         "binding": binding_of("c5_share_nq256" if mfma else "c5_share_nq1"),
+                         **({"achieved": round(ops / scan_s / 1e12, 1), "peak": MFMA_FP4_PEAK_TOPS, "unit": "TOP/s", "frac": round(ops / scan_s / 1e12 / MFMA_FP4_PEAK_TOPS, 4)}
+                            if (mfma and scan_s > 0 and (binding_of("c5_share_nq256") or {}).get("binding", "").startswith("matrix pipe"))
+                            else {"achieved": round(hbm_gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(hbm_gbps / HBM_PEAK_GBPS, 4)}),
+                         "hbm": {"achieved": round(hbm_gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(hbm_gbps / HBM_PEAK_GBPS, 4)},
+                         "traffic": None,
                          "mfma_TOPs": round(ops / scan_s / 1e12, 1) if (mfma and scan_s > 0) else None,
                          "launches": launches, "avg_launch_us": round(prof["scan_us"] / launches, 2), "timed_steps": timed_steps,
                          "note": "rank-0 shard; bytes = rows x %d B (%s); HIP events around the scan launches of every %d-th step" % (
