@@ -231,6 +231,23 @@ static void scenario_comm1() {
     });
     for (auto& x : th) x.join();
     CHECK(hard_errors.load() == 0, "1-rank communicator scenario: %d hard errors, last: %s", hard_errors.load(), last_error().c_str());
+    {   // a LOCAL failure of a sharded submit rides the exchange: submit hands out a ticket, wait reports the error, the context comes back
+        setenv("LYNSE_HIP_DEBUG_FAIL_SUBMIT", "1", 1);
+        Out o(64, 10);
+        lynse_hip_ticket* tk = nullptr;
+        const int rc = lynse_hip_flat_search_submit_f32_device(h, c, q.data(), 64, 10, 0, o.rows.data(), o.dists.data(), o.counts.data(), &tk);
+        CHECK(rc == LYNSE_OK && tk != nullptr, "a failing local part must still submit: rc %d (%s)", rc, last_error().c_str());
+        const int wrc = tk ? lynse_hip_flat_search_wait(tk) : -1;
+        CHECK(wrc == LYNSE_ERR_OUT_OF_MEMORY, "wait must report the local failure: rc %d (%s)", wrc, last_error().c_str());
+        unsetenv("LYNSE_HIP_DEBUG_FAIL_SUBMIT");
+        for (int it = 0; it < 10; ++it) {
+            lynse_hip_ticket* t2 = nullptr;
+            CHECK(lynse_hip_flat_search_submit_f32_device(h, c, q.data(), 64, 10, 0, o.rows.data(), o.dists.data(), o.counts.data(), &t2) == LYNSE_OK, "%s", last_error().c_str());
+            CHECK(t2 && lynse_hip_flat_search_wait(t2) == LYNSE_OK, "%s", last_error().c_str());
+        }
+        const auto more = rows_of(4, dim, 23);
+        CHECK(lynse_hip_flat_append_f32(h, more.data(), 4) == LYNSE_OK, "the writer guard must be open again: %s", last_error().c_str());
+    }
     lynse_hip_flat_destroy(h);
     lynse_hip_comm_destroy(c);
 }

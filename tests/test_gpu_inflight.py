@@ -279,3 +279,37 @@ def test_a_ticket_that_needs_the_lazy_f16_shadow_while_int8_tickets_are_outstand
                 _assert_oracle(oracle, q[qi], data, k, metric, r[qi], d[qi], c[qi], (with_comm, name, qi))
         if comm is not None:
             comm.close()
+
+
+def test_a_local_failure_of_a_sharded_submit_rides_the_exchange(L, oracle, monkeypatch):
+    """once a sharded batch's shape is pipelined, a LOCAL failure of the preparation (a lazy build out of memory, the writer
+    lock refused behind outstanding tickets, ...) must not end `submit` in front of the all-gather — the peers would wait out the collective
+    timeout.  LYNSE_HIP_DEBUG_FAIL_SUBMIT=1 simulates one on a 1-rank communicator: submit still returns a ticket (the exchange is enqueued with an
+    empty block + the failure bit), `wait` reports the local error, the context is given back and the next batch on the same handle is answered."""
+    import torch
+
+    from lynsedb_amd.sharded import NativeComm
+
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(23)
+    n, dim, nq, k = 90_000, 64, 64, 10
+    data = rng.random((n, dim), dtype=f32)
+    idx = L.FlatIndex(None, dim)
+    idx.write(data)
+    idx.finalize()
+    comm = NativeComm(None, 0, 1, 0)
+    q = (data[rng.integers(0, n, nq)] + 0.01).astype(f32)
+    dq = torch.as_tensor(q, device=dev)
+    o_bad, o_good = _tensors(torch, nq, k, dev), _tensors(torch, nq, k, dev)
+    monkeypatch.setenv("LYNSE_HIP_DEBUG_FAIL_SUBMIT", "1")
+    t = idx.search_submit(dq, k, "ip", *o_bad, comm=comm.handle)          # no exception here: the failure travels with the block
+    with pytest.raises(MemoryError, match="simulated local failure"):
+        t.wait()
+    monkeypatch.delenv("LYNSE_HIP_DEBUG_FAIL_SUBMIT")
+    for _ in range(9):                                                      # every context was given back: more batches than contexts in a row
+        idx.search_submit(dq, k, "ip", *o_good, comm=comm.handle).wait()
+    r, d, c = _host(o_good)
+    for qi in (0, nq - 1):
+        _assert_oracle(oracle, q[qi], data, k, IP, r[qi], d[qi], c[qi], qi)
+    idx.write(data[:10])                                                    # ... and the writer guard is open again (no ticket left counted)
+    comm.close()

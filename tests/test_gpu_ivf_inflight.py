@@ -333,3 +333,37 @@ def test_ivf_tickets_from_three_threads(L, oracle):
         assert _same(got[i], want[i]), i
     st = idx.ticket_stats()
     assert st["in_flight"] == 36 and st["inside_submit"] == 0, st
+
+
+def test_a_local_failure_of_a_sharded_ivf_submit_rides_the_exchange(L, oracle, monkeypatch):
+    """The IVF twin of tests/test_gpu_inflight.py::test_a_local_failure_of_a_sharded_submit_rides_the_exchange (ADVICE r5, medium): a local failure
+    of the preparation of a sharded IVF submit (LYNSE_HIP_DEBUG_FAIL_SUBMIT=1 simulates one) does not end the call in front of the all-gather: the
+    ticket's exchange runs with an empty block + the failure bit, `wait` reports the error, the next tickets are answered like the oracle."""
+    import torch
+
+    from lynsedb_amd.sharded import NativeComm, ShardedIvf, ShardOutputs
+
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(33)
+    n, dim, nlist, nq, k, nprobe = 30_000, 64, 40, 64, 10, 4
+    data, cen, asg, off, rows, _ = _index(L, oracle, rng, n, dim, nlist, L2, nc=10)
+    sh = ShardedIvf(dim, rank=0, world=1, device=0, group=None)
+    sh.load_local(data, cen, asg, "l2")
+    sh.comm = NativeComm(None, 0, 1, 0)
+    qs = (data[rng.integers(0, n, nq)] + 0.05 * rng.standard_normal((nq, dim))).astype(f32)
+    dq = torch.as_tensor(qs, device=dev)
+    sh.search_submit(dq, k, nprobe, ShardOutputs(nq, k, 1, dev)).wait()      # (derived data built; a first clean ticket)
+    monkeypatch.setenv("LYNSE_HIP_DEBUG_FAIL_SUBMIT", "1")
+    bad = sh.search_submit(dq, k, nprobe, ShardOutputs(nq, k, 1, dev))       # no exception here
+    with pytest.raises(MemoryError, match="simulated local failure"):
+        bad.wait()
+    monkeypatch.delenv("LYNSE_HIP_DEBUG_FAIL_SUBMIT")
+    out = ShardOutputs(nq, k, 1, dev)
+    for _ in range(9):                                                       # more tickets than contexts, one after the other: every context came back
+        sh.search_submit(dq, k, nprobe, out).wait()
+    torch.cuda.synchronize()
+    r, d, c = out.rows.cpu().numpy().view(np.uint64), out.dists.cpu().numpy(), out.counts.cpu().numpy()
+    for qi in (0, nq - 1):
+        e_ids, e_d, _ = oracle.ivf_search(qs[qi], data, cen, off, rows, nprobe, k, L2)
+        assert int(c[qi]) == len(e_ids) and np.array_equal(r[qi, :len(e_ids)], e_ids.astype(np.uint64)), qi
+        assert np.array_equal(d[qi, :len(e_ids)].view(np.uint32), e_d.view(np.uint32)), qi
