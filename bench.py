@@ -12,11 +12,16 @@ RCCL all-gather and merged on the device: total work is fixed -> "scaling": "str
 Inputs (rows and queries) are resident in HBM before the timed region; the timed region is bracketed
 by barrier + torch.cuda.synchronize() and the MAX over ranks is reported.
 
-Extra objects on the JSON line: "roofline" (dominant kernel k_scan_h16: the bytes it physically streams and its matrix
+Extra objects on the JSON line: "roofline" (dominant kernel k_scan_qs: the bytes it physically streams and its matrix
 ops over the HIP-event duration of its launches on the launch stream inside the timed region, against 8 TB/s and the
-dense MFMA peak — the larger fraction names the bound; the SURVEY 8(d) algorithmic-f32-bytes figure rides along) and
+dense MFMA peak; `bound` names the BINDING resource from the committed rocprofv3 --pmc pass of that kernel —
+profiles/rNN_binding.json: the int8 matrix pipe at the power-capped clock for the headline —, `binding` carries its
+counters, `hbm` / `mfma` both live fractions; the SURVEY 8(d) algorithmic-f32-bytes figure rides along) and
 "cpu_baseline" (the oracle's restatement of the reference's rayon scan on a persistent pinned pool, timed on this host's
-cores over a bounded row sample: all threads and 4 threads).
+cores over a bounded row sample: ONE protocol — 20 warm-ups + 30 queries — for the thread sweep and the figure, the best
+thread count run three times, median / best / spread / host CPU model and NUMA layout on the line).
+`configs` holds the other BASELINE.json configurations at one GPU's share: `ms` = the blocking C-ABI call through ctypes
+with prebuilt arguments, `ms_python_wrapper` = the same through lynsedb_amd's Python wrapper + a torch synchronise.
 """
 from __future__ import annotations
 
